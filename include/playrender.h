@@ -1,0 +1,198 @@
+/*
+ * playrender.h - C ABI of libplayrender.so, the MI355X (gfx950) volumetric renderer.
+ *
+ * The reference (willi-menapace/PlayableEnvironments) is pure Python/PyTorch: the interface this
+ * library replaces is the tensor-in / dict-of-tensors-out call
+ *     ObjectComposer.forward(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o,
+ *                            style, deformation, object_in_scene, perturb, ...)
+ * (model/object_composer.py:786-892) plus the ray set-up of
+ * EnvironmentModel.forward_from_scene_encoding (model/environment_model.py:1080-1112).  The Python
+ * package `playableenvironments_amd` keeps those signatures and marshals raw device pointers into
+ * the entry points below through ctypes (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pr_status on failure; pr_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers unless a parameter says "host"; the library never
+ *     allocates or frees device memory, never synchronises the device and enqueues all work on
+ *     the hipStream_t passed in (void* so that the header needs no HIP include);
+ *   - all floating-point data is IEEE fp32, C-contiguous, in the layouts written next to each field;
+ *   - "N" = frames (all leading dims of the reference tensors flattened), "R" = rays per frame,
+ *     "K" = object instances, "P_k" = samples per ray of object k, "F" = output features.
+ */
+#ifndef PLAYRENDER_H
+#define PLAYRENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PR_ABI_VERSION 1
+#define PR_MAX_OBJECTS 8
+#define PR_MAX_LAYERS 12
+#define PR_MAX_OCTAVES 16
+
+typedef enum pr_status {
+    PR_OK = 0,
+    PR_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+    PR_ERR_WORKSPACE = -2,    /* workspace too small */
+    PR_ERR_HIP = -3,          /* a HIP runtime call failed */
+    PR_ERR_NO_DEVICE = -4     /* no gfx950 device visible */
+} pr_status;
+
+/* flags of pr_call_t.flags */
+#define PR_FLAG_PERTURB        1u   /* stratified jitter + alpha noise; noise tensors must be supplied */
+#define PR_FLAG_CANONICAL_POSE 2u   /* zero the ray-bender displacements (canonical_pose=True) */
+#define PR_FLAG_FIX_OVERLAPS   4u   /* config["model"]["fix_object_overlaps"] */
+#define PR_FLAG_NAIVE_MLP      8u   /* debugging: scalar one-thread-per-sample MLP kernel instead of MFMA */
+
+/* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
+typedef struct pr_linear_t {
+    const float* weight;
+    const float* bias;
+    int32_t out_features;
+    int32_t in_features;
+} pr_linear_t;
+
+/*
+ * One object model = RayBendingStyleNerfModel (model/nerf_models/ray_bending_style_nerf_model.py:12)
+ * with its raw parameter pointers (the nn.Parameter storages, zero copy).
+ */
+typedef struct pr_object_model_t {
+    int32_t kind;                    /* 0 = AdaInStyleNerfModel, 1 = SkyboxAdaInStyleNerfModelV3 */
+    int32_t has_bender;              /* 1 = PositionalRayBender, 0 = ZeroedRayBender */
+    int32_t positions;               /* samples per ray evaluated by THIS model: P_coarse, or P_coarse + P_fine */
+    int32_t style_features;          /* S */
+    int32_t deformation_features;    /* D */
+    int32_t output_features;         /* F */
+    int32_t layers_width;            /* backbone width (256) */
+    int32_t backbone_count;          /* 8 */
+    int32_t skip_layer_idx;          /* 4 */
+    int32_t octaves;                 /* NeRF positional-encoder octaves (10); append_original is required */
+    int32_t bender_width;            /* 128 */
+    int32_t bender_count;            /* 6 */
+    int32_t bender_skip;             /* 3 */
+    int32_t bender_octaves;          /* 6 */
+    float bender_octave_weights[PR_MAX_OCTAVES]; /* annealing weights evaluated on the host from current_step
+                                                    (model/annealable_positional_encoder.py:59-63) */
+    float bbox[6];                   /* x_lo, x_hi, y_lo, y_hi, z_lo, z_hi */
+    float empty_space_alpha;
+    float z_near_min;
+    float z_far_max;
+    float bn_eps;                    /* 1e-5 */
+    /* nerf_model.* */
+    pr_linear_t backbone[PR_MAX_LAYERS];
+    pr_linear_t alpha_head;          /* weight == NULL for the skybox (sigma == 10) */
+    pr_linear_t head0;               /* features_head.0, no bias */
+    pr_linear_t affine1;             /* features_head.1.affine_transform (2*W, S) */
+    const float* bn1_mean;           /* features_head.1.ada_in.normalization.running_mean (W) */
+    const float* bn1_var;
+    pr_linear_t head3;               /* features_head.3, no bias (W/2, W) */
+    pr_linear_t affine4;             /* features_head.4.affine_transform (W, S) */
+    const float* bn4_mean;
+    const float* bn4_var;
+    pr_linear_t head6;               /* features_head.6 (F, W/2) */
+    /* ray_bender.* (ignored when has_bender == 0) */
+    pr_linear_t bender[PR_MAX_LAYERS];
+    pr_linear_t bender_out;          /* output_head (3, BW), no bias */
+} pr_object_model_t;
+
+/* Bytes of the MFMA-fragment-ordered copy of one model's weights (see DESIGN.md "packed weights"). */
+int pr_packed_size(const pr_object_model_t* model, size_t* bytes);
+
+/* Gathers the raw parameters into `packed` (device, pr_packed_size bytes, 256-B aligned).  Must be
+ * re-run whenever parameter VALUES change; cheap (one pass over ~2.9 MB). */
+int pr_pack_model(const pr_object_model_t* model, void* packed, size_t packed_bytes, void* stream);
+
+/* One object instance of a call: its (shared) coarse / fine models and their packed copies. */
+typedef struct pr_object_t {
+    pr_object_model_t coarse;
+    const void* packed_coarse;
+    pr_object_model_t fine;          /* used only when pr_call_t.use_fine != 0 */
+    const void* packed_fine;
+} pr_object_t;
+
+/* Optional explicit noise of one model type, NULL = not perturbed (required with PR_FLAG_PERTURB). */
+typedef struct pr_noise_t {
+    const float* jitter[PR_MAX_OBJECTS];      /* coarse only: U[0,1) (N,R,P_k)  ray_helper.py:1275 */
+    const float* alpha[PR_MAX_OBJECTS];       /* coarse only: N(0,1) (N,R,P_k)  object_composer.py:553 */
+    const float* pdf[PR_MAX_OBJECTS];         /* coarse only: U[0,1) (N,R,Pf_k) ray_helper.py:1380 */
+    const float* integrate[PR_MAX_OBJECTS];   /* N(0,1) (N,R,P_k) object_composer.py:880 -> :751 */
+    const float* integrate_global;            /* N(0,1) (N,R,sum P_k), applied AFTER the sort, :886 */
+} pr_noise_t;
+
+/* Result fields of ObjectComposer.integrate (model/object_composer.py:774-782); any pointer may be NULL. */
+typedef struct pr_entry_t {
+    float* integrated_features;               /* (N,R,F) */
+    float* opacity;                           /* (N,R) */
+    float* weights;                           /* (N,R,P) ; global: (N,R,sum P_k) in sorted order */
+    float* depth;                             /* (N,R) */
+    float* disparity;                         /* (N,R)  NaN where opacity == 0, as the reference */
+    float* integrated_displacements_magnitude;/* (N,R) */
+    float* integrated_divergence;             /* (N,R)  zeros (eval) */
+} pr_entry_t;
+
+typedef struct pr_outputs_t {
+    pr_entry_t object[PR_MAX_OBJECTS];
+    pr_entry_t global;
+    /* optional exports of intermediate per-sample state, for stage-level parity tests */
+    float* sample_t[PR_MAX_OBJECTS];          /* (N,R,P_k) sample depths */
+    float* sample_sigma[PR_MAX_OBJECTS];      /* (N,R,P_k) raw sigma incl. empty_space_alpha fill */
+    int32_t* sample_slot[PR_MAX_OBJECTS];     /* (N,R,P_k) compact row of the sample, -1 = outside the box */
+    int32_t* evaluated_samples;               /* (K) number of samples sent through the MLP */
+} pr_outputs_t;
+
+typedef struct pr_call_t {
+    int32_t frames;                  /* N */
+    int32_t rays;                    /* R */
+    int32_t objects;                 /* K */
+    int32_t static_objects;          /* first `static_objects` instances are static (overlap fix) */
+    int32_t use_fine;                /* 1 = hierarchical pass with the fine models (all objects) */
+    uint32_t flags;
+    const float* ray_origins;        /* (N,3) world frame */
+    const float* ray_directions;     /* (N,R,3) world frame, not normalised */
+    const float* w2o;                /* (N,K,3,4) top three rows of transformation_matrix_w2o */
+    const float* style;              /* (N,K,S) */
+    const float* deformation;        /* (N,K,D) */
+    const uint8_t* object_in_scene;  /* (N,K) */
+    const float* linspace_coarse[PR_MAX_OBJECTS]; /* torch.linspace(0,1,P_k) evaluated by the host (P_k) */
+    const float* linspace_fine[PR_MAX_OBJECTS];   /* torch.linspace(0,1,Pf_k) */
+    int32_t positions_fine[PR_MAX_OBJECTS];       /* Pf_k (resampled positions, use_fine only) */
+    pr_noise_t noise_coarse;
+    pr_noise_t noise_fine;           /* only .integrate / .integrate_global are read */
+} pr_call_t;
+
+/* Workspace bytes pr_render_forward needs for this call (host computation, no device work). */
+int pr_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes);
+
+/*
+ * The renderer: sample placement -> AABB cull + compaction -> fused MLP -> (hierarchical resampling
+ * -> fused MLP) -> per-object and cross-object compositing.  `coarse` receives the result of the
+ * coarse models, `fine` (may be NULL unless use_fine) the hierarchical pass.
+ */
+int pr_render_forward(const pr_call_t* call, const pr_object_t* objects,
+                      const pr_outputs_t* coarse, const pr_outputs_t* fine,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Camera rays (RayHelper.create_camera_rays + pixel selection + transform_rays, ray_helper.py:15-52,
+ * :433-482, :1203-1227): for frame n and ray r with pixel (rows[r], cols[r]),
+ *   d_cam = ((col - W/2)/f_n, -(row - H/2)/f_n, -1),  d_world = R_n d_cam,  o_world = t_n.
+ * c2w (N,3,4); focals (N) already multiplied by focal_length_multiplier; rows/cols int32 (R).
+ */
+int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width,
+                   const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols,
+                   float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
+
+/* Library / device introspection. */
+int pr_abi_version(void);
+const char* pr_last_error(void);
+int pr_device_info(int32_t* compute_units, int32_t* lds_bytes, char* arch_name, size_t arch_name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLAYRENDER_H */

@@ -506,8 +506,14 @@ def fix_overlaps(layout: ObjectLayout, all_raw, all_t, all_pos, all_disp, all_di
     return out_raw, out_t, out_pos, out_disp, out_div
 
 
-def compose(config, layout, ray_origins, all_f, all_raw, all_t, all_pos, all_disp, all_div):
-    """Concatenate all objects along P, sort by t, gather everything.  object_composer.py:399-447."""
+def compose(config, layout, ray_origins, all_f, all_raw, all_t, all_pos, all_disp, all_div,
+            stable_merge: bool = False):
+    """Concatenate all objects along P, sort by t, gather everything.  object_composer.py:399-447.
+
+    The reference calls ``torch.sort`` without ``stable=True`` (:435): the order inside groups of
+    equal t is unspecified (and differs between torch's CPU and GPU sorts).  ``stable_merge=True``
+    selects the tie rule the HIP renderer defines - stable in concatenation (object) order; it only
+    changes results on rays where an in-box sample sits in a tie (e.g. boxes sharing a face)."""
     if config["model"]["fix_object_overlaps"]:
         all_raw, all_t, all_pos, all_disp, all_div = fix_overlaps(layout, all_raw, all_t, all_pos,
                                                                   all_disp, all_div, ray_origins)
@@ -516,7 +522,7 @@ def compose(config, layout, ray_origins, all_f, all_raw, all_t, all_pos, all_dis
     t = torch.cat(all_t, dim=-1)
     disp = torch.cat(all_disp, dim=-2)
     div = torch.cat(all_div, dim=-1)
-    t, order = torch.sort(t, dim=-1)
+    t, order = torch.sort(t, dim=-1, stable=True) if stable_merge else torch.sort(t, dim=-1)
     raw = torch.gather(raw, -1, order)
     div = torch.gather(div, -1, order)
     f = torch.gather(f, -2, order.unsqueeze(-1).expand_as(f))
@@ -540,7 +546,8 @@ def composer_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, r
                      focal_normals: Tensor, w2o: Tensor, style: Tensor, deformation: Tensor,
                      object_in_scene: Tensor, perturb: bool, canonical_pose: bool = False,
                      training: bool = False, noise: Optional[dict] = None,
-                     record_noise: Optional[dict] = None, update_stats: bool = True) -> dict:
+                     record_noise: Optional[dict] = None, update_stats: bool = True,
+                     stable_merge: bool = False) -> dict:
     """ObjectComposer.forward.  model/object_composer.py:786-892 (+ forward_object :486-580).
 
     ray_origins (..., 3); ray_directions (..., R, 3); w2o (..., 4, 4, K); style (..., S, K);
@@ -621,7 +628,7 @@ def composer_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, r
             rec[f"int_{mtype}_{k}"] = used
             out["extra_outputs"] = {}
             results[mtype][f"object_{k}"] = out
-        cf, craw, ct, cdisp, cdiv = compose(config, layout, exp_origins, *cols)
+        cf, craw, ct, cdisp, cdiv = compose(config, layout, exp_origins, *cols, stable_merge=stable_merge)
         out, used = integrate(cf, craw, ray_directions, ct, cdisp, cdiv, perturb,
                               noise.get(f"int_{mtype}_global"))
         rec[f"int_{mtype}_global"] = used

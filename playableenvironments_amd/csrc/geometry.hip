@@ -1,0 +1,389 @@
+// Geometry stages of the renderer: camera rays, per-object sample placement (slab test +
+// stratified t), AABB cull + deterministic compaction, hierarchical (inverse-CDF) resampling.
+//
+// All arithmetic that feeds a discontinuous decision (slab hit/miss, in-box tests) is written with
+// explicit round-to-nearest mul/add/div in exactly the operation order of the reference's tensor
+// expressions, so the decisions are bit-identical to the fp32 PyTorch path (this file is built with
+// -ffp-contract=off).  Reference lines are cited at each step (paths relative to the reference).
+#include "pr_common.h"
+
+namespace pr {
+
+// ---------------------------------------------------------------------------------------------
+// Camera rays: RayHelper.create_camera_rays (utils/lib_3d/ray_helper.py:15-52), pixel selection
+// (:433-482 / all pixels) and transform_rays with the camera-to-world matrix (:1203-1227).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_camera_rays(int frames, int rays, float half_h, float half_w, const float* __restrict__ c2w,
+                              const float* __restrict__ focals, const int32_t* __restrict__ rows,
+                              const int32_t* __restrict__ cols, float* __restrict__ origins,
+                              float* __restrict__ dirs, float* __restrict__ normals) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)frames * rays;
+    if (g >= total) return;
+    const int n = (int)(g / rays);
+    const int r = (int)(g - (long)n * rays);
+    const float* m = c2w + (size_t)n * 12;
+    const float f = focals[n];
+    const float dx = __fdiv_rn(__fsub_rn((float)cols[r], half_w), f);
+    const float dy = -__fdiv_rn(__fsub_rn((float)rows[r], half_h), f);
+    const float dz = -1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float v = __fadd_rn(__fadd_rn(__fmul_rn(dx, m[i * 4 + 0]), __fmul_rn(dy, m[i * 4 + 1])),
+                                  __fmul_rn(dz, m[i * 4 + 2]));
+        dirs[g * 3 + i] = v;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            origins[n * 3 + i] = m[i * 4 + 3];
+            normals[n * 3 + i] = -m[i * 4 + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-level helpers (256 threads)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan over the 256 threads of a block; `total` = block sum.  lds: >= 4 ints.
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* lds, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_inclusive_scan(v);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-ray slab test, model/object_composer.py:104-151 + clamp :522-523
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ray_bounds(const ObjRay& ray, const float* lo, const float* hi, bool valid,
+                                           float zmin, float zmax, float* near_out, float* far_out) {
+    float z_near = 0.f, z_far = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float den = __fadd_rn(ray.d[a], 1e-6f);
+        const float z0 = __fdiv_rn(__fsub_rn(lo[a], ray.o[a]), den);
+        const float z1 = __fdiv_rn(__fsub_rn(hi[a], ray.o[a]), den);
+        const float mn = nan_min(z0, z1);
+        const float mx = nan_max(z0, z1);
+        if (a == 0) {
+            z_near = mn;
+            z_far = mx;
+        } else {
+            z_near = nan_max(z_near, mn);
+            z_far = nan_min(z_far, mx);
+        }
+    }
+    if ((z_far <= z_near) || !valid) {
+        z_far = 0.f;
+        z_near = 0.f;
+    }
+    *near_out = nan_clamp(z_near, zmin, zmax);
+    *far_out = nan_clamp(z_far, zmin, zmax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coarse placement: RayHelper.create_ray_positions (utils/lib_3d/ray_helper.py:1229-1282).
+// One thread per ray.  Writes t, the sigma fill, and the number of in-box samples per 256-ray block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
+    __shared__ int lds[4];
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.frames * p.rays;
+    int count = 0;
+    if (g < total) {
+        const int n = (int)(g / p.rays);
+        const float* m = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
+        const ObjRay ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
+        const bool valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
+        float z_near, z_far;
+        ray_bounds(ray, p.lo, p.hi, valid, p.z_near_min, p.z_far_max, &z_near, &z_far);
+        const int P = p.positions;
+        const size_t base = (size_t)g * P;
+        // t_i = near * (1 - s_i) + far * s_i
+        auto t_at = [&](int i) {
+            const float s = p.linspace[i];
+            return __fadd_rn(__fmul_rn(z_near, __fsub_rn(1.0f, s)), __fmul_rn(z_far, s));
+        };
+        float t_prev = 0.f, t_cur = t_at(0), t_next = (P > 1) ? t_at(1) : 0.f;
+        for (int i = 0; i < P; ++i) {
+            float t = t_cur;
+            if (p.jitter != nullptr) {
+                // mid points, upper = [mids, t_last], lower = [t_0, mids]   (:1267-1275)
+                const float upper = (i < P - 1) ? __fdiv_rn(__fadd_rn(t_next, t_cur), 2.0f) : t_cur;
+                const float lower = (i > 0) ? __fdiv_rn(__fadd_rn(t_cur, t_prev), 2.0f) : t_cur;
+                t = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), p.jitter[base + i]));
+            }
+            p.t[base + i] = t;
+            p.sigma[base + i] = p.empty_alpha;
+            if (p.dispmag) p.dispmag[base + i] = 0.f;
+            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
+            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
+            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
+            if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
+            t_prev = t_cur;
+            t_cur = t_next;
+            t_next = (i + 2 < P) ? t_at(i + 2) : 0.f;
+        }
+    }
+    int block_total;
+    block_exclusive_scan_256(count, lds, &block_total);
+    if (threadIdx.x == 0) p.block_sums[blockIdx.x] = block_total;
+}
+
+int launch_place_coarse(const PlaceParams& p, hipStream_t s) {
+    const long total = (long)p.frames * p.rays;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(k_place_coarse, dim3(blocks), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of the per-block in-box counts (single workgroup; n is a few thousand at most).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan_blocks(const int32_t* __restrict__ sums, int32_t* __restrict__ offsets,
+                                                    int32_t* __restrict__ total, int n) {
+    __shared__ int lds[4];
+    int carry = 0;
+    for (int start = 0; start < n; start += 256) {
+        const int i = start + threadIdx.x;
+        const int v = (i < n) ? sums[i] : 0;
+        int chunk_total;
+        const int ex = block_exclusive_scan_256(v, lds, &chunk_total);
+        if (i < n) offsets[i] = carry + ex;
+        carry += chunk_total;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, sums, offsets, total, n);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compaction: the in-box samples, in flat (frame, ray, sample) order - the same order in which the
+// reference's boolean-mask indexing compacts them (ray_bending_style_nerf_model.py:180-186).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill(FillParams p) {
+    __shared__ int lds[4];
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.frames * p.rays;
+    const int P = p.positions;
+    int count = 0;
+    ObjRay ray;
+    bool valid = false;
+    if (g < total) {
+        const int n = (int)(g / p.rays);
+        const float* m = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
+        ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
+        valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
+        const size_t base = (size_t)g * P;
+        for (int i = 0; i < P; ++i) {
+            const float t = p.t[base + i];
+            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
+            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
+            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
+            if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
+        }
+    }
+    int block_total;
+    int slot = p.block_offsets[blockIdx.x] + block_exclusive_scan_256(count, lds, &block_total);
+    if (g < total) {
+        const size_t base = (size_t)g * P;
+        for (int i = 0; i < P; ++i) {
+            const float t = p.t[base + i];
+            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
+            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
+            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
+            if (valid && in_box(x, y, z, p.lo, p.hi)) {
+                p.rec_pos[(size_t)slot * 3 + 0] = x;
+                p.rec_pos[(size_t)slot * 3 + 1] = y;
+                p.rec_pos[(size_t)slot * 3 + 2] = z;
+                p.rec_flat[slot] = (int32_t)(base + i);
+                p.slot[base + i] = slot;
+                ++slot;
+            } else {
+                p.slot[base + i] = -1;
+            }
+        }
+    }
+}
+
+int launch_fill(const FillParams& p, hipStream_t s) {
+    const long total = (long)p.frames * p.rays;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hierarchical resampling: coarse alphas/weights (model/object_composer.py:552-554), inverse-CDF
+// sampling (utils/lib_3d/ray_helper.py:1348-1403), merge + sort with the coarse t (:1337-1344).
+// One 64-lane workgroup per ray.  Sequential parts (cumprod, cumsum) are done by one lane in the
+// reference's left-to-right order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_f32(float* key, int n /*pow2*/, int lane) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < n; i += 64) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const float a = key[i], b = key[x];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size) {
+    extern __shared__ float sm[];
+    const int Pc = p.pc, Pf = p.pf;
+    float* tc = sm;             // [Pc]
+    float* al = tc + Pc;        // [Pc] alpha, then weights
+    float* mids = al + Pc;      // [Pc]
+    float* cdf = mids + Pc;     // [Pc]
+    float* key = cdf + Pc;      // [sort_size]
+    const int lane = threadIdx.x;
+    const long g = blockIdx.x;
+    const int n = (int)(g / p.rays);
+    const float* m = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
+    const ObjRay ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
+    const bool valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
+    // |d| in the object frame (forward_object passes the transformed directions, :552)
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ray.d[0], ray.d[0]), __fmul_rn(ray.d[1], ray.d[1])),
+                                       __fmul_rn(ray.d[2], ray.d[2])));
+    const size_t cbase = (size_t)g * Pc;
+    for (int i = lane; i < Pc; i += 64) tc[i] = p.t_coarse[cbase + i];
+    __syncthreads();
+    for (int i = lane; i < Pc; i += 64) {
+        float raw = valid ? p.sigma_coarse[cbase + i] : p.empty_alpha;
+        if (p.alpha_noise) raw = __fadd_rn(raw, p.alpha_noise[cbase + i]);
+        const float dt = (i < Pc - 1) ? __fsub_rn(tc[i + 1], tc[i]) : 1e10f;
+        const float dist = __fmul_rn(dt, norm);
+        const float relu = raw > 0.f ? raw : 0.f;
+        al[i] = __fsub_rn(1.0f, expf(__fmul_rn(-relu, dist)));
+        if (i < Pc - 1) mids[i] = __fdiv_rn(__fadd_rn(tc[i + 1], tc[i]), 2.0f);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        // weights = alpha * cumprod([1, 1 - alpha + 1e-10][:-1])
+        float trans = 1.0f;
+        for (int i = 0; i < Pc; ++i) {
+            const float a = al[i];
+            al[i] = __fmul_rn(a, trans);
+            trans = __fmul_rn(trans, __fadd_rn(__fsub_rn(1.0f, a), 1e-10f));
+        }
+        // pdf over weights[1:-1] + 1e-5 ; cdf = [0, cumsum(pdf)]
+        const int nb = Pc - 2;
+        float sum = 0.f;
+        for (int j = 0; j < nb; ++j) sum = __fadd_rn(sum, __fadd_rn(al[j + 1], 1e-5f));
+        float c = 0.f;
+        cdf[0] = 0.f;
+        for (int j = 0; j < nb; ++j) {
+            c = __fadd_rn(c, __fdiv_rn(__fadd_rn(al[j + 1], 1e-5f), sum));
+            cdf[j + 1] = c;
+        }
+    }
+    __syncthreads();
+    const int ncdf = Pc - 1;
+    for (int i = lane; i < sort_size; i += 64) key[i] = (i < Pc) ? tc[i] : __builtin_inff();
+    for (int f = lane; f < Pf; f += 64) {
+        const float u = p.u_random ? p.u_random[(size_t)g * Pf + f] : p.u_fixed[f];
+        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
+        int lo_i = 0, hi_i = ncdf;
+        while (lo_i < hi_i) {
+            const int mid = (lo_i + hi_i) >> 1;
+            if (cdf[mid] > u) hi_i = mid; else lo_i = mid + 1;
+        }
+        const int below = lo_i - 1 < 0 ? 0 : lo_i - 1;
+        const int above = lo_i > ncdf - 1 ? ncdf - 1 : lo_i;
+        float den = __fsub_rn(cdf[above], cdf[below]);
+        if (den < 1e-5f) den = 1.0f;
+        const float frac = __fdiv_rn(__fsub_rn(u, cdf[below]), den);
+        key[Pc + f] = __fadd_rn(mids[below], __fmul_rn(frac, __fsub_rn(mids[above], mids[below])));
+    }
+    __syncthreads();
+    bitonic_sort_f32(key, sort_size, lane);
+    const int Pm = Pc + Pf;
+    const size_t fbase = (size_t)g * Pm;
+    int count = 0;
+    for (int i = lane; i < Pm; i += 64) {
+        const float t = key[i];
+        p.t_fine[fbase + i] = t;
+        p.sigma_fine[fbase + i] = p.empty_alpha;
+        if (p.dispmag_fine) p.dispmag_fine[fbase + i] = 0.f;
+        const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
+        const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
+        const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
+        if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) count += __shfl_down(count, d, 64);
+    if (lane == 0 && count) atomicAdd(&p.block_sums[g >> 8], count);
+}
+
+static int next_pow2(int v) {
+    int r = 1;
+    while (r < v) r <<= 1;
+    return r;
+}
+
+int launch_resample(const ResampleParams& p, hipStream_t s) {
+    PR_REQUIRE(p.pc >= 3, "hierarchical sampling needs at least 3 coarse positions (got %d)", p.pc);
+    const long total = (long)p.frames * p.rays;
+    const int nblocks256 = (int)((total + 255) / 256);
+    PR_CHECK_HIP(hipMemsetAsync(p.block_sums, 0, sizeof(int32_t) * nblocks256, s));
+    int sort_size = next_pow2(p.pc + p.pf);
+    if (sort_size < 64) sort_size = 64;
+    const size_t lds = sizeof(float) * (4 * (size_t)p.pc + sort_size);
+    PR_REQUIRE(lds <= 64 * 1024, "resample: too many positions per ray (%d + %d)", p.pc, p.pf);
+    hipLaunchKernelGGL(k_resample, dim3((unsigned)total), dim3(64), lds, s, p, sort_size);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+}  // namespace pr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, const float* c2w,
+                              const float* focals, const int32_t* rows, const int32_t* cols, float* ray_origins,
+                              float* ray_directions, float* focal_normals, void* stream) {
+    PR_REQUIRE(frames > 0 && rays > 0, "pr_camera_rays: empty call (%d frames, %d rays)", frames, rays);
+    PR_REQUIRE(c2w && focals && rows && cols && ray_origins && ray_directions && focal_normals,
+               "pr_camera_rays: NULL pointer");
+    const long total = (long)frames * rays;
+    const int blocks = (int)((total + 255) / 256);
+    // width / 2 and height / 2 are Python floats in the reference (true division)
+    hipLaunchKernelGGL(pr::k_camera_rays, dim3(blocks), dim3(256), 0, (hipStream_t)stream, frames, rays,
+                       (float)height / 2.0f, (float)width / 2.0f, c2w, focals, rows, cols, ray_origins,
+                       ray_directions, focal_normals);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}

@@ -1,0 +1,804 @@
+// Fused per-object MLP of the renderer on the gfx950 matrix cores (exact-fp32 MFMA).
+//
+//   [PositionalRayBender]  x/size -> annealed PE (+ deformation) -> 6 x (Linear 128 + ReLU, skip) ->
+//                          Linear 128->3 -> * size -> clamp into the box -> x' = x + delta
+//   [AdaInStyleNerfModel]  x'/size -> PE -> 8 x (Linear 256 + ReLU, skip) -> sigma head ;
+//                          Linear 256->256 -> AdaIN -> ReLU -> Linear 256->128 -> AdaIN -> ReLU -> Linear 128->F
+//   [SkyboxAdaInStyleNerfModelV3] same trunk on [o/size, d/|d|], sigma == 10
+// (model/nerf_models/{positional_ray_bender_model,adain_style_nerf_model,skybox_adain_style_nerf_model_v3}.py).
+//
+// Structure (DESIGN.md "K3"): a persistent workgroup of 8 waves owns a tile of 64 compacted samples.
+// Activations live in LDS as X[64][260] fp32 (row stride 260 -> conflict-free ds_read_b128), the
+// positional encoding in E[64][132].  For a layer out = X . W^T each wave owns one 32-column block
+// of the output for all 64 rows: A fragments (activations) come from LDS, B fragments (weights) are
+// read straight from L2 in a host-prepared fragment order (one dwordx4 per lane per 4 MFMAs), the
+// accumulators start from the bias, and the epilogue (ReLU / folded AdaIN + ReLU / feature store)
+// runs on the accumulator registers.  v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain.
+#include "pr_common.h"
+
+#include <stdarg.h>
+
+namespace pr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Dimensions and packed layout (host)
+// ---------------------------------------------------------------------------------------------
+int compute_dims(const pr_object_model_t& m, ModelDims* d) {
+    PR_REQUIRE(m.kind == 0 || m.kind == 1, "unknown nerf model kind %d", m.kind);
+    PR_REQUIRE(m.octaves >= 0 && m.octaves <= PR_MAX_OCTAVES, "octaves %d out of range", m.octaves);
+    d->din = m.kind == 0 ? 3 : 6;
+    d->enc = d->din + 2 * d->din * m.octaves;
+    d->enc_pad = round_up(d->enc, 8);
+    d->W = m.layers_width;
+    d->Wpad = round_up(d->W, 32);
+    d->W2 = m.layers_width / 2;
+    d->W2pad = round_up(d->W2, 32);
+    d->F = m.output_features;
+    d->Fpad = round_up(d->F, 32);
+    PR_REQUIRE(d->enc_pad <= MAX_ENC, "encoding width %d exceeds %d", d->enc, MAX_ENC);
+    PR_REQUIRE(d->W >= 2 && d->Wpad <= MAX_WIDTH, "layers_width %d unsupported (max %d)", d->W, MAX_WIDTH);
+    PR_REQUIRE(d->F >= 1 && d->Fpad <= MAX_WIDTH, "output_features %d unsupported (max %d)", d->F, MAX_WIDTH);
+    PR_REQUIRE(m.backbone_count >= 2 && m.backbone_count <= PR_MAX_LAYERS, "backbone_layers_count %d unsupported",
+               m.backbone_count);
+    PR_REQUIRE(m.skip_layer_idx >= 1 && m.skip_layer_idx < m.backbone_count, "skip_layer_idx %d unsupported",
+               m.skip_layer_idx);
+    d->benc = d->bin = d->bin_pad = d->BW = d->BWpad = 0;
+    if (m.has_bender) {
+        PR_REQUIRE(m.kind == 0, "a ray bender on the skybox model is not supported");
+        PR_REQUIRE(m.bender_octaves >= 0 && m.bender_octaves <= PR_MAX_OCTAVES, "bender octaves out of range");
+        d->benc = 3 + 6 * m.bender_octaves;
+        d->bin = d->benc + m.deformation_features;
+        d->bin_pad = round_up(d->bin, 8);
+        d->BW = m.bender_width;
+        d->BWpad = round_up(d->BW, 32);
+        PR_REQUIRE(d->bin_pad <= MAX_ENC, "bender input width %d exceeds %d", d->bin, MAX_ENC);
+        PR_REQUIRE(d->BW >= 1 && d->BWpad <= MAX_WIDTH, "bender width %d unsupported", d->BW);
+        PR_REQUIRE(m.bender_count >= 2 && m.bender_count <= PR_MAX_LAYERS, "bender layers_count %d unsupported",
+                   m.bender_count);
+        PR_REQUIRE(m.bender_skip >= 1 && m.bender_skip < m.bender_count, "bender skip_layer_idx %d unsupported",
+                   m.bender_skip);
+    }
+    return PR_OK;
+}
+
+static int seg_floats(int nblk, int kpad) { return nblk * (kpad / 8) * 256; }
+
+int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout* l) {
+    int off = 0;
+    memset(l, 0, sizeof(*l));
+    if (m.has_bender) {
+        const int nb = d.BWpad / 32;
+        for (int j = 0; j < m.bender_count; ++j) {
+            l->b_seg_off[j][0] = off;
+            off += seg_floats(nb, j == 0 ? d.bin_pad : d.BWpad);
+            l->b_seg_off[j][1] = off;
+            if (j == m.bender_skip) off += seg_floats(nb, d.bin_pad);
+            l->b_bias_off[j] = off;
+            off += d.BWpad;
+        }
+        l->b_out_off = off;
+        off += round_up(3 * d.BWpad, 32);
+    }
+    const int nb = d.Wpad / 32;
+    for (int i = 0; i < m.backbone_count; ++i) {
+        l->n_seg_off[i][0] = off;
+        off += seg_floats(nb, i == 0 ? d.enc_pad : d.Wpad);
+        l->n_seg_off[i][1] = off;
+        if (i == m.skip_layer_idx) off += seg_floats(nb, d.enc_pad);
+        l->n_bias_off[i] = off;
+        off += d.Wpad;
+    }
+    l->sigma_off = off;
+    off += d.Wpad + 32;
+    l->h0_off = off;
+    off += seg_floats(d.Wpad / 32, d.Wpad);
+    l->h3_off = off;
+    off += seg_floats(d.W2pad / 32, d.Wpad);
+    l->h6_off = off;
+    off += seg_floats(d.Fpad / 32, d.W2pad);
+    l->h6_bias_off = off;
+    off += d.Fpad;
+    l->total = off;
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing.  Fragment order of one K-segment of a Linear (out = n, in = k):
+//   dst[((nb * kq + q) * 64 + lane) * 4 + e] = W[nb*32 + (lane & 31)][col_off + (lane >> 5) * 4*kq + 4*q + e]
+// i.e. lanes 0-31 sweep the first half of the (padded) K range and lanes 32-63 the second half,
+// matching how the kernel reads the A operand; rows/cols beyond the real shape are zero.
+// ---------------------------------------------------------------------------------------------
+struct PackJob {
+    const float* src;
+    float* dst;
+    int kind;       // 0 = fragment-ordered matrix segment, 1 = padded vector / raw row copy
+    int in_total;   // row stride of src
+    int col_off;
+    int k_real, n_real, kq, nblk;
+    int count;      // elements of dst
+};
+constexpr int MAX_PACK_JOBS = 56;
+struct PackJobs {
+    PackJob job[MAX_PACK_JOBS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
+    const PackJob& j = jobs.job[blockIdx.y];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < j.count; idx += gridDim.x * 256) {
+        float v = 0.f;
+        if (j.kind == 0) {
+            const int e = idx & 3;
+            const int lane = (idx >> 2) & 63;
+            const int rest = idx >> 8;
+            const int q = rest % j.kq;
+            const int nb = rest / j.kq;
+            const int n = nb * 32 + (lane & 31);
+            const int k = (lane >> 5) * 4 * j.kq + 4 * q + e;
+            if (n < j.n_real && k < j.k_real) v = j.src[(size_t)n * j.in_total + j.col_off + k];
+        } else {
+            // rows of length kq (padded) from rows of length k_real; n_real rows
+            const int row = idx / j.kq, c = idx % j.kq;
+            if (j.src && row < j.n_real && c < j.k_real) v = j.src[(size_t)row * j.in_total + j.col_off + c];
+        }
+        j.dst[idx] = v;
+    }
+}
+
+static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
+    PR_REQUIRE(js->n < MAX_PACK_JOBS, "too many pack jobs");
+    PR_REQUIRE(lin.weight != nullptr, "missing weight pointer");
+    PackJob& j = js->job[js->n++];
+    j.src = lin.weight;
+    j.dst = dst;
+    j.kind = 0;
+    j.in_total = lin.in_features;
+    j.col_off = col_off;
+    j.k_real = k_real;
+    j.n_real = lin.out_features;
+    j.kq = kpad / 8;
+    j.nblk = npad / 32;
+    j.count = seg_floats(j.nblk, kpad);
+    return PR_OK;
+}
+
+static int add_vec(PackJobs* js, const float* src, int rows, int row_real, int row_stride, int row_pad, float* dst) {
+    PR_REQUIRE(js->n < MAX_PACK_JOBS, "too many pack jobs");
+    PackJob& j = js->job[js->n++];
+    j.src = src;
+    j.dst = dst;
+    j.kind = 1;
+    j.in_total = row_stride;
+    j.col_off = 0;
+    j.k_real = row_real;
+    j.n_real = rows;
+    j.kq = row_pad;
+    j.nblk = 0;
+    j.count = rows * row_pad;
+    return PR_OK;
+}
+
+#define PR_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != PR_OK) return _r;  \
+    } while (0)
+
+static int check_linear(const pr_linear_t& l, int out, int in, const char* name) {
+    PR_REQUIRE(l.weight != nullptr, "%s: weight pointer is NULL", name);
+    PR_REQUIRE(l.out_features == out && l.in_features == in, "%s: shape (%d, %d), expected (%d, %d)", name,
+               l.out_features, l.in_features, out, in);
+    return PR_OK;
+}
+
+static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, float* base,
+                           PackJobs* js) {
+    js->n = 0;
+    if (m.has_bender) {
+        for (int j = 0; j < m.bender_count; ++j) {
+            const int in = (j == 0) ? d.bin : (j == m.bender_skip ? d.BW + d.bin : d.BW);
+            PR_TRY(check_linear(m.bender[j], d.BW, in, "ray_bender.backbone_layers"));
+            PR_REQUIRE(m.bender[j].bias != nullptr, "ray_bender.backbone_layers: bias is NULL");
+            if (j == 0) {
+                PR_TRY(add_seg(js, m.bender[j], 0, d.bin, d.bin_pad, d.BWpad, base + l.b_seg_off[j][0]));
+            } else {
+                PR_TRY(add_seg(js, m.bender[j], 0, d.BW, d.BWpad, d.BWpad, base + l.b_seg_off[j][0]));
+                if (j == m.bender_skip)
+                    PR_TRY(add_seg(js, m.bender[j], d.BW, d.bin, d.bin_pad, d.BWpad, base + l.b_seg_off[j][1]));
+            }
+            PR_TRY(add_vec(js, m.bender[j].bias, 1, d.BW, d.BW, d.BWpad, base + l.b_bias_off[j]));
+        }
+        PR_TRY(check_linear(m.bender_out, 3, d.BW, "ray_bender.output_head"));
+        PR_TRY(add_vec(js, m.bender_out.weight, 3, d.BW, d.BW, d.BWpad, base + l.b_out_off));
+    }
+    for (int i = 0; i < m.backbone_count; ++i) {
+        const int in = (i == 0) ? d.enc : (i == m.skip_layer_idx ? d.W + d.enc : d.W);
+        PR_TRY(check_linear(m.backbone[i], d.W, in, "nerf_model.backbone_layers"));
+        PR_REQUIRE(m.backbone[i].bias != nullptr, "nerf_model.backbone_layers: bias is NULL");
+        if (i == 0) {
+            PR_TRY(add_seg(js, m.backbone[i], 0, d.enc, d.enc_pad, d.Wpad, base + l.n_seg_off[i][0]));
+        } else {
+            PR_TRY(add_seg(js, m.backbone[i], 0, d.W, d.Wpad, d.Wpad, base + l.n_seg_off[i][0]));
+            if (i == m.skip_layer_idx)
+                PR_TRY(add_seg(js, m.backbone[i], d.W, d.enc, d.enc_pad, d.Wpad, base + l.n_seg_off[i][1]));
+        }
+        PR_TRY(add_vec(js, m.backbone[i].bias, 1, d.W, d.W, d.Wpad, base + l.n_bias_off[i]));
+    }
+    if (m.kind == 0) {
+        PR_TRY(check_linear(m.alpha_head, 1, d.W, "nerf_model.alpha_head"));
+        PR_REQUIRE(m.alpha_head.bias != nullptr, "nerf_model.alpha_head: bias is NULL");
+        PR_TRY(add_vec(js, m.alpha_head.weight, 1, d.W, d.W, d.Wpad, base + l.sigma_off));
+        PR_TRY(add_vec(js, m.alpha_head.bias, 1, 1, 1, 32, base + l.sigma_off + d.Wpad));
+    } else {
+        PR_TRY(add_vec(js, nullptr, 1, 0, 0, d.Wpad + 32, base + l.sigma_off));
+    }
+    PR_TRY(check_linear(m.head0, d.W, d.W, "nerf_model.features_head.0"));
+    PR_TRY(check_linear(m.head3, d.W2, d.W, "nerf_model.features_head.3"));
+    PR_TRY(check_linear(m.head6, d.F, d.W2, "nerf_model.features_head.6"));
+    PR_REQUIRE(m.head6.bias != nullptr, "nerf_model.features_head.6: bias is NULL");
+    PR_TRY(add_seg(js, m.head0, 0, d.W, d.Wpad, d.Wpad, base + l.h0_off));
+    PR_TRY(add_seg(js, m.head3, 0, d.W, d.Wpad, d.W2pad, base + l.h3_off));
+    PR_TRY(add_seg(js, m.head6, 0, d.W2, d.W2pad, d.Fpad, base + l.h6_off));
+    PR_TRY(add_vec(js, m.head6.bias, 1, d.F, d.F, d.Fpad, base + l.h6_bias_off));
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdaIN fold: for every (frame, object)  [scale | bias] = Linear(style)   (model/layers/adain.py:30-32)
+// and eval-mode BatchNorm1d(affine=False) folded in:  y = h * g + b  with
+//   g = scale / sqrt(running_var + eps),  b = bias - running_mean * g       (adain.py:47,58-59)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) {
+    const int n = blockIdx.x;
+    const float* style = p.style + ((size_t)n * p.objects + p.object_index) * p.S;
+    float* row = p.table + (size_t)n * p.row_floats;
+    const int total = p.Wpad + p.W2pad;
+    for (int c = threadIdx.x; c < total; c += 256) {
+        const bool first = c < p.Wpad;
+        const int ch = first ? c : c - p.Wpad;
+        const int width = first ? p.W : p.W2;
+        const pr_linear_t& a = first ? p.affine1 : p.affine4;
+        const float* mean = first ? p.bn1_mean : p.bn4_mean;
+        const float* var = first ? p.bn1_var : p.bn4_var;
+        float g = 0.f, b = 0.f;
+        if (ch < width) {
+            float scale = a.bias[ch], bias = a.bias[width + ch];
+            const float* ws = a.weight + (size_t)ch * p.S;
+            const float* wb = a.weight + (size_t)(width + ch) * p.S;
+            for (int s = 0; s < p.S; ++s) {
+                scale = fmaf(ws[s], style[s], scale);
+                bias = fmaf(wb[s], style[s], bias);
+            }
+            const float inv = 1.0f / sqrtf(var[ch] + p.eps);
+            g = scale * inv;
+            b = bias - mean[ch] * g;
+        }
+        if (first) {
+            row[ch] = g;
+            row[p.Wpad + ch] = b;
+        } else {
+            row[2 * p.Wpad + ch] = g;
+            row[2 * p.Wpad + p.W2pad + ch] = b;
+        }
+    }
+}
+
+int launch_adain_fold(const FoldParams& p, hipStream_t s) {
+    PR_REQUIRE(p.affine1.weight && p.affine1.bias && p.affine4.weight && p.affine4.bias && p.bn1_mean && p.bn1_var &&
+                   p.bn4_mean && p.bn4_var,
+               "AdaIN parameters missing");
+    PR_REQUIRE(p.affine1.out_features == 2 * p.W && p.affine1.in_features == p.S, "features_head.1 affine shape");
+    PR_REQUIRE(p.affine4.out_features == 2 * p.W2 && p.affine4.in_features == p.S, "features_head.4 affine shape");
+    hipLaunchKernelGGL(k_adain_fold, dim3(p.frames), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared memory image of one tile
+// ---------------------------------------------------------------------------------------------
+struct Smem {
+    float X[TILE_M * LDX];
+    float E[TILE_M * LDE];
+    float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
+    int flat[TILE_M];
+    int frame[TILE_M];
+    int alive[TILE_M];       // row holds a real sample that passed every AABB test
+    int valid[TILE_M];       // row holds a real sample
+};
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// positional encoding element j of input v[din]  (model/positional_encoder.py:54-64)
+__device__ __forceinline__ float pe_element(const float* v, int din, int enc, int j, const float* octave_weights) {
+    if (j < din) return v[j];
+    if (j >= enc) return 0.f;
+    const int jj = j - din;
+    const int k = jj / (2 * din);
+    const int rem = jj - k * 2 * din;
+    const int fn = rem / din;
+    const int ax = rem - fn * din;
+    const float arg = __fmul_rn(ldexpf(1.0f, k), v[ax]);
+    float e = fn ? cosf(arg) : sinf(arg);
+    if (octave_weights) e = __fmul_rn(e, octave_weights[k]);
+    return e;
+}
+
+// One layer on the tile.  All 512 threads call it (two workgroup barriers inside).
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int nblk = L.nblk;
+    const bool both = nblk > 4;
+    int cb, rb;
+    bool active;
+    if (both) {
+        cb = wave;
+        rb = 0;
+        active = wave < nblk;
+    } else {
+        cb = wave % nblk;
+        rb = wave / nblk;
+        active = rb < 2;
+    }
+    f32x16 acc0, acc1;
+    {
+        const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc0[i] = bias;
+            acc1[i] = bias;
+        }
+    }
+    if (active) {
+        for (int sidx = 0; sidx < L.nseg; ++sidx) {
+            const Seg& sg = L.seg[sidx];
+            const float* src = sg.src == 0 ? S.X : S.E;
+            const int ld = sg.src == 0 ? LDX : LDE;
+            const int kq = sg.kq;
+            const float* ap = src + (rb * 32 + r) * ld + half * 4 * kq;
+            const float4* wp = reinterpret_cast<const float4*>(sg.w) + (size_t)cb * kq * 64 + lane;
+            float4 b = wp[0];
+            if (both) {
+                for (int q = 0; q < kq; ++q) {
+                    const int qn = (q + 1 < kq) ? q + 1 : q;
+                    const float4 bn = wp[(size_t)qn * 64];
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
+                    const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+                    b = bn;
+                }
+            } else {
+                for (int q = 0; q < kq; ++q) {
+                    const int qn = (q + 1 < kq) ? q + 1 : q;
+                    const float4 bn = wp[(size_t)qn * 64];
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+                    b = bn;
+                }
+            }
+        }
+    }
+    __syncthreads();  // every wave has finished reading X / E
+    if (active) {
+        const int col = cb * 32 + r;
+        const int nrb = both ? 2 : 1;
+        for (int blk = 0; blk < nrb; ++blk) {
+            const f32x16& acc = blk == 0 ? acc0 : acc1;
+            const int row0 = (both ? blk : rb) * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = row0 + acc_row(i, half);
+                float v = acc[i];
+                if (L.epi == EPI_RELU) {
+                    S.X[row * LDX + col] = v > 0.f ? v : 0.f;
+                } else if (L.epi == EPI_ADAIN_RELU) {
+                    const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + L.adain_off;
+                    v = fmaf(v, tab[col], tab[L.nblk * 32 + col]);
+                    S.X[row * LDX + col] = v > 0.f ? v : 0.f;
+                } else {
+                    if (S.valid[row] && col < L.n_real)
+                        p.feat[(size_t)(tile_base + row) * p.F + col] = S.alive[row] ? v : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// dot products of every tile row with `nout` (<= 3) weight rows of length `width` (raw, padded),
+// 8 threads per row; result valid in the thread with part == 0.
+__device__ __forceinline__ void row_dots(const Smem& S, const float* w, int width, int wstride, int nout, float* out) {
+    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = part; k < width; k += 8) {
+        const float x = S.X[s * LDX + k];
+        for (int a = 0; a < nout; ++a) acc[a] = fmaf(x, w[a * wstride + k], acc[a]);
+    }
+    for (int a = 0; a < nout; ++a) {
+        float v = acc[a];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        out[a] = v;
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = *p.total;
+    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+        const int tile_base = tile * TILE_M;
+        // ---- load the sample records of the tile --------------------------------------------
+        if (tid < TILE_M) {
+            const int idx = tile_base + tid;
+            const bool valid = idx < total;
+            const int src = valid ? idx : tile_base;   // padding rows replicate the first sample
+            const int flat = p.rec_flat[src];
+            const int frame = flat / p.samples_per_frame;
+            S.flat[tid] = flat;
+            S.frame[tid] = frame;
+            S.valid[tid] = valid ? 1 : 0;
+            S.alive[tid] = valid ? 1 : 0;
+            if (p.kind == 0) {
+                S.pos[tid * 8 + 0] = p.rec_pos[(size_t)src * 3 + 0];
+                S.pos[tid * 8 + 1] = p.rec_pos[(size_t)src * 3 + 1];
+                S.pos[tid * 8 + 2] = p.rec_pos[(size_t)src * 3 + 2];
+            } else {
+                // skybox input [o / size, d / |d|]   (skybox_adain_style_nerf_model_v3.py:88-96)
+                const int ray = (flat - frame * p.samples_per_frame) / p.positions;
+                const ObjRay rr = object_ray(p.w2o + (size_t)frame * p.w2o_stride, p.ray_origins + (size_t)frame * 3,
+                                             p.ray_directions + ((size_t)frame * p.rays + ray) * 3);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rr.d[0], rr.d[0]), __fmul_rn(rr.d[1], rr.d[1])),
+                                                  __fmul_rn(rr.d[2], rr.d[2])));
+                for (int a = 0; a < 3; ++a) {
+                    S.pos[tid * 8 + a] = __fdiv_rn(rr.o[a], p.size[a]);
+                    S.pos[tid * 8 + 3 + a] = __fdiv_rn(rr.d[a], nrm);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- ray bender -----------------------------------------------------------------------
+        if (p.has_bender) {
+            for (int idx = tid; idx < TILE_M * p.bin_pad; idx += MLP_THREADS) {
+                const int s = idx / p.bin_pad, j = idx - s * p.bin_pad;
+                float v;
+                if (j < p.benc) {
+                    float xn[3];
+                    for (int a = 0; a < 3; ++a) xn[a] = __fdiv_rn(S.pos[s * 8 + a], p.size[a]);
+                    v = pe_element(xn, 3, p.benc, j, p.b_weights);
+                } else if (j < p.benc + p.D) {
+                    v = p.deformation[(size_t)S.frame[s] * p.deformation_stride + (j - p.benc)];
+                } else {
+                    v = 0.f;
+                }
+                S.E[s * LDE + j] = v;
+            }
+            __syncthreads();
+            for (int l = 0; l < p.b_count; ++l) run_layer(p.b_layers[l], S, p, tile_base);
+            // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
+            float out[3];
+            row_dots(S, p.b_out, p.BWpad, p.BWpad, 3, out);
+            __syncthreads();
+            if ((tid & 7) == 0) {
+                const int s = tid >> 3;
+                float d[3], bent[3];
+                for (int a = 0; a < 3; ++a) {
+                    const float x = S.pos[s * 8 + a];
+                    float dl = __fmul_rn(out[a], p.size[a]);
+                    dl = nan_max(dl, __fsub_rn(p.lo[a], x));
+                    dl = nan_min(dl, __fsub_rn(p.hi[a], x));
+                    if (p.canonical) dl = __fmul_rn(dl, 0.0f);
+                    d[a] = dl;
+                    bent[a] = __fadd_rn(x, dl);
+                    S.pos[s * 8 + a] = bent[a];
+                }
+                if (S.valid[s]) {
+                    if (p.dispmag)
+                        p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
+                                                               __fmul_rn(d[2], d[2])));
+                    // second AABB test on the bent position (adain_style_nerf_model.py:173-184)
+                    if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.alive[s] = 0;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- positional encoding of the NeRF input --------------------------------------------
+        for (int idx = tid; idx < TILE_M * p.enc_pad; idx += MLP_THREADS) {
+            const int s = idx / p.enc_pad, j = idx - s * p.enc_pad;
+            float v[6];
+            if (p.kind == 0) {
+                for (int a = 0; a < 3; ++a) v[a] = __fdiv_rn(S.pos[s * 8 + a], p.size[a]);
+            } else {
+                for (int a = 0; a < 6; ++a) v[a] = S.pos[s * 8 + a];
+            }
+            S.E[s * LDE + j] = pe_element(v, p.din, p.enc, j, nullptr);
+        }
+        __syncthreads();
+
+        // ---- backbone ---------------------------------------------------------------------------
+        for (int l = 0; l < p.n_backbone; ++l) run_layer(p.layers[l], S, p, tile_base);
+
+        // ---- sigma head -------------------------------------------------------------------------
+        if (p.kind == 0) {
+            float sg;
+            row_dots(S, p.sigma_w, p.Wpad, p.Wpad, 1, &sg);
+            if ((tid & 7) == 0) {
+                const int s = tid >> 3;
+                if (S.valid[s] && S.alive[s]) p.sigma[S.flat[s]] = sg + p.sigma_w[p.Wpad];
+            }
+        } else if (tid < TILE_M) {
+            if (S.valid[tid]) p.sigma[S.flat[tid]] = 10.0f;
+        }
+
+        // ---- style-modulated feature head -------------------------------------------------------
+        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scalar debugging kernel: one thread per sample, raw (reference-layout) weights.  Used by tests
+// to separate packing / MFMA-layout bugs from pipeline bugs.  Never used by the product path
+// unless PR_FLAG_NAIVE_MLP is set explicitly.
+// ---------------------------------------------------------------------------------------------
+__device__ void naive_linear(const pr_linear_t& l, const float* in, float* out, bool relu) {
+    for (int n = 0; n < l.out_features; ++n) {
+        float acc = l.bias ? l.bias[n] : 0.f;
+        const float* w = l.weight + (size_t)n * l.in_features;
+        for (int k = 0; k < l.in_features; ++k) acc = fmaf(in[k], w[k], acc);
+        out[n] = relu ? (acc > 0.f ? acc : 0.f) : acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mlp_naive(MlpParams p, pr_object_model_t m) {
+    const int total = *p.total;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= total) return;
+    float in[MAX_WIDTH + MAX_ENC], h[MAX_WIDTH], enc[MAX_ENC];
+    const int flat = p.rec_flat[idx];
+    const int frame = flat / p.samples_per_frame;
+    float v[6];
+    bool alive = true;
+    if (p.kind == 0) {
+        float x[3] = {p.rec_pos[(size_t)idx * 3], p.rec_pos[(size_t)idx * 3 + 1], p.rec_pos[(size_t)idx * 3 + 2]};
+        if (p.has_bender) {
+            float xn[3];
+            for (int a = 0; a < 3; ++a) xn[a] = __fdiv_rn(x[a], p.size[a]);
+            const int bin = p.benc + p.D;
+            for (int j = 0; j < p.benc; ++j) enc[j] = pe_element(xn, 3, p.benc, j, p.b_weights);
+            for (int j = 0; j < p.D; ++j) enc[p.benc + j] = p.deformation[(size_t)frame * p.deformation_stride + j];
+            for (int j = 0; j < bin; ++j) in[j] = enc[j];
+            for (int l = 0; l < p.b_count; ++l) {
+                if (l == m.bender_skip) {
+                    for (int j = 0; j < p.BW; ++j) in[j] = h[j];
+                    for (int j = 0; j < bin; ++j) in[p.BW + j] = enc[j];
+                } else if (l > 0) {
+                    for (int j = 0; j < p.BW; ++j) in[j] = h[j];
+                }
+                naive_linear(m.bender[l], in, h, true);
+            }
+            float out[3];
+            naive_linear(m.bender_out, h, out, false);
+            float d[3];
+            for (int a = 0; a < 3; ++a) {
+                float dl = __fmul_rn(out[a], p.size[a]);
+                dl = nan_max(dl, __fsub_rn(p.lo[a], x[a]));
+                dl = nan_min(dl, __fsub_rn(p.hi[a], x[a]));
+                if (p.canonical) dl = __fmul_rn(dl, 0.0f);
+                d[a] = dl;
+                x[a] = __fadd_rn(x[a], dl);
+            }
+            if (p.dispmag)
+                p.dispmag[flat] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
+                                                  __fmul_rn(d[2], d[2])));
+            alive = in_box(x[0], x[1], x[2], p.lo, p.hi);
+        }
+        for (int a = 0; a < 3; ++a) v[a] = __fdiv_rn(x[a], p.size[a]);
+    } else {
+        const int ray = (flat - frame * p.samples_per_frame) / p.positions;
+        const ObjRay rr = object_ray(p.w2o + (size_t)frame * p.w2o_stride, p.ray_origins + (size_t)frame * 3,
+                                     p.ray_directions + ((size_t)frame * p.rays + ray) * 3);
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rr.d[0], rr.d[0]), __fmul_rn(rr.d[1], rr.d[1])),
+                                          __fmul_rn(rr.d[2], rr.d[2])));
+        for (int a = 0; a < 3; ++a) {
+            v[a] = __fdiv_rn(rr.o[a], p.size[a]);
+            v[3 + a] = __fdiv_rn(rr.d[a], nrm);
+        }
+    }
+    for (int j = 0; j < p.enc; ++j) enc[j] = pe_element(v, p.din, p.enc, j, nullptr);
+    for (int j = 0; j < p.enc; ++j) in[j] = enc[j];
+    for (int l = 0; l < p.n_backbone; ++l) {
+        if (l == m.skip_layer_idx) {
+            for (int j = 0; j < p.W; ++j) in[j] = h[j];
+            for (int j = 0; j < p.enc; ++j) in[p.W + j] = enc[j];
+        } else if (l > 0) {
+            for (int j = 0; j < p.W; ++j) in[j] = h[j];
+        }
+        naive_linear(m.backbone[l], in, h, true);
+    }
+    if (p.kind == 0) {
+        float sg;
+        naive_linear(m.alpha_head, h, &sg, false);
+        if (alive) p.sigma[flat] = sg;
+    } else {
+        p.sigma[flat] = 10.0f;
+    }
+    const float* tab = p.adain + (size_t)frame * p.adain_stride;
+    const int W2 = m.layers_width / 2;
+    const int W2pad = round_up(W2, 32);
+    naive_linear(m.head0, h, in, false);
+    for (int j = 0; j < p.W; ++j) {
+        const float y = fmaf(in[j], tab[j], tab[p.Wpad + j]);
+        h[j] = y > 0.f ? y : 0.f;
+    }
+    naive_linear(m.head3, h, in, false);
+    for (int j = 0; j < W2; ++j) {
+        const float y = fmaf(in[j], tab[2 * p.Wpad + j], tab[2 * p.Wpad + W2pad + j]);
+        h[j] = y > 0.f ? y : 0.f;
+    }
+    naive_linear(m.head6, h, in, false);
+    for (int j = 0; j < p.F; ++j) p.feat[(size_t)idx * p.F + j] = alive ? in[j] : 0.f;
+}
+
+static int g_cu_count = 0;
+
+int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s) {
+    if (max_tiles <= 0) return PR_OK;
+    if (naive) {
+        hipLaunchKernelGGL(k_mlp_naive, dim3(max_tiles), dim3(64), 0, s, p, *raw);
+        PR_LAUNCH_CHECK();
+        return PR_OK;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        int dev = 0;
+        PR_CHECK_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_cu_count = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int grid = max_tiles < g_cu_count ? max_tiles : g_cu_count;
+    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// Fills the layer tables of MlpParams from the packed buffer.
+int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
+                     MlpParams* p) {
+    p->kind = m.kind;
+    p->has_bender = m.has_bender;
+    p->b_count = 0;
+    if (m.has_bender) {
+        p->b_octaves = m.bender_octaves;
+        p->benc = d.benc;
+        p->bin_pad = d.bin_pad;
+        p->D = m.deformation_features;
+        for (int k = 0; k < PR_MAX_OCTAVES; ++k) p->b_weights[k] = m.bender_octave_weights[k];
+        p->b_count = m.bender_count;
+        p->BW = d.BW;
+        p->BWpad = d.BWpad;
+        p->b_out = base + l.b_out_off;
+        for (int j = 0; j < m.bender_count; ++j) {
+            Layer& L = p->b_layers[j];
+            memset(&L, 0, sizeof(L));
+            L.nblk = d.BWpad / 32;
+            L.n_real = d.BW;
+            L.bias = base + l.b_bias_off[j];
+            L.epi = EPI_RELU;
+            L.nseg = 1;
+            if (j == 0) {
+                L.seg[0] = Seg{base + l.b_seg_off[j][0], d.bin_pad / 8, 1};
+            } else {
+                L.seg[0] = Seg{base + l.b_seg_off[j][0], d.BWpad / 8, 0};
+                if (j == m.bender_skip) {
+                    L.seg[1] = Seg{base + l.b_seg_off[j][1], d.bin_pad / 8, 1};
+                    L.nseg = 2;
+                }
+            }
+        }
+    }
+    p->octaves = m.octaves;
+    p->din = d.din;
+    p->enc = d.enc;
+    p->enc_pad = d.enc_pad;
+    p->W = d.W;
+    p->Wpad = d.Wpad;
+    p->F = d.F;
+    p->n_backbone = m.backbone_count;
+    p->n_layers = m.backbone_count + 3;
+    for (int i = 0; i < m.backbone_count; ++i) {
+        Layer& L = p->layers[i];
+        memset(&L, 0, sizeof(L));
+        L.nblk = d.Wpad / 32;
+        L.n_real = d.W;
+        L.bias = base + l.n_bias_off[i];
+        L.epi = EPI_RELU;
+        L.nseg = 1;
+        if (i == 0) {
+            L.seg[0] = Seg{base + l.n_seg_off[i][0], d.enc_pad / 8, 1};
+        } else {
+            L.seg[0] = Seg{base + l.n_seg_off[i][0], d.Wpad / 8, 0};
+            if (i == m.skip_layer_idx) {
+                L.seg[1] = Seg{base + l.n_seg_off[i][1], d.enc_pad / 8, 1};
+                L.nseg = 2;
+            }
+        }
+    }
+    p->sigma_w = base + l.sigma_off;
+    Layer& h0 = p->layers[m.backbone_count];
+    memset(&h0, 0, sizeof(h0));
+    h0.seg[0] = Seg{base + l.h0_off, d.Wpad / 8, 0};
+    h0.nseg = 1;
+    h0.nblk = d.Wpad / 32;
+    h0.n_real = d.W;
+    h0.epi = EPI_ADAIN_RELU;
+    h0.adain_off = 0;
+    Layer& h3 = p->layers[m.backbone_count + 1];
+    memset(&h3, 0, sizeof(h3));
+    h3.seg[0] = Seg{base + l.h3_off, d.Wpad / 8, 0};
+    h3.nseg = 1;
+    h3.nblk = d.W2pad / 32;
+    h3.n_real = d.W2;
+    h3.epi = EPI_ADAIN_RELU;
+    h3.adain_off = 2 * d.Wpad;
+    Layer& h6 = p->layers[m.backbone_count + 2];
+    memset(&h6, 0, sizeof(h6));
+    h6.seg[0] = Seg{base + l.h6_off, d.W2pad / 8, 0};
+    h6.nseg = 1;
+    h6.nblk = d.Fpad / 32;
+    h6.n_real = d.F;
+    h6.bias = base + l.h6_bias_off;
+    h6.epi = EPI_FEATURES;
+    return PR_OK;
+}
+
+}  // namespace pr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int pr_packed_size(const pr_object_model_t* model, size_t* bytes) {
+    PR_REQUIRE(model && bytes, "pr_packed_size: NULL argument");
+    pr::ModelDims d;
+    pr::PackedLayout l;
+    PR_TRY(pr::compute_dims(*model, &d));
+    PR_TRY(pr::compute_layout(*model, d, &l));
+    *bytes = (size_t)l.total * sizeof(float);
+    return PR_OK;
+}
+
+extern "C" int pr_pack_model(const pr_object_model_t* model, void* packed, size_t packed_bytes, void* stream) {
+    PR_REQUIRE(model && packed, "pr_pack_model: NULL argument");
+    PR_REQUIRE(((uintptr_t)packed & 15) == 0, "pr_pack_model: packed buffer must be 16-byte aligned");
+    pr::ModelDims d;
+    pr::PackedLayout l;
+    PR_TRY(pr::compute_dims(*model, &d));
+    PR_TRY(pr::compute_layout(*model, d, &l));
+    PR_REQUIRE(packed_bytes >= (size_t)l.total * sizeof(float), "pr_pack_model: buffer too small (%zu < %zu)",
+               packed_bytes, (size_t)l.total * sizeof(float));
+    pr::PackJobs jobs;
+    PR_TRY(pr::build_pack_jobs(*model, d, l, static_cast<float*>(packed), &jobs));
+    hipLaunchKernelGGL(pr::k_pack, dim3(64, jobs.n), dim3(256), 0, (hipStream_t)stream, jobs);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}

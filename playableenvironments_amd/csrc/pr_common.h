@@ -1,0 +1,277 @@
+// Internal declarations shared by the libplayrender translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "playrender.h"
+
+namespace pr {
+
+// ---------------------------------------------------------------------------------------------
+// Errors
+// ---------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define PR_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            pr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PR_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define PR_REQUIRE(cond, ...)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            pr::set_error(__VA_ARGS__);                                                 \
+            return PR_ERR_INVALID;                                                      \
+        }                                                                               \
+    } while (0)
+
+#define PR_LAUNCH_CHECK() PR_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of the MLP tiling
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_M = 64;        // samples per workgroup tile
+constexpr int MLP_WAVES = 8;      // 512 threads
+constexpr int MLP_THREADS = MLP_WAVES * 64;
+constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
+constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
+constexpr int MAX_ENC = 128;      // padded encoding width limit
+constexpr int LDE = MAX_ENC + 4;
+
+__host__ __device__ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// A K-segment of a layer: packed weights [nblk][kq][64 lanes][4] (see pack kernels).
+struct Seg {
+    const float* w;     // packed, device
+    int kq;             // K_pad / 8
+    int src;            // 0 = activation buffer X, 1 = encoding buffer E
+};
+
+enum Epilogue { EPI_RELU = 0, EPI_ADAIN_RELU = 1, EPI_FEATURES = 2 };
+
+struct Layer {
+    Seg seg[2];
+    int nseg;
+    const float* bias;  // padded to nblk*32, device (NULL = no bias)
+    int nblk;           // padded out features / 32
+    int epi;
+    int adain_off;      // offset (floats) of [g | b] of this layer inside one AdaIN table row
+    int n_real;         // real out features
+};
+
+// Offsets (in floats) inside the packed buffer of one model.
+struct PackedLayout {
+    // bender
+    int b_seg_off[PR_MAX_LAYERS][2];
+    int b_bias_off[PR_MAX_LAYERS];
+    int b_out_off;                     // raw copy (3, BWpad)
+    // nerf backbone
+    int n_seg_off[PR_MAX_LAYERS][2];
+    int n_bias_off[PR_MAX_LAYERS];
+    int sigma_off;                     // raw copy (Wpad) + bias at [Wpad]
+    int h0_off, h3_off, h6_off, h6_bias_off;
+    // AdaIN affine (raw copies): affine1 W (2W x S) + b (2W), bn1 mean/var ...
+    int total;
+};
+
+struct ModelDims {
+    int enc;        // real NeRF encoding size  (din + 2*din*octaves)
+    int enc_pad;    // multiple of 8
+    int din;        // 3 (AdaIN) or 6 (skybox)
+    int W, Wpad;    // backbone width
+    int W2, W2pad;  // W / 2
+    int F, Fpad;
+    int benc;       // bender PE size (3 + 6*boct)
+    int bin, bin_pad; // bender input = benc + D
+    int BW, BWpad;
+};
+
+int compute_dims(const pr_object_model_t& m, ModelDims* d);
+int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout* l);
+
+// Kernel parameters of the fused per-object MLP (passed by value).
+struct MlpParams {
+    // compact sample records
+    const float* rec_pos;      // (cap, 3) object-frame positions ; unused for skybox
+    const int32_t* rec_flat;   // (cap) flat sample index n*R*P + r*P + i
+    const int32_t* total;      // device scalar: number of records
+    int samples_per_frame;     // R * P
+    int positions;             // P
+    int rays;                  // R
+    // object
+    int kind;
+    int has_bender;
+    int canonical;
+    float lo[3], hi[3], size[3];
+    float empty_alpha;
+    // skybox inputs
+    const float* ray_directions; // (N,R,3)
+    const float* ray_origins;    // (N,3)
+    const float* w2o;            // (N,K,3,4) base already offset to this object; stride below
+    int w2o_stride;              // floats between frames (K*12)
+    // bender
+    int b_octaves, benc, bin_pad, D;
+    float b_weights[PR_MAX_OCTAVES];
+    const float* deformation;    // base offset to object k
+    int deformation_stride;      // floats between frames (K*D)
+    Layer b_layers[PR_MAX_LAYERS];
+    int b_count;
+    const float* b_out;          // raw (3, BWpad)
+    int BW, BWpad;
+    // nerf
+    int octaves, din, enc, enc_pad;
+    Layer layers[PR_MAX_LAYERS + 3];
+    int n_layers;                // backbone + 3 head layers
+    int n_backbone;
+    const float* sigma_w;        // (Wpad) + bias
+    int W, Wpad;
+    const float* adain;          // table base for this object; row = frame
+    int adain_stride;            // floats between frames
+    int F;
+    // outputs
+    float* sigma;                // dense (N,R,P)
+    float* dispmag;              // dense (N,R,P) or NULL
+    float* feat;                 // compact (cap, F)
+};
+
+// AdaIN table row layout for one (frame, object): g1[Wpad] b1[Wpad] g2[W2pad] b2[W2pad]
+static inline int adain_row_floats(const ModelDims& d) { return 2 * d.Wpad + 2 * d.W2pad; }
+
+// ---------------------------------------------------------------------------------------------
+// Stage launchers (each enqueues on `stream`, returns pr_status)
+// ---------------------------------------------------------------------------------------------
+struct PlaceParams {
+    int frames, rays, positions, objects, object_index;
+    const float* ray_origins;     // (N,3)
+    const float* ray_directions;  // (N,R,3)
+    const float* w2o;             // (N,K,3,4)
+    const uint8_t* in_scene;      // (N,K)
+    float lo[3], hi[3];
+    float z_near_min, z_far_max, empty_alpha;
+    const float* linspace;        // (P)
+    const float* jitter;          // (N,R,P) or NULL
+    float* t;                     // (N,R,P) out
+    float* sigma;                 // (N,R,P) out, filled with empty_alpha
+    float* dispmag;               // (N,R,P) out zeros or NULL
+    int32_t* block_sums;          // (ceil(N*R/256)) in-box counts per block of 256 rays
+};
+int launch_place_coarse(const PlaceParams& p, hipStream_t s);
+
+struct FillParams {
+    int frames, rays, positions, objects, object_index;
+    const float* ray_origins;
+    const float* ray_directions;
+    const float* w2o;
+    const uint8_t* in_scene;
+    float lo[3], hi[3];
+    const float* t;               // (N,R,P)
+    const int32_t* block_offsets; // exclusive scan of block_sums
+    float* rec_pos;               // (cap,3)
+    int32_t* rec_flat;            // (cap)
+    int32_t* slot;                // (N,R,P) compact row or -1
+};
+int launch_fill(const FillParams& p, hipStream_t s);
+
+// exclusive scan of n block sums (single workgroup), writes total to *total
+int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hipStream_t s);
+
+struct ResampleParams {
+    int frames, rays, objects, object_index;
+    int pc, pf;
+    const float* ray_origins;
+    const float* ray_directions;
+    const float* w2o;
+    const uint8_t* in_scene;
+    float lo[3], hi[3];
+    float empty_alpha;
+    const float* t_coarse;        // (N,R,Pc)
+    const float* sigma_coarse;    // (N,R,Pc)
+    const float* alpha_noise;     // (N,R,Pc) or NULL
+    const float* u_fixed;         // linspace(0,1,Pf) (Pf)
+    const float* u_random;        // (N,R,Pf) or NULL
+    float* t_fine;                // (N,R,Pc+Pf) out
+    float* sigma_fine;            // (N,R,Pc+Pf) out, filled with empty_alpha
+    float* dispmag_fine;          // or NULL
+    int32_t* block_sums;
+};
+int launch_resample(const ResampleParams& p, hipStream_t s);
+
+struct FoldParams {
+    int frames, objects, object_index;
+    const float* style;           // (N,K,S)
+    int S;
+    pr_linear_t affine1; const float* bn1_mean; const float* bn1_var;
+    pr_linear_t affine4; const float* bn4_mean; const float* bn4_var;
+    float eps;
+    int W, Wpad, W2, W2pad;
+    float* table;                 // (N, row) rows of this object
+    int row_floats;
+};
+int launch_adain_fold(const FoldParams& p, hipStream_t s);
+
+int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s);
+
+struct CompositeObject {
+    const float* t;
+    const float* sigma;
+    const int32_t* slot;
+    const float* dispmag;   // or NULL
+    const float* feat;      // compact rows
+    const float* noise;     // integrate noise (N,R,P) or NULL
+    int positions;
+    pr_entry_t out;
+};
+struct CompositeParams {
+    int frames, rays, objects, static_objects, F;
+    int fix_overlaps;
+    int total_positions;         // sum P_k
+    int sort_size;               // next pow2 >= total_positions
+    const float* ray_directions; // (N,R,3) world
+    const float* noise_global;   // (N,R,sumP) or NULL
+    CompositeObject obj[PR_MAX_OBJECTS];
+    pr_entry_t global;
+};
+int launch_composite(const CompositeParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+// torch.min / torch.max / clamp propagate NaN; fminf/fmaxf do not.
+__device__ __forceinline__ float nan_min(float a, float b) { return (a < b || a != a) ? a : b; }
+__device__ __forceinline__ float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ float nan_clamp(float v, float lo, float hi) {
+    // torch.clamp(v, min=lo, max=hi) = min(max(v, lo), hi), NaN stays NaN
+    float r = (v < lo) ? lo : v;
+    r = (r > hi) ? hi : r;
+    return r;
+}
+
+// Object-frame ray of (frame, ray) exactly as RayHelper.transform_rays computes it:
+// sum_j p_j * M[i][j] evaluated as ((p0*m0 + p1*m1) + p2*m2) (+ m3)   (ray_helper.py:1195-1199)
+struct ObjRay { float o[3]; float d[3]; };
+__device__ __forceinline__ ObjRay object_ray(const float* __restrict__ m /*3x4*/, const float* __restrict__ o,
+                                            const float* __restrict__ d) {
+    ObjRay r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float m0 = m[i * 4 + 0], m1 = m[i * 4 + 1], m2 = m[i * 4 + 2], m3 = m[i * 4 + 3];
+        r.o[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(o[0], m0), __fmul_rn(o[1], m1)), __fmul_rn(o[2], m2)), m3);
+        r.d[i] = __fadd_rn(__fadd_rn(__fmul_rn(d[0], m0), __fmul_rn(d[1], m1)), __fmul_rn(d[2], m2));
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool in_box(const float x, const float y, const float z, const float* lo, const float* hi) {
+    return x >= lo[0] && x <= hi[0] && y >= lo[1] && y <= hi[1] && z >= lo[2] && z <= hi[2];
+}
+#endif
+
+}  // namespace pr

@@ -1,0 +1,341 @@
+// Host orchestration of one renderer call (the body of ObjectComposer.forward,
+// model/object_composer.py:786-892) and the small introspection entry points of the C ABI.
+#include "pr_common.h"
+
+#include <stdarg.h>
+
+namespace pr {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
+                     MlpParams* p);
+
+#define PR_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != PR_OK) return _r;  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Workspace plan
+// ---------------------------------------------------------------------------------------------
+struct TypePlan {
+    size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
+    size_t adain[PR_MAX_OBJECTS];
+    size_t feat[PR_MAX_OBJECTS];
+    int positions[PR_MAX_OBJECTS];
+    size_t totals;  // K ints
+};
+struct Plan {
+    TypePlan type[2];
+    size_t block_sums, block_offsets;
+    size_t rec_pos, rec_flat;
+    size_t bytes;
+    int nblocks256;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int validate_call(const pr_call_t& c, const pr_object_t* objs) {
+    PR_REQUIRE(c.frames > 0 && c.rays > 0, "empty call: %d frames x %d rays", c.frames, c.rays);
+    PR_REQUIRE(c.objects >= 1 && c.objects <= PR_MAX_OBJECTS, "objects %d out of range 1..%d", c.objects, PR_MAX_OBJECTS);
+    PR_REQUIRE(c.static_objects >= 0 && c.static_objects <= c.objects, "static_objects %d out of range", c.static_objects);
+    PR_REQUIRE((long)c.frames * c.rays < (1L << 31), "too many rays in one call");
+    PR_REQUIRE(c.ray_origins && c.ray_directions && c.w2o && c.style && c.deformation && c.object_in_scene,
+               "NULL input pointer");
+    for (int k = 0; k < c.objects; ++k) {
+        const pr_object_model_t& m = objs[k].coarse;
+        PR_REQUIRE(m.positions >= 1, "object %d: positions_count_coarse %d", k, m.positions);
+        PR_REQUIRE(c.linspace_coarse[k] != nullptr, "object %d: linspace_coarse missing", k);
+        PR_REQUIRE(objs[k].packed_coarse != nullptr, "object %d: packed coarse weights missing", k);
+        PR_REQUIRE((long)c.frames * c.rays * (long)m.positions < (1L << 31), "too many samples in one call");
+        if (c.use_fine) {
+            PR_REQUIRE(c.positions_fine[k] >= 1, "object %d: positions_count_fine %d", k, c.positions_fine[k]);
+            PR_REQUIRE(objs[k].fine.positions == m.positions + c.positions_fine[k],
+                       "object %d: fine model positions %d != %d + %d", k, objs[k].fine.positions, m.positions,
+                       c.positions_fine[k]);
+            PR_REQUIRE(objs[k].packed_fine != nullptr, "object %d: packed fine weights missing", k);
+            PR_REQUIRE(c.linspace_fine[k] != nullptr || c.noise_coarse.pdf[k] != nullptr,
+                       "object %d: linspace_fine missing", k);
+            PR_REQUIRE((long)c.frames * c.rays * (long)objs[k].fine.positions < (1L << 31), "too many samples in one call");
+        }
+    }
+    if (c.flags & PR_FLAG_FIX_OVERLAPS) {
+        for (int t = 0; t < (c.use_fine ? 2 : 1); ++t)
+            for (int s = 0; s < c.static_objects; ++s)
+                for (int d = c.static_objects; d < c.objects; ++d) {
+                    const int ps = t ? objs[s].fine.positions : objs[s].coarse.positions;
+                    const int pd = t ? objs[d].fine.positions : objs[d].coarse.positions;
+                    // the reference indexes the dynamic list with the static P - 1 (object_composer.py:322)
+                    PR_REQUIRE(ps <= pd, "overlap fix: static object %d has more positions (%d) than dynamic object %d (%d); "
+                               "the reference raises IndexError here", s, ps, d, pd);
+                }
+    }
+    return PR_OK;
+}
+
+static int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
+    memset(plan, 0, sizeof(*plan));
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align_up(bytes);
+        return at;
+    };
+    const size_t nr = (size_t)c.frames * c.rays;
+    plan->nblocks256 = (int)((nr + 255) / 256);
+    plan->block_sums = take(sizeof(int32_t) * plan->nblocks256);
+    plan->block_offsets = take(sizeof(int32_t) * plan->nblocks256);
+    size_t max_cap = 0;
+    size_t feat_bytes[2] = {0, 0};
+    const int ntypes = c.use_fine ? 2 : 1;
+    for (int t = 0; t < ntypes; ++t) {
+        TypePlan& tp = plan->type[t];
+        tp.totals = take(sizeof(int32_t) * PR_MAX_OBJECTS);
+        for (int k = 0; k < c.objects; ++k) {
+            const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+            ModelDims d;
+            PR_TRY(compute_dims(m, &d));
+            tp.positions[k] = m.positions;
+            const size_t cap = nr * m.positions;
+            if (cap > max_cap) max_cap = cap;
+            tp.t[k] = take(sizeof(float) * cap);
+            tp.sigma[k] = take(sizeof(float) * cap);
+            tp.slot[k] = take(sizeof(int32_t) * cap);
+            tp.dispmag[k] = m.has_bender ? take(sizeof(float) * cap) : (size_t)-1;
+            tp.adain[k] = take(sizeof(float) * (size_t)c.frames * adain_row_floats(d));
+            tp.feat[k] = feat_bytes[t];  // relative to the feature arena
+            feat_bytes[t] += align_up(sizeof(float) * cap * m.output_features);
+        }
+    }
+    plan->rec_pos = take(sizeof(float) * 3 * max_cap);
+    plan->rec_flat = take(sizeof(int32_t) * max_cap);
+    // coarse and fine feature rows share one arena: the coarse rows are dead once the coarse
+    // compositing pass has run, before the first fine MLP is launched.
+    const size_t arena = take(feat_bytes[0] > feat_bytes[1] ? feat_bytes[0] : feat_bytes[1]);
+    for (int t = 0; t < ntypes; ++t)
+        for (int k = 0; k < c.objects; ++k) plan->type[t].feat[k] += arena;
+    plan->bytes = off;
+    return PR_OK;
+}
+
+static void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size) {
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = m.bbox[2 * a];
+        hi[a] = m.bbox[2 * a + 1];
+        if (size) size[a] = m.bbox[2 * a + 1] - m.bbox[2 * a];   // BoundingBox.get_size, fp32 subtraction
+    }
+}
+
+static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_t* outs[2], char* ws, const Plan& plan,
+                  hipStream_t s) {
+    const int ntypes = c.use_fine ? 2 : 1;
+    const int K = c.objects;
+    int32_t* block_sums = reinterpret_cast<int32_t*>(ws + plan.block_sums);
+    int32_t* block_offsets = reinterpret_cast<int32_t*>(ws + plan.block_offsets);
+    float* rec_pos = reinterpret_cast<float*>(ws + plan.rec_pos);
+    int32_t* rec_flat = reinterpret_cast<int32_t*>(ws + plan.rec_flat);
+    const bool naive = (c.flags & PR_FLAG_NAIVE_MLP) != 0;
+
+    for (int t = 0; t < ntypes; ++t) {
+        const TypePlan& tp = plan.type[t];
+        int32_t* totals = reinterpret_cast<int32_t*>(ws + tp.totals);
+        const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
+        int total_positions = 0;
+        for (int k = 0; k < K; ++k) {
+            const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+            const float* packed = static_cast<const float*>(t ? objs[k].packed_fine : objs[k].packed_coarse);
+            ModelDims d;
+            PackedLayout l;
+            PR_TRY(compute_dims(m, &d));
+            PR_TRY(compute_layout(m, d, &l));
+            const int P = m.positions;
+            total_positions += P;
+            float* t_arr = reinterpret_cast<float*>(ws + tp.t[k]);
+            float* sigma = reinterpret_cast<float*>(ws + tp.sigma[k]);
+            int32_t* slot = reinterpret_cast<int32_t*>(ws + tp.slot[k]);
+            float* dispmag = m.has_bender ? reinterpret_cast<float*>(ws + tp.dispmag[k]) : nullptr;
+            float* feat = reinterpret_cast<float*>(ws + tp.feat[k]);
+            float* adain = reinterpret_cast<float*>(ws + tp.adain[k]);
+
+            // ---- sample placement --------------------------------------------------------------
+            if (t == 0) {
+                PlaceParams pp;
+                memset(&pp, 0, sizeof(pp));
+                pp.frames = c.frames; pp.rays = c.rays; pp.positions = P; pp.objects = K; pp.object_index = k;
+                pp.ray_origins = c.ray_origins; pp.ray_directions = c.ray_directions; pp.w2o = c.w2o;
+                pp.in_scene = c.object_in_scene;
+                bbox_split(m, pp.lo, pp.hi, nullptr);
+                pp.z_near_min = m.z_near_min; pp.z_far_max = m.z_far_max; pp.empty_alpha = m.empty_space_alpha;
+                pp.linspace = c.linspace_coarse[k];
+                pp.jitter = c.noise_coarse.jitter[k];
+                pp.t = t_arr; pp.sigma = sigma; pp.dispmag = dispmag; pp.block_sums = block_sums;
+                PR_TRY(launch_place_coarse(pp, s));
+            } else {
+                const TypePlan& cp = plan.type[0];
+                ResampleParams rp;
+                memset(&rp, 0, sizeof(rp));
+                rp.frames = c.frames; rp.rays = c.rays; rp.objects = K; rp.object_index = k;
+                rp.pc = objs[k].coarse.positions; rp.pf = c.positions_fine[k];
+                rp.ray_origins = c.ray_origins; rp.ray_directions = c.ray_directions; rp.w2o = c.w2o;
+                rp.in_scene = c.object_in_scene;
+                bbox_split(m, rp.lo, rp.hi, nullptr);
+                rp.empty_alpha = m.empty_space_alpha;
+                rp.t_coarse = reinterpret_cast<const float*>(ws + cp.t[k]);
+                rp.sigma_coarse = reinterpret_cast<const float*>(ws + cp.sigma[k]);
+                rp.alpha_noise = c.noise_coarse.alpha[k];
+                rp.u_fixed = c.linspace_fine[k];
+                rp.u_random = c.noise_coarse.pdf[k];
+                rp.t_fine = t_arr; rp.sigma_fine = sigma; rp.dispmag_fine = dispmag; rp.block_sums = block_sums;
+                PR_TRY(launch_resample(rp, s));
+            }
+            PR_TRY(launch_scan(block_sums, block_offsets, totals + k, plan.nblocks256, s));
+
+            // ---- compaction --------------------------------------------------------------------
+            FillParams fp;
+            memset(&fp, 0, sizeof(fp));
+            fp.frames = c.frames; fp.rays = c.rays; fp.positions = P; fp.objects = K; fp.object_index = k;
+            fp.ray_origins = c.ray_origins; fp.ray_directions = c.ray_directions; fp.w2o = c.w2o;
+            fp.in_scene = c.object_in_scene;
+            bbox_split(m, fp.lo, fp.hi, nullptr);
+            fp.t = t_arr; fp.block_offsets = block_offsets; fp.rec_pos = rec_pos; fp.rec_flat = rec_flat; fp.slot = slot;
+            PR_TRY(launch_fill(fp, s));
+
+            // ---- style affine + eval BatchNorm fold -------------------------------------------
+            FoldParams fo;
+            memset(&fo, 0, sizeof(fo));
+            fo.frames = c.frames; fo.objects = K; fo.object_index = k;
+            fo.style = c.style; fo.S = m.style_features;
+            fo.affine1 = m.affine1; fo.bn1_mean = m.bn1_mean; fo.bn1_var = m.bn1_var;
+            fo.affine4 = m.affine4; fo.bn4_mean = m.bn4_mean; fo.bn4_var = m.bn4_var;
+            fo.eps = m.bn_eps;
+            fo.W = d.W; fo.Wpad = d.Wpad; fo.W2 = d.W2; fo.W2pad = d.W2pad;
+            fo.table = adain; fo.row_floats = adain_row_floats(d);
+            PR_TRY(launch_adain_fold(fo, s));
+
+            // ---- fused MLP ---------------------------------------------------------------------
+            MlpParams mp;
+            memset(&mp, 0, sizeof(mp));
+            PR_TRY(build_mlp_layers(m, d, l, packed, &mp));
+            mp.rec_pos = rec_pos; mp.rec_flat = rec_flat; mp.total = totals + k;
+            mp.samples_per_frame = c.rays * P; mp.positions = P; mp.rays = c.rays;
+            mp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+            bbox_split(m, mp.lo, mp.hi, mp.size);
+            mp.empty_alpha = m.empty_space_alpha;
+            mp.ray_directions = c.ray_directions; mp.ray_origins = c.ray_origins;
+            mp.w2o = c.w2o + (size_t)k * 12; mp.w2o_stride = K * 12;
+            mp.deformation = c.deformation + (size_t)k * m.deformation_features;
+            mp.deformation_stride = K * m.deformation_features;
+            mp.adain = adain; mp.adain_stride = fo.row_floats;
+            mp.sigma = sigma; mp.dispmag = dispmag; mp.feat = feat;
+            const size_t cap = (size_t)c.frames * c.rays * P;
+            const int max_tiles = (int)((cap + (naive ? 63 : TILE_M - 1)) / (naive ? 64 : TILE_M));
+            PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
+        }
+
+        // ---- compositing ------------------------------------------------------------------------
+        const pr_outputs_t* out = outs[t];
+        CompositeParams cp;
+        memset(&cp, 0, sizeof(cp));
+        cp.frames = c.frames; cp.rays = c.rays; cp.objects = K; cp.static_objects = c.static_objects;
+        cp.F = objs[0].coarse.output_features;
+        cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
+        cp.total_positions = total_positions;
+        int ss = 64;
+        while (ss < total_positions) ss <<= 1;
+        cp.sort_size = ss;
+        cp.ray_directions = c.ray_directions;
+        cp.noise_global = noise.integrate_global;
+        for (int k = 0; k < K; ++k) {
+            const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+            PR_REQUIRE(m.output_features == cp.F, "all objects must share output_features");
+            CompositeObject& o = cp.obj[k];
+            o.t = reinterpret_cast<const float*>(ws + tp.t[k]);
+            o.sigma = reinterpret_cast<const float*>(ws + tp.sigma[k]);
+            o.slot = reinterpret_cast<const int32_t*>(ws + tp.slot[k]);
+            o.dispmag = m.has_bender ? reinterpret_cast<const float*>(ws + tp.dispmag[k]) : nullptr;
+            o.feat = reinterpret_cast<const float*>(ws + tp.feat[k]);
+            o.noise = noise.integrate[k];
+            o.positions = m.positions;
+            if (out) o.out = out->object[k];
+        }
+        if (out) cp.global = out->global;
+        PR_TRY(launch_composite(cp, s));
+
+        // ---- optional exports -------------------------------------------------------------------
+        if (out) {
+            for (int k = 0; k < K; ++k) {
+                const size_t cap = (size_t)c.frames * c.rays * tp.positions[k];
+                if (out->sample_t[k])
+                    PR_CHECK_HIP(hipMemcpyAsync(out->sample_t[k], ws + tp.t[k], sizeof(float) * cap, hipMemcpyDeviceToDevice, s));
+                if (out->sample_sigma[k])
+                    PR_CHECK_HIP(hipMemcpyAsync(out->sample_sigma[k], ws + tp.sigma[k], sizeof(float) * cap, hipMemcpyDeviceToDevice, s));
+                if (out->sample_slot[k])
+                    PR_CHECK_HIP(hipMemcpyAsync(out->sample_slot[k], ws + tp.slot[k], sizeof(int32_t) * cap, hipMemcpyDeviceToDevice, s));
+            }
+            if (out->evaluated_samples)
+                PR_CHECK_HIP(hipMemcpyAsync(out->evaluated_samples, totals, sizeof(int32_t) * K, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    return PR_OK;
+}
+
+}  // namespace pr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int pr_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes) {
+    PR_REQUIRE(call && objects && bytes, "pr_workspace_size: NULL argument");
+    PR_TRY(pr::validate_call(*call, objects));
+    pr::Plan plan;
+    PR_TRY(pr::make_plan(*call, objects, &plan));
+    *bytes = plan.bytes;
+    return PR_OK;
+}
+
+extern "C" int pr_render_forward(const pr_call_t* call, const pr_object_t* objects, const pr_outputs_t* coarse,
+                                 const pr_outputs_t* fine, void* workspace, size_t workspace_bytes, void* stream) {
+    PR_REQUIRE(call && objects && workspace, "pr_render_forward: NULL argument");
+    PR_TRY(pr::validate_call(*call, objects));
+    pr::Plan plan;
+    PR_TRY(pr::make_plan(*call, objects, &plan));
+    if (workspace_bytes < plan.bytes) {
+        pr::set_error("workspace too small: %zu bytes given, %zu needed", workspace_bytes, plan.bytes);
+        return PR_ERR_WORKSPACE;
+    }
+    PR_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    const pr_outputs_t* outs[2] = {coarse, fine};
+    return pr::render(*call, objects, outs, static_cast<char*>(workspace), plan, (hipStream_t)stream);
+}
+
+extern "C" int pr_abi_version(void) { return PR_ABI_VERSION; }
+
+extern "C" const char* pr_last_error(void) { return pr::g_error; }
+
+extern "C" int pr_device_info(int32_t* compute_units, int32_t* lds_bytes, char* arch_name, size_t arch_name_len) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        pr::set_error("no HIP device visible");
+        return PR_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (arch_name && arch_name_len) {
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return PR_OK;
+}

@@ -1,0 +1,237 @@
+"""Parameter containers of the object models, ``state_dict``-compatible with the reference.
+
+These modules own the ``nn.Parameter`` / buffer storages under exactly the names the reference
+uses (``object_models_coarse.2.nerf_model.backbone_layers.4.weight``,
+``...features_head.1.ada_in.normalization.running_mean``, ``ray_bender.positional_encoder.current_step``
+...), so reference checkpoints load with ``load_state_dict`` and the trainers'
+``model.parameters()`` see the same tensors.  They deliberately have NO ``forward``: all arithmetic
+of these networks runs in the fused HIP kernel (csrc/mlp.hip), which reads the parameter storages
+in place.  Initialisation follows the reference constructors (cited per class).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+
+class BoundingBox(nn.Module):
+    """Axis-aligned box, ``dimensions`` (3, 2) non-persistent buffer (utils/lib_3d/bounding_box.py:10-21)."""
+
+    def __init__(self, dimensions):
+        super().__init__()
+        if len(dimensions) != 3:
+            raise Exception(f"Dimenions should have dimension 3, but dimension ({len(dimensions)}) was passed")
+        self.register_buffer("dimensions", torch.as_tensor(dimensions, dtype=torch.float32), persistent=False)
+
+    def get_size(self) -> torch.Tensor:
+        return self.dimensions[:, 1] - self.dimensions[:, 0]
+
+    def get_corner_points(self) -> torch.Tensor:
+        """(8, 3) corners in the reference's order (bounding_box.py:58-98): 0 = all-low, 6 = all-high."""
+        lo, hi = self.dimensions[:, 0], self.dimensions[:, 1]
+        pick = [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)]
+        both = torch.stack([lo, hi], 0)
+        return torch.stack([torch.stack([both[p[a], a] for a in range(3)]) for p in pick], 0)
+
+    def get_edge_points(self, points_per_edge: int = 5) -> torch.Tensor:
+        """Corners + ``points_per_edge`` interior points on each of the 12 edges (bounding_box.py:100-131)."""
+        edges = [0, 1, 1, 2, 2, 3, 3, 0, 4, 5, 5, 6, 6, 7, 7, 4, 0, 4, 1, 5, 2, 6, 3, 7]
+        corners = self.get_corner_points()
+        ends = corners[torch.as_tensor(edges, device=corners.device)].reshape(12, 2, 3)
+        frac = torch.linspace(0.0, 1.0, points_per_edge + 2, device=corners.device)[1:-1]
+        pts = ends[:, 0].unsqueeze(-1) + (ends[:, 1] - ends[:, 0]).unsqueeze(-1) * frac
+        pts = pts.transpose(1, 2).reshape(-1, 3)
+        return torch.cat([corners, pts], dim=0)
+
+
+class _Normalization(nn.Module):
+    """``ada_in`` level: holds ``normalization`` = BatchNorm1d(affine=False) (model/layers/adain.py:44-47)."""
+
+    def __init__(self, features: int):
+        super().__init__()
+        self.normalization = nn.BatchNorm1d(features, affine=False)
+
+
+class AffineTransformAdaIn(nn.Module):
+    """Style affine + AdaIN statistics (model/layers/adain.py:5-19): scale biased to 1, bias to 0."""
+
+    def __init__(self, in_features: int, style_features_count: int):
+        super().__init__()
+        self.style_features_count = style_features_count
+        self.affine_transform = nn.Linear(style_features_count, 2 * in_features)
+        self.ada_in = _Normalization(in_features)
+        self.affine_transform.bias.data[:in_features] = 1
+        self.affine_transform.bias.data[in_features:] = 0
+
+
+class _Placeholder(nn.Module):
+    """Parameter-free slot (the ReLUs of the reference's AdaInSequential) that keeps the indices."""
+
+
+def _features_head(width: int, style: int, out: int) -> nn.Sequential:
+    # indices 0,1,3,4,6 carry parameters (model/nerf_models/adain_style_nerf_model.py:57-71)
+    return nn.Sequential(
+        nn.Linear(width, width, bias=False),
+        AffineTransformAdaIn(width, style),
+        _Placeholder(),
+        nn.Linear(width, width // 2, bias=False),
+        AffineTransformAdaIn(width // 2, style),
+        _Placeholder(),
+        nn.Linear(width // 2, out),
+    )
+
+
+class AdaInStyleNerfModel(nn.Module):
+    """Weights of model/nerf_models/adain_style_nerf_model.py:14-55 (input: 3-D position)."""
+    input_dimensions = 3
+    kind = 0
+
+    def __init__(self, config: Dict, model_config: Dict):
+        super().__init__()
+        self.model_config = model_config
+        self.layers_width = model_config["layers_width"]
+        self.backbone_layers_count = model_config["backbone_layers_count"]
+        self.output_features = model_config["output_features"]
+        self.skip_layer_idx = model_config["skip_layer_idx"]
+        self.style_features = model_config["style_features"]
+        self.empty_space_alpha = model_config["empty_space_alpha"]
+        if self.skip_layer_idx >= self.backbone_layers_count:
+            raise Exception("Skip layer must refer to a valid backbone layer idx")
+        pe = model_config["position_encoder"]
+        if not pe["append_original"]:
+            raise Exception("position_encoder.append_original=False is not supported by the HIP renderer")
+        self.octaves = pe["octaves"]
+        self.encoding_size = self.input_dimensions * (1 + 2 * self.octaves)
+        self.bounding_box = BoundingBox(model_config["bounding_box"])
+        self.backbone_layers = nn.ModuleList()
+        size = self.encoding_size
+        for idx in range(self.backbone_layers_count):
+            if idx == self.skip_layer_idx:
+                size += self.encoding_size
+            self.backbone_layers.append(nn.Linear(size, self.layers_width))
+            size = self.layers_width
+        if self.kind == 0:
+            self.alpha_head = nn.Linear(self.layers_width, 1)
+        self.features_head = _features_head(self.layers_width, self.style_features, self.output_features)
+
+
+class SkyboxAdaInStyleNerfModelV3(AdaInStyleNerfModel):
+    """Weights of model/nerf_models/skybox_adain_style_nerf_model_v3.py:14-65 (input: origin + unit
+    direction, 6-D; no sigma head, sigma == 10)."""
+    input_dimensions = 6
+    kind = 1
+
+
+class _AnnealableEncoderState(nn.Module):
+    """``positional_encoder`` level of the bender: int32 ``current_step`` buffer
+    (model/annealable_positional_encoder.py:26-44)."""
+
+    def __init__(self, octaves: int, num_steps: int):
+        super().__init__()
+        self.octaves_count = octaves
+        self.num_steps = num_steps
+        self.register_buffer("current_step", torch.zeros((), dtype=torch.int))
+
+    def set_step(self, current_step: int):
+        self.current_step = self.current_step * 0 + current_step
+
+    def annealing_weights(self) -> torch.Tensor:
+        """(1 - cos(pi clamp(step * octaves / num_steps - k, 0, 1))) / 2  (annealable_positional_encoder.py:59-63)."""
+        alpha = self.current_step * self.octaves_count / self.num_steps
+        k = torch.arange(self.octaves_count, dtype=torch.float32, device=self.current_step.device)
+        return (1 - torch.cos(math.pi * torch.clamp(alpha - k, min=0.0, max=1.0))) / 2
+
+
+class PositionalRayBender(nn.Module):
+    """Weights of model/nerf_models/positional_ray_bender_model.py:12-79."""
+    has_weights = True
+
+    def __init__(self, config: Dict, model_config: Dict):
+        super().__init__()
+        self.model_config = model_config
+        self.layers_width = model_config["layers_width"]
+        self.layers_count = model_config["layers_count"]
+        self.skip_layer_idx = model_config["skip_layer_idx"]
+        self.deformation_features = model_config["deformation_features"]
+        pe = model_config["position_encoder"]
+        if not pe["append_original"]:
+            raise Exception("position_encoder.append_original=False is not supported by the HIP renderer")
+        self.positional_encoder = _AnnealableEncoderState(pe["octaves"], pe["num_steps"])
+        self.encoding_size = 3 * (1 + 2 * pe["octaves"])
+        self.bounding_box = BoundingBox(model_config["bounding_box"])
+        self.backbone_layers = nn.ModuleList()
+        size = self.encoding_size + self.deformation_features
+        for idx in range(self.layers_count):
+            if idx == self.skip_layer_idx:
+                size += self.encoding_size + self.deformation_features
+            self.backbone_layers.append(nn.Linear(size, self.layers_width))
+            size = self.layers_width
+        self.output_head = nn.Linear(self.layers_width, 3, bias=False)
+        for layer in self.backbone_layers:
+            torch.nn.init.kaiming_uniform_(layer.weight, a=0, mode="fan_in", nonlinearity="relu")
+            torch.nn.init.zeros_(layer.bias)
+        torch.nn.init.uniform_(self.backbone_layers[-1].weight, a=-1e-5, b=1e-5)
+
+    def set_step(self, current_step: int):
+        self.positional_encoder.set_step(current_step)
+
+
+class ZeroedRayBender(nn.Module):
+    """model/nerf_models/zeroed_ray_bender_model.py:7-37: no parameters, displacement == 0."""
+    has_weights = False
+
+    def __init__(self, config: Dict, model_config: Dict):
+        super().__init__()
+        self.model_config = model_config
+
+    def set_step(self, current_step: int):
+        pass
+
+
+_NERF_CLASSES = {
+    "model.nerf_models.adain_style_nerf_model": AdaInStyleNerfModel,
+    "model.nerf_models.skybox_adain_style_nerf_model_v3": SkyboxAdaInStyleNerfModelV3,
+}
+_BENDER_CLASSES = {
+    "model.nerf_models.positional_ray_bender_model": PositionalRayBender,
+    "model.nerf_models.zeroed_ray_bender_model": ZeroedRayBender,
+}
+
+
+class RayBendingStyleNerfModel(nn.Module):
+    """One object model: NeRF + ray bender + box (model/nerf_models/ray_bending_style_nerf_model.py:12-60).
+
+    The ``architecture`` strings of the reference configs are mapped to the classes above (the
+    reference resolves them with importlib; the dotted names are kept as keys so its YAML works)."""
+
+    def __init__(self, config: Dict, model_config: Dict):
+        super().__init__()
+        self.config = config
+        self.model_config = model_config
+        self.empty_space_alpha = model_config["empty_space_alpha"]
+        self.bounding_box = BoundingBox(model_config["bounding_box"])
+        self.style_features = model_config["style_features"]
+        self.deformation_features = model_config["deformation_features"]
+        self.nerf_model_config = model_config["nerf_model"]
+        self.ray_bender_model_config = model_config["ray_bender_model"]
+        for sub in (self.nerf_model_config, self.ray_bender_model_config):
+            sub["bounding_box"] = model_config["bounding_box"]
+            sub["empty_space_alpha"] = model_config["empty_space_alpha"]
+            sub["style_features"] = model_config["style_features"]
+            sub["deformation_features"] = model_config["deformation_features"]
+        try:
+            nerf_cls = _NERF_CLASSES[self.nerf_model_config["architecture"]]
+            bender_cls = _BENDER_CLASSES[self.ray_bender_model_config["architecture"]]
+        except KeyError as e:
+            raise Exception(f"object model architecture {e} is not supported by the HIP renderer")
+        self.nerf_model = nerf_cls(config, self.nerf_model_config)
+        self.ray_bender = bender_cls(config, self.ray_bender_model_config)
+
+    def set_step(self, current_step: int):
+        self.ray_bender.set_step(current_step)
+
+
+OBJECT_MODEL_CLASSES = {"model.nerf_models.ray_bending_style_nerf_model": RayBendingStyleNerfModel}

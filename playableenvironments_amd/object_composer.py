@@ -1,0 +1,408 @@
+"""Drop-in for the reference's ``ObjectComposer`` running on the HIP renderer.
+
+Same constructor (``ObjectComposer(config)``), same ``forward`` signature and result-dict schema
+as model/object_composer.py:18-57, :786-892 of the reference, same ``state_dict`` keys.  The body
+of ``forward`` marshals raw device pointers into ``pr_render_forward`` (include/playrender.h); all
+arithmetic runs in hand-written gfx950 kernels.  There is no CPU / PyTorch fallback: without the
+built extension or without a GPU tensor the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .modules import OBJECT_MODEL_CLASSES, RayBendingStyleNerfModel
+
+ENTRY_KEYS = ("integrated_features", "opacity", "weights", "depth", "disparity",
+              "integrated_displacements_magnitude", "integrated_divergence")
+
+
+class ObjectIDsHelper:
+    """Object instance <-> model index bookkeeping (model/utils/object_ids_helper.py:4-153): static
+    models first; model m owns ``object_parameters_encoder[m].objects_count`` consecutive instances."""
+
+    def __init__(self, config):
+        self.config = config
+        model = config["model"]
+        self.static_object_models_count = model["static_object_models"]
+        self.object_models_count = len(model["object_models"])
+        self.dynamic_object_models_count = self.object_models_count - self.static_object_models_count
+        self._counts = [int(e["objects_count"]) for e in model["object_parameters_encoder"]]
+        self.model_idx_by_object_idx_map = {}
+        self.first_object_idx_by_model_idx_map = {}
+        idx = 0
+        for m in range(self.object_models_count):
+            self.first_object_idx_by_model_idx_map[m] = idx
+            for _ in range(self._counts[m]):
+                self.model_idx_by_object_idx_map[idx] = m
+                idx += 1
+        self.objects_count = idx
+        self.static_objects_count = sum(self._counts[: self.static_object_models_count])
+        self.dynamic_objects_count = self.objects_count - self.static_objects_count
+
+    def is_static(self, model_idx: int) -> bool:
+        return model_idx < self.static_object_models_count
+
+    def is_dynamic(self, model_idx: int) -> bool:
+        return not self.is_static(model_idx)
+
+    def objects_count_by_model_idx(self, model_idx: int) -> int:
+        return self._counts[model_idx]
+
+    def model_idx_by_object_idx(self, object_idx: int) -> int:
+        return self.model_idx_by_object_idx_map[object_idx]
+
+    def object_idx_by_dynamic_object_idx(self, dynamic_object_idx: int) -> int:
+        object_idx = dynamic_object_idx + self.static_objects_count
+        if object_idx >= self.objects_count:
+            raise Exception(f"The provided object id {dynamic_object_idx} is out of range")
+        return object_idx
+
+    def dynamic_object_idx_by_object_idx(self, object_idx: int) -> int:
+        if object_idx < self.static_objects_count:
+            raise Exception(f"The provided object id {object_idx} does not correspond to a dynamic object")
+        return object_idx - self.static_objects_count
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _linear(layer: Optional[nn.Linear]) -> _lib.Linear:
+    s = _lib.Linear()
+    if layer is not None:
+        s.weight = layer.weight.data_ptr()
+        s.bias = layer.bias.data_ptr() if layer.bias is not None else None
+        s.out_features, s.in_features = layer.weight.shape
+    return s
+
+
+class ObjectComposer(nn.Module):
+
+    #: soft limit for the per-call scratch (MLP feature rows dominate); larger calls are split along
+    #: the ray dimension, which is exact because rays are independent.
+    max_workspace_bytes = 24 << 30
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.object_models_coarse = nn.ModuleList(self.create_object_models(fine=False))
+        self.object_models_fine = nn.ModuleList(self.create_object_models(fine=True))
+        self.apply_activation = self.config["model"]["apply_activation"]
+        if self.object_models_coarse[0].model_config["nerf_model"]["output_features"] != 3 and self.apply_activation:
+            raise Exception("The application of activations to the nerf output is requested, but the model seem not "
+                            "to output colors directly. Please make sure this is the behavior you desire")
+        if self.apply_activation:
+            raise NotImplementedError("apply_activation=True (sigmoid on raw features) is not implemented in the HIP "
+                                      "renderer; both shipped configurations use False")
+        self.object_id_helper = ObjectIDsHelper(self.config)
+        self._packed: Dict[int, tuple] = {}
+        self._linspace: Dict[tuple, torch.Tensor] = {}
+        self._workspace: Optional[torch.Tensor] = None
+        self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
+
+    # ------------------------------------------------------------------ construction
+    def create_object_models(self, fine: bool) -> List[Optional[nn.Module]]:
+        models = []
+        for cfg in self.config["model"]["object_models"]:
+            if fine and "use_fine" in cfg and cfg["use_fine"] == False:  # noqa: E712  (reference semantics)
+                models.append(None)
+            else:
+                try:
+                    cls = OBJECT_MODEL_CLASSES[cfg["architecture"]]
+                except KeyError:
+                    raise Exception(f"object model architecture {cfg['architecture']} is not supported")
+                models.append(cls(self.config, cfg))
+        return models
+
+    def set_step(self, current_step: int):
+        for m in self.object_models_coarse:
+            m.set_step(current_step)
+        for m in self.object_models_fine:
+            if m is not None:
+                m.set_step(current_step)
+
+    # ------------------------------------------------------------------ marshalling
+    def _model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
+        cfg = model.model_config
+        nerf, bender = model.nerf_model, model.ray_bender
+        s = _lib.ObjectModel()
+        s.kind = nerf.kind
+        s.has_bender = 1 if bender.has_weights else 0
+        s.positions = positions
+        s.style_features = cfg["style_features"]
+        s.deformation_features = cfg["deformation_features"]
+        s.output_features = nerf.output_features
+        s.layers_width = nerf.layers_width
+        s.backbone_count = nerf.backbone_layers_count
+        s.skip_layer_idx = nerf.skip_layer_idx
+        s.octaves = nerf.octaves
+        box = [float(v) for row in cfg["bounding_box"] for v in row]
+        for i in range(6):
+            s.bbox[i] = box[i]
+        s.empty_space_alpha = float(cfg["empty_space_alpha"])
+        s.z_near_min = float(cfg["z_near_min"])
+        s.z_far_max = float(cfg["z_far_max"])
+        head = nerf.features_head
+        s.bn_eps = float(head[1].ada_in.normalization.eps)
+        for i, layer in enumerate(nerf.backbone_layers):
+            s.backbone[i] = _linear(layer)
+        s.alpha_head = _linear(nerf.alpha_head if nerf.kind == 0 else None)
+        s.head0 = _linear(head[0])
+        s.affine1 = _linear(head[1].affine_transform)
+        s.bn1_mean = head[1].ada_in.normalization.running_mean.data_ptr()
+        s.bn1_var = head[1].ada_in.normalization.running_var.data_ptr()
+        s.head3 = _linear(head[3])
+        s.affine4 = _linear(head[4].affine_transform)
+        s.bn4_mean = head[4].ada_in.normalization.running_mean.data_ptr()
+        s.bn4_var = head[4].ada_in.normalization.running_var.data_ptr()
+        s.head6 = _linear(head[6])
+        if bender.has_weights:
+            s.bender_width = bender.layers_width
+            s.bender_count = bender.layers_count
+            s.bender_skip = bender.skip_layer_idx
+            s.bender_octaves = bender.positional_encoder.octaves_count
+            w = bender.positional_encoder.annealing_weights().detach().cpu().tolist()
+            for i, v in enumerate(w):
+                s.bender_octave_weights[i] = v
+            for i, layer in enumerate(bender.backbone_layers):
+                s.bender[i] = _linear(layer)
+            s.bender_out = _linear(bender.output_head)
+        return s
+
+    def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int) -> torch.Tensor:
+        """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
+        params = list(model.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cached = self._packed.get(id(model))
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        lib = _lib.load()
+        size = C.c_size_t()
+        _lib.check(lib.pr_packed_size(C.byref(struct), C.byref(size)), "pr_packed_size")
+        buf = torch.empty(size.value, dtype=torch.uint8, device=params[0].device)
+        _lib.check(lib.pr_pack_model(C.byref(struct), buf.data_ptr(), size.value, stream), "pr_pack_model")
+        self._packed[id(model)] = (key, buf)
+        return buf
+
+    def _linspace_for(self, count: int, device) -> torch.Tensor:
+        key = (count, str(device))
+        if key not in self._linspace:
+            # evaluated by torch so that it is bit-identical to the reference's torch.linspace
+            self._linspace[key] = torch.linspace(0.0, 1.0, count, device=device)
+        return self._linspace[key]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor, focal_normals: torch.Tensor,
+                transformation_matrix_w2o: torch.Tensor, style: torch.Tensor, deformation: torch.Tensor,
+                object_in_scene: torch.Tensor, perturb: bool, video_indexes: torch.Tensor = None,
+                canonical_pose: bool = False, _noise: Optional[dict] = None, _export: bool = False) -> Dict:
+        """See model/object_composer.py:786-811 for the argument and result documentation.
+
+        ray_origins (..., 3); ray_directions (..., R, 3); focal_normals (..., 3) [unused by the
+        renderer, as in the reference]; transformation_matrix_w2o (..., 4, 4, K); style (..., S, K);
+        deformation (..., D, K); object_in_scene (..., K).  ``_noise`` (extension, optional) replays
+        explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state."""
+        helper = self.object_id_helper
+        K = helper.objects_count
+        if transformation_matrix_w2o.size(-1) != K:
+            raise Exception(f"Transformation matrix must specifies transformations for"
+                            f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
+        if not ray_directions.is_cuda:
+            raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+        if self.training:
+            raise NotImplementedError("train-mode BatchNorm statistics / backward are not implemented yet in the HIP "
+                                      "renderer: call .eval()")
+        if torch.is_grad_enabled() and (ray_directions.requires_grad or style.requires_grad or
+                                        transformation_matrix_w2o.requires_grad or deformation.requires_grad):
+            raise NotImplementedError("the HIP renderer has no backward yet: call it under torch.no_grad()")
+
+        lead = list(ray_directions.shape[:-2])
+        R = ray_directions.size(-2)
+        N = int(math.prod(lead)) if lead else 1
+        dev = ray_directions.device
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        dirs = ray_directions.detach().to(torch.float32).reshape(N, R, 3).contiguous()
+        origins = torch.broadcast_to(ray_origins.detach().to(torch.float32), lead + [3]).reshape(N, 3).contiguous()
+        w2o = torch.broadcast_to(transformation_matrix_w2o.detach().to(torch.float32), lead + [4, 4, K])
+        w2o = w2o.reshape(N, 4, 4, K).permute(0, 3, 1, 2)[:, :, :3, :].contiguous()          # (N, K, 3, 4)
+        S = style.size(-2)
+        D = deformation.size(-2)
+        sty = torch.broadcast_to(style.detach().to(torch.float32), lead + [S, K]).reshape(N, S, K).permute(0, 2, 1).contiguous()
+        dfm = torch.broadcast_to(deformation.detach().to(torch.float32), lead + [D, K]).reshape(N, D, K).permute(0, 2, 1).contiguous()
+        present = torch.broadcast_to(object_in_scene, lead + [K]).reshape(N, K).to(torch.uint8).contiguous()
+
+        models_c = [self.object_models_coarse[helper.model_idx_by_object_idx(k)] for k in range(K)]
+        models_f = [self.object_models_fine[helper.model_idx_by_object_idx(k)] for k in range(K)]
+        # the reference iterates the result types of object 0 (object_composer.py:851)
+        use_fine = models_f[0] is not None
+        if use_fine and any(m is None for m in models_f):
+            raise KeyError("fine")  # what the reference does when only some objects have a fine model
+        pc = [m.model_config["positions_count_coarse"] for m in models_c]
+        pf = [m.model_config["positions_count_fine"] for m in models_c]
+
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lib = _lib.load()
+        keep = []  # tensors that must outlive the enqueue
+        objs = (_lib.Object * K)()
+        for k in range(K):
+            for attr in ("style_features", "deformation_features"):
+                want = S if attr == "style_features" else D
+                if models_c[k].model_config[attr] != want:
+                    raise Exception(f"object {k}: {attr} is {models_c[k].model_config[attr]} but the tensor has {want}")
+            objs[k].coarse = self._model_struct(models_c[k], pc[k])
+            objs[k].packed_coarse = self._packed_weights(models_c[k], objs[k].coarse, stream).data_ptr()
+            if use_fine:
+                objs[k].fine = self._model_struct(models_f[k], pc[k] + pf[k])
+                objs[k].packed_fine = self._packed_weights(models_f[k], objs[k].fine, stream).data_ptr()
+
+        flags = 0
+        if perturb:
+            flags |= _lib.PR_FLAG_PERTURB
+        if canonical_pose:
+            flags |= _lib.PR_FLAG_CANONICAL_POSE
+        if self.config["model"]["fix_object_overlaps"]:
+            flags |= _lib.PR_FLAG_FIX_OVERLAPS
+        if self.use_naive_mlp:
+            flags |= _lib.PR_FLAG_NAIVE_MLP
+
+        # ---- noise -----------------------------------------------------------------------------
+        types = ["coarse"] + (["fine"] if use_fine else [])
+        ptot = {"coarse": pc, "fine": [a + b for a, b in zip(pc, pf)]}
+        noise: Dict[str, torch.Tensor] = {}
+        if perturb:
+            def get(name, shape, normal):
+                if _noise is not None and _noise.get(name) is not None:
+                    t = _noise[name].to(**f32).reshape(shape).contiguous()
+                else:
+                    t = (torch.randn if normal else torch.rand)(shape, **f32)
+                noise[name] = t
+            for k in range(K):
+                get(f"jitter_{k}", (N, R, pc[k]), False)
+                get(f"alpha_{k}", (N, R, pc[k]), True)
+                if use_fine:
+                    get(f"pdf_{k}", (N, R, pf[k]), False)
+            for ty in types:
+                for k in range(K):
+                    get(f"int_{ty}_{k}", (N, R, ptot[ty][k]), True)
+                get(f"int_{ty}_global", (N, R, sum(ptot[ty])), True)
+
+        # ---- ray chunking against the workspace budget -----------------------------------------
+        def build_call(r0: int, r1: int):
+            call = _lib.Call()
+            call.frames, call.rays, call.objects = N, r1 - r0, K
+            call.static_objects = helper.static_objects_count
+            call.use_fine = 1 if use_fine else 0
+            call.flags = flags
+            d = dirs if (r0 == 0 and r1 == R) else dirs[:, r0:r1].contiguous()
+            keep.append(d)
+            call.ray_origins, call.ray_directions = origins.data_ptr(), d.data_ptr()
+            call.w2o, call.style, call.deformation = w2o.data_ptr(), sty.data_ptr(), dfm.data_ptr()
+            call.object_in_scene = present.data_ptr()
+            for k in range(K):
+                call.linspace_coarse[k] = self._linspace_for(pc[k], dev).data_ptr()
+                if use_fine:
+                    call.linspace_fine[k] = self._linspace_for(pf[k], dev).data_ptr()
+                    call.positions_fine[k] = pf[k]
+
+            def sl(name):
+                t = noise.get(name)
+                if t is None:
+                    return None
+                t = t if (r0 == 0 and r1 == R) else t[:, r0:r1].contiguous()
+                keep.append(t)
+                return t.data_ptr()
+            for k in range(K):
+                call.noise_coarse.jitter[k] = sl(f"jitter_{k}")
+                call.noise_coarse.alpha[k] = sl(f"alpha_{k}")
+                call.noise_coarse.pdf[k] = sl(f"pdf_{k}")
+                call.noise_coarse.integrate[k] = sl(f"int_coarse_{k}")
+                call.noise_fine.integrate[k] = sl(f"int_fine_{k}")
+            call.noise_coarse.integrate_global = sl("int_coarse_global")
+            call.noise_fine.integrate_global = sl("int_fine_global")
+            return call
+
+        def workspace_bytes(call) -> int:
+            size = C.c_size_t()
+            _lib.check(lib.pr_workspace_size(C.byref(call), objs, C.byref(size)), "pr_workspace_size")
+            return size.value
+
+        chunk = R
+        need = workspace_bytes(build_call(0, R))
+        if need > self.max_workspace_bytes and R > 1:
+            chunk = max(1, int(R * self.max_workspace_bytes / need))
+            chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
+        F = models_c[0].nerf_model.output_features
+
+        pieces = []
+        for r0 in range(0, R, chunk):
+            r1 = min(R, r0 + chunk)
+            call = build_call(r0, r1)
+            need = workspace_bytes(call)
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            rc = r1 - r0
+            outs = {}
+            structs = {}
+            for ty in types:
+                o = _lib.Outputs()
+                res = {}
+                for k in range(K + 1):
+                    P = ptot[ty][k] if k < K else sum(ptot[ty])
+                    e = {
+                        "integrated_features": torch.empty((N, rc, F), **f32),
+                        "opacity": torch.empty((N, rc), **f32),
+                        "weights": torch.empty((N, rc, P), **f32),
+                        "depth": torch.empty((N, rc), **f32),
+                        "disparity": torch.empty((N, rc), **f32),
+                        "integrated_displacements_magnitude": torch.empty((N, rc), **f32),
+                        "integrated_divergence": torch.empty((N, rc), **f32),
+                    }
+                    entry = o.object[k] if k < K else o.global_
+                    for name in ENTRY_KEYS:
+                        setattr(entry, name, e[name].data_ptr())
+                    res[f"object_{k}" if k < K else "global"] = e
+                if _export:
+                    ex = {"t": [], "sigma": [], "slot": []}
+                    for k in range(K):
+                        ex["t"].append(torch.empty((N, rc, ptot[ty][k]), **f32))
+                        ex["sigma"].append(torch.empty((N, rc, ptot[ty][k]), **f32))
+                        ex["slot"].append(torch.empty((N, rc, ptot[ty][k]), dtype=torch.int32, device=dev))
+                        o.sample_t[k] = ex["t"][k].data_ptr()
+                        o.sample_sigma[k] = ex["sigma"][k].data_ptr()
+                        o.sample_slot[k] = ex["slot"][k].data_ptr()
+                    ex["evaluated"] = torch.zeros((K,), dtype=torch.int32, device=dev)
+                    o.evaluated_samples = ex["evaluated"].data_ptr()
+                    res["_samples"] = ex
+                outs[ty] = res
+                structs[ty] = o
+            _lib.check(lib.pr_render_forward(C.byref(call), objs, C.byref(structs["coarse"]),
+                                             C.byref(structs["fine"]) if use_fine else None,
+                                             self._workspace.data_ptr(), self._workspace.numel(), stream),
+                       "pr_render_forward")
+            pieces.append(outs)
+
+        # ---- result dictionary (object_composer.py:848-892 schema) -----------------------------
+        results: Dict = {}
+        for ty in types:
+            results[ty] = {}
+            for name in [f"object_{k}" for k in range(K)] + ["global"]:
+                entry = {}
+                for key in ENTRY_KEYS:
+                    parts = [p[ty][name][key] for p in pieces]
+                    t = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+                    entry[key] = t.reshape(lead + list(t.shape[1:]))
+                if name != "global":
+                    entry["extra_outputs"] = {}
+                results[ty][name] = entry
+            if _export:
+                results[ty]["_samples"] = [p[ty]["_samples"] for p in pieces]
+        results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
+        return results
