@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mrays/s of the HIP renderer on BASELINE.json configs[1].
+
+Workload (per GPU): the tennis renderer (4 objects) with the hierarchical override - 64 coarse +
+128 resampled positions per object and ray, coarse and fine networks - on one 256x256 frame
+(65 536 rays) of the seeded synthetic tennis scene, eval mode, fp32.  A "step" is one full render
+from the scene encoding (camera, object poses, style, deformation - resident in HBM) to the result
+tensors of ``EnvironmentModel.forward(mode="scene_encodings")``.  With N GPUs every rank renders
+its own frame (weak scaling) and the rendered ``fine.global.integrated_features`` maps are gathered
+on rank 0 with one RCCL collective inside the timed region.
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the fused fp32-MFMA MLP,
+``k_mlp_mfma``): algorithmic FLOPs per launch (in-box samples actually evaluated x
+FLOP/sample of the object's networks) / average launch duration measured with HIP events on the
+launch stream.  ``cpu_baseline`` times the CPU oracle (a restatement of the reference's PyTorch op
+graph, 1000-ray chunks like the reference's full-frame path) on a bounded ray subset of the same
+frame on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def flops_per_sample(model_cfg: dict) -> float:
+    """Matmul FLOPs (2 per MAC) of one evaluated sample, SURVEY.md section 8d."""
+    n = model_cfg["nerf_model"]
+    din = 6 if n["architecture"].endswith("skybox_adain_style_nerf_model_v3") else 3
+    enc = din * (1 + 2 * n["position_encoder"]["octaves"])
+    w, layers, f = n["layers_width"], n["backbone_layers_count"], n["output_features"]
+    mac = enc * w + (layers - 2) * w * w + (w + enc) * w + w * w + w * (w // 2) + (w // 2) * f
+    if din == 3:
+        mac += w  # sigma head
+    b = model_cfg["ray_bender_model"]
+    if b["architecture"].endswith("positional_ray_bender_model"):
+        benc = 3 * (1 + 2 * b["position_encoder"]["octaves"]) + model_cfg["deformation_features"]
+        bw, bl = b["layers_width"], b["layers_count"]
+        mac += benc * bw + (bl - 2) * bw * bw + (bw + benc) * bw + bw * 3
+    return 2.0 * mac
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--image", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=32, help="the CPU baseline renders a cpu_rays x cpu_rays pixel grid")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch threads of the CPU baseline (all 256 host cores are >50x SLOWER on these small ops)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the renderer)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from playableenvironments_amd import configs, synthetic, _lib
+    from playableenvironments_amd.environment_model import EnvironmentModel
+
+    cfg = configs.tennis_config(hierarchical=(64, 128))
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
+    model.eval().to(dev)
+    size = (args.image, args.image)
+    scene = synthetic.tennis_scene(seed=1234 + rank, image_size=size)
+    scene_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+
+    def step():
+        with torch.no_grad():
+            out = model(scene_dev["camera_rotations"], scene_dev["camera_translations"], scene_dev["focals"], size,
+                        scene_dev["object_rotation_parameters"], scene_dev["object_translation_parameters"],
+                        scene_dev["object_style"], scene_dev["object_deformation"], scene_dev["object_in_scene"],
+                        0, False, mode="scene_encodings")
+        feats = out["fine"]["global"]["integrated_features"]
+        if world > 1:
+            gathered = [torch.empty_like(feats) for _ in range(world)] if rank == 0 else None
+            dist.gather(feats, gathered, dst=0)
+        return out
+
+    lib = _lib.load()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib.pr_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.pr_profile_enable(0)
+    ms = (C.c_double * 2)()
+    launches = (C.c_int32 * 2)()
+    _lib.check(lib.pr_profile_collect(ms, launches), "pr_profile_collect")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # algorithmic FLOPs of the MLP launches of one step: evaluated samples x FLOP/sample
+    comp = model.object_composer
+    comp_inputs = None
+    with torch.no_grad():
+        from playableenvironments_amd.environment_model import camera_rays, euler_to_matrix
+        rows = torch.arange(size[0] * size[1], dtype=torch.int32) // size[1]
+        cols = torch.arange(size[0] * size[1], dtype=torch.int32) % size[1]
+        c2w = euler_to_matrix(scene_dev["camera_rotations"], scene_dev["camera_translations"])
+        o, d, n = camera_rays(c2w, scene_dev["focals"] * cfg["data"]["focal_length_multiplier"], size[0], size[1], rows, cols)
+        w2o, _ = model.compute_transformation_matrix_w2o_o2w(scene_dev["object_rotation_parameters"],
+                                                             scene_dev["object_translation_parameters"])
+        ex = comp(o, d, n, w2o, scene_dev["object_style"].unsqueeze(-3), scene_dev["object_deformation"].unsqueeze(-3),
+                  scene_dev["object_in_scene"].unsqueeze(-2), False, _export=True)
+    torch.cuda.synchronize()
+    helper = comp.object_id_helper
+    flops = 0.0
+    evaluated = {}
+    for ty in ("coarse", "fine"):
+        ev = sum(p["evaluated"].cpu() for p in ex[ty]["_samples"])
+        evaluated[ty] = [int(v) for v in ev]
+        for k in range(helper.objects_count):
+            flops += float(ev[k]) * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
+
+    rays_per_gpu = size[0] * size[1]
+    total_rays = rays_per_gpu * world * args.steps
+    value = total_rays / elapsed / 1e6
+    mlp_ms = ms[0] / max(1, args.steps)
+    achieved = flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    result = {
+        "metric": "Mrays/s",
+        "value": round(value, 4),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"tennis renderer, {size[0]}x{size[1]} frame per GPU, 4 objects, 64+128 hierarchical samples/ray "
+                        "(coarse+fine networks), eval - BASELINE.json configs[1]",
+            "rays_per_gpu": rays_per_gpu,
+            "frames_per_gpu": 1,
+            "parallelism": f"frame shard x{world}" + (" + RCCL gather of feature maps" if world > 1 else ""),
+        },
+        "frames_per_s_256x256": round(value * 1e6 / 65536.0, 3),
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "k_mlp_mfma (fused fp32 MFMA MLP, all launches of one step)",
+            "achieved": round(achieved, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "flop_per_step": flops,
+            "mlp_ms_per_step": round(mlp_ms, 3),
+            "mlp_launches_per_step": int(launches[0] / max(1, args.steps)),
+            "composite_ms_per_step": round(ms[1] / max(1, args.steps), 3),
+            "evaluated_samples": evaluated,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import render_oracle as ro
+        from tests.helpers import composer_inputs, grid_pixels
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        torch.set_num_threads(threads)
+        sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+        n_side = args.cpu_rays
+        inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], n_side))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ro.batchified_composer_call(cfg, sd, *inputs, False, chunk=1000)
+            cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(n_side * n_side / cpu_s / 1e6, 6),
+            "unit": "Mrays/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{n_side}x{n_side} pixel grid ({n_side * n_side} rays) of the same frame and weights, "
+                      f"oracle/render_oracle.py in 1000-ray chunks, {cpu_s:.1f} s wall, {threads} torch threads "
+                      f"of {os.cpu_count()} host cores",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

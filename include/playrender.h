@@ -187,6 +187,15 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width,
                    const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols,
                    float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
 
+/*
+ * Kernel timing for bench.py: while enabled, every launch of the fused MLP kernel (category 0) and
+ * of the compositing kernel (category 1) is bracketed by hipEventRecord on the launch stream.
+ * pr_profile_collect synchronises the recorded events, returns the summed milliseconds and launch
+ * counts per category (host arrays of 2) and clears the list.
+ */
+int pr_profile_enable(int enable);
+int pr_profile_collect(double* milliseconds, int32_t* launches);
+
 /* Library / device introspection. */
 int pr_abi_version(void);
 const char* pr_last_error(void);

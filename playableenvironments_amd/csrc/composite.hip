@@ -296,6 +296,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
         attr_set = true;
     }
     const long total = (long)p.frames * p.rays;
+    ProfileScope scope(1, s);
     hipLaunchKernelGGL(k_composite, dim3((unsigned)total), dim3(64), lds, s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;

@@ -677,6 +677,7 @@ int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_mo
         attr_set = true;
     }
     const int grid = max_tiles < g_cu_count ? max_tiles : g_cu_count;
+    ProfileScope scope(0, s);
     hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;

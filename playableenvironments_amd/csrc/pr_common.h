@@ -240,6 +240,16 @@ struct CompositeParams {
 };
 int launch_composite(const CompositeParams& p, hipStream_t s);
 
+// Kernel timing (bench.py): records an event pair on `s` around a launch when profiling is on.
+struct ProfileScope {
+    ProfileScope(int category, hipStream_t s);
+    ~ProfileScope();
+    int category_;
+    hipStream_t stream_;
+    hipEvent_t start_;
+    bool active_;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Device helpers
 // ---------------------------------------------------------------------------------------------

@@ -4,7 +4,34 @@
 
 #include <stdarg.h>
 
+#include <mutex>
+#include <vector>
+
 namespace pr {
+
+// ---------------------------------------------------------------------------------------------
+// Kernel timing
+// ---------------------------------------------------------------------------------------------
+struct ProfileRecord { int category; hipEvent_t start, stop; };
+static bool g_profile_on = false;
+static std::vector<ProfileRecord> g_profile;
+static std::mutex g_profile_mutex;
+
+ProfileScope::ProfileScope(int category, hipStream_t s) : category_(category), stream_(s), start_(nullptr), active_(false) {
+    if (!g_profile_on) return;
+    if (hipEventCreate(&start_) != hipSuccess) return;
+    hipEventRecord(start_, stream_);
+    active_ = true;
+}
+
+ProfileScope::~ProfileScope() {
+    if (!active_) return;
+    hipEvent_t stop;
+    if (hipEventCreate(&stop) != hipSuccess) return;
+    hipEventRecord(stop, stream_);
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
+    g_profile.push_back(ProfileRecord{category_, start_, stop});
+}
 
 static thread_local char g_error[512] = "";
 
@@ -315,6 +342,33 @@ extern "C" int pr_render_forward(const pr_call_t* call, const pr_object_t* objec
     PR_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     const pr_outputs_t* outs[2] = {coarse, fine};
     return pr::render(*call, objects, outs, static_cast<char*>(workspace), plan, (hipStream_t)stream);
+}
+
+extern "C" int pr_profile_enable(int enable) {
+    pr::g_profile_on = enable != 0;
+    return PR_OK;
+}
+
+extern "C" int pr_profile_collect(double* milliseconds, int32_t* launches) {
+    PR_REQUIRE(milliseconds && launches, "pr_profile_collect: NULL argument");
+    std::lock_guard<std::mutex> lock(pr::g_profile_mutex);
+    for (int c = 0; c < 2; ++c) {
+        milliseconds[c] = 0.0;
+        launches[c] = 0;
+    }
+    for (auto& r : pr::g_profile) {
+        PR_CHECK_HIP(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        PR_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+        if (r.category >= 0 && r.category < 2) {
+            milliseconds[r.category] += ms;
+            launches[r.category] += 1;
+        }
+        hipEventDestroy(r.start);
+        hipEventDestroy(r.stop);
+    }
+    pr::g_profile.clear();
+    return PR_OK;
 }
 
 extern "C" int pr_abi_version(void) { return PR_ABI_VERSION; }

@@ -1,0 +1,288 @@
+"""Host orchestration of the renderer: the scene-encoding path of the reference's EnvironmentModel.
+
+Keeps the tensor-in / dict-out signatures of ``EnvironmentModel.forward(mode="scene_encodings")``,
+``forward_from_scene_encoding`` (model/environment_model.py:1041-1158),
+``render_full_frame_from_scene_encoding`` (:618-651), ``batchified_composer_call`` (:474-521),
+``merge_dictionaries`` (:523-545) and ``fold_dictionary`` (:547-579), so evaluators / play loops /
+the playable model that drive the reference through these entry points can drive this class.
+
+Everything between "scene encoding" and "composer result" runs on the GPU: rays come from the
+``pr_camera_rays`` kernel, the composer is the HIP renderer; the few per-(frame, object) 4x4
+matrices and box projections are tiny PyTorch-ROCm ops.  The observation-driven modes need the
+CNN encoders, which are out of scope for this package: they raise.
+"""
+from __future__ import annotations
+
+import collections.abc
+import ctypes as C
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .object_composer import ObjectComposer, ObjectIDsHelper
+
+
+def euler_to_matrix(rotations: torch.Tensor, translations: torch.Tensor) -> torch.Tensor:
+    """(..., 3) Euler angles (x, y, z; radians) and (..., 3) translations -> (..., 4, 4) with
+    R = Ry (Rx Rz)  (utils/lib_3d/transformations_3d.py:69-96)."""
+    cx, sx = torch.cos(rotations[..., 0]), torch.sin(rotations[..., 0])
+    cy, sy = torch.cos(rotations[..., 1]), torch.sin(rotations[..., 1])
+    cz, sz = torch.cos(rotations[..., 2]), torch.sin(rotations[..., 2])
+    zero, one = torch.zeros_like(cx), torch.ones_like(cx)
+    rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], -1).reshape(cx.shape + (3, 3))
+    ry = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], -1).reshape(cx.shape + (3, 3))
+    rz = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], -1).reshape(cx.shape + (3, 3))
+    rot = torch.matmul(ry, torch.matmul(rx, rz))
+    out = torch.zeros(cx.shape + (4, 4), dtype=rot.dtype, device=rot.device)
+    out[..., :3, :3] = rot
+    out[..., :3, 3] = translations
+    out[..., 3, 3] = 1.0
+    return out
+
+
+def strided_grid_pixels(height: int, width: int, strides) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rows, cols) of RayHelper.sample_all_rays_strided_grid (utils/lib_3d/ray_helper.py:433-482,
+    :533-582): pixel ``i*s + s//2`` for every stride, smallest stride first, row-major per stride."""
+    if not isinstance(strides, collections.abc.Sequence):
+        strides = [strides]
+    rows, cols = [], []
+    for s in strides:
+        if height % s != 0:
+            raise Exception("The image height is not divisible by the stride")
+        if width % s != 0:
+            raise Exception("The image width is not divisible by the stride")
+        r = torch.arange(height // s, dtype=torch.int32) * s + s // 2
+        c = torch.arange(width // s, dtype=torch.int32) * s + s // 2
+        rr, cc = torch.meshgrid(r, c, indexing="ij")
+        rows.append(rr.reshape(-1))
+        cols.append(cc.reshape(-1))
+    return torch.cat(rows), torch.cat(cols)
+
+
+def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int, rows: torch.Tensor,
+                cols: torch.Tensor):
+    """World-frame rays of the selected pixels through ``pr_camera_rays``.
+
+    c2w (..., 4, 4); focals (...) (already rescaled); rows / cols int (R).
+    Returns origins (..., 3), directions (..., R, 3), focal normals (..., 3)."""
+    if not c2w.is_cuda:
+        raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+    lead = list(c2w.shape[:-2])
+    n = int(math.prod(lead)) if lead else 1
+    dev = c2w.device
+    m = c2w.detach().to(torch.float32).reshape(n, 4, 4)[:, :3, :].contiguous()
+    f = torch.broadcast_to(focals.detach().to(torch.float32), lead).reshape(n).contiguous()
+    rows = rows.to(device=dev, dtype=torch.int32).contiguous()
+    cols = cols.to(device=dev, dtype=torch.int32).contiguous()
+    r = rows.numel()
+    origins = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((n, r, 3), dtype=torch.float32, device=dev)
+    normals = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pr_camera_rays(n, r, height, width, m.data_ptr(), f.data_ptr(), rows.data_ptr(), cols.data_ptr(),
+                                  origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
+    return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
+
+
+class EnvironmentModel(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.focal_length_multiplier = config["data"]["focal_length_multiplier"]
+        self.use_weighted_sampling = config["model"].get("use_weighted_sampling", False)
+        self.sampling_weights = config["model"].get("sampling_weights", None)
+        self.object_composer = ObjectComposer(config)
+        self.object_id_helper = ObjectIDsHelper(config)
+        self.current_step = 0
+
+    def set_step(self, current_step: int):
+        self.current_step = current_step
+        self.object_composer.set_step(current_step)
+
+    # ------------------------------------------------------------------ modes
+    def forward(self, *args, mode="observations", **kwargs):
+        if mode == "scene_encodings":
+            return self.forward_from_scene_encoding(*args, **kwargs)
+        if mode in ("observations", "observations_scene_encoding_only", "pose_consistency", "keypoint_consistency"):
+            raise NotImplementedError(
+                f"forward mode '{mode}' needs the CNN object encoders of the reference, which this renderer package "
+                "does not contain; encode the scene with the reference model and call mode='scene_encodings'")
+        raise Exception(f"Unknown forward mode '{mode}'")
+
+    # ------------------------------------------------------------------ tiny per-(frame, object) math
+    def compute_transformation_matrix_w2o_o2w(self, object_rotation_parameters_o2w: torch.Tensor,
+                                              object_translation_parameters_o2w: torch.Tensor):
+        """(..., 3, K) poses -> w2o, o2w of shape (..., 1, 4, 4, K) (singleton cameras dim).
+        model/environment_model.py:206-232."""
+        k = self.object_id_helper.objects_count
+        o2w = torch.stack([euler_to_matrix(object_rotation_parameters_o2w[..., i], object_translation_parameters_o2w[..., i])
+                           for i in range(k)], dim=-1)
+        w2o = torch.stack([torch.linalg.inv(o2w[..., i]) for i in range(k)], dim=-1)
+        return w2o.unsqueeze(-4), o2w.unsqueeze(-4)
+
+    @staticmethod
+    def _project(points: torch.Tensor, o2w: torch.Tensor, w2c: torch.Tensor, focals: torch.Tensor):
+        """Object-frame points (P, 3) -> image-plane coordinates (..., C, P, 2) relative to the image
+        centre (x right, y down) and the camera-frame z (..., C, P, 1).  environment_model.py:272-292."""
+        m = o2w.unsqueeze(-3)
+        world = torch.sum(points.unsqueeze(-2) * m[..., :3, :3], -1) + m[..., :3, -1]
+        world = world.unsqueeze(-3)
+        c = w2c.unsqueeze(-3)
+        cam = torch.sum(world.unsqueeze(-2) * c[..., :3, :3], -1) + c[..., :3, -1]
+        proj = -cam[..., :2] / cam[..., 2:3] * focals.unsqueeze(-1).unsqueeze(-1)
+        proj = torch.stack([proj[..., 0], -proj[..., 1]], dim=-1)
+        return proj, cam[..., 2:3]
+
+    def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width):
+        """Image-plane boxes (..., C, 4, K) [left, top, right, bottom] and projected box points
+        (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
+        if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
+            transformation_matrix_o2w = transformation_matrix_o2w[..., 0, :, :, :]
+        boxes, points = [], []
+        for k in range(self.object_id_helper.objects_count):
+            m = self.object_id_helper.model_idx_by_object_idx(k)
+            pts = self.object_composer.object_models_coarse[m].bounding_box.get_edge_points()
+            proj, z = self._project(pts, transformation_matrix_o2w[..., k], transformation_matrix_w2c, focals)
+            behind = (z > 0).expand_as(proj)
+            hi = torch.where(behind, torch.full_like(proj, 1e20), proj)
+            lo = torch.where(behind, torch.full_like(proj, -1e20), proj)
+            left, right = hi[..., 0].min(dim=-1)[0], lo[..., 0].max(dim=-1)[0]
+            top, bottom = hi[..., 1].min(dim=-1)[0], lo[..., 1].max(dim=-1)[0]
+            boxes.append(torch.stack([left, top, right, bottom], dim=-1))
+            points.append(proj)
+        boxes = torch.stack(boxes, dim=-1)
+        points = torch.stack(points, dim=-1)
+        scale = torch.as_tensor([width, height, width, height], dtype=boxes.dtype, device=boxes.device).unsqueeze(-1)
+        boxes = (boxes + scale / 2) / scale
+        pscale = torch.as_tensor([width, height], dtype=points.dtype, device=points.device).unsqueeze(-1)
+        points = (points + pscale / 2) / pscale
+        return torch.clamp(boxes, min=0.0, max=1.0), torch.clamp(points, min=0.0, max=1.0)
+
+    def compute_object_axes_projection(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width):
+        """Projected origin + unit axes of every object (..., C, 4, 2, K), normalised, not clamped.
+        model/environment_model.py:329-404."""
+        if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
+            transformation_matrix_o2w = transformation_matrix_o2w[..., 0, :, :, :]
+        pts = torch.tensor([(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)],
+                           device=transformation_matrix_o2w.device)
+        out = [self._project(pts, transformation_matrix_o2w[..., k], transformation_matrix_w2c, focals)[0]
+               for k in range(self.object_id_helper.objects_count)]
+        out = torch.stack(out, dim=-1)
+        pscale = torch.as_tensor([width, height], dtype=out.dtype, device=out.device).unsqueeze(-1)
+        return (out + pscale / 2) / pscale
+
+    # ------------------------------------------------------------------ composer plumbing
+    def batchified_composer_call(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                 deformation, object_in_scene, perturb, samples_per_image_batching: int = 0,
+                                 video_indexes=None, canonical_pose: bool = False):
+        """model/environment_model.py:474-521.  The reference chunks rays (1000 per call in full-frame
+        rendering) because it materialises (rays, samples, 192) tensors; the fused renderer does not
+        need to, so ``samples_per_image_batching`` is accepted and ignored - the composer splits a
+        call only if its scratch would exceed its workspace budget, which is exact."""
+        results = self.object_composer(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                       deformation, object_in_scene, perturb, video_indexes=video_indexes,
+                                       canonical_pose=canonical_pose)
+        return self.merge_dictionaries([results], dimension=ray_directions.dim() - 2)
+
+    def merge_dictionaries(self, dictionaries: List[Dict], dimension: int):
+        merged = {}
+        for key in list(dictionaries[0].keys()):
+            if key == "pytorch_hook":
+                continue
+            if torch.is_tensor(dictionaries[0][key]):
+                parts = [d[key] for d in dictionaries]
+                merged[key] = parts[0] if len(parts) == 1 else torch.cat(parts, dim=dimension)
+            else:
+                merged[key] = self.merge_dictionaries([d[key] for d in dictionaries], dimension)
+        return merged
+
+    def fold_dictionary(self, dictionary: Dict, height: int, width: int):
+        """Folds the first dimension of size ``height*width`` of every tensor into (height, width).
+        model/environment_model.py:547-579 (size matching, as the reference)."""
+        target = height * width
+        for key in dictionary:
+            cur = dictionary[key]
+            if type(cur) is dict:
+                dictionary[key] = self.fold_dictionary(cur, height, width)
+            elif torch.is_tensor(cur):
+                sizes = list(cur.size())
+                for idx, size in enumerate(sizes):
+                    if size == target:
+                        dictionary[key] = cur.reshape(sizes[:idx] + [height, width] + sizes[idx + 1:])
+                        break
+        return dictionary
+
+    # ------------------------------------------------------------------ scene encoding -> rays -> composer
+    def forward_from_scene_encoding(self, camera_rotations, camera_translations, focals, image_size,
+                                    object_rotation_parameters_o2w, object_translation_parameters_o2w, object_style,
+                                    object_deformation, object_in_scene, samples_per_image: int, perturb: bool,
+                                    samples_per_image_batching: int = 0, upsample_factor: float = 1.0,
+                                    patch_size: int = 0, patch_stride=0, canonical_pose: bool = False) -> Dict:
+        """model/environment_model.py:1041-1158; argument shapes documented there.
+
+        camera_* (..., O, C, 3); focals (..., O, C); object_* (..., O, 3|S|D, K); object_in_scene (..., O, K)."""
+        rescaled_focals = focals * self.focal_length_multiplier
+        height = int(image_size[0] * upsample_factor)
+        width = int(image_size[1] * upsample_factor)
+
+        c2w = euler_to_matrix(camera_rotations, camera_translations)
+        w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
+                                                              object_translation_parameters_o2w)
+        w2c = torch.linalg.inv(c2w)
+        boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, rescaled_focals * upsample_factor, height, width)
+        axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
+
+        if patch_size != 0 and samples_per_image != 0:
+            raise NotImplementedError("strided-patch ray sampling (training) is not implemented yet in the HIP renderer")
+        elif patch_stride and samples_per_image == 0:
+            rows, cols = strided_grid_pixels(height, width, patch_stride)
+        elif samples_per_image == 0:
+            r = torch.arange(height * width, dtype=torch.int32)
+            rows, cols = r // width, r % width
+        elif self.use_weighted_sampling:
+            raise NotImplementedError("bounding-box weighted ray sampling is not implemented yet in the HIP renderer")
+        else:
+            # RayHelper.sample_rays (ray_helper.py:730-795): a random subset of pixels, the same for all frames
+            perm = torch.randperm(height * width)[:samples_per_image].to(torch.int32)
+            rows, cols = perm // width, perm % width
+
+        origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
+
+        results = self.batchified_composer_call(origins, directions, normals, w2o, object_style.unsqueeze(-3),
+                                                object_deformation.unsqueeze(-3), object_in_scene.unsqueeze(-2),
+                                                perturb, samples_per_image_batching, canonical_pose=canonical_pose)
+        results["object_rotation_parameters"] = object_rotation_parameters_o2w
+        results["object_translation_parameters"] = object_translation_parameters_o2w
+        results["reconstructed_bounding_boxes"] = boxes
+        results["reconstructed_3d_bounding_boxes"] = box_points
+        results["projected_axes"] = axes
+        results["scene_encoding"] = {
+            "camera_rotations": camera_rotations,
+            "camera_translations": camera_translations,
+            "focals": focals,
+            "object_rotation_parameters": object_rotation_parameters_o2w,
+            "object_translation_parameters": object_translation_parameters_o2w,
+            "object_style": object_style,
+            "object_deformation": object_deformation,
+            "object_in_scene": object_in_scene,
+        }
+        return results
+
+    def render_full_frame_from_scene_encoding(self, camera_rotations, camera_translations, focals, image_size,
+                                              object_rotation_parameters_o2w, object_translation_parameters_o2w,
+                                              object_style, object_deformation, object_in_scene, perturb: bool,
+                                              samples_per_image_batching: int = 1000, upsample_factor: float = 1.0,
+                                              canonical_pose: bool = False) -> Dict:
+        """Every pixel of the frame, folded back to (height, width).  model/environment_model.py:618-651."""
+        flat = self(camera_rotations, camera_translations, focals, image_size, object_rotation_parameters_o2w,
+                    object_translation_parameters_o2w, object_style, object_deformation, object_in_scene, 0, perturb,
+                    samples_per_image_batching, upsample_factor=upsample_factor, canonical_pose=canonical_pose,
+                    mode="scene_encodings")
+        height = int(image_size[0] * upsample_factor)
+        width = int(image_size[1] * upsample_factor)
+        return self.fold_dictionary(flat, height, width)

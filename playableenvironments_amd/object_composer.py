@@ -86,7 +86,7 @@ class ObjectComposer(nn.Module):
 
     #: soft limit for the per-call scratch (MLP feature rows dominate); larger calls are split along
     #: the ray dimension, which is exact because rays are independent.
-    max_workspace_bytes = 24 << 30
+    max_workspace_bytes = 96 << 30
 
     def __init__(self, config):
         super().__init__()

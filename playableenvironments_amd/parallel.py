@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of the renderer: one process per GPU, torch.distributed (RCCL over xGMI).
+
+Rays are independent given the (tiny) scene encoding and the replicated weights, so the path
+shards with no data-path collective; the only exchange is the gather of the rendered feature maps
+(SURVEY.md section 8e).  The reference itself renders on a single GPU (evaluation bypasses
+nn.DataParallel, evaluation/evaluator.py:58).  The helpers are backend-agnostic so that the
+world_size-2 ``gloo`` tests on CPU exercise exactly the code the ``nccl`` (= RCCL) runs use.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [begin, end) slice of ``total`` work units for ``rank`` (the first
+    ``total % world`` ranks get one extra unit)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_frames(tensor: torch.Tensor, rank: int, world: int, dim: int = 0) -> torch.Tensor:
+    """This rank's frames of a per-frame tensor (scene encodings are sharded along the batch dim)."""
+    b, e = shard_range(tensor.size(dim), rank, world)
+    return tensor.narrow(dim, b, e - b)
+
+
+def gather_ray_shards(local: torch.Tensor, total: int, dim: int, dst: Optional[int] = 0,
+                      group=None) -> Optional[torch.Tensor]:
+    """Reassembles a tensor whose ``dim`` was sharded with ``shard_range`` (ragged shards allowed).
+
+    dst = rank that receives the full tensor (others return None); dst=None -> all_gather, every
+    rank returns it.  One collective; shards are padded to the largest shard so that the same
+    call works for RCCL and gloo."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    longest = max(e - b for b, e in sizes)
+    if local.size(dim) != sizes[rank][1] - sizes[rank][0]:
+        raise ValueError("local shard does not match shard_range")
+    pad = longest - local.size(dim)
+    buf = local.contiguous()
+    if pad:
+        shape = list(local.shape)
+        shape[dim] = pad
+        buf = torch.cat([buf, buf.new_zeros(shape)], dim=dim).contiguous()
+    if dst is None:
+        parts: List[torch.Tensor] = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+    else:
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, parts, dst=dst, group=group)
+        if rank != dst:
+            return None
+    return torch.cat([p.narrow(dim, 0, e - b) for p, (b, e) in zip(parts, sizes)], dim=dim)

@@ -1,0 +1,279 @@
+"""CPU suite (python -m pytest tests -m "not gpu"): oracle vs reference-generated golden vectors,
+host logic, C-ABI surface, multi-process sharding on gloo.  No compute call needs a GPU."""
+import ast
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import render_oracle as ro
+from oracle.make_golden import recipe_config
+from playableenvironments_amd import ObjectComposer, _lib, configs, synthetic
+from playableenvironments_amd.environment_model import strided_grid_pixels
+from playableenvironments_amd.object_composer import ObjectIDsHelper
+from tests.helpers import compare_results
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+def load_fixture(path):
+    z = np.load(path)
+    recipe = ast.literal_eval(bytes(z["recipe"]).decode())
+    inputs = [torch.from_numpy(z[f"in/{i}"]) for i in range(7)]
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    noise = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("noise/")}
+    out = {}
+    for k in z.files:
+        if k.startswith("out/"):
+            node = out
+            parts = k[4:].split("/")
+            for p in parts[:-1]:
+                node = node.setdefault(p, {})
+            node[parts[-1]] = torch.from_numpy(z[k])
+    return recipe, inputs, sd, noise, out, bool(int(z["perturb"]))
+
+
+def test_golden_fixtures_present():
+    assert len(GOLDEN) >= 7
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_reproduces_reference_golden(path):
+    """The oracle must reproduce the reference's recorded outputs bit for bit (same torch build) or
+    to fp32 round-off (other builds): tolerance rtol 1e-5 / atol 1e-6, NaNs in the same places."""
+    recipe, inputs, sd, noise, want, perturb = load_fixture(path)
+    cfg = recipe_config(recipe)
+    with torch.no_grad():
+        got = ro.composer_forward(cfg, sd, *inputs, perturb, noise=noise)
+    rep = compare_results(want, got, rtol=1e-5, atol=1e-6)
+    bad = {k: v for k, v in rep.items() if not v[1]}
+    assert not bad, bad
+
+
+def test_stable_merge_only_differs_on_tied_rays():
+    """The renderer defines cross-object ties as stable in object order; against the reference's
+    unspecified order this may change rays that contain an in-box sample inside a tie, nothing else."""
+    recipe, inputs, sd, noise, want, perturb = load_fixture(os.path.join(ROOT, "tests", "golden", "tennis_small_eval.npz"))
+    cfg = recipe_config(recipe)
+    with torch.no_grad():
+        got = ro.composer_forward(cfg, sd, *inputs, perturb, stable_merge=True)
+    diff = (got["coarse"]["global"]["opacity"] - want["coarse"]["global"]["opacity"]).abs()
+    assert (diff > 1e-6).float().mean() < 0.05
+
+
+def test_known_answer_bounding_box():
+    """The reference's only known-answer block (utils/lib_3d/bounding_box.py:134-148): unit box,
+    points strictly inside are inside, points beyond a face are outside; faces are inclusive."""
+    box = torch.tensor([[0.0, 1.0], [0.0, 1.0], [0.0, 1.0]])
+    inside = torch.tensor([[0.5, 0.5, 0.5], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.1, 0.9, 0.5], [1.0, 0.0, 0.3]])
+    outside = torch.tensor([[1.1, 0.5, 0.5], [-0.1, 0.5, 0.5], [0.5, 1.5, 0.5], [0.5, 0.5, -1e-6], [2.0, 2.0, 2.0]])
+    assert ro._in_box(inside, box).all() and not ro._in_box(outside, box).any()
+
+
+def test_euler_roundtrip_identity():
+    m = ro.euler_to_matrix(torch.zeros(3), torch.tensor([1.0, 2.0, 3.0]))
+    assert torch.equal(m[:3, :3], torch.eye(3)) and torch.equal(m[:3, 3], torch.tensor([1.0, 2.0, 3.0]))
+    r = ro.euler_to_matrix(torch.tensor([0.3, -1.1, 0.7]), torch.zeros(3))[:3, :3]
+    assert torch.allclose(r @ r.T, torch.eye(3), atol=1e-6)
+
+
+def test_weights_sum_to_opacity_and_stay_in_unit_interval():
+    torch.manual_seed(0)
+    raw = torch.randn(50, 40) * 3
+    t = torch.sort(torch.rand(50, 40) * 20 + 5, dim=-1)[0]
+    d = torch.randn(50, 3)
+    a, _ = ro.alphas_from_raw(raw, ro.position_distances(t, d), False)
+    w = ro.weights_from_alphas(a)
+    assert (w >= 0).all() and (w.sum(-1) <= 1 + 1e-5).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# host logic of the product package
+# ------------------------------------------------------------------------------------------------
+def test_state_dict_layout_matches_reference_names():
+    comp = ObjectComposer(configs.tennis_config())
+    sd = comp.state_dict()
+    assert len(sd) == 156 and sum(p.numel() for p in comp.parameters()) == 2867716  # SURVEY.md 3.4 / 2.2 [probed]
+    for key, shape in {
+        "object_models_coarse.0.nerf_model.backbone_layers.4.weight": (256, 319),
+        "object_models_coarse.2.nerf_model.alpha_head.weight": (1, 256),
+        "object_models_coarse.2.nerf_model.features_head.1.affine_transform.weight": (512, 64),
+        "object_models_coarse.2.nerf_model.features_head.4.ada_in.normalization.running_var": (128,),
+        "object_models_coarse.3.nerf_model.features_head.6.weight": (192, 128),
+        "object_models_coarse.2.ray_bender.backbone_layers.3.weight": (128, 199),
+        "object_models_coarse.2.ray_bender.output_head.weight": (3, 128),
+        "object_models_coarse.2.ray_bender.positional_encoder.current_step": (),
+    }.items():
+        assert tuple(sd[key].shape) == shape, key
+    mc = ObjectComposer(configs.minecraft_config()).state_dict()
+    assert tuple(mc["object_models_coarse.1.nerf_model.backbone_layers.0.weight"].shape) == (256, 126)
+    assert tuple(mc["object_models_coarse.1.nerf_model.backbone_layers.4.weight"].shape) == (256, 382)
+    assert "object_models_coarse.1.nerf_model.alpha_head.weight" not in mc
+
+
+@pytest.mark.parametrize("path", GOLDEN[:3], ids=[os.path.basename(p)[:-4] for p in GOLDEN[:3]])
+def test_reference_state_dict_loads_strictly(path):
+    recipe, _, sd, _, _, _ = load_fixture(path)
+    comp = ObjectComposer(recipe_config(recipe))
+    comp.load_state_dict(sd, strict=True)
+
+
+def test_fine_models_follow_use_fine():
+    comp = ObjectComposer(configs.tennis_config())
+    assert all(m is None for m in comp.object_models_fine)
+    comp = ObjectComposer(configs.tennis_config(hierarchical=(64, 128)))
+    assert all(m is not None for m in comp.object_models_fine)
+    assert any(k.startswith("object_models_fine.") for k in comp.state_dict())
+
+
+def test_object_ids_helper_minecraft():
+    h = ObjectIDsHelper(configs.minecraft_config())
+    assert (h.objects_count, h.static_objects_count, h.dynamic_objects_count) == (4, 2, 2)
+    assert [h.model_idx_by_object_idx(k) for k in range(4)] == [0, 1, 2, 2]
+    assert h.object_idx_by_dynamic_object_idx(1) == 3
+    layout = ro.ObjectLayout(configs.minecraft_config())
+    assert layout.model_of_object == [0, 1, 2, 2] and layout.static_objects == 2
+
+
+def test_annealing_weights_match_oracle():
+    comp = ObjectComposer(configs.tennis_config())
+    for step in (0, 5000, 20000, 60000, 100000):
+        comp.set_step(step)
+        enc = comp.object_models_coarse[2].ray_bender.positional_encoder
+        want = ro.annealing_weights(torch.tensor(step, dtype=torch.int), 6, 60000)
+        assert torch.equal(enc.annealing_weights(), want)
+
+
+def test_strided_grid_matches_oracle_and_sizes():
+    rows, cols = strided_grid_pixels(288, 512, [4, 8])
+    r2, c2 = ro.strided_grid_pixels(288, 512, [4, 8])
+    assert rows.numel() == 72 * 128 + 36 * 64 == 11520
+    assert torch.equal(rows.long(), r2) and torch.equal(cols.long(), c2)
+    assert rows[0] == 2 and cols[1] == 6 and rows[72 * 128] == 4
+    with pytest.raises(Exception):
+        strided_grid_pixels(100, 100, [8])
+
+
+def test_renderer_refuses_cpu_tensors_and_training():
+    comp = ObjectComposer(configs.tennis_single_player_config()).eval()
+    o, d, n = torch.zeros(1, 1, 1, 3), torch.zeros(1, 1, 1, 8, 3), torch.zeros(1, 1, 1, 3)
+    args = (o, d, n, torch.eye(4).reshape(1, 1, 1, 4, 4, 1), torch.zeros(1, 1, 1, 64, 1), torch.zeros(1, 1, 1, 32, 1),
+            torch.ones(1, 1, 1, 1, dtype=torch.bool), False)
+    with pytest.raises(RuntimeError):
+        comp(*args)  # no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI
+# ------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(built_library):
+    header = open(os.path.join(ROOT, "include", "playrender.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(pr_\w+)\s*\(", header, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert getattr(built_library, name) is not None
+    assert built_library.pr_abi_version() == 1
+
+
+def test_struct_sizes_match_header_layout():
+    """ctypes mirrors must have the C sizes (pointer = 8, int32 = 4, natural alignment)."""
+    assert C.sizeof(_lib.Linear) == 24
+    assert C.sizeof(_lib.Entry) == 56
+    assert C.sizeof(_lib.ObjectModel) == 14 * 4 + 16 * 4 + 6 * 4 + 4 * 4 + 24 * 12 + 24 + 24 + (24 + 16) + 24 + (24 + 16) + 24 + 24 * 12 + 24
+
+
+def _model_struct_host(cfg_model, positions):
+    """ObjectModel with non-NULL dummy pointers: enough for the host-only size computations."""
+    comp = ObjectComposer({"data": {"focal_length_multiplier": 1.0},
+                           "model": {"apply_activation": False, "fix_object_overlaps": False, "static_object_models": 0,
+                                     "object_parameters_encoder": [{"objects_count": 1}], "object_encoders": [{}],
+                                     "object_models": [cfg_model]}})
+    return comp, comp._model_struct(comp.object_models_coarse[0], positions)
+
+
+def test_packed_and_workspace_sizes_on_host(built_library):
+    cfg = configs.tennis_config()
+    comp, s = _model_struct_host(cfg["model"]["object_models"][2], 32)
+    size = C.c_size_t()
+    assert built_library.pr_packed_size(C.byref(s), C.byref(size)) == 0
+    # fragment-ordered copy is the padded weight count: between 1x and 1.2x of the raw parameters
+    raw = sum(p.numel() for n, p in comp.named_parameters() if "affine_transform" not in n) * 4
+    assert raw <= size.value <= 1.2 * raw
+    call = _lib.Call()
+    call.frames, call.rays, call.objects = 1, 1000, 1
+    for f in ("ray_origins", "ray_directions", "w2o", "style", "deformation", "object_in_scene"):
+        setattr(call, f, 256)
+    call.linspace_coarse[0] = 256
+    objs = (_lib.Object * 1)()
+    objs[0].coarse = s
+    objs[0].packed_coarse = 256
+    ws = C.c_size_t()
+    assert built_library.pr_workspace_size(C.byref(call), objs, C.byref(ws)) == 0
+    per_sample = ws.value / (1000 * 32)
+    assert 192 * 4 <= per_sample <= 192 * 4 + 64  # feature row + dense per-sample state
+    call.rays = 0
+    assert built_library.pr_workspace_size(C.byref(call), objs, C.byref(ws)) != 0
+    assert b"empty call" in built_library.pr_last_error()
+
+
+def test_unsupported_configuration_is_rejected_loudly(built_library):
+    cfg = configs.tennis_config()
+    m = dict(cfg["model"]["object_models"][0])
+    m["nerf_model"] = dict(m["nerf_model"], layers_width=512)
+    _, s = _model_struct_host(m, 4)
+    size = C.c_size_t()
+    assert built_library.pr_packed_size(C.byref(s), C.byref(size)) != 0
+    assert b"layers_width" in built_library.pr_last_error()
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-process sharding (gloo, world_size 2)
+# ------------------------------------------------------------------------------------------------
+def _gloo_worker(rank, world, port, total, results):
+    import torch.distributed as dist
+    from playableenvironments_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = torch.arange(total * 3, dtype=torch.float32).reshape(1, total, 3)
+        b, e = parallel.shard_range(total, rank, world)
+        local = full[:, b:e] * 1.0
+        out = parallel.gather_ray_shards(local, total, dim=1, dst=0)
+        everyone = parallel.gather_ray_shards(local, total, dim=1, dst=None)
+        ok = torch.equal(everyone, full) and ((rank == 0 and torch.equal(out, full)) or (rank != 0 and out is None))
+        frames = parallel.shard_frames(torch.arange(5), rank, world)
+        ok = ok and frames.tolist() == ([0, 1, 2] if rank == 0 else [3, 4])
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 11])
+def test_ray_shard_gather_world2_gloo(total):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = 29500 + (os.getpid() % 200) + total
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, total, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert results[0] and results[1]
+
+
+def test_shard_range_partitions():
+    from playableenvironments_amd.parallel import shard_range
+    for total in (0, 1, 7, 8, 65536):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
