@@ -196,6 +196,15 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width,
 int pr_profile_enable(int enable);
 int pr_profile_collect(double* milliseconds, int32_t* launches);
 
+/*
+ * Measures the fp32 matrix-core rate this device sustains: every CU runs 8 waves of dependent
+ * v_mfma_f32_32x32x2_f32 chains (2 accumulators per wave, the occupancy of the renderer's MLP kernel)
+ * for `iterations` x 8 MFMAs; returns TFLOP/s from HIP events.  SYNCHRONISES the stream (probe only).
+ * random_operands != 0 feeds full-range pseudo-random mantissas that change every iteration (the
+ * chip sustains a lower matrix rate on such data than on constant operands).
+ */
+int pr_probe_mfma_f32(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream);
+
 /* Library / device introspection. */
 int pr_abi_version(void);
 const char* pr_last_error(void);

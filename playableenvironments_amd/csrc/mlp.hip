@@ -17,6 +17,7 @@
 #include "pr_common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace pr {
 
@@ -30,7 +31,7 @@ int compute_dims(const pr_object_model_t& m, ModelDims* d) {
     PR_REQUIRE(m.octaves >= 0 && m.octaves <= PR_MAX_OCTAVES, "octaves %d out of range", m.octaves);
     d->din = m.kind == 0 ? 3 : 6;
     d->enc = d->din + 2 * d->din * m.octaves;
-    d->enc_pad = round_up(d->enc, 8);
+    d->enc_pad = round_up(d->enc, 16);   // K loops advance two 8-wide steps per iteration
     d->W = m.layers_width;
     d->Wpad = round_up(d->W, 32);
     d->W2 = m.layers_width / 2;
@@ -50,7 +51,7 @@ int compute_dims(const pr_object_model_t& m, ModelDims* d) {
         PR_REQUIRE(m.bender_octaves >= 0 && m.bender_octaves <= PR_MAX_OCTAVES, "bender octaves out of range");
         d->benc = 3 + 6 * m.bender_octaves;
         d->bin = d->benc + m.deformation_features;
-        d->bin_pad = round_up(d->bin, 8);
+        d->bin_pad = round_up(d->bin, 16);
         d->BW = m.bender_width;
         d->BWpad = round_up(d->BW, 32);
         PR_REQUIRE(d->bin_pad <= MAX_ENC, "bender input width %d exceeds %d", d->bin, MAX_ENC);
@@ -299,15 +300,21 @@ int launch_adain_fold(const FoldParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Shared memory image of one tile
 // ---------------------------------------------------------------------------------------------
+constexpr int HEAD_SIGMA = MAX_WIDTH + 8;   // sigma weights (Wpad) + bias
+constexpr int HEAD_BENDER = 0;              // the 3-row bender head is read from L2 (players are few)
 struct Smem {
+    int uniform_frame;       // every row of the tile belongs to the same frame
+    int pad_[3];
+    float head_w[HEAD_SIGMA + HEAD_BENDER];
     float X[TILE_M * LDX];
     float E[TILE_M * LDE];
     float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
     int flat[TILE_M];
     int frame[TILE_M];
-    int alive[TILE_M];       // row holds a real sample that passed every AABB test
-    int valid[TILE_M];       // row holds a real sample
+    int flags[TILE_M];       // bit 0: row holds a real sample; bit 1: it passed every AABB test
 };
+static_assert(sizeof(Smem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "the workgroups of one CU must fit its LDS");
+
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -321,16 +328,67 @@ __device__ __forceinline__ float pe_element(const float* v, int din, int enc, in
     const int fn = rem / din;
     const int ax = rem - fn * din;
     const float arg = __fmul_rn(ldexpf(1.0f, k), v[ax]);
+#ifdef PR_FAST_TRIG_ABLATION
+    float e = fn ? __cosf(arg) : __sinf(arg);
+#else
     float e = fn ? cosf(arg) : sinf(arg);
+#endif
     if (octave_weights) e = __fmul_rn(e, octave_weights[k]);
     return e;
 }
 
+// Epilogue stores of one 32x32 accumulator block.  Lane (r, half) holds column r and the rows
+// (i & 3) + 8 (i >> 2) + 4 half, i = 0..15: constant LDS offsets from the lane's base pointer.
+#define PR_ACC_ROW(i) (((i) & 3) + 8 * ((i) >> 2))
+
+__device__ __forceinline__ void store_relu(const f32x16& acc, float* base) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) base[PR_ACC_ROW(i) * LDX] = acc[i] > 0.f ? acc[i] : 0.f;
+}
+
+__device__ __forceinline__ void store_adain_uniform(const f32x16& acc, float* base, float g, float b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = fmaf(acc[i], g, b);
+        base[PR_ACC_ROW(i) * LDX] = v > 0.f ? v : 0.f;
+    }
+}
+
+__device__ __forceinline__ void store_adain_rows(const f32x16& acc, Smem& S, const MlpParams& p, int row0, int col,
+                                             int goff, int boff) {
+    // rare path (tiles that straddle two frames): kept out of line and in chunks of four rows so that
+    // it does not inflate the register allocation of the hot loops
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float g[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* tab = p.adain + (size_t)S.frame[row0 + PR_ACC_ROW(4 * c + i)] * p.adain_stride;
+            g[i] = tab[goff];
+            b[i] = tab[boff];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaf(acc[4 * c + i], g[i], b[i]);
+            S.X[(row0 + PR_ACC_ROW(4 * c + i)) * LDX + col] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_plain(const f32x16& acc, float* base) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) base[PR_ACC_ROW(i) * LDX] = acc[i];
+}
+
 // One layer on the tile.  All 512 threads call it (two workgroup barriers inside).
+#define PR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
+    // > 4 column blocks: wave w owns block w for both 32-row blocks (the two accumulators share the
+    // weight fragment); otherwise the row blocks are split across waves as well
     const bool both = nblk > 4;
     int cb, rb;
     bool active;
@@ -352,70 +410,141 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             acc1[i] = bias;
         }
     }
-    if (active) {
+    if (active && !(p.debug & 128)) {
         for (int sidx = 0; sidx < L.nseg; ++sidx) {
             const Seg& sg = L.seg[sidx];
             const float* src = sg.src == 0 ? S.X : S.E;
             const int ld = sg.src == 0 ? LDX : LDE;
-            const int kq = sg.kq;
+            const int kq = sg.kq;   // even (K is padded to a multiple of 16)
             const float* ap = src + (rb * 32 + r) * ld + half * 4 * kq;
             const float4* wp = reinterpret_cast<const float4*>(sg.w) + (size_t)cb * kq * 64 + lane;
-            float4 b = wp[0];
+            // two steps in flight: even/odd fragments live in their own registers and are re-loaded
+            // right after their last use, a full step before they are needed again
+            float4 be = wp[0], bo = wp[64];
             if (both) {
-                for (int q = 0; q < kq; ++q) {
-                    const int qn = (q + 1 < kq) ? q + 1 : q;
-                    const float4 bn = wp[(size_t)qn * 64];
-                    const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
-                    const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * q);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
-                    b = bn;
+                float4 a0e = *reinterpret_cast<const float4*>(ap);
+                float4 a1e = *reinterpret_cast<const float4*>(ap + 32 * ld);
+                float4 a0o = *reinterpret_cast<const float4*>(ap + 4);
+                float4 a1o = *reinterpret_cast<const float4*>(ap + 32 * ld + 4);
+                for (int q = 0; q < kq; q += 2) {
+                    const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                    PR_MFMA(acc0, a0e.x, be.x);
+                    PR_MFMA(acc1, a1e.x, be.x);
+                    PR_MFMA(acc0, a0e.y, be.y);
+                    PR_MFMA(acc1, a1e.y, be.y);
+                    PR_MFMA(acc0, a0e.z, be.z);
+                    PR_MFMA(acc1, a1e.z, be.z);
+                    PR_MFMA(acc0, a0e.w, be.w);
+                    PR_MFMA(acc1, a1e.w, be.w);
+                    be = wp[(size_t)qe * 64];
+                    a0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                    a1e = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * qe);
+                    PR_MFMA(acc0, a0o.x, bo.x);
+                    PR_MFMA(acc1, a1o.x, bo.x);
+                    PR_MFMA(acc0, a0o.y, bo.y);
+                    PR_MFMA(acc1, a1o.y, bo.y);
+                    PR_MFMA(acc0, a0o.z, bo.z);
+                    PR_MFMA(acc1, a1o.z, bo.z);
+                    PR_MFMA(acc0, a0o.w, bo.w);
+                    PR_MFMA(acc1, a1o.w, bo.w);
+                    bo = wp[(size_t)qo * 64];
+                    a0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                    a1o = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * qo);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             } else {
-                for (int q = 0; q < kq; ++q) {
-                    const int qn = (q + 1 < kq) ? q + 1 : q;
-                    const float4 bn = wp[(size_t)qn * 64];
-                    const float4 a0 = *reinterpret_cast<const float4*>(ap + 4 * q);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
-                    b = bn;
+                float4 a0e = *reinterpret_cast<const float4*>(ap);
+                float4 a0o = *reinterpret_cast<const float4*>(ap + 4);
+                for (int q = 0; q < kq; q += 2) {
+                    const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                    PR_MFMA(acc0, a0e.x, be.x);
+                    PR_MFMA(acc0, a0e.y, be.y);
+                    PR_MFMA(acc0, a0e.z, be.z);
+                    PR_MFMA(acc0, a0e.w, be.w);
+                    be = wp[(size_t)qe * 64];
+                    a0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                    PR_MFMA(acc0, a0o.x, bo.x);
+                    PR_MFMA(acc0, a0o.y, bo.y);
+                    PR_MFMA(acc0, a0o.z, bo.z);
+                    PR_MFMA(acc0, a0o.w, bo.w);
+                    bo = wp[(size_t)qo * 64];
+                    a0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
         }
     }
+    if (p.debug & 4) return;  // ablation: no barriers, no epilogue
     __syncthreads();  // every wave has finished reading X / E
-    if (active) {
+    if (active && !(p.debug & 8)) {
         const int col = cb * 32 + r;
-        const int nrb = both ? 2 : 1;
-        for (int blk = 0; blk < nrb; ++blk) {
-            const f32x16& acc = blk == 0 ? acc0 : acc1;
-            const int row0 = (both ? blk : rb) * 32;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = row0 + acc_row(i, half);
-                float v = acc[i];
-                if (L.epi == EPI_RELU) {
-                    S.X[row * LDX + col] = v > 0.f ? v : 0.f;
-                } else if (L.epi == EPI_ADAIN_RELU) {
-                    const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + L.adain_off;
-                    v = fmaf(v, tab[col], tab[L.nblk * 32 + col]);
-                    S.X[row * LDX + col] = v > 0.f ? v : 0.f;
-                } else {
-                    if (S.valid[row] && col < L.n_real)
-                        p.feat[(size_t)(tile_base + row) * p.F + col] = S.alive[row] ? v : 0.f;
-                }
+        const int rowA = (both ? 0 : rb * 32) + 4 * half;   // first row of this lane in acc0
+        if (L.epi == EPI_RELU) {
+            store_relu(acc0, S.X + rowA * LDX + col);
+            if (both) store_relu(acc1, S.X + (rowA + 32) * LDX + col);
+        } else if (L.epi == EPI_ADAIN_RELU) {
+            const int bofs = L.nblk * 32;
+            if (S.uniform_frame) {
+                const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride + L.adain_off;
+                const float g = tab[col], b = tab[bofs + col];
+                store_adain_uniform(acc0, S.X + rowA * LDX + col, g, b);
+                if (both) store_adain_uniform(acc1, S.X + (rowA + 32) * LDX + col, g, b);
+            } else {
+                store_adain_rows(acc0, S, p, rowA, col, L.adain_off + col, L.adain_off + bofs + col);
+                if (both) store_adain_rows(acc1, S, p, rowA + 32, col, L.adain_off + col, L.adain_off + bofs + col);
             }
+        } else {
+            // last layer: stage the tile in X, the caller writes it out with coalesced 16-byte stores
+            store_plain(acc0, S.X + rowA * LDX + col);
+            if (both) store_plain(acc1, S.X + (rowA + 32) * LDX + col);
         }
     }
     __syncthreads();
+}
+
+// Positional encoding of every tile row into E (model/positional_encoder.py:54-64):
+//   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [enc, pad) are zeroed.
+// 8 threads per row, thread `part` takes the octaves part, part + 8, ... (one sincos per axis).
+__device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
+                                              const float* octave_weights, bool normalise) {
+    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float v[6];
+    for (int a = 0; a < din; ++a) {
+        const float x = S.pos[s * 8 + a];
+        v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+    }
+    float* row = S.E + s * LDE;
+    if (part == 0)
+        for (int a = 0; a < din; ++a) row[a] = v[a];
+    if (part == 1)
+        for (int j = zero_from; j < pad; ++j) row[j] = 0.f;
+    for (int k = part; k < octaves; k += 8) {
+        const float f = ldexpf(1.0f, k);
+        const float w = octave_weights ? octave_weights[k] : 1.0f;
+        float* dst = row + din + k * 2 * din;
+        for (int a = 0; a < din; ++a) {
+            const float arg = __fmul_rn(f, v[a]);
+            float sn, cs;
+            sn = sinf(arg);
+            cs = cosf(arg);
+            if (octave_weights) {
+                sn = __fmul_rn(sn, w);
+                cs = __fmul_rn(cs, w);
+            }
+            dst[a] = sn;
+            dst[din + a] = cs;
+        }
+    }
 }
 
 // dot products of every tile row with `nout` (<= 3) weight rows of length `width` (raw, padded),
@@ -436,13 +565,20 @@ __device__ __forceinline__ void row_dots(const Smem& S, const float* w, int widt
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
+    // stage the small head weights once: [0, Wpad] sigma weights + bias, then 3 rows of the bender head
+    for (int i = tid; i <= p.Wpad; i += MLP_THREADS) S.head_w[i] = p.sigma_w[i];
+    const bool bender_head_staged = p.has_bender && 3 * p.BWpad <= HEAD_BENDER;
+    if (bender_head_staged)
+        for (int i = tid; i < 3 * p.BWpad; i += MLP_THREADS) S.head_w[HEAD_SIGMA + i] = p.b_out[i];
+    __syncthreads();
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
+        if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
         if (tid < TILE_M) {
             const int idx = tile_base + tid;
@@ -452,8 +588,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
             const int frame = flat / p.samples_per_frame;
             S.flat[tid] = flat;
             S.frame[tid] = frame;
-            S.valid[tid] = valid ? 1 : 0;
-            S.alive[tid] = valid ? 1 : 0;
+            S.flags[tid] = valid ? 3 : 0;
             if (p.kind == 0) {
                 S.pos[tid * 8 + 0] = p.rec_pos[(size_t)src * 3 + 0];
                 S.pos[tid * 8 + 1] = p.rec_pos[(size_t)src * 3 + 1];
@@ -472,28 +607,20 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
             }
         }
         __syncthreads();
+        if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;   // visible after the next barrier
 
         // ---- ray bender -----------------------------------------------------------------------
         if (p.has_bender) {
-            for (int idx = tid; idx < TILE_M * p.bin_pad; idx += MLP_THREADS) {
-                const int s = idx / p.bin_pad, j = idx - s * p.bin_pad;
-                float v;
-                if (j < p.benc) {
-                    float xn[3];
-                    for (int a = 0; a < 3; ++a) xn[a] = __fdiv_rn(S.pos[s * 8 + a], p.size[a]);
-                    v = pe_element(xn, 3, p.benc, j, p.b_weights);
-                } else if (j < p.benc + p.D) {
-                    v = p.deformation[(size_t)S.frame[s] * p.deformation_stride + (j - p.benc)];
-                } else {
-                    v = 0.f;
-                }
-                S.E[s * LDE + j] = v;
+            fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true);
+            for (int idx = tid; idx < TILE_M * p.D; idx += MLP_THREADS) {
+                const int s = idx / p.D, j = idx - s * p.D;
+                S.E[s * LDE + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
             }
             __syncthreads();
             for (int l = 0; l < p.b_count; ++l) run_layer(p.b_layers[l], S, p, tile_base);
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
             float out[3];
-            row_dots(S, p.b_out, p.BWpad, p.BWpad, 3, out);
+            row_dots(S, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
             __syncthreads();
             if ((tid & 7) == 0) {
                 const int s = tid >> 3;
@@ -508,28 +635,19 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
                     bent[a] = __fadd_rn(x, dl);
                     S.pos[s * 8 + a] = bent[a];
                 }
-                if (S.valid[s]) {
+                if (S.flags[s] & 1) {
                     if (p.dispmag)
                         p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
                                                                __fmul_rn(d[2], d[2])));
                     // second AABB test on the bent position (adain_style_nerf_model.py:173-184)
-                    if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.alive[s] = 0;
+                    if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.flags[s] &= ~2;
                 }
             }
             __syncthreads();
         }
 
         // ---- positional encoding of the NeRF input --------------------------------------------
-        for (int idx = tid; idx < TILE_M * p.enc_pad; idx += MLP_THREADS) {
-            const int s = idx / p.enc_pad, j = idx - s * p.enc_pad;
-            float v[6];
-            if (p.kind == 0) {
-                for (int a = 0; a < 3; ++a) v[a] = __fdiv_rn(S.pos[s * 8 + a], p.size[a]);
-            } else {
-                for (int a = 0; a < 6; ++a) v[a] = S.pos[s * 8 + a];
-            }
-            S.E[s * LDE + j] = pe_element(v, p.din, p.enc, j, nullptr);
-        }
+        fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
         __syncthreads();
 
         // ---- backbone ---------------------------------------------------------------------------
@@ -538,17 +656,37 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_mfma(MlpParams p) {
         // ---- sigma head -------------------------------------------------------------------------
         if (p.kind == 0) {
             float sg;
-            row_dots(S, p.sigma_w, p.Wpad, p.Wpad, 1, &sg);
+            row_dots(S, S.head_w, p.Wpad, p.Wpad, 1, &sg);
             if ((tid & 7) == 0) {
                 const int s = tid >> 3;
-                if (S.valid[s] && S.alive[s]) p.sigma[S.flat[s]] = sg + p.sigma_w[p.Wpad];
+                if ((S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
             }
         } else if (tid < TILE_M) {
-            if (S.valid[tid]) p.sigma[S.flat[tid]] = 10.0f;
+            if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
         }
 
         // ---- style-modulated feature head -------------------------------------------------------
         for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
+
+        // ---- feature rows -> HBM (rows that failed the second AABB test are zero) -----------------
+        if ((p.F & 3) == 0) {
+            const int f4 = p.F >> 2;
+            for (int idx = tid; idx < TILE_M * f4; idx += MLP_THREADS) {
+                const int row = idx / f4, c = (idx - row * f4) * 4;
+                const int fl = S.flags[row];
+                if (fl & 1) {
+                    float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+                    if (!(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(p.feat + (size_t)(tile_base + row) * p.F + c) = v;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < TILE_M * p.F; idx += MLP_THREADS) {
+                const int row = idx / p.F, c = idx - row * p.F;
+                const int fl = S.flags[row];
+                if (fl & 1) p.feat[(size_t)(tile_base + row) * p.F + c] = (fl & 2) ? S.X[row * LDX + c] : 0.f;
+            }
+        }
     }
 }
 
@@ -665,6 +803,13 @@ int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_mo
         PR_LAUNCH_CHECK();
         return PR_OK;
     }
+    static int debug_bits = -1;
+    if (debug_bits < 0) {
+        const char* e = getenv("PR_MLP_DEBUG");
+        debug_bits = e ? atoi(e) : 0;
+    }
+    MlpParams pd = p;
+    pd.debug = debug_bits;
     static bool attr_set = false;
     if (!attr_set) {
         PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma),
@@ -676,9 +821,10 @@ int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_mo
         g_cu_count = prop.multiProcessorCount;
         attr_set = true;
     }
-    const int grid = max_tiles < g_cu_count ? max_tiles : g_cu_count;
+    const int resident = g_cu_count * MLP_BLOCKS_PER_CU;
+    const int grid = max_tiles < resident ? max_tiles : resident;
     ProfileScope scope(0, s);
-    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, p);
+    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }
@@ -773,6 +919,80 @@ int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const Packe
     return PR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA peak probe ("confirm the peak on the box with a pure-MFMA microbenchmark")
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_probe_mfma(int iterations, float* sink, int random_operands) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        acc0[i] = 0.f;
+        acc1[i] = 1.f;
+    }
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    unsigned int x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+    for (int it = 0; it < iterations; ++it) {
+        if (random_operands) {
+            // full-range mantissas that change every iteration (xorshift -> floats in [-1, 1))
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            a = __uint_as_float((x & 0x807FFFFFu) | 0x3F000000u);
+            b = __uint_as_float(((x * 2654435761u) & 0x807FFFFFu) | 0x3F000000u);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc1, 0, 0, 0);
+        if (random_operands && (it & 63) == 63) {
+            // keep the accumulators bounded so that the data stays "ordinary"
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc0[i] *= 0.001f;
+                acc1[i] *= 0.001f;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    if (s == 123.456f) sink[0] = s;  // keep the chain alive
+}
+
+}  // namespace pr
+
+extern "C" int pr_probe_mfma_f32(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream) {
+    PR_REQUIRE(iterations > 0 && tflops, "pr_probe_mfma_f32: bad argument");
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    float* sink = nullptr;
+    PR_CHECK_HIP(hipMalloc(&sink, sizeof(float)));
+    hipEvent_t e0, e1;
+    PR_CHECK_HIP(hipEventCreate(&e0));
+    PR_CHECK_HIP(hipEventCreate(&e1));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(512), 0, s, 16, sink, random_operands);  // warm-up
+    PR_CHECK_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(512), 0, s, iterations, sink, random_operands);
+    PR_CHECK_HIP(hipEventRecord(e1, s));
+    PR_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = (double)cus * 8 * (double)iterations * 8.0 * (2.0 * 32 * 32 * 2);
+    *tflops = flop / (ms * 1e-3) / 1e12;
+    if (milliseconds) *milliseconds = ms;
+    PR_CHECK_HIP(hipEventDestroy(e0));
+    PR_CHECK_HIP(hipEventDestroy(e1));
+    PR_CHECK_HIP(hipFree(sink));
+    return PR_OK;
+}
+
+namespace pr {
 }  // namespace pr
 
 // ---------------------------------------------------------------------------------------------

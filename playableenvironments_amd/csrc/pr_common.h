@@ -37,8 +37,9 @@ void set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 // Geometry of the MLP tiling
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_M = 64;        // samples per workgroup tile
-constexpr int MLP_WAVES = 8;      // 512 threads
+constexpr int TILE_M = 64;        // samples per workgroup tile (two 32-row MFMA blocks)
+constexpr int MLP_WAVES = 8;      // 512 threads, one workgroup per CU (LDS ~103 KB)
+constexpr int MLP_BLOCKS_PER_CU = 1;
 constexpr int MLP_THREADS = MLP_WAVES * 64;
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
@@ -135,6 +136,7 @@ struct MlpParams {
     const float* adain;          // table base for this object; row = frame
     int adain_stride;            // floats between frames
     int F;
+    int debug;                   // PR_MLP_DEBUG ablation bits (timing experiments only; results are wrong)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
