@@ -50,18 +50,41 @@ __device__ __forceinline__ float disparity_of(float depth, float opacity) {
 
 constexpr int MAX_FCHUNK = 4;  // F <= 256 channels, 64 lanes
 
+// weights[j] = alpha[j] * prod_{i<j} (1 - alpha[i] + 1e-10)  over al[0..n), in place.
+// Blocks of 64 consecutive entries are scanned across the wave (log steps), the running product is
+// carried from block to block.  (The reference's cumprod is sequential; the association differs at
+// the ulp level only.)
+__device__ __forceinline__ void transmittance_weights(float* al, int n, int lane) {
+    float carry = 1.0f;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const float a = (j < n) ? al[j] : 0.f;
+        float incl = (j < n) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl *= o;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (j < n) al[j] = a * (carry * excl);
+        carry *= __shfl(incl, 63, 64);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     extern __shared__ __attribute__((aligned(16))) char raw_smem[];
     const int S = p.sort_size;
     CompositeSmem sm;
+    const int A = (p.total_positions + 63) & ~63;   // per-entry arrays (the sort keys need the power of two S)
     sm.key = reinterpret_cast<unsigned long long*>(raw_smem);
     sm.tt = reinterpret_cast<float*>(sm.key + S);
-    sm.sg = sm.tt + S;
-    sm.dm = sm.sg + S;
-    sm.wo = sm.dm + S;
-    sm.wg = sm.wo + S;
-    sm.al = sm.wg + S;
-    sm.sl = reinterpret_cast<int*>(sm.al + S);
+    sm.sg = sm.tt + A;
+    sm.dm = sm.sg + A;
+    sm.wo = sm.dm + A;
+    sm.wg = sm.wo + A;
+    sm.al = sm.wg + A;
+    sm.sl = reinterpret_cast<int*>(sm.al + A);
 
     const int lane = threadIdx.x;
     const long g = blockIdx.x;
@@ -90,14 +113,9 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             sm.al[i] = alpha_of(raw, __fmul_rn(dt, norm));
         }
         __syncthreads();
-        if (lane == 0) {
-            float trans = 1.0f;
-            for (int i = 0; i < P; ++i) {
-                const float a = sm.al[i];
-                sm.wo[off + i] = __fmul_rn(a, trans);
-                trans = __fmul_rn(trans, __fadd_rn(__fsub_rn(1.0f, a), 1e-10f));
-            }
-        }
+        transmittance_weights(sm.al, P, lane);
+        __syncthreads();
+        for (int i = lane; i < P; i += 64) sm.wo[off + i] = sm.al[i];
         __syncthreads();
         float depth = 0.f, opacity = 0.f, dmag = 0.f;
         for (int i = lane; i < P; i += 64) {
@@ -202,14 +220,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
     }
     __syncthreads();
-    if (lane == 0) {
-        float trans = 1.0f;
-        for (int j = 0; j < PT; ++j) {
-            const float a = sm.al[j];
-            sm.al[j] = __fmul_rn(a, trans);   // al now holds the sorted-order weights
-            trans = __fmul_rn(trans, __fadd_rn(__fsub_rn(1.0f, a), 1e-10f));
-        }
-    }
+    transmittance_weights(sm.al, PT, lane);   // al now holds the sorted-order weights
     __syncthreads();
     {
         float depth = 0.f, opacity = 0.f, dmag = 0.f;
@@ -237,7 +248,12 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     __syncthreads();
 
     // ---- features: one pass over the compact MLP rows --------------------------------------------
+    // Per object the contributing samples (inside the box, non-zero weight) are first compacted into a
+    // list (the sort keys are dead by now, their storage is reused), then consumed four rows at a time
+    // so that several 768-byte row reads are in flight per wave.  Sums run in sample order.
     const int F = p.F;
+    int* lrow = reinterpret_cast<int*>(sm.key);
+    float* lw1 = reinterpret_cast<float*>(sm.key) + S;
     float accg[MAX_FCHUNK];
 #pragma unroll
     for (int c = 0; c < MAX_FCHUNK; ++c) accg[c] = 0.f;
@@ -245,23 +261,63 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     for (int k = 0; k < p.objects; ++k) {
         const CompositeObject& o = p.obj[k];
         const int P = o.positions;
+        __syncthreads();
+        int count = 0;
+        for (int base = 0; base < P; base += 64) {
+            const int i = base + lane;
+            bool take = false;
+            int row = -1;
+            float w1 = 0.f, w2 = 0.f;
+            if (i < P) {
+                row = sm.sl[off + i];
+                w1 = sm.wo[off + i];
+                w2 = sm.wg[off + i];
+                take = row >= 0 && (w1 != 0.f || w2 != 0.f);
+            }
+            const unsigned long long m = __ballot(take);
+            if (take) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                lrow[pos] = row;
+                lw1[pos] = w1;
+                sm.al[pos] = w2;
+            }
+            count += __popcll(m);
+        }
+        __syncthreads();
         float acco[MAX_FCHUNK];
 #pragma unroll
         for (int c = 0; c < MAX_FCHUNK; ++c) acco[c] = 0.f;
-        for (int i = 0; i < P; ++i) {
-            const int row = sm.sl[off + i];
-            if (row < 0) continue;
-            const float w1 = sm.wo[off + i], w2 = sm.wg[off + i];
-            if (w1 == 0.f && w2 == 0.f) continue;
-            const float* f = o.feat + (size_t)row * F;
+        int i = 0;
+        for (; i + 4 <= count; i += 4) {
+            float v[4][MAX_FCHUNK];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* f = o.feat + (size_t)lrow[i + u] * F;
+#pragma unroll
+                for (int c = 0; c < MAX_FCHUNK; ++c) {
+                    const int ch = lane + 64 * c;
+                    v[u][c] = (ch < F) ? f[ch] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w1 = lw1[i + u], w2 = sm.al[i + u];
+#pragma unroll
+                for (int c = 0; c < MAX_FCHUNK; ++c) {
+                    acco[c] = __fadd_rn(acco[c], __fmul_rn(w1, v[u][c]));
+                    accg[c] = __fadd_rn(accg[c], __fmul_rn(w2, v[u][c]));
+                }
+            }
+        }
+        for (; i < count; ++i) {
+            const float* f = o.feat + (size_t)lrow[i] * F;
+            const float w1 = lw1[i], w2 = sm.al[i];
 #pragma unroll
             for (int c = 0; c < MAX_FCHUNK; ++c) {
                 const int ch = lane + 64 * c;
-                if (ch < F) {
-                    const float v = f[ch];
-                    acco[c] = __fadd_rn(acco[c], __fmul_rn(w1, v));
-                    accg[c] = __fadd_rn(accg[c], __fmul_rn(w2, v));
-                }
+                const float v = (ch < F) ? f[ch] : 0.f;
+                acco[c] = __fadd_rn(acco[c], __fmul_rn(w1, v));
+                accg[c] = __fadd_rn(accg[c], __fmul_rn(w2, v));
             }
         }
         if (o.out.integrated_features) {
@@ -287,7 +343,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
     PR_REQUIRE(p.sort_size >= p.total_positions && (p.sort_size & (p.sort_size - 1)) == 0, "bad sort size");
     for (int k = 0; k < p.objects; ++k)
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
-    const size_t lds = (size_t)p.sort_size * (8 + 7 * 4);
+    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 7 * 4;
     PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
     static bool attr_set = false;
     if (!attr_set) {
