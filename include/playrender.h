@@ -181,9 +181,12 @@ int pr_render_forward(const pr_call_t* call, const pr_object_t* objects,
  * Camera rays (RayHelper.create_camera_rays + pixel selection + transform_rays, ray_helper.py:15-52,
  * :433-482, :1203-1227): for frame n and ray r with pixel (rows[r], cols[r]),
  *   d_cam = ((col - W/2)/f_n, -(row - H/2)/f_n, -1),  d_world = R_n d_cam,  o_world = t_n.
- * c2w (N,3,4); focals (N) already multiplied by focal_length_multiplier; rows/cols int32 (R).
+ * c2w (N,3,4); focals (N) already multiplied by focal_length_multiplier; rows/cols int32 (R), shared
+ * by all frames, or (N,R) - one pixel list per frame, as the random samplers of the reference produce
+ * (sample_rays_strided_patch :236, sample_rays_weighted :611, sample_rays :730) - when
+ * per_frame_pixels != 0.
  */
-int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width,
+int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, int32_t per_frame_pixels,
                    const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols,
                    float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
 

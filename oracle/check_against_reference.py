@@ -95,6 +95,42 @@ def grid_pixels(h, w, n):
     return rr.reshape(-1), cc.reshape(-1)
 
 
+def check_samplers():
+    """Pixel samplers: reference vs oracle vs product, index for index under a shared seed."""
+    from utils.lib_3d.ray_helper import RayHelper
+    from playableenvironments_amd import ray_sampling as rs
+    torch.manual_seed(0)
+    n, h, w, k = 5, 96, 160, 4
+    boxes = torch.rand(n, 4, k) * 0.5
+    boxes[:, 2:] = boxes[:, :2] + 0.1 + torch.rand(n, 2, k) * 0.4
+    boxes = boxes.clamp(0, 1)
+    weights = [0.55, 0.15, 0.15, 0.15]
+    dirs, obs = torch.randn(n, h, w, 3), torch.randn(n, 3, h, w)
+    pick = lambda idx: dirs.reshape(n, h * w, 3)[torch.arange(n).unsqueeze(1), idx]
+    ok = True
+    for patch, strides in ((16, [4, 8]), (8, [2, 4]), (12, [4])):
+        torch.manual_seed(1)
+        d_ref, _, p_ref = RayHelper.sample_rays_strided_patch(dirs, obs, patch, strides, boxes, weights, align_grid=True)
+        torch.manual_seed(1)
+        a = ro.strided_patch_pixels(boxes, weights, h, w, patch, strides)
+        torch.manual_seed(1)
+        b = rs.strided_patch_pixels(boxes, weights, h, w, patch, strides)
+        ok &= torch.equal(d_ref, pick(a)) and torch.equal(a, b) and torch.equal(rs.positions_from_indices(b, h, w), p_ref)
+    torch.manual_seed(2)
+    d_ref, _, p_ref = RayHelper.sample_rays_weighted(dirs, obs, 300, boxes, weights)
+    torch.manual_seed(2)
+    a = ro.sample_pixels_weighted(boxes, weights, h, w, 300)
+    torch.manual_seed(2)
+    b = rs.sample_pixels_weighted(boxes, weights, h, w, 300)
+    ok &= torch.equal(d_ref, pick(a)) and torch.equal(a, b) and torch.equal(rs.positions_from_indices(b, h, w), p_ref)
+    torch.manual_seed(3)
+    d_ref, _, _ = RayHelper.sample_rays(dirs, obs, 200)
+    torch.manual_seed(3)
+    ok &= torch.equal(d_ref, pick(rs.sample_pixels_uniform(n, h, w, 200, "cpu")))
+    print(f"[pixel samplers: strided patch x3, weighted, uniform] identical indices: {ok}")
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size cases (minutes)")
@@ -123,6 +159,7 @@ def main():
                    perturb=True, training=True, alpha_bias=3.0)[1]
     ok &= run_case("tennis hierarchical TRAIN perturb", th, synthetic.tennis_scene(seed=15),
                    pixels=grid_pixels(256, 256, 16), perturb=True, training=True, alpha_bias=2.0)[1]
+    ok &= check_samplers()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

@@ -718,6 +718,72 @@ def render_from_scene_encoding(config, sd, camera_rotations, camera_translations
                                     chunk, canonical_pose, training)
 
 
+# --------------------------------------------------------------------------------------------
+# Pixel samplers (utils/lib_3d/ray_helper.py), loop-for-loop restatements returning flat indices
+# --------------------------------------------------------------------------------------------
+
+def _sampler_weight_mask(boxes: Tensor, weights, height: int, width: int, guard: bool) -> Tensor:
+    """ray_helper.py:300-330 (patch sampler, no zero-area guard) / :655-675 (weighted sampler, guarded)."""
+    flat = boxes.reshape(-1, 4, boxes.size(-1)).clone()
+    flat[:, 0, :] = torch.floor(flat[:, 0, :] * width)
+    flat[:, 2, :] = torch.ceil(flat[:, 2, :] * width)
+    flat[:, 1, :] = torch.floor(flat[:, 1, :] * height)
+    flat[:, 3, :] = torch.ceil(flat[:, 3, :] * height)
+    masks = torch.zeros((flat.size(0), height, width))
+    for n in range(flat.size(0)):
+        for k in range(flat.size(-1)):
+            left, top, right, bottom = (int(flat[n, i, k].item()) for i in range(4))
+            area = (right - left) * (bottom - top)
+            if guard and area == 0:
+                continue
+            masks[n, top:bottom, left:right] += weights[k] / area
+    return masks.reshape(-1, height * width)
+
+
+def sample_pixels_weighted(boxes: Tensor, weights, height: int, width: int, samples: int) -> Tensor:
+    """RayHelper.sample_rays_weighted, ray_helper.py:611-728 -> (N, samples) flat pixel indices."""
+    mask = _sampler_weight_mask(boxes, weights, height, width, True)
+    out = []
+    for n in range(mask.size(0)):
+        cur = mask[n] / mask[n].sum()
+        cdf = torch.cumsum(cur, dim=0)
+        u = torch.rand((samples,))
+        out.append(torch.clamp(torch.searchsorted(cdf, u), max=cdf.size(0) - 1))
+    return torch.stack(out, 0)
+
+
+def strided_patch_pixels(boxes: Tensor, weights, height: int, width: int, patch_size: int, strides) -> Tensor:
+    """RayHelper.sample_rays_strided_patch (align_grid=True), ray_helper.py:236-431 -> (N, sum p_i^2)."""
+    s0, sm = strides[0], strides[-1]
+    sizes = [(patch_size * s0) // s for s in strides]
+    half = sizes[-1] // 2
+    mask = _sampler_weight_mask(boxes, weights, height, width, False)
+    backward = list(range(sm // 2, sm)) + list(range(0, sm // 2))
+    forward = list(range(sm // 2 + sm, sm, -1)) + [0] + list(range(sm - 1, sm // 2, -1))
+    out = []
+    for n in range(mask.size(0)):
+        cur = mask[n] / mask[n].sum()
+        cdf = torch.cumsum(cur, dim=0)
+        u = torch.rand((1,))
+        flat = int(torch.clamp(torch.searchsorted(cdf, u), max=cdf.size(0) - 1)[0].item())
+        row, col = flat // width, flat % width
+        row = min(height - sm * (half - 1) - 1, max(half * sm, row))
+        col = min(width - sm * (half - 1) - 1, max(half * sm, col))
+        start = [row - half * sm, col - half * sm]
+        for a in range(2):
+            diff = start[a] % sm
+            if diff != sm // 2:
+                start[a] = start[a] - backward[diff] if start[a] >= sm // 2 else start[a] + forward[diff]
+        idx = []
+        for s, size in zip(strides, sizes):
+            off = sm // 2 - s // 2
+            for r in range(start[0] - off, start[0] - off + s * size, s):
+                for c in range(start[1] - off, start[1] - off + s * size, s):
+                    idx.append(r * width + c)
+        out.append(torch.as_tensor(idx, dtype=torch.int64))
+    return torch.stack(out, 0)
+
+
 def psnr(a: Tensor, b: Tensor) -> float:
     """PSNR = -10 log10(mean((a-b)^2) + 1e-8) on [0,1]-ranged data.  evaluation/metrics/psnr.py:10-34."""
     mse = torch.mean((a - b) ** 2)

@@ -98,7 +98,7 @@ SYMBOLS = {
     "pr_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
     "pr_render_forward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(Outputs), C.POINTER(Outputs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
-    "pr_camera_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+    "pr_camera_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_profile_enable": (C.c_int, [C.c_int]),
     "pr_profile_collect": (C.c_int, [C.POINTER(C.c_double), c_int32_p]),

@@ -13,7 +13,7 @@ namespace pr {
 // Camera rays: RayHelper.create_camera_rays (utils/lib_3d/ray_helper.py:15-52), pixel selection
 // (:433-482 / all pixels) and transform_rays with the camera-to-world matrix (:1203-1227).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_camera_rays(int frames, int rays, float half_h, float half_w, const float* __restrict__ c2w,
+__global__ void k_camera_rays(int frames, int rays, int per_frame, float half_h, float half_w, const float* __restrict__ c2w,
                               const float* __restrict__ focals, const int32_t* __restrict__ rows,
                               const int32_t* __restrict__ cols, float* __restrict__ origins,
                               float* __restrict__ dirs, float* __restrict__ normals) {
@@ -24,8 +24,9 @@ __global__ void k_camera_rays(int frames, int rays, float half_h, float half_w, 
     const int r = (int)(g - (long)n * rays);
     const float* m = c2w + (size_t)n * 12;
     const float f = focals[n];
-    const float dx = __fdiv_rn(__fsub_rn((float)cols[r], half_w), f);
-    const float dy = -__fdiv_rn(__fsub_rn((float)rows[r], half_h), f);
+    const long pix = per_frame ? g : (long)r;
+    const float dx = __fdiv_rn(__fsub_rn((float)cols[pix], half_w), f);
+    const float dy = -__fdiv_rn(__fsub_rn((float)rows[pix], half_h), f);
     const float dz = -1.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -372,8 +373,8 @@ int launch_resample(const ResampleParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, const float* c2w,
-                              const float* focals, const int32_t* rows, const int32_t* cols, float* ray_origins,
+extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, int32_t per_frame_pixels,
+                              const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols, float* ray_origins,
                               float* ray_directions, float* focal_normals, void* stream) {
     PR_REQUIRE(frames > 0 && rays > 0, "pr_camera_rays: empty call (%d frames, %d rays)", frames, rays);
     PR_REQUIRE(c2w && focals && rows && cols && ray_origins && ray_directions && focal_normals,
@@ -381,7 +382,7 @@ extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int3
     const long total = (long)frames * rays;
     const int blocks = (int)((total + 255) / 256);
     // width / 2 and height / 2 are Python floats in the reference (true division)
-    hipLaunchKernelGGL(pr::k_camera_rays, dim3(blocks), dim3(256), 0, (hipStream_t)stream, frames, rays,
+    hipLaunchKernelGGL(pr::k_camera_rays, dim3(blocks), dim3(256), 0, (hipStream_t)stream, frames, rays, per_frame_pixels,
                        (float)height / 2.0f, (float)width / 2.0f, c2w, focals, rows, cols, ray_origins,
                        ray_directions, focal_normals);
     PR_LAUNCH_CHECK();

@@ -21,7 +21,7 @@ from typing import Dict, List, Tuple
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ray_sampling
 from .object_composer import ObjectComposer, ObjectIDsHelper
 
 
@@ -66,7 +66,8 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
                 cols: torch.Tensor):
     """World-frame rays of the selected pixels through ``pr_camera_rays``.
 
-    c2w (..., 4, 4); focals (...) (already rescaled); rows / cols int (R).
+    c2w (..., 4, 4); focals (...) (already rescaled); rows / cols int (R) shared by all frames, or
+    (..., R) with one pixel list per frame.
     Returns origins (..., 3), directions (..., R, 3), focal normals (..., 3)."""
     if not c2w.is_cuda:
         raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
@@ -75,14 +76,18 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     dev = c2w.device
     m = c2w.detach().to(torch.float32).reshape(n, 4, 4)[:, :3, :].contiguous()
     f = torch.broadcast_to(focals.detach().to(torch.float32), lead).reshape(n).contiguous()
+    per_frame = rows.dim() > 1
+    r = rows.size(-1)
+    if per_frame:
+        rows = torch.broadcast_to(rows, lead + [r]).reshape(n, r)
+        cols = torch.broadcast_to(cols, lead + [r]).reshape(n, r)
     rows = rows.to(device=dev, dtype=torch.int32).contiguous()
     cols = cols.to(device=dev, dtype=torch.int32).contiguous()
-    r = rows.numel()
     origins = torch.empty((n, 3), dtype=torch.float32, device=dev)
     dirs = torch.empty((n, r, 3), dtype=torch.float32, device=dev)
     normals = torch.empty((n, 3), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.pr_camera_rays(n, r, height, width, m.data_ptr(), f.data_ptr(), rows.data_ptr(), cols.data_ptr(),
+    _lib.check(lib.pr_camera_rays(n, r, height, width, 1 if per_frame else 0, m.data_ptr(), f.data_ptr(), rows.data_ptr(), cols.data_ptr(),
                                   origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
                                   torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
     return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
@@ -237,19 +242,22 @@ class EnvironmentModel(nn.Module):
         boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, rescaled_focals * upsample_factor, height, width)
         axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
 
+        lead = list(camera_rotations.shape[:-1])
+        flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
         if patch_size != 0 and samples_per_image != 0:
-            raise NotImplementedError("strided-patch ray sampling (training) is not implemented yet in the HIP renderer")
+            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
+            rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
         elif patch_stride and samples_per_image == 0:
             rows, cols = strided_grid_pixels(height, width, patch_stride)
         elif samples_per_image == 0:
             r = torch.arange(height * width, dtype=torch.int32)
             rows, cols = r // width, r % width
         elif self.use_weighted_sampling:
-            raise NotImplementedError("bounding-box weighted ray sampling is not implemented yet in the HIP renderer")
+            idx = ray_sampling.sample_pixels_weighted(flat_boxes, self.sampling_weights, height, width, samples_per_image)
+            rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
         else:
-            # RayHelper.sample_rays (ray_helper.py:730-795): a random subset of pixels, the same for all frames
-            perm = torch.randperm(height * width)[:samples_per_image].to(torch.int32)
-            rows, cols = perm // width, perm % width
+            idx = ray_sampling.sample_pixels_uniform(flat_boxes.size(0), height, width, samples_per_image, boxes.device)
+            rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
 
         origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
 

@@ -277,3 +277,48 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+# ------------------------------------------------------------------------------------------------
+# pixel samplers (a2): the product's vectorised index logic against the oracle's loop restatement
+# ------------------------------------------------------------------------------------------------
+def _random_boxes(n, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.rand(n, 4, k, generator=g) * 0.5
+    boxes[:, 2:] = boxes[:, :2] + 0.1 + torch.rand(n, 2, k, generator=g) * 0.4
+    return boxes.clamp(0, 1)
+
+
+@pytest.mark.parametrize("patch,strides", [(16, [4, 8]), (8, [2, 4]), (12, [4]), (64, [4, 8])])
+def test_strided_patch_sampler_matches_oracle(patch, strides):
+    from playableenvironments_amd import ray_sampling as rs
+    h, w = (288, 512) if patch == 64 else (96, 160)
+    boxes = _random_boxes(4, 4, patch)
+    weights = [0.55, 0.15, 0.15, 0.15]
+    torch.manual_seed(5)
+    want = ro.strided_patch_pixels(boxes, weights, h, w, patch, strides)
+    torch.manual_seed(5)
+    got = rs.strided_patch_pixels(boxes, weights, h, w, patch, strides)
+    assert torch.equal(want, got)
+    sm = strides[-1]
+    rows, cols = got // w, got % w
+    assert int(rows.min()) >= 0 and int(rows.max()) < h and int(cols.min()) >= 0 and int(cols.max()) < w
+    # the coarsest grid is aligned to the centres of the (s_M x s_M) pixel cells
+    last = (patch * strides[0] // sm) ** 2
+    assert ((rows[:, -last:] % sm) == sm // 2).all() and ((cols[:, -last:] % sm) == sm // 2).all()
+    assert got.shape[1] == sum((patch * strides[0] // s) ** 2 for s in strides)
+
+
+def test_weighted_sampler_matches_oracle_and_prefers_boxes():
+    from playableenvironments_amd import ray_sampling as rs
+    boxes = _random_boxes(3, 4, 11)
+    boxes[0, :, 2] = torch.tensor([0.3, 0.3, 0.3, 0.3])  # an empty box must be skipped (zero-area guard)
+    weights = [0.0, 0.7, 0.15, 0.15]
+    torch.manual_seed(7)
+    want = ro.sample_pixels_weighted(boxes, weights, 64, 80, 500)
+    torch.manual_seed(7)
+    got = rs.sample_pixels_weighted(boxes, weights, 64, 80, 500)
+    assert torch.equal(want, got)
+    r, c = (got[1] // 80).float() / 64, (got[1] % 80).float() / 80
+    inside = ((c >= boxes[1, 0, 1:].min() - 0.02) & (r >= boxes[1, 1, 1:].min() - 0.02)).float().mean()
+    assert inside > 0.99

@@ -251,3 +251,37 @@ def test_environment_model_scene_encoding_modes():
     assert tuple(got["projected_axes"].shape) == (1, 2, 1, 4, 2, 4)
     with pytest.raises(NotImplementedError):
         model(*gargs, 0, False, mode="observations")
+
+
+def test_training_shaped_patch_call_config5_shape():
+    """BASELINE.json configs[4] forward shape: minecraft, patch 48 @ strides [4, 8] -> 48^2 + 24^2 = 2880 rays per
+    frame, perturb=True, 3 observations.  Per-frame pixel lists go through pr_camera_rays (bitwise check) and the
+    composer result has the reference's shapes."""
+    from playableenvironments_amd import ray_sampling as rs
+    cfg = configs.minecraft_config()
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=3.0, bender_scale=1e4)
+    model = model.eval().cuda()
+    scene = synthetic.minecraft_scene(batch=2, observations=3, seed=81, image_size=(288, 512))
+    args = [scene[k] for k in ("camera_rotations", "camera_translations", "focals")] + [scene["image_size"]] + \
+           [scene[k] for k in ("object_rotation_parameters", "object_translation_parameters", "object_style",
+                               "object_deformation", "object_in_scene")]
+    gargs = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    with torch.no_grad():
+        torch.manual_seed(4)
+        out = model(*gargs, 150, True, patch_size=48, patch_stride=[4, 8], mode="scene_encodings")
+    feats = out["coarse"]["global"]["integrated_features"]
+    assert tuple(feats.shape) == (2, 3, 1, 2880, 192) and torch.isfinite(feats).all()
+    assert tuple(out["coarse"]["object_3"]["weights"].shape) == (2, 3, 1, 2880, 32)
+    # per-frame pixel lists: the kernel must reproduce the oracle's gather of the full ray grid bit for bit
+    boxes = out["reconstructed_bounding_boxes"].reshape(-1, 4, 4).cpu()
+    torch.manual_seed(9)
+    idx = rs.strided_patch_pixels(boxes, cfg["model"]["sampling_weights"], 288, 512, 48, [4, 8])
+    rows, cols = rs.split_indices(idx.reshape(2, 3, 1, -1), 512)
+    c2w = ro.euler_to_matrix(scene["camera_rotations"], scene["camera_translations"])
+    f = scene["focals"] * cfg["data"]["focal_length_multiplier"]
+    go, gd, gn = em.camera_rays(c2w.cuda(), f.cuda(), 288, 512, rows, cols)
+    dirs, o, n = ro.create_camera_rays([2, 3, 1], 288, 512, f)
+    dirs = dirs.reshape(6, 288 * 512, 3)[torch.arange(6).unsqueeze(1), idx].reshape(2, 3, 1, -1, 3)
+    wo, wd, wn = ro.transform_rays(o, dirs, n, c2w)
+    assert torch.equal(gd.cpu(), wd) and torch.equal(go.cpu(), wo)
