@@ -6,8 +6,8 @@ Workload (per GPU): the tennis renderer (4 objects) with the hierarchical overri
 (65 536 rays) of the seeded synthetic tennis scene, eval mode, fp32.  A "step" is one full render
 from the scene encoding (camera, object poses, style, deformation - resident in HBM) to the result
 tensors of ``EnvironmentModel.forward(mode="scene_encodings")``.  With N GPUs every rank renders
-its own frame (weak scaling) and the rendered ``fine.global.integrated_features`` maps are gathered
-on rank 0 with one RCCL collective inside the timed region.
+its own frame (weak scaling) and the rendered ``fine.global.integrated_features`` maps are exchanged
+with one RCCL all_gather inside the timed region.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the fused fp32-MFMA MLP,
 ``k_mlp_mfma``): algorithmic FLOPs per launch (in-box samples actually evaluated x
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--image", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=32, help="the CPU baseline renders a cpu_rays x cpu_rays pixel grid")
+    ap.add_argument("--cpu-rays", type=int, default=64, help="the CPU baseline renders a cpu_rays x cpu_rays pixel grid")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (all 256 host cores are >50x SLOWER on these small ops)")
     args = ap.parse_args()
@@ -96,8 +96,10 @@ def main():
                         0, False, mode="scene_encodings")
         feats = out["fine"]["global"]["integrated_features"]
         if world > 1:
-            gathered = [torch.empty_like(feats) for _ in range(world)] if rank == 0 else None
-            dist.gather(feats, gathered, dst=0)
+            # one RCCL collective for the rendered feature maps (50 MB per frame); every rank receives
+            # the stack, rank 0 is the consumer (decoder / writer) in the reference's evaluation flow
+            gathered = torch.empty((world,) + tuple(feats.shape), dtype=feats.dtype, device=feats.device)
+            dist.all_gather_into_tensor(gathered, feats.contiguous())
         return out
 
     lib = _lib.load()
@@ -147,6 +149,19 @@ def main():
         for k in range(helper.objects_count):
             flops += float(ev[k]) * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
 
+    # HBM traffic of the dominant kernel from the committed PMC pass (collected separately: counters
+    # cannot ride along with the timed run), and the fp32 MFMA rate this box sustains
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path) and size == (256, 256):
+        with open(pmc_path) as f:
+            traffic = json.load(f)["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
+    probe = {}
+    for name, rnd in (("constant_operands", 0), ("random_operands", 1)):
+        tf, pms = C.c_double(), C.c_double()
+        _lib.check(lib.pr_probe_mfma_f32(100000, rnd, C.byref(tf), C.byref(pms), None), "pr_probe_mfma_f32")
+        probe[name] = round(tf.value, 1)
+
     rays_per_gpu = size[0] * size[1]
     total_rays = rays_per_gpu * world * args.steps
     value = total_rays / elapsed / 1e6
@@ -170,7 +185,7 @@ def main():
                         "(coarse+fine networks), eval - BASELINE.json configs[1]",
             "rays_per_gpu": rays_per_gpu,
             "frames_per_gpu": 1,
-            "parallelism": f"frame shard x{world}" + (" + RCCL gather of feature maps" if world > 1 else ""),
+            "parallelism": f"frame shard x{world}" + (" + RCCL all_gather of feature maps" if world > 1 else ""),
         },
         "frames_per_s_256x256": round(value * 1e6 / 65536.0, 3),
         "roofline": {
@@ -180,7 +195,9 @@ def main():
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (average over the launches of a step), rocprofv3 PMC pass, profiles/r01_pmc_traffic.json",
+            "peak_measured": probe,
             "flop_per_step": flops,
             "mlp_ms_per_step": round(mlp_ms, 3),
             "mlp_launches_per_step": int(launches[0] / max(1, args.steps)),

@@ -102,6 +102,7 @@ class ObjectComposer(nn.Module):
                                       "renderer; both shipped configurations use False")
         self.object_id_helper = ObjectIDsHelper(self.config)
         self._packed: Dict[int, tuple] = {}
+        self._annealing: Dict[int, tuple] = {}
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
@@ -167,13 +168,23 @@ class ObjectComposer(nn.Module):
             s.bender_count = bender.layers_count
             s.bender_skip = bender.skip_layer_idx
             s.bender_octaves = bender.positional_encoder.octaves_count
-            w = bender.positional_encoder.annealing_weights().detach().cpu().tolist()
-            for i, v in enumerate(w):
+            for i, v in enumerate(self._annealing_weights(bender.positional_encoder)):
                 s.bender_octave_weights[i] = v
             for i, layer in enumerate(bender.backbone_layers):
                 s.bender[i] = _linear(layer)
             s.bender_out = _linear(bender.output_head)
         return s
+
+    def _annealing_weights(self, encoder) -> list:
+        """Host copy of the bender's octave weights, refreshed only when ``current_step`` changed (reading the
+        buffer back is a device sync, which must not happen on every render call)."""
+        step = encoder.current_step
+        key = (id(encoder), step.data_ptr(), step._version)
+        cached = self._annealing.get(id(encoder))
+        if cached is None or cached[0] != key:
+            cached = (key, encoder.annealing_weights().detach().cpu().tolist())
+            self._annealing[id(encoder)] = cached
+        return cached[1]
 
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
