@@ -48,6 +48,9 @@ typedef enum pr_status {
 #define PR_FLAG_CANONICAL_POSE 2u   /* zero the ray-bender displacements (canonical_pose=True) */
 #define PR_FLAG_FIX_OVERLAPS   4u   /* config["model"]["fix_object_overlaps"] */
 #define PR_FLAG_NAIVE_MLP      8u   /* debugging: scalar one-thread-per-sample MLP kernel instead of MFMA */
+#define PR_FLAG_TRAIN_BN       16u  /* module.training: the AdaIN BatchNorm1d layers normalise with batch statistics of
+                                       the evaluated samples of each object call and update running_mean / running_var /
+                                       num_batches_tracked in place (model/layers/adain.py:47,58) */
 
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
@@ -88,12 +91,14 @@ typedef struct pr_object_model_t {
     pr_linear_t alpha_head;          /* weight == NULL for the skybox (sigma == 10) */
     pr_linear_t head0;               /* features_head.0, no bias */
     pr_linear_t affine1;             /* features_head.1.affine_transform (2*W, S) */
-    const float* bn1_mean;           /* features_head.1.ada_in.normalization.running_mean (W) */
-    const float* bn1_var;
+    float* bn1_mean;                 /* features_head.1.ada_in.normalization.running_mean (W); written with PR_FLAG_TRAIN_BN */
+    float* bn1_var;
+    int64_t* bn1_batches;            /* ...num_batches_tracked (int64 scalar) or NULL */
     pr_linear_t head3;               /* features_head.3, no bias (W/2, W) */
     pr_linear_t affine4;             /* features_head.4.affine_transform (W, S) */
-    const float* bn4_mean;
-    const float* bn4_var;
+    float* bn4_mean;
+    float* bn4_var;
+    int64_t* bn4_batches;
     pr_linear_t head6;               /* features_head.6 (F, W/2) */
     /* ray_bender.* (ignored when has_bender == 0) */
     pr_linear_t bender[PR_MAX_LAYERS];
@@ -143,6 +148,7 @@ typedef struct pr_outputs_t {
     float* sample_sigma[PR_MAX_OBJECTS];      /* (N,R,P_k) raw sigma incl. empty_space_alpha fill */
     int32_t* sample_slot[PR_MAX_OBJECTS];     /* (N,R,P_k) compact row of the sample, -1 = outside the box */
     int32_t* evaluated_samples;               /* (K) number of samples sent through the MLP */
+    int32_t* normalised_samples;              /* (K) PR_FLAG_TRAIN_BN: samples that entered the batch statistics */
 } pr_outputs_t;
 
 typedef struct pr_call_t {

@@ -17,6 +17,7 @@ PR_FLAG_PERTURB = 1
 PR_FLAG_CANONICAL_POSE = 2
 PR_FLAG_FIX_OVERLAPS = 4
 PR_FLAG_NAIVE_MLP = 8
+PR_FLAG_TRAIN_BN = 16
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -40,9 +41,9 @@ class ObjectModel(C.Structure):
         ("backbone", Linear * PR_MAX_LAYERS),
         ("alpha_head", Linear),
         ("head0", Linear),
-        ("affine1", Linear), ("bn1_mean", C.c_void_p), ("bn1_var", C.c_void_p),
+        ("affine1", Linear), ("bn1_mean", C.c_void_p), ("bn1_var", C.c_void_p), ("bn1_batches", C.c_void_p),
         ("head3", Linear),
-        ("affine4", Linear), ("bn4_mean", C.c_void_p), ("bn4_var", C.c_void_p),
+        ("affine4", Linear), ("bn4_mean", C.c_void_p), ("bn4_var", C.c_void_p), ("bn4_batches", C.c_void_p),
         ("head6", Linear),
         ("bender", Linear * PR_MAX_LAYERS),
         ("bender_out", Linear),
@@ -75,7 +76,7 @@ class Outputs(C.Structure):
     _fields_ = [
         ("object", Entry * PR_MAX_OBJECTS), ("global_", Entry),
         ("sample_t", C.c_void_p * PR_MAX_OBJECTS), ("sample_sigma", C.c_void_p * PR_MAX_OBJECTS),
-        ("sample_slot", C.c_void_p * PR_MAX_OBJECTS), ("evaluated_samples", C.c_void_p),
+        ("sample_slot", C.c_void_p * PR_MAX_OBJECTS), ("evaluated_samples", C.c_void_p), ("normalised_samples", C.c_void_p),
     ]
 
 

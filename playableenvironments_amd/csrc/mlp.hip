@@ -565,6 +565,54 @@ __device__ __forceinline__ void row_dots(const Smem& S, const float* w, int widt
     }
 }
 
+// Tile rows staged in X -> HBM with coalesced 16-byte stores (width % 4 == 0) or scalar stores.
+// zero_dead: rows that failed the second AABB test are written as zeros (feature rows).
+__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead) {
+    const int tid = threadIdx.x;
+    if ((width & 3) == 0 && (stride & 3) == 0) {
+        const int w4 = width >> 2;
+        for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            const int fl = S.flags[row];
+            if (fl & 1) {
+                float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+                if (zero_dead && !(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(dst + (size_t)(tile_base + row) * stride + c) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TILE_M * width; idx += MLP_THREADS) {
+            const int row = idx / width, c = idx - row * width;
+            const int fl = S.flags[row];
+            if (fl & 1) dst[(size_t)(tile_base + row) * stride + c] = (zero_dead && !(fl & 2)) ? 0.f : S.X[row * LDX + c];
+        }
+    }
+}
+
+// Per-channel sum and sum of squares of the alive rows of the tile staged in X -> global double
+// accumulators (one atomic per channel and tile); the number of alive rows is counted alongside.
+__device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams& p) {
+    const int tid = threadIdx.x;
+    for (int c = tid; c < p.h_out_width; c += MLP_THREADS) {
+        double s1 = 0.0, s2 = 0.0;   // double: var = E[x^2] - mean^2 cancels badly in fp32 when |mean| >> std
+        for (int row = 0; row < TILE_M; ++row) {
+            if ((S.flags[row] & 3) == 3) {
+                const double x = (double)S.X[row * LDX + c];
+                s1 += x;
+                s2 = fma(x, x, s2);
+            }
+        }
+        atomicAdd(p.stats + c, s1);
+        atomicAdd(p.stats + p.h_out_width + c, s2);
+    }
+    if (tid == 0 && p.phase == 1) {
+        int alive = 0;
+        for (int row = 0; row < TILE_M; ++row) alive += (S.flags[row] & 3) == 3;
+        atomicAdd(p.stat_count, alive);
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
@@ -666,28 +714,90 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         }
 
         // ---- style-modulated feature head -------------------------------------------------------
-        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
-
-        // ---- feature rows -> HBM (rows that failed the second AABB test are zero) -----------------
-        if ((p.F & 3) == 0) {
-            const int f4 = p.F >> 2;
-            for (int idx = tid; idx < TILE_M * f4; idx += MLP_THREADS) {
-                const int row = idx / f4, c = (idx - row * f4) * 4;
-                const int fl = S.flags[row];
-                if (fl & 1) {
-                    float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
-                    if (!(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(p.feat + (size_t)(tile_base + row) * p.F + c) = v;
-                }
-            }
+        if (p.phase == 0) {
+            for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
+            write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
+            __syncthreads();   // the next tile's prologue overwrites flags / X
         } else {
-            for (int idx = tid; idx < TILE_M * p.F; idx += MLP_THREADS) {
-                const int row = idx / p.F, c = idx - row * p.F;
-                const int fl = S.flags[row];
-                if (fl & 1) p.feat[(size_t)(tile_base + row) * p.F + c] = (fl & 2) ? S.X[row * LDX + c] : 0.f;
-            }
+            // train mode, phase 1: stop after the first head matmul; the raw activations go to HBM and
+            // their per-channel sums feed the batch statistics
+            Layer raw = p.layers[p.n_backbone];
+            raw.epi = EPI_FEATURES;   // plain store into X
+            run_layer(raw, S, p, tile_base);
+            if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
+            write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
+            accumulate_stats(S, p);
         }
     }
+}
+
+// Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
+// affine built from the BATCH statistics + ReLU, run the next head matmul.
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = *p.total;
+    const Layer& prev = p.layers[p.n_backbone + p.phase - 2];   // the layer whose output is h_in
+    const Layer& cur = p.layers[p.n_backbone + p.phase - 1];
+    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+        const int tile_base = tile * TILE_M;
+        if (tid < TILE_M) {
+            const int idx = tile_base + tid;
+            const bool valid = idx < total;
+            const int src = valid ? idx : tile_base;
+            S.flat[tid] = p.rec_flat[src];
+            S.frame[tid] = S.flat[tid] / p.samples_per_frame;
+            S.flags[tid] = valid ? p.row_flags[src] : 0;
+        }
+        __syncthreads();
+        const int wq = p.h_in_width >> 2;
+        for (int idx = tid; idx < TILE_M * wq; idx += MLP_THREADS) {
+            const int row = idx / wq, c = (idx - row * wq) * 4;
+            const int src = (tile_base + row < total) ? tile_base + row : tile_base;
+            const float4 h = *reinterpret_cast<const float4*>(p.h_in + (size_t)src * p.h_in_width + c);
+            const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + prev.adain_off;
+            const float4 g = *reinterpret_cast<const float4*>(tab + c);
+            const float4 b = *reinterpret_cast<const float4*>(tab + prev.nblk * 32 + c);
+            float4 y;
+            y.x = fmaf(h.x, g.x, b.x); y.y = fmaf(h.y, g.y, b.y); y.z = fmaf(h.z, g.z, b.z); y.w = fmaf(h.w, g.w, b.w);
+            y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f; y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
+            *reinterpret_cast<float4*>(S.X + row * LDX + c) = y;
+        }
+        __syncthreads();
+        Layer raw = cur;
+        raw.epi = EPI_FEATURES;   // plain store into X
+        run_layer(raw, S, p, tile_base);
+        if (p.phase == 2) {
+            write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
+            accumulate_stats(S, p);
+        } else {
+            write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.width) return;
+    const double n = (double)*p.count;
+    const double mean = p.stats[c] / n;
+    double var = p.stats[p.width_pad + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = var * n / (n - 1.0);   // NaN / inf for n <= 1, where the reference raises
+    p.batch_mean[c] = (float)mean;
+    p.batch_var[c] = (float)var;
+    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+    if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+}
+
+int launch_bn_finalize(const BnFinalizeParams& p, hipStream_t s) {
+    PR_REQUIRE(p.running_mean && p.running_var && p.batch_mean && p.batch_var && p.stats && p.count, "bn finalize: NULL pointer");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((p.width + 255) / 256), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,7 +934,17 @@ int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_mo
     const int resident = g_cu_count * MLP_BLOCKS_PER_CU;
     const int grid = max_tiles < resident ? max_tiles : resident;
     ProfileScope scope(0, s);
-    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
+    if (pd.phase >= 2) {
+        static bool head_attr_set = false;
+        if (!head_attr_set) {
+            PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_head),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+            head_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_mlp_head, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
+    } else {
+        hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
+    }
     PR_LAUNCH_CHECK();
     return PR_OK;
 }

@@ -137,6 +137,14 @@ struct MlpParams {
     int adain_stride;            // floats between frames
     int F;
     int debug;                   // PR_MLP_DEBUG ablation bits (timing experiments only; results are wrong)
+    // train-mode BatchNorm (batch statistics sit between the head matmuls -> three phases, see mlp.hip)
+    int phase;                   // 0 = eval (everything fused); 1 = ... -> raw h1; 2 = h1 -> raw h2; 3 = h2 -> features
+    float* h_out;                // phase 1/2: raw (pre-BN) head activations, (cap, h_out_width)
+    const float* h_in;           // phase 2/3: the previous phase's h_out
+    int h_out_width, h_in_width; // padded widths
+    int32_t* row_flags;          // (cap) bit 0 valid, bit 1 passed every AABB test; written in phase 1
+    double* stats;               // phase 1/2: [sum(h_out_width) | sum of squares(h_out_width)] over the alive rows
+    int32_t* stat_count;         // number of alive rows (written in phase 1)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
@@ -219,6 +227,22 @@ struct FoldParams {
 int launch_adain_fold(const FoldParams& p, hipStream_t s);
 
 int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s);
+
+// BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
+// running statistics updated in place with momentum 0.1 and the unbiased variance, num_batches_tracked += 1
+// (torch.nn.functional.batch_norm semantics, model/layers/adain.py:47,58).
+struct BnFinalizeParams {
+    const double* stats;          // [sum(width_pad) | sumsq(width_pad)]
+    const int32_t* count;
+    int width, width_pad;
+    float momentum;
+    float* running_mean;          // nn buffers, updated in place
+    float* running_var;
+    long long* num_batches_tracked;
+    float* batch_mean;            // out (width)
+    float* batch_var;             // out (width), biased
+};
+int launch_bn_finalize(const BnFinalizeParams& p, hipStream_t s);
 
 struct CompositeObject {
     const float* t;

@@ -65,6 +65,8 @@ struct Plan {
     TypePlan type[2];
     size_t block_sums, block_offsets;
     size_t rec_pos, rec_flat;
+    // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
+    size_t h1, h2, row_flags, stats, stat_count, batch_stats;
     size_t bytes;
     int nblocks256;
 };
@@ -145,6 +147,14 @@ static int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     plan->rec_pos = take(sizeof(float) * 3 * max_cap);
     plan->rec_flat = take(sizeof(int32_t) * max_cap);
+    if (c.flags & PR_FLAG_TRAIN_BN) {
+        plan->h1 = take(sizeof(float) * max_cap * MAX_WIDTH);
+        plan->h2 = take(sizeof(float) * max_cap * (MAX_WIDTH / 2 + 32));
+        plan->row_flags = take(sizeof(int32_t) * max_cap);
+        plan->stats = take(sizeof(double) * 4 * MAX_WIDTH);
+        plan->stat_count = take(sizeof(int32_t) * 4);
+        plan->batch_stats = take(sizeof(float) * 4 * MAX_WIDTH);
+    }
     // coarse and fine feature rows share one arena: the coarse rows are dead once the coarse
     // compositing pass has run, before the first fine MLP is launched.
     const size_t arena = take(feat_bytes[0] > feat_bytes[1] ? feat_bytes[0] : feat_bytes[1]);
@@ -236,7 +246,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             fp.t = t_arr; fp.block_offsets = block_offsets; fp.rec_pos = rec_pos; fp.rec_flat = rec_flat; fp.slot = slot;
             PR_TRY(launch_fill(fp, s));
 
-            // ---- style affine + eval BatchNorm fold -------------------------------------------
+            // ---- style affine + BatchNorm fold; fused MLP ---------------------------------------
             FoldParams fo;
             memset(&fo, 0, sizeof(fo));
             fo.frames = c.frames; fo.objects = K; fo.object_index = k;
@@ -246,9 +256,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             fo.eps = m.bn_eps;
             fo.W = d.W; fo.Wpad = d.Wpad; fo.W2 = d.W2; fo.W2pad = d.W2pad;
             fo.table = adain; fo.row_floats = adain_row_floats(d);
-            PR_TRY(launch_adain_fold(fo, s));
 
-            // ---- fused MLP ---------------------------------------------------------------------
             MlpParams mp;
             memset(&mp, 0, sizeof(mp));
             PR_TRY(build_mlp_layers(m, d, l, packed, &mp));
@@ -265,7 +273,47 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             mp.sigma = sigma; mp.dispmag = dispmag; mp.feat = feat;
             const size_t cap = (size_t)c.frames * c.rays * P;
             const int max_tiles = (int)((cap + (naive ? 63 : TILE_M - 1)) / (naive ? 64 : TILE_M));
-            PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
+            if (!(c.flags & PR_FLAG_TRAIN_BN)) {
+                PR_TRY(launch_adain_fold(fo, s));
+                PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
+            } else {
+                // BatchNorm in training mode: the batch statistics of the first (second) AdaIN layer are
+                // a reduction over every evaluated sample of this object call, between two matmuls
+                PR_REQUIRE(!naive, "the scalar debugging kernel has no train-mode BatchNorm");
+                double* stats = reinterpret_cast<double*>(ws + plan.stats);
+                int32_t* stat_count = reinterpret_cast<int32_t*>(ws + plan.stat_count);
+                float* batch = reinterpret_cast<float*>(ws + plan.batch_stats);
+                float* h1 = reinterpret_cast<float*>(ws + plan.h1);
+                float* h2 = reinterpret_cast<float*>(ws + plan.h2);
+                PR_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 4 * MAX_WIDTH, s));
+                PR_CHECK_HIP(hipMemsetAsync(stat_count, 0, sizeof(int32_t) * 4, s));
+                mp.row_flags = reinterpret_cast<int32_t*>(ws + plan.row_flags);
+                mp.stat_count = stat_count;
+                mp.phase = 1; mp.h_out = h1; mp.h_out_width = d.Wpad; mp.stats = stats;
+                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                BnFinalizeParams bf;
+                memset(&bf, 0, sizeof(bf));
+                bf.stats = stats; bf.count = stat_count; bf.width = d.W; bf.width_pad = d.Wpad; bf.momentum = 0.1f;
+                bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
+                bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
+                PR_TRY(launch_bn_finalize(bf, s));
+                fo.bn1_mean = batch; fo.bn1_var = batch + MAX_WIDTH;
+                PR_TRY(launch_adain_fold(fo, s));          // second layer still folded with placeholders
+                mp.phase = 2; mp.h_in = h1; mp.h_in_width = d.Wpad; mp.h_out = h2; mp.h_out_width = d.W2pad;
+                mp.stats = stats + 2 * MAX_WIDTH;
+                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                bf.stats = stats + 2 * MAX_WIDTH; bf.width = d.W2; bf.width_pad = d.W2pad;
+                bf.running_mean = m.bn4_mean; bf.running_var = m.bn4_var; bf.num_batches_tracked = (long long*)m.bn4_batches;
+                bf.batch_mean = batch + 2 * MAX_WIDTH; bf.batch_var = batch + 3 * MAX_WIDTH;
+                PR_TRY(launch_bn_finalize(bf, s));
+                fo.bn4_mean = batch + 2 * MAX_WIDTH; fo.bn4_var = batch + 3 * MAX_WIDTH;
+                PR_TRY(launch_adain_fold(fo, s));
+                mp.phase = 3; mp.h_in = h2; mp.h_in_width = d.W2pad; mp.h_out = nullptr;
+                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                if (outs[t] && outs[t]->normalised_samples)
+                    PR_CHECK_HIP(hipMemcpyAsync(outs[t]->normalised_samples + k, stat_count, sizeof(int32_t),
+                                                hipMemcpyDeviceToDevice, s));
+            }
         }
 
         // ---- compositing ------------------------------------------------------------------------

@@ -158,10 +158,12 @@ class ObjectComposer(nn.Module):
         s.affine1 = _linear(head[1].affine_transform)
         s.bn1_mean = head[1].ada_in.normalization.running_mean.data_ptr()
         s.bn1_var = head[1].ada_in.normalization.running_var.data_ptr()
+        s.bn1_batches = head[1].ada_in.normalization.num_batches_tracked.data_ptr()
         s.head3 = _linear(head[3])
         s.affine4 = _linear(head[4].affine_transform)
         s.bn4_mean = head[4].ada_in.normalization.running_mean.data_ptr()
         s.bn4_var = head[4].ada_in.normalization.running_var.data_ptr()
+        s.bn4_batches = head[4].ada_in.normalization.num_batches_tracked.data_ptr()
         s.head6 = _linear(head[6])
         if bender.has_weights:
             s.bender_width = bender.layers_width
@@ -226,12 +228,10 @@ class ObjectComposer(nn.Module):
                             f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
         if not ray_directions.is_cuda:
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
-        if self.training:
-            raise NotImplementedError("train-mode BatchNorm statistics / backward are not implemented yet in the HIP "
-                                      "renderer: call .eval()")
-        if torch.is_grad_enabled() and (ray_directions.requires_grad or style.requires_grad or
+        if torch.is_grad_enabled() and (self.training or ray_directions.requires_grad or style.requires_grad or
                                         transformation_matrix_w2o.requires_grad or deformation.requires_grad):
-            raise NotImplementedError("the HIP renderer has no backward yet: call it under torch.no_grad()")
+            raise NotImplementedError("the HIP renderer has no backward yet: call it under torch.no_grad() "
+                                      "(train-mode BatchNorm statistics ARE implemented for the forward pass)")
 
         lead = list(ray_directions.shape[:-2])
         R = ray_directions.size(-2)
@@ -282,6 +282,10 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_FIX_OVERLAPS
         if self.use_naive_mlp:
             flags |= _lib.PR_FLAG_NAIVE_MLP
+        if self.training:
+            # BatchNorm1d of the AdaIN layers in training mode: batch statistics per object call,
+            # running statistics updated in place (per replica, like the reference under DataParallel)
+            flags |= _lib.PR_FLAG_TRAIN_BN
 
         # ---- noise -----------------------------------------------------------------------------
         types = ["coarse"] + (["fine"] if use_fine else [])
@@ -346,7 +350,7 @@ class ObjectComposer(nn.Module):
 
         chunk = R
         need = workspace_bytes(build_call(0, R))
-        if need > self.max_workspace_bytes and R > 1:
+        if need > self.max_workspace_bytes and R > 1 and not self.training:  # batch statistics need the whole call
             chunk = max(1, int(R * self.max_workspace_bytes / need))
             chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
         F = models_c[0].nerf_model.output_features
@@ -380,6 +384,9 @@ class ObjectComposer(nn.Module):
                     for name in ENTRY_KEYS:
                         setattr(entry, name, e[name].data_ptr())
                     res[f"object_{k}" if k < K else "global"] = e
+                if self.training:
+                    res["_normalised"] = torch.zeros((K,), dtype=torch.int32, device=dev)
+                    o.normalised_samples = res["_normalised"].data_ptr()
                 if _export:
                     ex = {"t": [], "sigma": [], "slot": []}
                     for k in range(K):
@@ -399,6 +406,15 @@ class ObjectComposer(nn.Module):
                                              self._workspace.data_ptr(), self._workspace.numel(), stream),
                        "pr_render_forward")
             pieces.append(outs)
+
+        if self.training:
+            # BatchNorm1d raises for a single value per channel (torch.nn.functional.batch_norm); the reference
+            # does not guard against it (model/layers/adain.py:58) - one device read-back per training call
+            for ty in types:
+                counts = pieces[0][ty]["_normalised"].cpu().tolist()
+                if any(c <= 1 for c in counts):
+                    raise ValueError(f"Expected more than 1 value per channel when training, got {counts} evaluated "
+                                     f"samples per object ({ty} pass)")
 
         # ---- result dictionary (object_composer.py:848-892 schema) -----------------------------
         results: Dict = {}

@@ -184,7 +184,7 @@ def test_struct_sizes_match_header_layout():
     """ctypes mirrors must have the C sizes (pointer = 8, int32 = 4, natural alignment)."""
     assert C.sizeof(_lib.Linear) == 24
     assert C.sizeof(_lib.Entry) == 56
-    assert C.sizeof(_lib.ObjectModel) == 14 * 4 + 16 * 4 + 6 * 4 + 4 * 4 + 24 * 12 + 24 + 24 + (24 + 16) + 24 + (24 + 16) + 24 + 24 * 12 + 24
+    assert C.sizeof(_lib.ObjectModel) == 14 * 4 + 16 * 4 + 6 * 4 + 4 * 4 + 24 * 12 + 24 + 24 + (24 + 24) + 24 + (24 + 24) + 24 + 24 * 12 + 24
 
 
 def _model_struct_host(cfg_model, positions):
