@@ -109,8 +109,14 @@ typedef struct pr_object_model_t {
 int pr_packed_size(const pr_object_model_t* model, size_t* bytes);
 
 /* Gathers the raw parameters into `packed` (device, pr_packed_size bytes, 256-B aligned).  Must be
- * re-run whenever parameter VALUES change; cheap (one pass over ~2.9 MB). */
-int pr_pack_model(const pr_object_model_t* model, void* packed, size_t packed_bytes, void* stream);
+ * re-run whenever parameter VALUES change; cheap (one pass over ~2.9 MB).
+ * precision: PR_PRECISION_FP32 = fp32 MFMA fragments (exact fp32 arithmetic); PR_PRECISION_F16X3 = every weight
+ * as an fp16 pair (hi, lo = (w - hi) * 2^11) for the split kernel, which evaluates
+ * a*w ~ a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) * 2^-11 with three fp16 MFMAs and fp32 accumulation
+ * (~22 significant bits).  Both layouts have the same size. */
+#define PR_PRECISION_FP32  0
+#define PR_PRECISION_F16X3 1
+int pr_pack_model(const pr_object_model_t* model, int32_t precision, void* packed, size_t packed_bytes, void* stream);
 
 /* One object instance of a call: its (shared) coarse / fine models and their packed copies. */
 typedef struct pr_object_t {
@@ -158,6 +164,8 @@ typedef struct pr_call_t {
     int32_t static_objects;          /* first `static_objects` instances are static (overlap fix) */
     int32_t use_fine;                /* 1 = hierarchical pass with the fine models (all objects) */
     uint32_t flags;
+    int32_t precision;               /* PR_PRECISION_*: must match the precision the objects' weights were packed with */
+    int32_t reserved_;
     const float* ray_origins;        /* (N,3) world frame */
     const float* ray_directions;     /* (N,R,3) world frame, not normalised */
     const float* w2o;                /* (N,K,3,4) top three rows of transformation_matrix_w2o */

@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``, ``__graft_entry__.smoke
 ``cpu_baseline`` leg of ``bench.py`` may import this module; the product package
 (``playableenvironments_amd``) never does and has no CPU fallback.
 
-It is an own-code, functional restatement (plain PyTorch on CPU, fp32) of the reference's
+It is an own-code, functional restatement (plain PyTorch, fp32; tensors are created on the device of
+the inputs, so tests can also time this op graph with PyTorch-ROCm on the GPU) of the reference's
 algorithm for:  camera rays -> ray/object transforms -> slab test -> stratified / hierarchical
 sample placement -> AABB cull + compaction -> ray-bender MLP -> AdaIN style NeRF MLP (or skybox)
 -> per-object alpha compositing -> cross-object sort/compose (+ static/dynamic overlap fix)
@@ -57,8 +58,8 @@ class ObjectLayout:
         self.dynamic_objects = self.objects_count - self.static_objects
 
 
-def _bbox_tensor(model_cfg: dict) -> Tensor:
-    return torch.as_tensor(model_cfg["bounding_box"], dtype=torch.float32)  # (3, 2)
+def _bbox_tensor(model_cfg: dict, device=None) -> Tensor:
+    return torch.as_tensor(model_cfg["bounding_box"], dtype=torch.float32, device=device)  # (3, 2)
 
 
 # --------------------------------------------------------------------------------------------
@@ -103,12 +104,13 @@ def create_camera_rays(lead: List[int], height: int, width: int, focal: Tensor):
 
     utils/lib_3d/ray_helper.py:15-52.  ``focal`` is a (*lead) tensor."""
     focal = focal.unsqueeze(-1).unsqueeze(-1)
-    rows, cols = torch.meshgrid(torch.arange(0, height), torch.arange(0, width), indexing="ij")
+    dev = focal.device
+    rows, cols = torch.meshgrid(torch.arange(0, height, device=dev), torch.arange(0, width, device=dev), indexing="ij")
     dx = (cols - width / 2) / focal
     dy = -(rows - height / 2) / focal
     dz = -torch.ones_like(dx)
     directions = torch.stack([dx, dy, dz], -1)
-    normals = torch.zeros(lead + [3])
+    normals = torch.zeros(lead + [3], device=dev)
     normals[..., 2] = -1
     origins = torch.zeros_like(normals)
     return directions, origins, normals
@@ -182,14 +184,14 @@ def stratified_positions(origins: Tensor, directions: Tensor, z_near: Tensor, z_
 
     ``rand``: explicit U[0,1) tensor of the shape of ``t`` (otherwise drawn from torch's global
     CPU generator exactly where the reference draws it).  Returns (x, t, rand_used)."""
-    s = torch.linspace(0.0, 1.0, count)
+    s = torch.linspace(0.0, 1.0, count, device=z_near.device)
     t = z_near.unsqueeze(-1) * (1.0 - s) + z_far.unsqueeze(-1) * s
     used = None
     if perturb:
         mid = (t[..., 1:] + t[..., :-1]) / 2
         upper = torch.cat([mid, t[..., -1:]], dim=-1)
         lower = torch.cat([t[..., :1], mid], dim=-1)
-        used = torch.rand(t.size()) if rand is None else rand
+        used = torch.rand(t.size(), device=t.device) if rand is None else rand
         t = lower + (upper - lower) * used
     x = origins.unsqueeze(-2).unsqueeze(-2) + directions.unsqueeze(-2) * t.unsqueeze(-1)
     return x, t, used
@@ -206,10 +208,10 @@ def sample_pdf(bins: Tensor, weights: Tensor, count: int, perturb: bool,
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], dim=-1)
     used = None
     if not perturb:
-        u = torch.linspace(0.0, 1.0, count)
+        u = torch.linspace(0.0, 1.0, count, device=cdf.device)
         u = u.expand(list(cdf.shape[:-1]) + [count]).contiguous()
     else:
-        used = torch.rand(list(cdf.shape[:-1]) + [count]) if rand is None else rand
+        used = torch.rand(list(cdf.shape[:-1]) + [count], device=cdf.device) if rand is None else rand
         u = used.contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     below = torch.clamp(idx - 1, min=0)
@@ -246,7 +248,7 @@ def positional_encoding(x: Tensor, octaves: int, append_original: bool,
 
     model/positional_encoder.py:41-65; with ``octave_weights`` the annealed variant of
     model/annealable_positional_encoder.py:46-76."""
-    freqs = 2.0 ** torch.linspace(0.0, octaves - 1, octaves)
+    freqs = 2.0 ** torch.linspace(0.0, octaves - 1, octaves, device=x.device)
     parts = [x] if append_original else []
     for k in range(octaves):
         for fn in (torch.sin, torch.cos):
@@ -262,7 +264,7 @@ def annealing_weights(step: Tensor, octaves: int, num_steps: int) -> Tensor:
 
     model/annealable_positional_encoder.py:59-63 (``step`` is the int32 ``current_step`` buffer)."""
     alpha = step * octaves / num_steps
-    k = torch.arange(octaves, dtype=torch.float32)
+    k = torch.arange(octaves, dtype=torch.float32, device=step.device)
     return (1 - torch.cos(math.pi * torch.clamp(alpha - k, min=0.0, max=1.0))) / 2
 
 
@@ -347,8 +349,8 @@ def adain_nerf_forward(sd, prefix, cfg, bbox, empty_alpha, x, style, training, u
 
     model/nerf_models/adain_style_nerf_model.py:106-199."""
     m = x.size(0)
-    feats = torch.zeros((m, cfg["output_features"]), dtype=torch.float32)
-    sigma = torch.ones((m, 1), dtype=torch.float32) * empty_alpha
+    feats = torch.zeros((m, cfg["output_features"]), dtype=torch.float32, device=x.device)
+    sigma = torch.ones((m, 1), dtype=torch.float32, device=x.device) * empty_alpha
     mask = _in_box(x, bbox)
     xs, ss = x[mask, :], style[mask, :]
     size = bbox[:, 1] - bbox[:, 0]
@@ -387,7 +389,7 @@ def object_model_forward(sd: Dict[str, Tensor], prefix: str, model_cfg: dict, po
 
     positions (..., R, P, 3); origins (..., R, 3); directions (..., R, 3); style (..., 1, S);
     deformation (..., 1, D)  ->  features (..., R, P, F), sigma_raw (..., R, P), delta (..., R, P, 3)."""
-    bbox = _bbox_tensor(model_cfg)
+    bbox = _bbox_tensor(model_cfg, positions.device)
     nerf_cfg = model_cfg["nerf_model"]
     bender_cfg = model_cfg["ray_bender_model"]
     empty_alpha = model_cfg["empty_space_alpha"]
@@ -401,9 +403,10 @@ def object_model_forward(sd: Dict[str, Tensor], prefix: str, model_cfg: dict, po
     f_sty = flat(style.unsqueeze(-2).expand(lead + [style.size(-1)]))
     f_def = flat(deformation.unsqueeze(-2).expand(lead + [deformation.size(-1)]))
     total = f_pos.size(0)
-    out_f = torch.zeros((total, nerf_cfg["output_features"]), dtype=torch.float32)
-    out_s = torch.ones((total,), dtype=torch.float32) * empty_alpha
-    out_d = torch.zeros((total, 3), dtype=torch.float32)
+    dev = positions.device
+    out_f = torch.zeros((total, nerf_cfg["output_features"]), dtype=torch.float32, device=dev)
+    out_s = torch.ones((total,), dtype=torch.float32, device=dev) * empty_alpha
+    out_d = torch.zeros((total, 3), dtype=torch.float32, device=dev)
 
     mask = _in_box(f_pos, bbox)
     xs, os_, ds, ss, es = f_pos[mask, :], f_org[mask, :], f_dir[mask, :], f_sty[mask, :], f_def[mask, :]
@@ -435,7 +438,7 @@ def object_model_forward(sd: Dict[str, Tensor], prefix: str, model_cfg: dict, po
 def position_distances(t: Tensor, directions: Tensor) -> Tensor:
     """dt_i = (t_{i+1} - t_i) |d|, last = 1e10 |d|.  model/object_composer.py:153-178."""
     first = t[..., 1:] - t[..., :-1]
-    last = torch.ones(list(first.shape[:-1]) + [1], dtype=torch.float32) * 1e10
+    last = torch.ones(list(first.shape[:-1]) + [1], dtype=torch.float32, device=t.device) * 1e10
     dist = torch.cat([first, last], dim=-1)
     return dist * torch.linalg.norm(directions[..., None, :], dim=-1)
 
@@ -444,7 +447,7 @@ def alphas_from_raw(raw: Tensor, dist: Tensor, perturb: bool, noise: Optional[Te
     """alpha = 1 - exp(-relu(sigma_raw [+ N(0,1)]) dt).  model/object_composer.py:180-197."""
     used = None
     if perturb:
-        used = torch.randn(raw.size()) if noise is None else noise
+        used = torch.randn(raw.size(), device=raw.device) if noise is None else noise
         raw = raw + used
     return 1.0 - torch.exp(-F.relu(raw) * dist), used
 
@@ -491,7 +494,7 @@ def fix_overlaps(layout: ObjectLayout, all_raw, all_t, all_pos, all_disp, all_di
     out_div = [v.clone() for v in all_div]
     for s in range(layout.static_objects):
         ps = all_t[s].size(-1)
-        idx = torch.arange(ps)
+        idx = torch.arange(ps, device=all_t[s].device)
         for dyn in range(layout.dynamic_objects):
             d = layout.static_objects + dyn
             bounds = all_t[d][..., (0, ps - 1)]
@@ -571,7 +574,7 @@ def composer_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, r
         m = layout.model_of_object[k]
         mcfg = config["model"]["object_models"][m]
         has_fine = mcfg.get("use_fine", True) is not False
-        bbox = _bbox_tensor(mcfg)
+        bbox = _bbox_tensor(mcfg, ray_directions.device)
         present = object_in_scene[..., k]
         o, d, _ = transform_rays(ray_origins, ray_directions, focal_normals, w2o[..., k])
         near, far = raywise_z_bounds(o, d, bbox, present)
@@ -633,7 +636,7 @@ def composer_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, r
                               noise.get(f"int_{mtype}_global"))
         rec[f"int_{mtype}_global"] = used
         results[mtype]["global"] = out
-    results["pytorch_hook"] = torch.zeros((1,) * 9)
+    results["pytorch_hook"] = torch.zeros((1,) * 9, device=ray_directions.device)
     return results
 
 

@@ -18,6 +18,8 @@ PR_FLAG_CANONICAL_POSE = 2
 PR_FLAG_FIX_OVERLAPS = 4
 PR_FLAG_NAIVE_MLP = 8
 PR_FLAG_TRAIN_BN = 16
+PR_PRECISION_FP32 = 0
+PR_PRECISION_F16X3 = 1
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -83,7 +85,7 @@ class Outputs(C.Structure):
 class Call(C.Structure):
     _fields_ = [
         ("frames", C.c_int32), ("rays", C.c_int32), ("objects", C.c_int32), ("static_objects", C.c_int32),
-        ("use_fine", C.c_int32), ("flags", C.c_uint32),
+        ("use_fine", C.c_int32), ("flags", C.c_uint32), ("precision", C.c_int32), ("reserved_", C.c_int32),
         ("ray_origins", C.c_void_p), ("ray_directions", C.c_void_p), ("w2o", C.c_void_p), ("style", C.c_void_p),
         ("deformation", C.c_void_p), ("object_in_scene", C.c_void_p),
         ("linspace_coarse", C.c_void_p * PR_MAX_OBJECTS), ("linspace_fine", C.c_void_p * PR_MAX_OBJECTS),
@@ -95,7 +97,7 @@ class Call(C.Structure):
 # every exported symbol of include/playrender.h : (restype, argtypes)
 SYMBOLS = {
     "pr_packed_size": (C.c_int, [C.POINTER(ObjectModel), C.POINTER(C.c_size_t)]),
-    "pr_pack_model": (C.c_int, [C.POINTER(ObjectModel), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pr_pack_model": (C.c_int, [C.POINTER(ObjectModel), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pr_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
     "pr_render_forward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(Outputs), C.POINTER(Outputs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

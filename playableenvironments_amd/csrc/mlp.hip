@@ -31,7 +31,7 @@ int compute_dims(const pr_object_model_t& m, ModelDims* d) {
     PR_REQUIRE(m.octaves >= 0 && m.octaves <= PR_MAX_OCTAVES, "octaves %d out of range", m.octaves);
     d->din = m.kind == 0 ? 3 : 6;
     d->enc = d->din + 2 * d->din * m.octaves;
-    d->enc_pad = round_up(d->enc, 16);   // K loops advance two 8-wide steps per iteration
+    d->enc_pad = round_up(d->enc, 32);   // K loops advance two steps per iteration (2 x 8 fp32, 2 x 16 split)
     d->W = m.layers_width;
     d->Wpad = round_up(d->W, 32);
     d->W2 = m.layers_width / 2;
@@ -51,7 +51,7 @@ int compute_dims(const pr_object_model_t& m, ModelDims* d) {
         PR_REQUIRE(m.bender_octaves >= 0 && m.bender_octaves <= PR_MAX_OCTAVES, "bender octaves out of range");
         d->benc = 3 + 6 * m.bender_octaves;
         d->bin = d->benc + m.deformation_features;
-        d->bin_pad = round_up(d->bin, 16);
+        d->bin_pad = round_up(d->bin, 32);
         d->BW = m.bender_width;
         d->BWpad = round_up(d->BW, 32);
         PR_REQUIRE(d->bin_pad <= MAX_ENC, "bender input width %d exceeds %d", d->bin, MAX_ENC);
@@ -114,7 +114,8 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
 struct PackJob {
     const float* src;
     float* dst;
-    int kind;       // 0 = fragment-ordered matrix segment, 1 = padded vector / raw row copy
+    int kind;       // 0 = fp32 fragment-ordered matrix segment, 1 = padded vector / raw row copy,
+                    // 2 = fp16 hi/lo split fragments (same byte size as kind 0)
     int in_total;   // row stride of src
     int col_off;
     int k_real, n_real, kq, nblk;
@@ -139,6 +140,30 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
             const int n = nb * 32 + (lane & 31);
             const int k = (lane >> 5) * 4 * j.kq + 4 * q + e;
             if (n < j.n_real && k < j.k_real) v = j.src[(size_t)n * j.in_total + j.col_off + k];
+        } else if (j.kind == 2) {
+            // split fragments: per (column block, 16-wide K step): 64 lanes x 8 halves "hi", then the same for
+            // "lo" = (w - hi) * 2^11.  Lane l holds W[nb*32 + (l & 31)][16 s + 8 (l >> 5) + e], e = 0..7.
+            unsigned short out[2];
+            for (int t = 0; t < 2; ++t) {
+                const int h = idx * 2 + t;
+                const int e = h & 7;
+                const int lane = (h >> 3) & 63;
+                const int part = (h >> 9) & 1;
+                const int rest = h >> 10;
+                const int ks = j.kq >> 1;
+                const int sidx = rest % ks;
+                const int nb = rest / ks;
+                const int n = nb * 32 + (lane & 31);
+                const int k = 16 * sidx + 8 * (lane >> 5) + e;
+                float w = 0.f;
+                if (n < j.n_real && k < j.k_real) w = j.src[(size_t)n * j.in_total + j.col_off + k];
+                const _Float16 hi = (_Float16)w;
+                const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+                const _Float16 sel = part ? lo : hi;
+                out[t] = *reinterpret_cast<const unsigned short*>(&sel);
+            }
+            reinterpret_cast<unsigned int*>(j.dst)[idx] = (unsigned int)out[0] | ((unsigned int)out[1] << 16);
+            continue;
         } else {
             // rows of length kq (padded) from rows of length k_real; n_real rows
             const int row = idx / j.kq, c = idx % j.kq;
@@ -148,13 +173,14 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     }
 }
 
+static int g_pack_kind = 0;  // set by pr_pack_model for the duration of build_pack_jobs (0 exact, 2 split)
 static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
     PR_REQUIRE(js->n < MAX_PACK_JOBS, "too many pack jobs");
     PR_REQUIRE(lin.weight != nullptr, "missing weight pointer");
     PackJob& j = js->job[js->n++];
     j.src = lin.weight;
     j.dst = dst;
-    j.kind = 0;
+    j.kind = g_pack_kind;
     j.in_total = lin.in_features;
     j.col_off = col_off;
     j.k_real = k_real;
@@ -1128,7 +1154,8 @@ extern "C" int pr_packed_size(const pr_object_model_t* model, size_t* bytes) {
     return PR_OK;
 }
 
-extern "C" int pr_pack_model(const pr_object_model_t* model, void* packed, size_t packed_bytes, void* stream) {
+extern "C" int pr_pack_model(const pr_object_model_t* model, int32_t precision, void* packed, size_t packed_bytes, void* stream) {
+    PR_REQUIRE(precision == 0 || precision == 1, "pr_pack_model: precision must be 0 (fp32) or 1 (fp16 split)");
     PR_REQUIRE(model && packed, "pr_pack_model: NULL argument");
     PR_REQUIRE(((uintptr_t)packed & 15) == 0, "pr_pack_model: packed buffer must be 16-byte aligned");
     pr::ModelDims d;
@@ -1138,7 +1165,10 @@ extern "C" int pr_pack_model(const pr_object_model_t* model, void* packed, size_
     PR_REQUIRE(packed_bytes >= (size_t)l.total * sizeof(float), "pr_pack_model: buffer too small (%zu < %zu)",
                packed_bytes, (size_t)l.total * sizeof(float));
     pr::PackJobs jobs;
-    PR_TRY(pr::build_pack_jobs(*model, d, l, static_cast<float*>(packed), &jobs));
+    pr::g_pack_kind = precision ? 2 : 0;
+    const int build_status = pr::build_pack_jobs(*model, d, l, static_cast<float*>(packed), &jobs);
+    pr::g_pack_kind = 0;
+    PR_TRY(build_status);
     hipLaunchKernelGGL(pr::k_pack, dim3(64, jobs.n), dim3(256), 0, (hipStream_t)stream, jobs);
     PR_LAUNCH_CHECK();
     return PR_OK;

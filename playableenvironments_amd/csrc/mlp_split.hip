@@ -1,0 +1,403 @@
+// Split-precision variant of the fused per-object MLP: fp32 emulated with three fp16 MFMAs.
+//
+// Every operand is carried as an fp16 pair  x = hi + lo * 2^-11  (hi = fp16(x), lo = fp16((x - hi) * 2^11);
+// ~22 significant bits, the residual keeps full fp16 precision because it is rescaled).  A product sum
+// becomes      sum a*w  ~  sum a_hi*w_hi  +  2^-11 * ( sum a_hi*w_lo + sum a_lo*w_hi )
+// (the dropped a_lo*w_lo term is 2^-22 relative); the two sums live in separate fp32 accumulators of
+// v_mfma_f32_32x32x16_f16, whose products are exact in fp32.  The matrix pipe runs fp16 at 16x the fp32
+// rate, so three MFMAs per 16 K-values replace eight fp32 MFMAs: 5.3x less matrix time.
+//
+// Structure = csrc/mlp.hip (64-sample tile, 8 waves, one 32-column block per wave, weights as
+// fragment-ordered hi/lo pairs straight from L2, even/odd operand pipeline); activations live in LDS as
+// two fp16 planes.  Selected with pr_call_t.precision = PR_PRECISION_F16X3; eval-mode only.
+#include "pr_common.h"
+
+namespace pr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LDH = MAX_WIDTH + 8;   // halves per activation row (528 B = 33 16-byte slots: conflict-free b128)
+constexpr int LEH = MAX_ENC + 8;     // halves per encoding row (272 B = 17 slots)
+constexpr int LDSTAGE = 260;         // floats per row when the activation planes are reused as an fp32 staging tile
+
+struct SmemH {
+    int uniform_frame;
+    int pad_[3];
+    float head_w[MAX_WIDTH + 8];          // sigma head weights + bias
+    _Float16 Xh[TILE_M * LDH];            // activations, hi plane
+    _Float16 Xl[TILE_M * LDH];            // activations, lo plane (scaled by 2^11)
+    _Float16 Eh[TILE_M * LEH];
+    _Float16 El[TILE_M * LEH];
+    float pos[TILE_M * 8];
+    int flat[TILE_M];
+    int frame[TILE_M];
+    int flags[TILE_M];
+};
+static_assert(sizeof(_Float16) * 2 * TILE_M * LDH >= sizeof(float) * TILE_M * LDSTAGE, "staging tile must fit the activation planes");
+static_assert(sizeof(SmemH) <= 159 * 1024, "LDS budget");
+
+#define PR_ACC_ROW(i) (((i) & 3) + 8 * ((i) >> 2))
+#define PR_MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
+
+__device__ __forceinline__ void split_store(_Float16* hi_plane, _Float16* lo_plane, int idx, float v) {
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);   // fp16 range; never reached by sane activations
+    const _Float16 hi = (_Float16)v;
+    hi_plane[idx] = hi;
+    lo_plane[idx] = (_Float16)((v - (float)hi) * 2048.0f);
+}
+__device__ __forceinline__ float split_load(const _Float16* hi_plane, const _Float16* lo_plane, int idx) {
+    return (float)hi_plane[idx] + (float)lo_plane[idx] * (1.0f / 2048.0f);
+}
+
+// epilogues on (main, correction) accumulator pairs of one 32x32 block
+__device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, SmemH& S, int row0, int col) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = fmaf(c[i], 1.0f / 2048.0f, m[i]);
+        split_store(S.Xh, S.Xl, (row0 + PR_ACC_ROW(i)) * LDH + col, v > 0.f ? v : 0.f);
+    }
+}
+__device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, SmemH& S, const MlpParams& p, int row0,
+                                              int col, int goff, int boff, bool uniform, float ug, float ub) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = row0 + PR_ACC_ROW(i);
+        float g = ug, b = ub;
+        if (!uniform) {
+            const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride;
+            g = tab[goff];
+            b = tab[boff];
+        }
+        const float v = fmaf(fmaf(c[i], 1.0f / 2048.0f, m[i]), g, b);
+        split_store(S.Xh, S.Xl, row * LDH + col, v > 0.f ? v : 0.f);
+    }
+}
+__device__ __forceinline__ void store_stage_h(const f32x16& m, const f32x16& c, float* stage, int row0, int col) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) stage[(row0 + PR_ACC_ROW(i)) * LDSTAGE + col] = fmaf(c[i], 1.0f / 2048.0f, m[i]);
+}
+
+__device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int nblk = L.nblk;
+    const bool both = nblk > 4;
+    int cb, rb;
+    bool active;
+    if (both) {
+        cb = wave;
+        rb = 0;
+        active = wave < nblk;
+    } else {
+        cb = wave % nblk;
+        rb = wave / nblk;
+        active = rb < 2;
+    }
+    f32x16 m0, m1, c0, c1;   // main / correction accumulators of row block 0 / 1
+    {
+        const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            m0[i] = bias;
+            m1[i] = bias;
+            c0[i] = 0.f;
+            c1[i] = 0.f;
+        }
+    }
+    if (active) {
+        for (int sidx = 0; sidx < L.nseg; ++sidx) {
+            const Seg& sg = L.seg[sidx];
+            const _Float16* srch = sg.src == 0 ? S.Xh : S.Eh;
+            const _Float16* srcl = sg.src == 0 ? S.Xl : S.El;
+            const int ld = sg.src == 0 ? LDH : LEH;
+            const int ks = sg.kq >> 1;   // 16-wide steps
+            const int aoff = (rb * 32 + r) * ld + 8 * half;
+            // weights: per (column block, step): hi fragment (64 lanes x 16 B) then lo fragment
+            const f16x8* wp = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cb * ks * 128 + lane;
+            // two 16-wide steps in flight: even/odd operand sets live in their own registers and are
+            // re-loaded right after their last use (see csrc/mlp.hip); ks is even (K padded to 32)
+            f16x8 bhE = wp[0], blE = wp[64], bhO = wp[128], blO = wp[192];
+            if (both) {
+                const _Float16* a0h = srch + aoff;
+                const _Float16* a0l = srcl + aoff;
+                const _Float16* a1h = srch + aoff + 32 * ld;
+                const _Float16* a1l = srcl + aoff + 32 * ld;
+                f16x8 ah0E = *reinterpret_cast<const f16x8*>(a0h), al0E = *reinterpret_cast<const f16x8*>(a0l);
+                f16x8 ah1E = *reinterpret_cast<const f16x8*>(a1h), al1E = *reinterpret_cast<const f16x8*>(a1l);
+                f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
+                f16x8 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16), al1O = *reinterpret_cast<const f16x8*>(a1l + 16);
+                for (int s = 0; s < ks; s += 2) {
+                    const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                    PR_MFMA16(m0, ah0E, bhE);
+                    PR_MFMA16(m1, ah1E, bhE);
+                    PR_MFMA16(c0, ah0E, blE);
+                    PR_MFMA16(c1, ah1E, blE);
+                    PR_MFMA16(c0, al0E, bhE);
+                    PR_MFMA16(c1, al1E, bhE);
+                    bhE = wp[(size_t)se * 128];
+                    blE = wp[(size_t)se * 128 + 64];
+                    ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
+                    al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
+                    ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
+                    al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
+                    PR_MFMA16(m0, ah0O, bhO);
+                    PR_MFMA16(m1, ah1O, bhO);
+                    PR_MFMA16(c0, ah0O, blO);
+                    PR_MFMA16(c1, ah1O, blO);
+                    PR_MFMA16(c0, al0O, bhO);
+                    PR_MFMA16(c1, al1O, bhO);
+                    bhO = wp[(size_t)so * 128];
+                    blO = wp[(size_t)so * 128 + 64];
+                    ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
+                    al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
+                    ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
+                    al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                }
+            } else {
+                const _Float16* a0h = srch + aoff;
+                const _Float16* a0l = srcl + aoff;
+                f16x8 ah0E = *reinterpret_cast<const f16x8*>(a0h), al0E = *reinterpret_cast<const f16x8*>(a0l);
+                f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
+                for (int s = 0; s < ks; s += 2) {
+                    const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                    PR_MFMA16(m0, ah0E, bhE);
+                    PR_MFMA16(c0, ah0E, blE);
+                    PR_MFMA16(c0, al0E, bhE);
+                    bhE = wp[(size_t)se * 128];
+                    blE = wp[(size_t)se * 128 + 64];
+                    ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
+                    al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
+                    PR_MFMA16(m0, ah0O, bhO);
+                    PR_MFMA16(c0, ah0O, blO);
+                    PR_MFMA16(c0, al0O, bhO);
+                    bhO = wp[(size_t)so * 128];
+                    blO = wp[(size_t)so * 128 + 64];
+                    ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
+                    al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();  // every wave has finished reading the activation planes
+    if (active) {
+        const int col = cb * 32 + r;
+        const int rowA = (both ? 0 : rb * 32) + 4 * half;
+        if (L.epi == EPI_RELU) {
+            store_relu_h(m0, c0, S, rowA, col);
+            if (both) store_relu_h(m1, c1, S, rowA + 32, col);
+        } else if (L.epi == EPI_ADAIN_RELU) {
+            const int goff = L.adain_off + col, boff = L.adain_off + L.nblk * 32 + col;
+            const bool uniform = S.uniform_frame != 0;
+            float ug = 0.f, ub = 0.f;
+            if (uniform) {
+                const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride;
+                ug = tab[goff];
+                ub = tab[boff];
+            }
+            store_adain_h(m0, c0, S, p, rowA, col, goff, boff, uniform, ug, ub);
+            if (both) store_adain_h(m1, c1, S, p, rowA + 32, col, goff, boff, uniform, ug, ub);
+        } else {
+            float* stage = reinterpret_cast<float*>(S.Xh);
+            store_stage_h(m0, c0, stage, rowA, col);
+            if (both) store_stage_h(m1, c1, stage, rowA + 32, col);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fill_encoding_h(SmemH& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
+                                                const float* octave_weights, bool normalise) {
+    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float v[6];
+    for (int a = 0; a < din; ++a) {
+        const float x = S.pos[s * 8 + a];
+        v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+    }
+    const int row = s * LEH;
+    if (part == 0)
+        for (int a = 0; a < din; ++a) split_store(S.Eh, S.El, row + a, v[a]);
+    if (part == 1)
+        for (int j = zero_from; j < pad; ++j) split_store(S.Eh, S.El, row + j, 0.f);
+    for (int k = part; k < octaves; k += 8) {
+        const float f = ldexpf(1.0f, k);
+        const float w = octave_weights ? octave_weights[k] : 1.0f;
+        const int dst = row + din + k * 2 * din;
+        for (int a = 0; a < din; ++a) {
+            const float arg = __fmul_rn(f, v[a]);
+            float sn = sinf(arg), cs = cosf(arg);
+            if (octave_weights) {
+                sn = __fmul_rn(sn, w);
+                cs = __fmul_rn(cs, w);
+            }
+            split_store(S.Eh, S.El, dst + a, sn);
+            split_store(S.Eh, S.El, dst + din + a, cs);
+        }
+    }
+}
+
+__device__ __forceinline__ void row_dots_h(const SmemH& S, const float* w, int width, int wstride, int nout, float* out) {
+    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = part; k < width; k += 8) {
+        const float x = split_load(S.Xh, S.Xl, s * LDH + k);
+        for (int a = 0; a < nout; ++a) acc[a] = fmaf(x, w[a * wstride + k], acc[a]);
+    }
+    for (int a = 0; a < nout; ++a) {
+        float v = acc[a];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        out[a] = v;
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = *p.total;
+    for (int i = tid; i <= p.Wpad; i += MLP_THREADS) S.head_w[i] = p.sigma_w[i];
+    __syncthreads();
+    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+        const int tile_base = tile * TILE_M;
+        if (tid == 0) S.uniform_frame = 1;
+        if (tid < TILE_M) {
+            const int idx = tile_base + tid;
+            const bool valid = idx < total;
+            const int src = valid ? idx : tile_base;
+            const int flat = p.rec_flat[src];
+            const int frame = flat / p.samples_per_frame;
+            S.flat[tid] = flat;
+            S.frame[tid] = frame;
+            S.flags[tid] = valid ? 3 : 0;
+            if (p.kind == 0) {
+                S.pos[tid * 8 + 0] = p.rec_pos[(size_t)src * 3 + 0];
+                S.pos[tid * 8 + 1] = p.rec_pos[(size_t)src * 3 + 1];
+                S.pos[tid * 8 + 2] = p.rec_pos[(size_t)src * 3 + 2];
+            } else {
+                const int ray = (flat - frame * p.samples_per_frame) / p.positions;
+                const ObjRay rr = object_ray(p.w2o + (size_t)frame * p.w2o_stride, p.ray_origins + (size_t)frame * 3,
+                                             p.ray_directions + ((size_t)frame * p.rays + ray) * 3);
+                const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rr.d[0], rr.d[0]), __fmul_rn(rr.d[1], rr.d[1])),
+                                                  __fmul_rn(rr.d[2], rr.d[2])));
+                for (int a = 0; a < 3; ++a) {
+                    S.pos[tid * 8 + a] = __fdiv_rn(rr.o[a], p.size[a]);
+                    S.pos[tid * 8 + 3 + a] = __fdiv_rn(rr.d[a], nrm);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+
+        if (p.has_bender) {
+            fill_encoding_h(S, p, 3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, true);
+            for (int idx = tid; idx < TILE_M * p.D; idx += MLP_THREADS) {
+                const int s = idx / p.D, j = idx - s * p.D;
+                split_store(S.Eh, S.El, s * LEH + p.benc + j, p.deformation[(size_t)S.frame[s] * p.deformation_stride + j]);
+            }
+            __syncthreads();
+            for (int l = 0; l < p.b_count; ++l) run_layer_h(p.b_layers[l], S, p);
+            float out[3];
+            row_dots_h(S, p.b_out, p.BWpad, p.BWpad, 3, out);
+            __syncthreads();
+            if ((tid & 7) == 0) {
+                const int s = tid >> 3;
+                float d[3], bent[3];
+                for (int a = 0; a < 3; ++a) {
+                    const float x = S.pos[s * 8 + a];
+                    float dl = __fmul_rn(out[a], p.size[a]);
+                    dl = nan_max(dl, __fsub_rn(p.lo[a], x));
+                    dl = nan_min(dl, __fsub_rn(p.hi[a], x));
+                    if (p.canonical) dl = __fmul_rn(dl, 0.0f);
+                    d[a] = dl;
+                    bent[a] = __fadd_rn(x, dl);
+                    S.pos[s * 8 + a] = bent[a];
+                }
+                if (S.flags[s] & 1) {
+                    if (p.dispmag)
+                        p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
+                                                               __fmul_rn(d[2], d[2])));
+                    if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.flags[s] &= ~2;
+                }
+            }
+            __syncthreads();
+        }
+
+        fill_encoding_h(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+        __syncthreads();
+        for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p);
+
+        if (p.kind == 0) {
+            float sg;
+            row_dots_h(S, S.head_w, p.Wpad, p.Wpad, 1, &sg);
+            if ((tid & 7) == 0) {
+                const int s = tid >> 3;
+                if ((S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
+            }
+        } else if (tid < TILE_M) {
+            if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
+        }
+
+        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p);
+
+        // feature rows: the last layer staged an fp32 tile over the activation planes
+        {
+            const float* stage = reinterpret_cast<const float*>(S.Xh);
+            if ((p.F & 3) == 0) {
+                const int f4 = p.F >> 2;
+                for (int idx = tid; idx < TILE_M * f4; idx += MLP_THREADS) {
+                    const int row = idx / f4, c = (idx - row * f4) * 4;
+                    const int fl = S.flags[row];
+                    if (fl & 1) {
+                        float4 v = *reinterpret_cast<const float4*>(stage + row * LDSTAGE + c);
+                        if (!(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4*>(p.feat + (size_t)(tile_base + row) * p.F + c) = v;
+                    }
+                }
+            } else {
+                for (int idx = tid; idx < TILE_M * p.F; idx += MLP_THREADS) {
+                    const int row = idx / p.F, c = idx - row * p.F;
+                    const int fl = S.flags[row];
+                    if (fl & 1) p.feat[(size_t)(tile_base + row) * p.F + c] = (fl & 2) ? stage[row * LDSTAGE + c] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s) {
+    if (max_tiles <= 0) return PR_OK;
+    static bool attr_set = false;
+    static int cu_count = 0;
+    if (!attr_set) {
+        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_split),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemH)));
+        int dev = 0;
+        PR_CHECK_HIP(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        cu_count = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int grid = max_tiles < cu_count ? max_tiles : cu_count;
+    ProfileScope scope(0, s);
+    hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(MLP_THREADS), sizeof(SmemH), s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+}  // namespace pr

@@ -227,6 +227,7 @@ struct FoldParams {
 int launch_adain_fold(const FoldParams& p, hipStream_t s);
 
 int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s);
+int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s);   // PR_PRECISION_F16X3, eval only
 
 // BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
 // running statistics updated in place with momentum 0.1 and the unbiased variance, num_batches_tracked += 1

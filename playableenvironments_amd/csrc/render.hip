@@ -80,6 +80,9 @@ static int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     PR_REQUIRE((long)c.frames * c.rays < (1L << 31), "too many rays in one call");
     PR_REQUIRE(c.ray_origins && c.ray_directions && c.w2o && c.style && c.deformation && c.object_in_scene,
                "NULL input pointer");
+    PR_REQUIRE(c.precision == PR_PRECISION_FP32 || c.precision == PR_PRECISION_F16X3, "unknown precision %d", c.precision);
+    PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_TRAIN_BN)),
+               "the split-precision kernel has no train-mode BatchNorm phases yet: use PR_PRECISION_FP32 for training");
     for (int k = 0; k < c.objects; ++k) {
         const pr_object_model_t& m = objs[k].coarse;
         PR_REQUIRE(m.positions >= 1, "object %d: positions_count_coarse %d", k, m.positions);
@@ -275,7 +278,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             const int max_tiles = (int)((cap + (naive ? 63 : TILE_M - 1)) / (naive ? 64 : TILE_M));
             if (!(c.flags & PR_FLAG_TRAIN_BN)) {
                 PR_TRY(launch_adain_fold(fo, s));
-                PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
+                if (c.precision == PR_PRECISION_F16X3 && !naive)
+                    PR_TRY(launch_mlp_split(mp, max_tiles, s));
+                else
+                    PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
             } else {
                 // BatchNorm in training mode: the batch statistics of the first (second) AdaIN layer are
                 // a reduction over every evaluated sample of this object call, between two matmuls

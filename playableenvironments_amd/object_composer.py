@@ -106,6 +106,9 @@ class ObjectComposer(nn.Module):
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
+        #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3": every product as three fp16 MFMAs with
+        #: fp32 accumulation (a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) * 2^-11, ~22 significant bits) - eval only.
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ construction
     def create_object_models(self, fine: bool) -> List[Optional[nn.Module]]:
@@ -188,10 +191,18 @@ class ObjectComposer(nn.Module):
             self._annealing[id(encoder)] = cached
         return cached[1]
 
+    def _precision_code(self) -> int:
+        if self.precision not in ("fp32", "f16x3"):
+            raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32' or 'f16x3')")
+        if self.precision == "f16x3" and self.training:
+            return _lib.PR_PRECISION_FP32   # train-mode BatchNorm phases exist for the exact kernel only
+        return _lib.PR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.PR_PRECISION_FP32
+
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
         params = list(model.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        precision = self._precision_code()
+        key = (precision,) + tuple((p.data_ptr(), p._version) for p in params)
         cached = self._packed.get(id(model))
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -199,7 +210,7 @@ class ObjectComposer(nn.Module):
         size = C.c_size_t()
         _lib.check(lib.pr_packed_size(C.byref(struct), C.byref(size)), "pr_packed_size")
         buf = torch.empty(size.value, dtype=torch.uint8, device=params[0].device)
-        _lib.check(lib.pr_pack_model(C.byref(struct), buf.data_ptr(), size.value, stream), "pr_pack_model")
+        _lib.check(lib.pr_pack_model(C.byref(struct), precision, buf.data_ptr(), size.value, stream), "pr_pack_model")
         self._packed[id(model)] = (key, buf)
         return buf
 
@@ -315,6 +326,7 @@ class ObjectComposer(nn.Module):
             call.static_objects = helper.static_objects_count
             call.use_fine = 1 if use_fine else 0
             call.flags = flags
+            call.precision = self._precision_code()
             d = dirs if (r0 == 0 and r1 == R) else dirs[:, r0:r1].contiguous()
             keep.append(d)
             call.ray_origins, call.ray_directions = origins.data_ptr(), d.data_ptr()

@@ -47,15 +47,16 @@ def run(name, cfg, scene, pixels=None, strides=None, alpha_bias=2.0, seed=0, per
         t1 = time.time()
     comp = comp.cuda()
     gin = [v.cuda() for v in inputs]
-    for naive in (True, False):
+    for naive, precision in ((True, "fp32"), (False, "fp32"), (False, "f16x3")):
         comp.use_naive_mlp = naive
+        comp.precision = precision
         with torch.no_grad():
             got = comp(*gin, perturb, _noise=rec if perturb else None, _export=True)
         torch.cuda.synchronize()
         rep = compare_results(want, got, rtol=1e-4, atol=1e-5)
         bad = {k: f"{v[0]:.2e}" for k, v in rep.items() if not v[1]}
         worst = max(v[0] for v in rep.values())
-        print(f"[{name}] {'naive' if naive else 'mfma '} worst|diff|={worst:.3e} failing={len(bad)}/{len(rep)}")
+        print(f"[{name}] {'naive' if naive else 'mfma '} {precision:5s} worst|diff|={worst:.3e} failing={len(bad)}/{len(rep)}")
         for k, v in list(bad.items())[:12]:
             print("      ", k, v)
         if naive and not perturb:

@@ -25,9 +25,10 @@ def _need_gpu(built_library):
         pytest.fail("the gpu-marked tests need a GPU: the renderer has no CPU fallback")
 
 
-def build(cfg, seed=0, step=20000, alpha_bias=2.0):
+def build(cfg, seed=0, step=20000, alpha_bias=2.0, precision="fp32"):
     torch.manual_seed(seed)
     comp = ObjectComposer(cfg)
+    comp.precision = precision
     synthetic.randomize_module_state(comp, seed=seed, step=step, alpha_bias=alpha_bias, bender_scale=1e4)
     return comp.eval()
 
@@ -69,10 +70,13 @@ CASES = {
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("perturb", [False, True], ids=["eval", "perturb"])
-def test_composer_matches_oracle(name, perturb):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_composer_matches_oracle(name, perturb, precision):
+    """Both MLP kernels (exact fp32 MFMA, and fp32 emulated with three fp16 MFMAs) against the oracle at
+    the same tolerance (rtol 1e-4 / atol 1e-5)."""
     make_cfg, make_scene, n, bias = CASES[name]
     cfg, scene = make_cfg(), make_scene()
-    comp = build(cfg, alpha_bias=bias)
+    comp = build(cfg, alpha_bias=bias, precision=precision)
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
     want, got = run_both(cfg, comp, inputs, perturb=perturb)
     assert set(got) == set(want)
@@ -128,8 +132,9 @@ def test_mfma_kernel_agrees_with_scalar_kernel():
     assert_close(a, b, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_matches_reference_golden_vectors(path):
+def test_matches_reference_golden_vectors(path, precision):
     """Reference-generated fixtures (reduced widths exercise every padding path).  The reference's
     tie order is unspecified, so rays whose merged list contains an in-box sample inside a group of
     equal t are excluded from the global comparison (they are covered by the stable-merge oracle test)."""
@@ -137,6 +142,7 @@ def test_matches_reference_golden_vectors(path):
     cfg = recipe_config(recipe)
     comp = ObjectComposer(cfg)
     comp.load_state_dict(sd, strict=True)
+    comp.precision = precision
     comp = comp.eval().cuda()
     with torch.no_grad():
         got = comp(*[v.cuda() for v in inputs], perturb, _noise=noise if perturb else None)
