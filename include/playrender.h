@@ -221,6 +221,9 @@ int pr_profile_collect(double* milliseconds, int32_t* launches);
  * chip sustains a lower matrix rate on such data than on constant operands).
  */
 int pr_probe_mfma_f32(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream);
+/* Same for the fp16 matrix cores with the split-precision kernel's issue pattern (4 accumulators, 6
+ * v_mfma_f32_32x32x16_f16 per step); TFLOP/s counts hardware fp16 FLOPs (3 per emulated fp32 FLOP). */
+int pr_probe_mfma_f16(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream);
 
 /* Library / device introspection. */
 int pr_abi_version(void);

@@ -106,6 +106,7 @@ SYMBOLS = {
     "pr_profile_enable": (C.c_int, [C.c_int]),
     "pr_profile_collect": (C.c_int, [C.POINTER(C.c_double), c_int32_p]),
     "pr_probe_mfma_f32": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "pr_probe_mfma_f16": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "pr_abi_version": (C.c_int, []),
     "pr_last_error": (C.c_char_p, []),
     "pr_device_info": (C.c_int, [c_int32_p, c_int32_p, C.c_char_p, C.c_size_t]),

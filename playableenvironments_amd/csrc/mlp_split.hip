@@ -37,6 +37,23 @@ struct SmemH {
 static_assert(sizeof(_Float16) * 2 * TILE_M * LDH >= sizeof(float) * TILE_M * LDSTAGE, "staging tile must fit the activation planes");
 static_assert(sizeof(SmemH) <= 159 * 1024, "LDS budget");
 
+#ifndef PR_SPLIT_ABLATE
+#define PR_SPLIT_ABLATE 0   // profiling builds only: 1 = no weight re-loads, 2 = no activation re-loads, 8 = no epilogue
+#endif
+#if PR_SPLIT_ABLATE & 64
+// phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase
+__device__ unsigned long long g_phase_cycles[16];
+#define PR_PHASE_T0() unsigned long long _pt = __builtin_amdgcn_s_memtime()
+#define PR_PHASE(idx)                                                                      \
+    do {                                                                                   \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[idx], _n - _pt);                   \
+        _pt = _n;                                                                          \
+    } while (0)
+#else
+#define PR_PHASE_T0() do {} while (0)
+#define PR_PHASE(idx) do {} while (0)
+#endif
 #define PR_ACC_ROW(i) (((i) & 3) + 8 * ((i) >> 2))
 #define PR_MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
 
@@ -94,6 +111,7 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
         rb = wave / nblk;
         active = rb < 2;
     }
+    PR_PHASE_T0();
     f32x16 m0, m1, c0, c1;   // main / correction accumulators of row block 0 / 1
     {
         const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
@@ -135,24 +153,32 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                     PR_MFMA16(c1, ah1E, blE);
                     PR_MFMA16(c0, al0E, bhE);
                     PR_MFMA16(c1, al1E, bhE);
-                    bhE = wp[(size_t)se * 128];
-                    blE = wp[(size_t)se * 128 + 64];
-                    ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
-                    al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
-                    ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
-                    al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
+                    if (!(PR_SPLIT_ABLATE & 1)) {
+                        bhE = wp[(size_t)se * 128];
+                        blE = wp[(size_t)se * 128 + 64];
+                    }
+                    if (!(PR_SPLIT_ABLATE & 2)) {
+                        ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
+                        al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
+                        ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
+                        al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
+                    }
                     PR_MFMA16(m0, ah0O, bhO);
                     PR_MFMA16(m1, ah1O, bhO);
                     PR_MFMA16(c0, ah0O, blO);
                     PR_MFMA16(c1, ah1O, blO);
                     PR_MFMA16(c0, al0O, bhO);
                     PR_MFMA16(c1, al1O, bhO);
-                    bhO = wp[(size_t)so * 128];
-                    blO = wp[(size_t)so * 128 + 64];
-                    ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
-                    al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
-                    ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
-                    al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
+                    if (!(PR_SPLIT_ABLATE & 1)) {
+                        bhO = wp[(size_t)so * 128];
+                        blO = wp[(size_t)so * 128 + 64];
+                    }
+                    if (!(PR_SPLIT_ABLATE & 2)) {
+                        ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
+                        al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
+                        ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
+                        al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -170,15 +196,19 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                     PR_MFMA16(m0, ah0E, bhE);
                     PR_MFMA16(c0, ah0E, blE);
                     PR_MFMA16(c0, al0E, bhE);
-                    bhE = wp[(size_t)se * 128];
-                    blE = wp[(size_t)se * 128 + 64];
+                    if (!(PR_SPLIT_ABLATE & 1)) {
+                        bhE = wp[(size_t)se * 128];
+                        blE = wp[(size_t)se * 128 + 64];
+                    }
                     ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
                     al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
                     PR_MFMA16(m0, ah0O, bhO);
                     PR_MFMA16(c0, ah0O, blO);
                     PR_MFMA16(c0, al0O, bhO);
-                    bhO = wp[(size_t)so * 128];
-                    blO = wp[(size_t)so * 128 + 64];
+                    if (!(PR_SPLIT_ABLATE & 1)) {
+                        bhO = wp[(size_t)so * 128];
+                        blO = wp[(size_t)so * 128 + 64];
+                    }
                     ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
                     al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
@@ -191,8 +221,10 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             }
         }
     }
+    PR_PHASE(3);
     __syncthreads();  // every wave has finished reading the activation planes
-    if (active) {
+    PR_PHASE(4);
+    if (active && !((PR_SPLIT_ABLATE & 8) && L.epi != EPI_FEATURES)) {
         const int col = cb * 32 + r;
         const int rowA = (both ? 0 : rb * 32) + 4 * half;
         if (L.epi == EPI_RELU) {
@@ -215,7 +247,9 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             if (both) store_stage_h(m1, c1, stage, rowA + 32, col);
         }
     }
+    PR_PHASE(5);
     __syncthreads();
+    PR_PHASE(6);
 }
 
 __device__ __forceinline__ void fill_encoding_h(SmemH& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
@@ -273,6 +307,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
     __syncthreads();
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
+        PR_PHASE_T0();
         if (tid == 0) S.uniform_frame = 1;
         if (tid < TILE_M) {
             const int idx = tile_base + tid;
@@ -301,6 +336,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
         }
         __syncthreads();
         if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        PR_PHASE(0);
 
         if (p.has_bender) {
             fill_encoding_h(S, p, 3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, true);
@@ -335,10 +371,13 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
             }
             __syncthreads();
         }
+        PR_PHASE(1);
 
         fill_encoding_h(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
         __syncthreads();
+        PR_PHASE(2);
         for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p);
+        PR_PHASE(15);
 
         if (p.kind == 0) {
             float sg;
@@ -351,7 +390,9 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
             if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
         }
 
+        PR_PHASE(7);
         for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p);
+        PR_PHASE(15);
 
         // feature rows: the last layer staged an fp32 tile over the activation planes
         {
@@ -376,6 +417,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
             }
         }
         __syncthreads();
+        PR_PHASE(8);
     }
 }
 
@@ -397,7 +439,97 @@ int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s) {
     ProfileScope scope(0, s);
     hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(MLP_THREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();
+#if PR_SPLIT_ABLATE & 64
+    {
+        static unsigned long long total[16];
+        unsigned long long now[16];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(now, HIP_SYMBOL(g_phase_cycles), sizeof(now));
+        fprintf(stderr, "[split phases, cumulative Mcycles of thread 0 summed over workgroups]");
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " p%d=%.1f", i, (double)now[i] * 1e-6);
+        fprintf(stderr, "\n");
+        (void)total;
+    }
+#endif
     return PR_OK;
 }
 
+// fp16 matrix-pipe ceiling probe: the split kernel's own issue pattern (two main and two correction
+// accumulators, six MFMAs per step) with register-only operands
+__global__ __launch_bounds__(512) void k_probe_mfma_f16(int iterations, float* sink, int random_operands) {
+    f32x16 m0, m1, c0, c1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        m0[i] = 0.f;
+        m1[i] = 1.f;
+        c0[i] = 0.f;
+        c1[i] = 1.f;
+    }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    union Frag { u32x4 u; f16x8 h; };
+    Frag a, b;
+    unsigned int x = 0x9E3779B9u * (threadIdx.x + 1) + blockIdx.x;
+    for (int k = 0; k < 4; ++k) {
+        a.u[k] = 0x3C003C00u;   // 1.0, 1.0
+        b.u[k] = 0x38003800u;   // 0.5, 0.5
+    }
+    for (int it = 0; it < iterations; ++it) {
+        if (random_operands) {
+            for (int k = 0; k < 4; ++k) {
+                x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+                a.u[k] = (x & 0x83FF83FFu) | 0x38003800u;   // halves in +-[0.5, 1)
+                b.u[k] = ((x * 2654435761u) & 0x83FF83FFu) | 0x38003800u;
+            }
+        }
+        PR_MFMA16(m0, a.h, b.h);
+        PR_MFMA16(m1, b.h, a.h);
+        PR_MFMA16(c0, a.h, a.h);
+        PR_MFMA16(c1, b.h, b.h);
+        PR_MFMA16(c0, b.h, a.h);
+        PR_MFMA16(c1, a.h, b.h);
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                m0[i] *= 0.001f;
+                m1[i] *= 0.001f;
+                c0[i] *= 0.001f;
+                c1[i] *= 0.001f;
+            }
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += m0[i] + m1[i] + c0[i] + c1[i];
+    if (t == 123.456f) sink[0] = t;
+}
+
 }  // namespace pr
+
+extern "C" int pr_probe_mfma_f16(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream) {
+    PR_REQUIRE(iterations > 0 && tflops, "pr_probe_mfma_f16: bad argument");
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    hipStream_t s = (hipStream_t)stream;
+    float* sink = nullptr;
+    PR_CHECK_HIP(hipMalloc(&sink, sizeof(float)));
+    hipEvent_t e0, e1;
+    PR_CHECK_HIP(hipEventCreate(&e0));
+    PR_CHECK_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(pr::k_probe_mfma_f16, dim3(cus), dim3(512), 0, s, 16, sink, random_operands);  // warm-up
+    PR_CHECK_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(pr::k_probe_mfma_f16, dim3(cus), dim3(512), 0, s, iterations, sink, random_operands);
+    PR_CHECK_HIP(hipEventRecord(e1, s));
+    PR_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double flop = (double)cus * 8 * (double)iterations * 6.0 * (2.0 * 32 * 32 * 16);
+    *tflops = flop / (ms * 1e-3) / 1e12;
+    if (milliseconds) *milliseconds = ms;
+    PR_CHECK_HIP(hipEventDestroy(e0));
+    PR_CHECK_HIP(hipEventDestroy(e1));
+    PR_CHECK_HIP(hipFree(sink));
+    return PR_OK;
+}
