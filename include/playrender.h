@@ -52,6 +52,9 @@ typedef enum pr_status {
                                        the evaluated samples of each object call and update running_mean / running_var /
                                        num_batches_tracked in place (model/layers/adain.py:47,58) */
 
+#define PR_FLAG_SAVE_FOR_BACKWARD 32u /* keep every intermediate pr_render_backward needs inside the workspace (needs
+                                       PR_FLAG_TRAIN_BN); the workspace must stay untouched until the backward call */
+
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
     const float* weight;
@@ -190,6 +193,59 @@ int pr_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t*
 int pr_render_forward(const pr_call_t* call, const pr_object_t* objects,
                       const pr_outputs_t* coarse, const pr_outputs_t* fine,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward pass of pr_render_forward (what torch.autograd does for the reference's op graph when
+ * training/trainer_backpropagated_autoencoder.py:349 calls total_loss.backward()).  The forward call must
+ * have run with PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD on the same `call`, `objects` and
+ * `forward_workspace`, which must not have been touched since.  use_fine calls are not differentiable yet.
+ *
+ * Incoming gradients (d loss / d output field, same shapes as pr_entry_t; NULL = zero):
+ */
+typedef struct pr_entry_grads_t {
+    const float* integrated_features;                 /* (N,R,F) */
+    const float* opacity;                             /* (N,R) */
+    const float* depth;                               /* (N,R) */
+    const float* integrated_displacements_magnitude;  /* (N,R): flows into the displacements only, the weights are
+                                                         detached there (object_composer.py:772) */
+} pr_entry_grads_t;
+
+typedef struct pr_output_grads_t {
+    pr_entry_grads_t object[PR_MAX_OBJECTS];
+    pr_entry_grads_t global;
+} pr_output_grads_t;
+
+/* Gradient buffers of one object model, shaped like the parameters (nn.Linear layout).  The library ACCUMULATES
+ * (+=) into them: the caller zero-initialises; object instances that share a model pass the same pointers.
+ * Any pointer may be NULL (gradient not wanted). */
+typedef struct pr_linear_grad_t {
+    float* weight;
+    float* bias;
+} pr_linear_grad_t;
+
+typedef struct pr_model_grads_t {
+    pr_linear_grad_t backbone[PR_MAX_LAYERS];
+    pr_linear_grad_t alpha_head;
+    pr_linear_grad_t head0;
+    pr_linear_grad_t affine1;
+    pr_linear_grad_t head3;
+    pr_linear_grad_t affine4;
+    pr_linear_grad_t head6;
+    pr_linear_grad_t bender[PR_MAX_LAYERS];
+    pr_linear_grad_t bender_out;
+} pr_model_grads_t;
+
+typedef struct pr_input_grads_t {
+    float* w2o;              /* (N,K,3,4) accumulated; or NULL */
+    float* style;            /* (N,K,S)  accumulated; or NULL */
+    float* deformation;      /* (N,K,D)  accumulated; or NULL */
+    pr_model_grads_t model[PR_MAX_OBJECTS];   /* per object instance (coarse models) */
+} pr_input_grads_t;
+
+int pr_backward_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes);
+int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads,
+                       const pr_input_grads_t* out, void* forward_workspace, size_t forward_workspace_bytes,
+                       void* backward_workspace, size_t backward_workspace_bytes, void* stream);
 
 /*
  * Camera rays (RayHelper.create_camera_rays + pixel selection + transform_rays, ray_helper.py:15-52,

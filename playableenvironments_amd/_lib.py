@@ -18,6 +18,7 @@ PR_FLAG_CANONICAL_POSE = 2
 PR_FLAG_FIX_OVERLAPS = 4
 PR_FLAG_NAIVE_MLP = 8
 PR_FLAG_TRAIN_BN = 16
+PR_FLAG_SAVE_FOR_BACKWARD = 32
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
 
@@ -94,6 +95,34 @@ class Call(C.Structure):
     ]
 
 
+class EntryGrads(C.Structure):
+    _fields_ = [("integrated_features", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
+                ("integrated_displacements_magnitude", C.c_void_p)]
+
+
+GRAD_FIELDS = [f[0] for f in EntryGrads._fields_]
+
+
+class OutputGrads(C.Structure):
+    _fields_ = [("object", EntryGrads * PR_MAX_OBJECTS), ("global_", EntryGrads)]
+
+
+class LinearGrad(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class ModelGrads(C.Structure):
+    _fields_ = [
+        ("backbone", LinearGrad * PR_MAX_LAYERS), ("alpha_head", LinearGrad), ("head0", LinearGrad), ("affine1", LinearGrad),
+        ("head3", LinearGrad), ("affine4", LinearGrad), ("head6", LinearGrad), ("bender", LinearGrad * PR_MAX_LAYERS),
+        ("bender_out", LinearGrad),
+    ]
+
+
+class InputGrads(C.Structure):
+    _fields_ = [("w2o", C.c_void_p), ("style", C.c_void_p), ("deformation", C.c_void_p), ("model", ModelGrads * PR_MAX_OBJECTS)]
+
+
 # every exported symbol of include/playrender.h : (restype, argtypes)
 SYMBOLS = {
     "pr_packed_size": (C.c_int, [C.POINTER(ObjectModel), C.POINTER(C.c_size_t)]),
@@ -101,6 +130,9 @@ SYMBOLS = {
     "pr_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
     "pr_render_forward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(Outputs), C.POINTER(Outputs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pr_backward_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
+    "pr_render_backward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(OutputGrads), C.POINTER(InputGrads),
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pr_camera_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_profile_enable": (C.c_int, [C.c_int]),

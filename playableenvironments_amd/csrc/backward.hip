@@ -1,0 +1,1147 @@
+// Backward pass of the renderer (what autograd does for the reference graph when
+// training/trainer_backpropagated_autoencoder.py:349 calls total_loss.backward()):
+//
+//   compositing backward  (object_composer.py:153-214, :399-447, :724-784 differentiated)
+//     -> per object: feature-head / BatchNorm(train) / AdaIN backward, backbone, positional encoding,
+//        ray bender (adain_style_nerf_model.py:57-145, layers/adain.py:5-61, positional_ray_bender_model.py:81-163)
+//     -> sample placement / slab test backward into the object poses (ray_helper.py:1180-1282,
+//        object_composer.py:104-151).
+//
+// The forward pass ran with PR_FLAG_SAVE_FOR_BACKWARD: every layer input is in the forward workspace as
+// compact fp32 rows, so each layer's backward is two dense products - dX = dY.W and dW = dY^T.X (gemm.hip,
+// exact fp32 MFMA) - plus thin elementwise kernels.  Gradient buffers are accumulated into.
+#include "pr_common.h"
+#include "composite_dev.h"
+
+namespace pr {
+
+constexpr int BWD_SPLITS = 128;       // sample-dimension split of the weight-gradient products
+constexpr int MAX_FCHUNK_B = 4;
+
+// ---------------------------------------------------------------------------------------------
+// Compositing backward
+// ---------------------------------------------------------------------------------------------
+struct CompositeBwdObject {
+    const float* t;
+    const float* sigma;
+    const int32_t* slot;
+    const float* dispmag;    // or NULL
+    const float* feat;       // compact rows
+    const float* noise;      // integrate noise (N,R,P) or NULL
+    int positions;
+    pr_entry_grads_t g;      // gradients of results["object_k"]
+    float* g_feat;           // (cap, F) compact rows, every in-box row is written
+    float* g_sigma;          // (N,R,P)
+    float* g_t;              // (N,R,P)
+    float* g_dm;             // (N,R,P) or NULL
+};
+struct CompositeBwdParams {
+    int frames, rays, objects, static_objects, F;
+    int fix_overlaps;
+    int total_positions;
+    int sort_size;
+    const float* ray_directions;
+    const float* noise_global;
+    CompositeBwdObject obj[PR_MAX_OBJECTS];
+    pr_entry_grads_t global;
+};
+
+struct BwdSmem {
+    unsigned long long* key;
+    float *tt, *sg, *dm, *wo, *wg, *al, *gs, *gt, *gd, *Tj, *wv, *dw, *dd;
+    int *sl, *mk;
+};
+
+// T_j = prod_{i<j} (1 - alpha_i + 1e-10) and w_j = alpha_j T_j, same association as the forward kernel
+__device__ __forceinline__ void transmittance_scan(const float* al, float* Tj, float* wv, int n, int lane) {
+    float carry = 1.0f;
+    for (int base = 0; base < n; base += 64) {
+        const int j = base + lane;
+        const float a = (j < n) ? al[j] : 0.f;
+        float incl = (j < n) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl *= o;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (j < n) {
+            Tj[j] = carry * excl;
+            wv[j] = a * (carry * excl);
+        }
+        carry *= __shfl(incl, 63, 64);
+    }
+}
+
+// Backward of integrate() over one sample list of the ray.  sorted = false: entries off .. off + n in
+// order; sorted = true: the merged list in key order.  Adds into gs / gt / gd (per concatenation entry).
+__device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdSmem& sm, bool sorted, int off, int n,
+                                               const float* noise, float norm, const pr_entry_grads_t& g, long ray,
+                                               float* weights_out, int lane) {
+    const int F = p.F;
+    auto entry_of = [&](int j) -> int { return sorted ? (int)(sm.key[j] & 0xFFFFFFFFu) : off + j; };
+    for (int j = lane; j < n; j += 64) {
+        const int e = entry_of(j);
+        const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
+        float raw = sm.sg[e];
+        if (noise) raw = __fadd_rn(raw, noise[j]);
+        sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
+    }
+    __syncthreads();
+    transmittance_scan(sm.al, sm.Tj, sm.wv, n, lane);
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) weights_out[entry_of(j)] = sm.wv[j];
+
+    const float gO = g.opacity ? g.opacity[ray] : 0.f;
+    const float gD = g.depth ? g.depth[ray] : 0.f;
+    const float gM = g.integrated_displacements_magnitude ? g.integrated_displacements_magnitude[ray] : 0.f;
+    const bool has_gf = g.integrated_features != nullptr;
+    if (!has_gf && gO == 0.f && gD == 0.f && gM == 0.f) {   // uniform: nothing flows into this entry
+        __syncthreads();
+        return;
+    }
+    float gF[MAX_FCHUNK_B];
+#pragma unroll
+    for (int c = 0; c < MAX_FCHUNK_B; ++c) {
+        const int ch = lane + 64 * c;
+        gF[c] = (has_gf && ch < F) ? g.integrated_features[(size_t)ray * F + ch] : 0.f;
+    }
+    // d loss / d w_j
+    for (int j = 0; j < n; ++j) {
+        const int e = entry_of(j);
+        const int row = sm.sl[e];
+        float dot = 0.f;
+        if (has_gf && row >= 0 && sm.Tj[j] != 0.f) {
+            int k = 0, o2 = 0;
+            while (k + 1 < p.objects && e >= o2 + p.obj[k].positions) {
+                o2 += p.obj[k].positions;
+                ++k;
+            }
+            const float* f = p.obj[k].feat + (size_t)row * F;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK_B; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < F) part = fmaf(gF[c], f[ch], part);
+            }
+            dot = wave_sum(part);
+        }
+        if (lane == 0) sm.dw[j] = dot + gO + gD * sm.tt[e];
+    }
+    __syncthreads();
+    // d loss / d alpha_j = dw_j T_j - (sum_{i>j} dw_i w_i) / (1 - alpha_j + 1e-10)
+    if (lane == 0) {
+        float suffix = 0.f;
+        for (int j = n - 1; j >= 0; --j) {
+            const float dwj = sm.dw[j];
+            sm.dw[j] = dwj * sm.Tj[j] - suffix / __fadd_rn(__fsub_rn(1.0f, sm.al[j]), 1e-10f);
+            suffix = fmaf(dwj, sm.wv[j], suffix);
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {
+        const int e = entry_of(j);
+        const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
+        const float dist = __fmul_rn(dt, norm);
+        float raw = sm.sg[e];
+        if (noise) raw = __fadd_rn(raw, noise[j]);
+        const float s = raw > 0.f ? raw : 0.f;
+        const float E = expf(__fmul_rn(-s, dist));
+        const float da = sm.dw[j];
+        sm.dd[j] = (j < n - 1) ? da * s * E * norm : 0.f;
+        if (!sm.mk[e]) {
+            if (raw > 0.f) sm.gs[e] += da * dist * E;
+            sm.gt[e] += gD * sm.wv[j];
+            sm.gd[e] += gM * sm.wv[j] / (float)n;
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {
+        const int e = entry_of(j);
+        if (!sm.mk[e]) sm.gt[e] += ((j > 0) ? sm.dd[j - 1] : 0.f) - sm.dd[j];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
+    const int S = p.sort_size;
+    const int A = (p.total_positions + 63) & ~63;
+    BwdSmem sm;
+    sm.key = reinterpret_cast<unsigned long long*>(raw_smem);
+    float* fp = reinterpret_cast<float*>(sm.key + S);
+    sm.tt = fp; fp += A;
+    sm.sg = fp; fp += A;
+    sm.dm = fp; fp += A;
+    sm.wo = fp; fp += A;
+    sm.wg = fp; fp += A;
+    sm.al = fp; fp += A;
+    sm.gs = fp; fp += A;
+    sm.gt = fp; fp += A;
+    sm.gd = fp; fp += A;
+    sm.Tj = fp; fp += A;
+    sm.wv = fp; fp += A;
+    sm.dw = fp; fp += A;
+    sm.dd = fp; fp += A;
+    sm.sl = reinterpret_cast<int*>(fp); fp += A;
+    sm.mk = reinterpret_cast<int*>(fp);
+
+    const int lane = threadIdx.x;
+    const long g = blockIdx.x;
+    const float* d = p.ray_directions + (size_t)g * 3;
+    const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const int PT = p.total_positions;
+
+    int off = 0;
+    for (int k = 0; k < p.objects; ++k) {
+        const CompositeBwdObject& o = p.obj[k];
+        const int P = o.positions;
+        const size_t base = (size_t)g * P;
+        for (int i = lane; i < P; i += 64) {
+            sm.tt[off + i] = o.t[base + i];
+            sm.sg[off + i] = o.sigma[base + i];
+            sm.sl[off + i] = o.slot[base + i];
+            sm.dm[off + i] = o.dispmag ? o.dispmag[base + i] : 0.f;
+            sm.gs[off + i] = 0.f;
+            sm.gt[off + i] = 0.f;
+            sm.gd[off + i] = 0.f;
+            sm.mk[off + i] = 0;
+            sm.wg[off + i] = 0.f;
+        }
+        off += P;
+    }
+    __syncthreads();
+    // ---- per-object entries (integrated before the overlap fix, as the reference does) ------------
+    off = 0;
+    for (int k = 0; k < p.objects; ++k) {
+        const CompositeBwdObject& o = p.obj[k];
+        const int P = o.positions;
+        entry_backward(p, sm, false, off, P, o.noise ? o.noise + (size_t)g * P : nullptr, norm, o.g, g, sm.wo, lane);
+        off += P;
+    }
+    // ---- overlap fix: carved static samples are constants (sigma = -10, t = 0, |delta| = 0) -----------
+    if (p.fix_overlaps) {
+        int dyn_off0 = 0;
+        for (int k = 0; k < p.static_objects; ++k) dyn_off0 += p.obj[k].positions;
+        int soff = 0;
+        for (int s = 0; s < p.static_objects; ++s) {
+            const int Ps = p.obj[s].positions;
+            unsigned int masked_bits = 0;
+            int doff = dyn_off0;
+            for (int dd = p.static_objects; dd < p.objects; ++dd) {
+                const float b0 = sm.tt[doff + 0];
+                const float b1 = sm.tt[doff + Ps - 1];
+                int lo0 = 0, hi0 = Ps;
+                while (lo0 < hi0) {
+                    const int mid = (lo0 + hi0) >> 1;
+                    if (sm.tt[soff + mid] < b0) lo0 = mid + 1; else hi0 = mid;
+                }
+                int lo1 = 0, hi1 = Ps;
+                while (lo1 < hi1) {
+                    const int mid = (lo1 + hi1) >> 1;
+                    if (sm.tt[soff + mid] < b1) lo1 = mid + 1; else hi1 = mid;
+                }
+                int m = 0;
+                for (int i = lane; i < Ps; i += 64, ++m)
+                    if (i >= lo0 && i < lo1) masked_bits |= 1u << m;
+                doff += p.obj[dd].positions;
+            }
+            __syncthreads();
+            int m = 0;
+            for (int i = lane; i < Ps; i += 64, ++m) {
+                if ((masked_bits >> m) & 1u) {
+                    sm.tt[soff + i] = 0.f;
+                    sm.sg[soff + i] = -10.0f;
+                    sm.dm[soff + i] = 0.f;
+                    sm.mk[soff + i] = 1;
+                }
+            }
+            __syncthreads();
+            soff += Ps;
+        }
+    }
+    // ---- merged list ---------------------------------------------------------------------------------
+    for (int e = lane; e < S; e += 64)
+        sm.key[e] = (e < PT) ? (((unsigned long long)float_order_bits(sm.tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
+    for (int kk = 2; kk <= S; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < S; i += 64) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned long long a = sm.key[i], b = sm.key[x];
+                    const bool up = ((i & kk) == 0);
+                    if ((a > b) == up) {
+                        sm.key[i] = b;
+                        sm.key[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
+
+    // ---- write the per-sample gradients ----------------------------------------------------------------
+    const int F = p.F;
+    float gFg[MAX_FCHUNK_B];
+#pragma unroll
+    for (int c = 0; c < MAX_FCHUNK_B; ++c) {
+        const int ch = lane + 64 * c;
+        gFg[c] = (p.global.integrated_features && ch < F) ? p.global.integrated_features[(size_t)g * F + ch] : 0.f;
+    }
+    off = 0;
+    for (int k = 0; k < p.objects; ++k) {
+        const CompositeBwdObject& o = p.obj[k];
+        const int P = o.positions;
+        const size_t base = (size_t)g * P;
+        for (int i = lane; i < P; i += 64) {
+            o.g_sigma[base + i] = sm.gs[off + i];
+            o.g_t[base + i] = sm.gt[off + i];
+            if (o.g_dm) o.g_dm[base + i] = sm.gd[off + i];
+        }
+        float gFo[MAX_FCHUNK_B];
+#pragma unroll
+        for (int c = 0; c < MAX_FCHUNK_B; ++c) {
+            const int ch = lane + 64 * c;
+            gFo[c] = (o.g.integrated_features && ch < F) ? o.g.integrated_features[(size_t)g * F + ch] : 0.f;
+        }
+        for (int i = 0; i < P; ++i) {
+            const int row = sm.sl[off + i];
+            if (row < 0) continue;
+            const float w1 = sm.wo[off + i], w2 = sm.wg[off + i];
+            float* dst = o.g_feat + (size_t)row * F;
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK_B; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < F) dst[ch] = fmaf(w1, gFo[c], w2 * gFg[c]);
+            }
+        }
+        off += P;
+    }
+}
+
+static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
+    PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
+    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
+    PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const long total = (long)p.frames * p.rays;
+    hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)total), dim3(64), lds, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise kernels of the per-object network backward.  "rows" = compact evaluated samples, M = *total.
+// flags: bit 0 = real sample, bit 1 = passed the second AABB test (its outputs are used).
+// ---------------------------------------------------------------------------------------------
+struct RowCtx {
+    const int32_t* total;
+    const int32_t* rec_flat;
+    const int32_t* row_flags;
+    int samples_per_frame;
+};
+
+// gathers the dense sigma / |delta| gradients to rows and clears the feature gradients of unused rows
+__global__ __launch_bounds__(256) void k_gather_rows(RowCtx r, const float* g_sigma, const float* g_dm, float* gsr, float* gdr,
+                                                     float* g_feat, int F) {
+    const int M = *r.total;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const int fl = r.row_flags[m];
+        const int flat = r.rec_flat[m];
+        if (threadIdx.x == 0) {
+            gsr[m] = ((fl & 3) == 3) ? g_sigma[flat] : 0.f;
+            if (gdr) gdr[m] = (fl & 1) ? g_dm[flat] : 0.f;
+        }
+        if ((fl & 3) != 3)
+            for (int c = threadIdx.x; c < F; c += 256) g_feat[(size_t)m * F + c] = 0.f;
+    }
+}
+
+// a = relu(h * g[frame] + b[frame]) for the alive rows, 0 otherwise (train-mode AdaIN table: g = scale * rstd)
+__global__ __launch_bounds__(256) void k_adain_recompute(RowCtx r, const float* h, int ld, int width, const float* table,
+                                                         int table_stride, int goff, int boff, float* a) {
+    const int M = *r.total;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const bool alive = (r.row_flags[m] & 3) == 3;
+        const float* tab = table + (size_t)(r.rec_flat[m] / r.samples_per_frame) * table_stride;
+        for (int c = threadIdx.x; c < width; c += 256) {
+            float v = 0.f;
+            if (alive) {
+                v = fmaf(h[(size_t)m * ld + c], tab[goff + c], tab[boff + c]);
+                v = v > 0.f ? v : 0.f;
+            }
+            a[(size_t)m * ld + c] = v;
+        }
+    }
+}
+
+struct AdainBwd {
+    RowCtx r;
+    const float* h; int ld; int width;
+    const float* table; int table_stride, goff, boff;
+    const float* mean; const float* var; float eps;
+    float* g;               // in: d loss / d a (post-ReLU); out (reduce): d x_hat; out (apply): d h
+    double* sums;           // [sum d x_hat (width) | sum d x_hat * x_hat (width)]
+    float* dscale;          // (frames, width) accumulated
+    float* dbias;           // (frames, width)
+    const int32_t* count;   // rows that entered the batch statistics
+};
+
+// thread c owns channel c of a block of 256 rows
+__global__ __launch_bounds__(256) void k_adain_bwd_reduce(AdainBwd p) {
+    const int M = *p.r.total;
+    const int c = threadIdx.x;
+    if (c >= p.width) return;
+    const float mu = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
+    double s1 = 0.0, s2 = 0.0;
+    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+        int cur = -1;
+        float ds = 0.f, db = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            const size_t at = (size_t)m * p.ld + c;
+            float dxh = 0.f;
+            if ((p.r.row_flags[m] & 3) == 3) {
+                const int frame = p.r.rec_flat[m] / p.r.samples_per_frame;
+                if (frame != cur) {
+                    if (cur >= 0) {
+                        atomicAdd(p.dscale + (size_t)cur * p.width + c, ds);
+                        atomicAdd(p.dbias + (size_t)cur * p.width + c, db);
+                    }
+                    cur = frame;
+                    ds = 0.f;
+                    db = 0.f;
+                }
+                const float* tab = p.table + (size_t)frame * p.table_stride;
+                const float gg = tab[p.goff + c];
+                const float hv = p.h[at];
+                const float y = fmaf(hv, gg, tab[p.boff + c]);
+                const float dy = y > 0.f ? p.g[at] : 0.f;
+                const float xh = (hv - mu) * rstd;
+                ds = fmaf(dy, xh, ds);
+                db += dy;
+                dxh = dy * (gg / rstd);   // scale = g / rstd
+                s1 += (double)dxh;
+                s2 += (double)dxh * (double)xh;
+            }
+            p.g[at] = dxh;
+        }
+        if (cur >= 0) {
+            atomicAdd(p.dscale + (size_t)cur * p.width + c, ds);
+            atomicAdd(p.dbias + (size_t)cur * p.width + c, db);
+        }
+    }
+    atomicAdd(p.sums + c, s1);
+    atomicAdd(p.sums + p.width + c, s2);
+}
+
+// BatchNorm (batch statistics) backward: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))
+__global__ __launch_bounds__(256) void k_adain_bwd_apply(AdainBwd p) {
+    const int M = *p.r.total;
+    const int c = threadIdx.x;
+    if (c >= p.width) return;
+    const double n = (double)*p.count;
+    const float mu = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
+    const float m1 = (float)(p.sums[c] / n), m2 = (float)(p.sums[p.width + c] / n);
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const size_t at = (size_t)m * p.ld + c;
+        float v = 0.f;
+        if ((p.r.row_flags[m] & 3) == 3) {
+            const float xh = (p.h[at] - mu) * rstd;
+            v = rstd * (p.g[at] - m1 - xh * m2);
+        }
+        p.g[at] = v;
+    }
+}
+
+// d act7 = (d act7 + gsr * w_sigma) masked by act7 > 0; d w_sigma += sum gsr * act7, d b_sigma += sum gsr
+__global__ __launch_bounds__(256) void k_sigma_bwd(RowCtx r, float* g, const float* act, int ld, int width, const float* gsr,
+                                                   const float* w_sigma, float* dw, float* db) {
+    const int M = *r.total;
+    const int c = threadIdx.x;
+    if (c >= width) return;
+    const float ws = (gsr && w_sigma) ? w_sigma[c] : 0.f;
+    float acc = 0.f, accb = 0.f;
+    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+        for (int m = m0; m < m1; ++m) {
+            const size_t at = (size_t)m * ld + c;
+            const float gs = gsr ? gsr[m] : 0.f;
+            const float a = act[at];
+            acc = fmaf(gs, a, acc);
+            accb += gs;
+            const float v = fmaf(gs, ws, g[at]);
+            g[at] = a > 0.f ? v : 0.f;
+        }
+    }
+    if (gsr && dw) atomicAdd(dw + c, acc);
+    if (gsr && db && c == 0) atomicAdd(db, accb);
+}
+
+// Positional-encoding backward from the saved encoding (sin / cos values are reused):
+//   d v_a = g[a] + sum_k 2^k (cos_ka g[sin_ka] - sin_ka g[cos_ka])
+// out[m][a] (ld_out floats per row) = d v_a / divide[a]; rows that are not `need` get zeros.
+__global__ __launch_bounds__(256) void k_pe_bwd(RowCtx r, const float* enc, const float* g_enc, int ld, int din, int octaves,
+                                                float d0, float d1, float d2, int need_mask, float* out, int ld_out, int accumulate) {
+    const int M = *r.total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const bool need = (r.row_flags[m] & need_mask) == need_mask;
+    const float* e = enc + (size_t)m * ld;
+    const float* g = g_enc + (size_t)m * ld;
+    const float div[3] = {d0, d1, d2};
+    for (int a = 0; a < din; ++a) {
+        float v = 0.f;
+        if (need) {
+            v = g[a];
+            for (int k = 0; k < octaves; ++k) {
+                const int sn = din + k * 2 * din + a, cs = sn + din;
+                v += ldexpf(1.0f, k) * (e[cs] * g[sn] - e[sn] * g[cs]);
+            }
+            if (a < 3 && div[a] != 0.f) v /= div[a];
+        }
+        float* dst = out + (size_t)m * ld_out + a;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+// Bender output backward: bent = x + delta, delta = clamp(raw * size, lo - x, hi - x) (* 0 in canonical pose),
+// |delta| feeds integrated_displacements_magnitude.  In: g_bent (M,3) = d loss / d bent.  Out: g_x (M,3)
+// (the direct paths), g_braw (M,3).
+__global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g_bent, const float* gdr, const float* delta,
+                                                        const float* braw, const float* pos, float lo0, float lo1, float lo2,
+                                                        float hi0, float hi1, float hi2, int canonical, float* g_x, float* g_braw) {
+    const int M = *r.total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const bool real = (r.row_flags[m] & 1) != 0;
+    float dl[3], nrm = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        dl[a] = delta[(size_t)m * 3 + a];
+        nrm = fmaf(dl[a], dl[a], nrm);
+    }
+    nrm = sqrtf(nrm);
+    const float gd = (real && gdr) ? gdr[m] : 0.f;
+    for (int a = 0; a < 3; ++a) {
+        const float gb = real ? g_bent[(size_t)m * 3 + a] : 0.f;
+        float g_delta = gb + (nrm > 0.f ? gd * dl[a] / nrm : 0.f);
+        if (canonical) g_delta = 0.f;
+        const float x = pos[(size_t)m * 3 + a];
+        const float pre = braw[(size_t)m * 3 + a] * (hi[a] - lo[a]);
+        const float lob = lo[a] - x, hib = hi[a] - x;
+        const float m1 = pre > lob ? pre : lob;
+        float g_pre = 0.f, gx = gb;
+        if (m1 > hib) gx -= g_delta;            // delta = hi - x
+        else if (pre >= lob) g_pre = g_delta;   // unclamped
+        else gx -= g_delta;                     // delta = lo - x
+        g_x[(size_t)m * 3 + a] = real ? gx : 0.f;
+        g_braw[(size_t)m * 3 + a] = real ? g_pre * (hi[a] - lo[a]) : 0.f;
+    }
+}
+
+// Bender head (3, BW), no bias: d act = (g_braw . W) masked by act > 0 ; dW[a][c] += sum_m g_braw[m][a] act[m][c]
+__global__ __launch_bounds__(256) void k_bender_head_bwd(RowCtx r, const float* g_braw, const float* act, int ld, int width,
+                                                         const float* w_out, int w_ld, float* g_act, float* dw) {
+    const int M = *r.total;
+    const int c = threadIdx.x;
+    if (c >= width) return;
+    const float w0 = w_out[c], w1 = w_out[w_ld + c], w2 = w_out[2 * w_ld + c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+        for (int m = m0; m < m1; ++m) {
+            const float g0 = g_braw[(size_t)m * 3], g1 = g_braw[(size_t)m * 3 + 1], g2 = g_braw[(size_t)m * 3 + 2];
+            const float a = act[(size_t)m * ld + c];
+            a0 = fmaf(g0, a, a0);
+            a1 = fmaf(g1, a, a1);
+            a2 = fmaf(g2, a, a2);
+            g_act[(size_t)m * ld + c] = a > 0.f ? fmaf(g0, w0, fmaf(g1, w1, g2 * w2)) : 0.f;
+        }
+    }
+    if (dw) {
+        atomicAdd(dw + c, a0);
+        atomicAdd(dw + w_ld + c, a1);
+        atomicAdd(dw + 2 * w_ld + c, a2);
+    }
+}
+
+// d deformation[frame][j] += sum over the rows of the frame of g_bin[m][benc + j]
+__global__ __launch_bounds__(64) void k_deformation_bwd(RowCtx r, const float* g_bin, int ld, int benc, int D, float* d_def,
+                                                        int def_stride) {
+    const int M = *r.total;
+    const int j = threadIdx.x;
+    if (j >= D) return;
+    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+        int cur = -1;
+        float acc = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            if (!(r.row_flags[m] & 1)) continue;
+            const int frame = r.rec_flat[m] / r.samples_per_frame;
+            if (frame != cur) {
+                if (cur >= 0) atomicAdd(d_def + (size_t)cur * def_stride + j, acc);
+                cur = frame;
+                acc = 0.f;
+            }
+            acc += g_bin[(size_t)m * ld + benc + j];
+        }
+        if (cur >= 0) atomicAdd(d_def + (size_t)cur * def_stride + j, acc);
+    }
+}
+
+// Style affine backward: [scale | bias] = A style + b  (layers/adain.py:30-33).  d_out (frames, 2 width) is
+// given as two tables dscale, dbias (frames, width).
+__global__ __launch_bounds__(256) void k_style_bwd(int frames, int width, int S, const float* dscale, const float* dbias,
+                                                   const float* style, int style_stride, const float* A, float* dA, float* db,
+                                                   float* d_style) {
+    const int rows = 2 * width;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (long)rows * S) {   // dA[r][s] += sum_f d_out[f][r] style[f][s]
+        const int rr = (int)(idx / S), s = (int)(idx - (long)rr * S);
+        const float* src = rr < width ? dscale + rr : dbias + (rr - width);
+        float acc = 0.f;
+        for (int f = 0; f < frames; ++f) acc = fmaf(src[(size_t)f * width], style[(size_t)f * style_stride + s], acc);
+        if (dA) dA[idx] += acc;
+        if (s == 0 && db) {
+            float b = 0.f;
+            for (int f = 0; f < frames; ++f) b += src[(size_t)f * width];
+            db[rr] += b;
+        }
+    }
+    if (d_style && idx < (long)frames * S) {   // d_style[f][s] += sum_r A[r][s] d_out[f][r]
+        const int f = (int)(idx / S), s = (int)(idx - (long)f * S);
+        float acc = 0.f;
+        for (int rr = 0; rr < rows; ++rr) {
+            const float dv = rr < width ? dscale[(size_t)f * width + rr] : dbias[(size_t)f * width + rr - width];
+            acc = fmaf(A[(size_t)rr * S + s], dv, acc);
+        }
+        d_style[(size_t)f * style_stride + s] += acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sample placement backward: one thread per (frame, ray) of one object.
+//   x_i = o + d t_i,  t_i = stratified(near, far),  near / far = clamped slab test of (o, d),
+//   o = R o_w + T, d = R d_w   ->   d loss / d w2o (3 x 4)
+// ---------------------------------------------------------------------------------------------
+struct GeometryBwd {
+    int frames, rays, positions, objects, object_index, kind;
+    const float* ray_origins;
+    const float* ray_directions;
+    const float* w2o;
+    const uint8_t* in_scene;
+    float lo[3], hi[3];
+    float z_near_min, z_far_max;
+    const float* linspace;
+    const float* jitter;
+    const float* t;          // (N,R,P) forward sample depths
+    const int32_t* slot;     // (N,R,P)
+    const float* g_t;        // (N,R,P) from the compositing backward
+    const float* g_x;        // (cap,3) rows: d loss / d x (object frame), or NULL
+    const float* g_in6;      // skybox: (cap,6) rows: d loss / d [o / size, d / |d|]
+    float* d_w2o;            // (N,K,3,4)
+};
+
+__global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
+    __shared__ float red[12 * 4];
+    const int n = blockIdx.y;                              // frame
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    const long g = (long)n * p.rays + ray;
+    float dM[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dM[i] = 0.f;
+    if (ray < p.rays) {
+        const float* M = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
+        const float* ow = p.ray_origins + (size_t)n * 3;
+        const float* dw = p.ray_directions + (size_t)g * 3;
+        const ObjRay rr = object_ray(M, ow, dw);
+        const bool present = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
+        // forward slab test, remembering the selected candidates
+        float zmin[3], zmax[3];
+        int min_hi[3];   // 1: the high corner gave the minimum along this axis
+        for (int a = 0; a < 3; ++a) {
+            const float den = __fadd_rn(rr.d[a], 1e-6f);
+            const float tl = __fdiv_rn(__fsub_rn(p.lo[a], rr.o[a]), den);
+            const float th = __fdiv_rn(__fsub_rn(p.hi[a], rr.o[a]), den);
+            min_hi[a] = th < tl;
+            zmin[a] = min_hi[a] ? th : tl;
+            zmax[a] = min_hi[a] ? tl : th;
+        }
+        int an = 0, af = 0;
+        for (int a = 1; a < 3; ++a) {
+            if (zmin[a] > zmin[an]) an = a;
+            if (zmax[a] < zmax[af]) af = a;
+        }
+        float near = zmin[an], far = zmax[af];
+        const bool hit = present && !(far <= near);
+        bool near_free = hit && near >= p.z_near_min && near <= p.z_far_max;
+        bool far_free = hit && far >= p.z_near_min && far <= p.z_far_max;
+        // accumulate over the samples
+        float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, g_near = 0.f, g_far = 0.f;
+        const int P = p.positions;
+        const size_t base = (size_t)g * P;
+        for (int i = 0; i < P; ++i) {
+            float gt = p.g_t[base + i];
+            const int row = p.slot[base + i];
+            if (row >= 0 && p.g_x) {
+                const float ti = p.t[base + i];
+                for (int a = 0; a < 3; ++a) {
+                    const float gx = p.g_x[(size_t)row * 3 + a];
+                    go[a] += gx;
+                    gd[a] = fmaf(gx, ti, gd[a]);
+                    gt = fmaf(gx, rr.d[a], gt);
+                }
+            }
+            if (row >= 0 && p.g_in6) {   // skybox input [o / size, d / |d|]
+                const float* gi = p.g_in6 + (size_t)row * 6;
+                const float nrm = sqrtf(rr.d[0] * rr.d[0] + rr.d[1] * rr.d[1] + rr.d[2] * rr.d[2]);
+                float dotg = 0.f;
+                for (int a = 0; a < 3; ++a) dotg = fmaf(gi[3 + a], rr.d[a] / nrm, dotg);
+                for (int a = 0; a < 3; ++a) {
+                    go[a] += gi[a] / (p.hi[a] - p.lo[a]);
+                    gd[a] += (gi[3 + a] - dotg * rr.d[a] / nrm) / nrm;
+                }
+            }
+            // t_i = near A_i + far B_i  (stratified_positions: linspace placement, optional jitter between midpoints)
+            const float s_i = p.linspace[i];
+            float An = 1.0f - s_i, Bf = s_i;
+            if (p.jitter) {
+                const float u = p.jitter[base + i];
+                const float s_lo = i > 0 ? 0.5f * (p.linspace[i - 1] + s_i) : s_i;
+                const float s_hi = i < P - 1 ? 0.5f * (p.linspace[i + 1] + s_i) : s_i;
+                Bf = s_lo + (s_hi - s_lo) * u;
+                An = 1.0f - Bf;
+            }
+            g_near = fmaf(gt, An, g_near);
+            g_far = fmaf(gt, Bf, g_far);
+        }
+        // slab test backward: tb = (c - o_a) / (d_a + eps)
+        if (near_free) {
+            const int a = an;
+            const float c = min_hi[a] ? p.hi[a] : p.lo[a];
+            const float den = __fadd_rn(rr.d[a], 1e-6f);
+            go[a] -= g_near / den;
+            gd[a] -= g_near * (c - rr.o[a]) / (den * den);
+        }
+        if (far_free) {
+            const int a = af;
+            const float c = min_hi[a] ? p.lo[a] : p.hi[a];
+            const float den = __fadd_rn(rr.d[a], 1e-6f);
+            go[a] -= g_far / den;
+            gd[a] -= g_far * (c - rr.o[a]) / (den * den);
+        }
+        // o_i = sum_j M[i][j] ow_j + M[i][3],  d_i = sum_j M[i][j] dw_j
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) dM[i * 4 + j] = go[i] * ow[j] + gd[i] * dw[j];
+            dM[i * 4 + 3] = go[i];
+        }
+    }
+    // block reduction (blockIdx.y = frame), then one atomic per matrix entry
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float v = wave_sum(dM[i]);
+        if (lane == 0) red[i * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3];
+        atomicAdd(p.d_w2o + ((size_t)n * p.objects + p.object_index) * 12 + threadIdx.x, v);
+    }
+}
+
+}  // namespace pr
+
+// ---------------------------------------------------------------------------------------------
+// Orchestration
+// ---------------------------------------------------------------------------------------------
+namespace pr {
+
+struct BwdPlan {
+    size_t g_feat[PR_MAX_OBJECTS], g_sigma[PR_MAX_OBJECTS], g_t[PR_MAX_OBJECTS], g_dm[PR_MAX_OBJECTS];
+    size_t bufA, bufB, act, g_enc, gsr, gdr, g_bent, g_x, g_braw, g_in6, partial, sums, tables;
+    size_t bytes;
+    size_t max_cap;
+};
+
+static size_t align_up_b(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* bp) {
+    memset(bp, 0, sizeof(*bp));
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align_up_b(bytes);
+        return at;
+    };
+    const size_t nr = (size_t)c.frames * c.rays;
+    size_t max_cap = 0;
+    for (int k = 0; k < c.objects; ++k) {
+        const pr_object_model_t& m = objs[k].coarse;
+        const size_t cap = nr * m.positions;
+        if (cap > max_cap) max_cap = cap;
+        bp->g_feat[k] = take(sizeof(float) * cap * m.output_features);
+        bp->g_sigma[k] = take(sizeof(float) * cap);
+        bp->g_t[k] = take(sizeof(float) * cap);
+        bp->g_dm[k] = take(sizeof(float) * cap);
+    }
+    bp->max_cap = max_cap;
+    bp->bufA = take(sizeof(float) * max_cap * MAX_WIDTH);
+    bp->bufB = take(sizeof(float) * max_cap * MAX_WIDTH);
+    bp->act = take(sizeof(float) * max_cap * MAX_WIDTH);
+    bp->g_enc = take(sizeof(float) * max_cap * MAX_ENC);
+    bp->gsr = take(sizeof(float) * max_cap);
+    bp->gdr = take(sizeof(float) * max_cap);
+    bp->g_bent = take(sizeof(float) * max_cap * 3);
+    bp->g_x = take(sizeof(float) * max_cap * 3);
+    bp->g_braw = take(sizeof(float) * max_cap * 3);
+    bp->g_in6 = take(sizeof(float) * max_cap * 6);
+    bp->partial = take(sizeof(float) * gemm_tn_scratch_floats(BWD_SPLITS));
+    bp->sums = take(sizeof(double) * 2 * MAX_WIDTH);
+    bp->tables = take(sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH);
+    bp->bytes = off;
+    return PR_OK;
+}
+
+struct GemmCtx {
+    const int32_t* rows;
+    int max_rows;
+    float* partial;
+    hipStream_t s;
+};
+
+static int weight_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, const float* X, int ldx, int n_in, float* dW,
+                       int ldw, float* dbias) {
+    if (!dW && !dbias) return PR_OK;
+    GemmTN p;
+    memset(&p, 0, sizeof(p));
+    p.A = dY; p.lda = ldy; p.B = X; p.ldb = ldx;
+    p.rows = g.rows; p.ni = n_out; p.nj = n_in; p.splits = BWD_SPLITS;
+    p.partial = g.partial;
+    p.bias_partial = dbias ? g.partial + (size_t)BWD_SPLITS * 256 * 384 : nullptr;
+    p.bias = dbias;
+    static float* dummy = nullptr;
+    (void)dummy;
+    if (!dW) {
+        // bias only: still run the product into the scratch (rare; keeps one code path)
+        p.C = g.partial + (size_t)BWD_SPLITS * 256 * 384 + (size_t)BWD_SPLITS * 256;   // never reduced into: ni * nj = 0 below
+        p.nj = 0;
+        return PR_OK;
+    }
+    p.C = dW; p.ldc = ldw;
+    return launch_gemm_tn(p, g.s);
+}
+
+static int input_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, const float* W, int ldw, int n_in, float* dX,
+                      int ldx, bool accumulate, const float* mask, int ldm) {
+    GemmNN p;
+    memset(&p, 0, sizeof(p));
+    p.A = dY; p.lda = ldy; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx;
+    p.rows = g.rows; p.n = n_in; p.k = n_out; p.accumulate = accumulate ? 1 : 0;
+    p.mask = mask; p.ldm = ldm;
+    return launch_gemm_nn(p, g.max_rows, g.s);
+}
+
+// Backward through a ReLU MLP with one skip concatenation (backbone of the NeRF or of the ray bender).
+// On entry `cur` holds d loss / d pre-activation of the last layer; `acts` are the saved post-ReLU outputs.
+// Returns with the gradient of the network input [PE | extra] accumulated in g_in (n_in0 real columns).
+static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_linear_grad_t* grads, int count, int skip,
+                          int width, int width_pad, const float* acts, size_t act_stride, const float* in0, int ld_in0,
+                          int n_in0, float* cur, float* other, float* g_in) {
+    bool g_in_written = false;
+    for (int l = count - 1; l >= 0; --l) {
+        const pr_linear_t& L = layers[l];
+        const float* prev = l > 0 ? acts + (size_t)(l - 1) * act_stride : nullptr;
+        if (l == 0) {
+            PR_TRY(weight_grad(g, cur, width_pad, width, in0, ld_in0, n_in0, grads[l].weight, L.in_features, grads[l].bias));
+            PR_TRY(input_grad(g, cur, width_pad, width, L.weight, L.in_features, n_in0, g_in, ld_in0, g_in_written, nullptr, 0));
+        } else {
+            PR_TRY(weight_grad(g, cur, width_pad, width, prev, width_pad, width, grads[l].weight, L.in_features, grads[l].bias));
+            if (l == skip) {
+                PR_TRY(weight_grad(g, cur, width_pad, width, in0, ld_in0, n_in0,
+                                   grads[l].weight ? grads[l].weight + width : nullptr, L.in_features, nullptr));
+                PR_TRY(input_grad(g, cur, width_pad, width, L.weight + width, L.in_features, n_in0, g_in, ld_in0, false, nullptr, 0));
+                g_in_written = true;
+            }
+            PR_TRY(input_grad(g, cur, width_pad, width, L.weight, L.in_features, width, other, width_pad, false, prev, width_pad));
+            float* tmp = cur;
+            cur = other;
+            other = tmp;
+        }
+    }
+    return PR_OK;
+}
+
+static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output_grads_t& grads, const pr_input_grads_t& out,
+                    char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s) {
+    const int K = c.objects;
+    const TypePlan& tp = plan.type[0];
+    int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
+    const int F = objs[0].coarse.output_features;
+    PR_REQUIRE(F % 16 == 0, "backward: output_features %d must be a multiple of 16", F);
+
+    // ---- compositing backward ---------------------------------------------------------------------
+    CompositeBwdParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.frames = c.frames; cp.rays = c.rays; cp.objects = K; cp.static_objects = c.static_objects; cp.F = F;
+    cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
+    int total_positions = 0;
+    for (int k = 0; k < K; ++k) {
+        const pr_object_model_t& m = objs[k].coarse;
+        CompositeBwdObject& o = cp.obj[k];
+        o.t = reinterpret_cast<const float*>(fws + tp.t[k]);
+        o.sigma = reinterpret_cast<const float*>(fws + tp.sigma[k]);
+        o.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
+        o.dispmag = m.has_bender ? reinterpret_cast<const float*>(fws + tp.dispmag[k]) : nullptr;
+        o.feat = reinterpret_cast<const float*>(fws + tp.feat[k]);
+        o.noise = c.noise_coarse.integrate[k];
+        o.positions = m.positions;
+        o.g = grads.object[k];
+        o.g_feat = reinterpret_cast<float*>(bws + bp.g_feat[k]);
+        o.g_sigma = reinterpret_cast<float*>(bws + bp.g_sigma[k]);
+        o.g_t = reinterpret_cast<float*>(bws + bp.g_t[k]);
+        o.g_dm = m.has_bender ? reinterpret_cast<float*>(bws + bp.g_dm[k]) : nullptr;
+        total_positions += m.positions;
+    }
+    cp.total_positions = total_positions;
+    int ss = 64;
+    while (ss < total_positions) ss <<= 1;
+    cp.sort_size = ss;
+    cp.ray_directions = c.ray_directions;
+    cp.noise_global = c.noise_coarse.integrate_global;
+    cp.global = grads.global;
+    PR_TRY(launch_composite_bwd(cp, s));
+
+    // ---- per object -------------------------------------------------------------------------------
+    float* bufA = reinterpret_cast<float*>(bws + bp.bufA);
+    float* bufB = reinterpret_cast<float*>(bws + bp.bufB);
+    float* actb = reinterpret_cast<float*>(bws + bp.act);
+    float* g_enc = reinterpret_cast<float*>(bws + bp.g_enc);
+    float* gsr = reinterpret_cast<float*>(bws + bp.gsr);
+    float* gdr = reinterpret_cast<float*>(bws + bp.gdr);
+    float* g_bent = reinterpret_cast<float*>(bws + bp.g_bent);
+    float* g_x = reinterpret_cast<float*>(bws + bp.g_x);
+    float* g_braw = reinterpret_cast<float*>(bws + bp.g_braw);
+    float* g_in6 = reinterpret_cast<float*>(bws + bp.g_in6);
+    double* sums = reinterpret_cast<double*>(bws + bp.sums);
+    float* tables = reinterpret_cast<float*>(bws + bp.tables);
+
+    for (int k = 0; k < K; ++k) {
+        const pr_object_model_t& m = objs[k].coarse;
+        const pr_model_grads_t& G = out.model[k];
+        const SavedPlan& sv = tp.saved[k];
+        ModelDims d;
+        PR_TRY(compute_dims(m, &d));
+        const int P = m.positions;
+        const size_t cap = (size_t)c.frames * c.rays * P;
+        const int row_blocks = (int)((cap + 255) / 256);
+        const int grid_rows = cap < 4096 ? (int)cap : 4096;
+        const int grid_blk = row_blocks < 1024 ? row_blocks : 1024;
+        RowCtx rc;
+        rc.total = totals + k;
+        rc.rec_flat = reinterpret_cast<const int32_t*>(fws + sv.rec_flat);
+        rc.row_flags = reinterpret_cast<const int32_t*>(fws + sv.row_flags);
+        rc.samples_per_frame = c.rays * P;
+        GemmCtx gc;
+        gc.rows = totals + k; gc.max_rows = (int)cap; gc.partial = reinterpret_cast<float*>(bws + bp.partial); gc.s = s;
+
+        const float* rec_pos = reinterpret_cast<const float*>(fws + sv.rec_pos);
+        const float* enc = reinterpret_cast<const float*>(fws + sv.enc);
+        const float* acts = reinterpret_cast<const float*>(fws + sv.act);
+        const size_t act_stride = cap * d.Wpad;
+        const float* h1 = reinterpret_cast<const float*>(fws + sv.h1);
+        const float* h2 = reinterpret_cast<const float*>(fws + sv.h2);
+        const float* batch = reinterpret_cast<const float*>(fws + sv.batch);
+        const int32_t* stat_count = reinterpret_cast<const int32_t*>(fws + sv.stat_count);
+        const float* table = reinterpret_cast<const float*>(fws + tp.adain[k]);
+        const int table_stride = adain_row_floats(d);
+        float* g_feat = reinterpret_cast<float*>(bws + bp.g_feat[k]);
+        const float* g_sigma = reinterpret_cast<const float*>(bws + bp.g_sigma[k]);
+        const float* g_t = reinterpret_cast<const float*>(bws + bp.g_t[k]);
+        const float* g_dm = m.has_bender ? reinterpret_cast<const float*>(bws + bp.g_dm[k]) : nullptr;
+        float lo[3], hi[3], size[3];
+        bbox_split(m, lo, hi, size);
+
+        hipLaunchKernelGGL(k_gather_rows, dim3(grid_rows), dim3(256), 0, s, rc, g_sigma, g_dm, gsr, m.has_bender ? gdr : nullptr,
+                           g_feat, F);
+        PR_LAUNCH_CHECK();
+
+        // ---- feature head, layer 6 -------------------------------------------------------------
+        hipLaunchKernelGGL(k_adain_recompute, dim3(grid_rows), dim3(256), 0, s, rc, h2, d.W2pad, d.W2pad, table, table_stride,
+                           2 * d.Wpad, 2 * d.Wpad + d.W2pad, actb);
+        PR_LAUNCH_CHECK();
+        PR_TRY(weight_grad(gc, g_feat, F, F, actb, d.W2pad, d.W2, G.head6.weight, d.W2, G.head6.bias));
+        PR_TRY(input_grad(gc, g_feat, F, F, m.head6.weight, d.W2, d.W2, bufB, d.W2pad, false, nullptr, 0));
+        // ---- AdaIN + BatchNorm (batch statistics) 4 -----------------------------------------------
+        float* dscale1 = tables;
+        float* dbias1 = tables + (size_t)c.frames * MAX_WIDTH;
+        float* dscale2 = tables + (size_t)c.frames * 2 * MAX_WIDTH;
+        float* dbias2 = tables + (size_t)c.frames * 3 * MAX_WIDTH;
+        PR_CHECK_HIP(hipMemsetAsync(tables, 0, sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH, s));
+        AdainBwd ab;
+        memset(&ab, 0, sizeof(ab));
+        ab.r = rc; ab.h = h2; ab.ld = d.W2pad; ab.width = d.W2; ab.table = table; ab.table_stride = table_stride;
+        ab.goff = 2 * d.Wpad; ab.boff = 2 * d.Wpad + d.W2pad;
+        ab.mean = batch + 2 * MAX_WIDTH; ab.var = batch + 3 * MAX_WIDTH; ab.eps = m.bn_eps;
+        ab.g = bufB; ab.sums = sums; ab.dscale = dscale2; ab.dbias = dbias2; ab.count = stat_count;
+        PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
+        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk), dim3(256), 0, s, ab);
+        PR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
+        PR_LAUNCH_CHECK();
+        // ---- layer 3 ----------------------------------------------------------------------------
+        hipLaunchKernelGGL(k_adain_recompute, dim3(grid_rows), dim3(256), 0, s, rc, h1, d.Wpad, d.Wpad, table, table_stride, 0,
+                           d.Wpad, actb);
+        PR_LAUNCH_CHECK();
+        PR_TRY(weight_grad(gc, bufB, d.W2pad, d.W2, actb, d.Wpad, d.W, G.head3.weight, d.W, nullptr));
+        PR_TRY(input_grad(gc, bufB, d.W2pad, d.W2, m.head3.weight, d.W, d.W, bufA, d.Wpad, false, nullptr, 0));
+        // ---- AdaIN + BatchNorm 1 ------------------------------------------------------------------
+        ab.h = h1; ab.ld = d.Wpad; ab.width = d.W; ab.goff = 0; ab.boff = d.Wpad;
+        ab.mean = batch; ab.var = batch + MAX_WIDTH; ab.g = bufA; ab.dscale = dscale1; ab.dbias = dbias1;
+        PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
+        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk), dim3(256), 0, s, ab);
+        PR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
+        PR_LAUNCH_CHECK();
+        // ---- layer 0 of the head + sigma head ------------------------------------------------------
+        const int nb = m.backbone_count;
+        const float* act_last = acts + (size_t)(nb - 1) * act_stride;
+        PR_TRY(weight_grad(gc, bufA, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr));
+        PR_TRY(input_grad(gc, bufA, d.Wpad, d.W, m.head0.weight, d.W, d.W, bufB, d.Wpad, false, nullptr, 0));
+        hipLaunchKernelGGL(k_sigma_bwd, dim3(grid_blk), dim3(256), 0, s, rc, bufB, act_last, d.Wpad, d.W,
+                           m.kind == 0 ? gsr : nullptr, m.alpha_head.weight, G.alpha_head.weight, G.alpha_head.bias);
+        PR_LAUNCH_CHECK();
+        // ---- backbone -------------------------------------------------------------------------------
+        PR_TRY(chain_backward(gc, m.backbone, G.backbone, nb, m.skip_layer_idx, d.W, d.Wpad, acts, act_stride, enc, d.enc_pad,
+                              d.enc, bufB, bufA, g_enc));
+        // ---- positional encoding ----------------------------------------------------------------------
+        const float* gx_final = nullptr;
+        if (m.kind == 0) {
+            hipLaunchKernelGGL(k_pe_bwd, dim3(row_blocks), dim3(256), 0, s, rc, enc, g_enc, d.enc_pad, 3, m.octaves, size[0],
+                               size[1], size[2], 3, g_bent, 3, 0);
+            PR_LAUNCH_CHECK();
+            gx_final = g_bent;
+        } else {
+            hipLaunchKernelGGL(k_pe_bwd, dim3(row_blocks), dim3(256), 0, s, rc, enc, g_enc, d.enc_pad, 6, m.octaves, 0.f, 0.f, 0.f,
+                               3, g_in6, 6, 0);
+            PR_LAUNCH_CHECK();
+        }
+        // ---- ray bender -----------------------------------------------------------------------------------
+        if (m.has_bender) {
+            PR_REQUIRE(m.kind == 0, "backward: a skybox model with a ray bender is not supported");
+            const float* bin = reinterpret_cast<const float*>(fws + sv.bin);
+            const float* bacts = reinterpret_cast<const float*>(fws + sv.bact);
+            const size_t bact_stride = cap * d.BWpad;
+            const float* braw = reinterpret_cast<const float*>(fws + sv.braw);
+            const float* delta = reinterpret_cast<const float*>(fws + sv.delta);
+            hipLaunchKernelGGL(k_bender_out_bwd, dim3(row_blocks), dim3(256), 0, s, rc, g_bent, gdr, delta, braw, rec_pos, lo[0],
+                               lo[1], lo[2], hi[0], hi[1], hi[2], (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0, g_x, g_braw);
+            PR_LAUNCH_CHECK();
+            const int bc = m.bender_count;
+            hipLaunchKernelGGL(k_bender_head_bwd, dim3(grid_blk), dim3(256), 0, s, rc, g_braw, bacts + (size_t)(bc - 1) * bact_stride,
+                               d.BWpad, d.BW, m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
+            PR_LAUNCH_CHECK();
+            PR_TRY(chain_backward(gc, m.bender, G.bender, bc, m.bender_skip, d.BW, d.BWpad, bacts, bact_stride, bin, d.bin_pad,
+                                  d.bin, bufA, bufB, g_enc));
+            hipLaunchKernelGGL(k_pe_bwd, dim3(row_blocks), dim3(256), 0, s, rc, bin, g_enc, d.bin_pad, 3, m.bender_octaves, size[0],
+                               size[1], size[2], 1, g_x, 3, 1);
+            PR_LAUNCH_CHECK();
+            if (out.deformation) {
+                hipLaunchKernelGGL(k_deformation_bwd, dim3(grid_blk), dim3(64), 0, s, rc, g_enc, d.bin_pad, d.benc,
+                                   m.deformation_features, out.deformation + (size_t)k * m.deformation_features,
+                                   K * m.deformation_features);
+                PR_LAUNCH_CHECK();
+            }
+            gx_final = g_x;
+        }
+        // ---- style affine -----------------------------------------------------------------------------------
+        {
+            const int S = m.style_features;
+            const float* style_k = c.style + (size_t)k * S;
+            float* d_style_k = out.style ? out.style + (size_t)k * S : nullptr;
+            long n1 = (long)2 * d.W * S, n2 = (long)c.frames * S;
+            long n = n1 > n2 ? n1 : n2;
+            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.frames, d.W, S, dscale1, dbias1,
+                               style_k, K * S, m.affine1.weight, G.affine1.weight, G.affine1.bias, d_style_k);
+            PR_LAUNCH_CHECK();
+            n1 = (long)2 * d.W2 * S;
+            n = n1 > n2 ? n1 : n2;
+            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.frames, d.W2, S, dscale2, dbias2,
+                               style_k, K * S, m.affine4.weight, G.affine4.weight, G.affine4.bias, d_style_k);
+            PR_LAUNCH_CHECK();
+        }
+        // ---- sample placement -> object pose -----------------------------------------------------------------
+        if (out.w2o) {
+            GeometryBwd gb;
+            memset(&gb, 0, sizeof(gb));
+            gb.frames = c.frames; gb.rays = c.rays; gb.positions = P; gb.objects = K; gb.object_index = k; gb.kind = m.kind;
+            gb.ray_origins = c.ray_origins; gb.ray_directions = c.ray_directions; gb.w2o = c.w2o; gb.in_scene = c.object_in_scene;
+            for (int a = 0; a < 3; ++a) {
+                gb.lo[a] = lo[a];
+                gb.hi[a] = hi[a];
+            }
+            gb.z_near_min = m.z_near_min; gb.z_far_max = m.z_far_max;
+            gb.linspace = c.linspace_coarse[k];
+            gb.jitter = c.noise_coarse.jitter[k];
+            gb.t = reinterpret_cast<const float*>(fws + tp.t[k]);
+            gb.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
+            gb.g_t = g_t;
+            gb.g_x = gx_final;
+            gb.g_in6 = m.kind == 1 ? g_in6 : nullptr;
+            gb.d_w2o = out.w2o;
+            hipLaunchKernelGGL(k_geometry_bwd, dim3((c.rays + 255) / 256, c.frames), dim3(256), 0, s, gb);
+            PR_LAUNCH_CHECK();
+        }
+    }
+    return PR_OK;
+}
+
+}  // namespace pr
+
+static int check_backward_call(const pr_call_t* call, const pr_object_t* objects) {
+    PR_REQUIRE(call && objects, "NULL argument");
+    PR_TRY(pr::validate_call(*call, objects));
+    PR_REQUIRE(call->flags & PR_FLAG_SAVE_FOR_BACKWARD, "pr_render_backward: the forward call must set PR_FLAG_SAVE_FOR_BACKWARD");
+    PR_REQUIRE(!call->use_fine, "pr_render_backward: hierarchical (use_fine) calls are not differentiable yet");
+    for (int k = 0; k < call->objects; ++k)
+        PR_REQUIRE(objects[k].coarse.skip_layer_idx > 0 && (!objects[k].coarse.has_bender || objects[k].coarse.bender_skip > 0),
+                   "pr_render_backward: skip_layer_idx 0 is not supported");
+    return PR_OK;
+}
+
+extern "C" int pr_backward_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes) {
+    PR_REQUIRE(bytes, "pr_backward_workspace_size: NULL argument");
+    PR_TRY(check_backward_call(call, objects));
+    pr::BwdPlan bp;
+    PR_TRY(pr::make_bwd_plan(*call, objects, &bp));
+    *bytes = bp.bytes;
+    return PR_OK;
+}
+
+extern "C" int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads,
+                                  const pr_input_grads_t* out, void* forward_workspace, size_t forward_workspace_bytes,
+                                  void* backward_workspace, size_t backward_workspace_bytes, void* stream) {
+    PR_REQUIRE(grads && out && forward_workspace && backward_workspace, "pr_render_backward: NULL argument");
+    PR_TRY(check_backward_call(call, objects));
+    pr::Plan plan;
+    PR_TRY(pr::make_plan(*call, objects, &plan));
+    pr::BwdPlan bp;
+    PR_TRY(pr::make_bwd_plan(*call, objects, &bp));
+    if (forward_workspace_bytes < plan.bytes || backward_workspace_bytes < bp.bytes) {
+        pr::set_error("workspace too small: forward %zu of %zu bytes, backward %zu of %zu bytes", forward_workspace_bytes, plan.bytes,
+                      backward_workspace_bytes, bp.bytes);
+        return PR_ERR_WORKSPACE;
+    }
+    PR_REQUIRE((((uintptr_t)forward_workspace | (uintptr_t)backward_workspace) & 255) == 0, "workspaces must be 256-byte aligned");
+    return pr::backward(*call, objects, *grads, *out, static_cast<char*>(forward_workspace), plan,
+                        static_cast<char*>(backward_workspace), bp, (hipStream_t)stream);
+}

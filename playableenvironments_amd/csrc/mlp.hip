@@ -593,15 +593,17 @@ __device__ __forceinline__ void row_dots(const Smem& S, const float* w, int widt
 
 // Tile rows staged in X -> HBM with coalesced 16-byte stores (width % 4 == 0) or scalar stores.
 // zero_dead: rows that failed the second AABB test are written as zeros (feature rows).
-__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead) {
+__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead,
+                                                const float* src = nullptr, int ld = LDX) {
     const int tid = threadIdx.x;
+    if (src == nullptr) src = S.X;
     if ((width & 3) == 0 && (stride & 3) == 0) {
         const int w4 = width >> 2;
         for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
             const int row = idx / w4, c = (idx - row * w4) * 4;
             const int fl = S.flags[row];
             if (fl & 1) {
-                float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+                float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
                 if (zero_dead && !(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(dst + (size_t)(tile_base + row) * stride + c) = v;
             }
@@ -610,7 +612,7 @@ __device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int w
         for (int idx = tid; idx < TILE_M * width; idx += MLP_THREADS) {
             const int row = idx / width, c = idx - row * width;
             const int fl = S.flags[row];
-            if (fl & 1) dst[(size_t)(tile_base + row) * stride + c] = (zero_dead && !(fl & 2)) ? 0.f : S.X[row * LDX + c];
+            if (fl & 1) dst[(size_t)(tile_base + row) * stride + c] = (zero_dead && !(fl & 2)) ? 0.f : src[row * ld + c];
         }
     }
 }
@@ -691,7 +693,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                 S.E[s * LDE + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
             }
             __syncthreads();
-            for (int l = 0; l < p.b_count; ++l) run_layer(p.b_layers[l], S, p, tile_base);
+            if (p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false, S.E, LDE);
+            for (int l = 0; l < p.b_count; ++l) {
+                run_layer(p.b_layers[l], S, p, tile_base);
+                if (p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
+                    write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
+                    __syncthreads();
+                }
+            }
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
             float out[3];
             row_dots(S, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
@@ -699,6 +708,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             if ((tid & 7) == 0) {
                 const int s = tid >> 3;
                 float d[3], bent[3];
+                if (p.save_braw && (S.flags[s] & 1))
+                    for (int a = 0; a < 3; ++a) p.save_braw[(size_t)(tile_base + s) * 3 + a] = out[a];
                 for (int a = 0; a < 3; ++a) {
                     const float x = S.pos[s * 8 + a];
                     float dl = __fmul_rn(out[a], p.size[a]);
@@ -713,6 +724,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                     if (p.dispmag)
                         p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
                                                                __fmul_rn(d[2], d[2])));
+                    if (p.save_delta)
+                        for (int a = 0; a < 3; ++a) p.save_delta[(size_t)(tile_base + s) * 3 + a] = d[a];
                     // second AABB test on the bent position (adain_style_nerf_model.py:173-184)
                     if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.flags[s] &= ~2;
                 }
@@ -723,9 +736,16 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         // ---- positional encoding of the NeRF input --------------------------------------------
         fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
         __syncthreads();
+        if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false, S.E, LDE);
 
         // ---- backbone ---------------------------------------------------------------------------
-        for (int l = 0; l < p.n_backbone; ++l) run_layer(p.layers[l], S, p, tile_base);
+        for (int l = 0; l < p.n_backbone; ++l) {
+            run_layer(p.layers[l], S, p, tile_base);
+            if (p.save_act) {
+                write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
+                __syncthreads();
+            }
+        }
 
         // ---- sigma head -------------------------------------------------------------------------
         if (p.kind == 0) {

@@ -145,6 +145,15 @@ struct MlpParams {
     int32_t* row_flags;          // (cap) bit 0 valid, bit 1 passed every AABB test; written in phase 1
     double* stats;               // phase 1/2: [sum(h_out_width) | sum of squares(h_out_width)] over the alive rows
     int32_t* stat_count;         // number of alive rows (written in phase 1)
+    // saved for the backward pass (phase 1 only; NULL = not saved): compact rows like `feat`
+    float* save_enc;             // (cap, enc_pad) NeRF input encoding
+    float* save_act;             // n_backbone blocks of (cap, Wpad): post-ReLU output of every backbone layer
+    size_t save_act_stride;      // floats between the blocks
+    float* save_bin;             // (cap, bin_pad) bender input [annealed PE | deformation]
+    float* save_bact;            // b_count blocks of (cap, BWpad)
+    size_t save_bact_stride;
+    float* save_braw;            // (cap, 3) bender head output before * size and the clamp
+    float* save_delta;           // (cap, 3) final displacement (after clamp / canonical_pose)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
@@ -266,6 +275,69 @@ struct CompositeParams {
     pr_entry_t global;
 };
 int launch_composite(const CompositeParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Workspace plan of one call (render.hip); pr_render_backward recomputes it from the same call
+// ---------------------------------------------------------------------------------------------
+#define PR_TRY(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != PR_OK) return _r;  \
+    } while (0)
+
+struct SavedPlan {   // PR_FLAG_SAVE_FOR_BACKWARD: per object instance and model type
+    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta;
+};
+struct TypePlan {
+    size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
+    size_t adain[PR_MAX_OBJECTS];
+    size_t feat[PR_MAX_OBJECTS];
+    int positions[PR_MAX_OBJECTS];
+    size_t totals;  // K ints
+    SavedPlan saved[PR_MAX_OBJECTS];
+};
+struct Plan {
+    TypePlan type[2];
+    size_t block_sums, block_offsets;
+    size_t rec_pos, rec_flat;
+    // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
+    size_t h1, h2, row_flags, stats, stat_count, batch_stats;
+    size_t bytes;
+    int nblocks256;
+};
+int validate_call(const pr_call_t& c, const pr_object_t* objs);
+int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);
+void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size);
+int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
+                     MlpParams* p);
+
+// ---------------------------------------------------------------------------------------------
+// Backward pass building blocks (gemm.hip, backward.hip)
+// ---------------------------------------------------------------------------------------------
+struct GemmNN {            // C[M x n] (+)= A[M x k] . B[k x n], then optionally zeroed where mask <= 0
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const int32_t* rows;   // device scalar M
+    int n, k;
+    int accumulate;
+    const float* mask; int ldm;
+};
+int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s);
+
+struct GemmTN {            // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += sum_m A[m][i]
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    float* bias;           // or NULL
+    const int32_t* rows;
+    int ni, nj;
+    int splits;
+    float* partial;        // gemm_tn_scratch_floats(splits) floats
+    float* bias_partial;   // inside the same scratch, or NULL
+};
+int launch_gemm_tn(const GemmTN& p, hipStream_t s);
+size_t gemm_tn_scratch_floats(int splits);
 
 // Kernel timing (bench.py): records an event pair on `s` around a launch when profiling is on.
 struct ProfileScope {

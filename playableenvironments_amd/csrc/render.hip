@@ -45,35 +45,12 @@ void set_error(const char* fmt, ...) {
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
                      MlpParams* p);
 
-#define PR_TRY(expr)                 \
-    do {                             \
-        int _r = (expr);             \
-        if (_r != PR_OK) return _r;  \
-    } while (0)
-
 // ---------------------------------------------------------------------------------------------
-// Workspace plan
+// Workspace plan (structs in pr_common.h)
 // ---------------------------------------------------------------------------------------------
-struct TypePlan {
-    size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
-    size_t adain[PR_MAX_OBJECTS];
-    size_t feat[PR_MAX_OBJECTS];
-    int positions[PR_MAX_OBJECTS];
-    size_t totals;  // K ints
-};
-struct Plan {
-    TypePlan type[2];
-    size_t block_sums, block_offsets;
-    size_t rec_pos, rec_flat;
-    // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
-    size_t h1, h2, row_flags, stats, stat_count, batch_stats;
-    size_t bytes;
-    int nblocks256;
-};
-
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int validate_call(const pr_call_t& c, const pr_object_t* objs) {
+int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     PR_REQUIRE(c.frames > 0 && c.rays > 0, "empty call: %d frames x %d rays", c.frames, c.rays);
     PR_REQUIRE(c.objects >= 1 && c.objects <= PR_MAX_OBJECTS, "objects %d out of range 1..%d", c.objects, PR_MAX_OBJECTS);
     PR_REQUIRE(c.static_objects >= 0 && c.static_objects <= c.objects, "static_objects %d out of range", c.static_objects);
@@ -83,6 +60,9 @@ static int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     PR_REQUIRE(c.precision == PR_PRECISION_FP32 || c.precision == PR_PRECISION_F16X3, "unknown precision %d", c.precision);
     PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_TRAIN_BN)),
                "the split-precision kernel has no train-mode BatchNorm phases yet: use PR_PRECISION_FP32 for training");
+    PR_REQUIRE(!(c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || (c.flags & PR_FLAG_TRAIN_BN),
+               "PR_FLAG_SAVE_FOR_BACKWARD needs PR_FLAG_TRAIN_BN (the backward pass differentiates the train-mode BatchNorm)");
+    PR_REQUIRE(!(c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || !(c.flags & PR_FLAG_NAIVE_MLP), "the scalar debugging kernel saves nothing");
     for (int k = 0; k < c.objects; ++k) {
         const pr_object_model_t& m = objs[k].coarse;
         PR_REQUIRE(m.positions >= 1, "object %d: positions_count_coarse %d", k, m.positions);
@@ -114,7 +94,7 @@ static int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     return PR_OK;
 }
 
-static int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
+int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     memset(plan, 0, sizeof(*plan));
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -146,6 +126,25 @@ static int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
             tp.adain[k] = take(sizeof(float) * (size_t)c.frames * adain_row_floats(d));
             tp.feat[k] = feat_bytes[t];  // relative to the feature arena
             feat_bytes[t] += align_up(sizeof(float) * cap * m.output_features);
+            if (c.flags & PR_FLAG_SAVE_FOR_BACKWARD) {
+                // everything the backward pass re-reads, per object instance (compact rows, worst-case capacity)
+                SavedPlan& sv = tp.saved[k];
+                sv.rec_pos = take(sizeof(float) * 3 * cap);
+                sv.rec_flat = take(sizeof(int32_t) * cap);
+                sv.row_flags = take(sizeof(int32_t) * cap);
+                sv.enc = take(sizeof(float) * cap * d.enc_pad);
+                sv.act = take(sizeof(float) * cap * d.Wpad * m.backbone_count);
+                sv.h1 = take(sizeof(float) * cap * d.Wpad);
+                sv.h2 = take(sizeof(float) * cap * d.W2pad);
+                sv.batch = take(sizeof(float) * 4 * MAX_WIDTH);
+                sv.stat_count = take(sizeof(int32_t) * 4);
+                if (m.has_bender) {
+                    sv.bin = take(sizeof(float) * cap * d.bin_pad);
+                    sv.bact = take(sizeof(float) * cap * d.BWpad * m.bender_count);
+                    sv.braw = take(sizeof(float) * 3 * cap);
+                    sv.delta = take(sizeof(float) * 3 * cap);
+                }
+            }
         }
     }
     plan->rec_pos = take(sizeof(float) * 3 * max_cap);
@@ -160,14 +159,22 @@ static int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     // coarse and fine feature rows share one arena: the coarse rows are dead once the coarse
     // compositing pass has run, before the first fine MLP is launched.
-    const size_t arena = take(feat_bytes[0] > feat_bytes[1] ? feat_bytes[0] : feat_bytes[1]);
-    for (int t = 0; t < ntypes; ++t)
-        for (int k = 0; k < c.objects; ++k) plan->type[t].feat[k] += arena;
+    if (c.flags & PR_FLAG_SAVE_FOR_BACKWARD) {
+        // the backward pass needs the feature rows of both model types
+        for (int t = 0; t < ntypes; ++t) {
+            const size_t arena = take(feat_bytes[t]);
+            for (int k = 0; k < c.objects; ++k) plan->type[t].feat[k] += arena;
+        }
+    } else {
+        const size_t arena = take(feat_bytes[0] > feat_bytes[1] ? feat_bytes[0] : feat_bytes[1]);
+        for (int t = 0; t < ntypes; ++t)
+            for (int k = 0; k < c.objects; ++k) plan->type[t].feat[k] += arena;
+    }
     plan->bytes = off;
     return PR_OK;
 }
 
-static void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size) {
+void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size) {
     for (int a = 0; a < 3; ++a) {
         lo[a] = m.bbox[2 * a];
         hi[a] = m.bbox[2 * a + 1];
@@ -205,6 +212,12 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             float* dispmag = m.has_bender ? reinterpret_cast<float*>(ws + tp.dispmag[k]) : nullptr;
             float* feat = reinterpret_cast<float*>(ws + tp.feat[k]);
             float* adain = reinterpret_cast<float*>(ws + tp.adain[k]);
+            const bool save = (c.flags & PR_FLAG_SAVE_FOR_BACKWARD) != 0;
+            const SavedPlan& sv = tp.saved[k];
+            if (save) {
+                rec_pos = reinterpret_cast<float*>(ws + sv.rec_pos);
+                rec_flat = reinterpret_cast<int32_t*>(ws + sv.rec_flat);
+            }
 
             // ---- sample placement --------------------------------------------------------------
             if (t == 0) {
@@ -287,14 +300,27 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 // a reduction over every evaluated sample of this object call, between two matmuls
                 PR_REQUIRE(!naive, "the scalar debugging kernel has no train-mode BatchNorm");
                 double* stats = reinterpret_cast<double*>(ws + plan.stats);
-                int32_t* stat_count = reinterpret_cast<int32_t*>(ws + plan.stat_count);
-                float* batch = reinterpret_cast<float*>(ws + plan.batch_stats);
-                float* h1 = reinterpret_cast<float*>(ws + plan.h1);
-                float* h2 = reinterpret_cast<float*>(ws + plan.h2);
+                int32_t* stat_count = reinterpret_cast<int32_t*>(ws + (save ? sv.stat_count : plan.stat_count));
+                float* batch = reinterpret_cast<float*>(ws + (save ? sv.batch : plan.batch_stats));
+                float* h1 = reinterpret_cast<float*>(ws + (save ? sv.h1 : plan.h1));
+                float* h2 = reinterpret_cast<float*>(ws + (save ? sv.h2 : plan.h2));
                 PR_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 4 * MAX_WIDTH, s));
                 PR_CHECK_HIP(hipMemsetAsync(stat_count, 0, sizeof(int32_t) * 4, s));
-                mp.row_flags = reinterpret_cast<int32_t*>(ws + plan.row_flags);
+                mp.row_flags = reinterpret_cast<int32_t*>(ws + (save ? sv.row_flags : plan.row_flags));
                 mp.stat_count = stat_count;
+                if (save) {
+                    const size_t cap_rows = (size_t)c.frames * c.rays * P;
+                    mp.save_enc = reinterpret_cast<float*>(ws + sv.enc);
+                    mp.save_act = reinterpret_cast<float*>(ws + sv.act);
+                    mp.save_act_stride = cap_rows * d.Wpad;
+                    if (m.has_bender) {
+                        mp.save_bin = reinterpret_cast<float*>(ws + sv.bin);
+                        mp.save_bact = reinterpret_cast<float*>(ws + sv.bact);
+                        mp.save_bact_stride = cap_rows * d.BWpad;
+                        mp.save_braw = reinterpret_cast<float*>(ws + sv.braw);
+                        mp.save_delta = reinterpret_cast<float*>(ws + sv.delta);
+                    }
+                }
                 mp.phase = 1; mp.h_out = h1; mp.h_out_width = d.Wpad; mp.stats = stats;
                 PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
                 BnFinalizeParams bf;

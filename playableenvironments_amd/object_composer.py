@@ -82,6 +82,77 @@ def _linear(layer: Optional[nn.Linear]) -> _lib.Linear:
     return s
 
 
+GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude")
+
+
+class _RenderFunction(torch.autograd.Function):
+    """autograd node of one renderer call: forward = pr_render_forward with PR_FLAG_SAVE_FOR_BACKWARD,
+    backward = pr_render_backward.  Inputs after the bookkeeping arguments: transformation_matrix_w2o, style,
+    deformation, then every trainable parameter of the composer."""
+
+    @staticmethod
+    def forward(ctx, composer, args, holder, w2o, style, deformation, *params):
+        results, state = composer._render(*args, _save=True)
+        ctx.composer, ctx.state, ctx.params = composer, state, params
+        ctx.shapes = (w2o.shape, style.shape, deformation.shape)
+        holder["results"], holder["types"] = results, state["types"]
+        flat, skip = [], []
+        for ty in state["types"]:
+            for name in [f"object_{k}" for k in range(state["K"])] + ["global"]:
+                for key in ENTRY_KEYS:
+                    t = results[ty][name][key]
+                    flat.append(t)
+                    if key not in GRAD_KEYS:
+                        skip.append(t)
+        ctx.mark_non_differentiable(*skip)
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        st, composer = ctx.state, ctx.composer
+        N, R, K, S, D, F = st["N"], st["R"], st["K"], st["S"], st["D"], st["F"]
+        lib = _lib.load()
+        dev = st["workspace"].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        keep = []
+        og = _lib.OutputGrads()
+        i = 0
+        for ty in st["types"]:
+            for k in range(K + 1):
+                entry = og.object[k] if k < K else og.global_
+                for key in ENTRY_KEYS:
+                    g = grad_outputs[i]
+                    i += 1
+                    if key in GRAD_KEYS and g is not None:
+                        g = g.to(torch.float32).reshape((N, R, F) if key == "integrated_features" else (N, R)).contiguous()
+                        keep.append(g)
+                        setattr(entry, key, g.data_ptr())
+        grads = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in ctx.params}
+        ig = _lib.InputGrads()
+        d_w2o = torch.zeros((N, K, 3, 4), **f32)
+        d_style = torch.zeros((N, K, S), **f32)
+        d_def = torch.zeros((N, K, D), **f32)
+        ig.w2o, ig.style, ig.deformation = d_w2o.data_ptr(), d_style.data_ptr(), d_def.data_ptr()
+        for k in range(K):
+            ig.model[k] = composer._model_grad_struct(st["models"][k], grads)
+        size = C.c_size_t()
+        _lib.check(lib.pr_backward_workspace_size(C.byref(st["call"]), st["objs"], C.byref(size)), "pr_backward_workspace_size")
+        scratch = torch.empty(size.value, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.pr_render_backward(C.byref(st["call"]), st["objs"], C.byref(og), C.byref(ig), st["workspace"].data_ptr(),
+                                          st["workspace"].numel(), scratch.data_ptr(), scratch.numel(), stream),
+                   "pr_render_backward")
+        lead = st["lead"]
+        w_shape, s_shape, d_shape = ctx.shapes
+        g_w2o = torch.zeros((N, 4, 4, K), **f32)
+        g_w2o[:, :3] = d_w2o.permute(0, 2, 3, 1)
+        g_w2o = g_w2o.reshape(lead + [4, 4, K]).sum_to_size(w_shape)
+        g_style = d_style.permute(0, 2, 1).reshape(lead + [S, K]).sum_to_size(s_shape)
+        g_def = d_def.permute(0, 2, 1).reshape(lead + [D, K]).sum_to_size(d_shape)
+        ctx.state = None   # releases the forward workspace
+        return (None, None, None, g_w2o, g_style, g_def) + tuple(grads[id(p)] for p in ctx.params)
+
+
 class ObjectComposer(nn.Module):
 
     #: soft limit for the per-call scratch (MLP feature rows dominate); larger calls are split along
@@ -231,18 +302,46 @@ class ObjectComposer(nn.Module):
         ray_origins (..., 3); ray_directions (..., R, 3); focal_normals (..., 3) [unused by the
         renderer, as in the reference]; transformation_matrix_w2o (..., 4, 4, K); style (..., S, K);
         deformation (..., D, K); object_in_scene (..., K).  ``_noise`` (extension, optional) replays
-        explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state."""
-        helper = self.object_id_helper
-        K = helper.objects_count
+        explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state.
+
+        Autograd: with gradients enabled and the module in training mode the call is differentiable with
+        respect to the parameters, ``style``, ``deformation`` and ``transformation_matrix_w2o`` through
+        ``integrated_features``, ``opacity``, ``depth`` and ``integrated_displacements_magnitude`` of every
+        entry (pr_render_backward).  Not differentiated: the camera rays (dataset inputs in the reference's
+        trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (zeros)."""
+        K = self.object_id_helper.objects_count
         if transformation_matrix_w2o.size(-1) != K:
             raise Exception(f"Transformation matrix must specifies transformations for"
                             f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
         if not ray_directions.is_cuda:
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
-        if torch.is_grad_enabled() and (self.training or ray_directions.requires_grad or style.requires_grad or
-                                        transformation_matrix_w2o.requires_grad or deformation.requires_grad):
-            raise NotImplementedError("the HIP renderer has no backward yet: call it under torch.no_grad() "
-                                      "(train-mode BatchNorm statistics ARE implemented for the forward pass)")
+        args = (ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation, object_in_scene,
+                perturb, canonical_pose, _noise, _export)
+        params = [p for p in self.parameters() if p.requires_grad]
+        wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
+                                                  transformation_matrix_w2o.requires_grad)
+        if not wants_grad:
+            return self._render(*args)[0]
+        if not self.training:
+            raise NotImplementedError("the backward pass differentiates the train-mode BatchNorm (module.train()); call the "
+                                      "module under torch.no_grad() for evaluation")
+        holder = {}
+        flat = _RenderFunction.apply(self, args, holder, transformation_matrix_w2o, style, deformation, *params)
+        results = holder["results"]
+        i = 0
+        for ty in holder["types"]:
+            for name in [f"object_{k}" for k in range(K)] + ["global"]:
+                for key in ENTRY_KEYS:
+                    results[ty][name][key] = flat[i]
+                    i += 1
+        return results
+
+    def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
+                object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False):
+        """The renderer call proper.  Returns (results, state); ``state`` (only with ``_save``) keeps what
+        pr_render_backward needs: the call structures, their tensors and the forward workspace."""
+        helper = self.object_id_helper
+        K = helper.objects_count
 
         lead = list(ray_directions.shape[:-2])
         R = ray_directions.size(-2)
@@ -297,6 +396,11 @@ class ObjectComposer(nn.Module):
             # BatchNorm1d of the AdaIN layers in training mode: batch statistics per object call,
             # running statistics updated in place (per replica, like the reference under DataParallel)
             flags |= _lib.PR_FLAG_TRAIN_BN
+        if _save:
+            if use_fine:
+                raise NotImplementedError("hierarchical (use_fine) configurations are not differentiable yet; both "
+                                          "shipped configurations train with use_fine: False")
+            flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
 
         # ---- noise -----------------------------------------------------------------------------
         types = ["coarse"] + (["fine"] if use_fine else [])
@@ -360,6 +464,7 @@ class ObjectComposer(nn.Module):
             _lib.check(lib.pr_workspace_size(C.byref(call), objs, C.byref(size)), "pr_workspace_size")
             return size.value
 
+        state = None
         chunk = R
         need = workspace_bytes(build_call(0, R))
         if need > self.max_workspace_bytes and R > 1 and not self.training:  # batch statistics need the whole call
@@ -372,9 +477,14 @@ class ObjectComposer(nn.Module):
             r1 = min(R, r0 + chunk)
             call = build_call(r0, r1)
             need = workspace_bytes(call)
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-                self._workspace = None
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            if _save:
+                # the backward pass re-reads this workspace: it belongs to the autograd node, not to the module
+                workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            else:
+                if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                    self._workspace = None
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                workspace = self._workspace
             rc = r1 - r0
             outs = {}
             structs = {}
@@ -415,9 +525,12 @@ class ObjectComposer(nn.Module):
                 structs[ty] = o
             _lib.check(lib.pr_render_forward(C.byref(call), objs, C.byref(structs["coarse"]),
                                              C.byref(structs["fine"]) if use_fine else None,
-                                             self._workspace.data_ptr(), self._workspace.numel(), stream),
+                                             workspace.data_ptr(), workspace.numel(), stream),
                        "pr_render_forward")
             pieces.append(outs)
+            if _save:
+                state = dict(call=call, objs=objs, keep=keep + [origins, w2o, sty, dfm, present], workspace=workspace,
+                             N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, types=types, ptot=ptot)
 
         if self.training:
             # BatchNorm1d raises for a single value per channel (torch.nn.functional.batch_norm); the reference
@@ -444,4 +557,32 @@ class ObjectComposer(nn.Module):
             if _export:
                 results[ty]["_samples"] = [p[ty]["_samples"] for p in pieces]
         results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
-        return results
+        return results, (state if _save else None)
+
+    # ------------------------------------------------------------------ backward marshalling
+    def _model_grad_struct(self, model: RayBendingStyleNerfModel, grads: Dict[int, torch.Tensor]) -> _lib.ModelGrads:
+        """Gradient buffers of one model in the layout of pr_model_grads_t (NULL where no gradient is wanted)."""
+        def lg(layer) -> _lib.LinearGrad:
+            g = _lib.LinearGrad()
+            if layer is not None:
+                w = grads.get(id(layer.weight))
+                b = grads.get(id(layer.bias)) if layer.bias is not None else None
+                g.weight = _ptr(w)
+                g.bias = _ptr(b)
+            return g
+        nerf, bender = model.nerf_model, model.ray_bender
+        s = _lib.ModelGrads()
+        for i, layer in enumerate(nerf.backbone_layers):
+            s.backbone[i] = lg(layer)
+        s.alpha_head = lg(nerf.alpha_head if nerf.kind == 0 else None)
+        head = nerf.features_head
+        s.head0 = lg(head[0])
+        s.affine1 = lg(head[1].affine_transform)
+        s.head3 = lg(head[3])
+        s.affine4 = lg(head[4].affine_transform)
+        s.head6 = lg(head[6])
+        if bender.has_weights:
+            for i, layer in enumerate(bender.backbone_layers):
+                s.bender[i] = lg(layer)
+            s.bender_out = lg(bender.output_head)
+        return s
