@@ -88,6 +88,62 @@ def run_case(name, config, scene, pixels=None, strides=None, perturb=False, trai
     return rep, not bad
 
 
+GRAD_FIELDS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude")
+
+
+def probe_loss(results, seed=7):
+    """A random linear functional of every differentiable result field (coarse pass)."""
+    gen = torch.Generator().manual_seed(seed)
+    total = 0.0
+    for name in sorted(results["coarse"].keys()):
+        for key in GRAD_FIELDS:
+            t = results["coarse"][name][key]
+            total = total + (t * torch.randn(t.shape, generator=gen)).sum()
+    return total
+
+
+def run_gradient_case(name, config, scene, pixels, perturb, alpha_bias=0.0, seed=0):
+    """Reference train-mode forward + backward against torch.autograd through the oracle: gradients of every
+    parameter and of transformation_matrix_w2o / style / deformation."""
+    torch.manual_seed(seed)
+    ref = refshim.build_reference_composer(copy.deepcopy(config))
+    synthetic.randomize_module_state(ref, seed=seed, step=20000, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref.train(True)
+    inputs = scene_to_composer_inputs(config, scene, None, pixels)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    names = [k for k, _ in ref.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    grads = []
+    for which in range(2):
+        leaf = [inputs[i].detach().clone().requires_grad_(True) for i in (3, 4, 5)]
+        args = list(inputs[:3]) + leaf + [inputs[6]]
+        torch.manual_seed(seed + 1)
+        if which == 0:
+            out = ref(*args, perturb)
+            probe_loss(out).backward()
+            g = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+        else:
+            out = ro.composer_forward(config, sd, *args, perturb, training=True, update_stats=False)
+            probe_loss(out).backward()
+            g = {k: sd[k].grad.clone() for k in names if sd[k].grad is not None}
+        for label, t in zip(("w2o", "style", "deformation"), leaf):
+            g[label] = t.grad.clone()
+        grads.append(g)
+    worst, bad = 0.0, []
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1].get(k)
+        if b is None:
+            bad.append(k + " (missing)")
+            continue
+        rel = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-30)
+        worst = max(worst, rel)
+        if rel > 1e-5:
+            bad.append(f"{k} ({rel:.2e})")
+    print(f"[{name}] gradient tensors={len(grads[0])} worst relative |diff|={worst:.3e} failing={bad}")
+    return not bad
+
+
 def grid_pixels(h, w, n):
     r = torch.linspace(0, h - 1, n).long()
     c = torch.linspace(0, w - 1, n).long()
@@ -159,6 +215,14 @@ def main():
                    perturb=True, training=True, alpha_bias=3.0)[1]
     ok &= run_case("tennis hierarchical TRAIN perturb", th, synthetic.tennis_scene(seed=15),
                    pixels=grid_pixels(256, 256, 16), perturb=True, training=True, alpha_bias=2.0)[1]
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1,
+                 bender_octaves=3)
+    ok &= run_gradient_case("tennis reduced TRAIN gradients", configs.reduced_config(t, **small), synthetic.tennis_scene(),
+                            grid_pixels(256, 256, 16), perturb=True, alpha_bias=2.0)
+    ok &= run_gradient_case("minecraft reduced TRAIN gradients", configs.reduced_config(m, **small),
+                            synthetic.minecraft_scene(), grid_pixels(256, 256, 16), perturb=True, alpha_bias=3.0)
+    ok &= run_gradient_case("minecraft shipped TRAIN gradients", m, synthetic.minecraft_scene(seed=13),
+                            grid_pixels(256, 256, 12), perturb=True, alpha_bias=3.0)
     ok &= check_samplers()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1

@@ -79,6 +79,63 @@ def make(name, recipe, scene, pixels, perturb=False, seed=0, alpha_bias=2.0, ste
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(fr)} output fields")
 
 
+GRAD_FIELDS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude")
+
+
+def make_gradients(name, recipe, scene, pixels, perturb=True, seed=0, alpha_bias=2.0, step=20000):
+    """Train-mode fixture: reference forward + backward of a fixed random linear functional of every differentiable
+    result field; stores the functional's coefficients, the forward results and d loss / d (every parameter, w2o,
+    style, deformation) as the REFERENCE's autograd computed them."""
+    cfg = recipe_config(recipe)
+    torch.manual_seed(seed)
+    ref = refshim.build_reference_composer(copy.deepcopy(cfg))
+    synthetic.randomize_module_state(ref, seed=seed, step=step, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref.train()
+    inputs = composer_inputs(cfg, scene, pixels=pixels)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    leaf = [inputs[i].clone().requires_grad_(True) for i in (3, 4, 5)]
+    args = list(inputs[:3]) + leaf + [inputs[6]]
+    torch.manual_seed(seed + 1)
+    out_ref = ref(*args, perturb)
+    torch.manual_seed(seed + 1)
+    rec = {}
+    with torch.enable_grad():
+        out_or = ro.composer_forward(cfg, {k: v.clone() for k, v in sd.items()}, *[a.detach() for a in args[:3]],
+                                     *[t.detach().clone().requires_grad_(True) for t in leaf], inputs[6], perturb,
+                                     training=True, record_noise=rec)
+    fr, fo = flatten(out_ref), flatten(out_or)
+    for k in fr:
+        assert np.array_equal(fr[k], fo[k], equal_nan=True), f"{name}: oracle != reference on {k}"
+    gen = torch.Generator().manual_seed(seed + 2)
+    data = {}
+    loss = 0.0
+    for entry in sorted(out_ref["coarse"].keys()):
+        for key in GRAD_FIELDS:
+            t = out_ref["coarse"][entry][key]
+            w = torch.randn(t.shape, generator=gen)
+            data[f"probe/{entry}/{key}"] = w.numpy()
+            loss = loss + (t * w).sum()
+    loss.backward()
+    for k, p in ref.named_parameters():
+        data["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for label, t in zip(("w2o", "style", "deformation"), leaf):
+        data["grad/" + label] = t.grad.numpy()
+    data.update({"out/" + k: v for k, v in fr.items()})
+    for i, v in enumerate(inputs):
+        data[f"in/{i}"] = v.numpy()
+    for k, v in sd.items():
+        data["sd/" + k] = v.numpy()
+    for k, v in rec.items():
+        if v is not None and not k.startswith("div_"):
+            data["noise/" + k] = v.detach().numpy()
+    data["recipe"] = np.frombuffer(repr(recipe).encode(), dtype=np.uint8)
+    data["perturb"] = np.array(int(perturb))
+    os.makedirs(os.path.join(OUT, "grads"), exist_ok=True)
+    path = os.path.join(OUT, "grads", name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {sum(k.startswith('grad/') for k in data)} gradient tensors")
+
+
 REDUCE = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1,
               bender_octaves=3)
 ODD = dict(width=48, layers=3, skip=1, features=16, octaves=3, bender_width=16, bender_layers=3, bender_skip=2,
@@ -102,6 +159,12 @@ def main():
     make("minecraft_small_hier_perturb", {"base": "minecraft", "reduce": REDUCE, "fine": True,
                                           "positions": {"background": (8, 8), "skybox": (3, 2), "player_1": (12, 12)}},
          synthetic.minecraft_scene(seed=26), grid_pixels(256, 256, 12), perturb=True, alpha_bias=3.0)
+    make_gradients("tennis_small_train", {"base": "tennis", "reduce": REDUCE}, synthetic.tennis_scene(seed=31),
+                   grid_pixels(256, 256, 12))
+    make_gradients("minecraft_small_train", {"base": "minecraft", "reduce": REDUCE}, synthetic.minecraft_scene(seed=32),
+                   grid_pixels(256, 256, 12), alpha_bias=3.0)
+    make_gradients("tennis_small_train_two_frames", {"base": "tennis", "reduce": REDUCE},
+                   synthetic.tennis_scene(seed=33, batch=2), grid_pixels(256, 256, 8), perturb=False)
     make("single_player_eval", {"base": "single", "reduce": REDUCE, "positions": {"player_1": (16, 16)}},
          synthetic.single_player_scene(seed=27, image_size=(16, 16)), None)
 

@@ -395,52 +395,81 @@ struct AdainBwd {
     const int32_t* count;   // rows that entered the batch statistics
 };
 
-// thread c owns channel c of a block of 256 rows
+// Block = 64 channels (blockIdx.y) x 4 row groups over 256 rows; thread (c, rg) walks rows rg, rg + 4, ...
+// The four partial sums of a channel are combined through LDS before the atomics.
 __global__ __launch_bounds__(256) void k_adain_bwd_reduce(AdainBwd p) {
+    __shared__ float sh_ds[4][64], sh_db[4][64];
+    __shared__ double sh_s1[4][64], sh_s2[4][64];
+    __shared__ int sh_frame[4][64];
     const int M = *p.r.total;
-    const int c = threadIdx.x;
-    if (c >= p.width) return;
-    const float mu = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < p.width;
+    const float mu = live ? p.mean[c] : 0.f, rstd = live ? 1.0f / sqrtf(p.var[c] + p.eps) : 0.f;
     double s1 = 0.0, s2 = 0.0;
     for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
         const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
         int cur = -1;
         float ds = 0.f, db = 0.f;
-        for (int m = m0; m < m1; ++m) {
-            const size_t at = (size_t)m * p.ld + c;
-            float dxh = 0.f;
-            if ((p.r.row_flags[m] & 3) == 3) {
-                const int frame = p.r.rec_flat[m] / p.r.samples_per_frame;
-                if (frame != cur) {
-                    if (cur >= 0) {
-                        atomicAdd(p.dscale + (size_t)cur * p.width + c, ds);
-                        atomicAdd(p.dbias + (size_t)cur * p.width + c, db);
+        if (live) {
+            for (int m = m0 + rg; m < m1; m += 4) {
+                const size_t at = (size_t)m * p.ld + c;
+                float dxh = 0.f;
+                if ((p.r.row_flags[m] & 3) == 3) {
+                    const int frame = p.r.rec_flat[m] / p.r.samples_per_frame;
+                    if (frame != cur) {
+                        if (cur >= 0) {
+                            atomicAdd(p.dscale + (size_t)cur * p.width + c, ds);
+                            atomicAdd(p.dbias + (size_t)cur * p.width + c, db);
+                        }
+                        cur = frame;
+                        ds = 0.f;
+                        db = 0.f;
                     }
-                    cur = frame;
-                    ds = 0.f;
-                    db = 0.f;
+                    const float* tab = p.table + (size_t)frame * p.table_stride;
+                    const float gg = tab[p.goff + c];
+                    const float hv = p.h[at];
+                    const float y = fmaf(hv, gg, tab[p.boff + c]);
+                    const float dy = y > 0.f ? p.g[at] : 0.f;
+                    const float xh = (hv - mu) * rstd;
+                    ds = fmaf(dy, xh, ds);
+                    db += dy;
+                    dxh = dy * (gg / rstd);   // scale = g / rstd
+                    s1 += (double)dxh;
+                    s2 += (double)dxh * (double)xh;
                 }
-                const float* tab = p.table + (size_t)frame * p.table_stride;
-                const float gg = tab[p.goff + c];
-                const float hv = p.h[at];
-                const float y = fmaf(hv, gg, tab[p.boff + c]);
-                const float dy = y > 0.f ? p.g[at] : 0.f;
-                const float xh = (hv - mu) * rstd;
-                ds = fmaf(dy, xh, ds);
-                db += dy;
-                dxh = dy * (gg / rstd);   // scale = g / rstd
-                s1 += (double)dxh;
-                s2 += (double)dxh * (double)xh;
+                p.g[at] = dxh;
             }
-            p.g[at] = dxh;
         }
-        if (cur >= 0) {
-            atomicAdd(p.dscale + (size_t)cur * p.width + c, ds);
-            atomicAdd(p.dbias + (size_t)cur * p.width + c, db);
+        sh_frame[rg][cl] = cur;
+        sh_ds[rg][cl] = ds;
+        sh_db[rg][cl] = db;
+        __syncthreads();
+        if (rg == 0 && live) {
+            // frames end where the last rows of the block are: groups usually agree on it
+            for (int q = 0; q < 4; ++q) {
+                const int f = sh_frame[q][cl];
+                if (f < 0) continue;
+                float a = sh_ds[q][cl], b = sh_db[q][cl];
+                for (int q2 = q + 1; q2 < 4; ++q2)
+                    if (sh_frame[q2][cl] == f) {
+                        a += sh_ds[q2][cl];
+                        b += sh_db[q2][cl];
+                        sh_frame[q2][cl] = -1;
+                    }
+                atomicAdd(p.dscale + (size_t)f * p.width + c, a);
+                atomicAdd(p.dbias + (size_t)f * p.width + c, b);
+            }
         }
+        __syncthreads();
     }
-    atomicAdd(p.sums + c, s1);
-    atomicAdd(p.sums + p.width + c, s2);
+    sh_s1[rg][cl] = s1;
+    sh_s2[rg][cl] = s2;
+    __syncthreads();
+    if (rg == 0 && live) {
+        atomicAdd(p.sums + c, sh_s1[0][cl] + sh_s1[1][cl] + sh_s1[2][cl] + sh_s1[3][cl]);
+        atomicAdd(p.sums + p.width + c, sh_s2[0][cl] + sh_s2[1][cl] + sh_s2[2][cl] + sh_s2[3][cl]);
+    }
 }
 
 // BatchNorm (batch statistics) backward: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh))
@@ -463,27 +492,37 @@ __global__ __launch_bounds__(256) void k_adain_bwd_apply(AdainBwd p) {
 }
 
 // d act7 = (d act7 + gsr * w_sigma) masked by act7 > 0; d w_sigma += sum gsr * act7, d b_sigma += sum gsr
+// (64 channels x 4 row groups per block, like k_adain_bwd_reduce)
 __global__ __launch_bounds__(256) void k_sigma_bwd(RowCtx r, float* g, const float* act, int ld, int width, const float* gsr,
                                                    const float* w_sigma, float* dw, float* db) {
+    __shared__ float sh[4][64], shb[4][64];
     const int M = *r.total;
-    const int c = threadIdx.x;
-    if (c >= width) return;
-    const float ws = (gsr && w_sigma) ? w_sigma[c] : 0.f;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < width;
+    const float ws = (live && gsr && w_sigma) ? w_sigma[c] : 0.f;
     float acc = 0.f, accb = 0.f;
-    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
-        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
-        for (int m = m0; m < m1; ++m) {
-            const size_t at = (size_t)m * ld + c;
-            const float gs = gsr ? gsr[m] : 0.f;
-            const float a = act[at];
-            acc = fmaf(gs, a, acc);
-            accb += gs;
-            const float v = fmaf(gs, ws, g[at]);
-            g[at] = a > 0.f ? v : 0.f;
+    if (live) {
+        for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+            const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+            for (int m = m0 + rg; m < m1; m += 4) {
+                const size_t at = (size_t)m * ld + c;
+                const float gs = gsr ? gsr[m] : 0.f;
+                const float a = act[at];
+                acc = fmaf(gs, a, acc);
+                accb += gs;
+                const float v = fmaf(gs, ws, g[at]);
+                g[at] = a > 0.f ? v : 0.f;
+            }
         }
     }
-    if (gsr && dw) atomicAdd(dw + c, acc);
-    if (gsr && db && c == 0) atomicAdd(db, accb);
+    sh[rg][cl] = acc;
+    shb[rg][cl] = accb;
+    __syncthreads();
+    if (rg == 0 && live && gsr) {
+        if (dw) atomicAdd(dw + c, sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+        if (db && c == 0) atomicAdd(db, shb[0][cl] + shb[1][cl] + shb[2][cl] + shb[3][cl]);
+    }
 }
 
 // Positional-encoding backward from the saved encoding (sin / cos values are reused):
@@ -551,26 +590,32 @@ __global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g
 // Bender head (3, BW), no bias: d act = (g_braw . W) masked by act > 0 ; dW[a][c] += sum_m g_braw[m][a] act[m][c]
 __global__ __launch_bounds__(256) void k_bender_head_bwd(RowCtx r, const float* g_braw, const float* act, int ld, int width,
                                                          const float* w_out, int w_ld, float* g_act, float* dw) {
+    __shared__ float sh[3][4][64];
     const int M = *r.total;
-    const int c = threadIdx.x;
-    if (c >= width) return;
-    const float w0 = w_out[c], w1 = w_out[w_ld + c], w2 = w_out[2 * w_ld + c];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const bool live = c < width;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
-        const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
-        for (int m = m0; m < m1; ++m) {
-            const float g0 = g_braw[(size_t)m * 3], g1 = g_braw[(size_t)m * 3 + 1], g2 = g_braw[(size_t)m * 3 + 2];
-            const float a = act[(size_t)m * ld + c];
-            a0 = fmaf(g0, a, a0);
-            a1 = fmaf(g1, a, a1);
-            a2 = fmaf(g2, a, a2);
-            g_act[(size_t)m * ld + c] = a > 0.f ? fmaf(g0, w0, fmaf(g1, w1, g2 * w2)) : 0.f;
+    if (live) {
+        const float w0 = w_out[c], w1 = w_out[w_ld + c], w2 = w_out[2 * w_ld + c];
+        for (int blk = blockIdx.x; blk * 256 < M; blk += gridDim.x) {
+            const int m0 = blk * 256, m1 = (m0 + 256 < M) ? m0 + 256 : M;
+            for (int m = m0 + rg; m < m1; m += 4) {
+                const float g0 = g_braw[(size_t)m * 3], g1 = g_braw[(size_t)m * 3 + 1], g2 = g_braw[(size_t)m * 3 + 2];
+                const float a = act[(size_t)m * ld + c];
+                a0 = fmaf(g0, a, a0);
+                a1 = fmaf(g1, a, a1);
+                a2 = fmaf(g2, a, a2);
+                g_act[(size_t)m * ld + c] = a > 0.f ? fmaf(g0, w0, fmaf(g1, w1, g2 * w2)) : 0.f;
+            }
         }
     }
-    if (dw) {
-        atomicAdd(dw + c, a0);
-        atomicAdd(dw + w_ld + c, a1);
-        atomicAdd(dw + 2 * w_ld + c, a2);
+    sh[0][rg][cl] = a0;
+    sh[1][rg][cl] = a1;
+    sh[2][rg][cl] = a2;
+    __syncthreads();
+    if (rg == 0 && live && dw) {
+        for (int a = 0; a < 3; ++a) atomicAdd(dw + a * w_ld + c, sh[a][0][cl] + sh[a][1][cl] + sh[a][2][cl] + sh[a][3][cl]);
     }
 }
 
@@ -599,12 +644,32 @@ __global__ __launch_bounds__(64) void k_deformation_bwd(RowCtx r, const float* g
 }
 
 // Style affine backward: [scale | bias] = A style + b  (layers/adain.py:30-33).  d_out (frames, 2 width) is
-// given as two tables dscale, dbias (frames, width).
+// given as two tables dscale, dbias (frames, width).  Blocks [0, frames): d_style of one frame (the 2 width
+// rows are spread over the threads); remaining blocks: dA / db elements.
 __global__ __launch_bounds__(256) void k_style_bwd(int frames, int width, int S, const float* dscale, const float* dbias,
                                                    const float* style, int style_stride, const float* A, float* dA, float* db,
                                                    float* d_style) {
+    __shared__ float sh[256];
     const int rows = 2 * width;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if ((int)blockIdx.x < frames) {   // d_style[f][s] += sum_r A[r][s] d_out[f][r]
+        const int f = blockIdx.x;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+            float acc = 0.f;
+            if (s < S)
+                for (int rr = part; rr < rows; rr += 4) {
+                    const float dv = rr < width ? dscale[(size_t)f * width + rr] : dbias[(size_t)f * width + rr - width];
+                    acc = fmaf(A[(size_t)rr * S + s], dv, acc);
+                }
+            sh[threadIdx.x] = acc;
+            __syncthreads();
+            if (part == 0 && s < S && d_style)
+                d_style[(size_t)f * style_stride + s] += sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
+            __syncthreads();
+        }
+        return;
+    }
+    const long idx = (long)(blockIdx.x - frames) * 256 + threadIdx.x;
     if (idx < (long)rows * S) {   // dA[r][s] += sum_f d_out[f][r] style[f][s]
         const int rr = (int)(idx / S), s = (int)(idx - (long)rr * S);
         const float* src = rr < width ? dscale + rr : dbias + (rr - width);
@@ -616,15 +681,6 @@ __global__ __launch_bounds__(256) void k_style_bwd(int frames, int width, int S,
             for (int f = 0; f < frames; ++f) b += src[(size_t)f * width];
             db[rr] += b;
         }
-    }
-    if (d_style && idx < (long)frames * S) {   // d_style[f][s] += sum_r A[r][s] d_out[f][r]
-        const int f = (int)(idx / S), s = (int)(idx - (long)f * S);
-        float acc = 0.f;
-        for (int rr = 0; rr < rows; ++rr) {
-            const float dv = rr < width ? dscale[(size_t)f * width + rr] : dbias[(size_t)f * width + rr - width];
-            acc = fmaf(A[(size_t)rr * S + s], dv, acc);
-        }
-        d_style[(size_t)f * style_stride + s] += acc;
     }
 }
 
@@ -829,14 +885,7 @@ static int weight_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, co
     p.partial = g.partial;
     p.bias_partial = dbias ? g.partial + (size_t)BWD_SPLITS * 256 * 384 : nullptr;
     p.bias = dbias;
-    static float* dummy = nullptr;
-    (void)dummy;
-    if (!dW) {
-        // bias only: still run the product into the scratch (rare; keeps one code path)
-        p.C = g.partial + (size_t)BWD_SPLITS * 256 * 384 + (size_t)BWD_SPLITS * 256;   // never reduced into: ni * nj = 0 below
-        p.nj = 0;
-        return PR_OK;
-    }
+    PR_REQUIRE(dW != nullptr, "a bias gradient buffer needs its weight gradient buffer");
     p.C = dW; p.ldc = ldw;
     return launch_gemm_tn(p, g.s);
 }
@@ -994,7 +1043,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
         ab.mean = batch + 2 * MAX_WIDTH; ab.var = batch + 3 * MAX_WIDTH; ab.eps = m.bn_eps;
         ab.g = bufB; ab.sums = sums; ab.dscale = dscale2; ab.dbias = dbias2; ab.count = stat_count;
         PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
-        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk), dim3(256), 0, s, ab);
+        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk, (d.W2 + 63) / 64), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
@@ -1008,7 +1057,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
         ab.h = h1; ab.ld = d.Wpad; ab.width = d.W; ab.goff = 0; ab.boff = d.Wpad;
         ab.mean = batch; ab.var = batch + MAX_WIDTH; ab.g = bufA; ab.dscale = dscale1; ab.dbias = dbias1;
         PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
-        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk), dim3(256), 0, s, ab);
+        hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk, (d.W + 63) / 64), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
@@ -1017,7 +1066,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
         const float* act_last = acts + (size_t)(nb - 1) * act_stride;
         PR_TRY(weight_grad(gc, bufA, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr));
         PR_TRY(input_grad(gc, bufA, d.Wpad, d.W, m.head0.weight, d.W, d.W, bufB, d.Wpad, false, nullptr, 0));
-        hipLaunchKernelGGL(k_sigma_bwd, dim3(grid_blk), dim3(256), 0, s, rc, bufB, act_last, d.Wpad, d.W,
+        hipLaunchKernelGGL(k_sigma_bwd, dim3(grid_blk, (d.W + 63) / 64), dim3(256), 0, s, rc, bufB, act_last, d.Wpad, d.W,
                            m.kind == 0 ? gsr : nullptr, m.alpha_head.weight, G.alpha_head.weight, G.alpha_head.bias);
         PR_LAUNCH_CHECK();
         // ---- backbone -------------------------------------------------------------------------------
@@ -1047,7 +1096,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
                                lo[1], lo[2], hi[0], hi[1], hi[2], (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0, g_x, g_braw);
             PR_LAUNCH_CHECK();
             const int bc = m.bender_count;
-            hipLaunchKernelGGL(k_bender_head_bwd, dim3(grid_blk), dim3(256), 0, s, rc, g_braw, bacts + (size_t)(bc - 1) * bact_stride,
+            hipLaunchKernelGGL(k_bender_head_bwd, dim3(grid_blk, (d.BW + 63) / 64), dim3(256), 0, s, rc, g_braw, bacts + (size_t)(bc - 1) * bact_stride,
                                d.BWpad, d.BW, m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
             PR_LAUNCH_CHECK();
             PR_TRY(chain_backward(gc, m.bender, G.bender, bc, m.bender_skip, d.BW, d.BWpad, bacts, bact_stride, bin, d.bin_pad,
@@ -1068,15 +1117,13 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
             const int S = m.style_features;
             const float* style_k = c.style + (size_t)k * S;
             float* d_style_k = out.style ? out.style + (size_t)k * S : nullptr;
-            long n1 = (long)2 * d.W * S, n2 = (long)c.frames * S;
-            long n = n1 > n2 ? n1 : n2;
-            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.frames, d.W, S, dscale1, dbias1,
-                               style_k, K * S, m.affine1.weight, G.affine1.weight, G.affine1.bias, d_style_k);
+            long n = (long)2 * d.W * S;
+            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)(c.frames + (n + 255) / 256)), dim3(256), 0, s, c.frames, d.W, S, dscale1,
+                               dbias1, style_k, K * S, m.affine1.weight, G.affine1.weight, G.affine1.bias, d_style_k);
             PR_LAUNCH_CHECK();
-            n1 = (long)2 * d.W2 * S;
-            n = n1 > n2 ? n1 : n2;
-            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.frames, d.W2, S, dscale2, dbias2,
-                               style_k, K * S, m.affine4.weight, G.affine4.weight, G.affine4.bias, d_style_k);
+            n = (long)2 * d.W2 * S;
+            hipLaunchKernelGGL(k_style_bwd, dim3((unsigned)(c.frames + (n + 255) / 256)), dim3(256), 0, s, c.frames, d.W2, S, dscale2,
+                               dbias2, style_k, K * S, m.affine4.weight, G.affine4.weight, G.affine4.bias, d_style_k);
             PR_LAUNCH_CHECK();
         }
         // ---- sample placement -> object pose -----------------------------------------------------------------

@@ -3,7 +3,7 @@
 //   gemm_nn :  C[M x N] (+)= A[M x K] . B[K x N]   (dX = dY . W ; M = evaluated samples, read from the device)
 //   gemm_tn :  C[Ni x Nj] += sum_m A[m][i] B[m][j]  (dW = dY^T . X, bias gradient = column sums of dY)
 //
-// Both stage 16-deep operand slabs in LDS with the reduction index as the slow dimension (row stride
+// Both stage 32-deep operand slabs in LDS (the next slab is fetched into registers while the current one is multiplied) with the reduction index as the slow dimension (row stride
 // 160 floats: the two K-halves of a wavefront land 32 banks apart), four waves per workgroup, each wave
 // a 64 x 64 block of the 128 x 128 output tile (2 x 2 MFMA accumulators).  gemm_tn splits the sample
 // dimension over `splits` workgroups per output tile and reduces the partial tiles in a second, fixed-order
@@ -16,13 +16,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PR_MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
 constexpr int GT = 128;        // output tile edge
-constexpr int GK = 16;         // reduction slab depth
+constexpr int GK = 32;         // reduction slab depth
 constexpr int GLD = 160;       // LDS row stride (floats)
+constexpr int TN_MIN_CHUNK = 512;   // fewest samples per split of the weight-gradient reduction
 
-struct GemmSmem {
-    float A[GK * GLD];
-    float B[GK * GLD];
-};
+constexpr int GLA = GK + 2;    // row-major A operand (gemm_nn): 34-float rows -> conflict-free b32 fragment reads
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -33,66 +31,80 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 }
 
-// one 16-deep slab: every wave multiplies its 64 x 64 block
-__device__ __forceinline__ void slab_mfma(const GemmSmem& S, f32x16 (&acc)[2][2], int wr, int wc, int r, int half) {
-#pragma unroll
-    for (int kk = 0; kk < GK; kk += 2) {
-        const float a0 = S.A[(kk + half) * GLD + wr * 64 + r];
-        const float a1 = S.A[(kk + half) * GLD + wr * 64 + 32 + r];
-        const float b0 = S.B[(kk + half) * GLD + wc * 64 + r];
-        const float b1 = S.B[(kk + half) * GLD + wc * 64 + 32 + r];
-        PR_MFMA32(acc[0][0], a0, b0);
-        PR_MFMA32(acc[0][1], a0, b1);
-        PR_MFMA32(acc[1][0], a1, b0);
-        PR_MFMA32(acc[1][1], a1, b1);
-    }
-}
-
+// The next slab travels HBM -> registers while the current one is multiplied out of LDS.  Every global
+// load instruction of a wavefront covers whole contiguous segments (16-byte vectors along the contiguous
+// dimension of the activations; the weight rows, whose leading dimension is arbitrary, one dword per lane).
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
-    __shared__ GemmSmem S;
+    __shared__ __attribute__((aligned(16))) float SA[GT * GLA];   // [row][k]
+    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];   // [k][n]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
     const int n0 = blockIdx.y * GT;
+    const int ak4 = tid & 7, arow = tid >> 3;       // A: rows arow + 32 i, one float4 of k each
+    const int bn = tid & 127, bk = tid >> 7;        // B: k rows bk + 2 i, one dword each
     for (int row0 = blockIdx.x * GT; row0 < M; row0 += gridDim.x * GT) {
         f32x16 acc[2][2];
         zero_acc(acc);
-        for (int k0 = 0; k0 < p.k; k0 += GK) {
-            {   // A slab: 128 rows x 16 k, row-major source -> k-major LDS
-                const int row = tid >> 1, kofs = (tid & 1) * 8;
-                float v[8];
-                if (row0 + row < M) {
-                    const float4* src = reinterpret_cast<const float4*>(p.A + (size_t)(row0 + row) * p.lda + k0 + kofs);
-                    const float4 x = src[0], y = src[1];
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-                } else {
+        float4 ra[4];
+        float rb[16];
+        auto fetch = [&](int k0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) S.A[(kofs + i) * GLD + row] = v[i];
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + arow + 32 * i;
+                ra[i] = (row < M && k0 + 4 * ak4 < p.k)
+                            ? *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + k0 + 4 * ak4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            {   // B slab: 16 k x 128 n from the row-major weight (unaligned leading dimension)
-                const int kk = tid >> 4, nofs = (tid & 15) * 8;
-                const float* src = p.B + (size_t)(k0 + kk) * p.ldb + n0 + nofs;
+            const bool ncol = n0 + bn < p.n;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) S.B[kk * GLD + nofs + i] = (n0 + nofs + i < p.n) ? src[i] : 0.f;
+            for (int i = 0; i < 16; ++i) {
+                const int kk = k0 + bk + 2 * i;
+                rb[i] = (ncol && kk < p.k) ? p.B[(size_t)kk * p.ldb + n0 + bn] : 0.f;
+            }
+        };
+        auto stage = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* dst = SA + (arow + 32 * i) * GLA + 4 * ak4;
+                *reinterpret_cast<float2*>(dst) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(ra[i].z, ra[i].w);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) SB[(bk + 2 * i) * GLD + bn] = rb[i];
+        };
+        fetch(0);
+        stage();
+        __syncthreads();
+        for (int k0 = 0; k0 < p.k; k0 += GK) {
+            const bool more = k0 + GK < p.k;
+            if (more) fetch(k0 + GK);
+#pragma unroll
+            for (int kk = 0; kk < GK; kk += 2) {
+                const float a0 = SA[(wr * 64 + r) * GLA + kk + half];
+                const float a1 = SA[(wr * 64 + 32 + r) * GLA + kk + half];
+                const float b0 = SB[(kk + half) * GLD + wc * 64 + r];
+                const float b1 = SB[(kk + half) * GLD + wc * 64 + 32 + r];
+                PR_MFMA32(acc[0][0], a0, b0);
+                PR_MFMA32(acc[0][1], a0, b1);
+                PR_MFMA32(acc[1][0], a1, b0);
+                PR_MFMA32(acc[1][1], a1, b1);
             }
             __syncthreads();
-            slab_mfma(S, acc, wr, wc, r, half);
+            if (more) stage();
             __syncthreads();
         }
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb2 = 0; rb2 < 2; ++rb2)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const int col = n0 + wc * 64 + cb * 32 + r;
                 if (col >= p.n) continue;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int row = row0 + wr * 64 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                    const int row = row0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
                     if (row >= M) continue;
-                    float v = acc[rb][cb][i];
+                    float v = acc[rb2][cb][i];
                     float* dst = p.C + (size_t)row * p.ldc + col;
                     if (p.accumulate) v += *dst;
                     if (p.mask && !(p.mask[(size_t)row * p.ldm + col] > 0.f)) v = 0.f;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
 }
 
 int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s) {
-    PR_REQUIRE(p.k % GK == 0 && (p.lda & 3) == 0, "gemm_nn: K %d / lda %d not aligned", p.k, p.lda);
+    PR_REQUIRE(p.k % 16 == 0 && (p.lda & 3) == 0, "gemm_nn: K %d / lda %d not aligned", p.k, p.lda);
     if (max_rows <= 0 || p.n <= 0) return PR_OK;
     int row_tiles = (max_rows + GT - 1) / GT;
     if (row_tiles > 1024) row_tiles = 1024;
@@ -115,8 +127,17 @@ int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // dW: reduction over the samples, split across workgroups
 // ---------------------------------------------------------------------------------------------
+// samples per split and the number of splits that own any: chunk is a multiple of the slab depth, at least
+// TN_MIN_CHUNK, so that calls with few evaluated samples do not pay for (and later re-read) empty partial tiles
+__device__ __forceinline__ int tn_chunk(int M, int splits) {
+    int chunk = (M + splits - 1) / splits;
+    if (chunk < TN_MIN_CHUNK) chunk = TN_MIN_CHUNK;
+    return (chunk + GK - 1) / GK * GK;
+}
+
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
-    __shared__ GemmSmem S;
+    __shared__ __attribute__((aligned(16))) float SA[GK * GLD];   // [sample][i]
+    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];   // [sample][j]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
@@ -124,32 +145,59 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
     const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
     const int i0 = ti * GT, j0 = tj * GT;
     const int split = blockIdx.y;
-    int chunk = (M + p.splits - 1) / p.splits;
-    chunk = (chunk + GK - 1) / GK * GK;
+    const int chunk = tn_chunk(M, p.splits);
     const int m_begin = split * chunk;
+    if (m_begin >= M && split > 0) return;   // split 0 always writes (M == 0 -> zeros)
     const int m_end = (m_begin + chunk < M) ? m_begin + chunk : M;
     f32x16 acc[2][2];
     zero_acc(acc);
     float bsum = 0.f;
+    const int c4 = tid & 31, rr = tid >> 5;   // 32 samples x 128 columns per slab: samples rr + 8 i, one float4 each
+    const bool acol = i0 + 4 * c4 < ((p.ni + 3) & ~3), bcol = j0 + 4 * c4 < ((p.nj + 3) & ~3);
+    float4 ra[4], rb[4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rr + 8 * i;
+            const bool live = m < m_end;
+            ra[i] = (live && acol) ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + i0 + 4 * c4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = (live && bcol) ? *reinterpret_cast<const float4*>(p.B + (size_t)m * p.ldb + j0 + 4 * c4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&SA[(rr + 8 * i) * GLD + 4 * c4]) = ra[i];
+            *reinterpret_cast<float4*>(&SB[(rr + 8 * i) * GLD + 4 * c4]) = rb[i];
+        }
+    };
+    if (m_begin < m_end) {
+        fetch(m_begin);
+        stage();
+    }
+    __syncthreads();
     for (int m0 = m_begin; m0 < m_end; m0 += GK) {
-        const int kk = tid >> 4, ofs = (tid & 15) * 8;
-        const bool live = m0 + kk < m_end;
-        {
-            const float* src = p.A + (size_t)(m0 + kk) * p.lda + i0 + ofs;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) S.A[kk * GLD + ofs + i] = (live && i0 + ofs + i < p.ni) ? src[i] : 0.f;
-        }
-        {
-            const float* src = p.B + (size_t)(m0 + kk) * p.ldb + j0 + ofs;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) S.B[kk * GLD + ofs + i] = (live && j0 + ofs + i < p.nj) ? src[i] : 0.f;
-        }
-        __syncthreads();
+        const bool more = m0 + GK < m_end;
+        if (more) fetch(m0 + GK);
         if (p.bias_partial && tj == 0 && tid < GT) {
 #pragma unroll
-            for (int q = 0; q < GK; ++q) bsum += S.A[q * GLD + tid];
+            for (int q = 0; q < GK; ++q) bsum += SA[q * GLD + tid];
         }
-        slab_mfma(S, acc, wr, wc, r, half);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a0 = SA[(kk + half) * GLD + wr * 64 + r];
+            const float a1 = SA[(kk + half) * GLD + wr * 64 + 32 + r];
+            const float b0 = SB[(kk + half) * GLD + wc * 64 + r];
+            const float b1 = SB[(kk + half) * GLD + wc * 64 + 32 + r];
+            PR_MFMA32(acc[0][0], a0, b0);
+            PR_MFMA32(acc[0][1], a0, b1);
+            PR_MFMA32(acc[1][0], a1, b0);
+            PR_MFMA32(acc[1][1], a1, b1);
+        }
+        __syncthreads();
+        if (more) stage();
         __syncthreads();
     }
     // partial tile -> P[split][i][j] (padded to whole tiles)
@@ -157,14 +205,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
     const int rows_p = ((p.ni + GT - 1) / GT) * GT;
     float* P = p.partial + (size_t)split * rows_p * ldp;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb2 = 0; rb2 < 2; ++rb2)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int col = j0 + wc * 64 + cb * 32 + r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = i0 + wr * 64 + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                P[(size_t)row * ldp + col] = acc[rb][cb][i];
+                const int row = i0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                P[(size_t)row * ldp + col] = acc[rb2][cb][i];
             }
         }
     if (p.bias_partial && tj == 0 && tid < GT) p.bias_partial[(size_t)split * rows_p + i0 + tid] = bsum;
@@ -172,6 +220,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
 
 // C[i][j] += sum_s P[s][i][j] in split order; bias[i] += sum_s PB[s][i]
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(GemmTN p) {
+    const int M = *p.rows;
+    const int chunk = tn_chunk(M, p.splits);
+    int active = (M + chunk - 1) / chunk;
+    if (active < 1) active = 1;
     const int tiles_j = (p.nj + GT - 1) / GT;
     const int ldp = tiles_j * GT;
     const int rows_p = ((p.ni + GT - 1) / GT) * GT;
@@ -179,12 +231,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(GemmTN p) {
     if (idx < (long)p.ni * p.nj) {
         const int i = (int)(idx / p.nj), j = (int)(idx - (long)i * p.nj);
         float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.partial[((size_t)s * rows_p + i) * ldp + j];
+        for (int s = 0; s < active; ++s) v += p.partial[((size_t)s * rows_p + i) * ldp + j];
         p.C[(size_t)i * p.ldc + j] += v;
     }
     if (p.bias_partial && p.bias && idx < p.ni) {
         float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.bias_partial[(size_t)s * rows_p + idx];
+        for (int s = 0; s < active; ++s) v += p.bias_partial[(size_t)s * rows_p + idx];
         p.bias[idx] += v;
     }
 }
@@ -196,6 +248,8 @@ size_t gemm_tn_scratch_floats(int splits) {
 
 int launch_gemm_tn(const GemmTN& p, hipStream_t s) {
     PR_REQUIRE(p.ni <= 256 && p.nj <= 384, "gemm_tn: %d x %d exceeds the partial buffer", p.ni, p.nj);
+    PR_REQUIRE((p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 &&
+               p.lda >= ((p.ni + 3) & ~3) && p.ldb >= ((p.nj + 3) & ~3), "gemm_tn: operands must be 16-byte aligned rows");
     PR_REQUIRE(p.splits >= 1 && p.partial, "gemm_tn: no partial buffer");
     const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
     hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, p.splits), dim3(256), 0, s, p);
