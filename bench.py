@@ -48,6 +48,67 @@ def flops_per_sample(model_cfg: dict) -> float:
     return 2.0 * mac
 
 
+def train_step_leg(args, dev, world, rank, dist, lib):
+    """Secondary figure (never the headline): one data-parallel training step of the renderer in the shape of
+    BASELINE.json configs[4] / SURVEY.md C5 - minecraft, 3 frames per GPU, one 48x48 patch at strides [4, 8] per frame
+    (2880 rays), perturb=True, train-mode BatchNorm, forward + backward (pr_render_backward) + gradient all-reduce
+    over RCCL + Adam on the composer parameters.  The loss reads global.integrated_features only, which is where the
+    shipped configurations send gradients (every other renderer loss weight is 0)."""
+    from playableenvironments_amd import configs, synthetic, parallel
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    cfg = configs.minecraft_config()
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.train().to(dev)
+    size = (288, 512)
+    scene = synthetic.minecraft_scene(batch=3, seed=77 + rank, image_size=size)
+    sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
+        sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
+    params = list(model.object_composer.parameters())
+    opt = torch.optim.Adam(params, lr=1e-5)
+    steps, warmup = max(1, args.steps), max(2, args.warmup)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(sc["camera_rotations"], sc["camera_translations"], sc["focals"], size, sc["object_rotation_parameters"],
+                    sc["object_translation_parameters"], sc["object_style"], sc["object_deformation"], sc["object_in_scene"],
+                    2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings")
+        loss = out["coarse"]["global"]["integrated_features"].square().mean()
+        loss.backward()
+        parallel.allreduce_gradients(params)
+        opt.step()
+        return out
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    rays = int(out["coarse"]["global"]["opacity"].numel())
+    return {
+        "value": round(rays * world * steps / dt / 1e6, 4),
+        "unit": "Mrays/s trained (forward + backward + optimiser step)",
+        "ms_per_step": round(dt / steps * 1e3, 3),
+        "rays_per_gpu_per_step": rays,
+        "workload": "minecraft shipped config, 3 frames/GPU x (48x48 patch @ strides [4, 8] = 2880 rays), perturb, train-mode "
+                    "BatchNorm - BASELINE.json configs[4] renderer part",
+        "parallelism": f"data parallel x{world}" + (", one flat RCCL all_reduce of the parameter gradients" if world > 1 else ""),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +119,7 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
                     help="fp32 = exact fp32 MFMA (default, the headline); f16x3 = fp32 emulated with three fp16 MFMAs")
     ap.add_argument("--no-split-precision", action="store_true", help="skip the secondary f16x3 measurement")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--cpu-rays", type=int, default=64, help="the CPU baseline renders a cpu_rays x cpu_rays pixel grid")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the CPU baseline (all 256 host cores are >50x SLOWER on these small ops)")
@@ -238,6 +300,8 @@ def main():
                     "MFMAs, ~22-bit operands, fp32 accumulation; passes the same oracle/golden parity tolerance; "
                     "reported beside the exact-fp32 headline, not as it",
         }
+    if not args.no_train_step:
+        result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import render_oracle as ro
         from tests.helpers import composer_inputs, grid_pixels

@@ -1,5 +1,11 @@
 """Multi-GPU sharding of the renderer: one process per GPU, torch.distributed (RCCL over xGMI).
 
+Training is data-parallel over frames: every rank renders and differentiates
+its own frames (per-rank BatchNorm batch statistics, as the reference's nn.DataParallel replicas do), then
+the parameter gradients are summed with ``allreduce_gradients`` - one flat bucket per <= 64 MiB, because
+ring all-reduce over point-to-point xGMI links is per-link bandwidth bound and wants few, large messages
+(the composer's 11.5 MB of gradients travel as a single collective).
+
 Rays are independent given the (tiny) scene encoding and the replicated weights, so the path
 shards with no data-path collective; the only exchange is the gather of the rendered feature maps
 (SURVEY.md section 8e).  The reference itself renders on a single GPU (evaluation bypasses
@@ -8,7 +14,7 @@ world_size-2 ``gloo`` tests on CPU exercise exactly the code the ``nccl`` (= RCC
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -59,3 +65,49 @@ def gather_ray_shards(local: torch.Tensor, total: int, dim: int, dst: Optional[i
         if rank != dst:
             return None
     return torch.cat([p.narrow(dim, 0, e - b) for p, (b, e) in zip(parts, sizes)], dim=dim)
+
+
+def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None, average: bool = True,
+                        bucket_bytes: int = 64 << 20) -> int:
+    """Sums (``average``: averages) ``.grad`` of ``parameters`` over the ranks, in place; parameters without a
+    gradient contribute zeros so that every rank issues the same collectives.  Gradients are packed into flat
+    buckets of at most ``bucket_bytes``; returns the number of collectives issued."""
+    params = [p for p in parameters if p.requires_grad]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or not params:
+        return 0
+    world = dist.get_world_size(group)
+    buckets: List[List[torch.nn.Parameter]] = [[]]
+    used = 0
+    for p in params:
+        size = p.numel() * 4
+        if buckets[-1] and used + size > bucket_bytes:
+            buckets.append([])
+            used = 0
+        buckets[-1].append(p)
+        used += size
+    for bucket in buckets:
+        ref = bucket[0]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
+                          for p in bucket]).to(ref.device)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        offset = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[offset:offset + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            offset += n
+    return len(buckets)
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Copies ``src``'s buffers (BatchNorm running statistics, annealing step) to every rank - the reference keeps
+    replica 0's running statistics under nn.DataParallel; call this before checkpointing to match."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for b in module.buffers():
+        dist.broadcast(b, src=src, group=group)

@@ -269,6 +269,49 @@ def test_ray_shard_gather_world2_gloo(total):
     assert results[0] and results[1]
 
 
+def _gloo_grad_worker(rank, world, port, results):
+    import torch.distributed as dist
+    from playableenvironments_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 3, bias=False))
+        grads = []
+        for i, p in enumerate(net.parameters()):
+            g = torch.full_like(p, float(rank + 1) * (i + 1))
+            grads.append(g)
+            if not (rank == 1 and i == 0):          # one rank has no gradient for one parameter
+                p.grad = g.clone()
+        calls = parallel.allreduce_gradients(net.parameters(), bucket_bytes=64)   # tiny buckets: several collectives
+        ok = calls > 1
+        for i, p in enumerate(net.parameters()):
+            want = (1.0 * (i + 1) + (0.0 if i == 0 else 2.0 * (i + 1))) / 2.0
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+        net[1].running_mean.fill_(float(rank + 3))
+        parallel.broadcast_buffers(net, src=0)
+        ok = ok and float(net[1].running_mean[0]) == 3.0
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    """Data-parallel training exchange (C5): bucketed in-place gradient average + buffer broadcast."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_gloo_grad_worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert results[0] and results[1]
+
+
 def test_shard_range_partitions():
     from playableenvironments_amd.parallel import shard_range
     for total in (0, 1, 7, 8, 65536):
