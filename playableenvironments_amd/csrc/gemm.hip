@@ -15,6 +15,9 @@ namespace pr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define PR_MFMA32(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
+#ifndef PR_GEMM_ABLATE
+#define PR_GEMM_ABLATE 0       // timing builds only: 1 = no epilogue, 2 = no operand re-fetch, 4 = no MFMA
+#endif
 constexpr int GT = 128;        // output tile edge
 constexpr int GK = 32;         // reduction slab depth
 constexpr int GLD = 160;       // LDS row stride (floats)
@@ -35,8 +38,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 // load instruction of a wavefront covers whole contiguous segments (16-byte vectors along the contiguous
 // dimension of the activations; the weight rows, whose leading dimension is arbitrary, one dword per lane).
 __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
-    __shared__ __attribute__((aligned(16))) float SA[GT * GLA];   // [row][k]
-    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];   // [k][n]
+    __shared__ __attribute__((aligned(16))) float smem[GT * GLA + GK * GLD];
+    float* SA = smem;                 // [row][k]
+    float* SB = smem + GT * GLA;      // [k][n]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
@@ -77,10 +81,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
         stage();
         __syncthreads();
         for (int k0 = 0; k0 < p.k; k0 += GK) {
-            const bool more = k0 + GK < p.k;
+            const bool more = (k0 + GK < p.k) && !(PR_GEMM_ABLATE & 2);
             if (more) fetch(k0 + GK);
 #pragma unroll
-            for (int kk = 0; kk < GK; kk += 2) {
+            for (int kk = 0; kk < ((PR_GEMM_ABLATE & 4) ? 2 : GK); kk += 2) {
                 const float a0 = SA[(wr * 64 + r) * GLA + kk + half];
                 const float a1 = SA[(wr * 64 + 32 + r) * GLA + kk + half];
                 const float b0 = SB[(kk + half) * GLD + wc * 64 + r];
@@ -94,23 +98,61 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
             if (more) stage();
             __syncthreads();
         }
+        // epilogue through LDS (the operand slabs are dead after the last barrier): every wave parks a 32 x 64 half
+        // of its block, then moves whole 256-byte row segments with 16-byte accesses; the mask / previous values of
+        // a half are all requested before the first store (C, mask and A may alias as far as the compiler knows)
+        if ((PR_GEMM_ABLATE & 1) && acc[0][0][0] != 123.456f) continue;
+        const float* __restrict__ mask = p.mask;
+        float* __restrict__ C = p.C;
+        float* park = SA + wave * (32 * 68);          // 4 waves x 32 rows x 68 floats = 34 KB <= SA + SB
+        static_assert(4 * 32 * 68 <= GT * GLA + GK * GLD, "epilogue staging must fit the operand slabs");
+        const bool vec_ok = ((p.ldc & 3) == 0) && (mask == nullptr || (p.ldm & 3) == 0) && (n0 + wc * 64 + 64 <= p.n);
 #pragma unroll
-        for (int rb2 = 0; rb2 < 2; ++rb2)
+        for (int rb2 = 0; rb2 < 2; ++rb2) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int col = n0 + wc * 64 + cb * 32 + r;
-                if (col >= p.n) continue;
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = row0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                for (int i = 0; i < 16; ++i)
+                    park[((i & 3) + 8 * (i >> 2) + 4 * half) * 68 + cb * 32 + r] = acc[rb2][cb][i];
+            // (wave-private region: no workgroup barrier needed, the wave's own LDS accesses are ordered)
+            const int rbase = row0 + wr * 64 + rb2 * 32;
+            const int cbase = n0 + wc * 64;
+            if (vec_ok) {
+                const int c4 = lane & 15, rq = lane >> 4;      // 16 lanes x float4 = one 64-column row; 4 rows per pass
+                float4 mv[8], old[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = rbase + rq + 4 * q;
+                    const bool ok = row < M;
+                    mv[q] = (ok && mask) ? *reinterpret_cast<const float4*>(mask + (size_t)row * p.ldm + cbase + 4 * c4)
+                                         : make_float4(1.f, 1.f, 1.f, 1.f);
+                    old[q] = (ok && p.accumulate) ? *reinterpret_cast<const float4*>(C + (size_t)row * p.ldc + cbase + 4 * c4)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = rbase + rq + 4 * q;
                     if (row >= M) continue;
-                    float v = acc[rb2][cb][i];
-                    float* dst = p.C + (size_t)row * p.ldc + col;
-                    if (p.accumulate) v += *dst;
-                    if (p.mask && !(p.mask[(size_t)row * p.ldm + col] > 0.f)) v = 0.f;
-                    *dst = v;
+                    const float4 v = *reinterpret_cast<const float4*>(park + (rq + 4 * q) * 68 + 4 * c4);
+                    float4 o;
+                    o.x = mv[q].x > 0.f ? v.x + old[q].x : 0.f;
+                    o.y = mv[q].y > 0.f ? v.y + old[q].y : 0.f;
+                    o.z = mv[q].z > 0.f ? v.z + old[q].z : 0.f;
+                    o.w = mv[q].w > 0.f ? v.w + old[q].w : 0.f;
+                    *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + cbase + 4 * c4) = o;
+                }
+            } else {
+                for (int q = 0; q < 32; ++q) {
+                    const int row = rbase + q, col = cbase + lane;
+                    if (row < M && col < p.n) {
+                        const float m = mask ? mask[(size_t)row * p.ldm + col] : 1.0f;
+                        const float o = p.accumulate ? C[(size_t)row * p.ldc + col] : 0.f;
+                        C[(size_t)row * p.ldc + col] = m > 0.f ? park[q * 68 + lane] + o : 0.f;
+                    }
                 }
             }
+        }
+        __syncthreads();   // the next row tile's prologue overwrites the slabs
     }
 }
 
@@ -230,8 +272,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(GemmTN p) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx < (long)p.ni * p.nj) {
         const int i = (int)(idx / p.nj), j = (int)(idx - (long)i * p.nj);
+        const float* __restrict__ src = p.partial + (size_t)i * ldp + j;
+        const size_t stride = (size_t)rows_p * ldp;
         float v = 0.f;
-        for (int s = 0; s < active; ++s) v += p.partial[((size_t)s * rows_p + i) * ldp + j];
+        int s = 0;
+        for (; s + 8 <= active; s += 8) {   // eight loads in flight; the additions stay in split order
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(s + q) * stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += t[q];
+        }
+        for (; s < active; ++s) v += src[(size_t)s * stride];
         p.C[(size_t)i * p.ldc + j] += v;
     }
     if (p.bias_partial && p.bias && idx < p.ni) {

@@ -39,5 +39,46 @@ def main():
               f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
 
+def train_step():
+    """The C5-shaped training step of tests/perf_train_step.py through torch.autograd on the GPU."""
+    from tests.perf_train_step import patch_pixels
+    cfg = configs.minecraft_config()
+    torch.manual_seed(0)
+    comp = ObjectComposer(cfg)
+    synthetic.randomize_module_state(comp, seed=0, step=20000, alpha_bias=1.0, bender_scale=1e4)
+    scene = synthetic.minecraft_scene(batch=3, seed=5)
+    inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=patch_pixels())]
+    o, d, n, w2o, sty, dfm, ins = inputs
+    sd = {k: v.detach().cuda().clone() for k, v in comp.state_dict().items()}
+    names = [k for k, _ in comp.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    for t in (w2o, sty, dfm):
+        t.requires_grad_(True)
+    opt = torch.optim.Adam([sd[k] for k in names], lr=1e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = ro.composer_forward(cfg, sd, o, d, n, w2o, sty, dfm, ins, True, training=True)
+        out["coarse"]["global"]["integrated_features"].square().mean().backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 5
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rays = d.numel() // 3
+    print(f"PyTorch-ROCm autograd training step (minecraft, {rays} rays): {dt * 1e3:.1f} ms -> {rays / dt / 1e6:.4f} Mrays/s "
+          f"trained, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        train_step()
+    else:
+        main()

@@ -12,6 +12,17 @@ from playableenvironments_amd.object_composer import ObjectComposer  # noqa: E40
 from tests.helpers import composer_inputs  # noqa: E402
 
 
+def patch_pixels():
+    """a 192 x 192 pixel window sampled at strides 4 and 8 (48^2 + 24^2 = 2880 rays)"""
+    rows, cols = [], []
+    for s, p in ((4, 48), (8, 24)):
+        r = torch.arange(p) * s + s // 2 + 32
+        rr, cc = torch.meshgrid(r, r, indexing="ij")
+        rows.append(rr.reshape(-1))
+        cols.append(cc.reshape(-1))
+    return torch.cat(rows), torch.cat(cols)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "minecraft"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -22,14 +33,7 @@ def main():
     synthetic.randomize_module_state(comp, seed=0, step=20000, alpha_bias=1.0, bender_scale=1e4)
     comp = comp.cuda().train()
     h, w = scene["image_size"]
-    # a 192 x 192 pixel window sampled at strides 4 and 8 (48^2 + 24^2 = 2880 rays)
-    rows, cols = [], []
-    for s, p in ((4, 48), (8, 24)):
-        r = torch.arange(p) * s + s // 2 + 32
-        rr, cc = torch.meshgrid(r, r, indexing="ij")
-        rows.append(rr.reshape(-1))
-        cols.append(cc.reshape(-1))
-    pixels = (torch.cat(rows), torch.cat(cols))
+    pixels = patch_pixels()
     inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=pixels)]
     o, d, n, w2o, sty, dfm, ins = inputs
     w2o.requires_grad_(True)
