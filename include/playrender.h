@@ -136,6 +136,10 @@ typedef struct pr_noise_t {
     const float* pdf[PR_MAX_OBJECTS];         /* coarse only: U[0,1) (N,R,Pf_k) ray_helper.py:1380 */
     const float* integrate[PR_MAX_OBJECTS];   /* N(0,1) (N,R,P_k) object_composer.py:880 -> :751 */
     const float* integrate_global;            /* N(0,1) (N,R,sum P_k), applied AFTER the sort, :886 */
+    const float* divergence[PR_MAX_OBJECTS];  /* N(0,1) (N,R,P_k,3): Hutchinson probe of compute_approximate_divergence
+                                                 (object_composer.py:582-601); read only with PR_FLAG_SAVE_FOR_BACKWARD
+                                                 (the reference returns zeros unless it trains with a graph), objects
+                                                 with a ray bender only; NULL = divergence left at zero */
 } pr_noise_t;
 
 /* Result fields of ObjectComposer.integrate (model/object_composer.py:774-782); any pointer may be NULL. */

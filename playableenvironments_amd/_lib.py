@@ -61,7 +61,7 @@ class Noise(C.Structure):
     _fields_ = [
         ("jitter", C.c_void_p * PR_MAX_OBJECTS), ("alpha", C.c_void_p * PR_MAX_OBJECTS),
         ("pdf", C.c_void_p * PR_MAX_OBJECTS), ("integrate", C.c_void_p * PR_MAX_OBJECTS),
-        ("integrate_global", C.c_void_p),
+        ("integrate_global", C.c_void_p), ("divergence", C.c_void_p * PR_MAX_OBJECTS),
     ]
 
 

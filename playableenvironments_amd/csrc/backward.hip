@@ -1192,3 +1192,116 @@ extern "C" int pr_render_backward(const pr_call_t* call, const pr_object_t* obje
     return pr::backward(*call, objects, *grads, *out, static_cast<char*>(forward_workspace), plan,
                         static_cast<char*>(backward_workspace), bp, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Hutchinson divergence estimate (train mode with a graph only; object_composer.py:582-601)
+// ---------------------------------------------------------------------------------------------
+namespace pr {
+
+// tangent of the bender input [annealed PE(x / size) | deformation] along e: d v_a = e_a / size_a;
+// sin slot: 2^k cos_saved d v ; cos slot: -2^k sin_saved d v (the saved values carry the annealing weight)
+__global__ __launch_bounds__(256) void k_div_tangent_in(const int32_t* total, const int32_t* rec_flat, const float* noise,
+                                                        const float* bin, int ld, int benc, int octaves, float s0, float s1,
+                                                        float s2, float* t0) {
+    const int M = *total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float size[3] = {s0, s1, s2};
+    const float* e = noise + (size_t)rec_flat[m] * 3;
+    const float* b = bin + (size_t)m * ld;
+    float* t = t0 + (size_t)m * ld;
+    float dv[3];
+    for (int a = 0; a < 3; ++a) {
+        dv[a] = e[a] / size[a];
+        t[a] = dv[a];
+    }
+    for (int k = 0; k < octaves; ++k) {
+        const float f = ldexpf(1.0f, k);
+        for (int a = 0; a < 3; ++a) {
+            const int sn = 3 + k * 6 + a, cs = sn + 3;
+            t[sn] = f * b[cs] * dv[a];
+            t[cs] = -f * b[sn] * dv[a];
+        }
+    }
+    for (int j = benc; j < ld; ++j) t[j] = 0.f;
+}
+
+// div = sum_a e_a (J e)_a with (J e)_a = size_a * (W_out t)_a where the clamp passes the network output,
+// -e_a where delta = lo - x or hi - x, 0 in canonical pose
+__global__ __launch_bounds__(256) void k_div_out(const int32_t* total, const int32_t* rec_flat, const int32_t* row_flags,
+                                                 const float* noise, const float* tlast, int ld, int width, const float* w_out,
+                                                 const float* braw, const float* pos, float lo0, float lo1, float lo2, float hi0,
+                                                 float hi1, float hi2, int canonical, float* div) {
+    const int M = *total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M || !(row_flags[m] & 1)) return;
+    const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const int flat = rec_flat[m];
+    const float* e = noise + (size_t)flat * 3;
+    const float* t = tlast + (size_t)m * ld;
+    float tan[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < width; ++c) {
+        const float tv = t[c];
+        tan[0] = fmaf(tv, w_out[c], tan[0]);
+        tan[1] = fmaf(tv, w_out[width + c], tan[1]);
+        tan[2] = fmaf(tv, w_out[2 * width + c], tan[2]);
+    }
+    float acc = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        const float x = pos[(size_t)m * 3 + a];
+        const float size = hi[a] - lo[a];
+        const float pre = braw[(size_t)m * 3 + a] * size;
+        const float lob = lo[a] - x, hib = hi[a] - x;
+        const float m1 = pre > lob ? pre : lob;
+        float je;
+        if (m1 > hib) je = -e[a];
+        else if (pre >= lob) je = size * tan[a];
+        else je = -e[a];
+        if (canonical) je = 0.f;
+        acc = fmaf(e[a], je, acc);
+    }
+    div[flat] = acc;
+}
+
+int launch_divergence(const DivergenceParams& p, hipStream_t s) {
+    if (p.max_rows <= 0) return PR_OK;
+    const int blocks = (p.max_rows + 255) / 256;
+    hipLaunchKernelGGL(k_div_tangent_in, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.noise, p.bin, p.bin_pad, p.benc,
+                       p.b_octaves, p.hi[0] - p.lo[0], p.hi[1] - p.lo[1], p.hi[2] - p.lo[2], p.t0);
+    PR_LAUNCH_CHECK();
+    float* cur = p.ta;
+    float* other = p.tb;
+    const float* prev = p.t0;
+    for (int l = 0; l < p.b_count; ++l) {
+        const pr_linear_t& L = p.layers[l];
+        GemmNN g;
+        memset(&g, 0, sizeof(g));
+        g.rows = p.total; g.C = cur; g.ldc = p.BWpad; g.n = p.BW;
+        g.mask = p.bacts + (size_t)l * p.bact_stride; g.ldm = p.BWpad;
+        g.b_transposed = 1; g.B = L.weight; g.ldb = L.in_features;
+        if (l == 0) {
+            g.A = p.t0; g.lda = p.bin_pad; g.k = p.bin_pad; g.k_valid = p.bin_real;
+            PR_TRY(launch_gemm_nn(g, p.max_rows, s));
+        } else if (l == p.b_skip) {
+            // input = [h | bender input]: two products, the ReLU mask goes with the second
+            GemmNN g1 = g;
+            g1.A = prev; g1.lda = p.BWpad; g1.k = p.BWpad; g1.k_valid = p.BW; g1.mask = nullptr;
+            PR_TRY(launch_gemm_nn(g1, p.max_rows, s));
+            g.A = p.t0; g.lda = p.bin_pad; g.k = p.bin_pad; g.k_valid = p.bin_real; g.B = L.weight + p.BW; g.accumulate = 1;
+            PR_TRY(launch_gemm_nn(g, p.max_rows, s));
+        } else {
+            g.A = prev; g.lda = p.BWpad; g.k = p.BWpad; g.k_valid = p.BW;
+            PR_TRY(launch_gemm_nn(g, p.max_rows, s));
+        }
+        prev = cur;
+        float* tmp = cur;
+        cur = other;
+        other = tmp;
+    }
+    hipLaunchKernelGGL(k_div_out, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.row_flags, p.noise, prev, p.BWpad, p.BW,
+                       p.out_head.weight, p.braw, p.rec_pos, p.lo[0], p.lo[1], p.lo[2], p.hi[0], p.hi[1], p.hi[2], p.canonical, p.div);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+}  // namespace pr

@@ -21,6 +21,7 @@ struct CompositeSmem {
     float* wo;      // per-object weight per entry
     float* wg;      // global weight per entry (indexed by concatenation index)
     float* al;      // alpha scratch
+    float* dv;      // |divergence estimate| per entry (after the overlap fix)
     int* sl;        // compact feature row per entry (-1: outside the box)
     unsigned long long* key;
 };
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     sm.wo = sm.dm + A;
     sm.wg = sm.wo + A;
     sm.al = sm.wg + A;
-    sm.sl = reinterpret_cast<int*>(sm.al + A);
+    sm.dv = sm.al + A;
+    sm.sl = reinterpret_cast<int*>(sm.dv + A);
 
     const int lane = threadIdx.x;
     const long g = blockIdx.x;
@@ -81,14 +83,18 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             sm.sg[off + i] = o.sigma[base + i];
             sm.sl[off + i] = o.slot[base + i];
             sm.dm[off + i] = o.dispmag ? o.dispmag[base + i] : 0.f;
+            sm.dv[off + i] = o.divergence ? fabsf(o.divergence[base + i]) : 0.f;
         }
         __syncthreads();
+        float adiv = 0.f;   // sum alpha |div|  (object_composer.py:768-769, alphas detached)
         for (int i = lane; i < P; i += 64) {
             const float dt = (i < P - 1) ? __fsub_rn(sm.tt[off + i + 1], sm.tt[off + i]) : 1e10f;
             float raw = sm.sg[off + i];
             if (o.noise) raw = __fadd_rn(raw, o.noise[base + i]);
             sm.al[i] = alpha_of(raw, __fmul_rn(dt, norm));
+            adiv += sm.al[i] * sm.dv[off + i];
         }
+        adiv = wave_sum(adiv);
         __syncthreads();
         transmittance_weights(sm.al, P, lane);
         __syncthreads();
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             if (o.out.opacity) o.out.opacity[g] = opacity;
             if (o.out.disparity) o.out.disparity[g] = disparity_of(depth, opacity);
             if (o.out.integrated_displacements_magnitude) o.out.integrated_displacements_magnitude[g] = dmag / (float)P;
-            if (o.out.integrated_divergence) o.out.integrated_divergence[g] = 0.f;
+            if (o.out.integrated_divergence) o.out.integrated_divergence[g] = adiv / (float)P;
         }
         off += P;
     }
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
                     sm.tt[soff + i] = 0.f;
                     sm.sg[soff + i] = -10.0f;
                     sm.dm[soff + i] = 0.f;
+                    sm.dv[soff + i] = 0.f;
                 }
             }
             __syncthreads();
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
 
     // ---- global alphas / weights in sorted order -------------------------------------------------
     const size_t gbase = (size_t)g * PT;
+    float gdiv = 0.f;
     for (int j = lane; j < PT; j += 64) {
         const int e = (int)(sm.key[j] & 0xFFFFFFFFu);
         float dt = 1e10f;
@@ -195,7 +203,9 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         float raw = sm.sg[e];
         if (p.noise_global) raw = __fadd_rn(raw, p.noise_global[gbase + j]);
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
+        gdiv += sm.al[j] * sm.dv[e];
     }
+    gdiv = wave_sum(gdiv);
     __syncthreads();
     transmittance_weights(sm.al, PT, lane);   // al now holds the sorted-order weights
     __syncthreads();
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             if (p.global.disparity) p.global.disparity[g] = disparity_of(depth, opacity);
             if (p.global.integrated_displacements_magnitude)
                 p.global.integrated_displacements_magnitude[g] = dmag / (float)PT;
-            if (p.global.integrated_divergence) p.global.integrated_divergence[g] = 0.f;
+            if (p.global.integrated_divergence) p.global.integrated_divergence[g] = gdiv / (float)PT;
         }
     }
     __syncthreads();
@@ -320,7 +330,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
     PR_REQUIRE(p.sort_size >= p.total_positions && (p.sort_size & (p.sort_size - 1)) == 0, "bad sort size");
     for (int k = 0; k < p.objects; ++k)
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
-    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 7 * 4;
+    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 8 * 4;
     PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
     static bool attr_set = false;
     if (!attr_set) {

@@ -61,10 +61,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
                             : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const bool ncol = n0 + bn < p.n;
+            const int kv = p.k_valid ? p.k_valid : p.k;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = k0 + bk + 2 * i;
-                rb[i] = (ncol && kk < p.k) ? p.B[(size_t)kk * p.ldb + n0 + bn] : 0.f;
+                rb[i] = (ncol && kk < kv) ? (p.b_transposed ? p.B[(size_t)(n0 + bn) * p.ldb + kk] : p.B[(size_t)kk * p.ldb + n0 + bn])
+                                          : 0.f;
             }
         };
         auto stage = [&]() {

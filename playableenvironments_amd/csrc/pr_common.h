@@ -258,6 +258,7 @@ struct CompositeObject {
     const float* t;
     const float* sigma;
     const int32_t* slot;
+    const float* divergence;  // (N,R,P) Hutchinson divergence estimate, or NULL (zeros)
     const float* dispmag;   // or NULL
     const float* feat;      // compact rows
     const float* noise;     // integrate noise (N,R,P) or NULL
@@ -286,7 +287,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s);
     } while (0)
 
 struct SavedPlan {   // PR_FLAG_SAVE_FOR_BACKWARD: per object instance and model type
-    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta;
+    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta, div;
 };
 struct TypePlan {
     size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
@@ -302,6 +303,7 @@ struct Plan {
     size_t rec_pos, rec_flat;
     // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
     size_t h1, h2, row_flags, stats, stat_count, batch_stats;
+    size_t div_t0, div_ta, div_tb;   // divergence tangent scratch
     size_t bytes;
     int nblocks256;
 };
@@ -322,6 +324,8 @@ struct GemmNN {            // C[M x n] (+)= A[M x k] . B[k x n], then optionally
     int n, k;
     int accumulate;
     const float* mask; int ldm;
+    int b_transposed;      // B element (k, n) is read from B[n * ldb + k] (C = A . W^T for a row-major W)
+    int k_valid;           // rows of B beyond k_valid are zero (0 = all k rows exist)
 };
 int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s);
 
@@ -338,6 +342,23 @@ struct GemmTN {            // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += s
 };
 int launch_gemm_tn(const GemmTN& p, hipStream_t s);
 size_t gemm_tn_scratch_floats(int splits);
+
+// Hutchinson divergence estimate e^T (d delta / d x) e of the ray bender (object_composer.py:582-601) as a
+// forward-mode derivative through the saved bender activations; writes the dense (N,R,P) array `div`.
+struct DivergenceParams {
+    const int32_t* total; int max_rows;
+    const int32_t* rec_flat; const int32_t* row_flags; const float* rec_pos;
+    const float* noise;            // (N,R,P,3)
+    const float* bin; int bin_pad, benc, b_octaves;
+    const float* bacts; size_t bact_stride; int BW, BWpad, b_count, b_skip, bin_real;
+    const pr_linear_t* layers; pr_linear_t out_head;
+    const float* braw;
+    float lo[3], hi[3];
+    int canonical;
+    float* t0; float* ta; float* tb;   // scratch: (cap, bin_pad), (cap, BWpad) x 2
+    float* div;                    // (N,R,P), zero-initialised by the caller
+};
+int launch_divergence(const DivergenceParams& p, hipStream_t s);
 
 // Kernel timing (bench.py): records an event pair on `s` around a launch when profiling is on.
 struct ProfileScope {

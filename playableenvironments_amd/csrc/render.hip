@@ -108,6 +108,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     plan->block_offsets = take(sizeof(int32_t) * plan->nblocks256);
     size_t max_cap = 0;
     size_t feat_bytes[2] = {0, 0};
+    size_t div_t0 = 0, div_t = 0;   // divergence tangent scratch (shared by the bender objects)
     const int ntypes = c.use_fine ? 2 : 1;
     for (int t = 0; t < ntypes; ++t) {
         TypePlan& tp = plan->type[t];
@@ -139,6 +140,9 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
                 sv.batch = take(sizeof(float) * 4 * MAX_WIDTH);
                 sv.stat_count = take(sizeof(int32_t) * 4);
                 if (m.has_bender) {
+                    sv.div = take(sizeof(float) * cap);
+                    if (cap * d.bin_pad > div_t0) div_t0 = cap * d.bin_pad;
+                    if (cap * d.BWpad > div_t) div_t = cap * d.BWpad;
                     sv.bin = take(sizeof(float) * cap * d.bin_pad);
                     sv.bact = take(sizeof(float) * cap * d.BWpad * m.bender_count);
                     sv.braw = take(sizeof(float) * 3 * cap);
@@ -159,6 +163,11 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     // coarse and fine feature rows share one arena: the coarse rows are dead once the coarse
     // compositing pass has run, before the first fine MLP is launched.
+    if (div_t) {
+        plan->div_t0 = take(sizeof(float) * div_t0);
+        plan->div_ta = take(sizeof(float) * div_t);
+        plan->div_tb = take(sizeof(float) * div_t);
+    }
     if (c.flags & PR_FLAG_SAVE_FOR_BACKWARD) {
         // the backward pass needs the feature rows of both model types
         for (int t = 0; t < ntypes; ++t) {
@@ -345,6 +354,30 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 if (outs[t] && outs[t]->normalised_samples)
                     PR_CHECK_HIP(hipMemcpyAsync(outs[t]->normalised_samples + k, stat_count, sizeof(int32_t),
                                                 hipMemcpyDeviceToDevice, s));
+                if (save && m.has_bender) {
+                    // Hutchinson divergence of the displacement field (train mode with a graph; zeros without a probe)
+                    const size_t cap_rows = (size_t)c.frames * c.rays * P;
+                    float* div = reinterpret_cast<float*>(ws + sv.div);
+                    PR_CHECK_HIP(hipMemsetAsync(div, 0, sizeof(float) * cap_rows, s));
+                    if (noise.divergence[k]) {
+                        DivergenceParams dp;
+                        memset(&dp, 0, sizeof(dp));
+                        dp.total = totals + k; dp.max_rows = (int)cap_rows;
+                        dp.rec_flat = rec_flat; dp.row_flags = mp.row_flags; dp.rec_pos = rec_pos;
+                        dp.noise = noise.divergence[k];
+                        dp.bin = mp.save_bin; dp.bin_pad = d.bin_pad; dp.benc = d.benc; dp.b_octaves = m.bender_octaves;
+                        dp.bacts = mp.save_bact; dp.bact_stride = mp.save_bact_stride; dp.BW = d.BW; dp.BWpad = d.BWpad;
+                        dp.b_count = m.bender_count; dp.b_skip = m.bender_skip; dp.bin_real = d.bin;
+                        dp.layers = m.bender; dp.out_head = m.bender_out; dp.braw = mp.save_braw;
+                        bbox_split(m, dp.lo, dp.hi, nullptr);
+                        dp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+                        dp.t0 = reinterpret_cast<float*>(ws + plan.div_t0);
+                        dp.ta = reinterpret_cast<float*>(ws + plan.div_ta);
+                        dp.tb = reinterpret_cast<float*>(ws + plan.div_tb);
+                        dp.div = div;
+                        PR_TRY(launch_divergence(dp, s));
+                    }
+                }
             }
         }
 
@@ -369,6 +402,8 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             o.sigma = reinterpret_cast<const float*>(ws + tp.sigma[k]);
             o.slot = reinterpret_cast<const int32_t*>(ws + tp.slot[k]);
             o.dispmag = m.has_bender ? reinterpret_cast<const float*>(ws + tp.dispmag[k]) : nullptr;
+            o.divergence = ((c.flags & PR_FLAG_SAVE_FOR_BACKWARD) && m.has_bender)
+                               ? reinterpret_cast<const float*>(ws + tp.saved[k].div) : nullptr;
             o.feat = reinterpret_cast<const float*>(ws + tp.feat[k]);
             o.noise = noise.integrate[k];
             o.positions = m.positions;

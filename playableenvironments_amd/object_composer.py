@@ -307,8 +307,10 @@ class ObjectComposer(nn.Module):
         Autograd: with gradients enabled and the module in training mode the call is differentiable with
         respect to the parameters, ``style``, ``deformation`` and ``transformation_matrix_w2o`` through
         ``integrated_features``, ``opacity``, ``depth`` and ``integrated_displacements_magnitude`` of every
-        entry (pr_render_backward).  Not differentiated: the camera rays (dataset inputs in the reference's
-        trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (zeros)."""
+        entry (pr_render_backward).  ``integrated_divergence`` carries the Hutchinson estimate of the reference
+        (object_composer.py:582-601) in that mode.  Not differentiated: the camera rays (dataset inputs in the
+        reference's trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (its loss weight
+        is 0 in the shipped configurations; a second-order pass would be needed)."""
         K = self.object_id_helper.objects_count
         if transformation_matrix_w2o.size(-1) != K:
             raise Exception(f"Transformation matrix must specifies transformations for"
@@ -406,13 +408,21 @@ class ObjectComposer(nn.Module):
         types = ["coarse"] + (["fine"] if use_fine else [])
         ptot = {"coarse": pc, "fine": [a + b for a, b in zip(pc, pf)]}
         noise: Dict[str, torch.Tensor] = {}
+
+        def get(name, shape, normal):
+            if _noise is not None and _noise.get(name) is not None:
+                t = _noise[name].to(**f32).reshape(shape).contiguous()
+            else:
+                t = (torch.randn if normal else torch.rand)(shape, **f32)
+            noise[name] = t
+        if _save:
+            # Hutchinson probes of compute_approximate_divergence (object_composer.py:597): drawn whenever the
+            # reference trains with a graph, independent of `perturb`; only objects with a ray bender have a
+            # non-zero displacement field
+            for k in range(K):
+                if models_c[k].ray_bender.has_weights:
+                    get(f"div_coarse_{k}", (N, R, pc[k], 3), True)
         if perturb:
-            def get(name, shape, normal):
-                if _noise is not None and _noise.get(name) is not None:
-                    t = _noise[name].to(**f32).reshape(shape).contiguous()
-                else:
-                    t = (torch.randn if normal else torch.rand)(shape, **f32)
-                noise[name] = t
             for k in range(K):
                 get(f"jitter_{k}", (N, R, pc[k]), False)
                 get(f"alpha_{k}", (N, R, pc[k]), True)
@@ -454,6 +464,7 @@ class ObjectComposer(nn.Module):
                 call.noise_coarse.alpha[k] = sl(f"alpha_{k}")
                 call.noise_coarse.pdf[k] = sl(f"pdf_{k}")
                 call.noise_coarse.integrate[k] = sl(f"int_coarse_{k}")
+                call.noise_coarse.divergence[k] = sl(f"div_coarse_{k}")
                 call.noise_fine.integrate[k] = sl(f"int_fine_{k}")
             call.noise_coarse.integrate_global = sl("int_coarse_global")
             call.noise_fine.integrate_global = sl("int_fine_global")

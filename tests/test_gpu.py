@@ -385,10 +385,17 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False):
     _probe_loss(want, probes, K).backward()
     comp = comp.cuda()
     hip_in = [t.clone().cuda().requires_grad_(True) for t in (w2o, sty, dfm)]
-    got = comp(o.cuda(), d.cuda(), nrm.cuda(), *hip_in, ins.cuda(), perturb, canonical_pose=canonical,
-               _noise=rec if perturb else None)
+    got = comp(o.cuda(), d.cuda(), nrm.cuda(), *hip_in, ins.cuda(), perturb, canonical_pose=canonical, _noise=rec)
     _probe_loss(got, probes, K).backward()
     torch.cuda.synchronize()
+    # forward fields of the differentiable call, incl. the Hutchinson divergence (replayed probes)
+    rep = compare_results({"coarse": want["coarse"]}, {"coarse": got["coarse"]}, rtol=1e-3, atol=2e-4)
+    bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
+    assert not bad, bad
+    if not canonical:
+        a = want["coarse"]["global"]["integrated_divergence"].detach()
+        b = got["coarse"]["global"]["integrated_divergence"].detach().cpu()
+        assert float(a.abs().max()) > 1e-2 and float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 2e-4
     params = dict(comp.named_parameters())
     ref = {k: sd[k].grad for k in names}
     hip = {k: params[k].grad for k in names}
