@@ -202,7 +202,9 @@ int pr_render_forward(const pr_call_t* call, const pr_object_t* objects,
  * Backward pass of pr_render_forward (what torch.autograd does for the reference's op graph when
  * training/trainer_backpropagated_autoencoder.py:349 calls total_loss.backward()).  The forward call must
  * have run with PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD on the same `call`, `objects` and
- * `forward_workspace`, which must not have been touched since.  use_fine calls are not differentiable yet.
+ * `forward_workspace`, which must not have been touched since.  In hierarchical (use_fine) calls the resampled
+ * depths are constants (the reference detaches them, ray_helper.py:1340): the fine pass differentiates through the
+ * coarse depths it merged in and through the sample positions, the coarse pass through its own results only.
  *
  * Incoming gradients (d loss / d output field, same shapes as pr_entry_t; NULL = zero):
  */
@@ -244,11 +246,13 @@ typedef struct pr_input_grads_t {
     float* style;            /* (N,K,S)  accumulated; or NULL */
     float* deformation;      /* (N,K,D)  accumulated; or NULL */
     pr_model_grads_t model[PR_MAX_OBJECTS];   /* per object instance (coarse models) */
+    pr_model_grads_t model_fine[PR_MAX_OBJECTS]; /* fine models (use_fine calls only) */
 } pr_input_grads_t;
 
 int pr_backward_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes);
-int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads,
-                       const pr_input_grads_t* out, void* forward_workspace, size_t forward_workspace_bytes,
+int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads_coarse,
+                       const pr_output_grads_t* grads_fine /* NULL unless use_fine */, const pr_input_grads_t* out,
+                       void* forward_workspace, size_t forward_workspace_bytes,
                        void* backward_workspace, size_t backward_workspace_bytes, void* stream);
 
 /*

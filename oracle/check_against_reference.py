@@ -92,13 +92,16 @@ GRAD_FIELDS = ("integrated_features", "opacity", "depth", "integrated_displaceme
 
 
 def probe_loss(results, seed=7):
-    """A random linear functional of every differentiable result field (coarse pass)."""
+    """A random linear functional of every differentiable result field (coarse and fine passes)."""
     gen = torch.Generator().manual_seed(seed)
     total = 0.0
-    for name in sorted(results["coarse"].keys()):
-        for key in GRAD_FIELDS:
-            t = results["coarse"][name][key]
-            total = total + (t * torch.randn(t.shape, generator=gen)).sum()
+    for ty in ("coarse", "fine"):
+        if ty not in results:
+            continue
+        for name in sorted(results[ty].keys()):
+            for key in GRAD_FIELDS:
+                t = results[ty][name][key]
+                total = total + (t * torch.randn(t.shape, generator=gen)).sum()
     return total
 
 
@@ -221,6 +224,10 @@ def main():
                             grid_pixels(256, 256, 16), perturb=True, alpha_bias=2.0)
     ok &= run_gradient_case("minecraft reduced TRAIN gradients", configs.reduced_config(m, **small),
                             synthetic.minecraft_scene(), grid_pixels(256, 256, 16), perturb=True, alpha_bias=3.0)
+    hier = configs.reduced_config(configs.enable_fine(t), positions={"background": (8, 12), "background_backplate": (8, 12),
+                                                                     "player_1": (12, 20), "player_2": (12, 20)}, **small)
+    ok &= run_gradient_case("tennis reduced hierarchical TRAIN gradients", hier, synthetic.tennis_scene(seed=5),
+                            grid_pixels(256, 256, 14), perturb=True, alpha_bias=2.0)
     ok &= run_gradient_case("minecraft shipped TRAIN gradients", m, synthetic.minecraft_scene(seed=13),
                             grid_pixels(256, 256, 12), perturb=True, alpha_bias=3.0)
     ok &= check_samplers()

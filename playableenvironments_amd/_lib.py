@@ -120,7 +120,8 @@ class ModelGrads(C.Structure):
 
 
 class InputGrads(C.Structure):
-    _fields_ = [("w2o", C.c_void_p), ("style", C.c_void_p), ("deformation", C.c_void_p), ("model", ModelGrads * PR_MAX_OBJECTS)]
+    _fields_ = [("w2o", C.c_void_p), ("style", C.c_void_p), ("deformation", C.c_void_p), ("model", ModelGrads * PR_MAX_OBJECTS),
+                ("model_fine", ModelGrads * PR_MAX_OBJECTS)]
 
 
 # every exported symbol of include/playrender.h : (restype, argtypes)
@@ -131,8 +132,8 @@ SYMBOLS = {
     "pr_render_forward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(Outputs), C.POINTER(Outputs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "pr_backward_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
-    "pr_render_backward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(OutputGrads), C.POINTER(InputGrads),
-                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pr_render_backward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(OutputGrads), C.POINTER(OutputGrads),
+                                     C.POINTER(InputGrads), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pr_camera_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_profile_enable": (C.c_int, [C.c_int]),

@@ -705,6 +705,10 @@ struct GeometryBwd {
     const float* g_x;        // (cap,3) rows: d loss / d x (object frame), or NULL
     const float* g_in6;      // skybox: (cap,6) rows: d loss / d [o / size, d / |d|]
     float* d_w2o;            // (N,K,3,4)
+    // hierarchical pass: `positions` = Pc + Pf merged depths; the entries that are coarse depths (matched by value
+    // against t_coarse, both lists are sorted) carry the near / far dependence, the resampled ones are constants
+    const float* t_coarse;   // (N,R,Pc) or NULL (coarse pass)
+    int pc;
 };
 
 __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
@@ -745,6 +749,9 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
         float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, g_near = 0.f, g_far = 0.f;
         const int P = p.positions;
         const size_t base = (size_t)g * P;
+        const int Pc = p.t_coarse ? p.pc : P;
+        const size_t cbase = (size_t)g * Pc;
+        int jc = 0;   // next unmatched coarse depth (hierarchical pass)
         for (int i = 0; i < P; ++i) {
             float gt = p.g_t[base + i];
             const int row = p.slot[base + i];
@@ -768,12 +775,19 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
                 }
             }
             // t_i = near A_i + far B_i  (stratified_positions: linspace placement, optional jitter between midpoints)
-            const float s_i = p.linspace[i];
+            int ci = i;   // index of the coarse depth this sample is
+            if (p.t_coarse) {
+                const float ti = p.t[base + i];
+                while (jc < Pc && p.t_coarse[cbase + jc] < ti) ++jc;
+                if (jc < Pc && p.t_coarse[cbase + jc] == ti) ci = jc++;
+                else continue;   // resampled depth: detached (ray_helper.py:1340)
+            }
+            const float s_i = p.linspace[ci];
             float An = 1.0f - s_i, Bf = s_i;
             if (p.jitter) {
-                const float u = p.jitter[base + i];
-                const float s_lo = i > 0 ? 0.5f * (p.linspace[i - 1] + s_i) : s_i;
-                const float s_hi = i < P - 1 ? 0.5f * (p.linspace[i + 1] + s_i) : s_i;
+                const float u = p.jitter[cbase + ci];
+                const float s_lo = ci > 0 ? 0.5f * (p.linspace[ci - 1] + s_i) : s_i;
+                const float s_hi = ci < Pc - 1 ? 0.5f * (p.linspace[ci + 1] + s_i) : s_i;
                 Bf = s_lo + (s_hi - s_lo) * u;
                 An = 1.0f - Bf;
             }
@@ -842,7 +856,7 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     const size_t nr = (size_t)c.frames * c.rays;
     size_t max_cap = 0;
     for (int k = 0; k < c.objects; ++k) {
-        const pr_object_model_t& m = objs[k].coarse;
+        const pr_object_model_t& m = c.use_fine ? objs[k].fine : objs[k].coarse;   // the fine pass has more positions
         const size_t cap = nr * m.positions;
         if (cap > max_cap) max_cap = cap;
         bp->g_feat[k] = take(sizeof(float) * cap * m.output_features);
@@ -930,10 +944,12 @@ static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_
     return PR_OK;
 }
 
-static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output_grads_t& grads, const pr_input_grads_t& out,
+// backward of one model type (t = 0: coarse models / results["coarse"], 1: fine)
+static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
                     char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s) {
     const int K = c.objects;
-    const TypePlan& tp = plan.type[0];
+    const TypePlan& tp = plan.type[t];
+    const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
     int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
     const int F = objs[0].coarse.output_features;
     PR_REQUIRE(F % 16 == 0, "backward: output_features %d must be a multiple of 16", F);
@@ -945,14 +961,14 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
     cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
     int total_positions = 0;
     for (int k = 0; k < K; ++k) {
-        const pr_object_model_t& m = objs[k].coarse;
+        const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
         CompositeBwdObject& o = cp.obj[k];
         o.t = reinterpret_cast<const float*>(fws + tp.t[k]);
         o.sigma = reinterpret_cast<const float*>(fws + tp.sigma[k]);
         o.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
         o.dispmag = m.has_bender ? reinterpret_cast<const float*>(fws + tp.dispmag[k]) : nullptr;
         o.feat = reinterpret_cast<const float*>(fws + tp.feat[k]);
-        o.noise = c.noise_coarse.integrate[k];
+        o.noise = noise.integrate[k];
         o.positions = m.positions;
         o.g = grads.object[k];
         o.g_feat = reinterpret_cast<float*>(bws + bp.g_feat[k]);
@@ -966,7 +982,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
     while (ss < total_positions) ss <<= 1;
     cp.sort_size = ss;
     cp.ray_directions = c.ray_directions;
-    cp.noise_global = c.noise_coarse.integrate_global;
+    cp.noise_global = noise.integrate_global;
     cp.global = grads.global;
     PR_TRY(launch_composite_bwd(cp, s));
 
@@ -985,8 +1001,8 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
     float* tables = reinterpret_cast<float*>(bws + bp.tables);
 
     for (int k = 0; k < K; ++k) {
-        const pr_object_model_t& m = objs[k].coarse;
-        const pr_model_grads_t& G = out.model[k];
+        const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+        const pr_model_grads_t& G = t ? out.model_fine[k] : out.model[k];
         const SavedPlan& sv = tp.saved[k];
         ModelDims d;
         PR_TRY(compute_dims(m, &d));
@@ -1139,6 +1155,10 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, const pr_output
             gb.z_near_min = m.z_near_min; gb.z_far_max = m.z_far_max;
             gb.linspace = c.linspace_coarse[k];
             gb.jitter = c.noise_coarse.jitter[k];
+            if (t) {
+                gb.t_coarse = reinterpret_cast<const float*>(fws + plan.type[0].t[k]);
+                gb.pc = objs[k].coarse.positions;
+            }
             gb.t = reinterpret_cast<const float*>(fws + tp.t[k]);
             gb.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
             gb.g_t = g_t;
@@ -1158,10 +1178,11 @@ static int check_backward_call(const pr_call_t* call, const pr_object_t* objects
     PR_REQUIRE(call && objects, "NULL argument");
     PR_TRY(pr::validate_call(*call, objects));
     PR_REQUIRE(call->flags & PR_FLAG_SAVE_FOR_BACKWARD, "pr_render_backward: the forward call must set PR_FLAG_SAVE_FOR_BACKWARD");
-    PR_REQUIRE(!call->use_fine, "pr_render_backward: hierarchical (use_fine) calls are not differentiable yet");
     for (int k = 0; k < call->objects; ++k)
-        PR_REQUIRE(objects[k].coarse.skip_layer_idx > 0 && (!objects[k].coarse.has_bender || objects[k].coarse.bender_skip > 0),
-                   "pr_render_backward: skip_layer_idx 0 is not supported");
+        for (int t = 0; t < (call->use_fine ? 2 : 1); ++t) {
+            const pr_object_model_t& m = t ? objects[k].fine : objects[k].coarse;
+            PR_REQUIRE(m.skip_layer_idx > 0 && (!m.has_bender || m.bender_skip > 0), "pr_render_backward: skip_layer_idx 0 is not supported");
+        }
     return PR_OK;
 }
 
@@ -1175,10 +1196,12 @@ extern "C" int pr_backward_workspace_size(const pr_call_t* call, const pr_object
 }
 
 extern "C" int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads,
-                                  const pr_input_grads_t* out, void* forward_workspace, size_t forward_workspace_bytes,
-                                  void* backward_workspace, size_t backward_workspace_bytes, void* stream) {
+                                  const pr_output_grads_t* grads_fine, const pr_input_grads_t* out, void* forward_workspace,
+                                  size_t forward_workspace_bytes, void* backward_workspace, size_t backward_workspace_bytes,
+                                  void* stream) {
     PR_REQUIRE(grads && out && forward_workspace && backward_workspace, "pr_render_backward: NULL argument");
     PR_TRY(check_backward_call(call, objects));
+    PR_REQUIRE(!call->use_fine || grads_fine, "pr_render_backward: use_fine calls need grads_fine");
     pr::Plan plan;
     PR_TRY(pr::make_plan(*call, objects, &plan));
     pr::BwdPlan bp;
@@ -1189,8 +1212,12 @@ extern "C" int pr_render_backward(const pr_call_t* call, const pr_object_t* obje
         return PR_ERR_WORKSPACE;
     }
     PR_REQUIRE((((uintptr_t)forward_workspace | (uintptr_t)backward_workspace) & 255) == 0, "workspaces must be 256-byte aligned");
-    return pr::backward(*call, objects, *grads, *out, static_cast<char*>(forward_workspace), plan,
-                        static_cast<char*>(backward_workspace), bp, (hipStream_t)stream);
+    PR_TRY(pr::backward(*call, objects, 0, *grads, *out, static_cast<char*>(forward_workspace), plan,
+                        static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
+    if (call->use_fine)
+        PR_TRY(pr::backward(*call, objects, 1, *grads_fine, *out, static_cast<char*>(forward_workspace), plan,
+                            static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
+    return PR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

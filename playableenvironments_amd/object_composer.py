@@ -115,9 +115,10 @@ class _RenderFunction(torch.autograd.Function):
         dev = st["workspace"].device
         f32 = dict(dtype=torch.float32, device=dev)
         keep = []
-        og = _lib.OutputGrads()
+        ogs = {ty: _lib.OutputGrads() for ty in ("coarse", "fine")}
         i = 0
         for ty in st["types"]:
+            og = ogs[ty]
             for k in range(K + 1):
                 entry = og.object[k] if k < K else og.global_
                 for key in ENTRY_KEYS:
@@ -135,11 +136,15 @@ class _RenderFunction(torch.autograd.Function):
         ig.w2o, ig.style, ig.deformation = d_w2o.data_ptr(), d_style.data_ptr(), d_def.data_ptr()
         for k in range(K):
             ig.model[k] = composer._model_grad_struct(st["models"][k], grads)
+            if "fine" in st["types"]:
+                ig.model_fine[k] = composer._model_grad_struct(st["models_fine"][k], grads)
         size = C.c_size_t()
         _lib.check(lib.pr_backward_workspace_size(C.byref(st["call"]), st["objs"], C.byref(size)), "pr_backward_workspace_size")
         scratch = torch.empty(size.value, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.pr_render_backward(C.byref(st["call"]), st["objs"], C.byref(og), C.byref(ig), st["workspace"].data_ptr(),
+        _lib.check(lib.pr_render_backward(C.byref(st["call"]), st["objs"], C.byref(ogs["coarse"]),
+                                          C.byref(ogs["fine"]) if "fine" in st["types"] else None, C.byref(ig),
+                                          st["workspace"].data_ptr(),
                                           st["workspace"].numel(), scratch.data_ptr(), scratch.numel(), stream),
                    "pr_render_backward")
         lead = st["lead"]
@@ -399,9 +404,6 @@ class ObjectComposer(nn.Module):
             # running statistics updated in place (per replica, like the reference under DataParallel)
             flags |= _lib.PR_FLAG_TRAIN_BN
         if _save:
-            if use_fine:
-                raise NotImplementedError("hierarchical (use_fine) configurations are not differentiable yet; both "
-                                          "shipped configurations train with use_fine: False")
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
 
         # ---- noise -----------------------------------------------------------------------------
@@ -422,6 +424,8 @@ class ObjectComposer(nn.Module):
             for k in range(K):
                 if models_c[k].ray_bender.has_weights:
                     get(f"div_coarse_{k}", (N, R, pc[k], 3), True)
+                if use_fine and models_f[k].ray_bender.has_weights:
+                    get(f"div_fine_{k}", (N, R, pc[k] + pf[k], 3), True)
         if perturb:
             for k in range(K):
                 get(f"jitter_{k}", (N, R, pc[k]), False)
@@ -465,6 +469,7 @@ class ObjectComposer(nn.Module):
                 call.noise_coarse.pdf[k] = sl(f"pdf_{k}")
                 call.noise_coarse.integrate[k] = sl(f"int_coarse_{k}")
                 call.noise_coarse.divergence[k] = sl(f"div_coarse_{k}")
+                call.noise_fine.divergence[k] = sl(f"div_fine_{k}")
                 call.noise_fine.integrate[k] = sl(f"int_fine_{k}")
             call.noise_coarse.integrate_global = sl("int_coarse_global")
             call.noise_fine.integrate_global = sl("int_fine_global")
@@ -541,7 +546,8 @@ class ObjectComposer(nn.Module):
             pieces.append(outs)
             if _save:
                 state = dict(call=call, objs=objs, keep=keep + [origins, w2o, sty, dfm, present], workspace=workspace,
-                             N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, types=types, ptot=ptot)
+                             N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, models_fine=models_f, types=types,
+                             ptot=ptot)
 
         if self.training:
             # BatchNorm1d raises for a single value per channel (torch.nn.functional.batch_norm); the reference

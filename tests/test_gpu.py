@@ -335,9 +335,6 @@ def test_train_mode_guards():
     inputs = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=2), pixels=grid_pixels(256, 256, 8))]
     with pytest.raises(NotImplementedError):
         comp(*inputs, False)          # eval mode with gradients enabled: only the train-mode graph is differentiable
-    hier = build(configs.tennis_config(hierarchical=(8, 8))).cuda().train()
-    with pytest.raises(NotImplementedError):
-        hier(*inputs, False)          # use_fine is not differentiable yet
     comp.train()
     # a camera that sees nothing -> no evaluated sample -> torch's BatchNorm error, as in the reference
     scene = synthetic.tennis_scene(seed=2)
@@ -357,10 +354,13 @@ SMALL_NETS = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_wid
 
 def _probe_loss(results, probes, K):
     total = 0.0
-    for name in [f"object_{k}" for k in range(K)] + ["global"]:
-        for key in GRAD_KEYS:
-            t = results["coarse"][name][key]
-            total = total + (t * probes[(name, key)].to(t.device)).sum()
+    for ty in ("coarse", "fine"):
+        if ty not in results:
+            continue
+        for name in [f"object_{k}" for k in range(K)] + ["global"]:
+            for key in GRAD_KEYS:
+                t = results[ty][name][key]
+                total = total + (t * probes[(ty, name, key)].to(t.device)).sum()
     return total
 
 
@@ -380,7 +380,8 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False):
     want = ro.composer_forward(cfg, sd, o, d, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=True,
                                record_noise=rec, stable_merge=True)
     gen = torch.Generator().manual_seed(7)
-    probes = {(nm, key): torch.randn(want["coarse"][nm][key].shape, generator=gen)
+    probes = {(ty, nm, key): torch.randn(want[ty][nm][key].shape, generator=gen)
+              for ty in ("coarse", "fine") if ty in want
               for nm in [f"object_{k}" for k in range(K)] + ["global"] for key in GRAD_KEYS}
     _probe_loss(want, probes, K).backward()
     comp = comp.cuda()
@@ -389,7 +390,8 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False):
     _probe_loss(got, probes, K).backward()
     torch.cuda.synchronize()
     # forward fields of the differentiable call, incl. the Hutchinson divergence (replayed probes)
-    rep = compare_results({"coarse": want["coarse"]}, {"coarse": got["coarse"]}, rtol=1e-3, atol=2e-4)
+    fields = {ty: want[ty] for ty in ("coarse", "fine") if ty in want}
+    rep = compare_results(fields, {ty: got[ty] for ty in fields}, rtol=1e-3, atol=2e-4)
     bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
     assert not bad, bad
     if not canonical:
@@ -410,8 +412,12 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False):
     return out
 
 
+HIER_POSITIONS = {"background": (8, 12), "background_backplate": (8, 12), "player_1": (12, 20), "player_2": (12, 20)}
+
+
 @pytest.mark.parametrize("name,perturb", [("tennis", False), ("tennis", True), ("minecraft", False), ("minecraft", True),
-                                          ("tennis_frames", True)])
+                                          ("tennis_frames", True), ("tennis_hierarchical", False),
+                                          ("tennis_hierarchical", True)])
 def test_backward_matches_oracle_autograd(name, perturb):
     """Every parameter gradient, d style, d deformation and d transformation_matrix_w2o against torch.autograd
     through the oracle (train mode, replayed noise), on shallow networks where the comparison is well conditioned:
@@ -421,17 +427,25 @@ def test_backward_matches_oracle_autograd(name, perturb):
     elif name == "tennis_frames":
         cfg, scene, n, bias = (configs.reduced_config(configs.tennis_config(), **SMALL_NETS),
                                synthetic.tennis_scene(batch=2, observations=2, seed=3), 12, 2.0)
+    elif name == "tennis_hierarchical":
+        # coarse + fine models, resampled depths detached: gradients of both passes
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
     else:
         cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
     grads = _gradients(cfg, scene, n, bias, perturb)
     assert len(grads) > 50
+    # the fine pass places its samples by inverse-CDF resampling of the coarse weights, so fp32 round-off of the coarse
+    # pass moves fine samples: perturbing the resampling variates by 1e-6 moves the ORACLE's own gradients by 6e-5 and
+    # a 1e-6 relative weight perturbation by up to 6e-2 (a ReLU / AABB flip; measured) -> 1e-3 there, 1e-4 elsewhere
+    tol = 1e-3 if name == "tennis_hierarchical" else 1e-4
     bad = {}
     nonzero = 0
     for k, (a, b) in grads.items():
         scale = float(a.abs().max())
         nonzero += scale > 0
         err = float((a - b).abs().max())
-        if err > 1e-4 * scale + 1e-9:
+        if err > tol * scale + 1e-9:
             bad[k] = (err, scale)
     assert not bad, bad
     assert nonzero > 40
