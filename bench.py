@@ -62,7 +62,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
     model.train().to(dev)
     size = (288, 512)
-    scene = synthetic.minecraft_scene(batch=3, seed=77 + rank, image_size=size)
+    scene = synthetic.minecraft_scene(batch=3, seed=77, image_size=size)   # same frames on every rank: weak scaling
     sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
@@ -72,9 +72,18 @@ def train_step_leg(args, dev, world, rank, dist, lib):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(sc["camera_rotations"], sc["camera_translations"], sc["focals"], size, sc["object_rotation_parameters"],
-                    sc["object_translation_parameters"], sc["object_style"], sc["object_deformation"], sc["object_in_scene"],
-                    2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings")
+        for attempt in range(20):
+            try:
+                out = model(sc["camera_rotations"], sc["camera_translations"], sc["focals"], size,
+                            sc["object_rotation_parameters"], sc["object_translation_parameters"], sc["object_style"],
+                            sc["object_deformation"], sc["object_in_scene"], 2880, True, 0, patch_size=48,
+                            patch_stride=[4, 8], mode="scene_encodings")
+                break
+            except ValueError:
+                # a random patch that misses an object leaves its BatchNorm without samples: torch (and the reference)
+                # raise; a trainer would skip the batch - here the patch is re-drawn (before any collective)
+                if attempt == 19:
+                    raise
         loss = out["coarse"]["global"]["integrated_features"].square().mean()
         loss.backward()
         parallel.allreduce_gradients(params)
