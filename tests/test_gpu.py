@@ -364,7 +364,7 @@ def _probe_loss(results, probes, K):
     return total
 
 
-def _gradients(cfg, scene, n, bias, perturb, canonical=False):
+def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=()):
     """(oracle autograd, HIP backward) gradients of a random linear functional of every differentiable output."""
     comp = build(cfg, alpha_bias=bias).train()
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
@@ -385,6 +385,9 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False):
               for nm in [f"object_{k}" for k in range(K)] + ["global"] for key in GRAD_KEYS}
     _probe_loss(want, probes, K).backward()
     comp = comp.cuda()
+    for k, p in comp.named_parameters():
+        if any(f in k for f in frozen):
+            p.requires_grad_(False)
     hip_in = [t.clone().cuda().requires_grad_(True) for t in (w2o, sty, dfm)]
     got = comp(o.cuda(), d.cuda(), nrm.cuda(), *hip_in, ins.cuda(), perturb, canonical_pose=canonical, _noise=rec)
     _probe_loss(got, probes, K).backward()
@@ -468,6 +471,24 @@ def test_backward_full_size_networks():
         if not (cos > 0.999 and rel < 5e-2):
             bad[k] = (cos, rel, na)
     assert not bad, bad
+
+
+def test_backward_absent_object_and_frozen_parameters():
+    """An object that is absent from one frame contributes no samples there; frozen parameters get no gradient buffer
+    (NULL in pr_model_grads_t) while everything else still matches the oracle."""
+    cfg = configs.reduced_config(configs.tennis_config(), **SMALL_NETS)
+    scene = synthetic.tennis_scene(batch=2, seed=9)
+    scene["object_in_scene"][0, ..., 2] = False
+    grads = _gradients(cfg, scene, 12, 2.0, True, frozen=("object_models_coarse.1.", "ray_bender.backbone_layers.0"))
+    frozen = 0
+    for k, (a, b) in grads.items():
+        if "object_models_coarse.1." in k or "ray_bender.backbone_layers.0" in k:
+            assert float(b.abs().max()) == 0.0, k          # no gradient was produced for a frozen parameter
+            frozen += 1
+            continue
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
+    assert frozen > 10
 
 
 def test_backward_canonical_pose_and_unused_outputs():
