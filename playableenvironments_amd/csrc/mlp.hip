@@ -406,6 +406,21 @@ __device__ __forceinline__ void store_plain(const f32x16& acc, float* base) {
     for (int i = 0; i < 16; ++i) base[PR_ACC_ROW(i) * LDX] = acc[i];
 }
 
+#ifdef PR_MLP_TIMING
+// phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase
+__device__ unsigned long long g_mlp_phase[16];
+#define PR_PHASE_T0() unsigned long long _pt = __builtin_amdgcn_s_memtime()
+#define PR_PHASE(idx)                                                                      \
+    do {                                                                                   \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0) atomicAdd(&g_mlp_phase[idx], _n - _pt);                      \
+        _pt = _n;                                                                          \
+    } while (0)
+#else
+#define PR_PHASE_T0() do {} while (0)
+#define PR_PHASE(idx) do {} while (0)
+#endif
+
 // One layer on the tile.  All 512 threads call it (two workgroup barriers inside).
 #define PR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
 
@@ -427,6 +442,7 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         rb = wave / nblk;
         active = rb < 2;
     }
+    PR_PHASE_T0();
     f32x16 acc0, acc1;
     {
         const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
@@ -511,7 +527,9 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         }
     }
     if (p.debug & 4) return;  // ablation: no barriers, no epilogue
+    PR_PHASE(3);
     __syncthreads();  // every wave has finished reading X / E
+    PR_PHASE(4);
     if (active && !(p.debug & 8)) {
         const int col = cb * 32 + r;
         const int rowA = (both ? 0 : rb * 32) + 4 * half;   // first row of this lane in acc0
@@ -535,7 +553,9 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             if (both) store_plain(acc1, S.X + (rowA + 32) * LDX + col);
         }
     }
+    PR_PHASE(5);
     __syncthreads();
+    PR_PHASE(6);
 }
 
 // Positional encoding of every tile row into E (model/positional_encoder.py:54-64):
@@ -654,6 +674,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
     __syncthreads();
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
+        PR_PHASE_T0();
         if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
         if (tid < TILE_M) {
@@ -684,6 +705,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         }
         __syncthreads();
         if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;   // visible after the next barrier
+        PR_PHASE(0);
 
         // ---- ray bender -----------------------------------------------------------------------
         if (p.has_bender) {
@@ -733,9 +755,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             __syncthreads();
         }
 
+        PR_PHASE(1);
         // ---- positional encoding of the NeRF input --------------------------------------------
         fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
         __syncthreads();
+        PR_PHASE(2);
         if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false, S.E, LDE);
 
         // ---- backbone ---------------------------------------------------------------------------
@@ -747,6 +771,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             }
         }
 
+        PR_PHASE(15);
         // ---- sigma head -------------------------------------------------------------------------
         if (p.kind == 0) {
             float sg;
@@ -759,11 +784,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
         }
 
+        PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
         if (p.phase == 0) {
             for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
+            PR_PHASE(15);
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
             __syncthreads();   // the next tile's prologue overwrites flags / X
+            PR_PHASE(8);
         } else {
             // train mode, phase 1: stop after the first head matmul; the raw activations go to HBM and
             // their per-channel sums feed the batch statistics
@@ -994,6 +1022,16 @@ int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_mo
         hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
     }
     PR_LAUNCH_CHECK();
+#ifdef PR_MLP_TIMING
+    {
+        unsigned long long now[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(now, HIP_SYMBOL(g_mlp_phase), sizeof(now));
+        fprintf(stderr, "[mlp phases, cumulative Mticks of thread 0 summed over workgroups]");
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " p%d=%.1f", i, (double)now[i] * 1e-6);
+        fprintf(stderr, "\n");
+    }
+#endif
     return PR_OK;
 }
 
