@@ -162,6 +162,8 @@ typedef struct pr_outputs_t {
     int32_t* sample_slot[PR_MAX_OBJECTS];     /* (N,R,P_k) compact row of the sample, -1 = outside the box */
     int32_t* evaluated_samples;               /* (K) number of samples sent through the MLP */
     int32_t* normalised_samples;              /* (K) PR_FLAG_TRAIN_BN: samples that entered the batch statistics */
+    float* sample_delta[PR_MAX_OBJECTS];      /* (N,R,P_k,3) ray-bender displacement of every sample (zeros outside the
+                                                 box / without a bender), input of pr_expected_positions */
 } pr_outputs_t;
 
 typedef struct pr_call_t {
@@ -267,6 +269,16 @@ int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const 
 int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, int32_t per_frame_pixels,
                    const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols,
                    float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
+
+/*
+ * ObjectComposer.compute_expected_positions (model/object_composer.py:603-622) for object `object_index` of a call:
+ *   expected[n][r] = sum_i w_i (o + d t_i + delta_i) / (sum_i w_i + 1e-8)      (object frame)
+ * with o, d the w2o-transformed ray (RayHelper.transform_rays), t / weights (N,R,P) as produced by pr_render_forward
+ * (sample_t export, object entry weights) and delta (N,R,P,3) or NULL.  expected: (N,R,3).
+ */
+int pr_expected_positions(int32_t frames, int32_t rays, int32_t objects, int32_t object_index, int32_t positions,
+                          const float* ray_origins, const float* ray_directions, const float* w2o, const float* t,
+                          const float* weights, const float* delta, float* expected, void* stream);
 
 /*
  * Kernel timing for bench.py: while enabled, every launch of the fused MLP kernel (category 0) and

@@ -147,6 +147,28 @@ def run_gradient_case(name, config, scene, pixels, perturb, alpha_bias=0.0, seed
     return not bad
 
 
+def run_expected_positions_case(name, config, scene, pixels, object_id, perturb, alpha_bias=0.0, seed=0):
+    """Reference forward_expected_positions against the oracle (bitwise expected under a shared seed)."""
+    torch.manual_seed(seed)
+    ref = refshim.build_reference_composer(copy.deepcopy(config))
+    synthetic.randomize_module_state(ref, seed=seed, step=20000, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref.eval()
+    o, d, n, w2o, sty, dfm, ins = scene_to_composer_inputs(config, scene, None, pixels)
+    args = (o, d, n, w2o[..., object_id], sty[..., object_id], dfm[..., object_id], ins[..., object_id])   # singleton camera dim kept
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        torch.manual_seed(seed + 1)
+        want = ref.forward_expected_positions(*[a.clone() for a in args], object_id, perturb)
+        torch.manual_seed(seed + 1)
+        got = ro.expected_positions_forward(config, sd, *args, object_id, perturb)
+    worst = 0.0
+    for ty in want:
+        for a, b in zip(want[ty], got[ty]):
+            worst = max(worst, float((a - b).abs().max()))
+    print(f"[{name}] passes={list(want)} worst|diff|={worst:.3e}")
+    return worst == 0.0 and set(want) == set(got)
+
+
 def grid_pixels(h, w, n):
     r = torch.linspace(0, h - 1, n).long()
     c = torch.linspace(0, w - 1, n).long()
@@ -230,6 +252,14 @@ def main():
                             grid_pixels(256, 256, 14), perturb=True, alpha_bias=2.0)
     ok &= run_gradient_case("minecraft shipped TRAIN gradients", m, synthetic.minecraft_scene(seed=13),
                             grid_pixels(256, 256, 12), perturb=True, alpha_bias=3.0)
+    ok &= run_expected_positions_case("expected positions, tennis player_1", t, synthetic.tennis_scene(seed=17),
+                                      grid_pixels(256, 256, 24), 2, perturb=False, alpha_bias=2.0)
+    ok &= run_expected_positions_case("expected positions, tennis player_1, perturb", t, synthetic.tennis_scene(seed=17),
+                                      grid_pixels(256, 256, 24), 2, perturb=True, alpha_bias=2.0)
+    ok &= run_expected_positions_case("expected positions, hierarchical, perturb", th, synthetic.tennis_scene(seed=19),
+                                      grid_pixels(256, 256, 16), 3, perturb=True, alpha_bias=2.0)
+    ok &= run_expected_positions_case("expected positions, minecraft background", m, synthetic.minecraft_scene(seed=21),
+                                      grid_pixels(256, 256, 24), 0, perturb=False, alpha_bias=3.0)
     ok &= check_samplers()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1

@@ -644,6 +644,62 @@ def composer_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, r
 # EnvironmentModel-level orchestration (model/environment_model.py), scene-encoding mode
 # --------------------------------------------------------------------------------------------
 
+def expected_positions(positions: Tensor, displacements: Tensor, weights: Tensor, eps: float = 1e-8) -> Tensor:
+    """Weight-averaged bent sample position (the first surface a ray meets); the weights are detached.
+
+    model/object_composer.py:603-622."""
+    weights = weights.detach()
+    bent = positions + displacements
+    total = (bent * weights.unsqueeze(-1)).sum(dim=-2)
+    return total / (weights.unsqueeze(-1).sum(dim=-2) + eps)
+
+
+def expected_positions_forward(config: dict, sd: Dict[str, Tensor], ray_origins: Tensor, ray_directions: Tensor,
+                               focal_normals: Tensor, w2o: Tensor, style: Tensor, deformation: Tensor,
+                               object_in_scene: Tensor, object_id: int, perturb: bool, canonical_pose: bool = False,
+                               training: bool = False, noise: Optional[dict] = None,
+                               record_noise: Optional[dict] = None) -> dict:
+    """ObjectComposer.forward_expected_positions (model/object_composer.py:624-722): one object instance,
+    w2o (..., 4, 4), style (..., S), deformation (..., D), object_in_scene (...).  Returns
+    {"coarse": (expected positions (..., R, 3), opacity (..., R)) [, "fine": ...]}.  The sample distances use the
+    OBJECT-frame directions here and the coarse alpha noise feeds both the coarse weights and the resampler.
+    Noise keys: jitter, alpha, pdf, alpha_fine."""
+    layout = ObjectLayout(config)
+    m = layout.model_of_object[object_id]
+    mcfg = config["model"]["object_models"][m]
+    has_fine = mcfg.get("use_fine", True) is not False
+    noise = noise or {}
+    rec = record_noise if record_noise is not None else {}
+    bbox = _bbox_tensor(mcfg, ray_directions.device)
+    o, d, _ = transform_rays(ray_origins, ray_directions, focal_normals, w2o)
+    near, far = raywise_z_bounds(o, d, bbox, object_in_scene)
+    near = torch.clamp(near, min=mcfg["z_near_min"], max=mcfg["z_far_max"])
+    far = torch.clamp(far, min=mcfg["z_near_min"], max=mcfg["z_far_max"])
+    x, t, used = stratified_positions(o, d, near, far, mcfg["positions_count_coarse"], perturb, noise.get("jitter"))
+    rec["jitter"] = used
+    sty, dfm = style.unsqueeze(-2), deformation.unsqueeze(-2)
+    o_exp = o.unsqueeze(-2).expand(list(d.shape))
+    absent = torch.logical_not(object_in_scene)
+
+    def one_pass(prefix, positions, depths, key):
+        _, raw, disp = object_model_forward(sd, prefix, mcfg, positions, o_exp, d, sty, dfm, canonical_pose, training)
+        raw = raw.clone()
+        raw[absent] = mcfg["empty_space_alpha"]
+        alphas, used_alpha = alphas_from_raw(raw, position_distances(depths, d), perturb, noise.get(key))
+        rec[key] = used_alpha
+        weights = weights_from_alphas(alphas)
+        return expected_positions(positions, disp, weights), weights.sum(dim=-1), weights
+
+    exp_c, opacity_c, w_c = one_pass(f"object_models_coarse.{m}.", x, t, "alpha")
+    results = {"coarse": (exp_c, opacity_c)}
+    if has_fine:
+        xf, tf, used = hierarchical_positions(o, d, mcfg["positions_count_fine"], t, w_c, perturb, noise.get("pdf"))
+        rec["pdf"] = used
+        exp_f, opacity_f, _ = one_pass(f"object_models_fine.{m}.", xf, tf, "alpha_fine")
+        results["fine"] = (exp_f, opacity_f)
+    return results
+
+
 def merge_dictionaries(dicts: List[dict], dim: int) -> dict:
     """Recursive cat of result dicts; drops ``pytorch_hook``.  model/environment_model.py:523-545."""
     out = {}

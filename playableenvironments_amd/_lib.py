@@ -80,6 +80,7 @@ class Outputs(C.Structure):
         ("object", Entry * PR_MAX_OBJECTS), ("global_", Entry),
         ("sample_t", C.c_void_p * PR_MAX_OBJECTS), ("sample_sigma", C.c_void_p * PR_MAX_OBJECTS),
         ("sample_slot", C.c_void_p * PR_MAX_OBJECTS), ("evaluated_samples", C.c_void_p), ("normalised_samples", C.c_void_p),
+        ("sample_delta", C.c_void_p * PR_MAX_OBJECTS),
     ]
 
 
@@ -136,6 +137,8 @@ SYMBOLS = {
                                      C.POINTER(InputGrads), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pr_camera_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_expected_positions": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_profile_enable": (C.c_int, [C.c_int]),
     "pr_profile_collect": (C.c_int, [C.POINTER(C.c_double), c_int32_p]),
     "pr_probe_mfma_f32": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),

@@ -348,6 +348,31 @@ __global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size
     if (lane == 0 && count) atomicAdd(&p.block_sums[g >> 8], count);
 }
 
+// expected[n][r] = sum_i w_i (o + d t_i + delta_i) / (sum_i w_i + 1e-8), torch op order of
+// compute_expected_positions (object_composer.py:603-622): products first, then the sums over the samples
+__global__ __launch_bounds__(256) void k_expected_positions(int frames, int rays, int objects, int object_index, int P,
+                                                            const float* ray_origins, const float* ray_directions,
+                                                            const float* w2o, const float* t, const float* weights,
+                                                            const float* delta, float* expected) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (long)frames * rays) return;
+    const int n = (int)(g / rays);
+    const ObjRay ray = object_ray(w2o + ((size_t)n * objects + object_index) * 12, ray_origins + (size_t)n * 3,
+                                  ray_directions + (size_t)g * 3);
+    const size_t base = (size_t)g * P;
+    float acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+    for (int i = 0; i < P; ++i) {
+        const float ti = t[base + i], w = weights[base + i];
+        for (int a = 0; a < 3; ++a) {
+            float x = __fadd_rn(ray.o[a], __fmul_rn(ray.d[a], ti));
+            if (delta) x = __fadd_rn(x, delta[(base + i) * 3 + a]);
+            acc[a] = __fadd_rn(acc[a], __fmul_rn(x, w));
+        }
+        wsum = __fadd_rn(wsum, w);
+    }
+    for (int a = 0; a < 3; ++a) expected[(size_t)g * 3 + a] = __fdiv_rn(acc[a], __fadd_rn(wsum, 1e-8f));
+}
+
 static int next_pow2(int v) {
     int r = 1;
     while (r < v) r <<= 1;
@@ -373,6 +398,19 @@ int launch_resample(const ResampleParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+extern "C" int pr_expected_positions(int32_t frames, int32_t rays, int32_t objects, int32_t object_index, int32_t positions,
+                                     const float* ray_origins, const float* ray_directions, const float* w2o, const float* t,
+                                     const float* weights, const float* delta, float* expected, void* stream) {
+    PR_REQUIRE(frames > 0 && rays > 0 && positions > 0 && objects > 0 && object_index >= 0 && object_index < objects,
+               "pr_expected_positions: bad sizes");
+    PR_REQUIRE(ray_origins && ray_directions && w2o && t && weights && expected, "pr_expected_positions: NULL pointer");
+    const long total = (long)frames * rays;
+    hipLaunchKernelGGL(pr::k_expected_positions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, frames,
+                       rays, objects, object_index, positions, ray_origins, ray_directions, w2o, t, weights, delta, expected);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, int32_t per_frame_pixels,
                               const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols, float* ray_origins,
                               float* ray_directions, float* focal_normals, void* stream) {

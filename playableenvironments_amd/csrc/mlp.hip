@@ -748,6 +748,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                                                                __fmul_rn(d[2], d[2])));
                     if (p.save_delta)
                         for (int a = 0; a < 3; ++a) p.save_delta[(size_t)(tile_base + s) * 3 + a] = d[a];
+                    if (p.delta_dense)
+                        for (int a = 0; a < 3; ++a) p.delta_dense[(size_t)S.flat[s] * 3 + a] = d[a];
                     // second AABB test on the bent position (adain_style_nerf_model.py:173-184)
                     if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.flags[s] &= ~2;
                 }

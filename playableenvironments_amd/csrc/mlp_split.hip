@@ -363,6 +363,8 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
                     S.pos[s * 8 + a] = bent[a];
                 }
                 if (S.flags[s] & 1) {
+                    if (p.delta_dense)
+                        for (int a = 0; a < 3; ++a) p.delta_dense[(size_t)S.flat[s] * 3 + a] = d[a];
                     if (p.dispmag)
                         p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
                                                                __fmul_rn(d[2], d[2])));

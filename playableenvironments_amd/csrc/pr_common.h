@@ -154,6 +154,7 @@ struct MlpParams {
     size_t save_bact_stride;
     float* save_braw;            // (cap, 3) bender head output before * size and the clamp
     float* save_delta;           // (cap, 3) final displacement (after clamp / canonical_pose)
+    float* delta_dense;          // (N,R,P,3) the same, scattered to the sample grid (optional export)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL

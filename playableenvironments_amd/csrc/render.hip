@@ -296,6 +296,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             mp.deformation_stride = K * m.deformation_features;
             mp.adain = adain; mp.adain_stride = fo.row_floats;
             mp.sigma = sigma; mp.dispmag = dispmag; mp.feat = feat;
+            if (outs[t] && outs[t]->sample_delta[k]) {
+                PR_CHECK_HIP(hipMemsetAsync(outs[t]->sample_delta[k], 0, sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
+                if (m.has_bender) mp.delta_dense = outs[t]->sample_delta[k];
+            }
             const size_t cap = (size_t)c.frames * c.rays * P;
             const int max_tiles = (int)((cap + (naive ? 63 : TILE_M - 1)) / (naive ? 64 : TILE_M));
             if (!(c.flags & PR_FLAG_TRAIN_BN)) {

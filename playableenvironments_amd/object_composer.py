@@ -344,11 +344,14 @@ class ObjectComposer(nn.Module):
         return results
 
     def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False):
+                object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False, _object_ids=None):
         """The renderer call proper.  Returns (results, state); ``state`` (only with ``_save``) keeps what
-        pr_render_backward needs: the call structures, their tensors and the forward workspace."""
+        pr_render_backward needs: the call structures, their tensors and the forward workspace.
+        ``_object_ids``: render only these object instances (the tensors then carry ``len(_object_ids)`` objects);
+        used by forward_expected_positions."""
         helper = self.object_id_helper
-        K = helper.objects_count
+        ids = list(range(helper.objects_count)) if _object_ids is None else list(_object_ids)
+        K = len(ids)
 
         lead = list(ray_directions.shape[:-2])
         R = ray_directions.size(-2)
@@ -366,8 +369,8 @@ class ObjectComposer(nn.Module):
         dfm = torch.broadcast_to(deformation.detach().to(torch.float32), lead + [D, K]).reshape(N, D, K).permute(0, 2, 1).contiguous()
         present = torch.broadcast_to(object_in_scene, lead + [K]).reshape(N, K).to(torch.uint8).contiguous()
 
-        models_c = [self.object_models_coarse[helper.model_idx_by_object_idx(k)] for k in range(K)]
-        models_f = [self.object_models_fine[helper.model_idx_by_object_idx(k)] for k in range(K)]
+        models_c = [self.object_models_coarse[helper.model_idx_by_object_idx(k)] for k in ids]
+        models_f = [self.object_models_fine[helper.model_idx_by_object_idx(k)] for k in ids]
         # the reference iterates the result types of object 0 (object_composer.py:851)
         use_fine = models_f[0] is not None
         if use_fine and any(m is None for m in models_f):
@@ -395,7 +398,7 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_PERTURB
         if canonical_pose:
             flags |= _lib.PR_FLAG_CANONICAL_POSE
-        if self.config["model"]["fix_object_overlaps"]:
+        if self.config["model"]["fix_object_overlaps"] and _object_ids is None:
             flags |= _lib.PR_FLAG_FIX_OVERLAPS
         if self.use_naive_mlp:
             flags |= _lib.PR_FLAG_NAIVE_MLP
@@ -441,7 +444,7 @@ class ObjectComposer(nn.Module):
         def build_call(r0: int, r1: int):
             call = _lib.Call()
             call.frames, call.rays, call.objects = N, r1 - r0, K
-            call.static_objects = helper.static_objects_count
+            call.static_objects = helper.static_objects_count if _object_ids is None else 0
             call.use_fine = 1 if use_fine else 0
             call.flags = flags
             call.precision = self._precision_code()
@@ -526,8 +529,10 @@ class ObjectComposer(nn.Module):
                     res["_normalised"] = torch.zeros((K,), dtype=torch.int32, device=dev)
                     o.normalised_samples = res["_normalised"].data_ptr()
                 if _export:
-                    ex = {"t": [], "sigma": [], "slot": []}
+                    ex = {"t": [], "sigma": [], "slot": [], "delta": []}
                     for k in range(K):
+                        ex["delta"].append(torch.empty((N, rc, ptot[ty][k], 3), **f32))
+                        o.sample_delta[k] = ex["delta"][k].data_ptr()
                         ex["t"].append(torch.empty((N, rc, ptot[ty][k]), **f32))
                         ex["sigma"].append(torch.empty((N, rc, ptot[ty][k]), **f32))
                         ex["slot"].append(torch.empty((N, rc, ptot[ty][k]), dtype=torch.int32, device=dev))
@@ -575,6 +580,63 @@ class ObjectComposer(nn.Module):
                 results[ty]["_samples"] = [p[ty]["_samples"] for p in pieces]
         results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
         return results, (state if _save else None)
+
+    def forward_expected_positions(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor, focal_normals: torch.Tensor,
+                                   transformation_matrix_w2o: torch.Tensor, style: torch.Tensor, deformation: torch.Tensor,
+                                   object_in_scene: torch.Tensor, object_id: int, perturb: bool,
+                                   video_indexes: torch.Tensor = None, canonical_pose: bool = False,
+                                   _noise: Optional[dict] = None) -> Dict:
+        """model/object_composer.py:624-722: the weight-averaged bent surface point of ONE object instance.
+
+        transformation_matrix_w2o (..., 4, 4); style (..., S); deformation (..., D); object_in_scene (...).
+        Returns {"coarse": (expected positions (..., R, 3), opacity (..., R)) [, "fine": (...)]} in the object frame.
+        The renderer runs with this single object (pr_render_forward), pr_expected_positions forms the average.  Forward
+        only (the pose / keypoint consistency losses that consume it have weight 0 in the shipped configurations);
+        ``_noise`` keys: jitter, alpha, pdf, alpha_fine (oracle/render_oracle.py:expected_positions_forward)."""
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (transformation_matrix_w2o, style, deformation)):
+            raise NotImplementedError("forward_expected_positions has no backward: call it under torch.no_grad()")
+        if not ray_directions.is_cuda:
+            raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+        noise = None
+        if _noise is not None:
+            # one alpha draw feeds both the coarse weights and the resampler (object_composer.py:683-684, :697)
+            noise = {"jitter_0": _noise.get("jitter"), "alpha_0": _noise.get("alpha"), "int_coarse_0": _noise.get("alpha"),
+                     "pdf_0": _noise.get("pdf"), "int_fine_0": _noise.get("alpha_fine")}
+        elif perturb:
+            lead = list(ray_directions.shape[:-2])
+            model = self.object_models_coarse[self.object_id_helper.model_idx_by_object_idx(object_id)]
+            shape = lead + [ray_directions.size(-2), model.model_config["positions_count_coarse"]]
+            shared = torch.randn(shape, dtype=torch.float32, device=ray_directions.device)
+            noise = {"alpha_0": shared, "int_coarse_0": shared}
+        with torch.no_grad():
+            results, _ = self._render(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o.unsqueeze(-1),
+                                      style.unsqueeze(-1), deformation.unsqueeze(-1), object_in_scene.unsqueeze(-1), perturb,
+                                      canonical_pose, noise, True, False, _object_ids=[object_id])
+            lib = _lib.load()
+            dev = ray_directions.device
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            lead = list(ray_directions.shape[:-2])
+            R = ray_directions.size(-2)
+            N = int(math.prod(lead)) if lead else 1
+            dirs = ray_directions.to(torch.float32).reshape(N, R, 3).contiguous()
+            origins = torch.broadcast_to(ray_origins.to(torch.float32), lead + [3]).reshape(N, 3).contiguous()
+            w2o = torch.broadcast_to(transformation_matrix_w2o.to(torch.float32), lead + [4, 4]).reshape(N, 1, 4, 4)[:, :, :3, :].contiguous()
+            out = {}
+            for ty in ("coarse", "fine"):
+                if ty not in results:
+                    continue
+                pieces = results[ty]["_samples"]
+                t = pieces[0]["t"][0] if len(pieces) == 1 else torch.cat([p["t"][0] for p in pieces], dim=1)
+                delta = pieces[0]["delta"][0] if len(pieces) == 1 else torch.cat([p["delta"][0] for p in pieces], dim=1)
+                entry = results[ty]["object_0"]
+                weights = entry["weights"].reshape(N, R, -1).contiguous()
+                expected = torch.empty((N, R, 3), dtype=torch.float32, device=dev)
+                _lib.check(lib.pr_expected_positions(N, R, 1, 0, weights.size(-1), origins.data_ptr(), dirs.data_ptr(),
+                                                     w2o.data_ptr(), t.contiguous().data_ptr(), weights.data_ptr(),
+                                                     delta.contiguous().data_ptr(), expected.data_ptr(), stream),
+                           "pr_expected_positions")
+                out[ty] = (expected.reshape(lead + [R, 3]), entry["opacity"])
+        return out
 
     # ------------------------------------------------------------------ backward marshalling
     def _model_grad_struct(self, model: RayBendingStyleNerfModel, grads: Dict[int, torch.Tensor]) -> _lib.ModelGrads:

@@ -576,3 +576,39 @@ def test_environment_model_training_step_gradients_reach_the_poses():
         assert float(a.abs().max()) > 0
         # the pose matrices are built on the GPU here (ulp-level differences feed discontinuous AABB decisions)
         assert float((a - b).norm()) <= 2e-2 * float(a.norm()), (k, float((a - b).norm()), float(a.norm()))
+
+
+@pytest.mark.parametrize("case", ["tennis_player", "tennis_player_perturb", "hierarchical_perturb", "minecraft_background",
+                                  "minecraft_player_canonical"])
+def test_forward_expected_positions_matches_oracle(case):
+    """ObjectComposer.forward_expected_positions (object_composer.py:624-722) for one object instance: expected bent
+    surface point and opacity per ray against the oracle (pinned bitwise against the reference), replayed noise."""
+    perturb = case.endswith("perturb")
+    canonical = case.endswith("canonical")
+    if case.startswith("hierarchical"):
+        cfg, scene, obj, bias = configs.tennis_config(hierarchical=(16, 32)), synthetic.tennis_scene(seed=19), 3, 2.0
+    elif case.startswith("minecraft"):
+        cfg, scene, bias = configs.minecraft_config(), synthetic.minecraft_scene(seed=21), 3.0
+        obj = 0 if "background" in case else 2
+    else:
+        cfg, scene, obj, bias = configs.tennis_config(), synthetic.tennis_scene(seed=17), 2, 2.0
+    comp = build(cfg, alpha_bias=bias)
+    o, d, n, w2o, sty, dfm, ins = composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 20))
+    args = (o, d, n, w2o[..., obj], sty[..., obj], dfm[..., obj], ins[..., obj])
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+    rec = {}
+    with torch.no_grad():
+        torch.manual_seed(11)
+        want = ro.expected_positions_forward(cfg, sd, *args, obj, perturb, canonical_pose=canonical, record_noise=rec)
+        comp = comp.cuda()
+        got = comp.forward_expected_positions(*[a.cuda() for a in args], obj, perturb, canonical_pose=canonical,
+                                              _noise=rec if perturb else None)
+    torch.cuda.synchronize()
+    assert set(got) == set(want)
+    for ty in want:
+        for a, b, what in zip(want[ty], got[ty], ("expected_positions", "opacity")):
+            b = b.cpu()
+            assert a.shape == b.shape
+            assert torch.allclose(a, b, rtol=RTOL, atol=1e-4 if what == "expected_positions" else ATOL), \
+                (ty, what, float((a - b).abs().max()))
+        assert float(want[ty][1].max()) > 0.1   # the object is actually hit
