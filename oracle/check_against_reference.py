@@ -169,6 +169,56 @@ def run_expected_positions_case(name, config, scene, pixels, object_id, perturb,
     return worst == 0.0 and set(want) == set(got)
 
 
+def check_wire_format():
+    """playableenvironments_amd.wire_format against the reference's renderer <-> decoder glue (exact equality)."""
+    from utils.lib_3d.ray_helper import RayHelper
+    from model.environment_model_backpropagated_autoencoder import EnvironmentModelBackpropagatedAutoencoder as RefAE
+    from model.environment_model_multiresolution_backpropagated_autoencoder import \
+        EnvironmentModelMultiresolutionBackpropagatedAutoencoder as RefMulti
+    from playableenvironments_amd import wire_format as wf
+    torch.manual_seed(0)
+    ok = True
+    h, w, strides = 32, 48, [4, 8]
+    total = sum(h // s * w // s for s in strides)
+    x = torch.randn(2, 3, total, 5)
+    a, b = RayHelper.fold_strided_grid_samples(x, strides, (h, w), dim=2), wf.fold_strided_grid_samples(x, strides, (h, w), dim=2)
+    ok &= all(torch.equal(p, q) for p, q in zip(a, b)) and len(a) == len(b)
+    d1 = {"u": {"v": torch.randn(2, total, 7), "k": torch.randn(3)}, "w": torch.randn(total)}
+    d2 = {"u": {"v": d1["u"]["v"].clone(), "k": d1["u"]["k"].clone()}, "w": d1["w"].clone()}
+    folder = type("Folder", (), {"fold_strided_tensors": RefAE.fold_strided_tensors})()
+    r1 = folder.fold_strided_tensors(d1, h, w, strides)
+    r2 = wf.fold_strided_tensors(d2, h, w, strides)
+    ok &= all(torch.equal(p, q) for p, q in zip(r1["u"]["v"], r2["u"]["v"])) and torch.equal(r1["u"]["k"], r2["u"]["k"])
+    ok &= all(torch.equal(p, q) for p, q in zip(r1["w"], r2["w"]))
+    patch, ps = 12, [4, 8]
+    samples = torch.randn(2, 3, patch * patch + (patch // 2) ** 2, 192)
+    a, b = RayHelper.split_strided_patch_ray_samples(samples, patch, ps), wf.split_strided_patch_ray_samples(samples, patch, ps)
+    ok &= all(torch.equal(p, q) for p, q in zip(a, b))
+    ok &= torch.equal(RayHelper.strided_patch_ray_samples_to_patch(a[0]), wf.strided_patch_ray_samples_to_patch(b[0]))
+
+    class _AE:
+        def get_features_count_by_layer(self):
+            return [64, 128]
+    holder = type("H", (), {"autoencoder_model": _AE()})()
+    for order, t in (("hwc", samples), ("chw", torch.randn(2, 192, 6, 5))):
+        a = RefMulti.split_features_by_layer(holder, t, channel_order=order)
+        b = wf.split_features_by_layer(t, [64, 128], channel_order=order)
+        ok &= all(torch.equal(p, q) for p, q in zip(a, b))
+    feats = torch.randn(2, 3, 7, 20, 28)
+    pos = torch.rand(2, 3, 50, 2)
+    ok &= torch.equal(RayHelper.sample_features_at(feats, pos, original_image_size=(20, 28)),
+                      wf.sample_features_at(feats, pos, original_image_size=(20, 28)))
+    obs = torch.randn(2, 3, 64, 96)
+    rows = (torch.arange(6) * 4 + 2 + 8).float() / 64
+    cols = (torch.arange(6) * 4 + 2 + 16).float() / 96
+    rr, cc = torch.meshgrid(rows, cols, indexing="ij")
+    ppos = torch.stack([rr.reshape(-1), cc.reshape(-1)], -1).unsqueeze(0).repeat(2, 1, 1)
+    ok &= torch.equal(RayHelper.sample_original_region_from_patch_samples(obs, ppos, 4),
+                      wf.sample_original_region_from_patch_samples(obs, ppos, 4))
+    print(f"[wire format: fold / split / patch / layer split / grid samplers] identical: {ok}")
+    return ok
+
+
 def grid_pixels(h, w, n):
     r = torch.linspace(0, h - 1, n).long()
     c = torch.linspace(0, w - 1, n).long()
@@ -261,6 +311,7 @@ def main():
     ok &= run_expected_positions_case("expected positions, minecraft background", m, synthetic.minecraft_scene(seed=21),
                                       grid_pixels(256, 256, 24), 0, perturb=False, alpha_bias=3.0)
     ok &= check_samplers()
+    ok &= check_wire_format()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

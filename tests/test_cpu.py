@@ -415,3 +415,47 @@ def test_oracle_autograd_reproduces_reference_gradients(path):
     for k, a in grads.items():
         b = mine[k] if mine[k] is not None else torch.zeros_like(a)
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, k
+
+
+# --------------------------------------------------------------------------------------------
+# renderer <-> decoder wire format (next row f-1): closed-form checks (the reference comparison runs in
+# oracle/check_against_reference.py, exact equality)
+# --------------------------------------------------------------------------------------------
+def test_wire_format_folds_and_patches():
+    from playableenvironments_amd import wire_format as wf
+    h, w, strides = 16, 24, [4, 8]
+    rows, cols = strided_grid_pixels(h, w, strides)
+    image = torch.arange(h * w, dtype=torch.float32).reshape(h, w)
+    rays = image[rows.long(), cols.long()].reshape(1, -1, 1)          # one value per ray, strided-grid order
+    folded = wf.fold_strided_grid_samples(rays, strides, (h, w), dim=1)
+    assert [tuple(f.shape) for f in folded] == [(1, 4, 6, 1), (1, 2, 3, 1)]
+    for f, s in zip(folded, strides):
+        assert torch.equal(f[0, ..., 0], image[s // 2::s, s // 2::s])
+    d = wf.fold_strided_tensors({"a": {"b": rays.clone()}, "c": torch.zeros(5)}, h, w, strides)
+    assert isinstance(d["a"]["b"], list) and torch.equal(d["a"]["b"][1], folded[1]) and torch.is_tensor(d["c"])
+    with pytest.raises(Exception):
+        wf.fold_strided_grid_samples(rays, [5], (h, w), dim=1)
+    # strided patch: 8x8 @ stride 4 and 4x4 @ stride 8, 192 channels -> decoder inputs [64 @ /4, 128 @ /8]
+    feats = torch.randn(2, 8 * 8 + 4 * 4, 192)
+    splitted, patches = wf.decoder_patches(feats, 8, [4, 8], [64, 128])
+    assert [tuple(p.shape) for p in patches] == [(2, 64, 8, 8), (2, 128, 4, 4)]
+    assert torch.equal(patches[0][1, 5, 2, 3], feats[1, 2 * 8 + 3, 5])
+    assert torch.equal(patches[1][0, 7, 1, 2], feats[0, 64 + 1 * 4 + 2, 64 + 7])
+    assert torch.equal(splitted[1], feats[:, 64:, 64:])
+
+
+def test_wire_format_grid_samplers():
+    from playableenvironments_amd import wire_format as wf
+    feats = torch.randn(2, 5, 12, 20)
+    r = torch.tensor([0, 3, 11, 7])
+    c = torch.tensor([0, 19, 4, 10])
+    pos = torch.stack([r.float() / 12, c.float() / 20], -1).unsqueeze(0).repeat(2, 1, 1)
+    got = wf.sample_features_at(feats, pos, original_image_size=(12, 20))
+    assert torch.allclose(got, feats[:, :, r, c].permute(0, 2, 1), atol=1e-5)        # pixel centres are hit exactly
+    obs = torch.randn(1, 3, 32, 48)
+    rows = (torch.arange(4) * 4 + 2 + 8).float() / 32
+    cols = (torch.arange(4) * 4 + 2 + 12).float() / 48
+    rr, cc = torch.meshgrid(rows, cols, indexing="ij")
+    ppos = torch.stack([rr.reshape(-1), cc.reshape(-1)], -1).unsqueeze(0)
+    region = wf.sample_original_region_from_patch_samples(obs, ppos, 4)
+    assert torch.equal(region, obs[:, :, 8:24, 12:28])
