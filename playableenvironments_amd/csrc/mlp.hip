@@ -125,6 +125,7 @@ constexpr int MAX_PACK_JOBS = 56;
 struct PackJobs {
     PackJob job[MAX_PACK_JOBS];
     int n;
+    int seg_kind;   // kind of the weight-segment jobs: 0 = fp32 fragments, 2 = fp16 hi / lo fragment pairs
 };
 
 __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
@@ -173,14 +174,13 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
     }
 }
 
-static int g_pack_kind = 0;  // set by pr_pack_model for the duration of build_pack_jobs (0 exact, 2 split)
 static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
     PR_REQUIRE(js->n < MAX_PACK_JOBS, "too many pack jobs");
     PR_REQUIRE(lin.weight != nullptr, "missing weight pointer");
     PackJob& j = js->job[js->n++];
     j.src = lin.weight;
     j.dst = dst;
-    j.kind = g_pack_kind;
+    j.kind = js->seg_kind;
     j.in_total = lin.in_features;
     j.col_off = col_off;
     j.k_real = k_real;
@@ -1227,10 +1227,8 @@ extern "C" int pr_pack_model(const pr_object_model_t* model, int32_t precision, 
     PR_REQUIRE(packed_bytes >= (size_t)l.total * sizeof(float), "pr_pack_model: buffer too small (%zu < %zu)",
                packed_bytes, (size_t)l.total * sizeof(float));
     pr::PackJobs jobs;
-    pr::g_pack_kind = precision ? 2 : 0;
-    const int build_status = pr::build_pack_jobs(*model, d, l, static_cast<float*>(packed), &jobs);
-    pr::g_pack_kind = 0;
-    PR_TRY(build_status);
+    jobs.seg_kind = precision ? 2 : 0;   // fragment layout of the weight segments: exact fp32 or fp16 hi / lo pairs
+    PR_TRY(pr::build_pack_jobs(*model, d, l, static_cast<float*>(packed), &jobs));
     hipLaunchKernelGGL(pr::k_pack, dim3(64, jobs.n), dim3(256), 0, (hipStream_t)stream, jobs);
     PR_LAUNCH_CHECK();
     return PR_OK;
