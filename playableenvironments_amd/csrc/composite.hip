@@ -62,8 +62,10 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     sm.wo = sm.dm + A;
     sm.wg = sm.wo + A;
     sm.al = sm.wg + A;
-    sm.dv = sm.al + A;
-    sm.sl = reinterpret_cast<int*>(sm.dv + A);
+    // the divergence column exists only in differentiable training calls (keeps the eval footprint at 7 arrays)
+    const bool use_div = p.any_divergence != 0;
+    sm.dv = use_div ? sm.al + A : nullptr;
+    sm.sl = reinterpret_cast<int*>(sm.al + (use_div ? 2 * A : A));
 
     const int lane = threadIdx.x;
     const long g = blockIdx.x;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             sm.sg[off + i] = o.sigma[base + i];
             sm.sl[off + i] = o.slot[base + i];
             sm.dm[off + i] = o.dispmag ? o.dispmag[base + i] : 0.f;
-            sm.dv[off + i] = o.divergence ? fabsf(o.divergence[base + i]) : 0.f;
+            if (use_div) sm.dv[off + i] = o.divergence ? fabsf(o.divergence[base + i]) : 0.f;
         }
         __syncthreads();
         float adiv = 0.f;   // sum alpha |div|  (object_composer.py:768-769, alphas detached)
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             float raw = sm.sg[off + i];
             if (o.noise) raw = __fadd_rn(raw, o.noise[base + i]);
             sm.al[i] = alpha_of(raw, __fmul_rn(dt, norm));
-            adiv += sm.al[i] * sm.dv[off + i];
+            if (use_div) adiv += sm.al[i] * sm.dv[off + i];
         }
         adiv = wave_sum(adiv);
         __syncthreads();
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
                     sm.tt[soff + i] = 0.f;
                     sm.sg[soff + i] = -10.0f;
                     sm.dm[soff + i] = 0.f;
-                    sm.dv[soff + i] = 0.f;
+                    if (use_div) sm.dv[soff + i] = 0.f;
                 }
             }
             __syncthreads();
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         float raw = sm.sg[e];
         if (p.noise_global) raw = __fadd_rn(raw, p.noise_global[gbase + j]);
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
-        gdiv += sm.al[j] * sm.dv[e];
+        if (use_div) gdiv += sm.al[j] * sm.dv[e];
     }
     gdiv = wave_sum(gdiv);
     __syncthreads();
@@ -330,7 +332,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
     PR_REQUIRE(p.sort_size >= p.total_positions && (p.sort_size & (p.sort_size - 1)) == 0, "bad sort size");
     for (int k = 0; k < p.objects; ++k)
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
-    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 8 * 4;
+    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 8 : 7) * 4;
     PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
     static bool attr_set = false;
     if (!attr_set) {

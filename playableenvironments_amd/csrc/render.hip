@@ -408,6 +408,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             o.dispmag = m.has_bender ? reinterpret_cast<const float*>(ws + tp.dispmag[k]) : nullptr;
             o.divergence = ((c.flags & PR_FLAG_SAVE_FOR_BACKWARD) && m.has_bender)
                                ? reinterpret_cast<const float*>(ws + tp.saved[k].div) : nullptr;
+            if (o.divergence) cp.any_divergence = 1;
             o.feat = reinterpret_cast<const float*>(ws + tp.feat[k]);
             o.noise = noise.integrate[k];
             o.positions = m.positions;
