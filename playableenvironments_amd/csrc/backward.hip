@@ -262,24 +262,10 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
         }
     }
     // ---- merged list ---------------------------------------------------------------------------------
-    for (int e = lane; e < S; e += 64)
-        sm.key[e] = (e < PT) ? (((unsigned long long)float_order_bits(sm.tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
-    __syncthreads();
-    for (int kk = 2; kk <= S; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < S; i += 64) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const unsigned long long a = sm.key[i], b = sm.key[x];
-                    const bool up = ((i & kk) == 0);
-                    if ((a > b) == up) {
-                        sm.key[i] = b;
-                        sm.key[x] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    {
+        int counts[PR_MAX_OBJECTS];
+        for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane);
     }
     entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
 

@@ -169,27 +169,11 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         }
     }
 
-    // ---- merge: sort (t, concatenation index) ----------------------------------------------------
-    for (int e = lane; e < S; e += 64) {
-        sm.key[e] = (e < PT) ? (((unsigned long long)float_order_bits(sm.tt[e]) << 32) | (unsigned int)e)
-                             : 0xFFFFFFFFFFFFFFFFull;
-    }
-    __syncthreads();
-    for (int kk = 2; kk <= S; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < S; i += 64) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const unsigned long long a = sm.key[i], b = sm.key[x];
-                    const bool up = ((i & kk) == 0);
-                    if ((a > b) == up) {
-                        sm.key[i] = b;
-                        sm.key[x] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    // ---- merge: order by (t, concatenation index) ------------------------------------------------
+    {
+        int counts[PR_MAX_OBJECTS];
+        for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane);
     }
 
     // ---- global alphas / weights in sorted order -------------------------------------------------

@@ -28,4 +28,74 @@ __device__ __forceinline__ float disparity_of(float depth, float opacity) {
     return __fdiv_rn(1.0f, q);
 }
 
+// Orders the concatenated per-object lists by (t, concatenation index) into key[0 .. total): key[rank] =
+// (order bits of t << 32) | entry.  Each object's list is normally already sorted (linspace placement, or the
+// output of the resampler's sort), so the rank of an entry is its own index plus, for every other object, the
+// number of entries that precede it - two binary searches per other object instead of a bitonic network over
+// all entries.  Falls back to the bitonic sort when a list is not non-decreasing (overlap-fixed lists, or depths
+// whose spacing is below one ulp).  One 64-lane workgroup; `sort_size` = power of two >= total.
+__device__ __forceinline__ void order_entries(unsigned long long* key, const float* tt, const int* positions, int objects,
+                                              int total, int sort_size, bool lists_may_be_sorted, int lane) {
+    bool merge = lists_may_be_sorted;
+    if (merge) {
+        bool ok = true;
+        int off = 0;
+        for (int k = 0; k < objects; ++k) {
+            const int P = positions[k];
+            for (int i = lane; i + 1 < P; i += 64) ok = ok && (tt[off + i] <= tt[off + i + 1]);
+            off += P;
+        }
+        merge = __ballot(ok) == ~0ull;
+    }
+    if (merge) {
+        int off = 0;
+        for (int k = 0; k < objects; ++k) {
+            const int P = positions[k];
+            for (int i = lane; i < P; i += 64) {
+                const float t = tt[off + i];
+                int rank = i;
+                int o2 = 0;
+                for (int k2 = 0; k2 < objects; ++k2) {
+                    const int P2 = positions[k2];
+                    if (k2 != k) {
+                        // entries of an earlier object win ties (stable in object order)
+                        int lo = 0, hi = P2;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            const float v = tt[o2 + mid];
+                            const bool before = (k2 < k) ? (v <= t) : (v < t);
+                            if (before) lo = mid + 1; else hi = mid;
+                        }
+                        rank += lo;
+                    }
+                    o2 += P2;
+                }
+                key[rank] = ((unsigned long long)float_order_bits(t) << 32) | (unsigned int)(off + i);
+            }
+            off += P;
+        }
+        __syncthreads();
+        return;
+    }
+    for (int e = lane; e < sort_size; e += 64)
+        key[e] = (e < total) ? (((unsigned long long)float_order_bits(tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
+    for (int kk = 2; kk <= sort_size; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < sort_size; i += 64) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned long long a = key[i], b = key[x];
+                    const bool up = ((i & kk) == 0);
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace pr
