@@ -221,6 +221,61 @@ def test_packed_and_workspace_sizes_on_host(built_library):
     assert b"empty call" in built_library.pr_last_error()
 
 
+def test_abi_error_paths_without_a_device(built_library):
+    """Status codes and messages of the host-side validation (no device work happens before it)."""
+    lib = built_library
+    cfg = configs.tennis_config()
+    _, s = _model_struct_host(cfg["model"]["object_models"][2], 32)
+    call = _lib.Call()
+    call.frames, call.rays, call.objects = 1, 64, 1
+    for f in ("ray_origins", "ray_directions", "w2o", "style", "deformation", "object_in_scene"):
+        setattr(call, f, 256)
+    call.linspace_coarse[0] = 256
+    objs = (_lib.Object * 1)()
+    objs[0].coarse = s
+    objs[0].packed_coarse = 256
+    size = C.c_size_t()
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == 0
+    out = _lib.Outputs()
+    # workspace too small / misaligned: refused before anything is enqueued
+    assert lib.pr_render_forward(C.byref(call), objs, C.byref(out), None, 256, size.value - 1, None) == -2
+    assert b"workspace too small" in lib.pr_last_error()
+    assert lib.pr_render_forward(C.byref(call), objs, C.byref(out), None, 257, size.value, None) == -1
+    assert b"aligned" in lib.pr_last_error()
+    assert lib.pr_render_forward(None, objs, C.byref(out), None, 256, size.value, None) == -1
+    # the backward pass needs a forward call that saved its intermediates
+    bsize = C.c_size_t()
+    assert lib.pr_backward_workspace_size(C.byref(call), objs, C.byref(bsize)) == -1
+    assert b"PR_FLAG_SAVE_FOR_BACKWARD" in lib.pr_last_error()
+    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # saving needs train-mode BatchNorm
+    assert b"PR_FLAG_TRAIN_BN" in lib.pr_last_error()
+    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD | _lib.PR_FLAG_TRAIN_BN
+    eval_size = size.value
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == 0 and size.value > 4 * eval_size
+    assert lib.pr_backward_workspace_size(C.byref(call), objs, C.byref(bsize)) == 0 and bsize.value > 0
+    call.precision = _lib.PR_PRECISION_F16X3
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # split kernel: eval only
+    call.precision, call.flags = 7, 0
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1
+    assert b"precision" in lib.pr_last_error()
+    call.precision = 0
+    call.objects = 9
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1
+    # overlap fix with a static object that has more positions than a dynamic one: the reference raises IndexError
+    call.objects, call.static_objects, call.flags = 2, 1, _lib.PR_FLAG_FIX_OVERLAPS
+    two = (_lib.Object * 2)()
+    _, s_static = _model_struct_host(cfg["model"]["object_models"][2], 48)
+    two[0].coarse, two[1].coarse = s_static, s
+    two[0].packed_coarse = two[1].packed_coarse = 256
+    call.linspace_coarse[1] = 256
+    assert lib.pr_workspace_size(C.byref(call), two, C.byref(size)) == -1
+    assert b"IndexError" in lib.pr_last_error()
+    # expected positions / camera rays argument checks
+    assert lib.pr_expected_positions(1, 8, 1, 1, 4, 256, 256, 256, 256, 256, None, 256, None) == -1
+    assert lib.pr_camera_rays(0, 8, 4, 4, 0, 256, 256, 256, 256, 256, 256, 256, None) == -1
+
+
 def test_unsupported_configuration_is_rejected_loudly(built_library):
     cfg = configs.tennis_config()
     m = dict(cfg["model"]["object_models"][0])
