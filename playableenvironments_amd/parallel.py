@@ -111,3 +111,41 @@ def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None
         return
     for b in module.buffers():
         dist.broadcast(b, src=src, group=group)
+
+
+class AsyncFeatureGather:
+    """Pipelined all-gather of per-rank result tensors (the rendered feature maps of a frame shard).
+
+    ``submit(t)`` enqueues one ``all_gather_into_tensor`` behind the kernels that produced ``t`` and returns at once: the
+    collective runs on the backend's own stream and overlaps whatever the caller enqueues next (the next frame's
+    rendering); at most ``depth`` collectives stay in flight, older ones are waited for first.  ``drain()`` waits for the
+    rest and returns the gathered tensors in submission order - (world * t.shape[0], ...) each, rank-major."""
+
+    def __init__(self, group=None, depth: int = 1):
+        self.group = group
+        self.depth = max(1, depth)
+        self._in_flight: List[tuple] = []
+        self._done: List[torch.Tensor] = []
+
+    def submit(self, tensor: torch.Tensor) -> None:
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            self._done.append(tensor)
+            return
+        world = dist.get_world_size(self.group)
+        src = tensor.contiguous()
+        out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        self._in_flight.append((work, out, src))
+        while len(self._in_flight) > self.depth:
+            self._retire()
+
+    def _retire(self) -> None:
+        work, out, _ = self._in_flight.pop(0)
+        work.wait()
+        self._done.append(out)
+
+    def drain(self, keep: bool = True) -> List[torch.Tensor]:
+        while self._in_flight:
+            self._retire()
+        done, self._done = self._done, []
+        return done if keep else []

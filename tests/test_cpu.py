@@ -347,6 +347,14 @@ def _gloo_grad_worker(rank, world, port, results):
         net[1].running_mean.fill_(float(rank + 3))
         parallel.broadcast_buffers(net, src=0)
         ok = ok and float(net[1].running_mean[0]) == 3.0
+        # pipelined gather of per-rank feature maps (bench.py, evaluation): order and contents
+        pipe = parallel.AsyncFeatureGather(depth=1)
+        for i in range(3):
+            pipe.submit(torch.full((2, 5), float(10 * rank + i)))
+        stacks = pipe.drain()
+        ok = ok and len(stacks) == 3
+        for i, st in enumerate(stacks):
+            ok = ok and tuple(st.shape) == (2 * world, 5) and st[::2, 0].tolist() == [float(i), float(10 + i)]
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
