@@ -55,7 +55,8 @@ __device__ unsigned long long g_phase_cycles[16];
 #define PR_PHASE(idx) do {} while (0)
 #endif
 #define PR_ACC_ROW(i) (((i) & 3) + 8 * ((i) >> 2))
-#define PR_MFMA16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
+// a = activation fragment, w = weight fragment: D[feature][sample] += w (A operand) x a (B operand)
+#define PR_MFMA16(acc, a, w) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, acc, 0, 0, 0)
 
 __device__ __forceinline__ void split_store(_Float16* hi_plane, _Float16* lo_plane, int idx, float v) {
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);   // fp16 range; never reached by sane activations
@@ -67,32 +68,59 @@ __device__ __forceinline__ float split_load(const _Float16* hi_plane, const _Flo
     return (float)hi_plane[idx] + (float)lo_plane[idx] * (1.0f / 2048.0f);
 }
 
-// epilogues on (main, correction) accumulator pairs of one 32x32 block
-__device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, SmemH& S, int row0, int col) {
+// Epilogues on (main, correction) accumulator pairs of one 32x32 block.  The weights are the MFMA A operand and the
+// activations the B operand, so the block is D[feature][sample]: lane (r, half) holds SAMPLE r and the features
+// (i & 3) + 8 (i >> 2) + 4 half - four groups of four consecutive features, i.e. one 8-byte store per group and plane.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// splits four values into the hi / lo planes at halves offset `idx` (8-byte aligned)
+__device__ __forceinline__ void split_store4(_Float16* hi_plane, _Float16* lo_plane, int idx, f32x4 v) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float v = fmaf(c[i], 1.0f / 2048.0f, m[i]);
-        split_store(S.Xh, S.Xl, (row0 + PR_ACC_ROW(i)) * LDH + col, v > 0.f ? v : 0.f);
+    for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], -65504.0f), 65504.0f);   // fp16 range; never reached by sane activations
+    const f16x4 hi = __builtin_convertvector(v, f16x4);
+    const f32x4 back = __builtin_convertvector(hi, f32x4);
+    const f16x4 lo = __builtin_convertvector((v - back) * 2048.0f, f16x4);
+    *reinterpret_cast<f16x4*>(hi_plane + idx) = hi;
+    *reinterpret_cast<f16x4*>(lo_plane + idx) = lo;
+}
+
+__device__ __forceinline__ f32x4 combine4(const f32x16& m, const f32x16& c, int j) {
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaf(c[4 * j + k], 1.0f / 2048.0f, m[4 * j + k]);
+    return v;
+}
+
+// idx0 = sample row * LDH + first feature of the lane
+__device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, SmemH& S, int idx0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 v = combine4(m, c, j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
     }
 }
-__device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, SmemH& S, const MlpParams& p, int row0,
-                                              int col, int goff, int boff, bool uniform, float ug, float ub) {
+// g / b point at the lane's first feature in the AdaIN table row of the sample's frame
+__device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, SmemH& S, int idx0, const float* g, const float* b) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = row0 + PR_ACC_ROW(i);
-        float g = ug, b = ub;
-        if (!uniform) {
-            const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride;
-            g = tab[goff];
-            b = tab[boff];
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 8 * j);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * j);
+        f32x4 v = combine4(m, c, j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = fmaf(v[k], gg[k], bb[k]);
+            v[k] = v[k] > 0.f ? v[k] : 0.f;
         }
-        const float v = fmaf(fmaf(c[i], 1.0f / 2048.0f, m[i]), g, b);
-        split_store(S.Xh, S.Xl, row * LDH + col, v > 0.f ? v : 0.f);
+        split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
     }
 }
-__device__ __forceinline__ void store_stage_h(const f32x16& m, const f32x16& c, float* stage, int row0, int col) {
+// stage = fp32 staging tile over the activation planes; base = &stage[sample row * LDSTAGE + first feature]
+__device__ __forceinline__ void store_stage_h(const f32x16& m, const f32x16& c, float* base) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) stage[(row0 + PR_ACC_ROW(i)) * LDSTAGE + col] = fmaf(c[i], 1.0f / 2048.0f, m[i]);
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(base + 8 * j) = combine4(m, c, j);
 }
 
 __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p) {
@@ -113,16 +141,22 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     }
     PR_PHASE_T0();
     f32x16 m0, m1, c0, c1;   // main / correction accumulators of row block 0 / 1
-    {
-        const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            m0[i] = bias;
-            m1[i] = bias;
-            c0[i] = 0.f;
-            c1[i] = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        m0[i] = 0.f;
+        c0[i] = 0.f;
+        c1[i] = 0.f;
+    }
+    if (L.bias != nullptr && active) {
+        const float* bp = L.bias + cb * 32 + 4 * half;   // the lane's 4 x 4 features
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m0[4 * j + k] = b4[k];
         }
     }
+    m1 = m0;
     if (active) {
         for (int sidx = 0; sidx < L.nseg; ++sidx) {
             const Seg& sg = L.seg[sidx];
@@ -225,26 +259,24 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     __syncthreads();  // every wave has finished reading the activation planes
     PR_PHASE(4);
     if (active && !((PR_SPLIT_ABLATE & 8) && L.epi != EPI_FEATURES)) {
-        const int col = cb * 32 + r;
-        const int rowA = (both ? 0 : rb * 32) + 4 * half;
+        const int feat0 = cb * 32 + 4 * half;              // first feature of this lane
+        const int row0 = (both ? 0 : rb * 32) + r;         // sample row of this lane in m0 / c0 (m1 / c1: + 32)
         if (L.epi == EPI_RELU) {
-            store_relu_h(m0, c0, S, rowA, col);
-            if (both) store_relu_h(m1, c1, S, rowA + 32, col);
+            store_relu_h(m0, c0, S, row0 * LDH + feat0);
+            if (both) store_relu_h(m1, c1, S, (row0 + 32) * LDH + feat0);
         } else if (L.epi == EPI_ADAIN_RELU) {
-            const int goff = L.adain_off + col, boff = L.adain_off + L.nblk * 32 + col;
+            const int bofs = L.nblk * 32;
             const bool uniform = S.uniform_frame != 0;
-            float ug = 0.f, ub = 0.f;
-            if (uniform) {
-                const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride;
-                ug = tab[goff];
-                ub = tab[boff];
+            const float* tab0 = p.adain + (size_t)S.frame[uniform ? 0 : row0] * p.adain_stride + L.adain_off + feat0;
+            store_adain_h(m0, c0, S, row0 * LDH + feat0, tab0, tab0 + bofs);
+            if (both) {
+                const float* tab1 = p.adain + (size_t)S.frame[uniform ? 0 : row0 + 32] * p.adain_stride + L.adain_off + feat0;
+                store_adain_h(m1, c1, S, (row0 + 32) * LDH + feat0, tab1, tab1 + bofs);
             }
-            store_adain_h(m0, c0, S, p, rowA, col, goff, boff, uniform, ug, ub);
-            if (both) store_adain_h(m1, c1, S, p, rowA + 32, col, goff, boff, uniform, ug, ub);
         } else {
             float* stage = reinterpret_cast<float*>(S.Xh);
-            store_stage_h(m0, c0, stage, rowA, col);
-            if (both) store_stage_h(m1, c1, stage, rowA + 32, col);
+            store_stage_h(m0, c0, stage + row0 * LDSTAGE + feat0);
+            if (both) store_stage_h(m1, c1, stage + (row0 + 32) * LDSTAGE + feat0);
         }
     }
     PR_PHASE(5);
