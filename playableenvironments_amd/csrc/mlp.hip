@@ -1184,14 +1184,17 @@ extern "C" int pr_probe_mfma_f32(int32_t iterations, int32_t random_operands, do
     PR_CHECK_HIP(hipEventCreate(&e0));
     PR_CHECK_HIP(hipEventCreate(&e1));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(512), 0, s, 16, sink, random_operands);  // warm-up
+#ifndef PR_PROBE_WAVES
+#define PR_PROBE_WAVES 8   // the renderer's occupancy; 4 = one wave per SIMD (experiments)
+#endif
+    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(64 * PR_PROBE_WAVES), 0, s, 16, sink, random_operands);  // warm-up
     PR_CHECK_HIP(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(512), 0, s, iterations, sink, random_operands);
+    hipLaunchKernelGGL(pr::k_probe_mfma, dim3(cus), dim3(64 * PR_PROBE_WAVES), 0, s, iterations, sink, random_operands);
     PR_CHECK_HIP(hipEventRecord(e1, s));
     PR_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     PR_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-    const double flop = (double)cus * 8 * (double)iterations * 8.0 * (2.0 * 32 * 32 * 2);
+    const double flop = (double)cus * PR_PROBE_WAVES * (double)iterations * 8.0 * (2.0 * 32 * 32 * 2);
     *tflops = flop / (ms * 1e-3) / 1e12;
     if (milliseconds) *milliseconds = ms;
     PR_CHECK_HIP(hipEventDestroy(e0));
