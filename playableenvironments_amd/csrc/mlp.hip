@@ -332,8 +332,7 @@ struct Smem {
     int uniform_frame;       // every row of the tile belongs to the same frame
     int pad_[3];
     float head_w[HEAD_SIGMA + HEAD_BENDER];
-    float X[TILE_M * LDX];
-    float E[TILE_M * LDE];
+    float X[TILE_M * LDX];   // activations; columns [0, K) also hold a layer's input encoding while it is needed
     float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
     int flat[TILE_M];
     int frame[TILE_M];
@@ -421,136 +420,200 @@ __device__ unsigned long long g_mlp_phase[16];
 #define PR_PHASE(idx) do {} while (0)
 #endif
 
-// One layer on the tile.  All 512 threads call it (two workgroup barriers inside).
-#define PR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p);
 
-__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base) {
+// One layer on the tile.  All threads of the workgroup call it (workgroup barriers inside).
+//
+// Geometry: the 64-sample tile is two 32-row MFMA blocks; wave w of the FOUR waves owns the 32-column blocks w and
+// w + 4 of the layer for both row blocks - four accumulators that share two activation and two weight fragments
+// per K step (16 MFMAs between operand loads).  Two such workgroups are resident per CU (LDS ~70 KB each), so the
+// serial phases of one tile (record loads, encodings, epilogues, barriers) overlap the other tile's matrix work.
+//
+// `input_kind` says what a segment with src == 1 (the layer's input encoding) means: 0 = NeRF input, 1 = ray-bender
+// input.  The first layer finds it in X already; the skip layer's second segment re-computes it into X[:, 0:K).
+#define PR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+#define PR_MFMA4(acc, a, b) \
+    PR_MFMA(acc, a.x, b.x); \
+    PR_MFMA(acc, a.y, b.y); \
+    PR_MFMA(acc, a.z, b.z); \
+    PR_MFMA(acc, a.w, b.w)
+
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind);
+
+// Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
+//   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
+// There is no separate encoding buffer: the encoding is (re)computed into the activation tile right before a
+// layer consumes it - layer 0, and once more for the second K segment of the skip layer - which keeps the
+// workgroup at ~70 KB of LDS, i.e. two independent tiles per CU.
+// 8 threads per row, thread `part` takes the octaves part, part + 8, ... (one sincos per axis).
+__device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
+                                              const float* octave_weights, bool normalise) {
+    const int part = threadIdx.x & 7;
+    for (int s = threadIdx.x >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+        float v[6];
+        for (int a = 0; a < din; ++a) {
+            const float x = S.pos[s * 8 + a];
+            v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+        }
+        float* row = S.X + s * LDX;
+        if (part == 0)
+            for (int a = 0; a < din; ++a) row[a] = v[a];
+        if (part == 1)
+            for (int j = zero_from; j < pad; ++j) row[j] = 0.f;
+        for (int k = part; k < octaves; k += 8) {
+            const float f = ldexpf(1.0f, k);
+            const float w = octave_weights ? octave_weights[k] : 1.0f;
+            float* dst = row + din + k * 2 * din;
+            for (int a = 0; a < din; ++a) {
+                const float arg = __fmul_rn(f, v[a]);
+                float sn, cs;
+                sn = sinf(arg);
+                cs = cosf(arg);
+                if (octave_weights) {
+                    sn = __fmul_rn(sn, w);
+                    cs = __fmul_rn(cs, w);
+                }
+                dst[a] = sn;
+                dst[din + a] = cs;
+            }
+        }
+    }
+}
+
+// input of the NeRF: PE of the (bent, normalised) position / of the skybox's [o / size, d / |d|]
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p) {
+    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+}
+
+// input of the ray bender: [annealed PE(x / size) | deformation code of the sample's frame], zero padded
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p) {
+    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true);
+    for (int idx = threadIdx.x; idx < TILE_M * p.D; idx += MLP_THREADS) {
+        const int s = idx / p.D, j = idx - s * p.D;
+        S.X[s * LDX + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
+    }
+}
+
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
-    // > 4 column blocks: wave w owns block w for both 32-row blocks (the two accumulators share the
-    // weight fragment); otherwise the row blocks are split across waves as well
-    const bool both = nblk > 4;
-    int cb, rb;
-    bool active;
-    if (both) {
-        cb = wave;
-        rb = 0;
-        active = wave < nblk;
-    } else {
-        cb = wave % nblk;
-        rb = wave / nblk;
-        active = rb < 2;
-    }
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    const bool active = cbA < nblk;      // this wave has a first column block
+    const bool two = cbB < nblk;         // ... and a second one
     PR_PHASE_T0();
-    f32x16 acc0, acc1;
+    f32x16 a00, a01, a10, a11;           // [column block A / B][row block 0 / 1]
     {
-        const float bias = (L.bias != nullptr && active) ? L.bias[cb * 32 + r] : 0.f;
+        const float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
+        const float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            acc0[i] = bias;
-            acc1[i] = bias;
+            a00[i] = biasA;
+            a01[i] = biasA;
+            a10[i] = biasB;
+            a11[i] = biasB;
         }
     }
-    if (active && !(p.debug & 128)) {
-        for (int sidx = 0; sidx < L.nseg; ++sidx) {
-            const Seg& sg = L.seg[sidx];
-            const float* src = sg.src == 0 ? S.X : S.E;
-            const int ld = sg.src == 0 ? LDX : LDE;
-            const int kq = sg.kq;   // even (K is padded to a multiple of 16)
-            const float* ap = src + (rb * 32 + r) * ld + half * 4 * kq;
-            const float4* wp = reinterpret_cast<const float4*>(sg.w) + (size_t)cb * kq * 64 + lane;
-            // two steps in flight: even/odd fragments live in their own registers and are re-loaded
-            // right after their last use, a full step before they are needed again
-            float4 be = wp[0], bo = wp[64];
-            if (both) {
-                float4 a0e = *reinterpret_cast<const float4*>(ap);
-                float4 a1e = *reinterpret_cast<const float4*>(ap + 32 * ld);
-                float4 a0o = *reinterpret_cast<const float4*>(ap + 4);
-                float4 a1o = *reinterpret_cast<const float4*>(ap + 32 * ld + 4);
-                for (int q = 0; q < kq; q += 2) {
-                    const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
-                    PR_MFMA(acc0, a0e.x, be.x);
-                    PR_MFMA(acc1, a1e.x, be.x);
-                    PR_MFMA(acc0, a0e.y, be.y);
-                    PR_MFMA(acc1, a1e.y, be.y);
-                    PR_MFMA(acc0, a0e.z, be.z);
-                    PR_MFMA(acc1, a1e.z, be.z);
-                    PR_MFMA(acc0, a0e.w, be.w);
-                    PR_MFMA(acc1, a1e.w, be.w);
-                    be = wp[(size_t)qe * 64];
-                    a0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
-                    a1e = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * qe);
-                    PR_MFMA(acc0, a0o.x, bo.x);
-                    PR_MFMA(acc1, a1o.x, bo.x);
-                    PR_MFMA(acc0, a0o.y, bo.y);
-                    PR_MFMA(acc1, a1o.y, bo.y);
-                    PR_MFMA(acc0, a0o.z, bo.z);
-                    PR_MFMA(acc1, a1o.z, bo.z);
-                    PR_MFMA(acc0, a0o.w, bo.w);
-                    PR_MFMA(acc1, a1o.w, bo.w);
-                    bo = wp[(size_t)qo * 64];
-                    a0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
-                    a1o = *reinterpret_cast<const float4*>(ap + 32 * ld + 4 * qo);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-            } else {
-                float4 a0e = *reinterpret_cast<const float4*>(ap);
-                float4 a0o = *reinterpret_cast<const float4*>(ap + 4);
-                for (int q = 0; q < kq; q += 2) {
-                    const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
-                    PR_MFMA(acc0, a0e.x, be.x);
-                    PR_MFMA(acc0, a0e.y, be.y);
-                    PR_MFMA(acc0, a0e.z, be.z);
-                    PR_MFMA(acc0, a0e.w, be.w);
-                    be = wp[(size_t)qe * 64];
-                    a0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
-                    PR_MFMA(acc0, a0o.x, bo.x);
-                    PR_MFMA(acc0, a0o.y, bo.y);
-                    PR_MFMA(acc0, a0o.z, bo.z);
-                    PR_MFMA(acc0, a0o.w, bo.w);
-                    bo = wp[(size_t)qo * 64];
-                    a0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+    for (int sidx = 0; sidx < L.nseg; ++sidx) {
+        const Seg& sg = L.seg[sidx];
+        if (sg.src == 1 && sidx > 0) {
+            // second K segment of a skip layer: its operand is the network input, re-encoded over the
+            // (now dead) activations of the first segment
+            __syncthreads();
+            if (input_kind == 1) fill_bender_input(S, p); else fill_nerf_input(S, p);
+            __syncthreads();
+        }
+        if (!active || (p.debug & 128)) continue;
+        const int kq = sg.kq;   // even (K is padded to a multiple of 16)
+        const float* ap = S.X + r * LDX + half * 4 * kq;
+        const float4* wpA = reinterpret_cast<const float4*>(sg.w) + (size_t)cbA * kq * 64 + lane;
+        // two steps in flight: even/odd fragments live in their own registers and are re-loaded
+        // right after their last use, a full step before they are needed again
+        float4 x0e = *reinterpret_cast<const float4*>(ap);
+        float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
+        float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
+        float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+        float4 wAe = wpA[0], wAo = wpA[64];
+        if (two) {
+            const float4* wpB = reinterpret_cast<const float4*>(sg.w) + (size_t)cbB * kq * 64 + lane;
+            float4 wBe = wpB[0], wBo = wpB[64];
+            for (int q = 0; q < kq; q += 2) {
+                const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                PR_MFMA4(a00, x0e, wAe);
+                PR_MFMA4(a01, x1e, wAe);
+                PR_MFMA4(a10, x0e, wBe);
+                PR_MFMA4(a11, x1e, wBe);
+                wAe = wpA[(size_t)qe * 64];
+                wBe = wpB[(size_t)qe * 64];
+                x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+                PR_MFMA4(a00, x0o, wAo);
+                PR_MFMA4(a01, x1o, wAo);
+                PR_MFMA4(a10, x0o, wBo);
+                PR_MFMA4(a11, x1o, wBo);
+                wAo = wpA[(size_t)qo * 64];
+                wBo = wpB[(size_t)qo * 64];
+                x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
+            for (int q = 0; q < kq; q += 2) {
+                const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                PR_MFMA4(a00, x0e, wAe);
+                PR_MFMA4(a01, x1e, wAe);
+                wAe = wpA[(size_t)qe * 64];
+                x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+                PR_MFMA4(a00, x0o, wAo);
+                PR_MFMA4(a01, x1o, wAo);
+                wAo = wpA[(size_t)qo * 64];
+                x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
     }
     if (p.debug & 4) return;  // ablation: no barriers, no epilogue
     PR_PHASE(3);
-    __syncthreads();  // every wave has finished reading X / E
+    __syncthreads();  // every wave has finished reading X
     PR_PHASE(4);
     if (active && !(p.debug & 8)) {
-        const int col = cb * 32 + r;
-        const int rowA = (both ? 0 : rb * 32) + 4 * half;   // first row of this lane in acc0
-        if (L.epi == EPI_RELU) {
-            store_relu(acc0, S.X + rowA * LDX + col);
-            if (both) store_relu(acc1, S.X + (rowA + 32) * LDX + col);
-        } else if (L.epi == EPI_ADAIN_RELU) {
-            const int bofs = L.nblk * 32;
-            if (S.uniform_frame) {
-                const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride + L.adain_off;
-                const float g = tab[col], b = tab[bofs + col];
-                store_adain_uniform(acc0, S.X + rowA * LDX + col, g, b);
-                if (both) store_adain_uniform(acc1, S.X + (rowA + 32) * LDX + col, g, b);
+        for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+            const int col = (blk ? cbB : cbA) * 32 + r;
+            const f32x16& lo = blk ? a10 : a00;   // rows 0..31
+            const f32x16& hi = blk ? a11 : a01;   // rows 32..63
+            float* x0 = S.X + (4 * half) * LDX + col;
+            if (L.epi == EPI_RELU) {
+                store_relu(lo, x0);
+                store_relu(hi, x0 + 32 * LDX);
+            } else if (L.epi == EPI_ADAIN_RELU) {
+                const int bofs = L.nblk * 32;
+                if (S.uniform_frame) {
+                    const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride + L.adain_off;
+                    const float g = tab[col], b = tab[bofs + col];
+                    store_adain_uniform(lo, x0, g, b);
+                    store_adain_uniform(hi, x0 + 32 * LDX, g, b);
+                } else {
+                    store_adain_rows(lo, S, p, 4 * half, col, L.adain_off + col, L.adain_off + bofs + col);
+                    store_adain_rows(hi, S, p, 4 * half + 32, col, L.adain_off + col, L.adain_off + bofs + col);
+                }
             } else {
-                store_adain_rows(acc0, S, p, rowA, col, L.adain_off + col, L.adain_off + bofs + col);
-                if (both) store_adain_rows(acc1, S, p, rowA + 32, col, L.adain_off + col, L.adain_off + bofs + col);
+                // last layer: stage the tile in X, the caller writes it out with coalesced 16-byte stores
+                store_plain(lo, x0);
+                store_plain(hi, x0 + 32 * LDX);
             }
-        } else {
-            // last layer: stage the tile in X, the caller writes it out with coalesced 16-byte stores
-            store_plain(acc0, S.X + rowA * LDX + col);
-            if (both) store_plain(acc1, S.X + (rowA + 32) * LDX + col);
         }
     }
     PR_PHASE(5);
@@ -558,45 +621,10 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     PR_PHASE(6);
 }
 
-// Positional encoding of every tile row into E (model/positional_encoder.py:54-64):
-//   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [enc, pad) are zeroed.
-// 8 threads per row, thread `part` takes the octaves part, part + 8, ... (one sincos per axis).
-__device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
-                                              const float* octave_weights, bool normalise) {
-    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
-    float v[6];
-    for (int a = 0; a < din; ++a) {
-        const float x = S.pos[s * 8 + a];
-        v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
-    }
-    float* row = S.E + s * LDE;
-    if (part == 0)
-        for (int a = 0; a < din; ++a) row[a] = v[a];
-    if (part == 1)
-        for (int j = zero_from; j < pad; ++j) row[j] = 0.f;
-    for (int k = part; k < octaves; k += 8) {
-        const float f = ldexpf(1.0f, k);
-        const float w = octave_weights ? octave_weights[k] : 1.0f;
-        float* dst = row + din + k * 2 * din;
-        for (int a = 0; a < din; ++a) {
-            const float arg = __fmul_rn(f, v[a]);
-            float sn, cs;
-            sn = sinf(arg);
-            cs = cosf(arg);
-            if (octave_weights) {
-                sn = __fmul_rn(sn, w);
-                cs = __fmul_rn(cs, w);
-            }
-            dst[a] = sn;
-            dst[din + a] = cs;
-        }
-    }
-}
-
 // dot products of every tile row with `nout` (<= 3) weight rows of length `width` (raw, padded),
-// 8 threads per row; result valid in the thread with part == 0.
-__device__ __forceinline__ void row_dots(const Smem& S, const float* w, int width, int wstride, int nout, float* out) {
-    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+// for tile row `s`: 8 threads per row (callers loop s = tid / 8, + MLP_THREADS / 8, ...); the result is valid in all 8.
+__device__ __forceinline__ void row_dots(const Smem& S, int s, const float* w, int width, int wstride, int nout, float* out) {
+    const int part = threadIdx.x & 7;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int k = part; k < width; k += 8) {
         const float x = S.X[s * LDX + k];
@@ -613,10 +641,10 @@ __device__ __forceinline__ void row_dots(const Smem& S, const float* w, int widt
 
 // Tile rows staged in X -> HBM with coalesced 16-byte stores (width % 4 == 0) or scalar stores.
 // zero_dead: rows that failed the second AABB test are written as zeros (feature rows).
-__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead,
-                                                const float* src = nullptr, int ld = LDX) {
+__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead) {
     const int tid = threadIdx.x;
-    if (src == nullptr) src = S.X;
+    const float* src = S.X;
+    const int ld = LDX;
     if ((width & 3) == 0 && (stride & 3) == 0) {
         const int w4 = width >> 2;
         for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
@@ -709,26 +737,21 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
 
         // ---- ray bender -----------------------------------------------------------------------
         if (p.has_bender) {
-            fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true);
-            for (int idx = tid; idx < TILE_M * p.D; idx += MLP_THREADS) {
-                const int s = idx / p.D, j = idx - s * p.D;
-                S.E[s * LDE + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
-            }
+            fill_bender_input(S, p);
             __syncthreads();
-            if (p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false, S.E, LDE);
+            if (p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
-                run_layer(p.b_layers[l], S, p, tile_base);
+                run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1);
                 if (p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
                     write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
                     __syncthreads();
                 }
             }
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
-            float out[3];
-            row_dots(S, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
-            __syncthreads();
-            if ((tid & 7) == 0) {
-                const int s = tid >> 3;
+            for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+                float out[3];
+                row_dots(S, s, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
+                if ((tid & 7) != 0) continue;
                 float d[3], bent[3];
                 if (p.save_braw && (S.flags[s] & 1))
                     for (int a = 0; a < 3; ++a) p.save_braw[(size_t)(tile_base + s) * 3 + a] = out[a];
@@ -754,19 +777,19 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                     if (!in_box(bent[0], bent[1], bent[2], p.lo, p.hi)) S.flags[s] &= ~2;
                 }
             }
-            __syncthreads();
+            __syncthreads();   // the bent positions and the row flags are complete; X may be overwritten
         }
 
         PR_PHASE(1);
         // ---- positional encoding of the NeRF input --------------------------------------------
-        fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+        fill_nerf_input(S, p);
         __syncthreads();
         PR_PHASE(2);
-        if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false, S.E, LDE);
+        if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false);
 
         // ---- backbone ---------------------------------------------------------------------------
         for (int l = 0; l < p.n_backbone; ++l) {
-            run_layer(p.layers[l], S, p, tile_base);
+            run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0);
             if (p.save_act) {
                 write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
                 __syncthreads();
@@ -776,11 +799,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         PR_PHASE(15);
         // ---- sigma head -------------------------------------------------------------------------
         if (p.kind == 0) {
-            float sg;
-            row_dots(S, S.head_w, p.Wpad, p.Wpad, 1, &sg);
-            if ((tid & 7) == 0) {
-                const int s = tid >> 3;
-                if ((S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
+            for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+                float sg;
+                row_dots(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
+                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
             }
         } else if (tid < TILE_M) {
             if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
@@ -789,7 +811,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
         if (p.phase == 0) {
-            for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base);
+            for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base, 0);
             PR_PHASE(15);
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
             __syncthreads();   // the next tile's prologue overwrites flags / X
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             // their per-channel sums feed the batch statistics
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
-            run_layer(raw, S, p, tile_base);
+            run_layer(raw, S, p, tile_base, 0);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             accumulate_stats(S, p);
@@ -843,7 +865,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
         __syncthreads();
         Layer raw = cur;
         raw.epi = EPI_FEATURES;   // plain store into X
-        run_layer(raw, S, p, tile_base);
+        run_layer(raw, S, p, tile_base, 0);
         if (p.phase == 2) {
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             accumulate_stats(S, p);
@@ -984,8 +1006,9 @@ __global__ __launch_bounds__(64) void k_mlp_naive(MlpParams p, pr_object_model_t
 
 static int g_cu_count = 0;
 
-int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s) {
-    if (max_tiles <= 0) return PR_OK;
+int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s) {
+    if (max_rows <= 0) return PR_OK;
+    const int max_tiles = naive ? (max_rows + 63) / 64 : (max_rows + TILE_M - 1) / TILE_M;
     if (naive) {
         hipLaunchKernelGGL(k_mlp_naive, dim3(max_tiles), dim3(64), 0, s, p, *raw);
         PR_LAUNCH_CHECK();

@@ -17,6 +17,8 @@ namespace pr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+constexpr int STILE_M = 64;          // samples per workgroup tile of the split kernel (two 32-row MFMA blocks)
+constexpr int STHREADS = 512;        // 8 waves, one workgroup per CU
 constexpr int LDH = MAX_WIDTH + 8;   // halves per activation row (528 B = 33 16-byte slots: conflict-free b128)
 constexpr int LEH = MAX_ENC + 8;     // halves per encoding row (272 B = 17 slots)
 constexpr int LDSTAGE = 260;         // floats per row when the activation planes are reused as an fp32 staging tile
@@ -25,16 +27,16 @@ struct SmemH {
     int uniform_frame;
     int pad_[3];
     float head_w[MAX_WIDTH + 8];          // sigma head weights + bias
-    _Float16 Xh[TILE_M * LDH];            // activations, hi plane
-    _Float16 Xl[TILE_M * LDH];            // activations, lo plane (scaled by 2^11)
-    _Float16 Eh[TILE_M * LEH];
-    _Float16 El[TILE_M * LEH];
-    float pos[TILE_M * 8];
-    int flat[TILE_M];
-    int frame[TILE_M];
-    int flags[TILE_M];
+    _Float16 Xh[STILE_M * LDH];            // activations, hi plane
+    _Float16 Xl[STILE_M * LDH];            // activations, lo plane (scaled by 2^11)
+    _Float16 Eh[STILE_M * LEH];
+    _Float16 El[STILE_M * LEH];
+    float pos[STILE_M * 8];
+    int flat[STILE_M];
+    int frame[STILE_M];
+    int flags[STILE_M];
 };
-static_assert(sizeof(_Float16) * 2 * TILE_M * LDH >= sizeof(float) * TILE_M * LDSTAGE, "staging tile must fit the activation planes");
+static_assert(sizeof(_Float16) * 2 * STILE_M * LDH >= sizeof(float) * STILE_M * LDSTAGE, "staging tile must fit the activation planes");
 static_assert(sizeof(SmemH) <= 159 * 1024, "LDS budget");
 
 #ifndef PR_SPLIT_ABLATE
@@ -330,18 +332,18 @@ __device__ __forceinline__ void row_dots_h(const SmemH& S, const float* w, int w
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
+__global__ __launch_bounds__(STHREADS) void k_mlp_split(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
-    for (int i = tid; i <= p.Wpad; i += MLP_THREADS) S.head_w[i] = p.sigma_w[i];
+    for (int i = tid; i <= p.Wpad; i += STHREADS) S.head_w[i] = p.sigma_w[i];
     __syncthreads();
-    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
-        const int tile_base = tile * TILE_M;
+    for (int tile = blockIdx.x; tile * STILE_M < total; tile += gridDim.x) {
+        const int tile_base = tile * STILE_M;
         PR_PHASE_T0();
         if (tid == 0) S.uniform_frame = 1;
-        if (tid < TILE_M) {
+        if (tid < STILE_M) {
             const int idx = tile_base + tid;
             const bool valid = idx < total;
             const int src = valid ? idx : tile_base;
@@ -367,12 +369,12 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
             }
         }
         __syncthreads();
-        if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
         PR_PHASE(0);
 
         if (p.has_bender) {
             fill_encoding_h(S, p, 3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, true);
-            for (int idx = tid; idx < TILE_M * p.D; idx += MLP_THREADS) {
+            for (int idx = tid; idx < STILE_M * p.D; idx += STHREADS) {
                 const int s = idx / p.D, j = idx - s * p.D;
                 split_store(S.Eh, S.El, s * LEH + p.benc + j, p.deformation[(size_t)S.frame[s] * p.deformation_stride + j]);
             }
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
                 const int s = tid >> 3;
                 if ((S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
             }
-        } else if (tid < TILE_M) {
+        } else if (tid < STILE_M) {
             if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
         }
 
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
             const float* stage = reinterpret_cast<const float*>(S.Xh);
             if ((p.F & 3) == 0) {
                 const int f4 = p.F >> 2;
-                for (int idx = tid; idx < TILE_M * f4; idx += MLP_THREADS) {
+                for (int idx = tid; idx < STILE_M * f4; idx += STHREADS) {
                     const int row = idx / f4, c = (idx - row * f4) * 4;
                     const int fl = S.flags[row];
                     if (fl & 1) {
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
                     }
                 }
             } else {
-                for (int idx = tid; idx < TILE_M * p.F; idx += MLP_THREADS) {
+                for (int idx = tid; idx < STILE_M * p.F; idx += STHREADS) {
                     const int row = idx / p.F, c = idx - row * p.F;
                     const int fl = S.flags[row];
                     if (fl & 1) p.feat[(size_t)(tile_base + row) * p.F + c] = (fl & 2) ? stage[row * LDSTAGE + c] : 0.f;
@@ -455,8 +457,9 @@ __global__ __launch_bounds__(MLP_THREADS) void k_mlp_split(MlpParams p) {
     }
 }
 
-int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s) {
-    if (max_tiles <= 0) return PR_OK;
+int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
+    if (max_rows <= 0) return PR_OK;
+    const int max_tiles = (max_rows + STILE_M - 1) / STILE_M;
     static bool attr_set = false;
     static int cu_count = 0;
     if (!attr_set) {
@@ -471,7 +474,7 @@ int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s) {
     }
     const int grid = max_tiles < cu_count ? max_tiles : cu_count;
     ProfileScope scope(0, s);
-    hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(MLP_THREADS), sizeof(SmemH), s, p);
+    hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();
 #if PR_SPLIT_ABLATE & 64
     {

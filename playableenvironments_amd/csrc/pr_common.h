@@ -38,8 +38,9 @@ void set_error(const char* fmt, ...);
 // Geometry of the MLP tiling
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_M = 64;        // samples per workgroup tile (two 32-row MFMA blocks)
-constexpr int MLP_WAVES = 8;      // 512 threads, one workgroup per CU (LDS ~103 KB)
-constexpr int MLP_BLOCKS_PER_CU = 1;
+constexpr int MLP_WAVES = 4;      // 256 threads; every wave owns two 32-column blocks x both row blocks
+constexpr int MLP_BLOCKS_PER_CU = 2;   // two independent tiles per CU (LDS ~70 KB each): one computes while the other
+                                       // is in a prologue / epilogue / barrier
 constexpr int MLP_THREADS = MLP_WAVES * 64;
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
@@ -236,8 +237,8 @@ struct FoldParams {
 };
 int launch_adain_fold(const FoldParams& p, hipStream_t s);
 
-int launch_mlp(const MlpParams& p, int max_tiles, bool naive, const pr_object_model_t* raw, hipStream_t s);
-int launch_mlp_split(const MlpParams& p, int max_tiles, hipStream_t s);   // PR_PRECISION_F16X3, eval only
+int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s);
+int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s);   // PR_PRECISION_F16X3, eval only
 
 // BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
 // running statistics updated in place with momentum 0.1 and the unbiased variance, num_batches_tracked += 1

@@ -301,7 +301,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 if (m.has_bender) mp.delta_dense = outs[t]->sample_delta[k];
             }
             const size_t cap = (size_t)c.frames * c.rays * P;
-            const int max_tiles = (int)((cap + (naive ? 63 : TILE_M - 1)) / (naive ? 64 : TILE_M));
+            const int max_tiles = (int)cap;   // rows: every launcher derives its own tile count
             if (!(c.flags & PR_FLAG_TRAIN_BN)) {
                 PR_TRY(launch_adain_fold(fo, s));
                 if (c.precision == PR_PRECISION_F16X3 && !naive)
