@@ -7,7 +7,7 @@
 // v_mfma_f32_32x32x16_f16, whose products are exact in fp32.  The matrix pipe runs fp16 at 16x the fp32
 // rate, so three MFMAs per 16 K-values replace eight fp32 MFMAs: 5.3x less matrix time.
 //
-// Structure = csrc/mlp.hip (64-sample tile, 8 waves, one 32-column block per wave, weights as
+// Structure = csrc/mlp.hip (64-sample tile, 4 waves x two 32-column blocks, two resident tiles per CU, weights as
 // fragment-ordered hi/lo pairs straight from L2, even/odd operand pipeline); activations live in LDS as
 // two fp16 planes.  Selected with pr_call_t.precision = PR_PRECISION_F16X3; eval-mode only.
 #include "pr_common.h"
@@ -18,7 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int STILE_M = 64;          // samples per workgroup tile of the split kernel (two 32-row MFMA blocks)
-constexpr int STHREADS = 512;        // 8 waves, one workgroup per CU
+constexpr int STHREADS = 256;        // 4 waves; two workgroups (tiles) per CU
+constexpr int SWAVES = 4;
+constexpr int SBLOCKS_PER_CU = 2;
 constexpr int LDH = MAX_WIDTH + 8;   // halves per activation row (528 B = 33 16-byte slots: conflict-free b128)
 constexpr int LEH = MAX_ENC + 8;     // halves per encoding row (272 B = 17 slots)
 constexpr int LDSTAGE = 260;         // floats per row when the activation planes are reused as an fp32 staging tile
@@ -29,15 +31,13 @@ struct SmemH {
     float head_w[MAX_WIDTH + 8];          // sigma head weights + bias
     _Float16 Xh[STILE_M * LDH];            // activations, hi plane
     _Float16 Xl[STILE_M * LDH];            // activations, lo plane (scaled by 2^11)
-    _Float16 Eh[STILE_M * LEH];
-    _Float16 El[STILE_M * LEH];
     float pos[STILE_M * 8];
     int flat[STILE_M];
     int frame[STILE_M];
     int flags[STILE_M];
 };
 static_assert(sizeof(_Float16) * 2 * STILE_M * LDH >= sizeof(float) * STILE_M * LDSTAGE, "staging tile must fit the activation planes");
-static_assert(sizeof(SmemH) <= 159 * 1024, "LDS budget");
+static_assert(sizeof(SmemH) * SBLOCKS_PER_CU <= 158 * 1024, "the workgroups of one CU must fit its LDS");
 
 #ifndef PR_SPLIT_ABLATE
 #define PR_SPLIT_ABLATE 0   // profiling builds only: 1 = no weight re-loads, 2 = no activation re-loads, 8 = no epilogue
@@ -125,135 +125,130 @@ __device__ __forceinline__ void store_stage_h(const f32x16& m, const f32x16& c, 
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(base + 8 * j) = combine4(m, c, j);
 }
 
-__device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p) {
+__device__ __forceinline__ void fill_nerf_input_h(SmemH& S, const MlpParams& p);
+__device__ __forceinline__ void fill_bender_input_h(SmemH& S, const MlpParams& p);
+
+// One layer on the tile (see run_layer in mlp.hip for the geometry: wave w owns the column blocks w and w + 4 for
+// both row blocks; here every block has a main and a correction accumulator).  input_kind: what a src == 1 segment
+// re-computes into X[:, 0:K) - 0 NeRF input, 1 ray-bender input.
+#define PR_SPLIT3(M, C, AH, AL, BH, BL) \
+    PR_MFMA16(M, AH, BH);               \
+    PR_MFMA16(C, AH, BL);               \
+    PR_MFMA16(C, AL, BH)
+
+__device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p, int input_kind) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
-    const bool both = nblk > 4;
-    int cb, rb;
-    bool active;
-    if (both) {
-        cb = wave;
-        rb = 0;
-        active = wave < nblk;
-    } else {
-        cb = wave % nblk;
-        rb = wave / nblk;
-        active = rb < 2;
-    }
+    const int cbA = wave, cbB = wave + SWAVES;
+    const bool active = cbA < nblk;
+    const bool two = cbB < nblk;
     PR_PHASE_T0();
-    f32x16 m0, m1, c0, c1;   // main / correction accumulators of row block 0 / 1
+    // main / correction accumulators: [column block A / B][row block 0 / 1]
+    f32x16 mA0, mA1, mB0, mB1, cA0, cA1, cB0, cB1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        m0[i] = 0.f;
-        c0[i] = 0.f;
-        c1[i] = 0.f;
+        mA0[i] = 0.f; mB0[i] = 0.f;
+        cA0[i] = 0.f; cA1[i] = 0.f; cB0[i] = 0.f; cB1[i] = 0.f;
     }
     if (L.bias != nullptr && active) {
-        const float* bp = L.bias + cb * 32 + 4 * half;   // the lane's 4 x 4 features
+        const float* bp = L.bias + cbA * 32 + 4 * half;   // the lane's 4 x 4 features
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * j);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m0[4 * j + k] = b4[k];
+            for (int k = 0; k < 4; ++k) mA0[4 * j + k] = b4[k];
+            if (two) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(bp + 32 * SWAVES + 8 * j);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mB0[4 * j + k] = c4[k];
+            }
         }
     }
-    m1 = m0;
-    if (active) {
-        for (int sidx = 0; sidx < L.nseg; ++sidx) {
-            const Seg& sg = L.seg[sidx];
-            const _Float16* srch = sg.src == 0 ? S.Xh : S.Eh;
-            const _Float16* srcl = sg.src == 0 ? S.Xl : S.El;
-            const int ld = sg.src == 0 ? LDH : LEH;
-            const int ks = sg.kq >> 1;   // 16-wide steps
-            const int aoff = (rb * 32 + r) * ld + 8 * half;
-            // weights: per (column block, step): hi fragment (64 lanes x 16 B) then lo fragment
-            const f16x8* wp = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cb * ks * 128 + lane;
-            // two 16-wide steps in flight: even/odd operand sets live in their own registers and are
-            // re-loaded right after their last use (see csrc/mlp.hip); ks is even (K padded to 32)
-            f16x8 bhE = wp[0], blE = wp[64], bhO = wp[128], blO = wp[192];
-            if (both) {
-                const _Float16* a0h = srch + aoff;
-                const _Float16* a0l = srcl + aoff;
-                const _Float16* a1h = srch + aoff + 32 * ld;
-                const _Float16* a1l = srcl + aoff + 32 * ld;
-                f16x8 ah0E = *reinterpret_cast<const f16x8*>(a0h), al0E = *reinterpret_cast<const f16x8*>(a0l);
-                f16x8 ah1E = *reinterpret_cast<const f16x8*>(a1h), al1E = *reinterpret_cast<const f16x8*>(a1l);
-                f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
-                f16x8 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16), al1O = *reinterpret_cast<const f16x8*>(a1l + 16);
-                for (int s = 0; s < ks; s += 2) {
-                    const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
-                    PR_MFMA16(m0, ah0E, bhE);
-                    PR_MFMA16(m1, ah1E, bhE);
-                    PR_MFMA16(c0, ah0E, blE);
-                    PR_MFMA16(c1, ah1E, blE);
-                    PR_MFMA16(c0, al0E, bhE);
-                    PR_MFMA16(c1, al1E, bhE);
-                    if (!(PR_SPLIT_ABLATE & 1)) {
-                        bhE = wp[(size_t)se * 128];
-                        blE = wp[(size_t)se * 128 + 64];
-                    }
-                    if (!(PR_SPLIT_ABLATE & 2)) {
-                        ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
-                        al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
-                        ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
-                        al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
-                    }
-                    PR_MFMA16(m0, ah0O, bhO);
-                    PR_MFMA16(m1, ah1O, bhO);
-                    PR_MFMA16(c0, ah0O, blO);
-                    PR_MFMA16(c1, ah1O, blO);
-                    PR_MFMA16(c0, al0O, bhO);
-                    PR_MFMA16(c1, al1O, bhO);
-                    if (!(PR_SPLIT_ABLATE & 1)) {
-                        bhO = wp[(size_t)so * 128];
-                        blO = wp[(size_t)so * 128 + 64];
-                    }
-                    if (!(PR_SPLIT_ABLATE & 2)) {
-                        ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
-                        al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
-                        ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
-                        al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                }
-            } else {
-                const _Float16* a0h = srch + aoff;
-                const _Float16* a0l = srcl + aoff;
-                f16x8 ah0E = *reinterpret_cast<const f16x8*>(a0h), al0E = *reinterpret_cast<const f16x8*>(a0l);
-                f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
-                for (int s = 0; s < ks; s += 2) {
-                    const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
-                    PR_MFMA16(m0, ah0E, bhE);
-                    PR_MFMA16(c0, ah0E, blE);
-                    PR_MFMA16(c0, al0E, bhE);
-                    if (!(PR_SPLIT_ABLATE & 1)) {
-                        bhE = wp[(size_t)se * 128];
-                        blE = wp[(size_t)se * 128 + 64];
-                    }
-                    ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
-                    al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
-                    PR_MFMA16(m0, ah0O, bhO);
-                    PR_MFMA16(c0, ah0O, blO);
-                    PR_MFMA16(c0, al0O, bhO);
-                    if (!(PR_SPLIT_ABLATE & 1)) {
-                        bhO = wp[(size_t)so * 128];
-                        blO = wp[(size_t)so * 128 + 64];
-                    }
-                    ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
-                    al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
+    mA1 = mA0;
+    mB1 = mB0;
+    for (int sidx = 0; sidx < L.nseg; ++sidx) {
+        const Seg& sg = L.seg[sidx];
+        if (sg.src == 1 && sidx > 0) {
+            __syncthreads();
+            if (input_kind == 1) fill_bender_input_h(S, p); else fill_nerf_input_h(S, p);
+            __syncthreads();
+        }
+        if (!active) continue;
+        const int ks = sg.kq >> 1;   // 16-wide steps, even (K padded to 32)
+        const int aoff = r * LDH + 8 * half;
+        const _Float16* a0h = S.Xh + aoff;
+        const _Float16* a0l = S.Xl + aoff;
+        const _Float16* a1h = S.Xh + aoff + 32 * LDH;
+        const _Float16* a1l = S.Xl + aoff + 32 * LDH;
+        // weights: per (column block, step): hi fragment (64 lanes x 16 B) then lo fragment
+        const f16x8* wpA = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cbA * ks * 128 + lane;
+        f16x8 ah0E = *reinterpret_cast<const f16x8*>(a0h), al0E = *reinterpret_cast<const f16x8*>(a0l);
+        f16x8 ah1E = *reinterpret_cast<const f16x8*>(a1h), al1E = *reinterpret_cast<const f16x8*>(a1l);
+        f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
+        f16x8 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16), al1O = *reinterpret_cast<const f16x8*>(a1l + 16);
+        f16x8 bAhE = wpA[0], bAlE = wpA[64], bAhO = wpA[128], bAlO = wpA[192];
+        if (two) {
+            const f16x8* wpB = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cbB * ks * 128 + lane;
+            f16x8 bBhE = wpB[0], bBlE = wpB[64], bBhO = wpB[128], bBlO = wpB[192];
+            for (int s = 0; s < ks; s += 2) {
+                const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                PR_SPLIT3(mA0, cA0, ah0E, al0E, bAhE, bAlE);
+                PR_SPLIT3(mA1, cA1, ah1E, al1E, bAhE, bAlE);
+                PR_SPLIT3(mB0, cB0, ah0E, al0E, bBhE, bBlE);
+                PR_SPLIT3(mB1, cB1, ah1E, al1E, bBhE, bBlE);
+                bAhE = wpA[(size_t)se * 128];
+                bAlE = wpA[(size_t)se * 128 + 64];
+                bBhE = wpB[(size_t)se * 128];
+                bBlE = wpB[(size_t)se * 128 + 64];
+                ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
+                al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
+                ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
+                al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
+                PR_SPLIT3(mA0, cA0, ah0O, al0O, bAhO, bAlO);
+                PR_SPLIT3(mA1, cA1, ah1O, al1O, bAhO, bAlO);
+                PR_SPLIT3(mB0, cB0, ah0O, al0O, bBhO, bBlO);
+                PR_SPLIT3(mB1, cB1, ah1O, al1O, bBhO, bBlO);
+                bAhO = wpA[(size_t)so * 128];
+                bAlO = wpA[(size_t)so * 128 + 64];
+                bBhO = wpB[(size_t)so * 128];
+                bBlO = wpB[(size_t)so * 128 + 64];
+                ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
+                al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
+                ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
+                al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+        } else {
+            for (int s = 0; s < ks; s += 2) {
+                const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                PR_SPLIT3(mA0, cA0, ah0E, al0E, bAhE, bAlE);
+                PR_SPLIT3(mA1, cA1, ah1E, al1E, bAhE, bAlE);
+                bAhE = wpA[(size_t)se * 128];
+                bAlE = wpA[(size_t)se * 128 + 64];
+                ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
+                al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
+                ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
+                al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
+                PR_SPLIT3(mA0, cA0, ah0O, al0O, bAhO, bAlO);
+                PR_SPLIT3(mA1, cA1, ah1O, al1O, bAhO, bAlO);
+                bAhO = wpA[(size_t)so * 128];
+                bAlO = wpA[(size_t)so * 128 + 64];
+                ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
+                al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
+                ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
+                al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
         }
     }
@@ -261,24 +256,27 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     __syncthreads();  // every wave has finished reading the activation planes
     PR_PHASE(4);
     if (active && !((PR_SPLIT_ABLATE & 8) && L.epi != EPI_FEATURES)) {
-        const int feat0 = cb * 32 + 4 * half;              // first feature of this lane
-        const int row0 = (both ? 0 : rb * 32) + r;         // sample row of this lane in m0 / c0 (m1 / c1: + 32)
-        if (L.epi == EPI_RELU) {
-            store_relu_h(m0, c0, S, row0 * LDH + feat0);
-            if (both) store_relu_h(m1, c1, S, (row0 + 32) * LDH + feat0);
-        } else if (L.epi == EPI_ADAIN_RELU) {
-            const int bofs = L.nblk * 32;
-            const bool uniform = S.uniform_frame != 0;
-            const float* tab0 = p.adain + (size_t)S.frame[uniform ? 0 : row0] * p.adain_stride + L.adain_off + feat0;
-            store_adain_h(m0, c0, S, row0 * LDH + feat0, tab0, tab0 + bofs);
-            if (both) {
-                const float* tab1 = p.adain + (size_t)S.frame[uniform ? 0 : row0 + 32] * p.adain_stride + L.adain_off + feat0;
-                store_adain_h(m1, c1, S, (row0 + 32) * LDH + feat0, tab1, tab1 + bofs);
+        for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+            const int feat0 = (blk ? cbB : cbA) * 32 + 4 * half;   // first feature of this lane
+            const f32x16& m0 = blk ? mB0 : mA0;   // samples 0..31
+            const f32x16& c0 = blk ? cB0 : cA0;
+            const f32x16& m1 = blk ? mB1 : mA1;   // samples 32..63
+            const f32x16& c1 = blk ? cB1 : cA1;
+            if (L.epi == EPI_RELU) {
+                store_relu_h(m0, c0, S, r * LDH + feat0);
+                store_relu_h(m1, c1, S, (r + 32) * LDH + feat0);
+            } else if (L.epi == EPI_ADAIN_RELU) {
+                const int bofs = L.nblk * 32;
+                const bool uniform = S.uniform_frame != 0;
+                const float* t0 = p.adain + (size_t)S.frame[uniform ? 0 : r] * p.adain_stride + L.adain_off + feat0;
+                const float* t1 = p.adain + (size_t)S.frame[uniform ? 0 : r + 32] * p.adain_stride + L.adain_off + feat0;
+                store_adain_h(m0, c0, S, r * LDH + feat0, t0, t0 + bofs);
+                store_adain_h(m1, c1, S, (r + 32) * LDH + feat0, t1, t1 + bofs);
+            } else {
+                float* stage = reinterpret_cast<float*>(S.Xh);
+                store_stage_h(m0, c0, stage + r * LDSTAGE + feat0);
+                store_stage_h(m1, c1, stage + (r + 32) * LDSTAGE + feat0);
             }
-        } else {
-            float* stage = reinterpret_cast<float*>(S.Xh);
-            store_stage_h(m0, c0, stage + row0 * LDSTAGE + feat0);
-            if (both) store_stage_h(m1, c1, stage + (row0 + 32) * LDSTAGE + feat0);
         }
     }
     PR_PHASE(5);
@@ -286,38 +284,54 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     PR_PHASE(6);
 }
 
+// (re)computes a network input into columns [0, pad) of the activation planes (see fill_encoding in mlp.hip)
 __device__ __forceinline__ void fill_encoding_h(SmemH& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
                                                 const float* octave_weights, bool normalise) {
-    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
-    float v[6];
-    for (int a = 0; a < din; ++a) {
-        const float x = S.pos[s * 8 + a];
-        v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
-    }
-    const int row = s * LEH;
-    if (part == 0)
-        for (int a = 0; a < din; ++a) split_store(S.Eh, S.El, row + a, v[a]);
-    if (part == 1)
-        for (int j = zero_from; j < pad; ++j) split_store(S.Eh, S.El, row + j, 0.f);
-    for (int k = part; k < octaves; k += 8) {
-        const float f = ldexpf(1.0f, k);
-        const float w = octave_weights ? octave_weights[k] : 1.0f;
-        const int dst = row + din + k * 2 * din;
+    const int part = threadIdx.x & 7;
+    for (int s = threadIdx.x >> 3; s < STILE_M; s += STHREADS / 8) {
+        float v[6];
         for (int a = 0; a < din; ++a) {
-            const float arg = __fmul_rn(f, v[a]);
-            float sn = sinf(arg), cs = cosf(arg);
-            if (octave_weights) {
-                sn = __fmul_rn(sn, w);
-                cs = __fmul_rn(cs, w);
+            const float x = S.pos[s * 8 + a];
+            v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+        }
+        const int row = s * LDH;
+        if (part == 0)
+            for (int a = 0; a < din; ++a) split_store(S.Xh, S.Xl, row + a, v[a]);
+        if (part == 1)
+            for (int j = zero_from; j < pad; ++j) split_store(S.Xh, S.Xl, row + j, 0.f);
+        for (int k = part; k < octaves; k += 8) {
+            const float f = ldexpf(1.0f, k);
+            const float w = octave_weights ? octave_weights[k] : 1.0f;
+            const int dst = row + din + k * 2 * din;
+            for (int a = 0; a < din; ++a) {
+                const float arg = __fmul_rn(f, v[a]);
+                float sn = sinf(arg), cs = cosf(arg);
+                if (octave_weights) {
+                    sn = __fmul_rn(sn, w);
+                    cs = __fmul_rn(cs, w);
+                }
+                split_store(S.Xh, S.Xl, dst + a, sn);
+                split_store(S.Xh, S.Xl, dst + din + a, cs);
             }
-            split_store(S.Eh, S.El, dst + a, sn);
-            split_store(S.Eh, S.El, dst + din + a, cs);
         }
     }
 }
 
-__device__ __forceinline__ void row_dots_h(const SmemH& S, const float* w, int width, int wstride, int nout, float* out) {
-    const int s = threadIdx.x >> 3, part = threadIdx.x & 7;
+__device__ __forceinline__ void fill_nerf_input_h(SmemH& S, const MlpParams& p) {
+    fill_encoding_h(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+}
+
+__device__ __forceinline__ void fill_bender_input_h(SmemH& S, const MlpParams& p) {
+    fill_encoding_h(S, p, 3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, true);
+    for (int idx = threadIdx.x; idx < STILE_M * p.D; idx += STHREADS) {
+        const int s = idx / p.D, j = idx - s * p.D;
+        split_store(S.Xh, S.Xl, s * LDH + p.benc + j, p.deformation[(size_t)S.frame[s] * p.deformation_stride + j]);
+    }
+}
+
+// dot products of tile row `s` with `nout` (<= 3) weight rows; 8 threads per row, result valid in all 8
+__device__ __forceinline__ void row_dots_h(const SmemH& S, int s, const float* w, int width, int wstride, int nout, float* out) {
+    const int part = threadIdx.x & 7;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int k = part; k < width; k += 8) {
         const float x = split_load(S.Xh, S.Xl, s * LDH + k);
@@ -332,7 +346,7 @@ __device__ __forceinline__ void row_dots_h(const SmemH& S, const float* w, int w
     }
 }
 
-__global__ __launch_bounds__(STHREADS) void k_mlp_split(MlpParams p) {
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
     const int tid = threadIdx.x;
@@ -373,18 +387,13 @@ __global__ __launch_bounds__(STHREADS) void k_mlp_split(MlpParams p) {
         PR_PHASE(0);
 
         if (p.has_bender) {
-            fill_encoding_h(S, p, 3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, true);
-            for (int idx = tid; idx < STILE_M * p.D; idx += STHREADS) {
-                const int s = idx / p.D, j = idx - s * p.D;
-                split_store(S.Eh, S.El, s * LEH + p.benc + j, p.deformation[(size_t)S.frame[s] * p.deformation_stride + j]);
-            }
+            fill_bender_input_h(S, p);
             __syncthreads();
-            for (int l = 0; l < p.b_count; ++l) run_layer_h(p.b_layers[l], S, p);
-            float out[3];
-            row_dots_h(S, p.b_out, p.BWpad, p.BWpad, 3, out);
-            __syncthreads();
-            if ((tid & 7) == 0) {
-                const int s = tid >> 3;
+            for (int l = 0; l < p.b_count; ++l) run_layer_h(p.b_layers[l], S, p, /*input_kind=*/1);
+            for (int s = tid >> 3; s < STILE_M; s += STHREADS / 8) {
+                float out[3];
+                row_dots_h(S, s, p.b_out, p.BWpad, p.BWpad, 3, out);
+                if ((tid & 7) != 0) continue;
                 float d[3], bent[3];
                 for (int a = 0; a < 3; ++a) {
                     const float x = S.pos[s * 8 + a];
@@ -409,25 +418,24 @@ __global__ __launch_bounds__(STHREADS) void k_mlp_split(MlpParams p) {
         }
         PR_PHASE(1);
 
-        fill_encoding_h(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+        fill_nerf_input_h(S, p);
         __syncthreads();
         PR_PHASE(2);
-        for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p);
+        for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p, 0);
         PR_PHASE(15);
 
         if (p.kind == 0) {
-            float sg;
-            row_dots_h(S, S.head_w, p.Wpad, p.Wpad, 1, &sg);
-            if ((tid & 7) == 0) {
-                const int s = tid >> 3;
-                if ((S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
+            for (int s = tid >> 3; s < STILE_M; s += STHREADS / 8) {
+                float sg;
+                row_dots_h(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
+                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
             }
         } else if (tid < STILE_M) {
             if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
         }
 
         PR_PHASE(7);
-        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p);
+        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p, 0);
         PR_PHASE(15);
 
         // feature rows: the last layer staged an fp32 tile over the activation planes
@@ -472,7 +480,8 @@ int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
         cu_count = prop.multiProcessorCount;
         attr_set = true;
     }
-    const int grid = max_tiles < cu_count ? max_tiles : cu_count;
+    const int resident = cu_count * SBLOCKS_PER_CU;
+    const int grid = max_tiles < resident ? max_tiles : resident;
     ProfileScope scope(0, s);
     hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();
