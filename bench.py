@@ -142,13 +142,20 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the renderer)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PR_BENCH_DEVICE / PR_BENCH_BACKEND: test knobs (several ranks on one GPU over gloo exercise the multi-rank path
+    # where only one device exists); the defaults are one rank per GPU over RCCL
+    device_index = int(os.environ.get("PR_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("PR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from playableenvironments_amd import configs, synthetic, _lib
     from playableenvironments_amd.environment_model import EnvironmentModel
