@@ -525,6 +525,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             __syncthreads();
         }
         if (!active || (p.debug & 128)) continue;
+        // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
+        __builtin_amdgcn_s_setprio(1);
         const int kq = sg.kq;   // even (K is padded to a multiple of 16)
         const float* ap = S.X + r * LDX + half * 4 * kq;
         const float4* wpA = reinterpret_cast<const float4*>(sg.w) + (size_t)cbA * kq * 64 + lane;
@@ -584,6 +586,7 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     if (p.debug & 4) return;  // ablation: no barriers, no epilogue
     PR_PHASE(3);

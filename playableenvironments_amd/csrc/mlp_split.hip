@@ -175,6 +175,7 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             __syncthreads();
         }
         if (!active) continue;
+        __builtin_amdgcn_s_setprio(1);   // matrix work outranks the other resident tile's serial phases
         const int ks = sg.kq >> 1;   // 16-wide steps, even (K padded to 32)
         const int aoff = r * LDH + 8 * half;
         const _Float16* a0h = S.Xh + aoff;
@@ -251,6 +252,7 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     PR_PHASE(3);
     __syncthreads();  // every wave has finished reading the activation planes
