@@ -219,6 +219,27 @@ def check_wire_format():
     return ok
 
 
+def check_ray_object_distances():
+    """EnvironmentModel.compute_ray_object_distances of the product against the reference method (exact)."""
+    from model.environment_model import EnvironmentModel as RefEnv
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    cfg = configs.minecraft_config()
+    mine = EnvironmentModel(cfg)
+    scene = synthetic.minecraft_scene(batch=2, seed=3)
+    o, d, n, w2o, *_ = scene_to_composer_inputs(cfg, scene, None, grid_pixels(256, 256, 10))
+    _, o2w = ro.object_matrices(scene["object_rotation_parameters"], scene["object_translation_parameters"])
+    o2w = o2w[..., 0, :, :, :]
+    holder = type("Holder", (), {})()
+    holder.object_id_helper = mine.object_id_helper
+    ref_composer = refshim.build_reference_composer(copy.deepcopy(cfg))
+    holder.object_composer = ref_composer
+    want = RefEnv.compute_ray_object_distances(holder, o, d, o2w)
+    got = mine.compute_ray_object_distances(o, d, o2w)
+    ok = torch.equal(want, got)
+    print(f"[ray-object distances] shape {tuple(got.shape)} identical: {ok}")
+    return ok
+
+
 def grid_pixels(h, w, n):
     r = torch.linspace(0, h - 1, n).long()
     c = torch.linspace(0, w - 1, n).long()
@@ -312,6 +333,7 @@ def main():
                                       grid_pixels(256, 256, 24), 0, perturb=False, alpha_bias=3.0)
     ok &= check_samplers()
     ok &= check_wire_format()
+    ok &= check_ray_object_distances()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

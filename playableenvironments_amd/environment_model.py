@@ -181,6 +181,25 @@ class EnvironmentModel(nn.Module):
         pscale = torch.as_tensor([width, height], dtype=out.dtype, device=out.device).unsqueeze(-1)
         return (out + pscale / 2) / pscale
 
+    def compute_ray_object_distances(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor,
+                                     transformation_matrix_o2w: torch.Tensor) -> torch.Tensor:
+        """Squared distance between every ray (a line) and every object's box centre.
+
+        ray_origins (..., C, 3); ray_directions (..., C, R, 3); transformation_matrix_o2w (..., 4, 4, K) ->
+        (..., C, R, K).  model/environment_model.py:653-706."""
+        origins = ray_origins.unsqueeze(-2)
+        unit = ray_directions / torch.norm(ray_directions, dim=-1, keepdim=True)
+        out = []
+        for k in range(self.object_id_helper.objects_count):
+            model = self.object_composer.object_models_coarse[self.object_id_helper.model_idx_by_object_idx(k)]
+            m = transformation_matrix_o2w[..., k]
+            centre = model.bounding_box.get_center_offset(device=origins.device)
+            centre = torch.sum(centre.unsqueeze(-2) * m[..., :3, :3], -1) + m[..., :3, -1]      # object -> world
+            to_object = origins - centre.unsqueeze(-2).unsqueeze(-2)
+            along = torch.sum(to_object * unit, dim=-1)
+            out.append((to_object - along.unsqueeze(-1) * unit).pow(2).sum(-1))
+        return torch.stack(out, dim=-1)
+
     # ------------------------------------------------------------------ composer plumbing
     def batchified_composer_call(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                  deformation, object_in_scene, perturb, samples_per_image_batching: int = 0,

@@ -29,6 +29,11 @@ class BoundingBox(nn.Module):
     def get_size(self) -> torch.Tensor:
         return self.dimensions[:, 1] - self.dimensions[:, 0]
 
+    def get_center_offset(self, device=None) -> torch.Tensor:
+        """Centre of the box relative to the canonical centre (0, 0, 0)  (bounding_box.py:23-33)."""
+        centre = self.dimensions[:, 0] + (self.dimensions[:, 1] - self.dimensions[:, 0]) / 2
+        return centre if device is None else centre.to(device)
+
     def get_corner_points(self) -> torch.Tensor:
         """(8, 3) corners in the reference's order (bounding_box.py:58-98): 0 = all-low, 6 = all-high."""
         lo, hi = self.dimensions[:, 0], self.dimensions[:, 1]

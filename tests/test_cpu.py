@@ -522,3 +522,24 @@ def test_wire_format_grid_samplers():
     ppos = torch.stack([rr.reshape(-1), cc.reshape(-1)], -1).unsqueeze(0)
     region = wf.sample_original_region_from_patch_samples(obs, ppos, 4)
     assert torch.equal(region, obs[:, :, 8:24, 12:28])
+
+
+def test_ray_object_distances_closed_form():
+    """EnvironmentModel.compute_ray_object_distances: squared point-line distance to the box centres (the exact
+    comparison with the reference method runs in oracle/check_against_reference.py)."""
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    cfg = configs.minecraft_config()
+    model = EnvironmentModel(cfg)
+    k = model.object_id_helper.objects_count
+    o2w = torch.eye(4).reshape(1, 4, 4, 1).repeat(1, 1, 1, k).clone()
+    o2w[0, 0, 3, :] = torch.arange(k, dtype=torch.float32)             # object k shifted by k along x
+    origins = torch.tensor([[[0.0, 5.0, 0.0]]])                         # (1, C=1, 3)
+    dirs = torch.tensor([[[[0.0, -2.0, 0.0], [1.0, 0.0, 0.0]]]])       # straight down / along x
+    d = model.compute_ray_object_distances(origins, dirs, o2w)
+    assert tuple(d.shape) == (1, 1, 2, k)
+    centres = torch.stack([model.object_composer.object_models_coarse[model.object_id_helper.model_idx_by_object_idx(i)]
+                           .bounding_box.get_center_offset() for i in range(k)]) + torch.stack(
+                               [torch.tensor([float(i), 0.0, 0.0]) for i in range(k)])
+    want_down = centres[:, 0] ** 2 + centres[:, 2] ** 2                # line x = z = 0
+    want_x = (centres[:, 1] - 5.0) ** 2 + centres[:, 2] ** 2           # line y = 5, z = 0
+    assert torch.allclose(d[0, 0, 0], want_down, atol=1e-5) and torch.allclose(d[0, 0, 1], want_x, atol=1e-5)
