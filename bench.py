@@ -67,7 +67,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
     params = list(model.object_composer.parameters())
-    opt = torch.optim.Adam(params, lr=1e-5)
+    opt = torch.optim.Adam(params, lr=1e-5, fused=True)
     steps, warmup = max(1, args.steps), max(2, args.warmup)
 
     def step():

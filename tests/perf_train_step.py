@@ -39,7 +39,7 @@ def main():
     w2o.requires_grad_(True)
     sty.requires_grad_(True)
     dfm.requires_grad_(True)
-    opt = torch.optim.Adam(comp.parameters(), lr=1e-5)
+    opt = torch.optim.Adam(comp.parameters(), lr=1e-5, fused=True)
 
     def step():
         opt.zero_grad(set_to_none=True)
