@@ -240,6 +240,45 @@ def check_ray_object_distances():
     return ok
 
 
+def pose_math_case(write_to=None):
+    """w2o / o2w, image-plane boxes, projected box points and axes of the product's host math (batched over the objects,
+    closed-form rigid inverse) against the reference methods (per-object loops, torch.inverse).  fp32 tolerance: the
+    LU inverse and the closed form differ in the last bits.  ``write_to``: also store inputs + reference outputs there."""
+    from model.environment_model import EnvironmentModel as RefEnv
+    from playableenvironments_amd.environment_model import EnvironmentModel, euler_to_matrix, rigid_inverse
+    cfg = configs.minecraft_config()
+    mine = EnvironmentModel(cfg)
+    scene = synthetic.minecraft_scene(batch=2, observations=3, seed=41, image_size=(288, 512))
+    holder = type("Holder", (), {})()
+    holder.object_id_helper = mine.object_id_helper
+    holder.object_composer = refshim.build_reference_composer(copy.deepcopy(cfg))
+    rot, tr = scene["object_rotation_parameters"], scene["object_translation_parameters"]
+    focals = scene["focals"] * cfg["data"]["focal_length_multiplier"]
+    c2w = euler_to_matrix(scene["camera_rotations"], scene["camera_translations"])
+    w2c_ref = torch.inverse(c2w)
+    w2o_ref, o2w_ref = RefEnv.compute_transformation_matrix_w2o_o2w(holder, rot, tr)
+    boxes_ref, points_ref = RefEnv.compute_object_bounding_boxes(holder, o2w_ref, w2c_ref, focals, 288, 512)
+    axes_ref = RefEnv.compute_object_axes_projection(holder, o2w_ref, w2c_ref, focals, 288, 512)
+    w2o, o2w = mine.compute_transformation_matrix_w2o_o2w(rot, tr)
+    w2c = rigid_inverse(c2w)
+    boxes, points = mine.compute_object_bounding_boxes(o2w, w2c, focals, 288, 512)
+    axes = mine.compute_object_axes_projection(o2w, w2c, focals, 288, 512)
+    ok = True
+    for name, a, b in (("o2w", o2w_ref, o2w), ("w2o", w2o_ref, w2o), ("w2c", w2c_ref, w2c), ("boxes", boxes_ref, boxes),
+                       ("box points", points_ref, points), ("axes", axes_ref, axes)):
+        same = a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+        print(f"[pose math] {name}: shape {tuple(b.shape)} max abs diff {float((a - b).abs().max()):.2e} ok: {same}")
+        ok &= same
+    if write_to is not None:
+        import numpy as np
+        np.savez_compressed(write_to, camera_rotations=scene["camera_rotations"].numpy(),
+                            camera_translations=scene["camera_translations"].numpy(), focals=scene["focals"].numpy(),
+                            object_rotation_parameters=rot.numpy(), object_translation_parameters=tr.numpy(),
+                            w2o=w2o_ref.numpy(), o2w=o2w_ref.numpy(), w2c=w2c_ref.numpy(), boxes=boxes_ref.numpy(),
+                            box_points=points_ref.numpy(), axes=axes_ref.numpy())
+    return ok
+
+
 def grid_pixels(h, w, n):
     r = torch.linspace(0, h - 1, n).long()
     c = torch.linspace(0, w - 1, n).long()
@@ -334,6 +373,7 @@ def main():
     ok &= check_samplers()
     ok &= check_wire_format()
     ok &= check_ray_object_distances()
+    ok &= pose_math_case()
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

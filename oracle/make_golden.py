@@ -165,6 +165,8 @@ def main():
                    grid_pixels(256, 256, 12), alpha_bias=3.0)
     make_gradients("tennis_small_train_two_frames", {"base": "tennis", "reduce": REDUCE},
                    synthetic.tennis_scene(seed=33, batch=2), grid_pixels(256, 256, 8), perturb=False)
+    from oracle.check_against_reference import pose_math_case
+    assert pose_math_case(write_to=os.path.join(OUT, "host", "pose_math_minecraft.npz"))
     make("single_player_eval", {"base": "single", "reduce": REDUCE, "positions": {"player_1": (16, 16)}},
          synthetic.single_player_scene(seed=27, image_size=(16, 16)), None)
 

@@ -43,6 +43,18 @@ def euler_to_matrix(rotations: torch.Tensor, translations: torch.Tensor) -> torc
     return out
 
 
+def rigid_inverse(m: torch.Tensor) -> torch.Tensor:
+    """Inverse of (..., 4, 4) rigid transforms [R t; 0 1] = [R^T  -R^T t; 0 1].
+
+    The reference calls ``torch.inverse`` on these matrices (environment_model.py:221, :1078); on a GPU that is a batched
+    LU with a host synchronisation per call (five per frame), which serialises the host behind the previous frame's
+    render.  Every matrix on this path comes out of ``euler_to_matrix``, so the closed form applies; it agrees with the
+    LU inverse to fp32 rounding and differentiates through plain tensor ops."""
+    rt = m[..., :3, :3].transpose(-1, -2)
+    t = -torch.matmul(rt, m[..., :3, 3:4])
+    return torch.cat([torch.cat([rt, t], dim=-1), m[..., 3:4, :]], dim=-2)
+
+
 def strided_grid_pixels(height: int, width: int, strides) -> Tuple[torch.Tensor, torch.Tensor]:
     """(rows, cols) of RayHelper.sample_all_rays_strided_grid (utils/lib_3d/ray_helper.py:433-482,
     :533-582): pixel ``i*s + s//2`` for every stride, smallest stride first, row-major per stride."""
@@ -104,6 +116,10 @@ class EnvironmentModel(nn.Module):
         self.object_composer = ObjectComposer(config)
         self.object_id_helper = ObjectIDsHelper(config)
         self.current_step = 0
+        # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
+        self._pixel_cache: Dict = {}
+        self._edge_point_cache: Dict = {}
+        self._axes_point_cache: Dict = {}
 
     def set_step(self, current_step: int):
         self.current_step = current_step
@@ -124,47 +140,62 @@ class EnvironmentModel(nn.Module):
                                               object_translation_parameters_o2w: torch.Tensor):
         """(..., 3, K) poses -> w2o, o2w of shape (..., 1, 4, 4, K) (singleton cameras dim).
         model/environment_model.py:206-232."""
-        k = self.object_id_helper.objects_count
-        o2w = torch.stack([euler_to_matrix(object_rotation_parameters_o2w[..., i], object_translation_parameters_o2w[..., i])
-                           for i in range(k)], dim=-1)
-        w2o = torch.stack([torch.linalg.inv(o2w[..., i]) for i in range(k)], dim=-1)
-        return w2o.unsqueeze(-4), o2w.unsqueeze(-4)
+        if object_rotation_parameters_o2w.size(-1) != self.object_id_helper.objects_count:
+            raise Exception(f"poses given for {object_rotation_parameters_o2w.size(-1)} objects instead of "
+                            f"{self.object_id_helper.objects_count}")
+        # all K objects in one batch of (..., K, 4, 4) matrices, then back to the reference's trailing object dimension
+        o2w = euler_to_matrix(object_rotation_parameters_o2w.movedim(-1, -2), object_translation_parameters_o2w.movedim(-1, -2))
+        w2o = rigid_inverse(o2w)
+        return w2o.movedim(-3, -1).unsqueeze(-4), o2w.movedim(-3, -1).unsqueeze(-4)
 
     @staticmethod
     def _project(points: torch.Tensor, o2w: torch.Tensor, w2c: torch.Tensor, focals: torch.Tensor):
-        """Object-frame points (P, 3) -> image-plane coordinates (..., C, P, 2) relative to the image
-        centre (x right, y down) and the camera-frame z (..., C, P, 1).  environment_model.py:272-292."""
-        m = o2w.unsqueeze(-3)
-        world = torch.sum(points.unsqueeze(-2) * m[..., :3, :3], -1) + m[..., :3, -1]
-        world = world.unsqueeze(-3)
-        c = w2c.unsqueeze(-3)
-        cam = torch.sum(world.unsqueeze(-2) * c[..., :3, :3], -1) + c[..., :3, -1]
-        proj = -cam[..., :2] / cam[..., 2:3] * focals.unsqueeze(-1).unsqueeze(-1)
+        """Object-frame points (K, P, 3) of all K objects, o2w (..., 4, 4, K), w2c (..., C, 4, 4), focals (..., C) ->
+        image-plane coordinates (..., C, K, P, 2) relative to the image centre (x right, y down) and the camera-frame
+        z (..., C, K, P, 1).  environment_model.py:272-292, all objects in one pass."""
+        m = o2w.movedim(-1, -3).unsqueeze(-3)                                                   # (..., K, 1, 4, 4)
+        world = torch.sum(points.unsqueeze(-2) * m[..., :3, :3], -1) + m[..., :3, -1]           # (..., K, P, 3)
+        world = world.unsqueeze(-4)                                                             # (..., 1, K, P, 3)
+        c = w2c.unsqueeze(-3).unsqueeze(-3)                                                     # (..., C, 1, 1, 4, 4)
+        cam = torch.sum(world.unsqueeze(-2) * c[..., :3, :3], -1) + c[..., :3, -1]              # (..., C, K, P, 3)
+        proj = -cam[..., :2] / cam[..., 2:3] * focals.unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
         proj = torch.stack([proj[..., 0], -proj[..., 1]], dim=-1)
         return proj, cam[..., 2:3]
+
+    def _image_scale(self, width: int, height: int, like: torch.Tensor) -> torch.Tensor:
+        """(4, 1) [width, height, width, height] on the device of ``like`` (uploaded once: a per-call host-to-device copy
+        would stall the host behind the queued render)."""
+        key = ("scale", width, height, like.dtype, str(like.device))
+        if key not in self._pixel_cache:
+            self._pixel_cache[key] = torch.as_tensor([width, height, width, height], dtype=like.dtype, device=like.device).unsqueeze(-1)
+        return self._pixel_cache[key]
+
+    def _edge_points(self, device) -> torch.Tensor:
+        """(K, 68, 3) box corner + edge points of every object instance (the boxes are fixed buffers: built once per device)."""
+        key = str(device)
+        if key not in self._edge_point_cache:
+            helper = self.object_id_helper
+            self._edge_point_cache[key] = torch.stack(
+                [self.object_composer.object_models_coarse[helper.model_idx_by_object_idx(k)].bounding_box.get_edge_points()
+                 for k in range(helper.objects_count)], dim=0).to(device)
+        return self._edge_point_cache[key]
 
     def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width):
         """Image-plane boxes (..., C, 4, K) [left, top, right, bottom] and projected box points
         (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
         if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
             transformation_matrix_o2w = transformation_matrix_o2w[..., 0, :, :, :]
-        boxes, points = [], []
-        for k in range(self.object_id_helper.objects_count):
-            m = self.object_id_helper.model_idx_by_object_idx(k)
-            pts = self.object_composer.object_models_coarse[m].bounding_box.get_edge_points()
-            proj, z = self._project(pts, transformation_matrix_o2w[..., k], transformation_matrix_w2c, focals)
-            behind = (z > 0).expand_as(proj)
-            hi = torch.where(behind, torch.full_like(proj, 1e20), proj)
-            lo = torch.where(behind, torch.full_like(proj, -1e20), proj)
-            left, right = hi[..., 0].min(dim=-1)[0], lo[..., 0].max(dim=-1)[0]
-            top, bottom = hi[..., 1].min(dim=-1)[0], lo[..., 1].max(dim=-1)[0]
-            boxes.append(torch.stack([left, top, right, bottom], dim=-1))
-            points.append(proj)
-        boxes = torch.stack(boxes, dim=-1)
-        points = torch.stack(points, dim=-1)
-        scale = torch.as_tensor([width, height, width, height], dtype=boxes.dtype, device=boxes.device).unsqueeze(-1)
+        proj, z = self._project(self._edge_points(transformation_matrix_o2w.device), transformation_matrix_o2w,
+                                transformation_matrix_w2c, focals)                             # (..., C, K, 68, 2)
+        behind = (z > 0).expand_as(proj)
+        hi = torch.where(behind, 1e20, proj)
+        lo = torch.where(behind, -1e20, proj)
+        lo_xy, hi_xy = hi.min(dim=-2)[0], lo.max(dim=-2)[0]                                    # (..., C, K, 2) [x, y]
+        boxes = torch.cat([lo_xy, hi_xy], dim=-1).movedim(-2, -1)                              # (..., C, 4, K) left top right bottom
+        points = proj.movedim(-3, -1)                                                          # (..., C, 68, 2, K)
+        scale = self._image_scale(width, height, boxes)
         boxes = (boxes + scale / 2) / scale
-        pscale = torch.as_tensor([width, height], dtype=points.dtype, device=points.device).unsqueeze(-1)
+        pscale = scale[:2]
         points = (points + pscale / 2) / pscale
         return torch.clamp(boxes, min=0.0, max=1.0), torch.clamp(points, min=0.0, max=1.0)
 
@@ -173,12 +204,13 @@ class EnvironmentModel(nn.Module):
         model/environment_model.py:329-404."""
         if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
             transformation_matrix_o2w = transformation_matrix_o2w[..., 0, :, :, :]
-        pts = torch.tensor([(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)],
-                           device=transformation_matrix_o2w.device)
-        out = [self._project(pts, transformation_matrix_o2w[..., k], transformation_matrix_w2c, focals)[0]
-               for k in range(self.object_id_helper.objects_count)]
-        out = torch.stack(out, dim=-1)
-        pscale = torch.as_tensor([width, height], dtype=out.dtype, device=out.device).unsqueeze(-1)
+        key = str(transformation_matrix_o2w.device)
+        if key not in self._axes_point_cache:
+            self._axes_point_cache[key] = torch.tensor([(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)],
+                                                       device=transformation_matrix_o2w.device)
+        pts = self._axes_point_cache[key].unsqueeze(0).expand(self.object_id_helper.objects_count, 4, 3)
+        out = self._project(pts, transformation_matrix_o2w, transformation_matrix_w2c, focals)[0].movedim(-3, -1)
+        pscale = self._image_scale(width, height, out)[:2]
         return (out + pscale / 2) / pscale
 
     def compute_ray_object_distances(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor,
@@ -257,7 +289,7 @@ class EnvironmentModel(nn.Module):
         c2w = euler_to_matrix(camera_rotations, camera_translations)
         w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
                                                               object_translation_parameters_o2w)
-        w2c = torch.linalg.inv(c2w)
+        w2c = rigid_inverse(c2w)
         boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, rescaled_focals * upsample_factor, height, width)
         axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
 
@@ -266,11 +298,18 @@ class EnvironmentModel(nn.Module):
         if patch_size != 0 and samples_per_image != 0:
             idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
             rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
-        elif patch_stride and samples_per_image == 0:
-            rows, cols = strided_grid_pixels(height, width, patch_stride)
         elif samples_per_image == 0:
-            r = torch.arange(height * width, dtype=torch.int32)
-            rows, cols = r // width, r % width
+            # static pixel lists (every pixel, or the strided grids): built once per (size, strides, device)
+            strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)
+            key = (height, width, strides if patch_stride else None, str(c2w.device))
+            if key not in self._pixel_cache:
+                if patch_stride:
+                    rows, cols = strided_grid_pixels(height, width, patch_stride)
+                else:
+                    r = torch.arange(height * width, dtype=torch.int32)
+                    rows, cols = r // width, r % width
+                self._pixel_cache[key] = (rows.to(c2w.device), cols.to(c2w.device))
+            rows, cols = self._pixel_cache[key]
         elif self.use_weighted_sampling:
             idx = ray_sampling.sample_pixels_weighted(flat_boxes, self.sampling_weights, height, width, samples_per_image)
             rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)

@@ -324,7 +324,7 @@ class ObjectComposer(nn.Module):
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
         args = (ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation, object_in_scene,
                 perturb, canonical_pose, _noise, _export)
-        params = [p for p in self.parameters() if p.requires_grad]
+        params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
                                                   transformation_matrix_w2o.requires_grad)
         if not wants_grad:

@@ -543,3 +543,29 @@ def test_ray_object_distances_closed_form():
     want_down = centres[:, 0] ** 2 + centres[:, 2] ** 2                # line x = z = 0
     want_x = (centres[:, 1] - 5.0) ** 2 + centres[:, 2] ** 2           # line y = 5, z = 0
     assert torch.allclose(d[0, 0, 0], want_down, atol=1e-5) and torch.allclose(d[0, 0, 1], want_x, atol=1e-5)
+
+
+def test_pose_math_against_reference_fixture():
+    """Host pose math of EnvironmentModel (objects batched, closed-form rigid inverse, no host synchronisation) against
+    outputs of the reference's per-object torch.inverse path (tests/golden/host/pose_math_minecraft.npz, written by
+    oracle/make_golden.py)."""
+    from playableenvironments_amd.environment_model import EnvironmentModel, euler_to_matrix, rigid_inverse
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "host", "pose_math_minecraft.npz")).items()}
+    cfg = configs.minecraft_config()
+    model = EnvironmentModel(cfg)
+    w2o, o2w = model.compute_transformation_matrix_w2o_o2w(g["object_rotation_parameters"], g["object_translation_parameters"])
+    c2w = euler_to_matrix(g["camera_rotations"], g["camera_translations"])
+    w2c = rigid_inverse(c2w)
+    focals = g["focals"] * cfg["data"]["focal_length_multiplier"]
+    boxes, points = model.compute_object_bounding_boxes(o2w, w2c, focals, 288, 512)
+    axes = model.compute_object_axes_projection(o2w, w2c, focals, 288, 512)
+    for name, got in (("w2o", w2o), ("o2w", o2w), ("w2c", w2c), ("boxes", boxes), ("box_points", points), ("axes", axes)):
+        assert got.shape == g[name].shape, name
+        assert torch.allclose(got, g[name], rtol=1e-4, atol=1e-5), name
+    # the inverse really is one: w2o o2w = I for every (frame, object)
+    prod = torch.einsum("...ijk,...jlk->...ilk", w2o, o2w)
+    assert torch.allclose(prod, torch.eye(4).reshape(4, 4, 1).expand_as(prod), atol=1e-5)
+    # gradients flow to the pose parameters through the closed form
+    rot = g["object_rotation_parameters"].clone().requires_grad_(True)
+    model.compute_transformation_matrix_w2o_o2w(rot, g["object_translation_parameters"])[0].square().sum().backward()
+    assert torch.isfinite(rot.grad).all() and float(rot.grad.abs().max()) > 0
