@@ -263,7 +263,7 @@ def main():
     # HBM traffic of the dominant kernel from the committed PMC pass (collected separately: counters
     # cannot ride along with the timed run), and the fp32 MFMA rate this box sustains
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     if os.path.exists(pmc_path) and size == (256, 256):
         with open(pmc_path) as f:
             traffic = json.load(f)["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
@@ -307,7 +307,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (average over the launches of a step), rocprofv3 PMC pass, profiles/r01_pmc_traffic.json",
+            "traffic_unit": "HBM bytes per launch (average over the launches of a step), rocprofv3 PMC passes of tools/collect_pmc.sh, profiles/r01_pmc_summary.json",
             "peak_measured": probe,
             "flop_per_step": flops,
             "mlp_ms_per_step": round(mlp_ms, 3),

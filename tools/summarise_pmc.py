@@ -1,0 +1,48 @@
+"""Sums the rocprofv3 counter_collection CSVs of tools/collect_pmc.sh per kernel and prints the JSON kept under profiles/.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB; FETCH_SIZE is doubled for the wide (16 B/lane) streaming reads
+of these kernels as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950; WRITE_SIZE is left as is
+and cross-checked against the algorithmic bytes written (feature rows x row bytes)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+per = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(set)
+for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            name = row["Kernel_Name"].split("(")[0]
+            per[name][row["Counter_Name"]] += float(row["Counter_Value"])
+            calls[(name, row["Counter_Name"])].add(row["Dispatch_Id"])
+out = {"source": "tools/collect_pmc.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py --steps 1 --warmup 0 "
+                 "--no-cpu-baseline --no-train-step --no-split-precision (2 renders: the timed step + the sample-count pass)",
+       "renders": 2, "kernels": {}}
+for name, counters in sorted(per.items()):
+    if not name.startswith("pr::"):
+        continue
+    entry = {k: v for k, v in counters.items()}
+    entry["dispatches"] = max(len(calls[(name, k)]) for k in counters)
+    out["kernels"][name] = entry
+for kernel in ("pr::k_mlp_mfma", "pr::k_composite"):
+    k = out["kernels"].get(kernel)
+    if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        continue
+    launches = k["dispatches"]
+    fetch = k["FETCH_SIZE"] * 1024.0
+    write = k["WRITE_SIZE"] * 1024.0
+    out[kernel.split("::")[1]] = {
+        "launches_per_render": launches / out["renders"],
+        "fetch_bytes_per_render_raw": fetch / out["renders"],
+        "fetch_bytes_per_render_corrected_x2": 2 * fetch / out["renders"],
+        "write_bytes_per_render": write / out["renders"],
+        "hbm_bytes_per_launch_avg": (2 * fetch + write) / launches,
+    }
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in k and k.get("GRBM_GUI_ACTIVE"):
+        # the SQ counter is summed over the 1024 SIMDs (4 per CU x 256 CUs), GRBM_GUI_ACTIVE over the 8 XCDs
+        out[kernel.split("::")[1]]["mfma_busy_fraction"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
+print(json.dumps(out, indent=1))
