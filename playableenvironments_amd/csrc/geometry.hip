@@ -100,47 +100,78 @@ __device__ __forceinline__ void ray_bounds(const ObjRay& ray, const float* lo, c
 
 // ---------------------------------------------------------------------------------------------
 // Coarse placement: RayHelper.create_ray_positions (utils/lib_3d/ray_helper.py:1229-1282).
-// One thread per ray.  Writes t, the sigma fill, and the number of in-box samples per 256-ray block.
+// Phase 1: one lane per ray (slab test).  Phase 2: the wave walks its 64 rays together, lanes across the samples of
+// one ray, so that t / sigma / displacement rows are written as whole cache lines (a lane-per-ray walk writes one
+// float per line and lane: ~20x write amplification measured with WRITE_SIZE).  Also counts the in-box samples per
+// 256-ray block for the compaction.
 // ---------------------------------------------------------------------------------------------
+struct WaveRay {
+    float o[3], d[3];
+    int valid;
+};
+
+__device__ __forceinline__ WaveRay broadcast_ray(const ObjRay& ray, bool valid, int src) {
+    WaveRay w;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        w.o[a] = __shfl(ray.o[a], src, 64);
+        w.d[a] = __shfl(ray.d[a], src, 64);
+    }
+    w.valid = __shfl((int)valid, src, 64);
+    return w;
+}
+
 __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
     __shared__ int lds[4];
+    const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)p.frames * p.rays;
-    int count = 0;
+    ObjRay ray = {};
+    bool valid = false;
+    float z_near = 0.f, z_far = 0.f;
     if (g < total) {
         const int n = (int)(g / p.rays);
         const float* m = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
-        const ObjRay ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
-        const bool valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
-        float z_near, z_far;
+        ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
+        valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
         ray_bounds(ray, p.lo, p.hi, valid, p.z_near_min, p.z_far_max, &z_near, &z_far);
-        const int P = p.positions;
-        const size_t base = (size_t)g * P;
+    }
+    const int P = p.positions;
+    const long wave_first = g - lane;
+    int count = 0;
+    for (int r = 0; r < 64 && wave_first + r < total; ++r) {
+        const WaveRay w = broadcast_ray(ray, valid, r);
+        const float zn = __shfl(z_near, r, 64), zf = __shfl(z_far, r, 64);
+        const size_t base = (size_t)(wave_first + r) * P;
         // t_i = near * (1 - s_i) + far * s_i
         auto t_at = [&](int i) {
             const float s = p.linspace[i];
-            return __fadd_rn(__fmul_rn(z_near, __fsub_rn(1.0f, s)), __fmul_rn(z_far, s));
+            return __fadd_rn(__fmul_rn(zn, __fsub_rn(1.0f, s)), __fmul_rn(zf, s));
         };
-        float t_prev = 0.f, t_cur = t_at(0), t_next = (P > 1) ? t_at(1) : 0.f;
-        for (int i = 0; i < P; ++i) {
-            float t = t_cur;
-            if (p.jitter != nullptr) {
-                // mid points, upper = [mids, t_last], lower = [t_0, mids]   (:1267-1275)
-                const float upper = (i < P - 1) ? __fdiv_rn(__fadd_rn(t_next, t_cur), 2.0f) : t_cur;
-                const float lower = (i > 0) ? __fdiv_rn(__fadd_rn(t_cur, t_prev), 2.0f) : t_cur;
-                t = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), p.jitter[base + i]));
+        int ray_count = 0;
+        for (int i0 = 0; i0 < P; i0 += 64) {
+            const int i = i0 + lane;
+            bool inside = false;
+            if (i < P) {
+                const float t_cur = t_at(i);
+                float t = t_cur;
+                if (p.jitter != nullptr) {
+                    // mid points, upper = [mids, t_last], lower = [t_0, mids]   (:1267-1275)
+                    const float upper = (i < P - 1) ? __fdiv_rn(__fadd_rn(t_at(i + 1), t_cur), 2.0f) : t_cur;
+                    const float lower = (i > 0) ? __fdiv_rn(__fadd_rn(t_cur, t_at(i - 1)), 2.0f) : t_cur;
+                    t = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), p.jitter[base + i]));
+                }
+                p.t[base + i] = t;
+                p.sigma[base + i] = p.empty_alpha;
+                if (p.dispmag) p.dispmag[base + i] = 0.f;
+                const float x = __fadd_rn(w.o[0], __fmul_rn(w.d[0], t));
+                const float y = __fadd_rn(w.o[1], __fmul_rn(w.d[1], t));
+                const float z = __fadd_rn(w.o[2], __fmul_rn(w.d[2], t));
+                inside = w.valid && in_box(x, y, z, p.lo, p.hi);
             }
-            p.t[base + i] = t;
-            p.sigma[base + i] = p.empty_alpha;
-            if (p.dispmag) p.dispmag[base + i] = 0.f;
-            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
-            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
-            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
-            if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
-            t_prev = t_cur;
-            t_cur = t_next;
-            t_next = (i + 2 < P) ? t_at(i + 2) : 0.f;
+            ray_count += __popcll(__ballot(inside));
         }
+        if (lane == r) count = ray_count;
     }
     int block_total;
     block_exclusive_scan_256(count, lds, &block_total);
@@ -185,47 +216,65 @@ int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hi
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fill(FillParams p) {
     __shared__ int lds[4];
+    const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)p.frames * p.rays;
     const int P = p.positions;
-    int count = 0;
-    ObjRay ray;
+    ObjRay ray = {};
     bool valid = false;
     if (g < total) {
         const int n = (int)(g / p.rays);
         const float* m = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
         ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
         valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
-        const size_t base = (size_t)g * P;
-        for (int i = 0; i < P; ++i) {
-            const float t = p.t[base + i];
-            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
-            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
-            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
-            if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
-        }
     }
+    // lanes across the samples of one ray at a time (coalesced reads of t, whole-line writes of slot / records)
+    const long wave_first = g - lane;
+    auto walk = [&](auto&& per_ray) {
+        for (int r = 0; r < 64 && wave_first + r < total; ++r) {
+            const WaveRay w = broadcast_ray(ray, valid, r);
+            per_ray(r, w, (size_t)(wave_first + r) * P);
+        }
+    };
+    auto inside_at = [&](const WaveRay& w, size_t base, int i, float* x, float* y, float* z) {
+        if (i >= P) return false;
+        const float t = p.t[base + i];
+        *x = __fadd_rn(w.o[0], __fmul_rn(w.d[0], t));
+        *y = __fadd_rn(w.o[1], __fmul_rn(w.d[1], t));
+        *z = __fadd_rn(w.o[2], __fmul_rn(w.d[2], t));
+        return w.valid && in_box(*x, *y, *z, p.lo, p.hi);
+    };
+    int count = 0;
+    walk([&](int r, const WaveRay& w, size_t base) {
+        int ray_count = 0;
+        for (int i0 = 0; i0 < P; i0 += 64) {
+            float x, y, z;
+            ray_count += __popcll(__ballot(inside_at(w, base, i0 + lane, &x, &y, &z)));
+        }
+        if (lane == r) count = ray_count;
+    });
     int block_total;
-    int slot = p.block_offsets[blockIdx.x] + block_exclusive_scan_256(count, lds, &block_total);
-    if (g < total) {
-        const size_t base = (size_t)g * P;
-        for (int i = 0; i < P; ++i) {
-            const float t = p.t[base + i];
-            const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
-            const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
-            const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
-            if (valid && in_box(x, y, z, p.lo, p.hi)) {
-                p.rec_pos[(size_t)slot * 3 + 0] = x;
-                p.rec_pos[(size_t)slot * 3 + 1] = y;
-                p.rec_pos[(size_t)slot * 3 + 2] = z;
-                p.rec_flat[slot] = (int32_t)(base + i);
-                p.slot[base + i] = slot;
-                ++slot;
-            } else {
+    const int first_slot = p.block_offsets[blockIdx.x] + block_exclusive_scan_256(count, lds, &block_total);
+    walk([&](int r, const WaveRay& w, size_t base) {
+        int slot = __shfl(first_slot, r, 64);
+        for (int i0 = 0; i0 < P; i0 += 64) {
+            const int i = i0 + lane;
+            float x = 0.f, y = 0.f, z = 0.f;
+            const bool inside = inside_at(w, base, i, &x, &y, &z);
+            const unsigned long long mask = __ballot(inside);
+            if (inside) {
+                const int mine = slot + __popcll(mask & ((1ull << lane) - 1ull));
+                p.rec_pos[(size_t)mine * 3 + 0] = x;
+                p.rec_pos[(size_t)mine * 3 + 1] = y;
+                p.rec_pos[(size_t)mine * 3 + 2] = z;
+                p.rec_flat[mine] = (int32_t)(base + i);
+                p.slot[base + i] = mine;
+            } else if (i < P) {
                 p.slot[base + i] = -1;
             }
+            slot += __popcll(mask);
         }
-    }
+    });
 }
 
 int launch_fill(const FillParams& p, hipStream_t s) {
