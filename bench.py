@@ -167,7 +167,9 @@ def main():
     model.eval().to(dev)
     model.object_composer.precision = args.precision
     size = (args.image, args.image)
-    scene = synthetic.tennis_scene(seed=1234 + rank, image_size=size)
+    # the same frame on every rank: weak scaling with exactly the same work per GPU (a different frame per rank would
+    # make the max-over-ranks time follow the heaviest frame instead of the system)
+    scene = synthetic.tennis_scene(seed=1234, image_size=size)
     scene_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
 
     def step():

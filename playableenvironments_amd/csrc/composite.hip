@@ -50,6 +50,10 @@ __device__ __forceinline__ void transmittance_weights(float* al, int n, int lane
     }
 }
 
+#ifndef ROWS_IN_FLIGHT
+#define ROWS_IN_FLIGHT 8
+#endif
+
 __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     extern __shared__ __attribute__((aligned(16))) char raw_smem[];
     const int S = p.sort_size;
@@ -257,14 +261,19 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             count += __popcll(m);
         }
         __syncthreads();
+#if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE == 1
+        count = 0;   // measurement build: no feature rows are read
+#endif
         float acco[MAX_FCHUNK];
 #pragma unroll
         for (int c = 0; c < MAX_FCHUNK; ++c) acco[c] = 0.f;
         int i = 0;
-        for (; i + 4 <= count; i += 4) {
-            float v[4][MAX_FCHUNK];
+        // ROWS_IN_FLIGHT compact rows (768 B each) are requested before the first is consumed: a ray's LDS footprint
+        // leaves room for ~5 waves per CU only, so the bytes in flight have to come from the depth of each wave's queue
+        for (; i + ROWS_IN_FLIGHT <= count; i += ROWS_IN_FLIGHT) {
+            float v[ROWS_IN_FLIGHT][MAX_FCHUNK];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
                 const float* f = o.feat + (size_t)lrow[i + u] * F;
 #pragma unroll
                 for (int c = 0; c < MAX_FCHUNK; ++c) {
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
                 const float w1 = lw1[i + u], w2 = sm.al[i + u];
 #pragma unroll
                 for (int c = 0; c < MAX_FCHUNK; ++c) {
