@@ -61,6 +61,9 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     model = EnvironmentModel(cfg)
     synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
     model.train().to(dev)
+    # the BatchNorm sample-count check is read back asynchronously (raised at the next call) so that the host can
+    # enqueue the backward pass and the next step while the device works
+    model.object_composer.batchnorm_check = "deferred"
     size = (288, 512)
     scene = synthetic.minecraft_scene(batch=3, seed=77, image_size=size)   # same frames on every rank: weak scaling
     sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
@@ -81,7 +84,9 @@ def train_step_leg(args, dev, world, rank, dist, lib):
                 break
             except ValueError:
                 # a random patch that misses an object leaves its BatchNorm without samples: torch (and the reference)
-                # raise; a trainer would skip the batch - here the patch is re-drawn (before any collective)
+                # raise; a trainer would skip the batch - here the patch is re-drawn.  With the deferred check the error
+                # concerns the PREVIOUS step (whose update was harmless: no samples, no gradient) and this call simply
+                # proceeds
                 if attempt == 19:
                     raise
         loss = out["coarse"]["global"]["integrated_features"].square().mean()

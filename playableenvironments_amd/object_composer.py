@@ -185,6 +185,27 @@ class ObjectComposer(nn.Module):
         #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3": every product as three fp16 MFMAs with
         #: fp32 accumulation (a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) * 2^-11, ~22 significant bits) - eval only.
         self.precision = "fp32"
+        #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
+        #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
+        #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
+        #: "deferred" copies them to pinned memory asynchronously and raises the same ValueError at the NEXT call of the
+        #: composer (the affected call itself is harmless: an object without samples contributes nothing and its running
+        #: statistics are left alone), which lets the host run ahead of the device.
+        self.batchnorm_check = "eager"
+        self._pending_bn_check: Optional[tuple] = None
+
+    def _raise_pending_batchnorm_check(self):
+        pending, self._pending_bn_check = self._pending_bn_check, None
+        if pending is None:
+            return
+        host, event, types, count = pending
+        event.synchronize()
+        counts = host.tolist()
+        for i, ty in enumerate(types):
+            cur = counts[i * count:(i + 1) * count]
+            if any(c <= 1 for c in cur):
+                raise ValueError(f"Expected more than 1 value per channel when training, got {cur} evaluated "
+                                 f"samples per object ({ty} pass of the previous composer call)")
 
     # ------------------------------------------------------------------ construction
     def create_object_models(self, fine: bool) -> List[Optional[nn.Module]]:
@@ -317,6 +338,7 @@ class ObjectComposer(nn.Module):
         reference's trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (its loss weight
         is 0 in the shipped configurations; a second-order pass would be needed)."""
         K = self.object_id_helper.objects_count
+        self._raise_pending_batchnorm_check()
         if transformation_matrix_w2o.size(-1) != K:
             raise Exception(f"Transformation matrix must specifies transformations for"
                             f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
@@ -554,7 +576,16 @@ class ObjectComposer(nn.Module):
                              N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, models_fine=models_f, types=types,
                              ptot=ptot)
 
-        if self.training:
+        if self.training and self.batchnorm_check == "deferred":
+            counts = torch.cat([pieces[0][ty]["_normalised"] for ty in types])
+            host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(dev))
+            self._pending_bn_check = (host, event, list(types), K)
+        elif self.training:
+            if self.batchnorm_check != "eager":
+                raise ValueError(f"unknown batchnorm_check {self.batchnorm_check!r} (expected 'eager' or 'deferred')")
             # BatchNorm1d raises for a single value per channel (torch.nn.functional.batch_norm); the reference
             # does not guard against it (model/layers/adain.py:58) - one device read-back per training call
             for ty in types:

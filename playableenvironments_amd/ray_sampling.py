@@ -30,7 +30,7 @@ def _weight_masks(bounding_boxes: torch.Tensor, weights: Sequence[float], height
     left, right = left.clamp(0, width), right.clamp(0, width)
     top, bottom = top.clamp(0, height), bottom.clamp(0, height)
     area = (right - left) * (bottom - top)                                    # (N, K)
-    w = torch.as_tensor(list(weights), dtype=torch.float32, device=bb.device)
+    w = _object_weights(weights, bb.device)
     per_object = w.unsqueeze(0) / area                                         # inf / nan for empty boxes, as the reference
     if guard_zero_area:
         per_object = torch.where(area != 0, per_object, torch.zeros_like(per_object))
@@ -42,6 +42,18 @@ def _weight_masks(bounding_boxes: torch.Tensor, weights: Sequence[float], height
     for obj in range(k):  # sequential accumulation in object order, like the reference's += loop
         mask = mask + torch.where(inside[..., obj], per_object[:, obj].view(n, 1, 1), torch.zeros((), device=bb.device))
     return mask.reshape(n, height * width)
+
+
+_OBJECT_WEIGHTS = {}
+
+
+def _object_weights(weights: Sequence[float], device) -> torch.Tensor:
+    """The per-object sampling weights as a device tensor (uploaded once: a host-to-device copy per call would stall
+    the host behind the queued kernels)."""
+    key = (tuple(float(v) for v in weights), str(device))
+    if key not in _OBJECT_WEIGHTS:
+        _OBJECT_WEIGHTS[key] = torch.as_tensor(list(weights), dtype=torch.float32, device=device)
+    return _OBJECT_WEIGHTS[key]
 
 
 def _sample_cdf(weights: torch.Tensor, count: int) -> torch.Tensor:
@@ -92,30 +104,44 @@ def strided_patch_pixels(bounding_boxes: torch.Tensor, weights: Sequence[float],
     sizes = [(patch_size * s0) // s for s in strides]
     half = sizes[-1] // 2
     mask = _weight_masks(bounding_boxes, weights, height, width, guard_zero_area=False)
-    centres = _sample_cdf(mask, 1)[:, 0].cpu().tolist()           # one small D2H copy for all frames
-    backward = list(range(sm // 2, sm)) + list(range(0, sm // 2))
-    forward = list(range(sm // 2 + sm, sm, -1)) + [0] + list(range(sm - 1, sm // 2, -1))
+    dev = mask.device
+    centres = _sample_cdf(mask, 1)[:, 0]                                       # (N,) flat pixel index, stays on the device
+    row = torch.div(centres, width, rounding_mode="floor")
+    col = centres - row * width
+    # min(hi, max(lo, x)): the patch stays inside the image
+    row = torch.clamp(torch.clamp(row, min=half * sm), max=height - sm * (half - 1) - 1)
+    col = torch.clamp(torch.clamp(col, min=half * sm), max=width - sm * (half - 1) - 1)
+    back, fwd = _alignment_tables(sm, dev)
 
-    def align(start: int) -> int:
+    def align(start: torch.Tensor) -> torch.Tensor:
+        # snap the patch start to the grid of the largest stride (offset sm // 2), towards the reference's side
         diff = start % sm
-        if diff != sm // 2:
-            start = start - backward[diff] if start >= sm // 2 else start + forward[diff]
-        return start
+        moved = torch.where(start >= sm // 2, start - back[diff], start + fwd[diff])
+        return torch.where(diff != sm // 2, moved, start)
 
-    out: List[torch.Tensor] = []
-    for flat in centres:
-        row, col = divmod(int(flat), width)
-        row = min(height - sm * (half - 1) - 1, max(half * sm, row))
-        col = min(width - sm * (half - 1) - 1, max(half * sm, col))
-        start_r, start_c = align(row - half * sm), align(col - half * sm)
-        parts = []
-        for s, size in zip(strides, sizes):
-            off = sm // 2 - s // 2
-            r = start_r - off + torch.arange(size) * s
-            c = start_c - off + torch.arange(size) * s
-            parts.append((r.view(-1, 1) * width + c.view(1, -1)).reshape(-1))
-        out.append(torch.cat(parts))
-    return torch.stack(out, 0).to(bounding_boxes.device)
+    start_r, start_c = align(row - half * sm), align(col - half * sm)         # (N,)
+    parts = []
+    for s, size in zip(strides, sizes):
+        off = sm // 2 - s // 2
+        steps = torch.arange(size, device=dev) * s
+        r = (start_r - off).unsqueeze(1) + steps                               # (N, size)
+        c = (start_c - off).unsqueeze(1) + steps
+        parts.append((r.unsqueeze(2) * width + c.unsqueeze(1)).reshape(r.size(0), size * size))
+    return torch.cat(parts, dim=1)
+
+
+_ALIGNMENT_TABLES = {}
+
+
+def _alignment_tables(sm: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per residue ``start % sm``: how far a patch start moves back (start >= sm // 2) or forward to reach the
+    residue sm // 2 (ray_helper.py:372-396).  Uploaded once per (stride, device)."""
+    key = (sm, str(device))
+    if key not in _ALIGNMENT_TABLES:
+        backward = list(range(sm // 2, sm)) + list(range(0, sm // 2))
+        forward = list(range(sm // 2 + sm, sm, -1)) + [0] + list(range(sm - 1, sm // 2, -1))
+        _ALIGNMENT_TABLES[key] = (torch.tensor(backward, device=device), torch.tensor(forward, device=device))
+    return _ALIGNMENT_TABLES[key]
 
 
 def split_indices(indices: torch.Tensor, width: int) -> Tuple[torch.Tensor, torch.Tensor]:

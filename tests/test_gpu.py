@@ -342,6 +342,18 @@ def test_train_mode_guards():
     blind = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 4))]
     with torch.no_grad(), pytest.raises(ValueError):
         comp(*blind, False)
+    # deferred check: the blind call returns finite results without a host synchronisation, the error surfaces at the
+    # next call of the composer, after which the composer is usable again
+    comp.batchnorm_check = "deferred"
+    with torch.no_grad():
+        out = comp(*blind, False)
+        assert torch.isfinite(out["coarse"]["global"]["integrated_features"]).all()
+        with pytest.raises(ValueError):
+            comp(*inputs, False)
+        out = comp(*inputs, False)
+        assert torch.isfinite(out["coarse"]["global"]["integrated_features"]).all()
+    torch.cuda.synchronize()
+    comp._raise_pending_batchnorm_check()      # the last call saw samples for every object: nothing pending to raise
 
 
 # --------------------------------------------------------------------------------------------
