@@ -121,6 +121,28 @@ __device__ __forceinline__ WaveRay broadcast_ray(const ObjRay& ray, bool valid, 
     return w;
 }
 
+// Lane layout of the cooperative phase: P2 = min(64, next power of two >= P) lanes per ray, 64 / P2 rays per pass, so
+// that short sample lists (16, 32 positions per ray) still use the whole wave.
+struct RayLanes {
+    int P2, per_pass, sub, idx;
+    unsigned long long sub_mask;
+    __device__ __forceinline__ RayLanes(int P, int lane) {
+        P2 = 1;
+        while (P2 < P && P2 < 64) P2 <<= 1;
+        per_pass = 64 / P2;
+        sub = lane / P2;
+        idx = lane - sub * P2;
+        sub_mask = (P2 == 64) ? ~0ull : ((1ull << P2) - 1ull);
+    }
+    // the bits of a wave ballot that belong to this lane's ray
+    __device__ __forceinline__ unsigned long long mine(unsigned long long ballot) const { return (ballot >> (sub * P2)) & sub_mask; }
+    // hands the per-ray value held by the lanes of ray (r0 + s) to lane r0 + s (the lane that owns that ray in phase 1)
+    __device__ __forceinline__ void collect(int value, int r0, int lane, int* owner_value) const {
+        const int v = __shfl(value, ((lane - r0) & (per_pass - 1)) * P2, 64);
+        if (lane >= r0 && lane < r0 + per_pass) *owner_value = v;
+    }
+};
+
 __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
     __shared__ int lds[4];
     const int lane = threadIdx.x & 63;
@@ -138,8 +160,11 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
     }
     const int P = p.positions;
     const long wave_first = g - lane;
+    const RayLanes L(P, lane);
     int count = 0;
-    for (int r = 0; r < 64 && wave_first + r < total; ++r) {
+    for (int r0 = 0; r0 < 64 && wave_first + r0 < total; r0 += L.per_pass) {
+        const int r = r0 + L.sub;
+        const bool live = wave_first + r < total;
         const WaveRay w = broadcast_ray(ray, valid, r);
         const float zn = __shfl(z_near, r, 64), zf = __shfl(z_far, r, 64);
         const size_t base = (size_t)(wave_first + r) * P;
@@ -149,10 +174,10 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
             return __fadd_rn(__fmul_rn(zn, __fsub_rn(1.0f, s)), __fmul_rn(zf, s));
         };
         int ray_count = 0;
-        for (int i0 = 0; i0 < P; i0 += 64) {
-            const int i = i0 + lane;
+        for (int i0 = 0; i0 < P; i0 += L.P2) {
+            const int i = i0 + L.idx;
             bool inside = false;
-            if (i < P) {
+            if (live && i < P) {
                 const float t_cur = t_at(i);
                 float t = t_cur;
                 if (p.jitter != nullptr) {
@@ -169,9 +194,9 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
                 const float z = __fadd_rn(w.o[2], __fmul_rn(w.d[2], t));
                 inside = w.valid && in_box(x, y, z, p.lo, p.hi);
             }
-            ray_count += __popcll(__ballot(inside));
+            ray_count += __popcll(L.mine(__ballot(inside)));
         }
-        if (lane == r) count = ray_count;
+        L.collect(ray_count, r0, lane, &count);
     }
     int block_total;
     block_exclusive_scan_256(count, lds, &block_total);
@@ -228,16 +253,17 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
         ray = object_ray(m, p.ray_origins + (size_t)n * 3, p.ray_directions + (size_t)g * 3);
         valid = p.in_scene[(size_t)n * p.objects + p.object_index] != 0;
     }
-    // lanes across the samples of one ray at a time (coalesced reads of t, whole-line writes of slot / records)
+    // lanes across the samples of a ray (coalesced reads of t, whole-line writes of slot / records)
     const long wave_first = g - lane;
+    const RayLanes L(P, lane);
     auto walk = [&](auto&& per_ray) {
-        for (int r = 0; r < 64 && wave_first + r < total; ++r) {
-            const WaveRay w = broadcast_ray(ray, valid, r);
-            per_ray(r, w, (size_t)(wave_first + r) * P);
+        for (int r0 = 0; r0 < 64 && wave_first + r0 < total; r0 += L.per_pass) {
+            const int r = r0 + L.sub;
+            per_ray(r0, r, wave_first + r < total, broadcast_ray(ray, valid, r), (size_t)(wave_first + r) * P);
         }
     };
-    auto inside_at = [&](const WaveRay& w, size_t base, int i, float* x, float* y, float* z) {
-        if (i >= P) return false;
+    auto inside_at = [&](bool live, const WaveRay& w, size_t base, int i, float* x, float* y, float* z) {
+        if (!live || i >= P) return false;
         const float t = p.t[base + i];
         *x = __fadd_rn(w.o[0], __fmul_rn(w.d[0], t));
         *y = __fadd_rn(w.o[1], __fmul_rn(w.d[1], t));
@@ -245,31 +271,31 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
         return w.valid && in_box(*x, *y, *z, p.lo, p.hi);
     };
     int count = 0;
-    walk([&](int r, const WaveRay& w, size_t base) {
+    walk([&](int r0, int r, bool live, const WaveRay& w, size_t base) {
         int ray_count = 0;
-        for (int i0 = 0; i0 < P; i0 += 64) {
+        for (int i0 = 0; i0 < P; i0 += L.P2) {
             float x, y, z;
-            ray_count += __popcll(__ballot(inside_at(w, base, i0 + lane, &x, &y, &z)));
+            ray_count += __popcll(L.mine(__ballot(inside_at(live, w, base, i0 + L.idx, &x, &y, &z))));
         }
-        if (lane == r) count = ray_count;
+        L.collect(ray_count, r0, lane, &count);
     });
     int block_total;
     const int first_slot = p.block_offsets[blockIdx.x] + block_exclusive_scan_256(count, lds, &block_total);
-    walk([&](int r, const WaveRay& w, size_t base) {
+    walk([&](int r0, int r, bool live, const WaveRay& w, size_t base) {
         int slot = __shfl(first_slot, r, 64);
-        for (int i0 = 0; i0 < P; i0 += 64) {
-            const int i = i0 + lane;
+        for (int i0 = 0; i0 < P; i0 += L.P2) {
+            const int i = i0 + L.idx;
             float x = 0.f, y = 0.f, z = 0.f;
-            const bool inside = inside_at(w, base, i, &x, &y, &z);
-            const unsigned long long mask = __ballot(inside);
+            const bool inside = inside_at(live, w, base, i, &x, &y, &z);
+            const unsigned long long mask = L.mine(__ballot(inside));
             if (inside) {
-                const int mine = slot + __popcll(mask & ((1ull << lane) - 1ull));
+                const int mine = slot + __popcll(mask & ((1ull << L.idx) - 1ull));
                 p.rec_pos[(size_t)mine * 3 + 0] = x;
                 p.rec_pos[(size_t)mine * 3 + 1] = y;
                 p.rec_pos[(size_t)mine * 3 + 2] = z;
                 p.rec_flat[mine] = (int32_t)(base + i);
                 p.slot[base + i] = mine;
-            } else if (i < P) {
+            } else if (live && i < P) {
                 p.slot[base + i] = -1;
             }
             slot += __popcll(mask);
