@@ -216,11 +216,18 @@ typedef struct pr_entry_grads_t {
     const float* depth;                               /* (N,R) */
     const float* integrated_displacements_magnitude;  /* (N,R): flows into the displacements only, the weights are
                                                          detached there (object_composer.py:772) */
+    const float* weights;                             /* (N,R,P) per object, (N,R,sum P) in merged order for the global
+                                                         entry: consumers of the compositing weights themselves
+                                                         (compute_expected_positions, object_composer.py:603-622) */
 } pr_entry_grads_t;
 
 typedef struct pr_output_grads_t {
     pr_entry_grads_t object[PR_MAX_OBJECTS];
     pr_entry_grads_t global;
+    /* gradients of the per-sample exports of pr_outputs_t (NULL = zero): the sample depths and the ray bender's
+       displacement vectors, which forward_expected_positions averages (object_composer.py:603-722) */
+    const float* sample_t[PR_MAX_OBJECTS];            /* (N,R,P) */
+    const float* sample_delta[PR_MAX_OBJECTS];        /* (N,R,P,3); objects with a ray bender */
 } pr_output_grads_t;
 
 /* Gradient buffers of one object model, shaped like the parameters (nn.Linear layout).  The library ACCUMULATES

@@ -169,6 +169,56 @@ def run_expected_positions_case(name, config, scene, pixels, object_id, perturb,
     return worst == 0.0 and set(want) == set(got)
 
 
+def run_expected_positions_gradient_case(name, config, scene, pixels, object_id, perturb, alpha_bias=0.0, seed=0):
+    """Reference forward_expected_positions in train mode + backward against torch.autograd through the oracle: gradients
+    of every parameter the object touches and of w2o / style / deformation (elementwise, incl. the component of d w2o
+    that leaves the rigid transforms)."""
+    torch.manual_seed(seed)
+    ref = refshim.build_reference_composer(copy.deepcopy(config))
+    synthetic.randomize_module_state(ref, seed=seed, step=20000, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref.train(True)
+    o, d, n, w2o, sty, dfm, ins = scene_to_composer_inputs(config, scene, None, pixels)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    names = [k for k, _ in ref.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    gen = torch.Generator().manual_seed(5)
+    probes = None
+    grads = []
+    for which in range(2):
+        leaf = [t[..., object_id].detach().clone().requires_grad_(True) for t in (w2o, sty, dfm)]
+        torch.manual_seed(seed + 1)
+        if which == 0:
+            out = ref.forward_expected_positions(o, d, n, *leaf, ins[..., object_id], object_id, perturb)
+        else:
+            out = ro.expected_positions_forward(config, sd, o, d, n, *leaf, ins[..., object_id], object_id, perturb,
+                                                training=True)
+        if probes is None:
+            probes = {ty: [torch.randn(t.shape, generator=gen) for t in out[ty]] for ty in out}
+        sum((t * p).sum() for ty in out for t, p in zip(out[ty], probes[ty])).backward()
+        if which == 0:
+            g = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+        else:
+            g = {k: sd[k].grad.clone() for k in names if sd[k].grad is not None}
+        for label, t in zip(("w2o", "style", "deformation"), leaf):
+            # the style only reaches the feature head, which the expected positions do not read: no gradient at all
+            g[label] = t.grad.clone() if t.grad is not None else torch.zeros_like(t)
+        grads.append(g)
+    largest = max(float(v.abs().max()) for v in grads[0].values())
+    worst, bad = 0.0, []
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1].get(k)
+        if b is None:
+            bad.append(k + " (missing)")
+            continue
+        rel = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6 * largest)
+        worst = max(worst, rel)
+        if rel > 1e-5:
+            bad.append(f"{k} ({rel:.2e})")
+    print(f"[{name}] gradient tensors={len(grads[0])} worst relative |diff|={worst:.3e} failing={bad}")
+    return not bad
+
+
 def check_wire_format():
     """playableenvironments_amd.wire_format against the reference's renderer <-> decoder glue (exact equality)."""
     from utils.lib_3d.ray_helper import RayHelper
@@ -370,6 +420,14 @@ def main():
                                       grid_pixels(256, 256, 16), 3, perturb=True, alpha_bias=2.0)
     ok &= run_expected_positions_case("expected positions, minecraft background", m, synthetic.minecraft_scene(seed=21),
                                       grid_pixels(256, 256, 24), 0, perturb=False, alpha_bias=3.0)
+    ok &= run_expected_positions_gradient_case("expected positions TRAIN gradients, tennis player_1",
+                                               configs.reduced_config(t, **small), synthetic.tennis_scene(seed=17),
+                                               grid_pixels(256, 256, 16), 2, perturb=True, alpha_bias=2.0)
+    ok &= run_expected_positions_gradient_case("expected positions TRAIN gradients, minecraft player_1",
+                                               configs.reduced_config(m, **small), synthetic.minecraft_scene(seed=19),
+                                               grid_pixels(256, 256, 16), 2, perturb=False, alpha_bias=3.0)
+    # (with use_fine the reference's own backward raises: compute_expected_positions keeps a view of the coarse weights
+    # that sample_pdf later modifies in place - there is no reference gradient to pin for hierarchical configurations)
     ok &= check_samplers()
     ok &= check_wire_format()
     ok &= check_ray_object_distances()

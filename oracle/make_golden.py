@@ -136,6 +136,55 @@ def make_gradients(name, recipe, scene, pixels, perturb=True, seed=0, alpha_bias
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {sum(k.startswith('grad/') for k in data)} gradient tensors")
 
 
+def make_expected_positions_gradients(name, recipe, scene, pixels, object_id, perturb, seed=0, alpha_bias=2.0, step=20000):
+    """Train-mode fixture of ObjectComposer.forward_expected_positions: reference forward + backward of a fixed random
+    linear functional of (expected positions, opacity); stores inputs, state_dict, replay noise (recorded by the oracle,
+    which draws in the reference's order - asserted bitwise), outputs and the REFERENCE's gradients."""
+    cfg = recipe_config(recipe)
+    torch.manual_seed(seed)
+    ref = refshim.build_reference_composer(copy.deepcopy(cfg))
+    synthetic.randomize_module_state(ref, seed=seed, step=step, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref.train()
+    o, d, n, w2o, sty, dfm, ins = composer_inputs(cfg, scene, pixels=pixels)
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    leaf = [t[..., object_id].clone().requires_grad_(True) for t in (w2o, sty, dfm)]
+    torch.manual_seed(seed + 1)
+    out_ref = ref.forward_expected_positions(o, d, n, *leaf, ins[..., object_id], object_id, perturb)
+    torch.manual_seed(seed + 1)
+    rec = {}
+    with torch.no_grad():
+        out_or = ro.expected_positions_forward(cfg, {k: v.clone() for k, v in sd.items()}, o, d, n, *[t.detach() for t in leaf],
+                                               ins[..., object_id], object_id, perturb, training=True, record_noise=rec)
+    gen = torch.Generator().manual_seed(seed + 2)
+    data, loss = {}, 0.0
+    for ty in out_ref:
+        for i, (a, b) in enumerate(zip(out_ref[ty], out_or[ty])):
+            assert torch.equal(a.detach(), b), f"{name}: oracle != reference on {ty}[{i}]"
+            w = torch.randn(a.shape, generator=gen)
+            data[f"probe/{ty}/{i}"] = w.numpy()
+            data[f"out/{ty}/{i}"] = a.detach().numpy()
+            loss = loss + (a * w).sum()
+    loss.backward()
+    for k, p in ref.named_parameters():
+        data["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for label, t in zip(("w2o", "style", "deformation"), leaf):
+        data["grad/" + label] = (t.grad if t.grad is not None else torch.zeros_like(t)).numpy()
+    for i, v in enumerate((o, d, n, w2o, sty, dfm, ins)):
+        data[f"in/{i}"] = v.numpy()
+    for k, v in sd.items():
+        data["sd/" + k] = v.numpy()
+    for k, v in rec.items():
+        if v is not None:
+            data["noise/" + k] = v.detach().numpy()
+    data["recipe"] = np.frombuffer(repr(recipe).encode(), dtype=np.uint8)
+    data["perturb"] = np.array(int(perturb))
+    data["object_id"] = np.array(int(object_id))
+    os.makedirs(os.path.join(OUT, "expected_positions"), exist_ok=True)
+    path = os.path.join(OUT, "expected_positions", name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 REDUCE = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1,
               bender_octaves=3)
 ODD = dict(width=48, layers=3, skip=1, features=16, octaves=3, bender_width=16, bender_layers=3, bender_skip=2,
@@ -165,6 +214,10 @@ def main():
                    grid_pixels(256, 256, 12), alpha_bias=3.0)
     make_gradients("tennis_small_train_two_frames", {"base": "tennis", "reduce": REDUCE},
                    synthetic.tennis_scene(seed=33, batch=2), grid_pixels(256, 256, 8), perturb=False)
+    make_expected_positions_gradients("tennis_player_train", {"base": "tennis", "reduce": REDUCE}, synthetic.tennis_scene(seed=34),
+                                      grid_pixels(256, 256, 12), 2, perturb=True)
+    make_expected_positions_gradients("minecraft_player_train", {"base": "minecraft", "reduce": REDUCE},
+                                      synthetic.minecraft_scene(seed=35), grid_pixels(256, 256, 12), 3, perturb=False, alpha_bias=3.0)
     from oracle.check_against_reference import pose_math_case
     assert pose_math_case(write_to=os.path.join(OUT, "host", "pose_math_minecraft.npz"))
     make("single_player_eval", {"base": "single", "reduce": REDUCE, "positions": {"player_1": (16, 16)}},

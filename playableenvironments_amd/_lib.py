@@ -98,14 +98,15 @@ class Call(C.Structure):
 
 class EntryGrads(C.Structure):
     _fields_ = [("integrated_features", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
-                ("integrated_displacements_magnitude", C.c_void_p)]
+                ("integrated_displacements_magnitude", C.c_void_p), ("weights", C.c_void_p)]
 
 
 GRAD_FIELDS = [f[0] for f in EntryGrads._fields_]
 
 
 class OutputGrads(C.Structure):
-    _fields_ = [("object", EntryGrads * PR_MAX_OBJECTS), ("global_", EntryGrads)]
+    _fields_ = [("object", EntryGrads * PR_MAX_OBJECTS), ("global_", EntryGrads),
+                ("sample_t", C.c_void_p * PR_MAX_OBJECTS), ("sample_delta", C.c_void_p * PR_MAX_OBJECTS)]
 
 
 class LinearGrad(C.Structure):

@@ -34,6 +34,7 @@ struct CompositeBwdObject {
     float* g_sigma;          // (N,R,P)
     float* g_t;              // (N,R,P)
     float* g_dm;             // (N,R,P) or NULL
+    const float* g_sample_t; // (N,R,P) gradient of the exported sample depths, or NULL
 };
 struct CompositeBwdParams {
     int frames, rays, objects, static_objects, F;
@@ -97,7 +98,8 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
     const float gD = g.depth ? g.depth[ray] : 0.f;
     const float gM = g.integrated_displacements_magnitude ? g.integrated_displacements_magnitude[ray] : 0.f;
     const bool has_gf = g.integrated_features != nullptr;
-    if (!has_gf && gO == 0.f && gD == 0.f && gM == 0.f) {   // uniform: nothing flows into this entry
+    const float* gW = g.weights ? g.weights + (size_t)ray * n : nullptr;   // in list order (merged order for the global entry)
+    if (!has_gf && !gW && gO == 0.f && gD == 0.f && gM == 0.f) {   // uniform: nothing flows into this entry
         __syncthreads();
         return;
     }
@@ -127,7 +129,7 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
             }
             dot = wave_sum(part);
         }
-        if (lane == 0) sm.dw[j] = dot + gO + gD * sm.tt[e];
+        if (lane == 0) sm.dw[j] = dot + gO + gD * sm.tt[e] + (gW ? gW[j] : 0.f);
     }
     __syncthreads();
     // d loss / d alpha_j = dw_j T_j - (sum_{i>j} dw_i w_i) / (1 - alpha_j + 1e-10)
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
         const size_t base = (size_t)g * P;
         for (int i = lane; i < P; i += 64) {
             o.g_sigma[base + i] = sm.gs[off + i];
-            o.g_t[base + i] = sm.gt[off + i];
+            o.g_t[base + i] = sm.gt[off + i] + (o.g_sample_t ? o.g_sample_t[base + i] : 0.f);
             if (o.g_dm) o.g_dm[base + i] = sm.gd[off + i];
         }
         float gFo[MAX_FCHUNK_B];
@@ -541,9 +543,10 @@ __global__ __launch_bounds__(256) void k_pe_bwd(RowCtx r, const float* enc, cons
 // Bender output backward: bent = x + delta, delta = clamp(raw * size, lo - x, hi - x) (* 0 in canonical pose),
 // |delta| feeds integrated_displacements_magnitude.  In: g_bent (M,3) = d loss / d bent.  Out: g_x (M,3)
 // (the direct paths), g_braw (M,3).
-__global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g_bent, const float* gdr, const float* delta,
-                                                        const float* braw, const float* pos, float lo0, float lo1, float lo2,
-                                                        float hi0, float hi1, float hi2, int canonical, float* g_x, float* g_braw) {
+__global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g_bent, const float* gdr, const float* g_delta_dense,
+                                                        const float* delta, const float* braw, const float* pos, float lo0,
+                                                        float lo1, float lo2, float hi0, float hi1, float hi2, int canonical,
+                                                        float* g_x, float* g_braw) {
     const int M = *r.total;
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
@@ -559,6 +562,8 @@ __global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g
     for (int a = 0; a < 3; ++a) {
         const float gb = real ? g_bent[(size_t)m * 3 + a] : 0.f;
         float g_delta = gb + (nrm > 0.f ? gd * dl[a] / nrm : 0.f);
+        // gradient of the exported displacement vector itself (sample_delta, on the sample grid)
+        if (real && g_delta_dense) g_delta += g_delta_dense[(size_t)r.rec_flat[m] * 3 + a];
         if (canonical) g_delta = 0.f;
         const float x = pos[(size_t)m * 3 + a];
         const float pre = braw[(size_t)m * 3 + a] * (hi[a] - lo[a]);
@@ -961,6 +966,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         o.g_sigma = reinterpret_cast<float*>(bws + bp.g_sigma[k]);
         o.g_t = reinterpret_cast<float*>(bws + bp.g_t[k]);
         o.g_dm = m.has_bender ? reinterpret_cast<float*>(bws + bp.g_dm[k]) : nullptr;
+        o.g_sample_t = grads.sample_t[k];
         total_positions += m.positions;
     }
     cp.total_positions = total_positions;
@@ -1094,7 +1100,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             const size_t bact_stride = cap * d.BWpad;
             const float* braw = reinterpret_cast<const float*>(fws + sv.braw);
             const float* delta = reinterpret_cast<const float*>(fws + sv.delta);
-            hipLaunchKernelGGL(k_bender_out_bwd, dim3(row_blocks), dim3(256), 0, s, rc, g_bent, gdr, delta, braw, rec_pos, lo[0],
+            hipLaunchKernelGGL(k_bender_out_bwd, dim3(row_blocks), dim3(256), 0, s, rc, g_bent, gdr, grads.sample_delta[k], delta, braw, rec_pos, lo[0],
                                lo[1], lo[2], hi[0], hi[1], hi[2], (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0, g_x, g_braw);
             PR_LAUNCH_CHECK();
             const int bc = m.bender_count;

@@ -82,7 +82,7 @@ def _linear(layer: Optional[nn.Linear]) -> _lib.Linear:
     return s
 
 
-GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude")
+GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude", "weights")
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -91,10 +91,11 @@ class _RenderFunction(torch.autograd.Function):
     deformation, then every trainable parameter of the composer."""
 
     @staticmethod
-    def forward(ctx, composer, args, holder, w2o, style, deformation, *params):
-        results, state = composer._render(*args, _save=True)
+    def forward(ctx, composer, kwargs, holder, w2o, style, deformation, *params):
+        results, state = composer._render(**kwargs, _save=True)
         ctx.composer, ctx.state, ctx.params = composer, state, params
         ctx.shapes = (w2o.shape, style.shape, deformation.shape)
+        ctx.set_materialize_grads(False)      # outputs the loss does not read arrive as None, not as zero tensors
         holder["results"], holder["types"] = results, state["types"]
         flat, skip = [], []
         for ty in state["types"]:
@@ -104,6 +105,14 @@ class _RenderFunction(torch.autograd.Function):
                     flat.append(t)
                     if key not in GRAD_KEYS:
                         skip.append(t)
+        ctx.exported = bool(kwargs.get("_export"))
+        if ctx.exported:
+            # per-sample exports as differentiable outputs: depths and displacement vectors of every object
+            for ty in state["types"]:
+                samples = results[ty]["_samples"][0]       # differentiable calls are never split along the rays
+                for k in range(state["K"]):
+                    flat.append(samples["t"][k])
+                    flat.append(samples["delta"][k])
         ctx.mark_non_differentiable(*skip)
         return tuple(flat)
 
@@ -125,9 +134,20 @@ class _RenderFunction(torch.autograd.Function):
                     g = grad_outputs[i]
                     i += 1
                     if key in GRAD_KEYS and g is not None:
-                        g = g.to(torch.float32).reshape((N, R, F) if key == "integrated_features" else (N, R)).contiguous()
+                        shape = {"integrated_features": (N, R, F), "weights": (N, R, -1)}.get(key, (N, R))
+                        g = g.to(torch.float32).reshape(shape).contiguous()
                         keep.append(g)
                         setattr(entry, key, g.data_ptr())
+        if ctx.exported:
+            for ty in st["types"]:
+                for k in range(K):
+                    for field in ("sample_t", "sample_delta"):
+                        g = grad_outputs[i]
+                        i += 1
+                        if g is not None:
+                            g = g.to(torch.float32).contiguous()
+                            keep.append(g)
+                            getattr(ogs[ty], field)[k] = g.data_ptr()
         grads = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in ctx.params}
         ig = _lib.InputGrads()
         d_w2o = torch.zeros((N, K, 3, 4), **f32)
@@ -354,8 +374,17 @@ class ObjectComposer(nn.Module):
         if not self.training:
             raise NotImplementedError("the backward pass differentiates the train-mode BatchNorm (module.train()); call the "
                                       "module under torch.no_grad() for evaluation")
+        kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
+                      transformation_matrix_w2o=transformation_matrix_w2o, style=style, deformation=deformation,
+                      object_in_scene=object_in_scene, perturb=perturb, canonical_pose=canonical_pose, _noise=_noise,
+                      _export=_export)
+        return self._render_with_graph(kwargs, K, params)
+
+    def _render_with_graph(self, kwargs: dict, K: int, params) -> Dict:
+        """One differentiable renderer call: the tensors of the result dictionary are the outputs of the autograd node."""
         holder = {}
-        flat = _RenderFunction.apply(self, args, holder, transformation_matrix_w2o, style, deformation, *params)
+        flat = _RenderFunction.apply(self, kwargs, holder, kwargs["transformation_matrix_w2o"], kwargs["style"],
+                                     kwargs["deformation"], *params)
         results = holder["results"]
         i = 0
         for ty in holder["types"]:
@@ -363,6 +392,12 @@ class ObjectComposer(nn.Module):
                 for key in ENTRY_KEYS:
                     results[ty][name][key] = flat[i]
                     i += 1
+        if kwargs.get("_export"):
+            for ty in holder["types"]:
+                samples = results[ty]["_samples"][0]
+                for k in range(K):
+                    samples["t"][k], samples["delta"][k] = flat[i], flat[i + 1]
+                    i += 2
         return results
 
     def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
@@ -621,13 +656,14 @@ class ObjectComposer(nn.Module):
 
         transformation_matrix_w2o (..., 4, 4); style (..., S); deformation (..., D); object_in_scene (...).
         Returns {"coarse": (expected positions (..., R, 3), opacity (..., R)) [, "fine": (...)]} in the object frame.
-        The renderer runs with this single object (pr_render_forward), pr_expected_positions forms the average.  Forward
-        only (the pose / keypoint consistency losses that consume it have weight 0 in the shipped configurations);
-        ``_noise`` keys: jitter, alpha, pdf, alpha_fine (oracle/render_oracle.py:expected_positions_forward)."""
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (transformation_matrix_w2o, style, deformation)):
-            raise NotImplementedError("forward_expected_positions has no backward: call it under torch.no_grad()")
+        The renderer runs with this single object (pr_render_forward); without a graph pr_expected_positions forms the
+        average, with gradients enabled (training mode) the call is differentiable with respect to the parameters, the
+        style, the deformation and the pose (_expected_positions_with_graph), as the pose / keypoint consistency losses
+        of the reference's trainers need.  ``_noise`` keys: jitter, alpha, pdf, alpha_fine
+        (oracle/render_oracle.py:expected_positions_forward)."""
         if not ray_directions.is_cuda:
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+        self._raise_pending_batchnorm_check()
         noise = None
         if _noise is not None:
             # one alpha draw feeds both the coarse weights and the resampler (object_composer.py:683-684, :697)
@@ -639,6 +675,16 @@ class ObjectComposer(nn.Module):
             shape = lead + [ray_directions.size(-2), model.model_config["positions_count_coarse"]]
             shared = torch.randn(shape, dtype=torch.float32, device=ray_directions.device)
             noise = {"alpha_0": shared, "int_coarse_0": shared}
+        params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
+                                                  transformation_matrix_w2o.requires_grad)
+        if wants_grad:
+            if not self.training:
+                raise NotImplementedError("the backward pass differentiates the train-mode BatchNorm (module.train()); call "
+                                          "the module under torch.no_grad() for evaluation")
+            return self._expected_positions_with_graph(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o,
+                                                       style, deformation, object_in_scene, object_id, perturb, canonical_pose,
+                                                       noise, params)
         with torch.no_grad():
             results, _ = self._render(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o.unsqueeze(-1),
                                       style.unsqueeze(-1), deformation.unsqueeze(-1), object_in_scene.unsqueeze(-1), perturb,
@@ -696,3 +742,37 @@ class ObjectComposer(nn.Module):
                 s.bender[i] = lg(layer)
             s.bender_out = lg(bender.output_head)
         return s
+
+
+    def _expected_positions_with_graph(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                       deformation, object_in_scene, object_id, perturb, canonical_pose, noise, params) -> Dict:
+        """Differentiable forward_expected_positions (the pose / keypoint consistency losses of the reference's trainers):
+        the single-object render is one autograd node whose outputs include the compositing weights, the sample depths
+        and the bender's displacement vectors (pr_render_backward takes their gradients); the weighted mean itself is a
+        handful of torch ops on (N, R, P) tensors, which also carry the direct dependence of the object-frame ray on the
+        pose."""
+        kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
+                      transformation_matrix_w2o=transformation_matrix_w2o.unsqueeze(-1), style=style.unsqueeze(-1),
+                      deformation=deformation.unsqueeze(-1), object_in_scene=object_in_scene.unsqueeze(-1), perturb=perturb,
+                      canonical_pose=canonical_pose, _noise=noise, _export=True, _object_ids=[object_id])
+        results = self._render_with_graph(kwargs, 1, params)
+        lead = list(ray_directions.shape[:-2])
+        R = ray_directions.size(-2)
+        m = torch.broadcast_to(transformation_matrix_w2o.to(torch.float32), lead + [4, 4])
+        o = torch.broadcast_to(ray_origins.to(torch.float32), lead + [3])
+        # object-frame ray (RayHelper.transform_rays, ray_helper.py:1203-1227)
+        o_obj = torch.sum(o.unsqueeze(-2) * m[..., :3, :3], -1) + m[..., :3, 3]                               # (..., 3)
+        d_obj = torch.sum(ray_directions.to(torch.float32).unsqueeze(-2) * m[..., :3, :3].unsqueeze(-3), -1)  # (..., R, 3)
+        out = {}
+        for ty in ("coarse", "fine"):
+            if ty not in results:
+                continue
+            samples = results[ty]["_samples"][0]
+            t = samples["t"][0].reshape(lead + [R, -1])
+            delta = samples["delta"][0].reshape(lead + [R, -1, 3])
+            entry = results[ty]["object_0"]
+            weights = entry["weights"].detach()       # compute_expected_positions detaches them (object_composer.py:615)
+            positions = o_obj.unsqueeze(-2).unsqueeze(-2) + d_obj.unsqueeze(-2) * t.unsqueeze(-1) + delta
+            expected = (positions * weights.unsqueeze(-1)).sum(-2) / (weights.sum(-1, keepdim=True) + 1e-8)
+            out[ty] = (expected, entry["opacity"])
+        return out

@@ -569,3 +569,62 @@ def test_pose_math_against_reference_fixture():
     rot = g["object_rotation_parameters"].clone().requires_grad_(True)
     model.compute_transformation_matrix_w2o_o2w(rot, g["object_translation_parameters"])[0].square().sum().backward()
     assert torch.isfinite(rot.grad).all() and float(rot.grad.abs().max()) > 0
+
+
+# --------------------------------------------------------------------------------------------
+# forward_expected_positions: outputs and gradients recorded from the reference (tests/golden/expected_positions)
+# --------------------------------------------------------------------------------------------
+EXPECTED_GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "expected_positions", "*.npz")))
+
+
+def load_expected_positions_fixture(path):
+    z = np.load(path)
+    t = lambda k: torch.from_numpy(z[k])
+    recipe = ast.literal_eval(bytes(z["recipe"]).decode())
+    inputs = [t(f"in/{i}") for i in range(7)]
+    sd = {k[3:]: t(k) for k in z.files if k.startswith("sd/")}
+    noise = {k[6:]: t(k) for k in z.files if k.startswith("noise/")}
+    types = sorted({k.split("/")[1] for k in z.files if k.startswith("out/")})
+    out = {ty: (t(f"out/{ty}/0"), t(f"out/{ty}/1")) for ty in types}
+    probes = {ty: (t(f"probe/{ty}/0"), t(f"probe/{ty}/1")) for ty in types}
+    grads = {k[5:]: t(k) for k in z.files if k.startswith("grad/")}
+    return recipe, inputs, sd, noise, out, probes, grads, bool(int(z["perturb"])), int(z["object_id"])
+
+
+def pose_parameter_gradients(w2o: torch.Tensor, grad_w2o: torch.Tensor):
+    """Projects an elementwise d loss / d w2o onto the rigid motions: gradients with respect to Euler angles and a
+    translation composed on the right of ``w2o`` (what the reference's pose parameters see)."""
+    lead = list(w2o.shape[:-2])
+    rot = torch.zeros(lead + [3], requires_grad=True)
+    tr = torch.zeros(lead + [3], requires_grad=True)
+    (torch.matmul(w2o, ro.euler_to_matrix(rot, tr)) * grad_w2o).sum().backward()
+    return rot.grad, tr.grad
+
+
+def test_expected_positions_fixtures_present():
+    assert len(EXPECTED_GOLDEN) >= 2
+
+
+@pytest.mark.parametrize("path", EXPECTED_GOLDEN, ids=[os.path.basename(p)[:-4] for p in EXPECTED_GOLDEN])
+def test_oracle_expected_positions_reproduce_reference_outputs_and_gradients(path):
+    recipe, inputs, sd, noise, want, probes, grads, perturb, obj = load_expected_positions_fixture(path)
+    cfg = recipe_config(recipe)
+    o, d, n, w2o, sty, dfm, ins = inputs
+    names = [k for k in grads if k not in ("w2o", "style", "deformation")]
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sd[k].requires_grad_(True)
+    leaf = [t[..., obj].clone().requires_grad_(True) for t in (w2o, sty, dfm)]
+    got = ro.expected_positions_forward(cfg, sd, o, d, n, *leaf, ins[..., obj], obj, perturb, training=True, noise=noise)
+    assert set(got) == set(want)
+    for ty in want:
+        for a, b in zip(want[ty], got[ty]):
+            assert torch.equal(a, b.detach()), ty
+    sum((t * p).sum() for ty in got for t, p in zip(got[ty], probes[ty])).backward()
+    mine = {k: sd[k].grad for k in names}
+    mine.update(dict(zip(("w2o", "style", "deformation"), (t.grad for t in leaf))))
+    largest = max(float(a.abs().max()) for a in grads.values())
+    for k, a in grads.items():
+        b = mine[k] if mine[k] is not None else torch.zeros_like(a)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-7 * largest, k
+    assert float(grads["w2o"].abs().max()) > 0 and float(grads["deformation"].abs().max()) > 0

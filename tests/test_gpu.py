@@ -357,7 +357,8 @@ def test_train_mode_guards():
 
 
 # --------------------------------------------------------------------------------------------
-# Backward pass (pr_render_backward) against the oracle's autograd
+# Backward pass (pr_render_backward) against the oracle's autograd.  The probed outputs include the compositing
+# weights themselves (per object, and the merged list of the global entry).
 # --------------------------------------------------------------------------------------------
 GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude")
 SMALL_NETS = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1,
@@ -366,18 +367,14 @@ SMALL_NETS = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_wid
 
 def _probe_loss(results, probes, K):
     total = 0.0
-    for ty in ("coarse", "fine"):
-        if ty not in results:
-            continue
-        for name in [f"object_{k}" for k in range(K)] + ["global"]:
-            for key in GRAD_KEYS:
-                t = results[ty][name][key]
-                total = total + (t * probes[(ty, name, key)].to(t.device)).sum()
+    for (ty, name, key), probe in probes.items():
+        t = results[ty][name][key]
+        total = total + (t * probe.to(t.device)).sum()
     return total
 
 
-def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=()):
-    """(oracle autograd, HIP backward) gradients of a random linear functional of every differentiable output."""
+def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS):
+    """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``."""
     comp = build(cfg, alpha_bias=bias).train()
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
     o, d, nrm, w2o, sty, dfm, ins = inputs
@@ -394,7 +391,7 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=()):
     gen = torch.Generator().manual_seed(7)
     probes = {(ty, nm, key): torch.randn(want[ty][nm][key].shape, generator=gen)
               for ty in ("coarse", "fine") if ty in want
-              for nm in [f"object_{k}" for k in range(K)] + ["global"] for key in GRAD_KEYS}
+              for nm in [f"object_{k}" for k in range(K)] + ["global"] for key in keys}
     _probe_loss(want, probes, K).backward()
     comp = comp.cuda()
     for k, p in comp.named_parameters():
@@ -464,6 +461,33 @@ def test_backward_matches_oracle_autograd(name, perturb):
             bad[k] = (err, scale)
     assert not bad, bad
     assert nonzero > 40
+
+
+@pytest.mark.parametrize("name,perturb", [("tennis", False), ("minecraft", True), ("tennis_hierarchical", False)])
+def test_backward_of_the_compositing_weights(name, perturb):
+    """pr_entry_grads_t.weights: a loss that reads the compositing weights themselves - per object, and the merged list of
+    the global entry (overlap fix included for minecraft) - against the oracle's autograd.  Per tensor: 1e-4 of its own
+    largest entry plus an fp32-epsilon floor relative to the largest gradient of the call (tiny tensors such as a
+    single bias are sums with cancellation)."""
+    if name == "minecraft":
+        cfg, scene, n, bias = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS), synthetic.minecraft_scene(), 16, 3.0
+    elif name == "tennis_hierarchical":
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
+    else:
+        cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
+    grads = _gradients(cfg, scene, n, bias, perturb, keys=("weights", "opacity"))
+    largest = max(float(a.abs().max()) for a, _ in grads.values())
+    tol = 1e-3 if name == "tennis_hierarchical" else 1e-4
+    bad, nonzero = {}, 0
+    for k, (a, b) in grads.items():
+        scale = float(a.abs().max())
+        nonzero += scale > 0
+        err = float((a - b).abs().max())
+        if err > tol * scale + 2e-7 * largest:
+            bad[k] = (err, scale)
+    assert not bad, bad
+    assert nonzero > 20
 
 
 def test_backward_full_size_networks():
@@ -624,3 +648,120 @@ def test_forward_expected_positions_matches_oracle(case):
             assert torch.allclose(a, b, rtol=RTOL, atol=1e-4 if what == "expected_positions" else ATOL), \
                 (ty, what, float((a - b).abs().max()))
         assert float(want[ty][1].max()) > 0.1   # the object is actually hit
+
+
+@pytest.mark.parametrize("case", ["tennis_player", "tennis_player_perturb", "minecraft_player", "tennis_hierarchical"])
+def test_expected_positions_backward_matches_oracle_autograd(case):
+    """Differentiable forward_expected_positions (pose / keypoint consistency losses): gradients of a random linear
+    functional of (expected positions, opacity) with respect to every parameter, the style, the deformation and the
+    pose against torch.autograd through the oracle; shallow networks, train mode, replayed noise."""
+    perturb = case in ("tennis_player_perturb", "tennis_hierarchical")
+    if case == "minecraft_player":
+        cfg, scene, obj, bias = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS), synthetic.minecraft_scene(seed=19), 2, 3.0
+    elif case == "tennis_hierarchical":
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, obj, bias = synthetic.tennis_scene(seed=5), 2, 2.0
+    else:
+        cfg, scene, obj, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(seed=17), 2, 2.0
+    comp = build(cfg, alpha_bias=bias).train()
+    h, w = scene["image_size"]
+    o, d, nrm, w2o, sty, dfm, ins = composer_inputs(cfg, scene, pixels=grid_pixels(h, w, 16))
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+    names = [k for k, _ in comp.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    # the pose enters as the reference produces it: a rigid transform generated by rotation / translation parameters
+    # (here a perturbation of the scene's w2o around the identity), and the gradients are compared on those parameters
+    single = (w2o[..., obj], sty[..., obj], dfm[..., obj])
+    lead = list(single[0].shape[:-2])
+
+    def pose_inputs(device):
+        rot = torch.zeros(lead + [3], device=device, requires_grad=True)
+        tr = torch.zeros(lead + [3], device=device, requires_grad=True)
+        return rot, tr, torch.matmul(single[0].to(device), ro.euler_to_matrix(rot, tr))
+
+    rot_ref, tr_ref, w2o_ref = pose_inputs("cpu")
+    ref_in = [t.clone().requires_grad_(True) for t in single[1:]]
+    rec = {}
+    torch.manual_seed(11)
+    want = ro.expected_positions_forward(cfg, sd, o, d, nrm, w2o_ref, *ref_in, ins[..., obj], obj, perturb, training=True,
+                                         record_noise=rec)
+    gen = torch.Generator().manual_seed(3)
+    probes = {ty: [torch.randn(t.shape, generator=gen) for t in want[ty]] for ty in want}
+    sum((t * p).sum() for ty in want for t, p in zip(want[ty], probes[ty])).backward()
+    comp = comp.cuda()
+    rot_hip, tr_hip, w2o_hip = pose_inputs("cuda")
+    hip_in = [t.clone().cuda().requires_grad_(True) for t in single[1:]]
+    got = comp.forward_expected_positions(o.cuda(), d.cuda(), nrm.cuda(), w2o_hip, *hip_in, ins[..., obj].cuda(), obj, perturb,
+                                          _noise=rec)
+    assert set(got) == set(want)
+    for ty in want:
+        for a, b in zip(want[ty], got[ty]):
+            assert torch.allclose(a.detach(), b.detach().cpu(), rtol=1e-3, atol=2e-4), (ty, float((a - b.detach().cpu()).abs().max()))
+    sum((t * p.cuda()).sum() for ty in got for t, p in zip(got[ty], probes[ty])).backward()
+    torch.cuda.synchronize()
+    params = dict(comp.named_parameters())
+    pairs = {k: (sd[k].grad, params[k].grad) for k in names}
+    for label, a, b in zip(("pose rotation", "pose translation", "style", "deformation"), [rot_ref, tr_ref] + ref_in,
+                           [rot_hip, tr_hip] + hip_in):
+        pairs[label] = (a.grad, b.grad)
+    largest = max(float(a.abs().max()) for a, _ in pairs.values() if a is not None)
+    tol = 1e-3 if case == "tennis_hierarchical" else 1e-4
+    bad, nonzero = {}, 0
+    for k, (a, b) in pairs.items():
+        if a is None and b is None:
+            continue
+        b = b.detach().cpu() if b is not None else torch.zeros_like(a)
+        a = a if a is not None else torch.zeros_like(b)
+        scale = float(a.abs().max())
+        nonzero += scale > 0
+        err = float((a - b).abs().max())
+        if err > tol * scale + 2e-7 * largest:      # fp32-epsilon floor: tensors whose true gradient is ~0
+            bad[k] = (err, scale)
+    assert not bad, bad
+    assert nonzero > 15 and float(pairs["pose rotation"][0].abs().max()) > 0 and float(pairs["deformation"][0].abs().max()) > 0
+
+
+from tests.test_cpu import EXPECTED_GOLDEN, load_expected_positions_fixture, pose_parameter_gradients  # noqa: E402
+
+
+@pytest.mark.parametrize("path", EXPECTED_GOLDEN, ids=[os.path.basename(p)[:-4] for p in EXPECTED_GOLDEN])
+def test_expected_positions_match_reference_fixtures(path):
+    """forward_expected_positions in training mode against outputs and gradients recorded from the reference
+    (tests/golden/expected_positions).  d loss / d w2o is compared on the rigid motions (Euler angles + translation,
+    the only way the reference produces these matrices): its component that leaves the rigid transforms - the
+    reference measures sample distances with the OBJECT-frame direction, whose length is 1 for every rigid pose - has
+    no effect on any pose parameter and is not produced by the renderer."""
+    recipe, inputs, sd, noise, want, probes, grads, perturb, obj = load_expected_positions_fixture(path)
+    cfg = recipe_config(recipe)
+    comp = ObjectComposer(cfg)
+    comp.load_state_dict(sd, strict=True)
+    comp = comp.cuda().train()
+    o, d, n, w2o, sty, dfm, ins = inputs
+    leaf = [t[..., obj].clone().cuda().requires_grad_(True) for t in (w2o, sty, dfm)]
+    got = comp.forward_expected_positions(o.cuda(), d.cuda(), n.cuda(), *leaf, ins[..., obj].cuda(), obj, perturb, _noise=noise)
+    assert set(got) == set(want)
+    for ty in want:
+        for a, b, atol in zip(want[ty], got[ty], (1e-4, ATOL)):
+            assert torch.allclose(a, b.detach().cpu(), rtol=RTOL, atol=atol), (ty, float((a - b.detach().cpu()).abs().max()))
+    sum((t * p.cuda()).sum() for ty in got for t, p in zip(got[ty], probes[ty])).backward()
+    torch.cuda.synchronize()
+    params = dict(comp.named_parameters())
+    largest = max(float(a.abs().max()) for a in grads.values())
+    bad = {}
+
+    def check(k, a, b):
+        err, scale = float((a - b).abs().max()), float(a.abs().max())
+        if err > 1e-4 * scale + 2e-7 * largest:
+            bad[k] = (err, scale)
+
+    for k, a in grads.items():
+        if k == "w2o":
+            want_pose = pose_parameter_gradients(w2o[..., obj], a)
+            got_pose = pose_parameter_gradients(w2o[..., obj], leaf[0].grad.detach().cpu())
+            check("pose rotation", want_pose[0], got_pose[0])
+            check("pose translation", want_pose[1], got_pose[1])
+            continue
+        b = leaf[("w2o", "style", "deformation").index(k)].grad if k in ("style", "deformation") else params[k].grad
+        check(k, a, b.detach().cpu() if b is not None else torch.zeros_like(a))
+    assert not bad, bad
