@@ -369,7 +369,29 @@ def check_samplers():
     torch.manual_seed(3)
     ok &= torch.equal(d_ref, pick(rs.sample_pixels_uniform(n, h, w, 200, "cpu")))
     print(f"[pixel samplers: strided patch x3, weighted, uniform] identical indices: {ok}")
-    return ok
+    # samplers of the pose / keypoint consistency paths (direction-grid lookups)
+    grid, pos = torch.randn(2, n, h, w, 3), torch.rand(2, n, 37, 2)
+    same = torch.equal(RayHelper.sample_rays_at(grid, pos, correct_range=True, original_image_size=(h, w)),
+                       rs.sample_rays_at(grid, pos, True, (h, w)))
+    same &= torch.equal(RayHelper.sample_rays_at(grid, pos, correct_range=False), rs.sample_rays_at(grid, pos, False))
+    imgs = torch.randn(2, n, 5, h, w)
+    one_box = torch.rand(2, n, 4) * 0.5
+    one_box[..., 2:] = one_box[..., :2] + 0.05 + torch.rand(2, n, 2) * 0.4
+    one_box = one_box.clamp(0, 1)
+    torch.manual_seed(4)
+    ra = RayHelper.sample_rays_at_object(grid, imgs, 50, one_box)
+    torch.manual_seed(4)
+    rb = rs.sample_rays_at_object(grid, imgs, 50, one_box)
+    same &= all(torch.equal(x, y) for x, y in zip(ra, rb))
+    grid6, keypoints = torch.randn(2, 3, 2, h, w, 3), torch.rand(2, 3, 2, 17, 3)
+    for count in (16, 40, 7):
+        torch.manual_seed(5)
+        ka = RayHelper.sample_rays_at_keypoints(grid6, keypoints, count)
+        torch.manual_seed(5)
+        kb = rs.sample_rays_at_keypoints(grid6, keypoints, count)
+        same &= all(torch.equal(x, y) for x, y in zip(ka, kb))
+    print(f"[consistency samplers: sample_rays_at x2, at_object, at_keypoints x3] identical: {same}")
+    return ok and same
 
 
 def main():

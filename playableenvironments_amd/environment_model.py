@@ -105,6 +105,28 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
 
 
+def camera_rays_at_positions(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int, positions: torch.Tensor,
+                             correct_range: bool = False):
+    """World-frame rays through CONTINUOUS image positions, without the (H, W, 3) direction grid the reference samples
+    with grid_sample (RayHelper.create_camera_rays + sample_rays_at + transform_rays; ray_helper.py:15-52, :1014-1052,
+    :1203-1227): a pinhole grid is linear in the pixel coordinates, so its bilinear lookup at pixel coordinate (v, u) is
+    ((u - W/2) / f, -(v - H/2) / f, -1).  Used by the pose / keypoint consistency paths (optical-flow targets, skeleton
+    samples).  Differentiable torch ops; agrees with the grid lookup to fp32 rounding.
+
+    c2w (..., 4, 4); focals (...) (already rescaled); positions (..., n, 2) as (row, col) normalised to [0, 1];
+    ``correct_range``: positions were produced as pixel / size (RayHelper.sample_rays_at's correction).
+    Returns origins (..., 3), directions (..., n, 3), focal normals (..., 3)."""
+    size = torch.tensor([height, width], dtype=positions.dtype, device=positions.device)
+    pos = positions * (size / (size - 1 + 1e-8)) if correct_range else positions
+    v = pos[..., 0] * (height - 1)                      # align_corners: 0 -> first pixel, 1 -> last pixel
+    u = pos[..., 1] * (width - 1)
+    f = focals.unsqueeze(-1)
+    d_cam = torch.stack([(u - width / 2) / f, -(v - height / 2) / f, -torch.ones_like(u)], dim=-1)
+    rot = c2w[..., :3, :3].unsqueeze(-3)
+    directions = torch.sum(d_cam.unsqueeze(-2) * rot, -1)
+    return c2w[..., :3, 3], directions, -c2w[..., :3, 2]
+
+
 class EnvironmentModel(nn.Module):
 
     def __init__(self, config):

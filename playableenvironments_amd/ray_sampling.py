@@ -146,3 +146,75 @@ def _alignment_tables(sm: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def split_indices(indices: torch.Tensor, width: int) -> Tuple[torch.Tensor, torch.Tensor]:
     return (indices // width).to(torch.int32), (indices % width).to(torch.int32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Samplers of the pose / keypoint consistency paths (model/environment_model.py:1197-1505).
+# They work on the camera-frame direction grid, as the reference does: (..., H, W, 3), the grid of
+# RayHelper.create_camera_rays.  Positions are (row / H, col / W) normalised to [0, 1].
+# ---------------------------------------------------------------------------------------------------------------------
+#: COCO keypoint pairs joined by a skeleton segment (ray_helper.py:815-832)
+SKELETON_SEGMENTS = ((0, 11), (0, 12), (5, 6), (5, 7), (5, 11), (5, 12), (6, 8), (6, 11), (6, 12), (7, 9), (8, 10), (11, 12),
+                     (11, 13), (12, 14), (13, 15), (14, 16))
+
+
+def sample_rays_at(ray_directions: torch.Tensor, sampled_positions: torch.Tensor, correct_range: bool = True,
+                   original_image_size: Tuple[int, int] = None) -> torch.Tensor:
+    """Bilinear lookup of the (..., H, W, 3) direction grid at (..., n, 2) positions -> (..., n, 3)
+    (RayHelper.sample_rays_at, ray_helper.py:1014-1052; grid_sample with align_corners)."""
+    lead = list(ray_directions.shape[:-3])
+    grid = ray_directions.reshape([-1] + list(ray_directions.shape[-3:])).permute(0, 3, 1, 2)
+    pos = sampled_positions.reshape([-1] + list(sampled_positions.shape[-2:]))
+    if correct_range:
+        size = torch.tensor(original_image_size, dtype=ray_directions.dtype, device=ray_directions.device)
+        pos = pos * (size / (size - 1 + 1e-8))
+    pos = (pos[..., [1, 0]].unsqueeze(-2) - 0.5) * 2
+    out = torch.nn.functional.grid_sample(grid, pos, align_corners=True).squeeze(-1).permute(0, 2, 1)
+    return out.reshape(lead + list(out.shape[1:]))
+
+
+def sample_rays_at_object(ray_directions: torch.Tensor, images: torch.Tensor, samples_per_image: int,
+                          bounding_box: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``samples_per_image`` pixels drawn uniformly (with replacement) inside one (..., 4) [left, top, right, bottom] box per
+    image: directions (..., n, 3), image values (..., n, C) and positions (..., n, 2)  (RayHelper.sample_rays_at_object,
+    ray_helper.py:910-1012).  One vectorised weight mask instead of a loop with four ``.item()`` reads per image."""
+    lead = list(ray_directions.shape[:-3])
+    height, width = ray_directions.size(-3), ray_directions.size(-2)
+    channels = images.size(-3)
+    boxes = bounding_box.reshape(-1, 4, 1)
+    # weight 1 inside the pixel-aligned box; boxes of zero area keep an all-zero mask (-> NaN cdf, index 0 ... as the reference)
+    mask = _weight_masks(boxes, (1.0,), height, width, guard_zero_area=True)
+    mask = torch.where(mask != 0, torch.ones_like(mask), mask)
+    indices = _sample_cdf(mask, samples_per_image)                                              # (M, n)
+    dirs = ray_directions.reshape(-1, height * width, 3)
+    obs = images.reshape(-1, channels, height * width).transpose(1, 2)
+    rows = torch.arange(dirs.size(0), device=dirs.device).unsqueeze(1)
+    out_d, out_o = dirs[rows, indices], obs[rows, indices]
+    positions = positions_from_indices(indices, height, width)
+    return (out_d.reshape(lead + list(out_d.shape[1:])), out_o.reshape(lead + list(out_o.shape[1:])),
+            positions.reshape(lead + list(positions.shape[1:])))
+
+
+def sample_rays_at_keypoints(ray_directions: torch.Tensor, keypoints: torch.Tensor, max_samples_per_image: int
+                             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Samples on the skeleton segments of COCO keypoints: ray_directions (..., O, C, H, W, 3), keypoints (..., O, C, 17, 3)
+    as (row, col, confidence) in [0, 1] -> directions (..., O, C, n, 3), positions (..., O, C, n, 2), confidences
+    (..., O, C, n).  One random fraction per (sequence, sample), shared by the observations and cameras of the sequence
+    (RayHelper.sample_rays_at_keypoints, ray_helper.py:797-908)."""
+    lead = list(ray_directions.shape[:-5])
+    observations, cameras = ray_directions.size(-5), ray_directions.size(-4)
+    dirs = ray_directions.reshape([-1] + list(ray_directions.shape[-5:]))
+    kp = keypoints.reshape([-1] + list(keypoints.shape[-4:]))
+    first = torch.as_tensor([a for a, _ in SKELETON_SEGMENTS], device=kp.device)
+    second = torch.as_tensor([b for _, b in SKELETON_SEGMENTS], device=kp.device)
+    begin, end = kp[..., first, :], kp[..., second, :]                                          # (M, O, C, 16, 3)
+    repeat = -(-max_samples_per_image // len(SKELETON_SEGMENTS))
+    begin = begin.repeat(1, 1, 1, repeat, 1)[..., :max_samples_per_image, :]
+    end = end.repeat(1, 1, 1, repeat, 1)[..., :max_samples_per_image, :]
+    fractions = torch.rand((kp.size(0), 1, 1, max_samples_per_image), dtype=kp.dtype, device=kp.device)
+    fractions = fractions.repeat(1, observations, cameras, 1).unsqueeze(-1)
+    points = begin + (end - begin) * fractions
+    positions, scores = points[..., :2], points[..., -1]
+    sampled = sample_rays_at(dirs, positions, correct_range=False)
+    return (sampled.reshape(lead + list(sampled.shape[1:])), positions.reshape(lead + list(positions.shape[1:])),
+            scores.reshape(lead + list(scores.shape[1:])))
