@@ -22,7 +22,6 @@ constexpr int STHREADS = 256;        // 4 waves; two workgroups (tiles) per CU
 constexpr int SWAVES = 4;
 constexpr int SBLOCKS_PER_CU = 2;
 constexpr int LDH = MAX_WIDTH + 8;   // halves per activation row (528 B = 33 16-byte slots: conflict-free b128)
-constexpr int LEH = MAX_ENC + 8;     // halves per encoding row (272 B = 17 slots)
 constexpr int LDSTAGE = 260;         // floats per row when the activation planes are reused as an fp32 staging tile
 
 struct SmemH {

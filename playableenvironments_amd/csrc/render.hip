@@ -20,7 +20,10 @@ static std::mutex g_profile_mutex;
 ProfileScope::ProfileScope(int category, hipStream_t s) : category_(category), stream_(s), start_(nullptr), active_(false) {
     if (!g_profile_on) return;
     if (hipEventCreate(&start_) != hipSuccess) return;
-    hipEventRecord(start_, stream_);
+    if (hipEventRecord(start_, stream_) != hipSuccess) {
+        (void)hipEventDestroy(start_);
+        return;
+    }
     active_ = true;
 }
 
@@ -28,7 +31,11 @@ ProfileScope::~ProfileScope() {
     if (!active_) return;
     hipEvent_t stop;
     if (hipEventCreate(&stop) != hipSuccess) return;
-    hipEventRecord(stop, stream_);
+    if (hipEventRecord(stop, stream_) != hipSuccess) {
+        (void)hipEventDestroy(stop);
+        (void)hipEventDestroy(start_);
+        return;
+    }
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     g_profile.push_back(ProfileRecord{category_, start_, stop});
 }
@@ -484,8 +491,8 @@ extern "C" int pr_profile_collect(double* milliseconds, int32_t* launches) {
             milliseconds[r.category] += ms;
             launches[r.category] += 1;
         }
-        hipEventDestroy(r.start);
-        hipEventDestroy(r.stop);
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
     }
     pr::g_profile.clear();
     return PR_OK;
