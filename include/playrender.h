@@ -52,8 +52,11 @@ typedef enum pr_status {
                                        the evaluated samples of each object call and update running_mean / running_var /
                                        num_batches_tracked in place (model/layers/adain.py:47,58) */
 
-#define PR_FLAG_SAVE_FOR_BACKWARD 32u /* keep every intermediate pr_render_backward needs inside the workspace (needs
-                                       PR_FLAG_TRAIN_BN); the workspace must stay untouched until the backward call */
+#define PR_FLAG_SAVE_FOR_BACKWARD 32u /* keep every intermediate pr_render_backward needs inside the workspace; the
+                                       workspace must stay untouched until the backward call.  With PR_FLAG_TRAIN_BN
+                                       the backward pass differentiates the batch statistics (training); without it
+                                       the running statistics are constants (a differentiable eval-mode call, e.g.
+                                       test-time optimisation of poses or style codes).  PR_PRECISION_FP32 only. */
 
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
@@ -203,7 +206,7 @@ int pr_render_forward(const pr_call_t* call, const pr_object_t* objects,
 /*
  * Backward pass of pr_render_forward (what torch.autograd does for the reference's op graph when
  * training/trainer_backpropagated_autoencoder.py:349 calls total_loss.backward()).  The forward call must
- * have run with PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD on the same `call`, `objects` and
+ * have run with PR_FLAG_SAVE_FOR_BACKWARD (with or without PR_FLAG_TRAIN_BN) on the same `call`, `objects` and
  * `forward_workspace`, which must not have been touched since.  In hierarchical (use_fine) calls the resampled
  * depths are constants (the reference detaches them, ray_helper.py:1340): the fine pass differentiates through the
  * coarse depths it merged in and through the sample positions, the coarse pass through its own results only.

@@ -381,6 +381,7 @@ struct AdainBwd {
     float* dscale;          // (frames, width) accumulated
     float* dbias;           // (frames, width)
     const int32_t* count;   // rows that entered the batch statistics
+    int frozen;             // eval mode: the statistics are constants (running buffers), no batch terms
 };
 
 // Block = 64 channels (blockIdx.y) x 4 row groups over 256 rows; thread (c, rg) walks rows rg, rg + 4, ...
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void k_adain_bwd_apply(AdainBwd p) {
     if (c >= p.width) return;
     const double n = (double)*p.count;
     const float mu = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
-    const float m1 = (float)(p.sums[c] / n), m2 = (float)(p.sums[p.width + c] / n);
+    const float m1 = p.frozen ? 0.f : (float)(p.sums[c] / n), m2 = p.frozen ? 0.f : (float)(p.sums[p.width + c] / n);
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
         const size_t at = (size_t)m * p.ld + c;
         float v = 0.f;
@@ -1050,6 +1051,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         ab.goff = 2 * d.Wpad; ab.boff = 2 * d.Wpad + d.W2pad;
         ab.mean = batch + 2 * MAX_WIDTH; ab.var = batch + 3 * MAX_WIDTH; ab.eps = m.bn_eps;
         ab.g = bufB; ab.sums = sums; ab.dscale = dscale2; ab.dbias = dbias2; ab.count = stat_count;
+        ab.frozen = (c.flags & PR_FLAG_TRAIN_BN) ? 0 : 1;
         PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
         hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk, (d.W2 + 63) / 64), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();

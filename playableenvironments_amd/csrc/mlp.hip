@@ -882,6 +882,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
 __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.width) return;
+    if (p.frozen) {   // eval mode: normalise with the running statistics (torch batch_norm with training=False)
+        p.batch_mean[c] = p.running_mean[c];
+        p.batch_var[c] = p.running_var[c];
+        return;
+    }
     const double n = (double)*p.count;
     const double mean = p.stats[c] / n;
     double var = p.stats[p.width_pad + c] / n - mean * mean;

@@ -253,6 +253,7 @@ struct BnFinalizeParams {
     long long* num_batches_tracked;
     float* batch_mean;            // out (width)
     float* batch_var;             // out (width), biased
+    int frozen;                   // eval mode: hand the running statistics through, update nothing
 };
 int launch_bn_finalize(const BnFinalizeParams& p, hipStream_t s);
 

@@ -67,8 +67,8 @@ int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     PR_REQUIRE(c.precision == PR_PRECISION_FP32 || c.precision == PR_PRECISION_F16X3, "unknown precision %d", c.precision);
     PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_TRAIN_BN)),
                "the split-precision kernel has no train-mode BatchNorm phases yet: use PR_PRECISION_FP32 for training");
-    PR_REQUIRE(!(c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || (c.flags & PR_FLAG_TRAIN_BN),
-               "PR_FLAG_SAVE_FOR_BACKWARD needs PR_FLAG_TRAIN_BN (the backward pass differentiates the train-mode BatchNorm)");
+    PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_SAVE_FOR_BACKWARD)),
+               "differentiable calls run on the exact kernel: use PR_PRECISION_FP32 with PR_FLAG_SAVE_FOR_BACKWARD");
     PR_REQUIRE(!(c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || !(c.flags & PR_FLAG_NAIVE_MLP), "the scalar debugging kernel saves nothing");
     for (int k = 0; k < c.objects; ++k) {
         const pr_object_model_t& m = objs[k].coarse;
@@ -160,7 +160,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     plan->rec_pos = take(sizeof(float) * 3 * max_cap);
     plan->rec_flat = take(sizeof(int32_t) * max_cap);
-    if (c.flags & PR_FLAG_TRAIN_BN) {
+    if (c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD)) {   // the phased launch structure (see render())
         plan->h1 = take(sizeof(float) * max_cap * MAX_WIDTH);
         plan->h2 = take(sizeof(float) * max_cap * (MAX_WIDTH / 2 + 32));
         plan->row_flags = take(sizeof(int32_t) * max_cap);
@@ -309,7 +309,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             }
             const size_t cap = (size_t)c.frames * c.rays * P;
             const int max_tiles = (int)cap;   // rows: every launcher derives its own tile count
-            if (!(c.flags & PR_FLAG_TRAIN_BN)) {
+            if (!(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD))) {
                 PR_TRY(launch_adain_fold(fo, s));
                 if (c.precision == PR_PRECISION_F16X3 && !naive)
                     PR_TRY(launch_mlp_split(mp, max_tiles, s));
@@ -317,7 +317,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
             } else {
                 // BatchNorm in training mode: the batch statistics of the first (second) AdaIN layer are
-                // a reduction over every evaluated sample of this object call, between two matmuls
+                // a reduction over every evaluated sample of this object call, between two matmuls.
+                // Differentiable eval-mode calls (SAVE without TRAIN_BN) use the same phases - they leave the pre-BatchNorm
+                // activations h1 / h2 behind for the backward pass - with the running statistics frozen.
+                const bool frozen = !(c.flags & PR_FLAG_TRAIN_BN);
                 PR_REQUIRE(!naive, "the scalar debugging kernel has no train-mode BatchNorm");
                 double* stats = reinterpret_cast<double*>(ws + plan.stats);
                 int32_t* stat_count = reinterpret_cast<int32_t*>(ws + (save ? sv.stat_count : plan.stat_count));
@@ -346,6 +349,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 BnFinalizeParams bf;
                 memset(&bf, 0, sizeof(bf));
                 bf.stats = stats; bf.count = stat_count; bf.width = d.W; bf.width_pad = d.Wpad; bf.momentum = 0.1f;
+                bf.frozen = frozen ? 1 : 0;
                 bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
                 bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
                 PR_TRY(launch_bn_finalize(bf, s));

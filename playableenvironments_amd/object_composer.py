@@ -308,17 +308,18 @@ class ObjectComposer(nn.Module):
             self._annealing[id(encoder)] = cached
         return cached[1]
 
-    def _precision_code(self) -> int:
+    def _precision_code(self, differentiable: bool = False) -> int:
         if self.precision not in ("fp32", "f16x3"):
             raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32' or 'f16x3')")
-        if self.precision == "f16x3" and self.training:
-            return _lib.PR_PRECISION_FP32   # train-mode BatchNorm phases exist for the exact kernel only
+        if self.precision == "f16x3" and (self.training or differentiable):
+            return _lib.PR_PRECISION_FP32   # train-mode BatchNorm phases / saved activations exist for the exact kernel only
         return _lib.PR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.PR_PRECISION_FP32
 
-    def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int) -> torch.Tensor:
+    def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int,
+                        differentiable: bool = False) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
         params = list(model.parameters())
-        precision = self._precision_code()
+        precision = self._precision_code(differentiable)
         key = (precision,) + tuple((p.data_ptr(), p._version) for p in params)
         cached = self._packed.get(id(model))
         if cached is not None and cached[0] == key:
@@ -350,7 +351,8 @@ class ObjectComposer(nn.Module):
         deformation (..., D, K); object_in_scene (..., K).  ``_noise`` (extension, optional) replays
         explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state.
 
-        Autograd: with gradients enabled and the module in training mode the call is differentiable with
+        Autograd: with gradients enabled the call is differentiable (training mode: through the batch statistics of the
+        BatchNorm layers; eval mode: with the running statistics as constants, e.g. test-time optimisation) with
         respect to the parameters, ``style``, ``deformation`` and ``transformation_matrix_w2o`` through
         ``integrated_features``, ``opacity``, ``depth`` and ``integrated_displacements_magnitude`` of every
         entry (pr_render_backward).  ``integrated_divergence`` carries the Hutchinson estimate of the reference
@@ -371,9 +373,6 @@ class ObjectComposer(nn.Module):
                                                   transformation_matrix_w2o.requires_grad)
         if not wants_grad:
             return self._render(*args)[0]
-        if not self.training:
-            raise NotImplementedError("the backward pass differentiates the train-mode BatchNorm (module.train()); call the "
-                                      "module under torch.no_grad() for evaluation")
         kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
                       transformation_matrix_w2o=transformation_matrix_w2o, style=style, deformation=deformation,
                       object_in_scene=object_in_scene, perturb=perturb, canonical_pose=canonical_pose, _noise=_noise,
@@ -445,10 +444,10 @@ class ObjectComposer(nn.Module):
                 if models_c[k].model_config[attr] != want:
                     raise Exception(f"object {k}: {attr} is {models_c[k].model_config[attr]} but the tensor has {want}")
             objs[k].coarse = self._model_struct(models_c[k], pc[k])
-            objs[k].packed_coarse = self._packed_weights(models_c[k], objs[k].coarse, stream).data_ptr()
+            objs[k].packed_coarse = self._packed_weights(models_c[k], objs[k].coarse, stream, _save).data_ptr()
             if use_fine:
                 objs[k].fine = self._model_struct(models_f[k], pc[k] + pf[k])
-                objs[k].packed_fine = self._packed_weights(models_f[k], objs[k].fine, stream).data_ptr()
+                objs[k].packed_fine = self._packed_weights(models_f[k], objs[k].fine, stream, _save).data_ptr()
 
         flags = 0
         if perturb:
@@ -477,10 +476,10 @@ class ObjectComposer(nn.Module):
             else:
                 t = (torch.randn if normal else torch.rand)(shape, **f32)
             noise[name] = t
-        if _save:
+        if _save and self.training:
             # Hutchinson probes of compute_approximate_divergence (object_composer.py:597): drawn whenever the
-            # reference trains with a graph, independent of `perturb`; only objects with a ray bender have a
-            # non-zero displacement field
+            # reference trains with a graph (zeros in eval mode), independent of `perturb`; only objects with a ray
+            # bender have a non-zero displacement field
             for k in range(K):
                 if models_c[k].ray_bender.has_weights:
                     get(f"div_coarse_{k}", (N, R, pc[k], 3), True)
@@ -504,7 +503,7 @@ class ObjectComposer(nn.Module):
             call.static_objects = helper.static_objects_count if _object_ids is None else 0
             call.use_fine = 1 if use_fine else 0
             call.flags = flags
-            call.precision = self._precision_code()
+            call.precision = self._precision_code(_save)
             d = dirs if (r0 == 0 and r1 == R) else dirs[:, r0:r1].contiguous()
             keep.append(d)
             call.ray_origins, call.ray_directions = origins.data_ptr(), d.data_ptr()
@@ -543,6 +542,10 @@ class ObjectComposer(nn.Module):
         state = None
         chunk = R
         need = workspace_bytes(build_call(0, R))
+        if _save and need > self.max_workspace_bytes:
+            raise RuntimeError(f"this differentiable renderer call would keep {need / 2**30:.1f} GiB of activations for its "
+                               f"backward pass (limit {self.max_workspace_bytes / 2**30:.0f} GiB): render under "
+                               "torch.no_grad(), or differentiate fewer rays per call (training uses ray patches)")
         if need > self.max_workspace_bytes and R > 1 and not self.training:  # batch statistics need the whole call
             chunk = max(1, int(R * self.max_workspace_bytes / need))
             chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
@@ -679,9 +682,6 @@ class ObjectComposer(nn.Module):
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
                                                   transformation_matrix_w2o.requires_grad)
         if wants_grad:
-            if not self.training:
-                raise NotImplementedError("the backward pass differentiates the train-mode BatchNorm (module.train()); call "
-                                          "the module under torch.no_grad() for evaluation")
             return self._expected_positions_with_graph(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o,
                                                        style, deformation, object_in_scene, object_id, perturb, canonical_pose,
                                                        noise, params)

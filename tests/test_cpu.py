@@ -247,15 +247,16 @@ def test_abi_error_paths_without_a_device(built_library):
     bsize = C.c_size_t()
     assert lib.pr_backward_workspace_size(C.byref(call), objs, C.byref(bsize)) == -1
     assert b"PR_FLAG_SAVE_FOR_BACKWARD" in lib.pr_last_error()
-    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD
-    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # saving needs train-mode BatchNorm
-    assert b"PR_FLAG_TRAIN_BN" in lib.pr_last_error()
-    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD | _lib.PR_FLAG_TRAIN_BN
     eval_size = size.value
+    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD                                        # differentiable eval-mode call
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == 0 and size.value > 4 * eval_size
+    assert lib.pr_backward_workspace_size(C.byref(call), objs, C.byref(bsize)) == 0 and bsize.value > 0
+    call.flags = _lib.PR_FLAG_SAVE_FOR_BACKWARD | _lib.PR_FLAG_TRAIN_BN
     assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == 0 and size.value > 4 * eval_size
     assert lib.pr_backward_workspace_size(C.byref(call), objs, C.byref(bsize)) == 0 and bsize.value > 0
     call.precision = _lib.PR_PRECISION_F16X3
-    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # split kernel: eval only
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # split kernel: no saved activations
+    assert b"PR_PRECISION_FP32" in lib.pr_last_error()
     call.precision, call.flags = 7, 0
     assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1
     assert b"precision" in lib.pr_last_error()

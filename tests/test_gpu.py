@@ -333,8 +333,12 @@ def test_train_mode_guards():
     cfg = configs.tennis_config()
     comp = build(cfg).cuda()
     inputs = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=2), pixels=grid_pixels(256, 256, 8))]
-    with pytest.raises(NotImplementedError):
-        comp(*inputs, False)          # eval mode with gradients enabled: only the train-mode graph is differentiable
+    out = comp(*inputs, False)         # eval mode with gradients enabled: a differentiable call (frozen BatchNorm)
+    assert out["coarse"]["global"]["integrated_features"].requires_grad
+    comp.max_workspace_bytes = 1 << 20
+    with pytest.raises(RuntimeError, match="activations"):
+        comp(*inputs, False)           # differentiable calls are never split: the saved activations must fit
+    del comp.max_workspace_bytes
     comp.train()
     # a camera that sees nothing -> no evaluated sample -> torch's BatchNorm error, as in the reference
     scene = synthetic.tennis_scene(seed=2)
@@ -373,9 +377,9 @@ def _probe_loss(results, probes, K):
     return total
 
 
-def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS):
+def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True):
     """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``."""
-    comp = build(cfg, alpha_bias=bias).train()
+    comp = build(cfg, alpha_bias=bias).train(training)
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
     o, d, nrm, w2o, sty, dfm, ins = inputs
     K = w2o.size(-1)
@@ -386,7 +390,7 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     ref_in = [t.clone().requires_grad_(True) for t in (w2o, sty, dfm)]
     rec = {}
     torch.manual_seed(123)
-    want = ro.composer_forward(cfg, sd, o, d, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=True,
+    want = ro.composer_forward(cfg, sd, o, d, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=training,
                                record_noise=rec, stable_merge=True)
     gen = torch.Generator().manual_seed(7)
     probes = {(ty, nm, key): torch.randn(want[ty][nm][key].shape, generator=gen)
@@ -406,7 +410,7 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     rep = compare_results(fields, {ty: got[ty] for ty in fields}, rtol=1e-3, atol=2e-4)
     bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
     assert not bad, bad
-    if not canonical:
+    if not canonical and training:
         a = want["coarse"]["global"]["integrated_divergence"].detach()
         b = got["coarse"]["global"]["integrated_divergence"].detach().cpu()
         assert float(a.abs().max()) > 1e-2 and float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 2e-4
@@ -488,6 +492,32 @@ def test_backward_of_the_compositing_weights(name, perturb):
             bad[k] = (err, scale)
     assert not bad, bad
     assert nonzero > 20
+
+
+@pytest.mark.parametrize("name,perturb", [("tennis", False), ("minecraft", True), ("tennis_hierarchical", False)])
+def test_backward_in_eval_mode_with_frozen_batchnorm(name, perturb):
+    """module.eval() with gradients enabled (test-time optimisation of poses / style codes / weights): the BatchNorm
+    layers normalise with their running statistics, which are constants of the graph - against the oracle's autograd
+    with training=False.  The running statistics must not move."""
+    if name == "minecraft":
+        cfg, scene, n, bias = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS), synthetic.minecraft_scene(), 16, 3.0
+    elif name == "tennis_hierarchical":
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
+    else:
+        cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
+    grads = _gradients(cfg, scene, n, bias, perturb, training=False)
+    largest = max(float(a.abs().max()) for a, _ in grads.values())
+    tol = 1e-3 if name == "tennis_hierarchical" else 1e-4
+    bad, nonzero = {}, 0
+    for k, (a, b) in grads.items():
+        scale = float(a.abs().max())
+        nonzero += scale > 0
+        err = float((a - b).abs().max())
+        if err > tol * scale + 2e-7 * largest:
+            bad[k] = (err, scale)
+    assert not bad, bad
+    assert nonzero > 40
 
 
 def test_backward_full_size_networks():
