@@ -795,3 +795,74 @@ def test_expected_positions_match_reference_fixtures(path):
         b = leaf[("w2o", "style", "deformation").index(k)].grad if k in ("style", "deformation") else params[k].grad
         check(k, a, b.detach().cpu() if b is not None else torch.zeros_like(a))
     assert not bad, bad
+
+
+# --------------------------------------------------------------------------------------------
+# Edge cases of the call shapes
+# --------------------------------------------------------------------------------------------
+def _compare_with_oracle(cfg, comp, inputs, perturb=False):
+    want, got = run_both(cfg, comp, inputs, perturb=perturb)
+    rep = compare_results(want, got, rtol=RTOL, atol=ATOL)
+    return {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
+
+
+def test_single_ray_and_single_frame_call():
+    """R = 1: one ray through the whole pipeline (compaction, MLP tile padding, compositing) - hit and miss."""
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    comp = build(cfg, alpha_bias=3.0)
+    scene = synthetic.minecraft_scene(seed=3)
+    for pixel in ((128, 128), (0, 0), (255, 255)):
+        inputs = composer_inputs(cfg, scene, pixels=(torch.tensor([pixel[0]]), torch.tensor([pixel[1]])))
+        assert inputs[1].shape[-2] == 1
+        bad = _compare_with_oracle(cfg, comp, inputs)
+        assert not bad, (pixel, bad)
+
+
+def test_every_object_absent():
+    """object_in_scene all False: every sample carries the empty-space alpha, nothing is evaluated by the MLP; fields
+    (including the NaN disparity of zero-opacity rays) as the oracle."""
+    cfg = configs.reduced_config(configs.tennis_config(), **SMALL_NETS)
+    comp = build(cfg)
+    inputs = list(composer_inputs(cfg, synthetic.tennis_scene(seed=4), pixels=grid_pixels(256, 256, 8)))
+    inputs[6] = torch.zeros_like(inputs[6])
+    bad = _compare_with_oracle(cfg, comp, inputs)
+    assert not bad, bad
+    want, got = run_both(cfg, comp, inputs)
+    assert float(got["coarse"]["global"]["opacity"].abs().max()) == 0.0
+
+
+def test_eight_object_instances():
+    """PR_MAX_OBJECTS = 8 instances in one call: two static models and six players sharing one model (K = 8 sample lists
+    merged per ray, overlap fix on), against the oracle."""
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    cfg["model"]["object_parameters_encoder"] = [{"objects_count": 1}, {"objects_count": 1}, {"objects_count": 6}]
+    comp = build(cfg, alpha_bias=3.0)
+    assert comp.object_id_helper.objects_count == 8
+    base = synthetic.minecraft_scene(seed=6)
+    scene = dict(base)
+    g = torch.Generator().manual_seed(1)
+    for key in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
+        t = base[key]
+        extra = t[..., 2:3].repeat_interleave(6, dim=-1)
+        if key == "object_translation_parameters":       # spread the six players around the first one
+            extra = extra + torch.cat([torch.zeros(list(t.shape[:-1]) + [1]), 1.5 * torch.randn(list(t.shape[:-1]) + [5], generator=g)], -1)
+            extra[..., 1, :] = t[..., 1, 2:3]             # keep them on the ground
+        elif key in ("object_style", "object_deformation"):
+            extra = torch.randn(extra.shape, generator=g)
+        scene[key] = torch.cat([t[..., :2], extra], dim=-1)
+    scene["object_in_scene"] = torch.ones(list(base["object_in_scene"].shape[:-1]) + [8], dtype=torch.bool)
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 16))
+    assert inputs[3].shape[-1] == 8
+    bad = _compare_with_oracle(cfg, comp, inputs, perturb=True)
+    assert not bad, bad
+    with pytest.raises(Exception):
+        cfg9 = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+        cfg9["model"]["object_parameters_encoder"] = [{"objects_count": 1}, {"objects_count": 1}, {"objects_count": 7}]
+        c9 = build(cfg9).cuda()
+        big = [t.cuda() for t in inputs]
+        big[3] = torch.cat([big[3], big[3][..., :1]], -1)
+        big[4] = torch.cat([big[4], big[4][..., :1]], -1)
+        big[5] = torch.cat([big[5], big[5][..., :1]], -1)
+        big[6] = torch.cat([big[6], big[6][..., :1]], -1)
+        with torch.no_grad():
+            c9(*big, False)            # nine instances: rejected (PR_MAX_OBJECTS)
