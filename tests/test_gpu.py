@@ -866,3 +866,36 @@ def test_eight_object_instances():
         big[6] = torch.cat([big[6], big[6][..., :1]], -1)
         with torch.no_grad():
             c9(*big, False)            # nine instances: rejected (PR_MAX_OBJECTS)
+
+
+def test_frame_graph_replay_is_bit_identical():
+    """FrameGraph: one minecraft frame captured as a HIP graph and replayed for other scene encodings - every field equal
+    to the eager render of the same encoding, for both kernels; stale weights are refused."""
+    from playableenvironments_amd.frame_graph import FrameGraph, SCENE_KEYS
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=3.0, bender_scale=1e4)
+    model = model.eval().cuda()
+    size = (64, 96)
+    scenes = [{k: v.cuda() for k, v in synthetic.minecraft_scene(seed=s, image_size=size).items() if torch.is_tensor(v)}
+              for s in (5, 6, 7)]
+    for precision in ("fp32", "f16x3"):
+        model.object_composer.precision = precision
+        graph = FrameGraph(model, scenes[0], size)
+        for scene in scenes[::-1]:
+            got = graph.render(scene)
+            with torch.no_grad():
+                want = model(*[scene[k] for k in SCENE_KEYS[:3]], size, *[scene[k] for k in SCENE_KEYS[3:]], 0, False,
+                             mode="scene_encodings")
+            torch.cuda.synchronize()
+            for entry in ("global", "object_0", "object_3"):
+                for key in ("integrated_features", "opacity", "depth", "weights"):
+                    assert torch.equal(got["coarse"][entry][key], want["coarse"][entry][key]), (precision, entry, key)
+            assert torch.equal(got["reconstructed_bounding_boxes"], want["reconstructed_bounding_boxes"])
+    with torch.no_grad():
+        next(model.object_composer.parameters()).add_(1e-3)
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        graph.render(scenes[0])
+    model.train()
+    with pytest.raises(ValueError):
+        FrameGraph(model, scenes[0], size)
