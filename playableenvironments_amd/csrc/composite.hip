@@ -177,7 +177,12 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     {
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
+#if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE >= 2
+        for (int e = lane; e < PT; e += 64) sm.key[e] = (unsigned long long)e;   // measurement build: no merge (wrong order)
+        __syncthreads();
+#else
         order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane);
+#endif
     }
 
     // ---- global alphas / weights in sorted order -------------------------------------------------
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             count += __popcll(m);
         }
         __syncthreads();
-#if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE == 1
+#if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE >= 1
         count = 0;   // measurement build: no feature rows are read
 #endif
         float acco[MAX_FCHUNK];

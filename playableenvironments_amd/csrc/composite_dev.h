@@ -48,24 +48,39 @@ __device__ __forceinline__ void order_entries(unsigned long long* key, const flo
         merge = __ballot(ok) == ~0ull;
     }
     if (merge) {
+        // Each lane owns a run of consecutive entries of a list: their ranks in another (sorted) list are non-decreasing,
+        // so every search after the first starts where the previous one ended and first probes a window of 8 entries.
         int off = 0;
         for (int k = 0; k < objects; ++k) {
             const int P = positions[k];
-            for (int i = lane; i < P; i += 64) {
+            const int run = (P + 63) >> 6;
+            const int first = lane * run;
+            int resume[PR_MAX_OBJECTS];
+#pragma unroll
+            for (int q = 0; q < PR_MAX_OBJECTS; ++q) resume[q] = 0;
+            for (int i = first; i < first + run && i < P; ++i) {
                 const float t = tt[off + i];
                 int rank = i;
                 int o2 = 0;
-                for (int k2 = 0; k2 < objects; ++k2) {
+#pragma unroll
+                for (int k2 = 0; k2 < PR_MAX_OBJECTS; ++k2) {
+                    if (k2 >= objects) break;
                     const int P2 = positions[k2];
                     if (k2 != k) {
                         // entries of an earlier object win ties (stable in object order)
-                        int lo = 0, hi = P2;
+                        auto before = [&](int idx) {
+                            const float v = tt[o2 + idx];
+                            return (k2 < k) ? (v <= t) : (v < t);
+                        };
+                        int lo = resume[k2], hi = P2;
+                        if (lo + 8 < hi) {
+                            if (before(lo + 7)) lo += 8; else hi = lo + 7;
+                        }
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
-                            const float v = tt[o2 + mid];
-                            const bool before = (k2 < k) ? (v <= t) : (v < t);
-                            if (before) lo = mid + 1; else hi = mid;
+                            if (before(mid)) lo = mid + 1; else hi = mid;
                         }
+                        resume[k2] = lo;
                         rank += lo;
                     }
                     o2 += P2;
