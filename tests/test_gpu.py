@@ -899,3 +899,45 @@ def test_frame_graph_replay_is_bit_identical():
     model.train()
     with pytest.raises(ValueError):
         FrameGraph(model, scenes[0], size)
+
+
+def test_two_cameras_per_observation():
+    """cameras_count = 2: the object tensors carry a singleton camera dimension that broadcasts against (..., O, C) rays
+    (model/environment_model.py:1041-1158 shapes).  The reference itself only runs with one camera (its boolean-mask
+    write of the empty-space alpha does not broadcast, object_composer.py:547), so the expectation is the oracle's
+    render of each camera on its own."""
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    model = em.EnvironmentModel(cfg)
+    torch.manual_seed(0)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=3.0, bender_scale=1e4)
+    model.eval()
+    two = synthetic.minecraft_scene(batch=1, observations=2, seed=91, image_size=(48, 64))
+    object_keys = ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation",
+                   "object_in_scene")
+
+    def arguments(scene):
+        return [scene[k] for k in ("camera_rotations", "camera_translations", "focals")] + [two["image_size"]] + \
+               [scene[k] for k in object_keys]
+
+    sd = {k: v.clone() for k, v in model.object_composer.state_dict().items()}
+    per_camera = []
+    with torch.no_grad():
+        for c in range(2):      # camera c of the pair as a single-camera scene, objects of observation 0
+            single = {k: two[k][:, c:c + 1] for k in ("camera_rotations", "camera_translations", "focals")}
+            single.update({k: two[k][:, :1] for k in object_keys})
+            per_camera.append(ro.render_from_scene_encoding(cfg, sd, *arguments(single), strides=[4, 8]))
+        pair = {"camera_rotations": two["camera_rotations"].reshape(1, 1, 2, 3),
+                "camera_translations": two["camera_translations"].reshape(1, 1, 2, 3), "focals": two["focals"].reshape(1, 1, 2)}
+        pair.update({k: two[k][:, :1] for k in object_keys})
+        model = model.cuda()
+        got = model(*[a.cuda() if torch.is_tensor(a) else a for a in arguments(pair)], 0, False, 1000, patch_stride=[4, 8],
+                    mode="scene_encodings")
+    b = got["coarse"]["global"]["integrated_features"].cpu()
+    assert b.shape == (1, 1, 2, 12 * 16 + 6 * 8, SMALL_NETS["features"])
+    for c in range(2):
+        a = per_camera[c]["coarse"]["global"]["integrated_features"][:, :, 0]
+        bad = ((a - b[:, :, c]).abs() > ATOL + RTOL * a.abs()).any(-1).float().mean()
+        assert float(bad) <= 0.005, (c, float(bad))
+    assert not torch.equal(b[0, 0, 0], b[0, 0, 1])                      # the two cameras see different images
+    assert tuple(got["reconstructed_bounding_boxes"].shape) == (1, 1, 2, 4, 4)
+    assert tuple(got["coarse"]["object_2"]["weights"].shape) == (1, 1, 2, 240, 32)
