@@ -148,7 +148,13 @@ class _RenderFunction(torch.autograd.Function):
                             g = g.to(torch.float32).contiguous()
                             keep.append(g)
                             getattr(ogs[ty], field)[k] = g.data_ptr()
-        grads = {id(p): torch.zeros_like(p, dtype=torch.float32) for p in ctx.params}
+        # every parameter gradient is a view of ONE zero-initialised buffer (a single fill instead of one per tensor;
+        # parallel.allreduce_gradients reduces such a buffer in place, without flattening copies)
+        flat = torch.zeros(sum(p.numel() for p in ctx.params), **f32)
+        grads, offset = {}, 0
+        for p in ctx.params:
+            grads[id(p)] = flat[offset:offset + p.numel()].view(p.shape)
+            offset += p.numel()
         ig = _lib.InputGrads()
         d_w2o = torch.zeros((N, K, 3, 4), **f32)
         d_style = torch.zeros((N, K, S), **f32)

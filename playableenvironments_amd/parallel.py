@@ -76,6 +76,16 @@ def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None, av
     if not dist.is_initialized() or dist.get_world_size(group) == 1 or not params:
         return 0
     world = dist.get_world_size(group)
+    shared = _shared_gradient_buffer(params)
+    if shared is not None:
+        # the renderer's backward hands out views of one flat buffer: reduce it where it lies
+        per_bucket = max(1, bucket_bytes // 4)
+        pieces = [shared[i:i + per_bucket] for i in range(0, shared.numel(), per_bucket)]
+        for piece in pieces:
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                piece /= world
+        return len(pieces)
     buckets: List[List[torch.nn.Parameter]] = [[]]
     used = 0
     for p in params:
@@ -102,6 +112,24 @@ def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None, av
                 p.grad.copy_(g)
             offset += n
     return len(buckets)
+
+
+def _shared_gradient_buffer(params: List[torch.nn.Parameter]):
+    """The flat fp32 tensor behind the gradients when they are consecutive contiguous views of one storage (what
+    ObjectComposer's backward produces), else None."""
+    first = params[0].grad
+    if first is None or first.dtype != torch.float32:
+        return None
+    storage = first.untyped_storage().data_ptr()
+    expect = first.storage_offset()
+    for p in params:
+        g = p.grad
+        if (g is None or g.dtype != torch.float32 or g.device != first.device or not g.is_contiguous()
+                or g.untyped_storage().data_ptr() != storage or g.storage_offset() != expect):
+            return None
+        expect += g.numel()
+    total = expect - first.storage_offset()
+    return torch.as_strided(first, (total,), (1,), first.storage_offset())
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -345,6 +345,20 @@ def _gloo_grad_worker(rank, world, port, results):
         for i, p in enumerate(net.parameters()):
             want = (1.0 * (i + 1) + (0.0 if i == 0 else 2.0 * (i + 1))) / 2.0
             ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+        # gradients that are consecutive views of one flat buffer (what ObjectComposer's backward hands out) are reduced
+        # in place, without flattening copies
+        flat = torch.empty(sum(p.numel() for p in net.parameters()))
+        offset = 0
+        for i, p in enumerate(net.parameters()):
+            p.grad = flat[offset:offset + p.numel()].view(p.shape)
+            p.grad.fill_(float(rank + 1) * (i + 1))
+            offset += p.numel()
+        before = flat.data_ptr()
+        calls = parallel.allreduce_gradients(net.parameters(), bucket_bytes=64)
+        ok = ok and calls == -(-flat.numel() // 16) and parallel._shared_gradient_buffer(list(net.parameters())) is not None
+        for i, p in enumerate(net.parameters()):
+            ok = ok and torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) and \
+                p.grad.untyped_storage().data_ptr() == before
         net[1].running_mean.fill_(float(rank + 3))
         parallel.broadcast_buffers(net, src=0)
         ok = ok and float(net[1].running_mean[0]) == 3.0
