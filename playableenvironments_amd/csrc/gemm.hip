@@ -44,10 +44,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
-    const int n0 = blockIdx.y * GT;
+    // Workgroup ids are dealt to the 8 XCDs round-robin.  The column tiles of one row tile read the same A rows: they
+    // get ids that differ by 8 (same XCD, dispatched one after the other), so the second read is an L2 hit.
+    const int ncol_tiles = (p.n + GT - 1) / GT;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int n0 = (slot % ncol_tiles) * GT;
+    const int first_tile = (slot / ncol_tiles) * 8 + xcd;
+    const int tile_stride = (gridDim.x / (8 * ncol_tiles)) * 8;
     const int ak4 = tid & 7, arow = tid >> 3;       // A: rows arow + 32 i, one float4 of k each
     const int bn = tid & 127, bk = tid >> 7;        // B: k rows bk + 2 i, one dword each
-    for (int row0 = blockIdx.x * GT; row0 < M; row0 += gridDim.x * GT) {
+    for (int row0 = first_tile * GT; row0 < M; row0 += tile_stride * GT) {
         f32x16 acc[2][2];
         zero_acc(acc);
         float4 ra[4];
@@ -163,7 +169,9 @@ int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s) {
     if (max_rows <= 0 || p.n <= 0) return PR_OK;
     int row_tiles = (max_rows + GT - 1) / GT;
     if (row_tiles > 1024) row_tiles = 1024;
-    hipLaunchKernelGGL(k_gemm_nn, dim3(row_tiles, (p.n + GT - 1) / GT), dim3(256), 0, s, p);
+    row_tiles = (row_tiles + 7) / 8 * 8;              // whole groups of 8 row tiles (one per XCD)
+    const int ncol_tiles = (p.n + GT - 1) / GT;
+    hipLaunchKernelGGL(k_gemm_nn, dim3(row_tiles * ncol_tiles), dim3(256), 0, s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }
