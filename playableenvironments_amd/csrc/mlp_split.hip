@@ -75,10 +75,8 @@ __device__ __forceinline__ float split_load(const _Float16* hi_plane, const _Flo
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// splits four values into the hi / lo planes at halves offset `idx` (8-byte aligned)
+// splits four values (already inside the fp16 range) into the hi / lo planes at halves offset `idx` (8-byte aligned)
 __device__ __forceinline__ void split_store4(_Float16* hi_plane, _Float16* lo_plane, int idx, f32x4 v) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], -65504.0f), 65504.0f);   // fp16 range; never reached by sane activations
     const f16x4 hi = __builtin_convertvector(v, f16x4);
     const f32x4 back = __builtin_convertvector(hi, f32x4);
     const f16x4 lo = __builtin_convertvector((v - back) * 2048.0f, f16x4);
@@ -98,8 +96,9 @@ __device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, S
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 v = combine4(m, c, j);
+        // ReLU and the fp16 range guard (never reached by sane activations) in one v_med3_f32
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], 0.f, 65504.0f);
         split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
     }
 }
@@ -112,8 +111,7 @@ __device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, 
         f32x4 v = combine4(m, c, j);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k] = fmaf(v[k], gg[k], bb[k]);
-            v[k] = v[k] > 0.f ? v[k] : 0.f;
+            v[k] = __builtin_amdgcn_fmed3f(fmaf(v[k], gg[k], bb[k]), 0.f, 65504.0f);   // ReLU + range guard
         }
         split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
     }
