@@ -420,8 +420,9 @@ __device__ unsigned long long g_mlp_phase[16];
 #define PR_PHASE(idx) do {} while (0)
 #endif
 
-__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p);
-__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p);
+struct EncRegs;
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
 
 // One layer on the tile.  All threads of the workgroup call it (workgroup barriers inside).
 //
@@ -439,7 +440,7 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p);
     PR_MFMA(acc, a.z, b.z); \
     PR_MFMA(acc, a.w, b.w)
 
-__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind);
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc);
 
 // Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
 //   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
@@ -447,55 +448,111 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
 // layer consumes it - layer 0, and once more for the second K segment of the skip layer - which keeps the
 // workgroup at ~70 KB of LDS, i.e. two independent tiles per CU.
 // 8 threads per row, thread `part` takes the octaves part, part + 8, ... (one sincos per axis).
+// A thread's share of a network input - two tile rows, the octaves part and part + 8, up to 6 input dimensions - kept in
+// registers between the first use of the input (layer 0) and its second (the skip layer's second K segment): the
+// replay writes the values back into X without evaluating the sines and cosines again (VALU work of one resident
+// tile is not hidden behind the other tile's matrix work; it adds to the kernel time).
+constexpr int ENC_ROWS = TILE_M / (MLP_THREADS / 8);
+constexpr int ENC_SLOTS = (PR_MAX_OCTAVES + 7) / 8;
+constexpr int ENC_DIMS = 3;        // positions; the 6-dimensional skybox input is simply evaluated twice
+struct EncRegs {
+    float raw[ENC_ROWS][ENC_DIMS];
+    float sc[ENC_ROWS][ENC_SLOTS][2 * ENC_DIMS];
+};
+static_assert(ENC_ROWS == 2, "fill_encoding keeps two rows per thread");
+
 __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
-                                              const float* octave_weights, bool normalise) {
+                                              const float* octave_weights, bool normalise, EncRegs& regs, bool replay) {
     const int part = threadIdx.x & 7;
-    for (int s = threadIdx.x >> 3; s < TILE_M; s += MLP_THREADS / 8) {
-        float v[6];
-        for (int a = 0; a < din; ++a) {
-            const float x = S.pos[s * 8 + a];
-            v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
-        }
-        float* row = S.X + s * LDX;
-        if (part == 0)
-            for (int a = 0; a < din; ++a) row[a] = v[a];
-        if (part == 1)
-            for (int j = zero_from; j < pad; ++j) row[j] = 0.f;
-        for (int k = part; k < octaves; k += 8) {
-            const float f = ldexpf(1.0f, k);
-            const float w = octave_weights ? octave_weights[k] : 1.0f;
-            float* dst = row + din + k * 2 * din;
+    if (din != ENC_DIMS) {
+        for (int s = threadIdx.x >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+            float v[6];
             for (int a = 0; a < din; ++a) {
-                const float arg = __fmul_rn(f, v[a]);
-                float sn, cs;
-                sn = sinf(arg);
-                cs = cosf(arg);
-                if (octave_weights) {
-                    sn = __fmul_rn(sn, w);
-                    cs = __fmul_rn(cs, w);
+                const float x = S.pos[s * 8 + a];
+                v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+            }
+            float* row = S.X + s * LDX;
+            if (part == 0)
+                for (int a = 0; a < din; ++a) row[a] = v[a];
+            if (part == 1)
+                for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
+            for (int k = part; k < octaves; k += 8) {
+                const float f = ldexpf(1.0f, k);
+                const float w = octave_weights ? octave_weights[k] : 1.0f;
+                float* dst = row + din + k * 2 * din;
+                for (int a = 0; a < din; ++a) {
+                    const float arg = __fmul_rn(f, v[a]);
+                    float sn = sinf(arg), cs = cosf(arg);
+                    if (octave_weights) {
+                        sn = __fmul_rn(sn, w);
+                        cs = __fmul_rn(cs, w);
+                    }
+                    dst[a] = sn;
+                    dst[din + a] = cs;
                 }
-                dst[a] = sn;
-                dst[din + a] = cs;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < ENC_ROWS; ++j) {
+        const int s = (threadIdx.x >> 3) + j * (MLP_THREADS / 8);
+        float* row = S.X + s * LDX;
+        if (!replay) {
+#pragma unroll
+            for (int a = 0; a < ENC_DIMS; ++a) {
+                const float x = S.pos[s * 8 + a];
+                regs.raw[j][a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+            }
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int a = 0; a < ENC_DIMS; ++a) row[a] = regs.raw[j][a];
+        }
+        if (part == 1)
+            for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < ENC_SLOTS; ++slot) {
+            const int k = part + 8 * slot;
+            if (k < octaves) {
+                float* dst = row + ENC_DIMS + k * 2 * ENC_DIMS;
+                if (!replay) {
+                    const float f = ldexpf(1.0f, k);
+                    const float w = octave_weights ? octave_weights[k] : 1.0f;
+#pragma unroll
+                    for (int a = 0; a < ENC_DIMS; ++a) {
+                        const float arg = __fmul_rn(f, regs.raw[j][a]);
+                        float sn = sinf(arg), cs = cosf(arg);
+                        if (octave_weights) {
+                            sn = __fmul_rn(sn, w);
+                            cs = __fmul_rn(cs, w);
+                        }
+                        regs.sc[j][slot][a] = sn;
+                        regs.sc[j][slot][ENC_DIMS + a] = cs;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 2 * ENC_DIMS; ++a) dst[a] = regs.sc[j][slot][a];
             }
         }
     }
 }
 
 // input of the NeRF: PE of the (bent, normalised) position / of the skybox's [o / size, d / |d|]
-__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p) {
-    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0);
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
+    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0, regs, replay);
 }
 
 // input of the ray bender: [annealed PE(x / size) | deformation code of the sample's frame], zero padded
-__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p) {
-    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
+    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true, regs, replay);
     for (int idx = threadIdx.x; idx < TILE_M * p.D; idx += MLP_THREADS) {
         const int s = idx / p.D, j = idx - s * p.D;
         S.X[s * LDX + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
     }
 }
 
-__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind) {
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
@@ -521,7 +578,7 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             // second K segment of a skip layer: its operand is the network input, re-encoded over the
             // (now dead) activations of the first segment
             __syncthreads();
-            if (input_kind == 1) fill_bender_input(S, p); else fill_nerf_input(S, p);
+            if (input_kind == 1) fill_bender_input(S, p, enc, true); else fill_nerf_input(S, p, enc, true);
             __syncthreads();
         }
         if (!active || (p.debug & 128)) continue;
@@ -705,6 +762,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
     __syncthreads();
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
+        EncRegs enc;   // this thread's share of the current network input (see fill_encoding)
         PR_PHASE_T0();
         if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
@@ -740,11 +798,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
 
         // ---- ray bender -----------------------------------------------------------------------
         if (p.has_bender) {
-            fill_bender_input(S, p);
+            fill_bender_input(S, p, enc, false);
             __syncthreads();
             if (p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
-                run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1);
+                run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc);
                 if (p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
                     write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
                     __syncthreads();
@@ -785,14 +843,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
 
         PR_PHASE(1);
         // ---- positional encoding of the NeRF input --------------------------------------------
-        fill_nerf_input(S, p);
+        fill_nerf_input(S, p, enc, false);
         __syncthreads();
         PR_PHASE(2);
         if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false);
 
         // ---- backbone ---------------------------------------------------------------------------
         for (int l = 0; l < p.n_backbone; ++l) {
-            run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0);
+            run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
             if (p.save_act) {
                 write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
                 __syncthreads();
@@ -814,7 +872,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
         if (p.phase == 0) {
-            for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base, 0);
+            for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base, 0, enc);
             PR_PHASE(15);
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
             __syncthreads();   // the next tile's prologue overwrites flags / X
@@ -824,7 +882,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             // their per-channel sums feed the batch statistics
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
-            run_layer(raw, S, p, tile_base, 0);
+            run_layer(raw, S, p, tile_base, 0, enc);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             accumulate_stats(S, p);
@@ -843,6 +901,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
     const Layer& cur = p.layers[p.n_backbone + p.phase - 1];
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
+        EncRegs enc;   // this thread's share of the current network input (see fill_encoding)
         if (tid < TILE_M) {
             const int idx = tile_base + tid;
             const bool valid = idx < total;
@@ -868,7 +927,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
         __syncthreads();
         Layer raw = cur;
         raw.epi = EPI_FEATURES;   // plain store into X
-        run_layer(raw, S, p, tile_base, 0);
+        run_layer(raw, S, p, tile_base, 0, enc);
         if (p.phase == 2) {
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             accumulate_stats(S, p);
