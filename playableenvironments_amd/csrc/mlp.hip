@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
             if (n < j.n_real && k < j.k_real) v = j.src[(size_t)n * j.in_total + j.col_off + k];
         } else if (j.kind == 2) {
             // split fragments: per (column block, 16-wide K step): 64 lanes x 8 halves "hi", then the same for
-            // "lo" = (w - hi) * 2^11.  Lane l holds W[nb*32 + (l & 31)][16 s + 8 (l >> 5) + e], e = 0..7.
+            // "lo" = w - hi (mostly an fp16 subnormal: the matrix pipe takes those exactly).  Lane l holds W[nb*32 + (l & 31)][16 s + 8 (l >> 5) + e], e = 0..7.
             unsigned short out[2];
             for (int t = 0; t < 2; ++t) {
                 const int h = idx * 2 + t;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 float w = 0.f;
                 if (n < j.n_real && k < j.k_real) w = j.src[(size_t)n * j.in_total + j.col_off + k];
                 const _Float16 hi = (_Float16)w;
-                const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+                const _Float16 lo = (_Float16)(w - (float)hi);
                 const _Float16 sel = part ? lo : hi;
                 out[t] = *reinterpret_cast<const unsigned short*>(&sel);
             }

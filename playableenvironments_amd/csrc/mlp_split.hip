@@ -63,10 +63,10 @@ __device__ __forceinline__ void split_store(_Float16* hi_plane, _Float16* lo_pla
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);   // fp16 range; never reached by sane activations
     const _Float16 hi = (_Float16)v;
     hi_plane[idx] = hi;
-    lo_plane[idx] = (_Float16)((v - (float)hi) * 2048.0f);
+    lo_plane[idx] = (_Float16)(v - (float)hi);
 }
 __device__ __forceinline__ float split_load(const _Float16* hi_plane, const _Float16* lo_plane, int idx) {
-    return (float)hi_plane[idx] + (float)lo_plane[idx] * (1.0f / 2048.0f);
+    return (float)hi_plane[idx] + (float)lo_plane[idx];
 }
 
 // Epilogues on (main, correction) accumulator pairs of one 32x32 block.  The weights are the MFMA A operand and the
@@ -79,23 +79,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_store4(_Float16* hi_plane, _Float16* lo_plane, int idx, f32x4 v) {
     const f16x4 hi = __builtin_convertvector(v, f16x4);
     const f32x4 back = __builtin_convertvector(hi, f32x4);
-    const f16x4 lo = __builtin_convertvector((v - back) * 2048.0f, f16x4);
+    const f16x4 lo = __builtin_convertvector(v - back, f16x4);
     *reinterpret_cast<f16x4*>(hi_plane + idx) = hi;
     *reinterpret_cast<f16x4*>(lo_plane + idx) = lo;
 }
 
-__device__ __forceinline__ f32x4 combine4(const f32x16& m, const f32x16& c, int j) {
+__device__ __forceinline__ f32x4 pick4(const f32x16& m, int j) {
     f32x4 v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = fmaf(c[4 * j + k], 1.0f / 2048.0f, m[4 * j + k]);
+    for (int k = 0; k < 4; ++k) v[k] = m[4 * j + k];
     return v;
 }
 
 // idx0 = sample row * LDH + first feature of the lane
-__device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, SmemH& S, int idx0) {
+__device__ __forceinline__ void store_relu_h(const f32x16& m, SmemH& S, int idx0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f32x4 v = combine4(m, c, j);
+        f32x4 v = pick4(m, j);
         // ReLU and the fp16 range guard (never reached by sane activations) in one v_med3_f32
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], 0.f, 65504.0f);
@@ -103,12 +103,12 @@ __device__ __forceinline__ void store_relu_h(const f32x16& m, const f32x16& c, S
     }
 }
 // g / b point at the lane's first feature in the AdaIN table row of the sample's frame
-__device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, SmemH& S, int idx0, const float* g, const float* b) {
+__device__ __forceinline__ void store_adain_h(const f32x16& m, SmemH& S, int idx0, const float* g, const float* b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 8 * j);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 8 * j);
-        f32x4 v = combine4(m, c, j);
+        f32x4 v = pick4(m, j);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             v[k] = __builtin_amdgcn_fmed3f(fmaf(v[k], gg[k], bb[k]), 0.f, 65504.0f);   // ReLU + range guard
@@ -117,9 +117,9 @@ __device__ __forceinline__ void store_adain_h(const f32x16& m, const f32x16& c, 
     }
 }
 // stage = fp32 staging tile over the activation planes; base = &stage[sample row * LDSTAGE + first feature]
-__device__ __forceinline__ void store_stage_h(const f32x16& m, const f32x16& c, float* base) {
+__device__ __forceinline__ void store_stage_h(const f32x16& m, float* base) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(base + 8 * j) = combine4(m, c, j);
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(base + 8 * j) = pick4(m, j);
 }
 
 __device__ __forceinline__ void fill_nerf_input_h(SmemH& S, const MlpParams& p);
@@ -128,10 +128,10 @@ __device__ __forceinline__ void fill_bender_input_h(SmemH& S, const MlpParams& p
 // One layer on the tile (see run_layer in mlp.hip for the geometry: wave w owns the column blocks w and w + 4 for
 // both row blocks; here every block has a main and a correction accumulator).  input_kind: what a src == 1 segment
 // re-computes into X[:, 0:K) - 0 NeRF input, 1 ray-bender input.
-#define PR_SPLIT3(M, C, AH, AL, BH, BL) \
-    PR_MFMA16(M, AH, BH);               \
-    PR_MFMA16(C, AH, BL);               \
-    PR_MFMA16(C, AL, BH)
+#define PR_SPLIT3(M, AH, AL, BH, BL) \
+    PR_MFMA16(M, AH, BH);            \
+    PR_MFMA16(M, AH, BL);            \
+    PR_MFMA16(M, AL, BH)
 
 __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p, int input_kind) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -141,12 +141,12 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     const bool active = cbA < nblk;
     const bool two = cbB < nblk;
     PR_PHASE_T0();
-    // main / correction accumulators: [column block A / B][row block 0 / 1]
-    f32x16 mA0, mA1, mB0, mB1, cA0, cA1, cB0, cB1;
+    // accumulators: [column block A / B][row block 0 / 1]; the three partial products of a step go into the same one
+    f32x16 mA0, mA1, mB0, mB1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        mA0[i] = 0.f; mB0[i] = 0.f;
-        cA0[i] = 0.f; cA1[i] = 0.f; cB0[i] = 0.f; cB1[i] = 0.f;
+        mA0[i] = 0.f;
+        mB0[i] = 0.f;
     }
     if (L.bias != nullptr && active) {
         const float* bp = L.bias + cbA * 32 + 4 * half;   // the lane's 4 x 4 features
@@ -191,10 +191,10 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             f16x8 bBhE = wpB[0], bBlE = wpB[64], bBhO = wpB[128], bBlO = wpB[192];
             for (int s = 0; s < ks; s += 2) {
                 const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
-                PR_SPLIT3(mA0, cA0, ah0E, al0E, bAhE, bAlE);
-                PR_SPLIT3(mA1, cA1, ah1E, al1E, bAhE, bAlE);
-                PR_SPLIT3(mB0, cB0, ah0E, al0E, bBhE, bBlE);
-                PR_SPLIT3(mB1, cB1, ah1E, al1E, bBhE, bBlE);
+                PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
+                PR_SPLIT3(mA1, ah1E, al1E, bAhE, bAlE);
+                PR_SPLIT3(mB0, ah0E, al0E, bBhE, bBlE);
+                PR_SPLIT3(mB1, ah1E, al1E, bBhE, bBlE);
                 bAhE = wpA[(size_t)se * 128];
                 bAlE = wpA[(size_t)se * 128 + 64];
                 bBhE = wpB[(size_t)se * 128];
@@ -203,10 +203,10 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
                 ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
                 al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
-                PR_SPLIT3(mA0, cA0, ah0O, al0O, bAhO, bAlO);
-                PR_SPLIT3(mA1, cA1, ah1O, al1O, bAhO, bAlO);
-                PR_SPLIT3(mB0, cB0, ah0O, al0O, bBhO, bBlO);
-                PR_SPLIT3(mB1, cB1, ah1O, al1O, bBhO, bBlO);
+                PR_SPLIT3(mA0, ah0O, al0O, bAhO, bAlO);
+                PR_SPLIT3(mA1, ah1O, al1O, bAhO, bAlO);
+                PR_SPLIT3(mB0, ah0O, al0O, bBhO, bBlO);
+                PR_SPLIT3(mB1, ah1O, al1O, bBhO, bBlO);
                 bAhO = wpA[(size_t)so * 128];
                 bAlO = wpA[(size_t)so * 128 + 64];
                 bBhO = wpB[(size_t)so * 128];
@@ -225,16 +225,16 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
         } else {
             for (int s = 0; s < ks; s += 2) {
                 const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
-                PR_SPLIT3(mA0, cA0, ah0E, al0E, bAhE, bAlE);
-                PR_SPLIT3(mA1, cA1, ah1E, al1E, bAhE, bAlE);
+                PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
+                PR_SPLIT3(mA1, ah1E, al1E, bAhE, bAlE);
                 bAhE = wpA[(size_t)se * 128];
                 bAlE = wpA[(size_t)se * 128 + 64];
                 ah0E = *reinterpret_cast<const f16x8*>(a0h + 16 * se);
                 al0E = *reinterpret_cast<const f16x8*>(a0l + 16 * se);
                 ah1E = *reinterpret_cast<const f16x8*>(a1h + 16 * se);
                 al1E = *reinterpret_cast<const f16x8*>(a1l + 16 * se);
-                PR_SPLIT3(mA0, cA0, ah0O, al0O, bAhO, bAlO);
-                PR_SPLIT3(mA1, cA1, ah1O, al1O, bAhO, bAlO);
+                PR_SPLIT3(mA0, ah0O, al0O, bAhO, bAlO);
+                PR_SPLIT3(mA1, ah1O, al1O, bAhO, bAlO);
                 bAhO = wpA[(size_t)so * 128];
                 bAlO = wpA[(size_t)so * 128 + 64];
                 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16 * so);
@@ -258,23 +258,21 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
         for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
             const int feat0 = (blk ? cbB : cbA) * 32 + 4 * half;   // first feature of this lane
             const f32x16& m0 = blk ? mB0 : mA0;   // samples 0..31
-            const f32x16& c0 = blk ? cB0 : cA0;
             const f32x16& m1 = blk ? mB1 : mA1;   // samples 32..63
-            const f32x16& c1 = blk ? cB1 : cA1;
             if (L.epi == EPI_RELU) {
-                store_relu_h(m0, c0, S, r * LDH + feat0);
-                store_relu_h(m1, c1, S, (r + 32) * LDH + feat0);
+                store_relu_h(m0, S, r * LDH + feat0);
+                store_relu_h(m1, S, (r + 32) * LDH + feat0);
             } else if (L.epi == EPI_ADAIN_RELU) {
                 const int bofs = L.nblk * 32;
                 const bool uniform = S.uniform_frame != 0;
                 const float* t0 = p.adain + (size_t)S.frame[uniform ? 0 : r] * p.adain_stride + L.adain_off + feat0;
                 const float* t1 = p.adain + (size_t)S.frame[uniform ? 0 : r + 32] * p.adain_stride + L.adain_off + feat0;
-                store_adain_h(m0, c0, S, r * LDH + feat0, t0, t0 + bofs);
-                store_adain_h(m1, c1, S, (r + 32) * LDH + feat0, t1, t1 + bofs);
+                store_adain_h(m0, S, r * LDH + feat0, t0, t0 + bofs);
+                store_adain_h(m1, S, (r + 32) * LDH + feat0, t1, t1 + bofs);
             } else {
                 float* stage = reinterpret_cast<float*>(S.Xh);
-                store_stage_h(m0, c0, stage + r * LDSTAGE + feat0);
-                store_stage_h(m1, c1, stage + (r + 32) * LDSTAGE + feat0);
+                store_stage_h(m0, stage + r * LDSTAGE + feat0);
+                store_stage_h(m1, stage + (r + 32) * LDSTAGE + feat0);
             }
         }
     }
