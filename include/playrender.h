@@ -117,8 +117,8 @@ int pr_packed_size(const pr_object_model_t* model, size_t* bytes);
 /* Gathers the raw parameters into `packed` (device, pr_packed_size bytes, 256-B aligned).  Must be
  * re-run whenever parameter VALUES change; cheap (one pass over ~2.9 MB).
  * precision: PR_PRECISION_FP32 = fp32 MFMA fragments (exact fp32 arithmetic); PR_PRECISION_F16X3 = every weight
- * as an fp16 pair (hi, lo = (w - hi) * 2^11) for the split kernel, which evaluates
- * a*w ~ a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) * 2^-11 with three fp16 MFMAs and fp32 accumulation
+ * as an fp16 pair (hi, lo = w - hi) for the split kernel, which evaluates
+ * a*w ~ a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with three fp16 MFMAs and fp32 accumulation
  * (~22 significant bits).  Both layouts have the same size. */
 #define PR_PRECISION_FP32  0
 #define PR_PRECISION_F16X3 1

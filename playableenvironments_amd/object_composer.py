@@ -209,7 +209,7 @@ class ObjectComposer(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
         #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3": every product as three fp16 MFMAs with
-        #: fp32 accumulation (a_hi*w_hi + (a_hi*w_lo + a_lo*w_hi) * 2^-11, ~22 significant bits) - eval only.
+        #: fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant bits) - eval only.
         self.precision = "fp32"
         #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
         #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
