@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -211,6 +212,7 @@ class ObjectComposer(nn.Module):
         #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3": every product as three fp16 MFMAs with
         #: fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant bits) - eval only.
         self.precision = "fp32"
+        self._warned_precision_fallback = False
         #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
         #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
         #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
@@ -318,7 +320,12 @@ class ObjectComposer(nn.Module):
         if self.precision not in ("fp32", "f16x3"):
             raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32' or 'f16x3')")
         if self.precision == "f16x3" and (self.training or differentiable):
-            return _lib.PR_PRECISION_FP32   # train-mode BatchNorm phases / saved activations exist for the exact kernel only
+            if not self._warned_precision_fallback:
+                self._warned_precision_fallback = True
+                warnings.warn("precision='f16x3' applies to evaluation renders; training-mode and differentiable calls run "
+                              "on the exact fp32 kernel (train-mode BatchNorm phases and saved activations exist there only)",
+                              stacklevel=3)
+            return _lib.PR_PRECISION_FP32
         return _lib.PR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.PR_PRECISION_FP32
 
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int,
