@@ -99,9 +99,10 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     dirs = torch.empty((n, r, 3), dtype=torch.float32, device=dev)
     normals = torch.empty((n, 3), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    _lib.check(lib.pr_camera_rays(n, r, height, width, 1 if per_frame else 0, m.data_ptr(), f.data_ptr(), rows.data_ptr(), cols.data_ptr(),
-                                  origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
-                                  torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
+    with torch.cuda.device(dev):      # the launch goes to the current device: it has to be the tensors' device
+        _lib.check(lib.pr_camera_rays(n, r, height, width, 1 if per_frame else 0, m.data_ptr(), f.data_ptr(), rows.data_ptr(),
+                                      cols.data_ptr(), origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
     return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
 
 

@@ -119,6 +119,12 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grad_outputs):
+        # the library launches on the caller's stream: that stream's device has to be the current one
+        with torch.cuda.device(ctx.state["workspace"].device):
+            return _RenderFunction._backward(ctx, *grad_outputs)
+
+    @staticmethod
+    def _backward(ctx, *grad_outputs):
         st, composer = ctx.state, ctx.composer
         N, R, K, S, D, F = st["N"], st["R"], st["K"], st["S"], st["D"], st["F"]
         lib = _lib.load()
@@ -372,6 +378,15 @@ class ObjectComposer(nn.Module):
         (object_composer.py:582-601) in that mode.  Not differentiated: the camera rays (dataset inputs in the
         reference's trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (its loss weight
         is 0 in the shipped configurations; a second-order pass would be needed)."""
+        if ray_directions.is_cuda:
+            # the library launches on the caller's stream: that stream's device has to be the current one
+            with torch.cuda.device(ray_directions.device):
+                return self._forward(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
+                                     object_in_scene, perturb, canonical_pose, _noise, _export)
+        raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+
+    def _forward(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
+                 object_in_scene, perturb, canonical_pose, _noise, _export) -> Dict:
         K = self.object_id_helper.objects_count
         self._raise_pending_batchnorm_check()
         if transformation_matrix_w2o.size(-1) != K:
@@ -679,6 +694,12 @@ class ObjectComposer(nn.Module):
         (oracle/render_oracle.py:expected_positions_forward)."""
         if not ray_directions.is_cuda:
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+        with torch.cuda.device(ray_directions.device):
+            return self._forward_expected_positions(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                                    deformation, object_in_scene, object_id, perturb, canonical_pose, _noise)
+
+    def _forward_expected_positions(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                    deformation, object_in_scene, object_id, perturb, canonical_pose, _noise) -> Dict:
         self._raise_pending_batchnorm_check()
         noise = None
         if _noise is not None:
