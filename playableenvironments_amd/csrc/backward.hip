@@ -314,12 +314,7 @@ static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
     const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
     PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 160 * 1024, nullptr));
     const long total = (long)p.frames * p.rays;
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)total), dim3(64), lds, s, p);
     PR_LAUNCH_CHECK();

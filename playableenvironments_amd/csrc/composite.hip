@@ -332,12 +332,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
     const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 8 : 7) * 4;
     PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite), 160 * 1024, nullptr));
     const long total = (long)p.frames * p.rays;
     ProfileScope scope(1, s);
     hipLaunchKernelGGL(k_composite, dim3((unsigned)total), dim3(64), lds, s, p);

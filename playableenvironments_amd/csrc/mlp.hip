@@ -1071,7 +1071,6 @@ __global__ __launch_bounds__(64) void k_mlp_naive(MlpParams p, pr_object_model_t
     for (int j = 0; j < p.F; ++j) p.feat[(size_t)idx * p.F + j] = alive ? in[j] : 0.f;
 }
 
-static int g_cu_count = 0;
 
 int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s) {
     if (max_rows <= 0) return PR_OK;
@@ -1088,27 +1087,12 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
     }
     MlpParams pd = p;
     pd.debug = debug_bits;
-    static bool attr_set = false;
-    if (!attr_set) {
-        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        int dev = 0;
-        PR_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_cu_count = prop.multiProcessorCount;
-        attr_set = true;
-    }
-    const int resident = g_cu_count * MLP_BLOCKS_PER_CU;
+    int cu_count = 0;
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(pd.phase >= 2 ? k_mlp_head : k_mlp_mfma), (int)sizeof(Smem), &cu_count));
+    const int resident = cu_count * MLP_BLOCKS_PER_CU;
     const int grid = max_tiles < resident ? max_tiles : resident;
     ProfileScope scope(0, s);
     if (pd.phase >= 2) {
-        static bool head_attr_set = false;
-        if (!head_attr_set) {
-            PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_head),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-            head_attr_set = true;
-        }
         hipLaunchKernelGGL(k_mlp_head, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
     } else {
         hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);

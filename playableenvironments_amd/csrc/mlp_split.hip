@@ -465,18 +465,8 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
 int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
     if (max_rows <= 0) return PR_OK;
     const int max_tiles = (max_rows + STILE_M - 1) / STILE_M;
-    static bool attr_set = false;
-    static int cu_count = 0;
-    if (!attr_set) {
-        PR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_split),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemH)));
-        int dev = 0;
-        PR_CHECK_HIP(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        cu_count = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    int cu_count = 0;
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_split), (int)sizeof(SmemH), &cu_count));
     const int resident = cu_count * SBLOCKS_PER_CU;
     const int grid = max_tiles < resident ? max_tiles : resident;
     ProfileScope scope(0, s);

@@ -311,6 +311,9 @@ struct Plan {
     size_t bytes;
     int nblocks256;
 };
+// Once per (kernel, device): raises the kernel's dynamic LDS limit on the CURRENT device; *cu_count (optional) receives
+// that device's number of compute units.  Function attributes are per device: a process may drive several.
+int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count);
 int validate_call(const pr_call_t& c, const pr_object_t* objs);
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size);

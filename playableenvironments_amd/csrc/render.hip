@@ -17,6 +17,26 @@ static bool g_profile_on = false;
 static std::vector<ProfileRecord> g_profile;
 static std::mutex g_profile_mutex;
 
+int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count) {
+    struct Entry { const void* kernel; int device; int cus; };
+    static std::vector<Entry> done;
+    static std::mutex guard;
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(guard);
+    for (const Entry& e : done)
+        if (e.kernel == kernel && e.device == dev) {
+            if (cu_count) *cu_count = e.cus;
+            return PR_OK;
+        }
+    PR_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipDeviceProp_t prop;
+    PR_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    done.push_back(Entry{kernel, dev, prop.multiProcessorCount});
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    return PR_OK;
+}
+
 ProfileScope::ProfileScope(int category, hipStream_t s) : category_(category), stream_(s), start_(nullptr), active_(false) {
     if (!g_profile_on) return;
     if (hipEventCreate(&start_) != hipSuccess) return;
