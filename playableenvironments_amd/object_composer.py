@@ -462,6 +462,26 @@ class ObjectComposer(nn.Module):
         pc = [m.model_config["positions_count_coarse"] for m in models_c]
         pf = [m.model_config["positions_count_fine"] for m in models_c]
 
+        if N * R == 0:
+            # no rays (an empty batch or an empty pixel list): the result dictionary with empty tensors, no launch
+            if _save:
+                raise ValueError("a differentiable renderer call needs at least one ray")
+            F = models_c[0].nerf_model.output_features
+            results: Dict = {}
+            for ty in ["coarse"] + (["fine"] if use_fine else []):
+                counts = pc if ty == "coarse" else [a + b for a, b in zip(pc, pf)]
+                results[ty] = {}
+                for k in range(K + 1):
+                    P = counts[k] if k < K else sum(counts)
+                    entry = {"integrated_features": torch.empty(lead + [R, F], **f32), "weights": torch.empty(lead + [R, P], **f32)}
+                    for key in ("opacity", "depth", "disparity", "integrated_displacements_magnitude", "integrated_divergence"):
+                        entry[key] = torch.empty(lead + [R], **f32)
+                    if k < K:
+                        entry["extra_outputs"] = {}
+                    results[ty][f"object_{k}" if k < K else "global"] = entry
+            results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
+            return results, None
+
         stream = torch.cuda.current_stream(dev).cuda_stream
         lib = _lib.load()
         keep = []  # tensors that must outlive the enqueue

@@ -941,3 +941,21 @@ def test_two_cameras_per_observation():
     assert not torch.equal(b[0, 0, 0], b[0, 0, 1])                      # the two cameras see different images
     assert tuple(got["reconstructed_bounding_boxes"].shape) == (1, 1, 2, 4, 4)
     assert tuple(got["coarse"]["object_2"]["weights"].shape) == (1, 1, 2, 240, 32)
+
+
+def test_empty_ray_list():
+    """R = 0 (an empty pixel list): the reference's tensor ops return empty results; so does the renderer, without a launch."""
+    cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+    comp = build(cfg).cuda()
+    o, d, n, w2o, sty, dfm, ins = [t.cuda() for t in composer_inputs(cfg, synthetic.tennis_scene(seed=5), pixels=grid_pixels(256, 256, 4))]
+    with torch.no_grad():
+        out = comp(o, d[..., :0, :], n, w2o, sty, dfm, ins, False)
+    assert set(out) == {"coarse", "fine", "pytorch_hook"}
+    lead = tuple(d.shape[:-2])
+    assert tuple(out["fine"]["global"]["integrated_features"].shape) == lead + (0, SMALL_NETS["features"])
+    assert tuple(out["fine"]["object_2"]["weights"].shape) == lead + (0, 32)
+    assert tuple(out["coarse"]["global"]["weights"].shape) == lead + (0, 8 + 8 + 12 + 12)
+    assert tuple(out["coarse"]["object_0"]["opacity"].shape) == lead + (0,)
+    comp.train()
+    with pytest.raises(ValueError):
+        comp(o, d[..., :0, :], n, w2o, sty, dfm, ins, False)     # a differentiable call needs rays
