@@ -959,3 +959,20 @@ def test_empty_ray_list():
     comp.train()
     with pytest.raises(ValueError):
         comp(o, d[..., :0, :], n, w2o, sty, dfm, ins, False)     # a differentiable call needs rays
+
+
+def test_many_samples_per_ray():
+    """512 coarse + 512 resampled positions per ray (a 1024-entry list per ray through placement, resampling, the
+    1024-key sort and compositing) against the oracle; beyond the kernels' LDS budget the library refuses the call."""
+    cfg = configs.reduced_config(configs.enable_fine(configs.tennis_single_player_config()), positions={"player_1": (512, 512)},
+                                 **SMALL_NETS)
+    comp = build(cfg, alpha_bias=1.0)
+    inputs = composer_inputs(cfg, synthetic.single_player_scene(seed=3, image_size=(16, 16)), pixels=grid_pixels(16, 16, 6))
+    want, got = run_both(cfg, comp, inputs)
+    rep = compare_results(want, got, rtol=RTOL, atol=ATOL)
+    bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
+    assert not bad, bad
+    assert tuple(got["fine"]["global"]["weights"].shape)[-1] == 1024
+    huge = configs.reduced_config(configs.tennis_single_player_config(), positions={"player_1": (8192, 8192)}, **SMALL_NETS)
+    with torch.no_grad(), pytest.raises(Exception, match="positions|samples"):
+        build(huge).cuda()(*[t.cuda() for t in inputs], False)
