@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     {
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
-        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane);
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64);
     }
     entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
 
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
 static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
     const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
-    PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
-    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 160 * 1024, nullptr));
+    PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
     const long total = (long)p.frames * p.rays;
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)total), dim3(64), lds, s, p);
     PR_LAUNCH_CHECK();

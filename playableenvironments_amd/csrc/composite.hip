@@ -54,8 +54,62 @@ __device__ __forceinline__ void transmittance_weights(float* al, int n, int lane
 #define ROWS_IN_FLIGHT 8
 #endif
 
-__global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
-    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
+// weights[j] = alpha[j] * prod_{i<j} (...) over al[0..n) by CW waves: wave w scans the contiguous segment
+// [w * seg, (w + 1) * seg) (seg a multiple of 64) from a unit carry, the segment products are exchanged through
+// `totals` and folded in afterwards.
+template <int CW>
+__device__ __forceinline__ void transmittance_weights_block(float* al, int n, float* totals, int wave, int lane) {
+    if (CW == 1) {
+        transmittance_weights(al, n, lane);
+        return;
+    }
+    const int seg = (((n + CW - 1) / CW) + 63) & ~63;
+    const int begin = wave * seg;
+    const int end = (begin + seg < n) ? begin + seg : n;
+    float carry = 1.0f;
+    for (int base = begin; base < end; base += 64) {
+        const int j = base + lane;
+        const float a = (j < end) ? al[j] : 0.f;
+        float incl = (j < end) ? __fadd_rn(__fsub_rn(1.0f, a), 1e-10f) : 1.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl *= o;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        if (j < end) al[j] = a * (carry * excl);
+        carry *= __shfl(incl, 63, 64);
+    }
+    if (lane == 0) totals[wave] = carry;
+    __syncthreads();
+    float before = 1.0f;
+    for (int w = 0; w < wave; ++w) before *= totals[w];
+    if (wave > 0)
+        for (int j = begin + lane; j < end; j += 64) al[j] *= before;
+    __syncthreads();
+}
+
+// sum over the workgroup of a per-thread value, in a fixed order (waves 0 .. CW - 1); every thread receives it
+template <int CW>
+__device__ __forceinline__ float block_sum(float v, float* scratch, int wave, int lane) {
+    v = wave_sum(v);
+    if (CW == 1) return v;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float total = 0.f;
+    for (int w = 0; w < CW; ++w) total += scratch[w];
+    return total;
+}
+
+// CW waves per ray.  Lists of a few hundred entries per ray keep the LDS footprint of a ray at tens of KB, i.e. a
+// handful of rays per CU: with one wave per ray the latency-bound phases (staging, scans, merge) and the number of
+// feature rows in flight were what set the kernel's time.  Wave w integrates the objects w, w + CW, ...; staging, the
+// overlap fix, the merge, the global list and the feature rows are shared by all waves.
+template <int CW>
+__device__ __forceinline__ void composite_ray(const CompositeParams& p, char* raw_smem) {
+    constexpr int CT = 64 * CW;
     const int S = p.sort_size;
     CompositeSmem sm;
     const int A = (p.total_positions + 63) & ~63;   // per-entry arrays (the sort keys need the power of two S)
@@ -70,45 +124,61 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     const bool use_div = p.any_divergence != 0;
     sm.dv = use_div ? sm.al + A : nullptr;
     sm.sl = reinterpret_cast<int*>(sm.al + (use_div ? 2 * A : A));
+    float* scratch = reinterpret_cast<float*>(sm.sl + A);   // [4 * 64 * MAX_FCHUNK] cross-wave reductions
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long g = blockIdx.x;
     const float* d = p.ray_directions + (size_t)g * 3;
     // |d| of the world-frame direction (integrate receives the untransformed directions, :880/:886)
     const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
     const int PT = p.total_positions;
 
-    // ---- stage every object's list, integrate it on its own -----------------------------------
-    int off = 0;
-    for (int k = 0; k < p.objects; ++k) {
-        const CompositeObject& o = p.obj[k];
-        const int P = o.positions;
-        const size_t base = (size_t)g * P;
-        for (int i = lane; i < P; i += 64) {
-            sm.tt[off + i] = o.t[base + i];
-            sm.sg[off + i] = o.sigma[base + i];
-            sm.sl[off + i] = o.slot[base + i];
-            sm.dm[off + i] = o.dispmag ? o.dispmag[base + i] : 0.f;
-            if (use_div) sm.dv[off + i] = o.divergence ? fabsf(o.divergence[base + i]) : 0.f;
+    // ---- stage every object's list ---------------------------------------------------------------
+    {
+        int off = 0;
+        for (int k = 0; k < p.objects; ++k) {
+            const CompositeObject& o = p.obj[k];
+            const int P = o.positions;
+            const size_t base = (size_t)g * P;
+            for (int i = tid; i < P; i += CT) {
+                sm.tt[off + i] = o.t[base + i];
+                sm.sg[off + i] = o.sigma[base + i];
+                sm.sl[off + i] = o.slot[base + i];
+                sm.dm[off + i] = o.dispmag ? o.dispmag[base + i] : 0.f;
+                if (use_div) sm.dv[off + i] = o.divergence ? fabsf(o.divergence[base + i]) : 0.f;
+            }
+            off += P;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- integrate every object on its own: wave w takes the objects w, w + CW, ... ------------------
+    // (wave-private data between the barriers: the alphas live in al[off ..), the object's own slice)
+    for (int round = 0; round * CW < p.objects; ++round) {
+        const int k = round * CW + wave;
+        const bool mine = k < p.objects;
+        int off = 0;
+        for (int q = 0; q < k && q < p.objects; ++q) off += p.obj[q].positions;
+        const CompositeObject& o = p.obj[mine ? k : 0];
+        const int P = mine ? o.positions : 0;
+        const size_t base = (size_t)g * P;
         float adiv = 0.f;   // sum alpha |div|  (object_composer.py:768-769, alphas detached)
         for (int i = lane; i < P; i += 64) {
             const float dt = (i < P - 1) ? __fsub_rn(sm.tt[off + i + 1], sm.tt[off + i]) : 1e10f;
             float raw = sm.sg[off + i];
             if (o.noise) raw = __fadd_rn(raw, o.noise[base + i]);
-            sm.al[i] = alpha_of(raw, __fmul_rn(dt, norm));
-            if (use_div) adiv += sm.al[i] * sm.dv[off + i];
+            const float a = alpha_of(raw, __fmul_rn(dt, norm));
+            sm.al[off + i] = a;
+            if (use_div) adiv += a * sm.dv[off + i];
         }
         adiv = wave_sum(adiv);
         __syncthreads();
-        transmittance_weights(sm.al, P, lane);
-        __syncthreads();
-        for (int i = lane; i < P; i += 64) sm.wo[off + i] = sm.al[i];
+        if (mine) transmittance_weights(sm.al + off, P, lane);
         __syncthreads();
         float depth = 0.f, opacity = 0.f, dmag = 0.f;
         for (int i = lane; i < P; i += 64) {
-            const float w = sm.wo[off + i];
+            const float w = sm.al[off + i];
+            sm.wo[off + i] = w;
             if (o.out.weights) o.out.weights[base + i] = w;
             depth += w * sm.tt[off + i];
             opacity += w;
@@ -117,14 +187,13 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         depth = wave_sum(depth);
         opacity = wave_sum(opacity);
         dmag = wave_sum(dmag);
-        if (lane == 0) {
+        if (mine && lane == 0) {
             if (o.out.depth) o.out.depth[g] = depth;
             if (o.out.opacity) o.out.opacity[g] = opacity;
             if (o.out.disparity) o.out.disparity[g] = disparity_of(depth, opacity);
             if (o.out.integrated_displacements_magnitude) o.out.integrated_displacements_magnitude[g] = dmag / (float)P;
             if (o.out.integrated_divergence) o.out.integrated_divergence[g] = adiv / (float)P;
         }
-        off += P;
     }
     __syncthreads();
 
@@ -138,7 +207,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         int soff = 0;
         for (int s = 0; s < p.static_objects; ++s) {
             const int Ps = p.obj[s].positions;
-            unsigned int masked_bits = 0;  // bit m <-> entry lane + 64 m of this static list (Ps <= 2048)
+            unsigned int masked_bits = 0;  // bit m <-> entry tid + CT m of this static list (Ps <= 2048)
             int doff = dyn_off0;
             for (int dd = p.static_objects; dd < p.objects; ++dd) {
                 const float b0 = sm.tt[doff + 0];
@@ -154,13 +223,13 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
                     if (sm.tt[soff + mid] < b1) lo1 = mid + 1; else hi1 = mid;
                 }
                 int m = 0;
-                for (int i = lane; i < Ps; i += 64, ++m)
+                for (int i = tid; i < Ps; i += CT, ++m)
                     if (i >= lo0 && i < lo1) masked_bits |= 1u << m;
                 doff += p.obj[dd].positions;
             }
-            __syncthreads();  // every lane has finished searching the ORIGINAL t of this list
+            __syncthreads();  // every thread has finished searching the ORIGINAL t of this list
             int m = 0;
-            for (int i = lane; i < Ps; i += 64, ++m) {
+            for (int i = tid; i < Ps; i += CT, ++m) {
                 if ((masked_bits >> m) & 1u) {
                     sm.tt[soff + i] = 0.f;
                     sm.sg[soff + i] = -10.0f;
@@ -178,17 +247,17 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
 #if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE >= 2
-        for (int e = lane; e < PT; e += 64) sm.key[e] = (unsigned long long)e;   // measurement build: no merge (wrong order)
+        for (int e = tid; e < PT; e += CT) sm.key[e] = (unsigned long long)e;   // measurement build: no merge (wrong order)
         __syncthreads();
 #else
-        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane);
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, tid, CT);
 #endif
     }
 
     // ---- global alphas / weights in sorted order -------------------------------------------------
     const size_t gbase = (size_t)g * PT;
     float gdiv = 0.f;
-    for (int j = lane; j < PT; j += 64) {
+    for (int j = tid; j < PT; j += CT) {
         const int e = (int)(sm.key[j] & 0xFFFFFFFFu);
         float dt = 1e10f;
         if (j < PT - 1) {
@@ -200,13 +269,12 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
         if (use_div) gdiv += sm.al[j] * sm.dv[e];
     }
-    gdiv = wave_sum(gdiv);
     __syncthreads();
-    transmittance_weights(sm.al, PT, lane);   // al now holds the sorted-order weights
-    __syncthreads();
+    transmittance_weights_block<CW>(sm.al, PT, scratch, wave, lane);   // al now holds the sorted-order weights
+    if (CW == 1) __syncthreads();
     {
         float depth = 0.f, opacity = 0.f, dmag = 0.f;
-        for (int j = lane; j < PT; j += 64) {
+        for (int j = tid; j < PT; j += CT) {
             const int e = (int)(sm.key[j] & 0xFFFFFFFFu);
             const float w = sm.al[j];
             sm.wg[e] = w;
@@ -215,10 +283,11 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             opacity += w;
             dmag += w * sm.dm[e];
         }
-        depth = wave_sum(depth);
-        opacity = wave_sum(opacity);
-        dmag = wave_sum(dmag);
-        if (lane == 0) {
+        depth = block_sum<CW>(depth, scratch, wave, lane);
+        opacity = block_sum<CW>(opacity, scratch, wave, lane);
+        dmag = block_sum<CW>(dmag, scratch, wave, lane);
+        if (use_div) gdiv = block_sum<CW>(gdiv, scratch, wave, lane);
+        if (tid == 0) {
             if (p.global.depth) p.global.depth[g] = depth;
             if (p.global.opacity) p.global.opacity[g] = opacity;
             if (p.global.disparity) p.global.disparity[g] = disparity_of(depth, opacity);
@@ -230,27 +299,31 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
     __syncthreads();
 
     // ---- features: one pass over the compact MLP rows --------------------------------------------
-    // Per object the contributing samples (inside the box, non-zero weight) are first compacted into a
-    // list (the sort keys are dead by now, their storage is reused), then consumed four rows at a time
-    // so that several 768-byte row reads are in flight per wave.  Sums run in sample order.
+    // Per object the contributing samples (inside the box, non-zero weight) are compacted into per-wave lists (wave w
+    // takes the w-th contiguous part of the object's samples; the sort keys are dead by now, their storage is reused),
+    // then consumed ROWS_IN_FLIGHT rows at a time.  Every wave accumulates all F channels of its part; the parts are added
+    // in wave order.
     const int F = p.F;
     int* lrow = reinterpret_cast<int*>(sm.key);
     float* lw1 = reinterpret_cast<float*>(sm.key) + S;
     float accg[MAX_FCHUNK];
 #pragma unroll
     for (int c = 0; c < MAX_FCHUNK; ++c) accg[c] = 0.f;
-    off = 0;
+    int off = 0;
     for (int k = 0; k < p.objects; ++k) {
         const CompositeObject& o = p.obj[k];
         const int P = o.positions;
+        const int part = (((P + CW - 1) / CW) + 63) & ~63;
+        const int begin = wave * part;
+        const int end = (begin + part < P) ? begin + part : P;
         __syncthreads();
         int count = 0;
-        for (int base = 0; base < P; base += 64) {
+        for (int base = begin; base < end; base += 64) {
             const int i = base + lane;
             bool take = false;
             int row = -1;
             float w1 = 0.f, w2 = 0.f;
-            if (i < P) {
+            if (i < end) {
                 row = sm.sl[off + i];
                 w1 = sm.wo[off + i];
                 w2 = sm.wg[off + i];
@@ -258,28 +331,29 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             }
             const unsigned long long m = __ballot(take);
             if (take) {
-                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                const int pos = off + begin + count + __popcll(m & ((1ull << lane) - 1ull));
                 lrow[pos] = row;
                 lw1[pos] = w1;
                 sm.al[pos] = w2;
             }
             count += __popcll(m);
         }
-        __syncthreads();
 #if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE >= 1
         count = 0;   // measurement build: no feature rows are read
 #endif
+        // (the list of a wave is written and read by that wave only: no barrier needed in between)
+        const int* rows_w = lrow + off + begin;
+        const float* w1_w = lw1 + off + begin;
+        const float* w2_w = sm.al + off + begin;
         float acco[MAX_FCHUNK];
 #pragma unroll
         for (int c = 0; c < MAX_FCHUNK; ++c) acco[c] = 0.f;
         int i = 0;
-        // ROWS_IN_FLIGHT compact rows (768 B each) are requested before the first is consumed: a ray's LDS footprint
-        // leaves room for ~5 waves per CU only, so the bytes in flight have to come from the depth of each wave's queue
         for (; i + ROWS_IN_FLIGHT <= count; i += ROWS_IN_FLIGHT) {
             float v[ROWS_IN_FLIGHT][MAX_FCHUNK];
 #pragma unroll
             for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
-                const float* f = o.feat + (size_t)lrow[i + u] * F;
+                const float* f = o.feat + (size_t)rows_w[i + u] * F;
 #pragma unroll
                 for (int c = 0; c < MAX_FCHUNK; ++c) {
                     const int ch = lane + 64 * c;
@@ -288,7 +362,7 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             }
 #pragma unroll
             for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
-                const float w1 = lw1[i + u], w2 = sm.al[i + u];
+                const float w1 = w1_w[i + u], w2 = w2_w[i + u];
 #pragma unroll
                 for (int c = 0; c < MAX_FCHUNK; ++c) {
                     acco[c] = __fadd_rn(acco[c], __fmul_rn(w1, v[u][c]));
@@ -297,8 +371,8 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             }
         }
         for (; i < count; ++i) {
-            const float* f = o.feat + (size_t)lrow[i] * F;
-            const float w1 = lw1[i], w2 = sm.al[i];
+            const float* f = o.feat + (size_t)rows_w[i] * F;
+            const float w1 = w1_w[i], w2 = w2_w[i];
 #pragma unroll
             for (int c = 0; c < MAX_FCHUNK; ++c) {
                 const int ch = lane + 64 * c;
@@ -308,21 +382,57 @@ __global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
             }
         }
         if (o.out.integrated_features) {
+            if (CW > 1) {
+                __syncthreads();
 #pragma unroll
-            for (int c = 0; c < MAX_FCHUNK; ++c) {
-                const int ch = lane + 64 * c;
-                if (ch < F) o.out.integrated_features[(size_t)g * F + ch] = acco[c];
+                for (int c = 0; c < MAX_FCHUNK; ++c) scratch[(wave * MAX_FCHUNK + c) * 64 + lane] = acco[c];
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int c = 0; c < MAX_FCHUNK; ++c)
+                        for (int w = 1; w < CW; ++w) acco[c] = __fadd_rn(acco[c], scratch[(w * MAX_FCHUNK + c) * 64 + lane]);
+                }
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int c = 0; c < MAX_FCHUNK; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < F) o.out.integrated_features[(size_t)g * F + ch] = acco[c];
+                }
             }
         }
         off += P;
     }
     if (p.global.integrated_features) {
+        if (CW > 1) {
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < MAX_FCHUNK; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < F) p.global.integrated_features[(size_t)g * F + ch] = accg[c];
+            for (int c = 0; c < MAX_FCHUNK; ++c) scratch[(wave * MAX_FCHUNK + c) * 64 + lane] = accg[c];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int c = 0; c < MAX_FCHUNK; ++c)
+                    for (int w = 1; w < CW; ++w) accg[c] = __fadd_rn(accg[c], scratch[(w * MAX_FCHUNK + c) * 64 + lane]);
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < F) p.global.integrated_features[(size_t)g * F + ch] = accg[c];
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
+    composite_ray<1>(p, raw_smem);
+}
+
+__global__ __launch_bounds__(256) void k_composite_4w(CompositeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
+    composite_ray<4>(p, raw_smem);
 }
 
 int launch_composite(const CompositeParams& p, hipStream_t s) {
@@ -330,12 +440,19 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
     PR_REQUIRE(p.sort_size >= p.total_positions && (p.sort_size & (p.sort_size - 1)) == 0, "bad sort size");
     for (int k = 0; k < p.objects; ++k)
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
-    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 8 : 7) * 4;
-    PR_REQUIRE(lds <= 160 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
-    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite), 160 * 1024, nullptr));
+    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 8 : 7) * 4 +
+                       sizeof(float) * 4 * 64 * MAX_FCHUNK;
+    PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
     const long total = (long)p.frames * p.rays;
     ProfileScope scope(1, s);
-    hipLaunchKernelGGL(k_composite, dim3((unsigned)total), dim3(64), lds, s, p);
+    // four waves per ray once the lists are long enough to keep them busy; short lists (a few dozen entries) stay on one
+    if (p.total_positions >= 256) {
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_4w), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
+        hipLaunchKernelGGL(k_composite_4w, dim3((unsigned)total), dim3(256), lds, s, p);
+    } else {
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
+        hipLaunchKernelGGL(k_composite, dim3((unsigned)total), dim3(64), lds, s, p);
+    }
     PR_LAUNCH_CHECK();
     return PR_OK;
 }

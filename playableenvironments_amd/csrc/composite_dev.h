@@ -31,30 +31,30 @@ __device__ __forceinline__ float disparity_of(float depth, float opacity) {
 // Orders the concatenated per-object lists by (t, concatenation index) into key[0 .. total): key[rank] =
 // (order bits of t << 32) | entry.  Each object's list is normally already sorted (linspace placement, or the
 // output of the resampler's sort), so the rank of an entry is its own index plus, for every other object, the
-// number of entries that precede it - two binary searches per other object instead of a bitonic network over
-// all entries.  Falls back to the bitonic sort when a list is not non-decreasing (overlap-fixed lists, or depths
-// whose spacing is below one ulp).  One 64-lane workgroup; `sort_size` = power of two >= total.
+// number of entries that precede it - binary searches instead of a bitonic network over all entries.  Falls back
+// to the bitonic sort when a list is not non-decreasing (overlap-fixed lists, or depths whose spacing is below one
+// ulp).  Workgroup of `threads` threads (a multiple of 64, every thread calls); `sort_size` = power of two >= total.
 __device__ __forceinline__ void order_entries(unsigned long long* key, const float* tt, const int* positions, int objects,
-                                              int total, int sort_size, bool lists_may_be_sorted, int lane) {
-    bool merge = lists_may_be_sorted;
+                                              int total, int sort_size, bool lists_may_be_sorted, int tid, int threads) {
+    int merge = lists_may_be_sorted ? 1 : 0;
     if (merge) {
-        bool ok = true;
+        int ok = 1;
         int off = 0;
         for (int k = 0; k < objects; ++k) {
             const int P = positions[k];
-            for (int i = lane; i + 1 < P; i += 64) ok = ok && (tt[off + i] <= tt[off + i + 1]);
+            for (int i = tid; i + 1 < P; i += threads) ok = ok && (tt[off + i] <= tt[off + i + 1]);
             off += P;
         }
-        merge = __ballot(ok) == ~0ull;
+        merge = __syncthreads_and(ok);
     }
     if (merge) {
-        // Each lane owns a run of consecutive entries of a list: their ranks in another (sorted) list are non-decreasing,
+        // Each thread owns a run of consecutive entries of a list: their ranks in another (sorted) list are non-decreasing,
         // so every search after the first starts where the previous one ended and first probes a window of 8 entries.
         int off = 0;
         for (int k = 0; k < objects; ++k) {
             const int P = positions[k];
-            const int run = (P + 63) >> 6;
-            const int first = lane * run;
+            const int run = (P + threads - 1) / threads;
+            const int first = tid * run;
             int resume[PR_MAX_OBJECTS];
 #pragma unroll
             for (int q = 0; q < PR_MAX_OBJECTS; ++q) resume[q] = 0;
@@ -92,12 +92,12 @@ __device__ __forceinline__ void order_entries(unsigned long long* key, const flo
         __syncthreads();
         return;
     }
-    for (int e = lane; e < sort_size; e += 64)
+    for (int e = tid; e < sort_size; e += threads)
         key[e] = (e < total) ? (((unsigned long long)float_order_bits(tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
     __syncthreads();
     for (int kk = 2; kk <= sort_size; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < sort_size; i += 64) {
+            for (int i = tid; i < sort_size; i += threads) {
                 const int x = i ^ j;
                 if (x > i) {
                     const unsigned long long a = key[i], b = key[x];
