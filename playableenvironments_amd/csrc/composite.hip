@@ -1,14 +1,14 @@
 // Alpha compositing: per-object integration and the cross-object merge (ObjectComposer.integrate,
 // compose, fix_object_overlap; model/object_composer.py:153-214, :295-447, :724-784).
 //
-// One 64-lane workgroup per ray.  All K per-object sample lists of the ray are staged in LDS; the
-// merged list is ordered by a bitonic sort on (t, concatenation index) - i.e. the merge is STABLE
-// in object order, which is how ties are defined for this renderer (the reference calls torch.sort
-// without stable=True; ties only occur between samples that carry zero alpha).
-// The per-sample 192-channel features are never materialised per ray: they are read exactly once
-// from the compact MLP output rows of the in-box samples and accumulated against both the
-// per-object and the global weights.  Sequential quantities (the exclusive cumulative product of
-// transmittances) are evaluated by one lane in the reference's left-to-right order.
+// One workgroup per ray (one wave for short lists, four for long ones).  All K per-object sample lists of the ray are
+// staged in LDS; the merged list is ordered by (t, concatenation index) - a rank merge of the already sorted lists, a
+// bitonic network as the fallback - i.e. the merge is STABLE in object order, which is how ties are defined for this
+// renderer (the reference calls torch.sort without stable=True; ties only occur between samples that carry zero alpha,
+// see DESIGN.md).  The per-sample 192-channel features are never materialised per ray: they are read exactly once
+// from the compact MLP output rows of the in-box samples and accumulated against both the per-object and the global
+// weights.  The exclusive cumulative product of the transmittances is a wave-level multiplicative scan (the
+// reference's cumprod is sequential; the association differs at the ulp level only).
 #include "pr_common.h"
 #include "composite_dev.h"
 
