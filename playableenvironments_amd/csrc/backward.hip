@@ -48,7 +48,7 @@ struct CompositeBwdParams {
 };
 
 struct BwdSmem {
-    unsigned long long* key;
+    unsigned int* key;
     float *tt, *sg, *dm, *wo, *wg, *al, *gs, *gt, *gd, *Tj, *wv, *dw, *dd;
     int *sl, *mk;
 };
@@ -81,7 +81,7 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
                                                const float* noise, float norm, const pr_entry_grads_t& g, long ray,
                                                float* weights_out, int lane) {
     const int F = p.F;
-    auto entry_of = [&](int j) -> int { return sorted ? (int)(sm.key[j] & 0xFFFFFFFFu) : off + j; };
+    auto entry_of = [&](int j) -> int { return sorted ? (int)sm.key[j] : off + j; };
     for (int j = lane; j < n; j += 64) {
         const int e = entry_of(j);
         const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     const int S = p.sort_size;
     const int A = (p.total_positions + 63) & ~63;
     BwdSmem sm;
-    sm.key = reinterpret_cast<unsigned long long*>(raw_smem);
+    sm.key = reinterpret_cast<unsigned int*>(raw_smem);
     float* fp = reinterpret_cast<float*>(sm.key + S);
     sm.tt = fp; fp += A;
     sm.sg = fp; fp += A;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     {
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
-        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64);
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64, nullptr);
     }
     entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
 
 static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
-    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
+    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
     const long total = (long)p.frames * p.rays;

@@ -23,7 +23,7 @@ struct CompositeSmem {
     float* al;      // alpha scratch
     float* dv;      // |divergence estimate| per entry (after the overlap fix)
     int* sl;        // compact feature row per entry (-1: outside the box)
-    unsigned long long* key;
+    unsigned int* key;   // entry index per merged rank
 };
 
 constexpr int MAX_FCHUNK = 4;  // F <= 256 channels, 64 lanes
@@ -108,25 +108,30 @@ __device__ __forceinline__ float block_sum(float v, float* scratch, int wave, in
 // feature rows in flight were what set the kernel's time.  Wave w integrates the objects w, w + CW, ...; staging, the
 // overlap fix, the merge, the global list and the feature rows are shared by all waves.
 template <int CW>
-__device__ __forceinline__ void composite_ray(const CompositeParams& p, char* raw_smem) {
+__global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
     constexpr int CT = 64 * CW;
     const int S = p.sort_size;
     CompositeSmem sm;
     const int A = (p.total_positions + 63) & ~63;   // per-entry arrays (the sort keys need the power of two S)
-    sm.key = reinterpret_cast<unsigned long long*>(raw_smem);
+    sm.key = reinterpret_cast<unsigned int*>(raw_smem);
     sm.tt = reinterpret_cast<float*>(sm.key + S);
     sm.sg = sm.tt + A;
     sm.dm = sm.sg + A;
     sm.wo = sm.dm + A;
-    sm.wg = sm.wo + A;
-    sm.al = sm.wg + A;
-    // the divergence column exists only in differentiable training calls (keeps the eval footprint at 7 arrays)
+    sm.wg = sm.sg;       // the raw sigmas are dead once the merged list's alphas exist, which is before its weights do
+    sm.al = sm.wo + A;
+    // the divergence column exists only in differentiable training calls (keeps the eval footprint at 6 arrays)
     const bool use_div = p.any_divergence != 0;
     sm.dv = use_div ? sm.al + A : nullptr;
     sm.sl = reinterpret_cast<int*>(sm.al + (use_div ? 2 * A : A));
-    float* scratch = reinterpret_cast<float*>(sm.sl + A);   // [4 * 64 * MAX_FCHUNK] cross-wave reductions
+    float* scratch = reinterpret_cast<float*>(sm.sl + A);   // [CW * 64] cross-wave reductions
+    // 64-bit sort scratch of the calls that always take the bitonic network (overlap fix), 8-byte aligned
+    unsigned long long* wide = p.fix_overlaps ? reinterpret_cast<unsigned long long*>(scratch + 4 * 64) : nullptr;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction: as a scalar it keeps the per-object parameter reads (p.obj[k]) on the scalar path
+    const int wave = (CW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const long g = blockIdx.x;
     const float* d = p.ray_directions + (size_t)g * 3;
     // |d| of the world-frame direction (integrate receives the untransformed directions, :880/:886)
@@ -247,10 +252,10 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
 #if defined(PR_COMPOSITE_ABLATE) && PR_COMPOSITE_ABLATE >= 2
-        for (int e = tid; e < PT; e += CT) sm.key[e] = (unsigned long long)e;   // measurement build: no merge (wrong order)
+        for (int e = tid; e < PT; e += CT) sm.key[e] = (unsigned int)e;   // measurement build: no merge (wrong order)
         __syncthreads();
 #else
-        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, tid, CT);
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, tid, CT, wide);
 #endif
     }
 
@@ -258,10 +263,10 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
     const size_t gbase = (size_t)g * PT;
     float gdiv = 0.f;
     for (int j = tid; j < PT; j += CT) {
-        const int e = (int)(sm.key[j] & 0xFFFFFFFFu);
+        const int e = (int)sm.key[j];
         float dt = 1e10f;
         if (j < PT - 1) {
-            const int en = (int)(sm.key[j + 1] & 0xFFFFFFFFu);
+            const int en = (int)sm.key[j + 1];
             dt = __fsub_rn(sm.tt[en], sm.tt[e]);
         }
         float raw = sm.sg[e];
@@ -275,7 +280,7 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
     {
         float depth = 0.f, opacity = 0.f, dmag = 0.f;
         for (int j = tid; j < PT; j += CT) {
-            const int e = (int)(sm.key[j] & 0xFFFFFFFFu);
+            const int e = (int)sm.key[j];
             const float w = sm.al[j];
             sm.wg[e] = w;
             if (p.global.weights) p.global.weights[gbase + j] = w;
@@ -304,8 +309,8 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
     // then consumed ROWS_IN_FLIGHT rows at a time.  Every wave accumulates all F channels of its part; the parts are added
     // in wave order.
     const int F = p.F;
-    int* lrow = reinterpret_cast<int*>(sm.key);
-    float* lw1 = reinterpret_cast<float*>(sm.key) + S;
+    int* lrow = reinterpret_cast<int*>(sm.key);   // the ranks and the depths are dead by now
+    float* lw1 = sm.tt;
     float accg[MAX_FCHUNK];
 #pragma unroll
     for (int c = 0; c < MAX_FCHUNK; ++c) accg[c] = 0.f;
@@ -383,14 +388,14 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
         }
         if (o.out.integrated_features) {
             if (CW > 1) {
-                __syncthreads();
 #pragma unroll
-                for (int c = 0; c < MAX_FCHUNK; ++c) scratch[(wave * MAX_FCHUNK + c) * 64 + lane] = acco[c];
-                __syncthreads();
-                if (wave == 0) {
-#pragma unroll
-                    for (int c = 0; c < MAX_FCHUNK; ++c)
-                        for (int w = 1; w < CW; ++w) acco[c] = __fadd_rn(acco[c], scratch[(w * MAX_FCHUNK + c) * 64 + lane]);
+                for (int c = 0; c < MAX_FCHUNK; ++c) {      // one 64-channel chunk at a time: 1 KB of scratch
+                    if (64 * c >= F) break;
+                    __syncthreads();
+                    scratch[wave * 64 + lane] = acco[c];
+                    __syncthreads();
+                    if (wave == 0)
+                        for (int w = 1; w < CW; ++w) acco[c] = __fadd_rn(acco[c], scratch[w * 64 + lane]);
                 }
             }
             if (wave == 0) {
@@ -405,14 +410,14 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
     }
     if (p.global.integrated_features) {
         if (CW > 1) {
-            __syncthreads();
 #pragma unroll
-            for (int c = 0; c < MAX_FCHUNK; ++c) scratch[(wave * MAX_FCHUNK + c) * 64 + lane] = accg[c];
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int c = 0; c < MAX_FCHUNK; ++c)
-                    for (int w = 1; w < CW; ++w) accg[c] = __fadd_rn(accg[c], scratch[(w * MAX_FCHUNK + c) * 64 + lane]);
+            for (int c = 0; c < MAX_FCHUNK; ++c) {
+                if (64 * c >= F) break;
+                __syncthreads();
+                scratch[wave * 64 + lane] = accg[c];
+                __syncthreads();
+                if (wave == 0)
+                    for (int w = 1; w < CW; ++w) accg[c] = __fadd_rn(accg[c], scratch[w * 64 + lane]);
             }
         }
         if (wave == 0) {
@@ -425,33 +430,23 @@ __device__ __forceinline__ void composite_ray(const CompositeParams& p, char* ra
     }
 }
 
-__global__ __launch_bounds__(64) void k_composite(CompositeParams p) {
-    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
-    composite_ray<1>(p, raw_smem);
-}
-
-__global__ __launch_bounds__(256) void k_composite_4w(CompositeParams p) {
-    extern __shared__ __attribute__((aligned(16))) char raw_smem[];
-    composite_ray<4>(p, raw_smem);
-}
-
 int launch_composite(const CompositeParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK);
     PR_REQUIRE(p.sort_size >= p.total_positions && (p.sort_size & (p.sort_size - 1)) == 0, "bad sort size");
     for (int k = 0; k < p.objects; ++k)
         PR_REQUIRE(p.obj[k].positions <= 64 * 32, "positions per ray %d too large for the overlap mask", p.obj[k].positions);
-    const size_t lds = (size_t)p.sort_size * 8 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 8 : 7) * 4 +
-                       sizeof(float) * 4 * 64 * MAX_FCHUNK;
+    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 7 : 6) * 4 +
+                       sizeof(float) * 4 * 64 + (p.fix_overlaps ? (size_t)p.sort_size * 8 : 0);
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
     const long total = (long)p.frames * p.rays;
     ProfileScope scope(1, s);
     // four waves per ray once the lists are long enough to keep them busy; short lists (a few dozen entries) stay on one
     if (p.total_positions >= 256) {
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_4w), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
-        hipLaunchKernelGGL(k_composite_4w, dim3((unsigned)total), dim3(256), lds, s, p);
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(&k_composite<4>), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
+        hipLaunchKernelGGL(k_composite<4>, dim3((unsigned)total), dim3(256), lds, s, p);
     } else {
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
-        hipLaunchKernelGGL(k_composite, dim3((unsigned)total), dim3(64), lds, s, p);
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(&k_composite<1>), 156 * 1024, nullptr));
+        hipLaunchKernelGGL(k_composite<1>, dim3((unsigned)total), dim3(64), lds, s, p);
     }
     PR_LAUNCH_CHECK();
     return PR_OK;

@@ -28,14 +28,16 @@ __device__ __forceinline__ float disparity_of(float depth, float opacity) {
     return __fdiv_rn(1.0f, q);
 }
 
-// Orders the concatenated per-object lists by (t, concatenation index) into key[0 .. total): key[rank] =
-// (order bits of t << 32) | entry.  Each object's list is normally already sorted (linspace placement, or the
+// Orders the concatenated per-object lists by (t, concatenation index) into key[0 .. total): key[rank] = entry.  Each object's list is normally already sorted (linspace placement, or the
 // output of the resampler's sort), so the rank of an entry is its own index plus, for every other object, the
 // number of entries that precede it - binary searches instead of a bitonic network over all entries.  Falls back
 // to the bitonic sort when a list is not non-decreasing (overlap-fixed lists, or depths whose spacing is below one
 // ulp).  Workgroup of `threads` threads (a multiple of 64, every thread calls); `sort_size` = power of two >= total.
-__device__ __forceinline__ void order_entries(unsigned long long* key, const float* tt, const int* positions, int objects,
-                                              int total, int sort_size, bool lists_may_be_sorted, int tid, int threads) {
+// `wide` (sort_size 64-bit words, or NULL): scratch for the bitonic network - calls that always take it (overlap fix)
+// provide it; without it the network compares through the depth array (slower, rare).
+__device__ __forceinline__ void order_entries(unsigned int* key, const float* tt, const int* positions, int objects,
+                                              int total, int sort_size, bool lists_may_be_sorted, int tid, int threads,
+                                              unsigned long long* wide) {
     int merge = lists_may_be_sorted ? 1 : 0;
     if (merge) {
         int ok = 1;
@@ -85,24 +87,51 @@ __device__ __forceinline__ void order_entries(unsigned long long* key, const flo
                     }
                     o2 += P2;
                 }
-                key[rank] = ((unsigned long long)float_order_bits(t) << 32) | (unsigned int)(off + i);
+                key[rank] = (unsigned int)(off + i);
             }
             off += P;
         }
         __syncthreads();
         return;
     }
-    for (int e = tid; e < sort_size; e += threads)
-        key[e] = (e < total) ? (((unsigned long long)float_order_bits(tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
+    if (wide != nullptr) {
+        for (int e = tid; e < sort_size; e += threads)
+            wide[e] = (e < total) ? (((unsigned long long)float_order_bits(tt[e]) << 32) | (unsigned int)e) : 0xFFFFFFFFFFFFFFFFull;
+        __syncthreads();
+        for (int kk = 2; kk <= sort_size; kk <<= 1) {
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < sort_size; i += threads) {
+                    const int x = i ^ j;
+                    if (x > i) {
+                        const unsigned long long a = wide[i], b = wide[x];
+                        const bool up = ((i & kk) == 0);
+                        if ((a > b) == up) {
+                            wide[i] = b;
+                            wide[x] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int e = tid; e < total; e += threads) key[e] = (unsigned int)(wide[e] & 0xFFFFFFFFu);
+        __syncthreads();
+        return;
+    }
+    // bitonic network on entry indices; the sort key of an entry is (order bits of its t, index), padding sorts last
+    for (int e = tid; e < sort_size; e += threads) key[e] = (e < total) ? (unsigned int)e : 0xFFFFFFFFu;
     __syncthreads();
+    auto sort_key = [&](unsigned int e) -> unsigned long long {
+        return e == 0xFFFFFFFFu ? 0xFFFFFFFFFFFFFFFFull : (((unsigned long long)float_order_bits(tt[e]) << 32) | e);
+    };
     for (int kk = 2; kk <= sort_size; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < sort_size; i += threads) {
                 const int x = i ^ j;
                 if (x > i) {
-                    const unsigned long long a = key[i], b = key[x];
+                    const unsigned int a = key[i], b = key[x];
                     const bool up = ((i & kk) == 0);
-                    if ((a > b) == up) {
+                    if ((sort_key(a) > sort_key(b)) == up) {
                         key[i] = b;
                         key[x] = a;
                     }
