@@ -187,7 +187,9 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     sm.dw = fp; fp += A;
     sm.dd = fp; fp += A;
     sm.sl = reinterpret_cast<int*>(fp); fp += A;
-    sm.mk = reinterpret_cast<int*>(fp);
+    sm.mk = reinterpret_cast<int*>(fp); fp += A;
+    // 64-bit sort scratch of the calls that always take the bitonic network (overlap fix); 4 S + 60 A bytes precede it
+    unsigned long long* wide = p.fix_overlaps ? reinterpret_cast<unsigned long long*>(fp) : nullptr;
 
     const int lane = threadIdx.x;
     const long g = blockIdx.x;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     {
         int counts[PR_MAX_OBJECTS];
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
-        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64, nullptr);
+        order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64, wide);
     }
     entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
 
@@ -312,7 +314,8 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
 
 static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
-    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4;
+    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4 +
+                       (p.fix_overlaps ? (size_t)p.sort_size * 8 : 0);
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
     const long total = (long)p.frames * p.rays;
