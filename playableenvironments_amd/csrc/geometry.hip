@@ -404,12 +404,43 @@ __global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size
         key[Pc + f] = __fadd_rn(mids[below], __fmul_rn(frac, __fsub_rn(mids[above], mids[below])));
     }
     __syncthreads();
-    bitonic_sort_f32(key, sort_size, lane);
     const int Pm = Pc + Pf;
+    // Both lists are normally sorted already - the coarse depths by construction, the resampled ones whenever the
+    // inverse CDF is evaluated at the fixed, increasing u (no perturbation) - and a merge by ranks costs a fraction of the
+    // instructions of the bitonic network (this kernel is bound by VALU issue, most of it the network's).  The merged
+    // VALUES are what the reference's sort returns, whatever it does with ties.
+    float* merged = key + sort_size;
+    bool sorted = true;
+    for (int i = lane; i + 1 < Pc; i += 64) sorted = sorted && (key[i] <= key[i + 1]);
+    for (int f = lane; f + 1 < Pf; f += 64) sorted = sorted && (key[Pc + f] <= key[Pc + f + 1]);
+    if (__ballot(sorted) == ~0ull) {
+        for (int i = lane; i < Pc; i += 64) {          // coarse entry i: ahead of it are the fine samples strictly below
+            const float t = key[i];
+            int lo = 0, hi = Pf;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (key[Pc + mid] < t) lo = mid + 1; else hi = mid;
+            }
+            merged[i + lo] = t;
+        }
+        for (int f = lane; f < Pf; f += 64) {          // fine sample f: ahead of it are the coarse depths below or equal
+            const float t = key[Pc + f];
+            int lo = 0, hi = Pc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (key[mid] <= t) lo = mid + 1; else hi = mid;
+            }
+            merged[f + lo] = t;
+        }
+        __syncthreads();
+    } else {
+        bitonic_sort_f32(key, sort_size, lane);
+        merged = key;
+    }
     const size_t fbase = (size_t)g * Pm;
     int count = 0;
     for (int i = lane; i < Pm; i += 64) {
-        const float t = key[i];
+        const float t = merged[i];
         p.t_fine[fbase + i] = t;
         p.sigma_fine[fbase + i] = p.empty_alpha;
         if (p.dispmag_fine) p.dispmag_fine[fbase + i] = 0.f;
@@ -461,7 +492,7 @@ int launch_resample(const ResampleParams& p, hipStream_t s) {
     PR_CHECK_HIP(hipMemsetAsync(p.block_sums, 0, sizeof(int32_t) * nblocks256, s));
     int sort_size = next_pow2(p.pc + p.pf);
     if (sort_size < 64) sort_size = 64;
-    const size_t lds = sizeof(float) * (4 * (size_t)p.pc + sort_size);
+    const size_t lds = sizeof(float) * (4 * (size_t)p.pc + 2 * (size_t)sort_size);   // inputs + sort keys + merged list
     PR_REQUIRE(lds <= 64 * 1024, "resample: too many positions per ray (%d + %d)", p.pc, p.pf);
     hipLaunchKernelGGL(k_resample, dim3((unsigned)total), dim3(64), lds, s, p, sort_size);
     PR_LAUNCH_CHECK();
