@@ -713,7 +713,10 @@ __device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int w
             if (fl & 1) {
                 float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
                 if (zero_dead && !(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(dst + (size_t)(tile_base + row) * stride + c) = v;
+                // streamed once, read next by another kernel: keep the rows from evicting the weight fragments in L2
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(dst + (size_t)(tile_base + row) * stride + c));
             }
         }
     } else {

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
                     if (fl & 1) {
                         float4 v = *reinterpret_cast<const float4*>(stage + row * LDSTAGE + c);
                         if (!(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        *reinterpret_cast<float4*>(p.feat + (size_t)(tile_base + row) * p.F + c) = v;
+                        // streamed once: keep the rows from evicting the weight fragments in L2
+                        typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                        f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(p.feat + (size_t)(tile_base + row) * p.F + c));
                     }
                 }
             } else {

@@ -17,6 +17,8 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"].split("(")[0]
+            if name.startswith("void "):          # template instantiations are printed with their return type
+                name = name[5:]
             per[name][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[(name, row["Counter_Name"])].add(row["Dispatch_Id"])
 out = {"source": "tools/collect_pmc.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py --steps 1 --warmup 0 "
@@ -28,14 +30,14 @@ for name, counters in sorted(per.items()):
     entry = {k: v for k, v in counters.items()}
     entry["dispatches"] = max(len(calls[(name, k)]) for k in counters)
     out["kernels"][name] = entry
-for kernel in ("pr::k_mlp_mfma", "pr::k_composite"):
+for kernel in ("pr::k_mlp_mfma", "pr::k_composite<4>"):
     k = out["kernels"].get(kernel)
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         continue
     launches = k["dispatches"]
     fetch = k["FETCH_SIZE"] * 1024.0
     write = k["WRITE_SIZE"] * 1024.0
-    out[kernel.split("::")[1]] = {
+    out[kernel.split("::")[1].split("<")[0]] = {
         "launches_per_render": launches / out["renders"],
         "fetch_bytes_per_render_raw": fetch / out["renders"],
         "fetch_bytes_per_render_corrected_x2": 2 * fetch / out["renders"],
@@ -44,5 +46,5 @@ for kernel in ("pr::k_mlp_mfma", "pr::k_composite"):
     }
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k and k.get("GRBM_GUI_ACTIVE"):
         # the SQ counter is summed over the 1024 SIMDs (4 per CU x 256 CUs), GRBM_GUI_ACTIVE over the 8 XCDs
-        out[kernel.split("::")[1]]["mfma_busy_fraction"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
+        out[kernel.split("::")[1].split("<")[0]]["mfma_busy_fraction"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
 print(json.dumps(out, indent=1))
