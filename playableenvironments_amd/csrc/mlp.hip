@@ -581,7 +581,10 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             if (input_kind == 1) fill_bender_input(S, p, enc, true); else fill_nerf_input(S, p, enc, true);
             __syncthreads();
         }
-        if (!active || (p.debug & 128)) continue;
+        if (!active) continue;
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 128)
+        continue;   // measurement build: no matrix work (results are wrong)
+#endif
         // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
         __builtin_amdgcn_s_setprio(1);
         const int kq = sg.kq;   // even (K is padded to a multiple of 16)
@@ -645,11 +648,17 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         }
         __builtin_amdgcn_s_setprio(0);
     }
-    if (p.debug & 4) return;  // ablation: no barriers, no epilogue
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 4)
+    return;   // measurement build: no barriers, no epilogue (results are wrong)
+#endif
     PR_PHASE(3);
     __syncthreads();  // every wave has finished reading X
     PR_PHASE(4);
-    if (active && !(p.debug & 8)) {
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 8)
+    if (false) {   // measurement build: no epilogue (results are wrong)
+#else
+    if (active) {
+#endif
         for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
             const int col = (blk ? cbB : cbA) * 32 + r;
             const f32x16& lo = blk ? a10 : a00;   // rows 0..31
@@ -1083,13 +1092,7 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
         PR_LAUNCH_CHECK();
         return PR_OK;
     }
-    static int debug_bits = -1;
-    if (debug_bits < 0) {
-        const char* e = getenv("PR_MLP_DEBUG");
-        debug_bits = e ? atoi(e) : 0;
-    }
-    MlpParams pd = p;
-    pd.debug = debug_bits;
+    const MlpParams& pd = p;
     int cu_count = 0;
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(pd.phase >= 2 ? k_mlp_head : k_mlp_mfma), (int)sizeof(Smem), &cu_count));
     const int resident = cu_count * MLP_BLOCKS_PER_CU;

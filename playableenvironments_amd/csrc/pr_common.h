@@ -137,7 +137,6 @@ struct MlpParams {
     const float* adain;          // table base for this object; row = frame
     int adain_stride;            // floats between frames
     int F;
-    int debug;                   // PR_MLP_DEBUG ablation bits (timing experiments only; results are wrong)
     // train-mode BatchNorm (batch statistics sit between the head matmuls -> three phases, see mlp.hip)
     int phase;                   // 0 = eval (everything fused); 1 = ... -> raw h1; 2 = h1 -> raw h2; 3 = h2 -> features
     float* h_out;                // phase 1/2: raw (pre-BN) head activations, (cap, h_out_width)
