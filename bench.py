@@ -6,20 +6,31 @@ Workload (per GPU): the tennis renderer (4 objects) with the hierarchical overri
 (65 536 rays) of the seeded synthetic tennis scene, eval mode, fp32.  A "step" is one full render
 from the scene encoding (camera, object poses, style, deformation - resident in HBM) to the result
 tensors of ``EnvironmentModel.forward(mode="scene_encodings")``.  With N GPUs every rank renders
-its own frame (weak scaling) and the rendered ``fine.global.integrated_features`` maps are exchanged
-with one RCCL all_gather inside the timed region.
+its own copy of the frame (weak scaling with identical work per GPU) and the rendered
+``fine.global.integrated_features`` maps are exchanged with one RCCL all_gather inside the timed region.
+
+``python bench.py --gpus N`` launches itself under ``torch.distributed.run`` (one process per GPU) when it
+is not already running under it, so both ``python bench.py --gpus 8`` and
+``python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`` work.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the fused fp32-MFMA MLP,
-``k_mlp_mfma``): algorithmic FLOPs per launch (in-box samples actually evaluated x
-FLOP/sample of the object's networks) / average launch duration measured with HIP events on the
-launch stream.  ``cpu_baseline`` times the CPU oracle (a restatement of the reference's PyTorch op
-graph, 1000-ray chunks like the reference's full-frame path) on a bounded ray subset of the same
-frame on this box's host cores.
+``k_mlp_mfma``): FLOPs per launch / average launch duration measured with HIP events on the launch
+stream.  Two FLOP counts are given: ``algorithmic`` (in-box samples x FLOP/sample of the
+object's networks - what the reference evaluates) and ``executed`` (minus the feature-head FLOPs of the
+samples whose density is <= 0, which the sigma-gated head skips exactly); ``achieved`` uses the EXECUTED
+count.  Secondary legs, none of which is the headline: the split-precision kernel, the same-GPU PyTorch
+op graph of the reference (``reference_graph_on_gpu``), PSNR against the CPU oracle, 8 distinct frames
+sharded over the ranks (BASELINE.json configs[3]), a data-parallel training step (configs[4], with its own
+roofline), configs[0] at full size, and ``cpu_baseline``: the CPU oracle (a restatement of the reference's
+PyTorch op graph, 1000-ray chunks like the reference's full-frame path) on bounded ray subsets of the same
+frame on this box's host cores with 1 / 16 / all threads.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,15 +40,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+SCENE_KEYS = ("camera_rotations", "camera_translations", "focals", "object_rotation_parameters",
+              "object_translation_parameters", "object_style", "object_deformation", "object_in_scene")
 
 
-def flops_per_sample(model_cfg: dict) -> float:
-    """Matmul FLOPs (2 per MAC) of one evaluated sample, SURVEY.md section 8d."""
+def flops_per_sample(model_cfg: dict, head_only: bool = False) -> float:
+    """Matmul FLOPs (2 per MAC) of one evaluated sample, SURVEY.md section 8d.  ``head_only``: the three feature-head
+    products alone (what the sigma gate skips for a sample that cannot contribute)."""
     n = model_cfg["nerf_model"]
     din = 6 if n["architecture"].endswith("skybox_adain_style_nerf_model_v3") else 3
     enc = din * (1 + 2 * n["position_encoder"]["octaves"])
     w, layers, f = n["layers_width"], n["backbone_layers_count"], n["output_features"]
-    mac = enc * w + (layers - 2) * w * w + (w + enc) * w + w * w + w * (w // 2) + (w // 2) * f
+    head = w * w + w * (w // 2) + (w // 2) * f
+    if head_only:
+        return 2.0 * head
+    mac = enc * w + (layers - 2) * w * w + (w + enc) * w + head
     if din == 3:
         mac += w  # sigma head
     b = model_cfg["ray_bender_model"]
@@ -48,13 +65,37 @@ def flops_per_sample(model_cfg: dict) -> float:
     return 2.0 * mac
 
 
+def scene_args(sc, size):
+    return [sc["camera_rotations"], sc["camera_translations"], sc["focals"], size, sc["object_rotation_parameters"],
+            sc["object_translation_parameters"], sc["object_style"], sc["object_deformation"], sc["object_in_scene"]]
+
+
+def to_device(scene, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+
+
+def profile_arrays():
+    from playableenvironments_amd import _lib
+    return (C.c_double * _lib.PR_PROFILE_CATEGORIES)(), (C.c_int32 * _lib.PR_PROFILE_CATEGORIES)()
+
+
+def max_over_ranks(value, dist, dev):
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def train_step_leg(args, dev, world, rank, dist, lib):
     """Secondary figure (never the headline): one data-parallel training step of the renderer in the shape of
     BASELINE.json configs[4] / SURVEY.md C5 - minecraft, 3 frames per GPU, one 48x48 patch at strides [4, 8] per frame
     (2880 rays), perturb=True, train-mode BatchNorm, forward + backward (pr_render_backward) + gradient all-reduce
     over RCCL + Adam on the composer parameters.  The loss reads global.integrated_features only, which is where the
-    shipped configurations send gradients (every other renderer loss weight is 0)."""
-    from playableenvironments_amd import configs, synthetic, parallel
+    shipped configurations send gradients (every other renderer loss weight is 0).  Its roofline: 3 x the forward
+    matmul FLOPs of the samples that were evaluated (dX + dW + forward) / step time, against the fp32
+    matrix peak, with the HIP-event time of the forward MLP launches and of the backward dX / dW products."""
+    from playableenvironments_amd import configs, synthetic, parallel, _lib
     from playableenvironments_amd.environment_model import EnvironmentModel
     cfg = configs.minecraft_config()
     torch.manual_seed(0)
@@ -66,21 +107,21 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     model.object_composer.batchnorm_check = "deferred"
     size = (288, 512)
     scene = synthetic.minecraft_scene(batch=3, seed=77, image_size=size)   # same frames on every rank: weak scaling
-    sc = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    sc = to_device(scene, dev)
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
     params = list(model.object_composer.parameters())
     opt = torch.optim.Adam(params, lr=1e-5, fused=True)
     steps, warmup = max(1, args.steps), max(2, args.warmup)
+    comp = model.object_composer
+    K = comp.object_id_helper.objects_count
+    evaluated = torch.zeros((K,), dtype=torch.int64, device=dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
         for attempt in range(20):
             try:
-                out = model(sc["camera_rotations"], sc["camera_translations"], sc["focals"], size,
-                            sc["object_rotation_parameters"], sc["object_translation_parameters"], sc["object_style"],
-                            sc["object_deformation"], sc["object_in_scene"], 2880, True, 0, patch_size=48,
-                            patch_stride=[4, 8], mode="scene_encodings")
+                out = model(*scene_args(sc, size), 2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings")
                 break
             except ValueError:
                 # a random patch that misses an object leaves its BatchNorm without samples: torch (and the reference)
@@ -93,6 +134,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
         loss.backward()
         parallel.allreduce_gradients(params)
         opt.step()
+        evaluated.add_(comp.last_normalised_samples["coarse"])
         return out
 
     for _ in range(warmup):
@@ -100,6 +142,8 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    evaluated.zero_()
+    lib.pr_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
@@ -107,19 +151,94 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    lib.pr_profile_enable(0)
+    ms, launches = profile_arrays()
+    _lib.check(lib.pr_profile_collect(ms, launches), "pr_profile_collect")
+    dt = max_over_ranks(dt, dist if world > 1 else None, dev)
     rays = int(out["coarse"]["global"]["opacity"].numel())
+    counts = [int(v) / steps for v in evaluated.cpu()]
+    helper = comp.object_id_helper
+    fwd_flops = sum(counts[k] * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
+                    for k in range(K))
+    step_ms = dt / steps * 1e3
+    achieved = 3.0 * fwd_flops / (step_ms * 1e-3) / 1e12
+    per = lambda i: round(ms[i] / steps, 3)
+    gemm_ms = (ms[2] + ms[3]) / steps
     return {
         "value": round(rays * world * steps / dt / 1e6, 4),
         "unit": "Mrays/s trained (forward + backward + optimiser step)",
-        "ms_per_step": round(dt / steps * 1e3, 3),
+        "ms_per_step": round(step_ms, 3),
         "rays_per_gpu_per_step": rays,
         "workload": "minecraft shipped config, 3 frames/GPU x (48x48 patch @ strides [4, 8] = 2880 rays), perturb, train-mode "
                     "BatchNorm - BASELINE.json configs[4] renderer part",
         "parallelism": f"data parallel x{world}" + (", one flat RCCL all_reduce of the parameter gradients" if world > 1 else ""),
+        "roofline": {
+            "bound": "mfma",
+            "achieved": round(achieved, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "flop_per_step": 3.0 * fwd_flops,
+            "definition": "3 x forward matmul FLOPs of the evaluated samples (forward + dX + dW) / whole step time "
+                          "(incl. compositing, BatchNorm passes, optimiser)",
+            "evaluated_samples_per_step": [round(c, 1) for c in counts],
+            "kernel_ms_per_step": {"forward_mlp": per(0), "forward_composite": per(1), "backward_dx_gemm": per(2),
+                                   "backward_dw_gemm": per(3), "backward_composite": per(4)},
+            "backward_gemm_tflops": round(2.0 * fwd_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
+            "forward_mlp_tflops": round(fwd_flops / (ms[0] / steps * 1e-3) / 1e12, 2) if ms[0] > 0 else None,
+        },
+    }
+
+
+def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, frames=8):
+    """BASELINE.json configs[3]: a batch of 8 DISTINCT seeded frames sharded over the ranks with
+    EnvironmentModel.render_sharded (parallel.shard_frames), the rendered feature maps gathered with one collective.
+    Unlike the headline's identical frames, distinct frames carry different amounts of work (in-box samples): the batch
+    time follows the heaviest shard.  Reports the whole-batch rate, every rank's render time and the max over ranks."""
+    from playableenvironments_amd import synthetic
+    scenes = [synthetic.tennis_scene(seed=4000 + i, image_size=size) for i in range(frames)]
+    batch = {k: torch.cat([s[k] for s in scenes], dim=0).to(dev) for k in SCENE_KEYS}
+    ty = "fine" if "hierarchical" in label else "coarse"
+
+    def run():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = model.render_sharded(*scene_args(batch, size), False, shard="frames" if frames >= world else "rays",
+                                   fields=("integrated_features",))
+        e1.record()
+        return out, e0, e1
+
+    run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    local_ms = 0.0
+    for _ in range(steps):
+        out, e0, e1 = run()
+        torch.cuda.synchronize()
+        local_ms += e0.elapsed_time(e1)
+    if world > 1:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
+    per_rank = [local_ms / steps]
+    if world > 1:
+        t = torch.tensor(per_rank, dtype=torch.float64, device=dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        per_rank = [float(p.item()) for p in parts]
+    feats = out[ty]["global"]["integrated_features"]
+    rays = frames * size[0] * size[1]
+    return {
+        "workload": f"{frames} distinct tennis frames ({label}), {size[0]}x{size[1]}, sharded by frame over {world} rank(s), "
+                    "feature maps gathered on every rank",
+        "value": round(rays * steps / dt / 1e6, 4),
+        "unit": "Mrays/s (whole batch, strong scaling over a fixed batch)",
+        "frames_per_s": round(frames * steps / dt, 3),
+        "ms_per_batch": round(dt / steps * 1e3, 3),
+        "per_rank_ms": [round(v, 3) for v in per_rank],
+        "max_rank_ms": round(max(per_rank), 3),
+        "gathered_shape": list(feats.shape),
     }
 
 
@@ -134,25 +253,39 @@ def main():
                     help="fp32 = exact fp32 MFMA (default, the headline); f16x3 = fp32 emulated with three fp16 MFMAs")
     ap.add_argument("--no-split-precision", action="store_true", help="skip the secondary f16x3 measurement")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
-    ap.add_argument("--cpu-rays", type=int, default=64, help="the CPU baseline renders a cpu_rays x cpu_rays pixel grid")
+    ap.add_argument("--no-distinct-frames", action="store_true", help="skip the 8-distinct-frames legs (configs[3])")
+    ap.add_argument("--no-reference-graph", action="store_true", help="skip the same-GPU PyTorch op graph measurement")
+    ap.add_argument("--no-gate", action="store_true", help="disable the sigma-gated feature head (measurement)")
+    ap.add_argument("--cpu-rays", type=int, default=64, help="the 16-thread CPU baseline renders a cpu_rays x cpu_rays pixel grid")
     ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="torch threads of the CPU baseline (all 256 host cores are >50x SLOWER on these small ops)")
+                    help="torch threads of the main CPU baseline run (all 256 host cores are >50x SLOWER on these small ops)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: one process per GPU under torch.distributed.run, rendezvous on the loopback interface
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the renderer)")
     # PR_BENCH_DEVICE / PR_BENCH_BACKEND: test knobs (several ranks on one GPU over gloo exercise the multi-rank path
     # where only one device exists); the defaults are one rank per GPU over RCCL
+    if "PR_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     device_index = int(os.environ.get("PR_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -170,19 +303,18 @@ def main():
     model = EnvironmentModel(cfg)
     synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
     model.eval().to(dev)
-    model.object_composer.precision = args.precision
+    comp = model.object_composer
+    comp.precision = args.precision
+    comp.gate_feature_head = not args.no_gate
     size = (args.image, args.image)
-    # the same frame on every rank: weak scaling with exactly the same work per GPU (a different frame per rank would
-    # make the max-over-ranks time follow the heaviest frame instead of the system)
+    # the same frame on every rank: weak scaling with exactly the same work per GPU (distinct frames per rank are the
+    # "distinct_frames" legs below)
     scene = synthetic.tennis_scene(seed=1234, image_size=size)
-    scene_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    scene_dev = to_device(scene, dev)
 
     def step():
         with torch.no_grad():
-            out = model(scene_dev["camera_rotations"], scene_dev["camera_translations"], scene_dev["focals"], size,
-                        scene_dev["object_rotation_parameters"], scene_dev["object_translation_parameters"],
-                        scene_dev["object_style"], scene_dev["object_deformation"], scene_dev["object_in_scene"],
-                        0, False, mode="scene_encodings")
+            out = model(*scene_args(scene_dev, size), 0, False, mode="scene_encodings")
         feats = out["fine"]["global"]["integrated_features"]
         if world > 1:
             # one RCCL collective for the rendered feature maps (50 MB per frame); every rank receives the stack,
@@ -225,13 +357,9 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         lib.pr_profile_enable(0)
-        kernel_ms = (C.c_double * 2)()
-        kernel_launches = (C.c_int32 * 2)()
+        kernel_ms, kernel_launches = profile_arrays()
         _lib.check(lib.pr_profile_collect(kernel_ms, kernel_launches), "pr_profile_collect")
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(dt, dist if world > 1 else None, dev)
         return dt, kernel_ms, kernel_launches
 
     elapsed, ms, launches = timed(args.steps, args.warmup)
@@ -239,14 +367,13 @@ def main():
     if args.precision == "fp32" and not args.no_split_precision:
         # secondary measurement, never the headline: the same step with the MLP on the split-precision
         # kernel (fp32 emulated with three fp16 MFMAs; same parity tolerance in tests/test_gpu.py)
-        model.object_composer.precision = "f16x3"
+        comp.precision = "f16x3"
         split_s, split_ms, _ = timed(args.steps, max(1, args.warmup))
-        model.object_composer.precision = "fp32"
+        comp.precision = "fp32"
         split = (split_s, split_ms[0] / max(1, args.steps))
 
-    # algorithmic FLOPs of the MLP launches of one step: evaluated samples x FLOP/sample
-    comp = model.object_composer
-    comp_inputs = None
+    # FLOPs of the MLP launches of one step: evaluated samples x FLOP/sample (algorithmic), minus the head FLOPs of
+    # the samples the sigma gate skipped (executed)
     with torch.no_grad():
         from playableenvironments_amd.environment_model import camera_rays, euler_to_matrix
         rows = torch.arange(size[0] * size[1], dtype=torch.int32) // size[1]
@@ -259,21 +386,29 @@ def main():
                   scene_dev["object_in_scene"].unsqueeze(-2), False, _export=True)
     torch.cuda.synchronize()
     helper = comp.object_id_helper
-    flops = 0.0
-    evaluated = {}
+    flops = executed = 0.0
+    evaluated, head_samples = {}, {}
     for ty in ("coarse", "fine"):
         ev = sum(p["evaluated"].cpu() for p in ex[ty]["_samples"])
+        hd = sum(p["head_evaluated"].cpu() for p in ex[ty]["_samples"])
         evaluated[ty] = [int(v) for v in ev]
+        head_samples[ty] = [int(v) for v in hd]
         for k in range(helper.objects_count):
-            flops += float(ev[k]) * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
+            mcfg = cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)]
+            flops += float(ev[k]) * flops_per_sample(mcfg)
+            executed += float(ev[k]) * flops_per_sample(mcfg) - float(ev[k] - hd[k]) * flops_per_sample(mcfg, head_only=True)
 
     # HBM traffic of the dominant kernel from the committed PMC pass (collected separately: counters
     # cannot ride along with the timed run), and the fp32 MFMA rate this box sustains
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc_path) and size == (256, 256):
-        with open(pmc_path) as f:
-            traffic = json.load(f)["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
+    traffic_source = None
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc_path) and size == (256, 256):
+            with open(pmc_path) as f:
+                traffic = json.load(f)["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
+            traffic_source = "profiles/" + name
+            break
     probe = {}
     for name, rnd in (("constant_operands", 0), ("random_operands", 1)):
         tf, pms = C.c_double(), C.c_double()
@@ -284,7 +419,7 @@ def main():
     total_rays = rays_per_gpu * world * args.steps
     value = total_rays / elapsed / 1e6
     mlp_ms = ms[0] / max(1, args.steps)
-    achieved = flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    achieved = executed / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
     result = {
         "metric": "Mrays/s",
         "value": round(value, 4),
@@ -306,6 +441,8 @@ def main():
             "parallelism": f"frame shard x{world}" + (" + RCCL all_gather of feature maps" if world > 1 else ""),
         },
         "frames_per_s_256x256": round(value * 1e6 / 65536.0, 3),
+        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": backend,
+                        "launched_by": "torch.distributed.run" if world > 1 else "single process"},
         "roofline": {
             "bound": "mfma",
             "kernel": "k_mlp_mfma (fused fp32 MFMA MLP, all launches of one step)",
@@ -314,57 +451,188 @@ def main():
             "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (average over the launches of a step), rocprofv3 PMC passes of tools/collect_pmc.sh, profiles/r01_pmc_summary.json",
+            "traffic_unit": f"HBM bytes per launch (average over the launches of a step), rocprofv3 PMC passes of tools/collect_pmc.sh, {traffic_source}",
             "peak_measured": probe,
-            "flop_per_step": flops,
+            "flop_per_step": executed,
+            "flop_per_step_algorithmic": flops,
+            "algorithmic_tflops": round(flops / (mlp_ms * 1e-3) / 1e12, 2) if mlp_ms > 0 else None,
+            "flop_note": "achieved = EXECUTED matmul FLOPs / HIP-event time of the MLP launches; executed = algorithmic (every in-box "
+                         "sample through every layer, what the reference computes) minus the three feature-head products of the "
+                         "samples with density <= 0, whose compositing weight is exactly 0 (sigma-gated head, bit-identical results)",
             "mlp_ms_per_step": round(mlp_ms, 3),
             "mlp_launches_per_step": int(launches[0] / max(1, args.steps)),
             "composite_ms_per_step": round(ms[1] / max(1, args.steps), 3),
             "evaluated_samples": evaluated,
+            "feature_head_samples": head_samples,
+            "sigma_gate": bool(comp.gate_feature_head),
         },
     }
 
     if args.precision == "f16x3":
         result["dtype"] = "f16x3 (fp32 emulated with three fp16 MFMAs, fp32 accumulate)"
-        result["roofline"]["kernel"] = "k_mlp_split (fused split-precision MFMA MLP); achieved/peak are in fp32-equivalent algorithmic FLOPs"
+        result["roofline"]["kernel"] = "k_mlp_split (fused split-precision MFMA MLP); achieved/peak are in fp32-equivalent FLOPs"
     if split is not None:
         result["split_precision"] = {
             "value": round(rays_per_gpu * world * args.steps / split[0] / 1e6, 4),
             "unit": "Mrays/s",
             "ms_per_step": round(split[0] / args.steps * 1e3, 3),
             "mlp_ms_per_step": round(split[1], 3),
-            "algorithmic_tflops": round(flops / (split[1] * 1e-3) / 1e12, 2) if split[1] > 0 else None,
+            "executed_tflops": round(executed / (split[1] * 1e-3) / 1e12, 2) if split[1] > 0 else None,
             "note": "same workload with ObjectComposer.precision='f16x3' (k_mlp_split): every fp32 product as three fp16 "
                     "MFMAs, ~22-bit operands, fp32 accumulation; passes the same oracle/golden parity tolerance; "
                     "reported beside the exact-fp32 headline, not as it",
         }
+    if not args.no_distinct_frames:
+        steps_d = max(1, min(args.steps, 3))
+        result["distinct_frames"] = {
+            "hierarchical_64_128": distinct_frames_leg(model, cfg, "hierarchical 64+128, the headline networks", size, dev, world,
+                                                       rank, dist, steps_d),
+        }
+        shipped_cfg = configs.tennis_config()
+        torch.manual_seed(0)
+        shipped = EnvironmentModel(shipped_cfg)
+        synthetic.randomize_module_state(shipped.object_composer, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
+        shipped.eval().to(dev)
+        result["distinct_frames"]["shipped_p72"] = distinct_frames_leg(shipped, shipped_cfg, "shipped 4+4+32+32 positions - BASELINE.json "
+                                                                       "configs[3]", size, dev, world, rank, dist, max(steps_d, 3))
+        del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import render_oracle as ro
-        from tests.helpers import composer_inputs, grid_pixels
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        torch.set_num_threads(threads)
-        sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
-        n_side = args.cpu_rays
-        inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], n_side))
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            ro.batchified_composer_call(cfg, sd, *inputs, False, chunk=1000)
-            cpu_s = time.perf_counter() - t0
-        result["cpu_baseline"] = {
-            "value": round(n_side * n_side / cpu_s / 1e6, 6),
-            "unit": "Mrays/s",
-            "cores": threads,
-            "kind": "port",
-            "sample": f"{n_side}x{n_side} pixel grid ({n_side * n_side} rays) of the same frame and weights, "
-                      f"oracle/render_oracle.py in 1000-ray chunks, {cpu_s:.1f} s wall, {threads} torch threads "
-                      f"of {os.cpu_count()} host cores",
-        }
+        result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
+    """Everything that runs the ORACLE (test infrastructure) as a yardstick, on rank 0 at N=1 only: the CPU baseline on
+    the host cores, the same PyTorch op graph executed by PyTorch-ROCm on this GPU (what north_star's ">= 10x the
+    reference PyTorch renderer on one MI355X" compares against), and the PSNR of the HIP result against it."""
+    from oracle import render_oracle as ro
+    from playableenvironments_amd import configs, synthetic, ObjectComposer
+    from tests.helpers import composer_inputs, grid_pixels
+    out = {}
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+    n_side = args.cpu_rays
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], n_side))
+
+    # ---- CPU baseline: 16 threads on the n_side^2 subset (the headline figure), 1 thread and all cores on smaller ones
+    host_cores = os.cpu_count() or 1
+    runs = []
+    want = None
+    for threads, side in ((max(1, min(args.cpu_threads, host_cores)), n_side), (1, max(8, n_side // 4)),
+                          (host_cores, max(8, n_side // 8))):
+        torch.set_num_threads(threads)
+        sub = inputs if side == n_side else composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], side))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            res = ro.batchified_composer_call(cfg, sd, *sub, False, chunk=1000)
+            cpu_s = time.perf_counter() - t0
+        if side == n_side:
+            want = res
+        runs.append({"threads": threads, "rays": side * side, "seconds": round(cpu_s, 2),
+                     "value": round(side * side / cpu_s / 1e6, 7), "unit": "Mrays/s"})
+    torch.set_num_threads(max(1, min(args.cpu_threads, host_cores)))
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    main_run = runs[0]
+    out["cpu_baseline"] = {
+        "value": main_run["value"],
+        "unit": "Mrays/s",
+        "cores": main_run["threads"],
+        "kind": "port",
+        "sample": f"{n_side}x{n_side} pixel grid ({n_side * n_side} rays) of the same frame and weights, "
+                  f"oracle/render_oracle.py in 1000-ray chunks, {main_run['seconds']:.1f} s wall, {main_run['threads']} torch threads "
+                  f"of {host_cores} host cores",
+        "runs": runs,
+        "extrapolation": "linear in the number of rays (rays are independent; every run renders a uniform pixel grid of the same frame)",
+        "cpu_model": cpu_model,
+        "host_cores": host_cores,
+        "torch": torch.__version__,
+        "gpu_over_cpu": round(gpu_mrays / main_run["value"], 1) if main_run["value"] > 0 else None,
+    }
+
+    # ---- PSNR of the HIP renderer against the oracle on the same rays (evaluation/metrics/psnr.py:10-34, features
+    # rescaled to [0, 1] with the oracle's min / max - SURVEY.md section 8d)
+    a = want["fine"]["global"]["integrated_features"]
+    lo, hi = float(a.min()), float(a.max())
+    psnr = {}
+    before = comp.precision
+    for precision in ("fp32", "f16x3"):
+        comp.precision = precision
+        with torch.no_grad():
+            got = comp(*[v.to(dev) for v in inputs], False)
+        b = got["fine"]["global"]["integrated_features"].cpu()
+        psnr[precision] = round(ro.psnr((a - lo) / (hi - lo), (b - lo) / (hi - lo)), 2)
+        psnr[precision + "_max_abs_diff"] = float((a - b).abs().max())
+    comp.precision = before
+    out["psnr_db"] = {**psnr, "against": "CPU oracle (pinned bitwise to the reference), fine.global.integrated_features rescaled "
+                      f"to [0, 1] on the {n_side * n_side}-ray subset; 80 dB is the formula's ceiling (its 1e-8 floor)"}
+
+    # ---- the reference's PyTorch op graph on this GPU (PyTorch-ROCm, 1000-ray chunks like render_full_frame_*)
+    if not args.no_reference_graph:
+        gin = [v.to(dev) for v in inputs]
+        gsd = {k: v.to(dev) for k, v in sd.items()}
+        graph = {}
+        for chunk in (1000, 4000):
+            with torch.no_grad():
+                ro.batchified_composer_call(cfg, gsd, *[v[..., :1000, :] if v.dim() == 5 and v.size(-2) > 1000 else v for v in gin],
+                                            False, chunk=chunk)   # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            graph[f"chunk_{chunk}"] = round(n_side * n_side / dt / 1e6, 5)
+        out["reference_graph_on_gpu"] = {
+            "value": graph["chunk_1000"], "unit": "Mrays/s",
+            "chunk_4000": graph["chunk_4000"],
+            "sample": f"the oracle's restatement of the reference's op graph (materialised per-sample tensors, boolean compaction, "
+                      f"sort + gather compose) run by PyTorch-ROCm on this GPU, {n_side * n_side} rays of the same frame, "
+                      "1000-ray chunks as render_full_frame_* uses (4000-ray chunks beside it)",
+            "hip_over_reference_graph": round(gpu_mrays / graph["chunk_1000"], 1) if graph["chunk_1000"] > 0 else None,
+            "hip_over_reference_graph_chunk_4000": round(gpu_mrays / graph["chunk_4000"], 1) if graph["chunk_4000"] > 0 else None,
+        }
+
+    # ---- BASELINE.json configs[0] at full size: one 128x128 frame, one player object, 32 samples per ray, every
+    # ray inside the box - HIP renderer and CPU oracle on all 16 384 rays
+    c1_cfg = configs.tennis_single_player_config()
+    torch.manual_seed(0)
+    c1 = ObjectComposer(c1_cfg)
+    synthetic.randomize_module_state(c1, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
+    c1.eval()
+    c1_inputs = composer_inputs(c1_cfg, synthetic.single_player_scene(image_size=(128, 128)))
+    c1_sd = {k: v.detach().clone() for k, v in c1.state_dict().items()}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        c1_want = ro.batchified_composer_call(c1_cfg, c1_sd, *c1_inputs, False, chunk=1000)
+        c1_cpu = time.perf_counter() - t0
+        c1 = c1.to(dev)
+        gin = [v.to(dev) for v in c1_inputs]
+        c1(*gin, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            c1_got = c1(*gin, False)
+        torch.cuda.synchronize()
+        c1_gpu = (time.perf_counter() - t0) / reps
+    diff = float((c1_want["coarse"]["global"]["integrated_features"] - c1_got["coarse"]["global"]["integrated_features"].cpu()).abs().max())
+    out["config0_single_player_128"] = {
+        "workload": "BASELINE.json configs[0]: 128x128 frame, 1 object (player: NeRF + ray bender), 32 samples/ray, all in the box",
+        "hip_mrays_per_s": round(16384 / c1_gpu / 1e6, 4), "hip_ms": round(c1_gpu * 1e3, 3),
+        "cpu_oracle_mrays_per_s": round(16384 / c1_cpu / 1e6, 6), "cpu_seconds": round(c1_cpu, 2),
+        "cpu_threads": torch.get_num_threads(), "max_abs_diff_features": diff,
+    }
+    return out
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PR_ABI_VERSION 1
+#define PR_ABI_VERSION 2
 #define PR_MAX_OBJECTS 8
 #define PR_MAX_LAYERS 12
 #define PR_MAX_OCTAVES 16
@@ -57,6 +57,15 @@ typedef enum pr_status {
                                        the backward pass differentiates the batch statistics (training); without it
                                        the running statistics are constants (a differentiable eval-mode call, e.g.
                                        test-time optimisation of poses or style codes).  PR_PRECISION_FP32 only. */
+
+#define PR_FLAG_GATE_HEAD 64u        /* sigma-gated feature head: samples whose raw density is <= 0 have alpha = 1 - exp(-relu(sigma) dt)
+                                       = 0 exactly, so their 192-channel feature rows never reach a compositing sum
+                                       (model/object_composer.py:180-214); with this flag the feature head (3 of the 11
+                                       matrix products of a sample) runs on the other samples only.  Results are
+                                       bit-identical.  Honoured for evaluation calls only - ignored with PR_FLAG_PERTURB
+                                       or any integrate-noise pointer (noise is added to the density before the ReLU),
+                                       PR_FLAG_TRAIN_BN (batch statistics need every row), PR_FLAG_SAVE_FOR_BACKWARD and
+                                       PR_FLAG_NAIVE_MLP. */
 
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
@@ -167,6 +176,8 @@ typedef struct pr_outputs_t {
     int32_t* normalised_samples;              /* (K) PR_FLAG_TRAIN_BN: samples that entered the batch statistics */
     float* sample_delta[PR_MAX_OBJECTS];      /* (N,R,P_k,3) ray-bender displacement of every sample (zeros outside the
                                                  box / without a bender), input of pr_expected_positions */
+    int32_t* head_samples;                    /* (K) number of samples sent through the feature head: evaluated_samples
+                                                 unless PR_FLAG_GATE_HEAD skipped the ones with density <= 0 */
 } pr_outputs_t;
 
 typedef struct pr_call_t {
@@ -291,11 +302,14 @@ int pr_expected_positions(int32_t frames, int32_t rays, int32_t objects, int32_t
                           const float* weights, const float* delta, float* expected, void* stream);
 
 /*
- * Kernel timing for bench.py: while enabled, every launch of the fused MLP kernel (category 0) and
- * of the compositing kernel (category 1) is bracketed by hipEventRecord on the launch stream.
+ * Kernel timing for bench.py: while enabled, the launches of the dominant kernels are bracketed by
+ * hipEventRecord on the launch stream.  Categories: 0 = fused MLP (k_mlp_mfma / k_mlp_split / k_mlp_head),
+ * 1 = forward compositing (k_composite), 2 = backward dX products (k_gemm_nn), 3 = backward dW products
+ * (k_gemm_tn + its reduction), 4 = backward compositing (k_composite_bwd); the rest are reserved.
  * pr_profile_collect synchronises the recorded events, returns the summed milliseconds and launch
- * counts per category (host arrays of 2) and clears the list.
+ * counts per category (host arrays of PR_PROFILE_CATEGORIES) and clears the list.
  */
+#define PR_PROFILE_CATEGORIES 8
 int pr_profile_enable(int enable);
 int pr_profile_collect(double* milliseconds, int32_t* launches);
 

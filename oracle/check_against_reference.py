@@ -394,6 +394,107 @@ def check_samplers():
     return ok and same
 
 
+def check_boundary_signatures():
+    """The drop-in classes against the imported reference classes: every method of the boundary has the reference's
+    parameter names, order and defaults (extensions are trailing, underscore-prefixed keyword arguments with defaults)."""
+    import inspect
+    from model.object_composer import ObjectComposer as RefComposer
+    from model.environment_model import EnvironmentModel as RefEnv
+    from playableenvironments_amd import ObjectComposer
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    ok = True
+    checked = 0
+    plan = [(RefComposer, ObjectComposer, ["__init__", "forward", "forward_expected_positions", "set_step",
+                                           "create_object_models"]),
+            (RefEnv, EnvironmentModel, ["__init__", "forward", "set_step", "forward_from_scene_encoding",
+                                        "render_full_frame_from_scene_encoding", "forward_from_observations",
+                                        "render_full_frame_from_observations", "forward_pose_consistency",
+                                        "forward_keypoint_consistency", "batchified_composer_call", "merge_dictionaries",
+                                        "fold_dictionary", "compute_ray_object_distances",
+                                        "compute_transformation_matrix_w2o_o2w", "compute_object_bounding_boxes",
+                                        "compute_object_axes_projection"])]
+    for ref_cls, cls, names in plan:
+        for name in names:
+            if not hasattr(cls, name):
+                print(f"[boundary] {cls.__name__}.{name}: MISSING")
+                ok = False
+                continue
+            want = list(inspect.signature(getattr(ref_cls, name)).parameters.values())
+            got = list(inspect.signature(getattr(cls, name)).parameters.values())
+            head, extra = got[:len(want)], got[len(want):]
+            same = len(head) == len(want) and all(a.name == b.name and a.kind == b.kind and a.default == b.default
+                                                   for a, b in zip(want, head))
+            same = same and all(e.name.startswith("_") and e.default is not inspect.Parameter.empty for e in extra)
+            if not same:
+                print(f"[boundary] {cls.__name__}.{name}: signature differs\n    reference: {want}\n    here:      {got}")
+            ok &= same
+            checked += 1
+    # attributes the reference's callers touch (environment_model.py:271,672; trainers)
+    cfg = configs.tennis_config()
+    comp = ObjectComposer(cfg)
+    ref = refshim.build_reference_composer(copy.deepcopy(cfg))
+    for attr in ("object_models_coarse", "object_models_fine", "object_id_helper", "apply_activation", "config"):
+        ok &= hasattr(comp, attr) and hasattr(ref, attr)
+    ok &= len(comp.object_models_coarse) == len(ref.object_models_coarse)
+    for mine, theirs in zip(comp.object_models_coarse, ref.object_models_coarse):
+        ok &= hasattr(mine, "bounding_box") and hasattr(mine, "model_config")
+        ok &= mine.model_config["positions_count_coarse"] == theirs.model_config["positions_count_coarse"]
+    sd_a, sd_b = comp.state_dict(), ref.state_dict()
+    ok &= list(sd_a.keys()) == list(sd_b.keys()) and all(sd_a[k].shape == sd_b[k].shape and sd_a[k].dtype == sd_b[k].dtype
+                                                          for k in sd_a)
+    print(f"[boundary] {checked} method signatures, attributes and {len(sd_a)} state_dict entries match the reference: {ok}")
+    return ok
+
+
+def _leaves(d, prefix=""):
+    out = {}
+    if isinstance(d, dict) or hasattr(d, "keys"):
+        for k in d.keys():
+            out.update(_leaves(d[k], f"{prefix}{k}."))
+    elif isinstance(d, (list, tuple)):
+        for i, v in enumerate(d):
+            out.update(_leaves(v, f"{prefix}{i}."))
+    else:
+        out[prefix[:-1]] = d
+    return out
+
+
+def check_configs_against_yaml():
+    """configs.tennis_config() / minecraft_config() against the shipped YAML files (with the defaults of
+    utils/configuration.py the renderer reads): every key both sides have carries the same value."""
+    ok = True
+    for name, mine in (("tennis", configs.tennis_config()), ("minecraft", configs.minecraft_config())):
+        ref_cfg = refshim.load_reference_config(name)
+        a, b = _leaves(mine), _leaves(ref_cfg)
+        shared = sorted(set(a) & set(b))
+        differing = [k for k in shared if a[k] != b[k]]
+        only_mine = sorted(set(a) - set(b))
+        print(f"[config {name}] shared leaves={len(shared)} differing={differing} only here={only_mine[:6]}{'...' if len(only_mine) > 6 else ''}")
+        ok &= not differing and len(shared) > 50
+    return ok
+
+
+def report_tie_fractions():
+    """Per golden fixture: the fraction of rays on which the reference's (unspecified) tie order and the renderer's stable
+    tie rule give different global results - the rays the GPU golden test compares against the stable-merge oracle only."""
+    import glob
+    import os
+    from oracle.make_golden import recipe_config
+    from tests.test_cpu import load_fixture
+    for path in sorted(glob.glob(os.path.join("tests", "golden", "*.npz"))):
+        recipe, inputs, sd, noise, want, perturb = load_fixture(path)
+        cfg = recipe_config(recipe)
+        with torch.no_grad():
+            stable = ro.composer_forward(cfg, sd, *inputs, perturb, noise=noise, stable_merge=True)
+        parts = []
+        for ty in want:
+            a, b = stable[ty]["global"], want[ty]["global"]
+            differ = (a["opacity"] != b["opacity"]) | (a["integrated_features"] != b["integrated_features"]).any(-1)
+            parts.append(f"{ty}: {float(differ.float().mean()) * 100:.2f}% of {differ.numel()} rays")
+        print(f"[tie rule] {os.path.basename(path)}: rays where stable order != reference order -> {', '.join(parts)}")
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the full-size cases (minutes)")
@@ -406,9 +507,15 @@ def main():
     ok &= run_case("tennis shipped eval, sigma bias 3", t, synthetic.tennis_scene(seed=7),
                    pixels=grid_pixels(256, 256, n), alpha_bias=3.0)[1]
     ok &= run_case("tennis 2 frames eval", t, synthetic.tennis_scene(batch=2, seed=3), pixels=grid_pixels(256, 256, 12))[1]
-    th = configs.tennis_config(hierarchical=(64, 128)) if args.full else configs.tennis_config(hierarchical=(16, 32))
+    th = configs.tennis_config(hierarchical=(16, 32))
     ok &= run_case("tennis hierarchical eval", th, synthetic.tennis_scene(seed=5), pixels=grid_pixels(256, 256, 16),
                    alpha_bias=2.0)[1]
+    # BASELINE.json configs[1] itself (4 objects x (64 + 128) positions, shipped network widths, the benchmark's scene)
+    c2 = configs.tennis_config(hierarchical=(64, 128))
+    ok &= run_case("tennis C2 64+128 hierarchical eval", c2, synthetic.tennis_scene(seed=1234),
+                   pixels=grid_pixels(256, 256, 32 if args.full else 12), alpha_bias=2.0)[1]
+    ok &= run_case("tennis C2 64+128 hierarchical eval, bench weights (sigma bias 0)", c2, synthetic.tennis_scene(seed=1234),
+                   pixels=grid_pixels(256, 256, 10), alpha_bias=0.0, step=60000)[1]
     m = configs.minecraft_config()
     ok &= run_case("minecraft shipped eval", m, synthetic.minecraft_scene(), pixels=grid_pixels(256, 256, n),
                    alpha_bias=3.0)[1]
@@ -450,6 +557,9 @@ def main():
                                                grid_pixels(256, 256, 16), 2, perturb=False, alpha_bias=3.0)
     # (with use_fine the reference's own backward raises: compute_expected_positions keeps a view of the coarse weights
     # that sample_pdf later modifies in place - there is no reference gradient to pin for hierarchical configurations)
+    ok &= check_boundary_signatures()
+    ok &= check_configs_against_yaml()
+    ok &= report_tie_fractions()
     ok &= check_samplers()
     ok &= check_wire_format()
     ok &= check_ray_object_distances()

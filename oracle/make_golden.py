@@ -191,8 +191,17 @@ ODD = dict(width=48, layers=3, skip=1, features=16, octaves=3, bender_width=16, 
            bender_octaves=2)
 
 
+C2_POSITIONS = {"background": (64, 128), "background_backplate": (64, 128), "player_1": (64, 128), "player_2": (64, 128)}
+
+
 def main():
     refshim.install()
+    if len(sys.argv) > 1 and sys.argv[1] == "c2":
+        # BASELINE.json configs[1] sample counts (64 coarse + 128 resampled per object, 256 / 768 merged entries per ray)
+        # on reduced network widths: the fixture of the headline configuration's list lengths
+        make("tennis_small_c2_hier_eval", {"base": "tennis", "reduce": REDUCE, "fine": True, "positions": C2_POSITIONS},
+             synthetic.tennis_scene(seed=28), grid_pixels(256, 256, 8))
+        return
     make("tennis_small_eval", {"base": "tennis", "reduce": REDUCE}, synthetic.tennis_scene(seed=21),
          grid_pixels(256, 256, 16))
     make("tennis_odd_widths_eval", {"base": "tennis", "reduce": ODD}, synthetic.tennis_scene(seed=22, batch=2),

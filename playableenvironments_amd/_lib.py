@@ -19,8 +19,10 @@ PR_FLAG_FIX_OVERLAPS = 4
 PR_FLAG_NAIVE_MLP = 8
 PR_FLAG_TRAIN_BN = 16
 PR_FLAG_SAVE_FOR_BACKWARD = 32
+PR_FLAG_GATE_HEAD = 64
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
+PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -80,7 +82,7 @@ class Outputs(C.Structure):
         ("object", Entry * PR_MAX_OBJECTS), ("global_", Entry),
         ("sample_t", C.c_void_p * PR_MAX_OBJECTS), ("sample_sigma", C.c_void_p * PR_MAX_OBJECTS),
         ("sample_slot", C.c_void_p * PR_MAX_OBJECTS), ("evaluated_samples", C.c_void_p), ("normalised_samples", C.c_void_p),
-        ("sample_delta", C.c_void_p * PR_MAX_OBJECTS),
+        ("sample_delta", C.c_void_p * PR_MAX_OBJECTS), ("head_samples", C.c_void_p),
     ]
 
 
@@ -171,8 +173,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pr_abi_version() != 1:
-        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 1")
+    if lib.pr_abi_version() != 2:
+        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 2 (rebuild: make -C playableenvironments_amd/csrc)")
     _LIB = lib
     return lib
 

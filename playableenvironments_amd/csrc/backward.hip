@@ -319,6 +319,7 @@ static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
     const long total = (long)p.frames * p.rays;
+    ProfileScope scope(4, s);
     hipLaunchKernelGGL(k_composite_bwd, dim3((unsigned)total), dim3(64), lds, s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;

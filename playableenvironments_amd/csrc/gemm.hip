@@ -171,6 +171,7 @@ int launch_gemm_nn(const GemmNN& p, int max_rows, hipStream_t s) {
     if (row_tiles > 1024) row_tiles = 1024;
     row_tiles = (row_tiles + 7) / 8 * 8;              // whole groups of 8 row tiles (one per XCD)
     const int ncol_tiles = (p.n + GT - 1) / GT;
+    ProfileScope scope(2, s);
     hipLaunchKernelGGL(k_gemm_nn, dim3(row_tiles * ncol_tiles), dim3(256), 0, s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;
@@ -314,6 +315,7 @@ int launch_gemm_tn(const GemmTN& p, hipStream_t s) {
                p.lda >= ((p.ni + 3) & ~3) && p.ldb >= ((p.nj + 3) & ~3), "gemm_tn: operands must be 16-byte aligned rows");
     PR_REQUIRE(p.splits >= 1 && p.partial, "gemm_tn: no partial buffer");
     const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+    ProfileScope scope(3, s);
     hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, p.splits), dim3(256), 0, s, p);
     PR_LAUNCH_CHECK();
     const long n = (long)p.ni * p.nj;

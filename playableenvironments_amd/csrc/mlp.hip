@@ -336,7 +336,10 @@ struct Smem {
     float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
     int flat[TILE_M];
     int frame[TILE_M];
-    int flags[TILE_M];       // bit 0: row holds a real sample; bit 1: it passed every AABB test
+    int flags[TILE_M];       // bit 0: row holds a real sample; bit 1: it passed every AABB test; bit 2 (sigma-gated
+                             // head only): its density is not <= 0, i.e. its feature row can reach a compositing sum
+    int dest[TILE_M];        // gated head: compact feature row a tile row is written to (-1: none)
+    int src[TILE_M];         // gated head: slot of the workgroup's pending stack a tile row is exchanged with (-1: none)
 };
 static_assert(sizeof(Smem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "the workgroups of one CU must fit its LDS");
 
@@ -737,6 +740,134 @@ __device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int w
     }
 }
 
+// Feature rows staged in X -> HBM rows S.dest[row] (rows with dest < 0 are skipped); see write_tile_rows.
+__device__ __forceinline__ void write_rows_indirect(const Smem& S, float* dst, int width, int stride) {
+    const int tid = threadIdx.x;
+    if ((width & 3) == 0 && (stride & 3) == 0) {
+        const int w4 = width >> 2;
+        for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            const int d = S.dest[row];
+            if (d >= 0) {
+                const float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(dst + (size_t)d * stride + c));
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TILE_M * width; idx += MLP_THREADS) {
+            const int row = idx / width, c = idx - row * width;
+            const int d = S.dest[row];
+            if (d >= 0) dst[(size_t)d * stride + c] = S.X[row * LDX + c];
+        }
+    }
+}
+
+// The three feature-head layers on the 64 rows in X whose destinations are in S.dest, then the write-out.
+__device__ __forceinline__ void head_on_tile(Smem& S, const MlpParams& p, EncRegs& enc, int valid_rows) {
+    for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, 0, 0, enc);
+    write_rows_indirect(S, p.feat, p.F, p.F);
+    if (threadIdx.x == 0 && p.head_count) atomicAdd(p.head_count, valid_rows);
+    __syncthreads();   // the next prologue overwrites flags / X
+}
+
+// Sigma-gated feature head (eval, no noise).  A sample whose raw density is <= 0 has alpha = 1 - exp(-relu(sigma) dt) = 0
+// exactly, in its object's list and in the merged list alike, so its feature row is never read by the compositing
+// kernel (composite.hip: take = row >= 0 && (w1 != 0 || w2 != 0)); neither are the rows of samples that failed the
+// second AABB test.  The head (3 of the 11 matrix products, 20 % of the FLOPs of a sample) therefore runs on the LIVE rows
+// only.  Rows are independent, so live rows of different tiles can share a head tile: every workgroup keeps a stack of
+// up to 63 pending live rows (their 256-wide backbone outputs) in global memory.  After the sigma head of a tile with L
+// live rows and P pending ones:
+//   P + L >= 64: the dead slots of X are refilled with 64 - L pending rows (popped from the stack), the head runs on a
+//                full tile, in place;
+//   otherwise:   the L live rows are pushed on the stack and the tile is done.
+// A tile that is entirely live (or dead) never touches the stack; what is left on it when the workgroup runs out of
+// tiles is flushed through one partial head tile.  MFMA rows do not interact, so the results are bit-identical to the
+// ungated kernel's for every row that is read downstream.
+__device__ __forceinline__ int gated_head(Smem& S, const MlpParams& p, int tile_base, int pending, EncRegs& enc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long live = __ballot((S.flags[lane] & 4) != 0);   // the same value in every wave
+    const int L = __popcll(live);
+    float* pact = p.pend_act + (size_t)blockIdx.x * TILE_M * p.Wpad;
+    int* pmeta = p.pend_meta + (size_t)blockIdx.x * TILE_M * 2;
+    const unsigned long long below = (1ull << lane) - 1ull;   // lanes below this one (tid < 64: rows below this row)
+    const int w4 = p.Wpad >> 2;
+    if (L == 0) {
+        __syncthreads();   // every wave has read the flags; the next prologue may overwrite them
+        return pending;
+    }
+    if (pending + L >= TILE_M) {
+        const int need = TILE_M - L;
+        if (tid == 0) S.uniform_frame = 1;
+        if (tid < TILE_M) {
+            if ((live >> tid) & 1ull) {
+                S.dest[tid] = tile_base + tid;
+                S.src[tid] = -1;
+            } else {
+                const int slot = pending - need + __popcll(~live & below);
+                S.src[tid] = slot;
+                S.dest[tid] = pmeta[2 * slot];
+                S.frame[tid] = pmeta[2 * slot + 1];
+            }
+        }
+        __syncthreads();
+        if (need) {
+            for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+                const int row = idx / w4, c = (idx - row * w4) * 4;
+                const int slot = S.src[row];
+                if (slot >= 0)
+                    *reinterpret_cast<float4*>(S.X + row * LDX + c) = *reinterpret_cast<const float4*>(pact + (size_t)slot * p.Wpad + c);
+            }
+        }
+        if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        __syncthreads();
+        head_on_tile(S, p, enc, TILE_M);
+        return pending - need;
+    }
+    if (tid < TILE_M) {
+        int slot = -1;
+        if ((live >> tid) & 1ull) {
+            slot = pending + __popcll(live & below);
+            pmeta[2 * slot] = tile_base + tid;
+            pmeta[2 * slot + 1] = S.frame[tid];
+        }
+        S.src[tid] = slot;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+        const int row = idx / w4, c = (idx - row * w4) * 4;
+        const int slot = S.src[row];
+        if (slot >= 0)
+            *reinterpret_cast<float4*>(pact + (size_t)slot * p.Wpad + c) = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+    }
+    __syncthreads();   // the pushed rows are visible to the whole workgroup; X / flags may be overwritten
+    return pending + L;
+}
+
+// What is left on the pending stack after the last tile of a workgroup.
+__device__ __forceinline__ void gated_head_flush(Smem& S, const MlpParams& p, int pending, EncRegs& enc) {
+    if (pending <= 0) return;
+    const int tid = threadIdx.x;
+    const float* pact = p.pend_act + (size_t)blockIdx.x * TILE_M * p.Wpad;
+    const int* pmeta = p.pend_meta + (size_t)blockIdx.x * TILE_M * 2;
+    const int w4 = p.Wpad >> 2;
+    if (tid == 0) S.uniform_frame = 1;
+    if (tid < TILE_M) {
+        const bool has = tid < pending;
+        S.dest[tid] = has ? pmeta[2 * tid] : -1;
+        S.frame[tid] = pmeta[2 * (has ? tid : 0) + 1];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < pending * w4; idx += MLP_THREADS) {
+        const int row = idx / w4, c = (idx - row * w4) * 4;
+        *reinterpret_cast<float4*>(S.X + row * LDX + c) = *reinterpret_cast<const float4*>(pact + (size_t)row * p.Wpad + c);
+    }
+    if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+    __syncthreads();
+    head_on_tile(S, p, enc, pending);
+}
+
 // Per-channel sum and sum of squares of the alive rows of the tile staged in X -> global double
 // accumulators (one atomic per channel and tile); the number of alive rows is counted alongside.
 __device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams& p) {
@@ -772,9 +903,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
     if (bender_head_staged)
         for (int i = tid; i < 3 * p.BWpad; i += MLP_THREADS) S.head_w[HEAD_SIGMA + i] = p.b_out[i];
     __syncthreads();
+    int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head), uniform across the workgroup
+    EncRegs enc;       // this thread's share of the current network input (see fill_encoding)
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
-        EncRegs enc;   // this thread's share of the current network input (see fill_encoding)
         PR_PHASE_T0();
         if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
@@ -875,15 +1007,26 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
                 float sg;
                 row_dots(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
-                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
+                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) {
+                    const float sv = sg + S.head_w[p.Wpad];
+                    p.sigma[S.flat[s]] = sv;
+                    if (!(sv <= 0.f)) S.flags[s] |= 4;   // a NaN density stays live (relu(NaN) = NaN in the reference)
+                }
             }
         } else if (tid < TILE_M) {
-            if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
+            if (S.flags[tid] & 1) {
+                p.sigma[S.flat[tid]] = 10.0f;
+                S.flags[tid] |= 4;
+            }
         }
 
         PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
-        if (p.phase == 0) {
+        if (p.phase == 0 && p.gate) {
+            __syncthreads();   // the liveness bits are complete
+            pending = gated_head(S, p, tile_base, pending, enc);
+            PR_PHASE(8);
+        } else if (p.phase == 0) {
             for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base, 0, enc);
             PR_PHASE(15);
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
@@ -900,6 +1043,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             accumulate_stats(S, p);
         }
     }
+    if (p.phase == 0 && p.gate) gated_head_flush(S, p, pending, enc);
 }
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
@@ -1095,8 +1239,10 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
     const MlpParams& pd = p;
     int cu_count = 0;
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(pd.phase >= 2 ? k_mlp_head : k_mlp_mfma), (int)sizeof(Smem), &cu_count));
-    const int resident = cu_count * MLP_BLOCKS_PER_CU;
+    int resident = cu_count * MLP_BLOCKS_PER_CU;
+    if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;   // the pending stacks of the gated head are sized for this
     const int grid = max_tiles < resident ? max_tiles : resident;
+    PR_REQUIRE(!pd.gate || (pd.pend_act && pd.pend_meta && pd.phase == 0), "gated head: pending buffers missing");
     ProfileScope scope(0, s);
     if (pd.phase >= 2) {
         hipLaunchKernelGGL(k_mlp_head, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);

@@ -44,6 +44,7 @@ constexpr int MLP_BLOCKS_PER_CU = 2;   // two independent tiles per CU (LDS ~70 
 constexpr int MLP_THREADS = MLP_WAVES * 64;
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
+constexpr int MAX_RESIDENT_TILES = 1024;   // upper bound of the persistent MLP grid (2 workgroups x CUs; 512 on MI355X)
 constexpr int MAX_ENC = 128;      // padded encoding width limit
 constexpr int LDE = MAX_ENC + 4;
 
@@ -155,6 +156,11 @@ struct MlpParams {
     float* save_braw;            // (cap, 3) bender head output before * size and the clamp
     float* save_delta;           // (cap, 3) final displacement (after clamp / canonical_pose)
     float* delta_dense;          // (N,R,P,3) the same, scattered to the sample grid (optional export)
+    // sigma-gated feature head (eval, no noise; see gated_head in mlp.hip)
+    int gate;                    // 1 = run the feature head on the samples with density > 0 only
+    float* pend_act;             // (MAX_RESIDENT_TILES, TILE_M, Wpad floats) per-workgroup stacks of pending live rows
+    int32_t* pend_meta;          // (MAX_RESIDENT_TILES, TILE_M, 2) [compact feature row, frame] of the pending rows
+    int32_t* head_count;         // device counter: rows sent through the feature head (NULL = not counted)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
@@ -298,12 +304,14 @@ struct TypePlan {
     size_t feat[PR_MAX_OBJECTS];
     int positions[PR_MAX_OBJECTS];
     size_t totals;  // K ints
+    size_t head_counts;  // K ints: rows sent through the feature head (sigma-gated head)
     SavedPlan saved[PR_MAX_OBJECTS];
 };
 struct Plan {
     TypePlan type[2];
     size_t block_sums, block_offsets;
     size_t rec_pos, rec_flat;
+    size_t pend_act, pend_meta;   // pending stacks of the sigma-gated head (gate_active calls only)
     // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
     size_t h1, h2, row_flags, stats, stat_count, batch_stats;
     size_t div_t0, div_ta, div_tb;   // divergence tangent scratch
@@ -314,6 +322,7 @@ struct Plan {
 // that device's number of compute units.  Function attributes are per device: a process may drive several.
 int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count);
 int validate_call(const pr_call_t& c, const pr_object_t* objs);
+bool gate_active(const pr_call_t& c);
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size);
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,

@@ -121,6 +121,16 @@ int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     return PR_OK;
 }
 
+// The sigma-gated feature head applies to calls whose compositing weights are a function of the raw densities alone:
+// evaluation without perturbation noise, nothing saved for a backward pass, fused (unphased) MLP launches.
+bool gate_active(const pr_call_t& c) {
+    if (!(c.flags & PR_FLAG_GATE_HEAD)) return false;
+    if (c.flags & (PR_FLAG_PERTURB | PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD | PR_FLAG_NAIVE_MLP)) return false;
+    for (int k = 0; k < c.objects; ++k)
+        if (c.noise_coarse.integrate[k] || c.noise_fine.integrate[k]) return false;
+    return !c.noise_coarse.integrate_global && !c.noise_fine.integrate_global;
+}
+
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     memset(plan, 0, sizeof(*plan));
     size_t off = 0;
@@ -140,6 +150,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     for (int t = 0; t < ntypes; ++t) {
         TypePlan& tp = plan->type[t];
         tp.totals = take(sizeof(int32_t) * PR_MAX_OBJECTS);
+        tp.head_counts = take(sizeof(int32_t) * PR_MAX_OBJECTS);
         for (int k = 0; k < c.objects; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             ModelDims d;
@@ -180,6 +191,10 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     plan->rec_pos = take(sizeof(float) * 3 * max_cap);
     plan->rec_flat = take(sizeof(int32_t) * max_cap);
+    if (gate_active(c)) {   // per-workgroup stacks of pending live rows (sigma-gated head)
+        plan->pend_act = take(sizeof(float) * (size_t)MAX_RESIDENT_TILES * TILE_M * MAX_WIDTH);
+        plan->pend_meta = take(sizeof(int32_t) * (size_t)MAX_RESIDENT_TILES * TILE_M * 2);
+    }
     if (c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD)) {   // the phased launch structure (see render())
         plan->h1 = take(sizeof(float) * max_cap * MAX_WIDTH);
         plan->h2 = take(sizeof(float) * max_cap * (MAX_WIDTH / 2 + 32));
@@ -227,10 +242,13 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
     float* rec_pos = reinterpret_cast<float*>(ws + plan.rec_pos);
     int32_t* rec_flat = reinterpret_cast<int32_t*>(ws + plan.rec_flat);
     const bool naive = (c.flags & PR_FLAG_NAIVE_MLP) != 0;
+    const bool gate = gate_active(c);
 
     for (int t = 0; t < ntypes; ++t) {
         const TypePlan& tp = plan.type[t];
         int32_t* totals = reinterpret_cast<int32_t*>(ws + tp.totals);
+        int32_t* head_counts = reinterpret_cast<int32_t*>(ws + tp.head_counts);
+        if (gate) PR_CHECK_HIP(hipMemsetAsync(head_counts, 0, sizeof(int32_t) * PR_MAX_OBJECTS, s));
         const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
         int total_positions = 0;
         for (int k = 0; k < K; ++k) {
@@ -323,6 +341,12 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             mp.deformation_stride = K * m.deformation_features;
             mp.adain = adain; mp.adain_stride = fo.row_floats;
             mp.sigma = sigma; mp.dispmag = dispmag; mp.feat = feat;
+            if (gate) {
+                mp.gate = 1;
+                mp.pend_act = reinterpret_cast<float*>(ws + plan.pend_act);
+                mp.pend_meta = reinterpret_cast<int32_t*>(ws + plan.pend_meta);
+                mp.head_count = head_counts + k;
+            }
             if (outs[t] && outs[t]->sample_delta[k]) {
                 PR_CHECK_HIP(hipMemsetAsync(outs[t]->sample_delta[k], 0, sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
                 if (m.has_bender) mp.delta_dense = outs[t]->sample_delta[k];
@@ -461,6 +485,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             }
             if (out->evaluated_samples)
                 PR_CHECK_HIP(hipMemcpyAsync(out->evaluated_samples, totals, sizeof(int32_t) * K, hipMemcpyDeviceToDevice, s));
+            if (out->head_samples)   // without the gate every evaluated sample goes through the feature head
+                PR_CHECK_HIP(hipMemcpyAsync(out->head_samples, gate ? head_counts : totals, sizeof(int32_t) * K,
+                                            hipMemcpyDeviceToDevice, s));
         }
     }
     return PR_OK;
@@ -503,7 +530,7 @@ extern "C" int pr_profile_enable(int enable) {
 extern "C" int pr_profile_collect(double* milliseconds, int32_t* launches) {
     PR_REQUIRE(milliseconds && launches, "pr_profile_collect: NULL argument");
     std::lock_guard<std::mutex> lock(pr::g_profile_mutex);
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < PR_PROFILE_CATEGORIES; ++c) {
         milliseconds[c] = 0.0;
         launches[c] = 0;
     }
@@ -511,7 +538,7 @@ extern "C" int pr_profile_collect(double* milliseconds, int32_t* launches) {
         PR_CHECK_HIP(hipEventSynchronize(r.stop));
         float ms = 0.f;
         PR_CHECK_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
-        if (r.category >= 0 && r.category < 2) {
+        if (r.category >= 0 && r.category < PR_PROFILE_CATEGORIES) {
             milliseconds[r.category] += ms;
             launches[r.category] += 1;
         }

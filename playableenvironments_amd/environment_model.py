@@ -301,10 +301,13 @@ class EnvironmentModel(nn.Module):
                                     object_rotation_parameters_o2w, object_translation_parameters_o2w, object_style,
                                     object_deformation, object_in_scene, samples_per_image: int, perturb: bool,
                                     samples_per_image_batching: int = 0, upsample_factor: float = 1.0,
-                                    patch_size: int = 0, patch_stride=0, canonical_pose: bool = False) -> Dict:
+                                    patch_size: int = 0, patch_stride=0, canonical_pose: bool = False,
+                                    _ray_range: Tuple[int, int] = None) -> Dict:
         """model/environment_model.py:1041-1158; argument shapes documented there.
 
-        camera_* (..., O, C, 3); focals (..., O, C); object_* (..., O, 3|S|D, K); object_in_scene (..., O, K)."""
+        camera_* (..., O, C, 3); focals (..., O, C); object_* (..., O, 3|S|D, K); object_in_scene (..., O, K).
+        ``_ray_range`` (extension): render only the rays [begin, end) of the pixel list - one rank's contiguous share of
+        a frame in ``render_sharded``."""
         rescaled_focals = focals * self.focal_length_multiplier
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
@@ -340,6 +343,8 @@ class EnvironmentModel(nn.Module):
             idx = ray_sampling.sample_pixels_uniform(flat_boxes.size(0), height, width, samples_per_image, boxes.device)
             rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
 
+        if _ray_range is not None:
+            rows, cols = rows[..., _ray_range[0]:_ray_range[1]], cols[..., _ray_range[0]:_ray_range[1]]
         origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
 
         results = self.batchified_composer_call(origins, directions, normals, w2o, object_style.unsqueeze(-3),
@@ -375,3 +380,67 @@ class EnvironmentModel(nn.Module):
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
         return self.fold_dictionary(flat, height, width)
+
+    # ------------------------------------------------------------------ multi-GPU: one render shared by all ranks
+    def render_sharded(self, camera_rotations, camera_translations, focals, image_size, object_rotation_parameters_o2w,
+                       object_translation_parameters_o2w, object_style, object_deformation, object_in_scene,
+                       perturb: bool = False, patch_stride=0, upsample_factor: float = 1.0, canonical_pose: bool = False,
+                       shard: str = "auto", fields=("integrated_features", "opacity", "depth"), entries=("global",),
+                       dst=None, group=None) -> Dict:
+        """One evaluation render of ``forward_from_scene_encoding`` (every pixel, or the strided grids of ``patch_stride``)
+        shared by the ranks of a torch.distributed group (one process per GPU; RCCL over xGMI): every rank holds the
+        whole scene encoding (a few KB) and the replicated weights, renders its share and the rendered maps are
+        exchanged with ONE collective per requested field (BASELINE.json configs[3]).
+
+        shard = "frames": the leading (batch) dimension is split over the ranks (``parallel.shard_range``; batches
+        that do not divide evenly give ragged shards); "rays": every rank renders a contiguous range of the pixel list
+        of all frames (a single frame across the node); "auto": frames when the batch has at least one frame per rank.
+        Rays are independent and eval-mode BatchNorm uses the running statistics, so the assembled result is bit-identical
+        to the single-GPU render.  Returns ``{type: {entry: {field: tensor}}}`` with the reference's shapes on ``dst``
+        (None on the other ranks), on every rank when ``dst`` is None.  Without an initialised process group (or with one
+        rank) it is the plain render."""
+        import torch.distributed as dist
+        from . import parallel
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if perturb and world > 1:
+            raise ValueError("render_sharded is an evaluation render (perturb=False): per-rank noise would not reproduce "
+                             "the single-GPU result")
+        batch = camera_rotations.size(0)
+        if shard == "auto":
+            shard = "frames" if batch >= world else "rays"
+        if shard not in ("frames", "rays"):
+            raise ValueError(f"unknown shard mode {shard!r} (expected 'auto', 'frames' or 'rays')")
+        args = [camera_rotations, camera_translations, focals, image_size, object_rotation_parameters_o2w,
+                object_translation_parameters_o2w, object_style, object_deformation, object_in_scene]
+        kwargs = dict(upsample_factor=upsample_factor, patch_stride=patch_stride, canonical_pose=canonical_pose,
+                      mode="scene_encodings")
+        if shard == "frames":
+            if batch < world:
+                raise ValueError(f"shard='frames' needs at least one frame per rank ({batch} frames, {world} ranks): use 'rays'")
+            local_args = [parallel.shard_frames(a, rank, world, 0) if torch.is_tensor(a) else a for a in args]
+            total, dim = batch, 0
+            ray_range = None
+        else:
+            local_args = args
+            height, width = int(image_size[0] * upsample_factor), int(image_size[1] * upsample_factor)
+            if patch_stride:
+                strides = patch_stride if isinstance(patch_stride, collections.abc.Sequence) else [patch_stride]
+                total = sum((height // s) * (width // s) for s in strides)
+            else:
+                total = height * width
+            dim = camera_rotations.dim() - 1
+            ray_range = parallel.shard_range(total, rank, world)
+        with torch.no_grad():
+            local = self(*local_args, 0, perturb, 0, _ray_range=ray_range, **kwargs)
+        out: Dict = {}
+        receives = dst is None or rank == dst
+        for ty in ("coarse", "fine"):
+            if ty not in local:
+                continue
+            for entry in entries:
+                for field in fields:
+                    full = parallel.gather_ray_shards(local[ty][entry][field], total, dim, dst=dst, group=group)
+                    if receives:
+                        out.setdefault(ty, {}).setdefault(entry, {})[field] = full
+        return out if receives else None

@@ -49,19 +49,33 @@ class FrameGraph:
             for _ in range(max(1, warmup)):
                 self._call()
         torch.cuda.current_stream(device).wait_stream(side)
-        self._workspace = model.object_composer._workspace      # the graph writes through this pointer: keep it alive
-        self._weights_version = self._parameter_versions()
+        composer = model.object_composer
+        self._workspace = composer._workspace      # the graph writes through this pointer: keep it alive
+        self._weights_version = self._signature()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.results = self._call()
+        # the graph also reads the composer's packed weight buffers through raw pointers: hold them, so that a repack
+        # (another precision, a differentiable call) can drop them from the composer's cache without freeing them
+        self._packed = [entry[1] for entry in composer._packed.values()]
+        self._linspace = list(composer._linspace.values())
+        if composer._workspace is not self._workspace:
+            raise RuntimeError("the composer re-allocated its workspace during the capture")
 
-    def _parameter_versions(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.object_composer.parameters())
+    def _signature(self):
+        """Everything the captured launches baked in besides the input buffers: parameter storages and values, the
+        arithmetic precision (selects the kernel and the packed layout), the sigma gate, and the annealing step of the ray benders
+        (their octave weights are kernel arguments)."""
+        composer = self.model.object_composer
+        # state_epoch counts set_step / load_state_dict / .to() calls (reading the step buffers back would synchronise)
+        return (tuple((p.data_ptr(), p._version) for p in composer.parameters()), composer.precision,
+                bool(composer.gate_feature_head), composer.state_epoch)
 
     def render(self, scene: Dict[str, torch.Tensor]) -> Dict:
         """Copies the scene encoding into the captured input buffers and replays the frame."""
-        if self._parameter_versions() != self._weights_version:
-            raise RuntimeError("the composer's parameters changed since the frame was captured: build a new FrameGraph")
+        if self._signature() != self._weights_version:
+            raise RuntimeError("the composer's parameters, precision or annealing step changed since the frame was captured: "
+                               "build a new FrameGraph")
         for k in SCENE_KEYS:
             src = scene[k]
             if src.shape != self.inputs[k].shape:

@@ -95,6 +95,9 @@ class _RenderFunction(torch.autograd.Function):
     def forward(ctx, composer, kwargs, holder, w2o, style, deformation, *params):
         results, state = composer._render(**kwargs, _save=True)
         ctx.composer, ctx.state, ctx.params = composer, state, params
+        # the backward pass reads the parameter storages in place: an in-place update between forward and backward
+        # (an optimiser step, a GAN-style second network update) must raise, as torch's saved-tensor check would
+        ctx.versions = tuple(p._version for p in composer.parameters())
         ctx.shapes = (w2o.shape, style.shape, deformation.shape)
         ctx.set_materialize_grads(False)      # outputs the loss does not read arrive as None, not as zero tensors
         holder["results"], holder["types"] = results, state["types"]
@@ -126,6 +129,13 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, *grad_outputs):
         st, composer = ctx.state, ctx.composer
+        if st is None:
+            raise RuntimeError("Trying to backward through the renderer call a second time: its saved activations (the forward "
+                               "workspace) have already been freed.  Render again, or sum the losses before calling backward().")
+        if tuple(p._version for p in composer.parameters()) != ctx.versions:
+            raise RuntimeError("one of the composer's parameters was modified in place between the renderer's forward and "
+                               "backward calls (pr_render_backward reads the parameter storages): call backward() before "
+                               "the optimiser step")
         N, R, K, S, D, F = st["N"], st["R"], st["K"], st["S"], st["D"], st["F"]
         lib = _lib.load()
         dev = st["workspace"].device
@@ -193,8 +203,9 @@ class _RenderFunction(torch.autograd.Function):
 
 class ObjectComposer(nn.Module):
 
-    #: soft limit for the per-call scratch (MLP feature rows dominate); larger calls are split along
-    #: the ray dimension, which is exact because rays are independent.
+    #: upper limit for the per-call scratch (MLP feature rows dominate); larger calls are split along the ray dimension,
+    #: which is exact because rays are independent.  The effective budget of a call is the smaller of this and 90 % of
+    #: the device memory that is free (or held by this module's own workspace / torch's cache) at call time.
     max_workspace_bytes = 96 << 30
 
     def __init__(self, config):
@@ -210,7 +221,9 @@ class ObjectComposer(nn.Module):
             raise NotImplementedError("apply_activation=True (sigmoid on raw features) is not implemented in the HIP "
                                       "renderer; both shipped configurations use False")
         self.object_id_helper = ObjectIDsHelper(self.config)
-        self._packed: Dict[int, tuple] = {}
+        #: bumped by set_step / load_state_dict / .to(): captured frame graphs compare it (frame_graph.FrameGraph)
+        self.state_epoch = 0
+        self._packed: Dict[tuple, tuple] = {}
         self._annealing: Dict[int, tuple] = {}
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
@@ -219,6 +232,12 @@ class ObjectComposer(nn.Module):
         #: fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant bits) - eval only.
         self.precision = "fp32"
         self._warned_precision_fallback = False
+        #: sigma-gated feature head (PR_FLAG_GATE_HEAD): evaluation renders skip the feature head of samples whose raw density
+        #: is <= 0 - their compositing weight is exactly 0, so the results are bit-identical.  Ignored (by the library) for
+        #: perturbed, training and differentiable calls.
+        self.gate_feature_head = True
+        #: device tensors (K,) per model type: samples that entered the BatchNorm batch statistics of the last training call
+        self.last_normalised_samples: Dict[str, torch.Tensor] = {}
         #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
         #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
         #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
@@ -261,6 +280,27 @@ class ObjectComposer(nn.Module):
         for m in self.object_models_fine:
             if m is not None:
                 m.set_step(current_step)
+        # set_step allocates a fresh buffer tensor every time: its (address, version) cannot identify the step
+        self._annealing.clear()
+        self.state_epoch += 1
+
+    def _drop_device_caches(self):
+        """Everything derived from parameter / buffer storages or tied to a device."""
+        self._packed.clear()
+        self._annealing.clear()
+        self._linspace.clear()
+        self._workspace = None
+        self.state_epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .float(): new storages, possibly at recycled addresses
+        out = super()._apply(fn, *args, **kwargs)
+        self._drop_device_caches()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._drop_device_caches()
+        return out
 
     # ------------------------------------------------------------------ marshalling
     def _model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
@@ -339,8 +379,9 @@ class ObjectComposer(nn.Module):
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
         params = list(model.parameters())
         precision = self._precision_code(differentiable)
-        key = (precision,) + tuple((p.data_ptr(), p._version) for p in params)
-        cached = self._packed.get(id(model))
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        slot = (id(model), precision)   # one buffer per precision: a render at the other precision never evicts this one
+        cached = self._packed.get(slot)
         if cached is not None and cached[0] == key:
             return cached[1]
         lib = _lib.load()
@@ -348,8 +389,20 @@ class ObjectComposer(nn.Module):
         _lib.check(lib.pr_packed_size(C.byref(struct), C.byref(size)), "pr_packed_size")
         buf = torch.empty(size.value, dtype=torch.uint8, device=params[0].device)
         _lib.check(lib.pr_pack_model(C.byref(struct), precision, buf.data_ptr(), size.value, stream), "pr_pack_model")
-        self._packed[id(model)] = (key, buf)
+        self._packed[slot] = (key, buf)
         return buf
+
+    def _workspace_budget(self, dev, need: int) -> int:
+        """Scratch bytes a call may use: ``max_workspace_bytes``, and - when the call needs more than the workspace this
+        module already holds - at most 90 % of what the device can still provide (free memory + torch's cached blocks +
+        the workspace that would be released first)."""
+        cap = int(self.max_workspace_bytes)
+        held = self._workspace.numel() if (self._workspace is not None and self._workspace.device == dev) else 0
+        if need <= min(cap, held):
+            return cap          # fits the workspace that is already allocated: no device query on the hot path
+        free, _ = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return max(1 << 20, min(cap, int(0.9 * (free + cached + held))))
 
     def _linspace_for(self, count: int, device) -> torch.Tensor:
         key = (count, str(device))
@@ -486,16 +539,19 @@ class ObjectComposer(nn.Module):
         lib = _lib.load()
         keep = []  # tensors that must outlive the enqueue
         objs = (_lib.Object * K)()
+        packed_keep = []   # the packed buffers this call reads (kept alive by the autograd state of differentiable calls)
         for k in range(K):
             for attr in ("style_features", "deformation_features"):
                 want = S if attr == "style_features" else D
                 if models_c[k].model_config[attr] != want:
                     raise Exception(f"object {k}: {attr} is {models_c[k].model_config[attr]} but the tensor has {want}")
             objs[k].coarse = self._model_struct(models_c[k], pc[k])
-            objs[k].packed_coarse = self._packed_weights(models_c[k], objs[k].coarse, stream, _save).data_ptr()
+            packed_keep.append(self._packed_weights(models_c[k], objs[k].coarse, stream, _save))
+            objs[k].packed_coarse = packed_keep[-1].data_ptr()
             if use_fine:
                 objs[k].fine = self._model_struct(models_f[k], pc[k] + pf[k])
-                objs[k].packed_fine = self._packed_weights(models_f[k], objs[k].fine, stream, _save).data_ptr()
+                packed_keep.append(self._packed_weights(models_f[k], objs[k].fine, stream, _save))
+                objs[k].packed_fine = packed_keep[-1].data_ptr()
 
         flags = 0
         if perturb:
@@ -512,6 +568,8 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_TRAIN_BN
         if _save:
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
+        if self.gate_feature_head:
+            flags |= _lib.PR_FLAG_GATE_HEAD      # honoured by the library for unperturbed evaluation calls only
 
         # ---- noise -----------------------------------------------------------------------------
         types = ["coarse"] + (["fine"] if use_fine else [])
@@ -590,12 +648,17 @@ class ObjectComposer(nn.Module):
         state = None
         chunk = R
         need = workspace_bytes(build_call(0, R))
-        if _save and need > self.max_workspace_bytes:
+        budget = self._workspace_budget(dev, need)
+        if _save and need > budget:
             raise RuntimeError(f"this differentiable renderer call would keep {need / 2**30:.1f} GiB of activations for its "
-                               f"backward pass (limit {self.max_workspace_bytes / 2**30:.0f} GiB): render under "
+                               f"backward pass (budget {budget / 2**30:.1f} GiB): render under "
                                "torch.no_grad(), or differentiate fewer rays per call (training uses ray patches)")
-        if need > self.max_workspace_bytes and R > 1 and not self.training:  # batch statistics need the whole call
-            chunk = max(1, int(R * self.max_workspace_bytes / need))
+        if need > budget and self.training:
+            raise RuntimeError(f"this training-mode renderer call needs {need / 2**30:.1f} GiB of scratch (budget "
+                               f"{budget / 2**30:.1f} GiB) and cannot be split along the rays: the BatchNorm batch statistics "
+                               "are taken over the whole call.  Use fewer rays per call (training uses ray patches)")
+        if need > budget and R > 1:
+            chunk = max(1, int(R * budget / need))
             chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
         F = models_c[0].nerf_model.output_features
 
@@ -649,6 +712,8 @@ class ObjectComposer(nn.Module):
                         o.sample_slot[k] = ex["slot"][k].data_ptr()
                     ex["evaluated"] = torch.zeros((K,), dtype=torch.int32, device=dev)
                     o.evaluated_samples = ex["evaluated"].data_ptr()
+                    ex["head_evaluated"] = torch.zeros((K,), dtype=torch.int32, device=dev)   # samples through the feature head
+                    o.head_samples = ex["head_evaluated"].data_ptr()
                     res["_samples"] = ex
                 outs[ty] = res
                 structs[ty] = o
@@ -658,10 +723,12 @@ class ObjectComposer(nn.Module):
                        "pr_render_forward")
             pieces.append(outs)
             if _save:
-                state = dict(call=call, objs=objs, keep=keep + [origins, w2o, sty, dfm, present], workspace=workspace,
+                state = dict(call=call, objs=objs, keep=keep + packed_keep + [origins, w2o, sty, dfm, present], workspace=workspace,
                              N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, models_fine=models_f, types=types,
                              ptot=ptot)
 
+        if self.training:
+            self.last_normalised_samples = {ty: pieces[0][ty]["_normalised"] for ty in types}
         if self.training and self.batchnorm_check == "deferred":
             counts = torch.cat([pieces[0][ty]["_normalised"] for ty in types])
             host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)

@@ -38,7 +38,7 @@ for precision in ("fp32", "f16x3"):
         step()
     torch.cuda.synchronize()
     lib.pr_profile_enable(0)
-    ms = (ctypes.c_double * 2)(); ln = (ctypes.c_int32 * 2)()
+    ms = (ctypes.c_double * _lib.PR_PROFILE_CATEGORIES)(); ln = (ctypes.c_int32 * _lib.PR_PROFILE_CATEGORIES)()
     lib.pr_profile_collect(ms, ln)
     print("minecraft kernels:", {n: (round(ms[i] / 5, 3), ln[i] // 5) for i, n in enumerate(("mlp", "composite"))})
     print(f"minecraft 256x256 eval, {precision}: {dt * 1e3:.2f} ms/frame, {65536 / dt / 1e6:.3f} Mrays/s, {1 / dt:.1f} frames/s")

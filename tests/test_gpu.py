@@ -58,6 +58,10 @@ CASES = {
     "minecraft": (lambda: configs.minecraft_config(), lambda: synthetic.minecraft_scene(), 24, 3.0),
     "minecraft_two_frames": (lambda: configs.minecraft_config(), lambda: synthetic.minecraft_scene(batch=2, seed=8), 14, 3.0),
     "tennis_hierarchical": (lambda: configs.tennis_config(hierarchical=(16, 32)), lambda: synthetic.tennis_scene(seed=5), 16, 2.0),
+    # BASELINE.json configs[1] itself: 4 objects x (64 coarse + 128 resampled) positions, the benchmark's scene - 256 / 768
+    # merged entries per ray, i.e. the four-wave compositing kernel with K > 1, the resampler's 64 -> 192 rank merge and
+    # the segmented transmittance scan across objects
+    "tennis_c2_64_128": (lambda: configs.tennis_config(hierarchical=(64, 128)), lambda: synthetic.tennis_scene(seed=1234), 24, 2.0),
     # the skybox ships with one position per ray, which the reference's resampler cannot handle
     # (empty pdf) -> give it 3 coarse + 2 fine positions
     "minecraft_hierarchical": (lambda: configs.reduced_config(configs.enable_fine(configs.minecraft_config()), width=256, layers=8,
@@ -184,10 +188,13 @@ def test_absent_object_contributes_nothing():
     assert float(got["coarse"]["object_2"]["opacity"].abs().max()) == 0.0
 
 
-def test_rays_are_independent_full_size_properties():
-    """Size-independent properties at the benchmark's ray count (256x256): rendering a ray subset
-    reproduces the corresponding slice bit for bit, opacity = sum(weights) <= 1, weights >= 0."""
-    cfg = configs.tennis_config()
+@pytest.mark.parametrize("which", ["shipped", "c2_64_128"])
+def test_rays_are_independent_full_size_properties(which):
+    """Size-independent properties at the benchmark's ray count (256x256), for the shipped tennis configuration and for
+    BASELINE.json configs[1] (64 + 128 hierarchical positions per object, coarse + fine networks): rendering a ray subset
+    reproduces the corresponding slice bit for bit, so does the ray-chunked path; opacity = sum(weights) <= 1,
+    weights >= 0."""
+    cfg = configs.tennis_config() if which == "shipped" else configs.tennis_config(hierarchical=(64, 128))
     comp = build(cfg).cuda()
     scene = synthetic.tennis_scene(seed=1234)
     o, d, n, w2o, sty, dfm, ins = [v.cuda() for v in composer_inputs(cfg, scene)]
@@ -195,19 +202,30 @@ def test_rays_are_independent_full_size_properties():
         full = comp(o, d, n, w2o, sty, dfm, ins, False)
         idx = torch.arange(0, d.size(-2), 97, device="cuda")
         part = comp(o, d[..., idx, :], n, w2o, sty, dfm, ins, False)
-        comp.max_workspace_bytes = 256 << 20   # force the ray-chunked path
+        comp.max_workspace_bytes = (256 << 20) if which == "shipped" else (4 << 30)   # force the ray-chunked path
         chunked = comp(o, d, n, w2o, sty, dfm, ins, False)
-    g, gp, gc = full["coarse"]["global"], part["coarse"]["global"], chunked["coarse"]["global"]
     assert d.size(-2) == 65536
-    for key in ("integrated_features", "opacity", "depth", "weights"):
-        assert torch.equal(torch.nan_to_num(g[key][..., idx, :] if g[key].dim() > 4 else g[key][..., idx]),
-                           torch.nan_to_num(gp[key])), key
-        assert torch.equal(torch.nan_to_num(g[key]), torch.nan_to_num(gc[key])), key
-    w = g["weights"]
-    assert float(w.min()) >= 0.0
-    assert torch.allclose(w.sum(-1), g["opacity"], rtol=1e-5, atol=1e-6)
-    assert float(g["opacity"].max()) <= 1.0 + 1e-5
-    assert torch.isfinite(g["integrated_features"]).all()
+    types = ["coarse"] if which == "shipped" else ["coarse", "fine"]
+    assert [t for t in ("coarse", "fine") if t in full] == types
+    for ty in types:
+        names = ["global"] + ([f"object_{k}" for k in range(4)] if ty == "fine" else [])
+        for name in names:
+            g, gp, gc = full[ty][name], part[ty][name], chunked[ty][name]
+            for key in ("integrated_features", "opacity", "depth", "weights"):
+                assert torch.equal(torch.nan_to_num(g[key][..., idx, :] if g[key].dim() > 4 else g[key][..., idx]),
+                                   torch.nan_to_num(gp[key])), (ty, name, key)
+                assert torch.equal(torch.nan_to_num(g[key]), torch.nan_to_num(gc[key])), (ty, name, key)
+            w = g["weights"]
+            assert float(w.min()) >= 0.0
+            assert torch.allclose(w.sum(-1), g["opacity"], rtol=1e-5, atol=1e-6)
+            assert float(g["opacity"].max()) <= 1.0 + 1e-5
+            assert torch.isfinite(g["integrated_features"]).all()
+    if which == "c2_64_128":
+        assert full["coarse"]["global"]["weights"].shape[-1] == 256 and full["fine"]["global"]["weights"].shape[-1] == 768
+        # the merged fine depths are sorted along the ray, so the weights of the global entry and of the objects carry
+        # the same mass wherever only one object is hit: sum over objects of the per-object opacity >= global opacity
+        per_object = sum(full["fine"][f"object_{k}"]["opacity"] for k in range(4))
+        assert bool((per_object + 1e-5 >= full["fine"]["global"]["opacity"]).all())
 
 
 def test_camera_rays_kernel_is_bit_identical():
@@ -976,3 +994,101 @@ def test_many_samples_per_ray():
     huge = configs.reduced_config(configs.tennis_single_player_config(), positions={"player_1": (8192, 8192)}, **SMALL_NETS)
     with torch.no_grad(), pytest.raises(Exception, match="positions|samples"):
         build(huge).cuda()(*[t.cuda() for t in inputs], False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sigma-gated feature head (PR_FLAG_GATE_HEAD)
+def mixed_sigma(comp, scale=40.0):
+    """Densities of both signs inside every object: the default initialisation gives |sigma| ~ 0.05 with a spread of 3e-3,
+    i.e. one sign per network; scaling the sigma head's weights spreads the values across zero."""
+    with torch.no_grad():
+        for name, p in comp.named_parameters():
+            if name.endswith("alpha_head.weight"):
+                p.mul_(scale)
+            elif name.endswith("alpha_head.bias"):
+                p.zero_()
+    return comp
+
+
+GATE_CASES = {
+    "tennis_hierarchical": (lambda: configs.tennis_config(hierarchical=(16, 32)), lambda: synthetic.tennis_scene(seed=5), 20),
+    "tennis_two_frames": (lambda: configs.tennis_config(), lambda: synthetic.tennis_scene(batch=2, observations=2, seed=3), 14),
+    "minecraft": (lambda: configs.minecraft_config(), lambda: synthetic.minecraft_scene(seed=9), 28),
+    "tennis_c2_64_128": (lambda: configs.tennis_config(hierarchical=(64, 128)), lambda: synthetic.tennis_scene(seed=1234), 16),
+}
+
+
+@pytest.mark.parametrize("name", list(GATE_CASES))
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_sigma_gated_head_is_bit_identical(name, precision):
+    """The gated head (feature head only for samples with density > 0, live rows of different tiles sharing head tiles)
+    against the ungated kernel: EVERY result field bit for bit; against the oracle at the usual tolerance; and the number
+    of rows sent through the head equals the number of evaluated samples with a positive (or NaN) density."""
+    make_cfg, make_scene, n = GATE_CASES[name]
+    cfg, scene = make_cfg(), make_scene()
+    comp = mixed_sigma(build(cfg, alpha_bias=0.0, precision=precision))
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+    comp = comp.cuda()
+    gin = [v.cuda() for v in inputs]
+    with torch.no_grad():
+        comp.gate_feature_head = True
+        gated = comp(*gin, False, _export=True)
+        comp.gate_feature_head = False
+        plain = comp(*gin, False, _export=True)
+        want = ro.composer_forward(cfg, sd, *inputs, False, stable_merge=True)
+    torch.cuda.synchronize()
+    skipped = 0
+    for ty in [t for t in ("coarse", "fine") if t in gated]:
+        for entry in gated[ty]:
+            if entry.startswith("_"):
+                continue
+            for key in ("integrated_features", "opacity", "weights", "depth", "disparity", "integrated_displacements_magnitude"):
+                a, b = gated[ty][entry][key], plain[ty][entry][key]
+                assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) and torch.equal(torch.isnan(a), torch.isnan(b)), (ty, entry, key)
+        ex, ex_plain = gated[ty]["_samples"][0], plain[ty]["_samples"][0]
+        assert torch.equal(ex["evaluated"], ex_plain["evaluated"])
+        assert torch.equal(ex_plain["head_evaluated"], ex_plain["evaluated"])      # no gate: every evaluated sample
+        for k in range(len(ex["sigma"])):
+            sigma, slot = ex["sigma"][k], ex["slot"][k]
+            live = int(((slot >= 0) & ~(sigma <= 0)).sum())
+            assert int(ex["head_evaluated"][k]) == live, (ty, k)
+            skipped += int(ex["evaluated"][k]) - live
+    assert skipped > 0, "the case does not exercise the gate"
+    assert_close(want, gated)
+
+
+def test_sigma_gate_is_ignored_when_noise_is_added():
+    """perturb=True adds noise to the densities before the ReLU: a sample with sigma <= 0 can contribute, the gate must not
+    apply (and the result still matches the oracle)."""
+    cfg, scene = configs.tennis_config(), synthetic.tennis_scene(seed=11)
+    comp = mixed_sigma(build(cfg, alpha_bias=0.0))
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 16))
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+    rec = {}
+    with torch.no_grad():
+        torch.manual_seed(3)
+        want = ro.composer_forward(cfg, sd, *inputs, True, record_noise=rec, stable_merge=True)
+        got = comp.cuda()(*[v.cuda() for v in inputs], True, _noise=rec, _export=True)
+    ex = got["coarse"]["_samples"][0]
+    assert torch.equal(ex["head_evaluated"], ex["evaluated"])
+    assert_close(want, got)
+
+
+def test_sigma_gated_head_full_frame_counts():
+    """Full 256x256 frame of the headline configuration with densities of both signs: thousands of tiles per workgroup,
+    pending stacks that fill and drain many times, the final flush; gated == ungated bit for bit."""
+    cfg = configs.tennis_config(hierarchical=(64, 128))
+    comp = mixed_sigma(build(cfg, alpha_bias=0.0)).cuda()
+    gin = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=1234))]
+    with torch.no_grad():
+        gated = comp(*gin, False, _export=True)
+        comp.gate_feature_head = False
+        plain = comp(*gin, False)
+    for ty in ("coarse", "fine"):
+        for entry in ("global", "object_0", "object_2"):
+            for key in ("integrated_features", "opacity", "depth"):
+                assert torch.equal(torch.nan_to_num(gated[ty][entry][key]), torch.nan_to_num(plain[ty][entry][key])), (ty, entry, key)
+        ex = gated[ty]["_samples"][0]
+        head, ev = ex["head_evaluated"].sum().item(), ex["evaluated"].sum().item()
+        assert 0 < head < ev
