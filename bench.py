@@ -143,7 +143,6 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     if world > 1:
         dist.barrier()
     evaluated.zero_()
-    lib.pr_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
@@ -151,12 +150,18 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, dist if world > 1 else None, dev)
+    counts = [int(v) / steps for v in evaluated.cpu()]
+    # per-kernel HIP-event times from a second, untimed pass (an event pair around each of the ~100 launches of a step
+    # would slow the timed steps down)
+    lib.pr_profile_enable(1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
     lib.pr_profile_enable(0)
     ms, launches = profile_arrays()
     _lib.check(lib.pr_profile_collect(ms, launches), "pr_profile_collect")
-    dt = max_over_ranks(dt, dist if world > 1 else None, dev)
     rays = int(out["coarse"]["global"]["opacity"].numel())
-    counts = [int(v) / steps for v in evaluated.cpu()]
     helper = comp.object_id_helper
     fwd_flops = sum(counts[k] * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
                     for k in range(K))
@@ -506,6 +511,31 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """CPUs this process can actually run on: os.cpu_count() capped by the scheduler affinity and the cgroup CPU quota (a
+    container on a 256-thread host may own far fewer; oversubscribing them with 256 spinning OpenMP threads is pathological)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    n = min(n, max(1, int(int(fields[0]) / int(fields[1]))))
+            else:
+                quota = int(fields[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(quota / int(f.read().split()[0]))))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
 def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     """Everything that runs the ORACLE (test infrastructure) as a yardstick, on rank 0 at N=1 only: the CPU baseline on
     the host cores, the same PyTorch op graph executed by PyTorch-ROCm on this GPU (what north_star's ">= 10x the
@@ -518,12 +548,13 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     n_side = args.cpu_rays
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], n_side))
 
-    # ---- CPU baseline: 16 threads on the n_side^2 subset (the headline figure), 1 thread and all cores on smaller ones
+    # ---- CPU baseline: 16 threads on the n_side^2 subset (the headline figure), 1 thread and all usable cores on smaller ones
     host_cores = os.cpu_count() or 1
+    usable = usable_cores()
     runs = []
     want = None
-    for threads, side in ((max(1, min(args.cpu_threads, host_cores)), n_side), (1, max(8, n_side // 4)),
-                          (host_cores, max(8, n_side // 8))):
+    for threads, side in ((max(1, min(args.cpu_threads, usable)), n_side), (1, max(8, n_side // 4)),
+                          (usable, max(8, n_side // 4))):
         torch.set_num_threads(threads)
         sub = inputs if side == n_side else composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], side))
         with torch.no_grad():
@@ -556,6 +587,8 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
         "extrapolation": "linear in the number of rays (rays are independent; every run renders a uniform pixel grid of the same frame)",
         "cpu_model": cpu_model,
         "host_cores": host_cores,
+        "usable_cores": usable,
+        "usable_cores_note": "min(os.cpu_count(), scheduler affinity, cgroup cpu quota): the 'all cores' run uses this many threads",
         "torch": torch.__version__,
         "gpu_over_cpu": round(gpu_mrays / main_run["value"], 1) if main_run["value"] > 0 else None,
     }

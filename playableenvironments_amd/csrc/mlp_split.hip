@@ -33,7 +33,9 @@ struct SmemH {
     float pos[STILE_M * 8];
     int flat[STILE_M];
     int frame[STILE_M];
-    int flags[STILE_M];
+    int flags[STILE_M];       // bit 0 real sample, bit 1 passed every AABB test, bit 2 density not <= 0 (gated head)
+    int dest[STILE_M];        // gated head: compact feature row of a tile row (-1: none)
+    int src[STILE_M];         // gated head: pending-stack slot a tile row is exchanged with (-1: none)
 };
 static_assert(sizeof(_Float16) * 2 * STILE_M * LDH >= sizeof(float) * STILE_M * LDSTAGE, "staging tile must fit the activation planes");
 static_assert(sizeof(SmemH) * SBLOCKS_PER_CU <= 158 * 1024, "the workgroups of one CU must fit its LDS");
@@ -343,6 +345,121 @@ __device__ __forceinline__ void row_dots_h(const SmemH& S, int s, const float* w
     }
 }
 
+// ---- sigma-gated feature head (see gated_head in mlp.hip; here a pending row is its hi plane followed by its lo plane) ----
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void write_rows_indirect_h(const SmemH& S, const MlpParams& p) {
+    const int tid = threadIdx.x;
+    const float* stage = reinterpret_cast<const float*>(S.Xh);
+    if ((p.F & 3) == 0) {
+        const int f4 = p.F >> 2;
+        for (int idx = tid; idx < STILE_M * f4; idx += STHREADS) {
+            const int row = idx / f4, c = (idx - row * f4) * 4;
+            const int d = S.dest[row];
+            if (d >= 0) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + row * LDSTAGE + c);
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(p.feat + (size_t)d * p.F + c));
+            }
+        }
+    } else {
+        for (int idx = tid; idx < STILE_M * p.F; idx += STHREADS) {
+            const int row = idx / p.F, c = idx - row * p.F;
+            const int d = S.dest[row];
+            if (d >= 0) p.feat[(size_t)d * p.F + c] = stage[row * LDSTAGE + c];
+        }
+    }
+}
+
+__device__ __forceinline__ void head_on_tile_h(SmemH& S, const MlpParams& p, int valid_rows) {
+    for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p, 0);
+    write_rows_indirect_h(S, p);
+    if (threadIdx.x == 0 && p.head_count) atomicAdd(p.head_count, valid_rows);
+    __syncthreads();
+}
+
+// rows [0, rows) x both planes between LDS and a pending stack; slot_of(row) < 0 skips the row
+template <bool TO_LDS, typename SlotOf>
+__device__ __forceinline__ void move_pending_rows(SmemH& S, const MlpParams& p, u32x4_t* stack, int rows, SlotOf slot_of) {
+    const int chunks = p.Wpad >> 3;            // 16-byte chunks per plane row
+    const int per_row = 2 * chunks;
+    for (int idx = threadIdx.x; idx < rows * per_row; idx += STHREADS) {
+        const int row = idx / per_row, rem = idx - row * per_row;
+        const int plane = rem / chunks, c = rem - plane * chunks;
+        const int slot = slot_of(row);
+        if (slot < 0) continue;
+        u32x4_t* lds = reinterpret_cast<u32x4_t*>((plane ? S.Xl : S.Xh) + row * LDH) + c;
+        u32x4_t* glb = stack + (size_t)slot * per_row + plane * chunks + c;
+        if (TO_LDS) *lds = *glb; else *glb = *lds;
+    }
+}
+
+__device__ __forceinline__ int gated_head_h(SmemH& S, const MlpParams& p, int tile_base, int pending) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long live = __ballot((S.flags[lane] & 4) != 0);   // the same value in every wave
+    const int L = __popcll(live);
+    u32x4_t* stack = reinterpret_cast<u32x4_t*>(p.pend_act + (size_t)blockIdx.x * STILE_M * p.Wpad);
+    int* pmeta = p.pend_meta + (size_t)blockIdx.x * STILE_M * 2;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (L == 0) {
+        __syncthreads();
+        return pending;
+    }
+    if (pending + L >= STILE_M) {
+        const int need = STILE_M - L;
+        if (tid == 0) S.uniform_frame = 1;
+        if (tid < STILE_M) {
+            if ((live >> tid) & 1ull) {
+                S.dest[tid] = tile_base + tid;
+                S.src[tid] = -1;
+            } else {
+                const int slot = pending - need + __popcll(~live & below);
+                S.src[tid] = slot;
+                S.dest[tid] = pmeta[2 * slot];
+                S.frame[tid] = pmeta[2 * slot + 1];
+            }
+        }
+        __syncthreads();
+        if (need) move_pending_rows<true>(S, p, stack, STILE_M, [&](int row) { return S.src[row]; });
+        if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        __syncthreads();
+        head_on_tile_h(S, p, STILE_M);
+        return pending - need;
+    }
+    if (tid < STILE_M) {
+        int slot = -1;
+        if ((live >> tid) & 1ull) {
+            slot = pending + __popcll(live & below);
+            pmeta[2 * slot] = tile_base + tid;
+            pmeta[2 * slot + 1] = S.frame[tid];
+        }
+        S.src[tid] = slot;
+    }
+    __syncthreads();
+    move_pending_rows<false>(S, p, stack, STILE_M, [&](int row) { return S.src[row]; });
+    __syncthreads();
+    return pending + L;
+}
+
+__device__ __forceinline__ void gated_head_flush_h(SmemH& S, const MlpParams& p, int pending) {
+    if (pending <= 0) return;
+    const int tid = threadIdx.x;
+    u32x4_t* stack = reinterpret_cast<u32x4_t*>(p.pend_act + (size_t)blockIdx.x * STILE_M * p.Wpad);
+    const int* pmeta = p.pend_meta + (size_t)blockIdx.x * STILE_M * 2;
+    if (tid == 0) S.uniform_frame = 1;
+    if (tid < STILE_M) {
+        const bool has = tid < pending;
+        S.dest[tid] = has ? pmeta[2 * tid] : -1;
+        S.frame[tid] = pmeta[2 * (has ? tid : 0) + 1];
+    }
+    __syncthreads();
+    move_pending_rows<true>(S, p, stack, pending, [&](int row) { return row; });
+    if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+    __syncthreads();
+    head_on_tile_h(S, p, pending);
+}
+
 __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
@@ -350,6 +467,7 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
     const int total = *p.total;
     for (int i = tid; i <= p.Wpad; i += STHREADS) S.head_w[i] = p.sigma_w[i];
     __syncthreads();
+    int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head)
     for (int tile = blockIdx.x; tile * STILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * STILE_M;
         PR_PHASE_T0();
@@ -425,13 +543,26 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
             for (int s = tid >> 3; s < STILE_M; s += STHREADS / 8) {
                 float sg;
                 row_dots_h(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
-                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) p.sigma[S.flat[s]] = sg + S.head_w[p.Wpad];
+                if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) {
+                    const float sv = sg + S.head_w[p.Wpad];
+                    p.sigma[S.flat[s]] = sv;
+                    if (!(sv <= 0.f)) S.flags[s] |= 4;
+                }
             }
         } else if (tid < STILE_M) {
-            if (S.flags[tid] & 1) p.sigma[S.flat[tid]] = 10.0f;
+            if (S.flags[tid] & 1) {
+                p.sigma[S.flat[tid]] = 10.0f;
+                S.flags[tid] |= 4;
+            }
         }
 
         PR_PHASE(7);
+        if (p.gate) {
+            __syncthreads();   // the liveness bits are complete
+            pending = gated_head_h(S, p, tile_base, pending);
+            PR_PHASE(8);
+            continue;
+        }
         for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p, 0);
         PR_PHASE(15);
 
@@ -463,6 +594,7 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
         __syncthreads();
         PR_PHASE(8);
     }
+    if (p.gate) gated_head_flush_h(S, p, pending);
 }
 
 int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
@@ -470,8 +602,10 @@ int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
     const int max_tiles = (max_rows + STILE_M - 1) / STILE_M;
     int cu_count = 0;
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_split), (int)sizeof(SmemH), &cu_count));
-    const int resident = cu_count * SBLOCKS_PER_CU;
+    int resident = cu_count * SBLOCKS_PER_CU;
+    if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;   // the pending stacks of the gated head are sized for this
     const int grid = max_tiles < resident ? max_tiles : resident;
+    PR_REQUIRE(!p.gate || (p.pend_act && p.pend_meta), "gated head: pending buffers missing");
     ProfileScope scope(0, s);
     hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();

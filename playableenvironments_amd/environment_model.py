@@ -8,8 +8,14 @@ the playable model that drive the reference through these entry points can drive
 
 Everything between "scene encoding" and "composer result" runs on the GPU: rays come from the
 ``pr_camera_rays`` kernel, the composer is the HIP renderer; the few per-(frame, object) 4x4
-matrices and box projections are tiny PyTorch-ROCm ops.  The observation-driven modes need the
-CNN encoders, which are out of scope for this package: they raise.
+matrices and box projections are tiny PyTorch-ROCm ops.
+
+The observation-driven modes (``forward_from_observations`` :847-1039, ``render_full_frame_from_observations``
+:581-616, ``forward_scene_encoding_from_observations`` :772-845, ``forward_pose_consistency`` :1197-1361,
+``forward_keypoint_consistency`` :1363-1505) are the same orchestration around the renderer plus the reference's CNN
+object encoders / pose estimators, which stay stock PyTorch modules and are out of scope for this package (SURVEY.md
+section 8): they are INJECTED - ``EnvironmentModel(config, object_encoders=..., object_parameters_encoders=...)`` or
+``set_encoders`` - with the call contracts of the reference's modules (documented at ``set_encoders``).
 """
 from __future__ import annotations
 
@@ -130,14 +136,21 @@ def camera_rays_at_positions(c2w: torch.Tensor, focals: torch.Tensor, height: in
 
 class EnvironmentModel(nn.Module):
 
-    def __init__(self, config):
+    def __init__(self, config, object_encoders=None, object_parameters_encoders=None):
         super().__init__()
         self.config = config
         self.focal_length_multiplier = config["data"]["focal_length_multiplier"]
         self.use_weighted_sampling = config["model"].get("use_weighted_sampling", False)
         self.sampling_weights = config["model"].get("sampling_weights", None)
+        self.enable_camera_parameters_offsets = config["model"].get("enable_camera_parameters_offsets", False)
+        self.use_image_decoder = "image_decoder" in config["model"]
         self.object_composer = ObjectComposer(config)
         self.object_id_helper = ObjectIDsHelper(config)
+        # the reference's attribute names (environment_model.py:44-50); empty until encoders are injected
+        self.object_parameters_encoders = nn.ModuleList()
+        self.object_encoders = nn.ModuleList()
+        if object_encoders is not None or object_parameters_encoders is not None:
+            self.set_encoders(object_encoders, object_parameters_encoders)
         self.current_step = 0
         # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
         self._pixel_cache: Dict = {}
@@ -148,14 +161,52 @@ class EnvironmentModel(nn.Module):
         self.current_step = current_step
         self.object_composer.set_step(current_step)
 
+    def set_encoders(self, object_encoders=None, object_parameters_encoders=None):
+        """Injects the (stock PyTorch) modules that turn observations into the renderer's inputs; one per OBJECT MODEL, in
+        the order of ``config["model"]["object_models"]``, with the call contracts of the reference's modules:
+
+        * ``object_encoders[m](observations, bounding_box (..., O, C, 4), camera_rotations, camera_translations,
+          global_frame_indexes, video_frame_indexes, video_indexes) -> (style (..., O, S), deformation (..., O, D),
+          attention, crops)``  (model/object_encoder_v4.py:80-178; environment_model.py:449-450);
+        * ``object_parameters_encoders[m]``: static models ``(observations) -> (rotations (..., O, 3, n_m), translations
+          (..., O, 3, n_m))``; dynamic models ``(observations, transformation_matrix_w2c, camera_rotations, focals,
+          bounding_boxes (..., O, C, 4, n_m), bounding_boxes_validity (..., O, C, n_m)) -> (rotations, translations)``
+          (model/classic_object_parameters_encoder.py:129-237; environment_model.py:178-191)."""
+        if object_encoders is not None:
+            self.object_encoders = nn.ModuleList(list(object_encoders))
+        if object_parameters_encoders is not None:
+            self.object_parameters_encoders = nn.ModuleList(list(object_parameters_encoders))
+        return self
+
+    def _require_encoders(self):
+        want = self.object_id_helper.object_models_count
+        if len(self.object_encoders) != want or len(self.object_parameters_encoders) != want:
+            raise RuntimeError(
+                f"the observation-driven modes need one object encoder and one object-parameters encoder per object model "
+                f"({want}); this package does not contain the reference's CNN encoders - inject them with "
+                "EnvironmentModel(config, object_encoders=..., object_parameters_encoders=...) or set_encoders(...), or "
+                "encode the scene elsewhere and call mode='scene_encodings'")
+
+    def _corrected_cameras(self, camera_rotations, camera_translations, focals, global_frame_indexes):
+        if self.enable_camera_parameters_offsets:
+            raise NotImplementedError("learnable per-frame camera offsets (enable_camera_parameters_offsets, "
+                                      "model/layers/camera_parameters_storage.py) are disabled in both shipped configurations "
+                                      "and are not part of this package")
+        return camera_rotations, camera_translations, focals
+
     # ------------------------------------------------------------------ modes
     def forward(self, *args, mode="observations", **kwargs):
+        """model/environment_model.py:743-770."""
+        if mode == "observations":
+            return self.forward_from_observations(*args, **kwargs)
         if mode == "scene_encodings":
             return self.forward_from_scene_encoding(*args, **kwargs)
-        if mode in ("observations", "observations_scene_encoding_only", "pose_consistency", "keypoint_consistency"):
-            raise NotImplementedError(
-                f"forward mode '{mode}' needs the CNN object encoders of the reference, which this renderer package "
-                "does not contain; encode the scene with the reference model and call mode='scene_encodings'")
+        if mode == "observations_scene_encoding_only":
+            return self.forward_scene_encoding_from_observations(*args, **kwargs)
+        if mode == "pose_consistency":
+            return self.forward_pose_consistency(*args, **kwargs)
+        if mode == "keypoint_consistency":
+            return self.forward_keypoint_consistency(*args, **kwargs)
         raise Exception(f"Unknown forward mode '{mode}'")
 
     # ------------------------------------------------------------------ tiny per-(frame, object) math
@@ -380,6 +431,317 @@ class EnvironmentModel(nn.Module):
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
         return self.fold_dictionary(flat, height, width)
+
+    # ------------------------------------------------------------------ observation-driven modes (injected encoders)
+    def compute_rotation_translation_o2w(self, observations, transformation_matrix_w2c, camera_rotations, focals,
+                                         bounding_boxes, bounding_boxes_validity):
+        """Object poses from the injected object-parameters encoders, concatenated along the object dimension
+        (model/environment_model.py:161-204; here the camera argument is the w2c MATRIX (..., C, 4, 4), not a
+        PoseParameters object)."""
+        rotations, translations = [], []
+        helper = self.object_id_helper
+        for m in range(helper.object_models_count):
+            encoder = self.object_parameters_encoders[m]
+            if helper.is_static(m):
+                r, t = encoder(observations)
+            else:
+                b, e = helper.dynamic_object_idx_range_by_model_idx(m)
+                r, t = encoder(observations, transformation_matrix_w2c, camera_rotations, focals, bounding_boxes[..., b:e],
+                               bounding_boxes_validity[..., b:e])
+            rotations.append(r)
+            translations.append(t)
+        return torch.cat(rotations, dim=-1), torch.cat(translations, dim=-1)
+
+    def compute_object_encodings(self, observations, camera_rotations, camera_translations, bounding_boxes,
+                                 reconstructed_bounding_boxes, global_frame_indexes, video_frame_indexes, video_indexes,
+                                 shuffle_style: bool):
+        """Style / deformation codes of every object instance from the injected object encoders: static objects are
+        cropped with their reconstructed box, dynamic ones with the annotated box; ``shuffle_style`` permutes the style codes
+        along the observations dimension with a permutation that is not the identity (environment_model.py:406-472)."""
+        video_indexes = video_indexes.unsqueeze(-1)
+        video_indexes, _ = torch.broadcast_tensors(video_indexes, video_frame_indexes)
+        helper = self.object_id_helper
+        style, deformation, attention, crops = [], [], [], []
+        for k in range(helper.objects_count):
+            m = helper.model_idx_by_object_idx(k)
+            box = reconstructed_bounding_boxes[..., k] if helper.is_static(m) else \
+                bounding_boxes[..., helper.dynamic_object_idx_by_object_idx(k)]
+            s, d, a, c = self.object_encoders[m](observations, box, camera_rotations, camera_translations, global_frame_indexes,
+                                                 video_frame_indexes, video_indexes)
+            if shuffle_style:
+                count = s.size(-2)
+                identity = torch.arange(count, device=observations.device, dtype=torch.int64)
+                while True:
+                    permutation = torch.randperm(count, device=observations.device)
+                    if not torch.all(identity == permutation):
+                        break
+                s = s[..., permutation, :]
+            style.append(s)
+            deformation.append(d)
+            attention.append(a)
+            crops.append(c)
+        return torch.stack(style, dim=-1), torch.stack(deformation, dim=-1), attention, crops
+
+    def _object_in_scene(self, bounding_boxes_validity: torch.Tensor, quirk: bool) -> torch.Tensor:
+        """(..., O, 1, n) presence flags, static objects first (always present), dynamic objects present when some
+        camera detects them.  ``quirk``: forward_from_observations builds the static block TWICE over
+        (environment_model.py:990-992: an already static_count-wide block is repeated static_count times), so its tensor has
+        static_count^2 + dynamic_count entries; the composer reads the first K, i.e. with two static objects the dynamic
+        objects' flags are never seen (they read as present).  Reproduced, because it decides what the trainers render."""
+        helper = self.object_id_helper
+        ones = torch.ones_like(bounding_boxes_validity[..., 0:1], dtype=torch.bool)
+        static = torch.cat([ones] * helper.static_objects_count, dim=-1)
+        blocks = [static] * helper.static_objects_count if quirk else [static]
+        present = torch.cat(blocks + [bounding_boxes_validity], dim=-1)
+        return present.max(dim=-2, keepdim=True)[0]
+
+    def forward_scene_encoding_from_observations(self, observations, camera_rotations, camera_translations, focals,
+                                                 bounding_boxes, bounding_boxes_validity, global_frame_indexes,
+                                                 video_frame_indexes, video_indexes, shuffle_style: bool = False) -> Dict:
+        """Scene encoding only (mode="observations_scene_encoding_only"; environment_model.py:772-845)."""
+        self._require_encoders()
+        camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
+                                                                                global_frame_indexes)
+        rescaled_focals = focals * self.focal_length_multiplier
+        height, width = observations.size(-2), observations.size(-1)
+        c2w = euler_to_matrix(camera_rotations, camera_translations)
+        w2c = rigid_inverse(c2w)
+        rot, tr = self.compute_rotation_translation_o2w(observations, w2c.detach(), camera_rotations, rescaled_focals.detach(),
+                                                        bounding_boxes, bounding_boxes_validity)
+        _, o2w = self.compute_transformation_matrix_w2o_o2w(rot, tr)
+        boxes, _ = self.compute_object_bounding_boxes(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
+        style, deformation, _, _ = self.compute_object_encodings(observations, camera_rotations, camera_translations,
+                                                                 bounding_boxes, boxes, global_frame_indexes,
+                                                                 video_frame_indexes, video_indexes, shuffle_style)
+        present = self._object_in_scene(bounding_boxes_validity, quirk=False)
+        return {"camera_rotations": camera_rotations, "camera_translations": camera_translations, "focals": focals,
+                "object_rotation_parameters": rot, "object_translation_parameters": tr, "object_style": style,
+                "object_deformation": deformation, "object_in_scene": present[..., 0, :]}
+
+    def _select_pixels(self, boxes, lead, height, width, samples_per_image, patch_size, patch_stride, device):
+        """The four pixel-selection branches of the reference (environment_model.py:949-958): flat pixel indices (..., R)
+        per frame, or a shared (R,) list for the static selections."""
+        flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
+        if patch_size != 0 and samples_per_image != 0:
+            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
+            return idx.reshape(lead + [-1])
+        if samples_per_image == 0:
+            strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)
+            key = ("flat", height, width, strides if patch_stride else None, str(device))
+            if key not in self._pixel_cache:
+                if patch_stride:
+                    rows, cols = strided_grid_pixels(height, width, patch_stride)
+                    idx = rows.to(torch.int64) * width + cols.to(torch.int64)
+                else:
+                    idx = torch.arange(height * width, dtype=torch.int64)
+                self._pixel_cache[key] = idx.to(device)
+            return self._pixel_cache[key]
+        if self.use_weighted_sampling:
+            return ray_sampling.sample_pixels_weighted(flat_boxes, self.sampling_weights, height, width,
+                                                       samples_per_image).reshape(lead + [-1])
+        return ray_sampling.sample_pixels_uniform(flat_boxes.size(0), height, width, samples_per_image, device).reshape(lead + [-1])
+
+    def forward_from_observations(self, observations, camera_rotations, camera_translations, focals, bounding_boxes,
+                                  bounding_boxes_validity, global_frame_indexes, video_frame_indexes, video_indexes,
+                                  samples_per_image: int, perturb: bool, samples_per_image_batching: int = 0,
+                                  shuffle_style: bool = False, upsample_factor: float = 1.0, patch_size: int = 0,
+                                  patch_stride: int = 0, align_grid: bool = True, canonical_pose: bool = False) -> Dict:
+        """model/environment_model.py:847-1039; argument shapes documented there.  observations (..., O, C, 3, H, W);
+        camera_* (..., O, C, 3); focals (..., O, C); bounding_boxes (..., O, C, 4, dynamic objects);
+        bounding_boxes_validity (..., O, C, dynamic objects); *_indexes (bs, O) / (bs).
+
+        What the trainers call (training/trainer.py).  Poses, style and deformation come from the injected encoders; the
+        span between them and the result dictionary - camera rays, box projection, pixel selection with the ground-truth
+        pixels gathered alongside, ray-object distances, the composer - is this package's (HIP renderer; batched,
+        synchronisation-free host math).  Differences from the reference, all in what it accepts: ``align_grid=False``
+        raises (the patch sampler of this package implements the aligned variant every shipped configuration uses), so do
+        the disabled-by-default camera offsets and the optional image decoder."""
+        self._require_encoders()
+        if patch_size != 0 and samples_per_image != 0 and not align_grid:
+            raise NotImplementedError("sample_rays_strided_patch(align_grid=False) is not implemented; every caller of the "
+                                      "reference passes align_grid=True")
+        if self.use_image_decoder:
+            raise NotImplementedError("config['model']['image_decoder'] (compute_decoded_image, environment_model.py:708-741) "
+                                      "is not part of this package")
+        camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
+                                                                                global_frame_indexes)
+        rescaled_focals = focals * self.focal_length_multiplier
+        if upsample_factor != 1.0:
+            h, w = observations.size(-2), observations.size(-1)
+            flat = observations.reshape([-1] + list(observations.shape[-3:]))
+            flat = torch.nn.functional.interpolate(flat, (int(h * upsample_factor), int(w * upsample_factor)), mode="bilinear")
+            observations = flat.reshape(list(observations.shape[:-3]) + list(flat.shape[-3:]))
+        height, width = observations.size(-2), observations.size(-1)
+        lead = list(observations.shape[:-3])
+
+        c2w = euler_to_matrix(camera_rotations, camera_translations)
+        w2c = rigid_inverse(c2w)
+        render_focals = rescaled_focals * upsample_factor
+        rot, tr = self.compute_rotation_translation_o2w(observations, w2c.detach(), camera_rotations, render_focals.detach(),
+                                                        bounding_boxes, bounding_boxes_validity)
+        w2o, o2w = self.compute_transformation_matrix_w2o_o2w(rot, tr)
+        boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c.detach(), render_focals.detach(), height, width)
+        axes = self.compute_object_axes_projection(o2w, w2c.detach(), render_focals.detach(), height, width)
+
+        # pixel selection; the ground-truth pixels and the normalised positions are gathered with the same indices
+        idx = self._select_pixels(boxes, lead, height, width, samples_per_image, patch_size, patch_stride, observations.device)
+        rows, cols = ray_sampling.split_indices(idx, width)
+        hwc = observations.movedim(-3, -1).reshape(lead + [height * width, observations.size(-3)])
+        full = idx if idx.dim() > 1 else idx.expand(lead + [idx.numel()])
+        sampled_observations = torch.gather(hwc, -2, full.unsqueeze(-1).expand(list(full.shape) + [hwc.size(-1)]))
+        sampled_positions = ray_sampling.positions_from_indices(full, height, width)
+
+        origins, directions, normals = camera_rays(c2w, render_focals, height, width, rows, cols)
+        style, deformation, attention, crops = self.compute_object_encodings(observations, camera_rotations, camera_translations,
+                                                                             bounding_boxes, boxes, global_frame_indexes,
+                                                                             video_frame_indexes, video_indexes, shuffle_style)
+        distances = self.compute_ray_object_distances(origins, directions, o2w[..., 0, :, :, :])
+        present = self._object_in_scene(bounding_boxes_validity, quirk=True)
+        expanded_video_indexes, _ = torch.broadcast_tensors(video_indexes.unsqueeze(-1).unsqueeze(-1), origins[..., 0])
+        results = self.batchified_composer_call(origins, directions, normals, w2o, style.unsqueeze(-3), deformation.unsqueeze(-3),
+                                                present, perturb, samples_per_image_batching, expanded_video_indexes,
+                                                canonical_pose=canonical_pose)
+        results["observations"] = sampled_observations
+        results["positions"] = sampled_positions
+        results["object_rotation_parameters"] = rot
+        results["object_translation_parameters"] = tr
+        results["ray_object_distances"] = distances
+        results["reconstructed_bounding_boxes"] = boxes
+        results["reconstructed_3d_bounding_boxes"] = box_points
+        results["projected_axes"] = axes
+        results["object_attention"] = attention
+        results["object_crops"] = crops
+        results["scene_encoding"] = {
+            "camera_rotations": camera_rotations, "camera_translations": camera_translations, "focals": focals,
+            "object_rotation_parameters": rot, "object_translation_parameters": tr, "object_style": style,
+            "object_deformation": deformation, "object_in_scene": present[..., 0, :],
+        }
+        return results
+
+    def render_full_frame_from_observations(self, observations, camera_rotations, camera_translations, focals,
+                                            bounding_boxes, bounding_boxes_validity, global_frame_indexes, video_frame_indexes,
+                                            video_indexes, perturb: bool, samples_per_image_batching: int = 1000,
+                                            upsample_factor: float = 1.0, canonical_pose: bool = False) -> Dict:
+        """Every pixel of the frames, folded back to (height, width).  model/environment_model.py:581-616."""
+        flat = self(observations, camera_rotations, camera_translations, focals, bounding_boxes, bounding_boxes_validity,
+                    global_frame_indexes, video_frame_indexes, video_indexes, 0, perturb, samples_per_image_batching,
+                    upsample_factor=upsample_factor, canonical_pose=canonical_pose)
+        height = int(observations.size(-2) * upsample_factor)
+        width = int(observations.size(-1) * upsample_factor)
+        return self.fold_dictionary(flat, height, width)
+
+    # ------------------------------------------------------------------ pose / keypoint consistency (expected positions)
+    @staticmethod
+    def merge_expected_position_results(expected_position_results: List[Dict]) -> Dict:
+        """environment_model.py:1160-1176: {key: [results of call 0, results of call 1, ...]}."""
+        return {key: [r[key] for r in expected_position_results] for key in expected_position_results[0].keys()}
+
+    @staticmethod
+    def invert_expected_position_results(all_expected_position_results: List[Dict]) -> Dict:
+        """environment_model.py:1178-1195: {model type: {"dynamic_object_i": results}}."""
+        inverted = {key: {} for key in all_expected_position_results[0].keys()}
+        for i, current in enumerate(all_expected_position_results):
+            for key in current:
+                inverted[key][f"dynamic_object_{i}"] = current[key]
+        return inverted
+
+    @staticmethod
+    def camera_direction_grid(focals: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        """Camera-frame pinhole directions (..., H, W, 3) = ((col - W/2) / f, -(row - H/2) / f, -1) of every pixel
+        (RayHelper.create_camera_rays, ray_helper.py:15-52) - the grid the consistency samplers look up."""
+        f = focals.unsqueeze(-1).unsqueeze(-1)
+        rows, cols = torch.meshgrid(torch.arange(0, height, device=focals.device), torch.arange(0, width, device=focals.device),
+                                    indexing="ij")
+        dx = (cols - width / 2) / f
+        dy = -(rows - height / 2) / f
+        return torch.stack([dx, dy, -torch.ones_like(dx)], dim=-1)
+
+    @staticmethod
+    def _world_rays(c2w: torch.Tensor, camera_directions: torch.Tensor):
+        """Camera-frame sample directions (..., n, 3) -> world origins (..., 3), directions (..., n, 3), focal normals
+        (..., 3) (RayHelper.transform_rays of origin 0 / normal (0, 0, -1), ray_helper.py:1203-1227)."""
+        rot = c2w[..., :3, :3]
+        directions = torch.sum(camera_directions.unsqueeze(-2) * rot.unsqueeze(-3), -1)
+        return c2w[..., :3, 3], directions, -rot[..., :, 2]
+
+    def forward_pose_consistency(self, optical_flow, camera_rotations, camera_translations, focals, bounding_boxes,
+                                 bounding_boxes_validity, global_frame_indexes, video_frame_indexes, video_indexes, object_style,
+                                 object_deformation, object_rotation_parameters_o2w, object_translation_parameters_o2w,
+                                 samples_per_image: int, perturb: bool) -> Dict:
+        """model/environment_model.py:1197-1361: for every dynamic object, pixels sampled inside its box in frame t, their
+        optical-flow targets in frame t + 1, and the expected surface position (object frame) the renderer finds along
+        both rays - ``{type: {"dynamic_object_i": [(positions, opacity) of frame t, (positions, opacity) of frame t+1]}}``.
+        optical_flow (..., O, C, 2, H, W) normalised, (row, col) channels; the other arguments as in the reference."""
+        camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
+                                                                                global_frame_indexes)
+        rescaled_focals = focals * self.focal_length_multiplier
+        height, width = optical_flow.size(-2), optical_flow.size(-1)
+        object_style = object_style.unsqueeze(-3)
+        object_deformation = object_deformation.unsqueeze(-3)
+        if video_indexes is not None:
+            video_indexes = video_indexes.unsqueeze(-1).unsqueeze(-1)
+        grid = self.camera_direction_grid(rescaled_focals, height, width)                      # (..., O, C, H, W, 3)
+        c2w = euler_to_matrix(camera_rotations, camera_translations)                           # (..., O, C, 4, 4)
+        w2o, _ = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w, object_translation_parameters_o2w)
+        helper = self.object_id_helper
+        all_results = []
+        for dyn in range(helper.dynamic_objects_count):
+            k = helper.object_idx_by_dynamic_object_idx(dyn)
+            box, valid = bounding_boxes[..., dyn], bounding_boxes_validity[..., dyn]
+            m, sty, dfm = w2o[..., k], object_style[..., k], object_deformation[..., k]
+            prev_dirs, prev_flow, prev_pos = ray_sampling.sample_rays_at_object(grid[..., :-1, :, :, :, :], optical_flow[..., :-1, :, :, :, :],
+                                                                               samples_per_image, box[..., :-1, :, :])
+            next_pos = prev_flow + prev_pos
+            # the optical flow comes from an unknown higher resolution: no range correction (environment_model.py:1316)
+            next_dirs = ray_sampling.sample_rays_at(grid[..., 1:, :, :, :, :], next_pos, correct_range=False)
+            po, pd, pn = self._world_rays(c2w[..., :-1, :, :, :], prev_dirs)
+            no, nd, nn_ = self._world_rays(c2w[..., 1:, :, :, :], next_dirs)
+            previous = self.object_composer.forward_expected_positions(po, pd, pn, m[..., :-1, :, :, :], sty[..., :-1, :, :],
+                                                                       dfm[..., :-1, :, :], object_in_scene=valid[..., :-1, :],
+                                                                       object_id=k, perturb=perturb, video_indexes=video_indexes)
+            following = self.object_composer.forward_expected_positions(no, nd, nn_, m[..., 1:, :, :, :], sty[..., 1:, :, :],
+                                                                        dfm[..., 1:, :, :], object_in_scene=valid[..., 1:, :],
+                                                                        object_id=k, perturb=perturb, video_indexes=video_indexes)
+            all_results.append(self.merge_expected_position_results([previous, following]))
+        results = self.invert_expected_position_results(all_results)
+        results["pytorch_backward_hook"] = results["coarse"]["dynamic_object_0"][0]
+        return results
+
+    def forward_keypoint_consistency(self, observations, camera_rotations, camera_translations, focals, bounding_boxes,
+                                     bounding_boxes_validity, global_frame_indexes, video_frame_indexes, video_indexes,
+                                     object_style, object_deformation, object_rotation_parameters_o2w,
+                                     object_translation_parameters_o2w, keypoints, keypoints_validity, max_samples_per_image: int,
+                                     perturb: bool) -> Dict:
+        """model/environment_model.py:1363-1505: for every dynamic object, rays through random points of its COCO skeleton
+        segments -> ``{type: {"dynamic_object_i": (expected positions, keypoint confidences, opacity, sampled positions)}}``.
+        keypoints (..., O, C, 17, 3, dynamic objects) as (row, col, confidence) in [0, 1]."""
+        camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
+                                                                                global_frame_indexes)
+        rescaled_focals = focals * self.focal_length_multiplier
+        height, width = observations.size(-2), observations.size(-1)
+        object_style = object_style.unsqueeze(-3)
+        object_deformation = object_deformation.unsqueeze(-3)
+        if video_indexes is not None:
+            video_indexes = video_indexes.unsqueeze(-1).unsqueeze(-1)
+        grid = self.camera_direction_grid(rescaled_focals, height, width)
+        c2w = euler_to_matrix(camera_rotations, camera_translations)
+        w2o, _ = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w, object_translation_parameters_o2w)
+        helper = self.object_id_helper
+        all_results = []
+        for dyn in range(helper.dynamic_objects_count):
+            k = helper.object_idx_by_dynamic_object_idx(dyn)
+            dirs, positions, confidences = ray_sampling.sample_rays_at_keypoints(grid, keypoints[..., dyn], max_samples_per_image)
+            o, d, n = self._world_rays(c2w, dirs)
+            expected = self.object_composer.forward_expected_positions(o, d, n, w2o[..., k], object_style[..., k],
+                                                                       object_deformation[..., k],
+                                                                       object_in_scene=bounding_boxes_validity[..., dyn], object_id=k,
+                                                                       perturb=perturb, video_indexes=video_indexes)
+            for key in list(expected):
+                expected[key] = (expected[key][0], confidences, expected[key][1], positions)
+            all_results.append(expected)
+        results = self.invert_expected_position_results(all_results)
+        results["pytorch_backward_hook"] = results["coarse"]["dynamic_object_0"][0]
+        return results
 
     # ------------------------------------------------------------------ multi-GPU: one render shared by all ranks
     def render_sharded(self, camera_rotations, camera_translations, focals, image_size, object_rotation_parameters_o2w,

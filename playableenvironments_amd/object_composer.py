@@ -69,6 +69,13 @@ class ObjectIDsHelper:
             raise Exception(f"The provided object id {object_idx} does not correspond to a dynamic object")
         return object_idx - self.static_objects_count
 
+    def dynamic_object_idx_range_by_model_idx(self, model_idx: int):
+        """[begin, end) of the dynamic-object ids a dynamic model owns (object_ids_helper.py:137-153)."""
+        if not self.is_dynamic(model_idx):
+            raise Exception(f"Model id {model_idx} does not refer to a dynamic object")
+        first = self.dynamic_object_idx_by_object_idx(self.first_object_idx_by_model_idx_map[model_idx])
+        return first, first + self.objects_count_by_model_idx(model_idx)
+
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
@@ -504,6 +511,10 @@ class ObjectComposer(nn.Module):
         D = deformation.size(-2)
         sty = torch.broadcast_to(style.detach().to(torch.float32), lead + [S, K]).reshape(N, S, K).permute(0, 2, 1).contiguous()
         dfm = torch.broadcast_to(deformation.detach().to(torch.float32), lead + [D, K]).reshape(N, D, K).permute(0, 2, 1).contiguous()
+        if _object_ids is None and object_in_scene.size(-1) > K:
+            # the reference indexes object_in_scene[..., object_idx] (object_composer.py:823-830): entries beyond the K
+            # objects are never read (forward_from_observations hands over such a tensor, environment_model.py:990-992)
+            object_in_scene = object_in_scene[..., :K]
         present = torch.broadcast_to(object_in_scene, lead + [K]).reshape(N, K).to(torch.uint8).contiguous()
 
         models_c = [self.object_models_coarse[helper.model_idx_by_object_idx(k)] for k in ids]

@@ -45,3 +45,109 @@ def compare_results(want, got, rtol, atol, path="", out=None):
         ok = nan_ok and torch.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
         out[path + k] = (diff, ok)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stand-in encoders for the observation-driven modes (EnvironmentModel.forward_from_observations needs one object encoder
+# and one object-parameters encoder per object model; the reference's are CNNs with roi_pool crops, out of scope).  Small
+# deterministic, differentiable torch modules with the call contracts of the reference's modules, so that the reference
+# itself (build container) and this package (GPU box) can run the same scene.
+class StandInObjectEncoder(torch.nn.Module):
+    """Contract of ObjectEncoderV4.forward (model/object_encoder_v4.py:80-178): (observations (..., O, C, 3, H, W),
+    bounding_box (..., O, C, 4), camera_rotations, camera_translations, global_frame_indexes, video_frame_indexes,
+    video_indexes) -> (style (..., O, S), deformation (..., O, D), attention, crops)."""
+
+    def __init__(self, style_features: int, deformation_features: int, seed: int):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.to_style = torch.nn.Parameter(torch.randn(7, style_features, generator=g))
+        self.to_deformation = torch.nn.Parameter(torch.randn(7, deformation_features, generator=g))
+
+    def forward(self, observations, bounding_box, camera_rotations, camera_translations, global_frame_indexes,
+                video_frame_indexes, video_indexes):
+        colour = observations[..., 0, :, :, :].mean(dim=(-1, -2))                      # first camera, (..., O, 3)
+        code = torch.cat([colour, bounding_box[..., 0, :]], dim=-1)                    # (..., O, 7)
+        style = torch.tanh(code @ self.to_style)
+        deformation = torch.tanh(code @ self.to_deformation)
+        attention = torch.zeros(list(code.shape[:-1]) + [1, 1, 2, 2], device=code.device)
+        crops = observations[..., 0:1, :, :4, :4]
+        return style, deformation, attention, crops
+
+
+class StandInStaticParameters(torch.nn.Module):
+    """Static object models sit at the world origin (model/static_object_parameters_encoder.py): (observations) ->
+    rotations, translations (..., O, 3, objects)."""
+
+    def __init__(self, objects_count: int):
+        super().__init__()
+        self.objects_count = objects_count
+
+    def forward(self, observations):
+        shape = list(observations.shape[:-4]) + [3, self.objects_count]
+        zeros = torch.zeros(shape, device=observations.device)
+        return zeros, zeros.clone()
+
+
+class StandInDynamicParameters(torch.nn.Module):
+    """Contract of ClassicObjectParametersEncoder.forward (model/classic_object_parameters_encoder.py:129-237):
+    (observations, transformation_matrix_w2c, camera_rotations, focals, bounding_boxes (..., O, C, 4, n),
+    bounding_boxes_validity (..., O, C, n)) -> rotations, translations (..., O, 3, n).  The pose is an affine function of
+    the first camera's box centre: ``translation = origin + u * (cx - .5) + v * (cy - .5)``, rotation about ``up``."""
+
+    def __init__(self, origin, u, v, up_axis: int, gain: float = 1.0):
+        super().__init__()
+        self.register_buffer("origin", torch.as_tensor(origin, dtype=torch.float32))
+        self.register_buffer("u", torch.as_tensor(u, dtype=torch.float32))
+        self.register_buffer("v", torch.as_tensor(v, dtype=torch.float32))
+        self.up_axis = up_axis
+        self.gain = torch.nn.Parameter(torch.tensor(float(gain)))
+
+    def forward(self, observations, transformation_matrix_w2c, camera_rotations, focals, bounding_boxes,
+                bounding_boxes_validity):
+        box = bounding_boxes[..., 0, :, :]                                             # first camera, (..., O, 4, n)
+        cx = (box[..., 0, :] + box[..., 2, :]) / 2 - 0.5                               # (..., O, n)
+        cy = (box[..., 1, :] + box[..., 3, :]) / 2 - 0.5
+        translation = (self.origin.unsqueeze(-1) + self.u.unsqueeze(-1) * cx.unsqueeze(-2) * self.gain
+                       + self.v.unsqueeze(-1) * cy.unsqueeze(-2) * self.gain)          # (..., O, 3, n)
+        rotation = torch.zeros_like(translation)
+        rotation[..., self.up_axis, :] = cx * 0.5
+        return rotation, translation
+
+
+def stand_in_encoders(config, world: str, seed: int = 5):
+    """(object_encoders, object_parameters_encoders) for a tennis or minecraft configuration: one module per object model."""
+    static = config["model"]["static_object_models"]
+    enc, par = [], []
+    for m, mcfg in enumerate(config["model"]["object_models"]):
+        enc.append(StandInObjectEncoder(mcfg["style_features"], mcfg["deformation_features"], seed + m))
+        count = int(config["model"]["object_parameters_encoder"][m]["objects_count"])
+        if m < static:
+            par.append(StandInStaticParameters(count))
+        elif world == "tennis":   # z up, court in the xy plane
+            par.append(StandInDynamicParameters(origin=(0.0, 1.0, 0.01), u=(8.0, 0.0, 0.0), v=(0.0, -30.0, 0.0), up_axis=2))
+        else:                     # minecraft: y up
+            par.append(StandInDynamicParameters(origin=(0.0, 0.0, 0.0), u=(0.0, 0.0, 8.0), v=(8.0, 0.0, 0.0), up_axis=1))
+    return enc, par
+
+
+def observation_batch(scene, boxes_seed: int = 3, dynamic_objects: int = 2):
+    """Synthetic dataset tensors for the observation-driven modes on top of a synthetic scene's cameras: smooth images,
+    annotated boxes of the dynamic objects, index tensors.  Returns a dict keyed like Batch.to_tuple()
+    (dataset/batching.py:252-264)."""
+    g = torch.Generator().manual_seed(boxes_seed)
+    cam = scene["camera_rotations"]
+    lead = list(cam.shape[:-1])                                                        # (bs, O, C)
+    h, w = scene["image_size"]
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+    base = torch.stack([xx, yy, xx * yy], 0)                                           # (3, H, W)
+    tint = torch.rand(lead + [3, 1, 1], generator=g)
+    observations = (base * 0.5 + tint * 0.5).contiguous()
+    centre = 0.3 + 0.4 * torch.rand(lead + [2, dynamic_objects], generator=g)
+    half = 0.05 + 0.1 * torch.rand(lead + [2, dynamic_objects], generator=g)
+    boxes = torch.cat([centre - half, centre + half], dim=-2).clamp(0, 1)              # [left, top, right, bottom]
+    validity = torch.ones(lead + [dynamic_objects], dtype=torch.bool)
+    bs, obs_count = lead[0], lead[1]
+    frame = torch.arange(bs * obs_count).reshape(bs, obs_count)
+    return {"observations": observations, "camera_rotations": cam, "camera_translations": scene["camera_translations"],
+            "focals": scene["focals"], "bounding_boxes": boxes, "bounding_boxes_validity": validity,
+            "global_frame_indexes": frame, "video_frame_indexes": frame.clone(), "video_indexes": torch.arange(bs)}
