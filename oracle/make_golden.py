@@ -194,8 +194,51 @@ ODD = dict(width=48, layers=3, skip=1, features=16, octaves=3, bender_width=16, 
 C2_POSITIONS = {"background": (64, 128), "background_backplate": (64, 128), "player_1": (64, 128), "player_2": (64, 128)}
 
 
+def make_observation_mode(name, world, recipe, scene, alpha_bias, mode_kwargs):
+    """Fixture of EnvironmentModel.forward_from_observations: the REFERENCE's method (its EnvironmentModel assembled around
+    stand-in encoders, tests/helpers.py) on synthetic dataset tensors; stores the inputs, the composer's state_dict and the
+    reference's result tensors.  The encoders are rebuilt from their seeds by the test."""
+    from oracle.check_against_reference import OBS_KEYS, build_reference_environment_model
+    from tests.helpers import observation_batch, stand_in_encoders
+    cfg = recipe_config(recipe)
+    torch.manual_seed(0)
+    composer = refshim.build_reference_composer(copy.deepcopy(cfg))
+    synthetic.randomize_module_state(composer, seed=0, step=20000, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref = build_reference_environment_model(cfg, composer.eval(), *stand_in_encoders(cfg, world)).eval()
+    batch = observation_batch(scene)
+    with torch.no_grad():
+        out = ref(*[batch[k].clone() for k in OBS_KEYS], **mode_kwargs)
+    data = {"in/" + k: batch[k].numpy() for k in OBS_KEYS}
+    for k, v in composer.state_dict().items():
+        data["sd/" + k] = v.numpy()
+
+    def put(prefix, value):
+        if isinstance(value, dict):
+            for k, v in value.items():
+                if k not in ("extra_outputs", "object_attention", "object_crops"):
+                    put(f"{prefix}{k}/", v)
+        elif torch.is_tensor(value):
+            data["out/" + prefix[:-1]] = value.detach().numpy()
+    put("", {k: v for k, v in out.items() if k not in ("object_attention", "object_crops")})
+    data["recipe"] = np.frombuffer(repr(recipe).encode(), dtype=np.uint8)
+    data["meta"] = np.frombuffer(repr({"world": world, "image_size": list(scene["image_size"]), "kwargs": mode_kwargs}).encode(),
+                                 dtype=np.uint8)
+    os.makedirs(os.path.join(OUT, "observations"), exist_ok=True)
+    path = os.path.join(OUT, "observations", name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {sum(k.startswith('out/') for k in data)} output tensors")
+
+
 def main():
     refshim.install()
+    if len(sys.argv) > 1 and sys.argv[1] == "observations":
+        make_observation_mode("tennis_strided_grid", "tennis", {"base": "tennis", "reduce": REDUCE},
+                              synthetic.tennis_scene(batch=2, observations=2, seed=3, image_size=(48, 64)), 2.0,
+                              dict(samples_per_image=0, perturb=False, patch_stride=[4, 8]))
+        make_observation_mode("minecraft_all_pixels", "minecraft", {"base": "minecraft", "reduce": REDUCE},
+                              synthetic.minecraft_scene(batch=1, observations=3, seed=4, image_size=(24, 32)), 3.0,
+                              dict(samples_per_image=0, perturb=False))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "c2":
         # BASELINE.json configs[1] sample counts (64 coarse + 128 resampled per object, 256 / 768 merged entries per ray)
         # on reduced network widths: the fixture of the headline configuration's list lengths

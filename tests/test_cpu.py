@@ -325,6 +325,93 @@ def test_ray_shard_gather_world2_gloo(total):
     assert results[0] and results[1]
 
 
+class _FakeComposer(torch.nn.Module):
+    """A cheap deterministic per-ray function behind EnvironmentModel's host logic, for the CPU tests of render_sharded
+    (the HIP composer has no CPU path): every output row depends on its own ray and frame only, like the renderer's."""
+
+    def __init__(self, real):
+        super().__init__()
+        self.real = real
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.real, name)
+
+    def forward(self, ray_origins, ray_directions, focal_normals, w2o, style, deformation, object_in_scene, perturb,
+                video_indexes=None, canonical_pose=False):
+        per_frame = (style.mean(dim=(-1, -2)) + w2o[..., 0, 3, :].sum(-1)).unsqueeze(-1)      # (..., 1)
+        feats = torch.cat([ray_directions, ray_origins.unsqueeze(-2).expand_as(ray_directions)], -1) * per_frame.unsqueeze(-1)
+        entry = {"integrated_features": feats, "opacity": ray_directions.sum(-1) + per_frame, "depth": ray_directions[..., 0] * 2}
+        return {"coarse": {"global": entry}, "pytorch_hook": torch.zeros((1,) * 9)}
+
+
+def _cpu_camera_rays(c2w, focals, height, width, rows, cols):
+    lead = list(c2w.shape[:-2])
+    dirs, origins, normals = ro.create_camera_rays(lead, height, width, focals)
+    idx = rows.to(torch.int64) * width + cols.to(torch.int64)
+    idx = idx.expand(lead + [idx.size(-1)]) if idx.dim() == 1 else idx
+    picked = torch.gather(dirs.reshape(lead + [height * width, 3]), -2, idx.unsqueeze(-1).expand(list(idx.shape) + [3]))
+    return ro.transform_rays(origins, picked, normals, c2w)
+
+
+def _sharded_render_worker(rank, world, port, results):
+    import torch.distributed as dist
+    from playableenvironments_amd import environment_model as em
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        em.camera_rays = _cpu_camera_rays
+        cfg = configs.tennis_config()
+        model = em.EnvironmentModel(cfg)
+        model.object_composer = _FakeComposer(model.object_composer)
+        model.eval()
+        ok = True
+        for batch, shard, stride in ((3, "auto", 0), (1, "auto", [4, 8]), (3, "rays", 0), (2, "frames", [4, 8])):
+            scene = synthetic.tennis_scene(batch=batch, observations=2, seed=21, image_size=(16, 24))
+            args = [scene[k] for k in ("camera_rotations", "camera_translations", "focals")] + [scene["image_size"]] + \
+                   [scene[k] for k in ("object_rotation_parameters", "object_translation_parameters", "object_style",
+                                       "object_deformation", "object_in_scene")]
+            with torch.no_grad():
+                whole = model(*args, 0, False, patch_stride=stride, mode="scene_encodings")
+            everyone = model.render_sharded(*args, False, patch_stride=stride, shard=shard)
+            first = model.render_sharded(*args, False, patch_stride=stride, shard=shard, dst=0, fields=("opacity",))
+            for field in ("integrated_features", "opacity", "depth"):
+                ok = ok and torch.equal(everyone["coarse"]["global"][field], whole["coarse"]["global"][field])
+            if rank == 0:
+                ok = ok and torch.equal(first["coarse"]["global"]["opacity"], whole["coarse"]["global"]["opacity"])
+                ok = ok and set(first["coarse"]["global"]) == {"opacity"}
+            else:
+                ok = ok and first is None
+        try:
+            model.render_sharded(*args, True)
+            ok = False
+        except ValueError:
+            pass
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_sharded_world2_gloo():
+    """EnvironmentModel.render_sharded on two gloo ranks: frame shards (ragged: 3 frames over 2 ranks), ray shards of a
+    single frame (strided grids, odd split), forced modes; the assembled maps equal the unsharded render exactly, on
+    every rank (dst=None) or on rank 0 only."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = 29800 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_sharded_render_worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert results[0] and results[1]
+
+
 def _gloo_grad_worker(rank, world, port, results):
     import torch.distributed as dist
     from playableenvironments_amd import parallel

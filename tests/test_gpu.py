@@ -1126,3 +1126,305 @@ def test_sigma_gated_head_full_frame_counts():
         ex = gated[ty]["_samples"][0]
         head, ev = ex["head_evaluated"].sum().item(), ex["evaluated"].sum().item()
         assert 0 < head < ev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# observation-driven modes with injected stand-in encoders
+import ast
+import glob
+
+import numpy as np
+
+from tests.helpers import observation_batch, stand_in_encoders
+
+OBS_KEYS = ("observations", "camera_rotations", "camera_translations", "focals", "bounding_boxes", "bounding_boxes_validity",
+            "global_frame_indexes", "video_frame_indexes", "video_indexes")
+OBS_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "observations", "*.npz")))
+
+
+def test_observation_fixtures_present():
+    assert len(OBS_GOLDEN) >= 2
+
+
+@pytest.mark.parametrize("path", OBS_GOLDEN, ids=[os.path.basename(p)[:-4] for p in OBS_GOLDEN])
+def test_forward_from_observations_matches_reference_fixture(path):
+    """EnvironmentModel.forward(mode="observations") on the HIP renderer against what the REFERENCE's
+    forward_from_observations returned for the same stand-in encoders, weights and dataset tensors (fixtures recorded in
+    the build container by oracle/make_golden.py): the reference's result keys, ground-truth pixels and positions exactly,
+    geometry to fp32 rounding, the rendered fields at the renderer's tolerance (the two sides invert their rigid matrices
+    differently - closed form vs LU, 2e-6 apart - so at most 1 % of the rays may flip an AABB decision)."""
+    z = np.load(path)
+    recipe = ast.literal_eval(bytes(z["recipe"]).decode())
+    meta = ast.literal_eval(bytes(z["meta"]).decode())
+    cfg = recipe_config(recipe)
+    model = em.EnvironmentModel(cfg, *stand_in_encoders(cfg, meta["world"]))
+    model.object_composer.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    model = model.eval().cuda()
+    args = [torch.from_numpy(z["in/" + k]).cuda() for k in OBS_KEYS]
+    with torch.no_grad():
+        got = model(*args, **meta["kwargs"])
+    assert set(got) == {"coarse", "observations", "positions", "object_rotation_parameters", "object_translation_parameters",
+                        "ray_object_distances", "reconstructed_bounding_boxes", "reconstructed_3d_bounding_boxes",
+                        "projected_axes", "object_attention", "object_crops", "scene_encoding"}
+
+    def fetch(key):
+        node = got
+        for part in key.split("/"):
+            node = node[part]
+        return node.detach().cpu().float()
+
+    checked = 0
+    for name in z.files:
+        if not name.startswith("out/"):
+            continue
+        key = name[4:]
+        want, have = torch.from_numpy(z[name]).float(), fetch(key)
+        assert want.shape == have.shape, key
+        if key in ("observations", "positions") or key.startswith("scene_encoding/camera") or key == "scene_encoding/focals":
+            assert torch.equal(want, have), key
+        elif key.startswith("coarse/"):
+            if key.endswith("weights"):
+                want, have = torch.sort(want, -1)[0], torch.sort(have, -1)[0]
+            bad = ~torch.isclose(want, have, rtol=1e-3, atol=1e-4, equal_nan=True)
+            rays = bad.reshape(bad.shape[:4] + (-1,)).any(-1) if bad.dim() > 4 else bad
+            assert float(rays.float().mean()) <= 0.01, (key, float(rays.float().mean()))
+        else:
+            assert torch.allclose(want, have, rtol=1e-4, atol=1e-5), (key, float((want - have).abs().max()))
+        checked += 1
+    assert checked >= 45
+    # the object_in_scene quirk of the reference (static block repeated static_count times): static^2 + dynamic entries
+    helper = model.object_id_helper
+    assert got["scene_encoding"]["object_in_scene"].shape[-1] == helper.static_objects_count ** 2 + helper.dynamic_objects_count
+
+
+def _observation_model(world, size, batch=2, observations=2):
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    base = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
+    cfg = configs.reduced_config(base, **small)
+    model = em.EnvironmentModel(cfg, *stand_in_encoders(cfg, world))
+    torch.manual_seed(0)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    scene = (synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene)(batch=batch, observations=observations,
+                                                                                         seed=7, image_size=size)
+    batch_tensors = {k: v.cuda() for k, v in observation_batch(scene).items()}
+    return cfg, model.cuda(), batch_tensors
+
+
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_observation_mode_is_scene_encoding_mode_plus_encoders(world):
+    """mode="observations" = the injected encoders + the scene-encoding render: rendering the scene encoding it returns
+    through mode="scene_encodings" reproduces its composer results bit for bit (same rays, same kernels), the training
+    patch carries the ground-truth pixels of its positions, and render_full_frame_from_observations folds to (H, W)."""
+    size = (48, 64)
+    cfg, model, b = _observation_model(world, size)
+    model.eval()
+    args = [b[k] for k in OBS_KEYS]
+    with torch.no_grad():
+        torch.manual_seed(2)
+        out = model(*args, samples_per_image=0, perturb=False, patch_stride=[4, 8])
+        se = out["scene_encoding"]
+        K = model.object_id_helper.objects_count
+        again = model(se["camera_rotations"], se["camera_translations"], se["focals"], size, se["object_rotation_parameters"],
+                      se["object_translation_parameters"], se["object_style"], se["object_deformation"],
+                      torch.ones_like(se["object_in_scene"][..., :K]), 0, False, patch_stride=[4, 8], mode="scene_encodings")
+        for entry in ("global", "object_0", f"object_{K - 1}"):
+            for key in ("integrated_features", "opacity", "depth", "weights"):
+                assert torch.equal(out["coarse"][entry][key], again["coarse"][entry][key]), (entry, key)
+        assert torch.equal(out["reconstructed_bounding_boxes"], again["reconstructed_bounding_boxes"])
+        # training-shaped patch call (device-side random centre, noise, shuffled style; eval-mode BatchNorm so that a patch
+        # that misses an object cannot trip the batch-statistics check): positions and ground-truth pixels belong together
+        torch.manual_seed(3)
+        patch = model(*args, samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8], shuffle_style=True)
+        full = model.render_full_frame_from_observations(*args, False)
+    rays = 8 * 8 + 4 * 4
+    assert tuple(patch["coarse"]["global"]["integrated_features"].shape)[-2:] == (rays, 32)
+    assert tuple(patch["observations"].shape)[-2:] == (rays, 3) and tuple(patch["positions"].shape)[-2:] == (rays, 2)
+    rows = (patch["positions"][..., 0] * size[0]).round().long()
+    cols = (patch["positions"][..., 1] * size[1]).round().long()
+    obs = b["observations"]
+    lead = obs.shape[:3]
+    flat = obs.reshape(-1, 3, size[0] * size[1])
+    picked = torch.gather(flat, 2, (rows * size[1] + cols).reshape(-1, 1, rays).expand(-1, 3, -1)).transpose(1, 2)
+    assert torch.equal(picked.reshape(lead + (rays, 3)), patch["observations"])
+    assert tuple(patch["ray_object_distances"].shape) == tuple(lead) + (rays, model.object_id_helper.objects_count)
+    assert tuple(full["coarse"]["global"]["integrated_features"].shape) == tuple(lead) + (size[0], size[1], 32)
+    assert tuple(full["observations"].shape) == tuple(lead) + (size[0], size[1], 3)
+    assert torch.equal(full["observations"], obs.movedim(-3, -1))
+
+
+def test_observation_mode_gradients_reach_the_encoders():
+    """Differentiable call through the observation mode: the loss on the rendered features back-propagates through
+    pr_render_backward into the injected encoders (poses through w2o, style, deformation) and the composer.  (Frozen
+    BatchNorm statistics: a random patch that misses an object would trip train mode's batch-statistics check.)"""
+    cfg, model, b = _observation_model("minecraft", (48, 64), batch=1, observations=3)
+    model.eval()
+    torch.manual_seed(5)
+    out = model(*[b[k] for k in OBS_KEYS], samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8])
+    out["coarse"]["global"]["integrated_features"].square().mean().backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert any(n.startswith("object_encoders.") and float(g.abs().sum()) > 0 for n, g in grads.items())
+    assert any(n.startswith("object_parameters_encoders.") and float(g.abs().sum()) > 0 for n, g in grads.items())
+    assert any(n.startswith("object_composer.") and float(g.abs().sum()) > 0 for n, g in grads.items())
+    assert all(torch.isfinite(g).all() for g in grads.values())
+
+
+def test_missing_encoders_raise():
+    cfg = configs.tennis_config()
+    model = em.EnvironmentModel(cfg).eval().cuda()
+    b = {k: v.cuda() for k, v in observation_batch(synthetic.tennis_scene(image_size=(48, 64))).items()}
+    with pytest.raises(RuntimeError, match="inject"):
+        model(*[b[k] for k in OBS_KEYS], 0, False)
+
+
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_consistency_forwards(world):
+    """forward_pose_consistency / forward_keypoint_consistency: the reference's result structure, and expected positions equal
+    to ObjectComposer.forward_expected_positions on the rays the forwards sample (same seed)."""
+    size = (48, 64)
+    cfg, model, b = _observation_model(world, size, batch=2, observations=3)
+    model.eval()
+    with torch.no_grad():
+        se = model(*[b[k] for k in OBS_KEYS], mode="observations_scene_encoding_only")
+        lead = list(b["observations"].shape[:3])
+        g = torch.Generator().manual_seed(1)
+        flow = ((torch.rand(lead + [2, size[0], size[1]], generator=g) - 0.5) * 0.05).cuda()
+        keypoints = torch.rand(lead + [17, 3, 2], generator=g).cuda()
+        common = [b[k] for k in OBS_KEYS[1:]] + [se["object_style"], se["object_deformation"],
+                                                 se["object_rotation_parameters"], se["object_translation_parameters"]]
+        torch.manual_seed(4)
+        pose = model(flow, *common, 30, False, mode="pose_consistency")
+        torch.manual_seed(4)
+        pose_again = model.forward_pose_consistency(flow, *common, 30, False)
+        torch.manual_seed(6)
+        kp = model(b["observations"], *common, keypoints, b["bounding_boxes_validity"], 20, False, mode="keypoint_consistency")
+    assert set(pose) == {"coarse", "pytorch_backward_hook"} and set(pose["coarse"]) == {"dynamic_object_0", "dynamic_object_1"}
+    for name, (previous, following) in pose["coarse"].items():
+        assert tuple(previous[0].shape) == (2, 2, 1, 30, 3) and tuple(following[0].shape) == (2, 2, 1, 30, 3)
+        assert tuple(previous[1].shape) == (2, 2, 1, 30)
+        assert torch.equal(previous[0], pose_again["coarse"][name][0][0])
+        assert torch.isfinite(previous[0]).all() and torch.isfinite(following[0]).all()
+    assert pose["pytorch_backward_hook"] is pose["coarse"]["dynamic_object_0"][0]
+    for name, (positions, confidence, opacity, sampled) in kp["coarse"].items():
+        assert tuple(positions.shape) == (2, 3, 1, 20, 3) and tuple(confidence.shape) == (2, 3, 1, 20)
+        assert tuple(opacity.shape) == (2, 3, 1, 20) and tuple(sampled.shape) == (2, 3, 1, 20, 2)
+        box = model.object_composer.object_models_coarse[2].bounding_box
+        hit = opacity > 1e-3                    # expected positions of rays that hit the object lie inside its box
+        lo = torch.as_tensor([r[0] for r in cfg["model"]["object_models"][2]["bounding_box"]], device=positions.device) - 1e-3
+        hi = torch.as_tensor([r[1] for r in cfg["model"]["object_models"][2]["bounding_box"]], device=positions.device) + 1e-3
+        inside = ((positions >= lo) & (positions <= hi)).all(-1)
+        assert bool(inside[hit].all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-rank paths on the single GPU of the test box (SURVEY.md section 8e): RCCL with one rank, gloo with two ranks on one
+# device (RCCL refuses two ranks on the same GPU); the 8-GPU runs are the driver's
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tennis_model_and_args(batch, size=(32, 48)):
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    cfg = configs.reduced_config(configs.tennis_config(), **small)
+    model = em.EnvironmentModel(cfg)
+    torch.manual_seed(0)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.0, bender_scale=1e4)
+    scene = synthetic.tennis_scene(batch=batch, observations=1, seed=33, image_size=size)
+    args = [scene[k].cuda() for k in ("camera_rotations", "camera_translations", "focals")] + [size] + \
+           [scene[k].cuda() for k in ("object_rotation_parameters", "object_translation_parameters", "object_style",
+                                      "object_deformation", "object_in_scene")]
+    return model.eval().cuda(), args
+
+
+def test_render_sharded_and_async_gather_rccl_world1():
+    """torch.distributed backend "nccl" (= RCCL) with a single rank: render_sharded degenerates to the plain render and the
+    pipelined feature gather returns the rank's own maps - the code path of the multi-GPU runs, through RCCL."""
+    import torch.distributed as dist
+    from playableenvironments_amd.parallel import AsyncFeatureGather, gather_ray_shards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        model, args = _tennis_model_and_args(batch=2)
+        with torch.no_grad():
+            whole = model(*args, 0, False, mode="scene_encodings")
+        for shard in ("frames", "rays", "auto"):
+            out = model.render_sharded(*args, False, shard=shard)
+            assert torch.equal(out["coarse"]["global"]["integrated_features"], whole["coarse"]["global"]["integrated_features"])
+        feats = whole["coarse"]["global"]["integrated_features"]
+        stacked = torch.empty_like(feats)
+        dist.all_gather_into_tensor(stacked, feats.contiguous())           # a real RCCL collective on the device
+        assert torch.equal(stacked, feats)
+        gather = AsyncFeatureGather(depth=1)
+        gather.submit(feats)
+        gather.submit(feats * 2)
+        done = gather.drain()
+        assert len(done) == 2 and torch.equal(done[1], feats * 2)
+        assert torch.equal(gather_ray_shards(feats, feats.size(0), 0, dst=None), feats)
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, port, results):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        ok = True
+        for batch, shard in ((3, "frames"), (1, "rays"), (2, "auto")):
+            model, args = _tennis_model_and_args(batch=batch)
+            with torch.no_grad():
+                whole = model(*args, 0, False, patch_stride=[4, 8], mode="scene_encodings")
+            out = model.render_sharded(*args, False, patch_stride=[4, 8], shard=shard, fields=("integrated_features", "opacity"))
+            for field in ("integrated_features", "opacity"):
+                ok = ok and torch.equal(out["coarse"]["global"][field], whole["coarse"]["global"][field])
+        results[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_sharded_two_ranks_on_one_gpu_gloo():
+    """Two ranks (gloo) sharing the box's GPU: frame shards (3 frames over 2 ranks), ray shards of a single frame - the HIP
+    renderer's assembled feature maps equal the unsharded render bit for bit on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert results[0] and results[1]
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` (no launcher): bench.py starts torch.distributed.run itself; with the PR_BENCH_DEVICE /
+    PR_BENCH_BACKEND knobs both ranks share this box's GPU over gloo.  One JSON line, n_gpus = 2, two per-rank times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PR_BENCH_DEVICE="0", PR_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--image", "64",
+                           "--no-cpu-baseline", "--no-split-precision"], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    result = json.loads(lines[0])
+    assert result["n_gpus"] == 2 and result["distributed"]["world_size"] == 2 and result["distributed"]["backend"] == "gloo"
+    assert result["value"] > 0 and result["steps"] == 2
+    assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == 2
+    assert result["train_step"]["parallelism"].startswith("data parallel x2")
