@@ -1180,8 +1180,10 @@ def test_forward_from_observations_matches_reference_fixture(path):
         key = name[4:]
         want, have = torch.from_numpy(z[name]).float(), fetch(key)
         assert want.shape == have.shape, key
-        if key in ("observations", "positions") or key.startswith("scene_encoding/camera") or key == "scene_encoding/focals":
+        if key == "observations" or key.startswith("scene_encoding/camera") or key == "scene_encoding/focals":
             assert torch.equal(want, have), key
+        elif key == "positions":     # row / H, col / W: the device's fp32 division may round the last bit differently
+            assert torch.allclose(want, have, rtol=0, atol=1e-7), key
         elif key.startswith("coarse/"):
             if key.endswith("weights"):
                 want, have = torch.sort(want, -1)[0], torch.sort(have, -1)[0]
@@ -1328,8 +1330,8 @@ def _free_port():
 def _tennis_model_and_args(batch, size=(32, 48)):
     small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
     cfg = configs.reduced_config(configs.tennis_config(), **small)
+    torch.manual_seed(0)        # BEFORE the construction: every rank of a multi-process test must draw the same weights
     model = em.EnvironmentModel(cfg)
-    torch.manual_seed(0)
     synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.0, bender_scale=1e4)
     scene = synthetic.tennis_scene(batch=batch, observations=1, seed=33, image_size=size)
     args = [scene[k].cuda() for k in ("camera_rotations", "camera_translations", "focals")] + [size] + \
