@@ -302,6 +302,23 @@ int pr_expected_positions(int32_t frames, int32_t rays, int32_t objects, int32_t
                           const float* weights, const float* delta, float* expected, void* stream);
 
 /*
+ * Region-of-interest max pooling: the crop the reference's object encoders and pose estimators take from the
+ * observations before their small ResNets - torchvision.ops.roi_pool(observations, boxes, input_size) at
+ * model/object_encoder_v4.py:121, model/object_encoder_v5.py:121 and model/object_parameters_encoder_v4.py:131
+ * (torchvision 0.9.1, a dependency outside the reference tree; the operator's published definition is restated in
+ * csrc/roi_pool.hip and oracle/roi_pool_oracle.py).  input (N,C,H,W); boxes (K,5) = [image index, x1, y1, x2, y2] in
+ * input pixels times spatial_scale; output (K,C,ph,pw); argmax (K,C,ph,pw) int32 flat h*W + w of the selected element,
+ * -1 for an empty bin, or NULL.  The backward call ACCUMULATES grad_output into grad_input (N,C,H,W) at the argmax
+ * positions (the caller zero-initialises).
+ */
+int pr_roi_pool_forward(int32_t images, int32_t channels, int32_t height, int32_t width, const float* input,
+                        int32_t rois, const float* boxes, int32_t pooled_height, int32_t pooled_width,
+                        float spatial_scale, float* output, int32_t* argmax, void* stream);
+int pr_roi_pool_backward(int32_t images, int32_t channels, int32_t height, int32_t width, int32_t rois,
+                         const float* boxes, int32_t pooled_height, int32_t pooled_width, const float* grad_output,
+                         const int32_t* argmax, float* grad_input, void* stream);
+
+/*
  * Kernel timing for bench.py: while enabled, the launches of the dominant kernels are bracketed by
  * hipEventRecord on the launch stream.  Categories: 0 = fused MLP (k_mlp_mfma / k_mlp_split / k_mlp_head),
  * 1 = forward compositing (k_composite), 2 = backward dX products (k_gemm_nn), 3 = backward dW products

@@ -582,6 +582,73 @@ def check_observation_modes():
     return ok
 
 
+def check_encoders():
+    """playableenvironments_amd.encoders against the reference's encoder modules on CPU: identical state_dict keys / shapes,
+    and - with the reference's weights loaded and the region-of-interest crop of BOTH sides served by the CPU restatement
+    of torchvision.ops.roi_pool (torchvision is absent here; the HIP kernel is tested against the same restatement on the
+    GPU) - identical outputs in eval and train mode."""
+    import importlib
+    import torchvision
+    from oracle import roi_pool_oracle
+    from playableenvironments_amd import encoders as enc
+    from playableenvironments_amd.environment_model import euler_to_matrix, rigid_inverse
+    torchvision.ops.roi_pool = lambda x, boxes, size: roi_pool_oracle.roi_pool(x.detach(), boxes.detach(), size)[0]
+    product_roi_pool = enc.roi_pool
+    enc.roi_pool = lambda x, boxes, size, spatial_scale=1.0: roi_pool_oracle.roi_pool(x.detach(), boxes.detach(), size, spatial_scale)[0]
+    ok = True
+    try:
+        g = torch.Generator().manual_seed(3)
+        lead = [2, 3, 1]
+        obs = torch.rand(lead + [3, 72, 128], generator=g)
+        centre = 0.3 + 0.4 * torch.rand(lead + [2, 2], generator=g)
+        half = 0.05 + 0.1 * torch.rand(lead + [2, 2], generator=g)
+        boxes = torch.cat([centre - half, centre + half], dim=-2)
+        validity = torch.rand(lead + [2], generator=g) > 0.2
+        cam_rot = torch.tensor([-0.3, 1.5, 0.0]) + 0.1 * torch.randn(lead + [3], generator=g)
+        cam_tr = torch.tensor([12.0, 4.0, 0.0]) + torch.randn(lead + [3], generator=g)
+        focals = torch.full(lead, 180.0)
+        w2c = rigid_inverse(euler_to_matrix(cam_rot, cam_tr))
+        frames = torch.arange(6).reshape(2, 3)
+        for section, cfg in (("tennis", configs.tennis_config(encoders=True)), ("minecraft", configs.minecraft_config(encoders=True))):
+            for kind, key, table in (("object encoder", "object_encoders", enc.OBJECT_ENCODER_CLASSES),
+                                     ("parameters encoder", "object_parameters_encoder", enc.OBJECT_PARAMETERS_ENCODER_CLASSES)):
+                for entry in cfg["model"][key]:
+                    torch.manual_seed(5)
+                    ref = importlib.import_module(entry["architecture"]).model(cfg, entry)
+                    mine = table[entry["architecture"]](cfg, entry)
+                    sd = ref.state_dict()
+                    same_keys = list(sd) == list(mine.state_dict()) and all(sd[k].shape == mine.state_dict()[k].shape for k in sd)
+                    mine.load_state_dict(sd, strict=True)
+                    worst = 0.0
+                    for training in (False, True):
+                        ref.train(training)
+                        mine.train(training)
+                        if kind == "object encoder":
+                            args = (obs, boxes[..., 0], cam_rot, cam_tr, frames, frames, torch.arange(2))
+                        elif "static" in entry["architecture"]:
+                            args = (obs,)
+                        else:
+                            n = entry["objects_count"]
+                            args = (obs, w2c, cam_rot, focals, boxes[..., :n], validity[..., :n])
+                        a = ref(*[t.clone() for t in args])
+                        b = mine(*[t.clone() for t in args])
+                        for x, y in zip(a, b):
+                            same_shape = x.shape == y.shape
+                            # relative to the tensor's scale: the ray cast of the pose estimators multiplies the 2e-6 difference
+                            # between the closed-form and the LU inverse of the camera matrix by distances of ~100
+                            rel = float((x - y).abs().max()) / (1.0 + float(x.abs().max())) if same_shape and x.numel() else \
+                                (0.0 if same_shape else float("inf"))
+                            worst = max(worst, rel)
+                    good = same_keys and worst <= 2e-5
+                    print(f"[encoders, {section}] {entry['architecture']}: {len(sd)} state_dict entries match: {same_keys}, "
+                          f"worst relative |diff| eval+train = {worst:.2e}")
+                    ok &= good
+    finally:
+        enc.roi_pool = product_roi_pool
+    print(f"[encoders] roi_pool restatement == ATen adaptive_max_pool2d on in-image boxes: {roi_pool_oracle.check_against_adaptive_max_pool()}")
+    return ok and roi_pool_oracle.check_against_adaptive_max_pool()
+
+
 def check_boundary_signatures():
     """The drop-in classes against the imported reference classes: every method of the boundary has the reference's
     parameter names, order and defaults (extensions are trailing keyword arguments with defaults)."""
@@ -652,7 +719,7 @@ def check_configs_against_yaml():
     """configs.tennis_config() / minecraft_config() against the shipped YAML files (with the defaults of
     utils/configuration.py the renderer reads): every key both sides have carries the same value."""
     ok = True
-    for name, mine in (("tennis", configs.tennis_config()), ("minecraft", configs.minecraft_config())):
+    for name, mine in (("tennis", configs.tennis_config(encoders=True)), ("minecraft", configs.minecraft_config(encoders=True))):
         ref_cfg = refshim.load_reference_config(name)
         a, b = _leaves(mine), _leaves(ref_cfg)
         shared = sorted(set(a) & set(b))
@@ -747,6 +814,7 @@ def main():
     # (with use_fine the reference's own backward raises: compute_expected_positions keeps a view of the coarse weights
     # that sample_pdf later modifies in place - there is no reference gradient to pin for hierarchical configurations)
     ok &= check_observation_modes()
+    ok &= check_encoders()
     ok &= check_boundary_signatures()
     ok &= check_configs_against_yaml()
     ok &= report_tie_fractions()

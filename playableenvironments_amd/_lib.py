@@ -142,6 +142,10 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_expected_positions": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_roi_pool_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_roi_pool_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_profile_enable": (C.c_int, [C.c_int]),
     "pr_profile_collect": (C.c_int, [C.POINTER(C.c_double), c_int32_p]),
     "pr_probe_mfma_f32": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),

@@ -65,7 +65,58 @@ def _object(name, bbox, coarse, fine, z_near, z_far, style, nerf, bender, use_fi
 
 
 def _wrap(focal_multiplier, fix_overlaps, static_models, objects: List[dict], counts: Sequence[int],
-          sampling_weights, strides=(4, 8)) -> dict:
+          sampling_weights, strides=(4, 8), encoders: Optional[dict] = None) -> dict:
+    cfg = _wrap_renderer(focal_multiplier, fix_overlaps, static_models, objects, counts, sampling_weights, strides)
+    if encoders is not None:
+        # the sections EnvironmentModel builds its CNN object encoders / pose estimators from (playableenvironments_amd.encoders)
+        cfg["model"]["object_encoders"] = copy.deepcopy(encoders["object_encoders"])
+        cfg["model"]["object_parameters_encoder"] = copy.deepcopy(encoders["object_parameters_encoder"])
+    return cfg
+
+
+_ZERO_RANGE = [[[-0.0, 0.0], [-0.0, 0.0], [-0.0, 0.0]]]
+
+#: object_encoders / object_parameters_encoder sections of the shipped tennis configuration (configs/tennis/193_...yaml)
+TENNIS_ENCODERS = {
+    "object_encoders": [
+        {"background": None, "architecture": "model.object_encoder_v5", "input_size": [64, 256], "style_features": 64, "deformation_features": 32},
+        {"background_backplate": None, "architecture": "model.object_encoder_v5", "input_size": [32, 256], "style_features": 64, "deformation_features": 32},
+        {"player_1": None, "architecture": "model.object_encoder_v4", "input_size": [64, 64], "style_features": 64, "deformation_features": 32},
+        {"player_2": None, "architecture": "model.object_encoder_v4", "input_size": [64, 64], "style_features": 64, "deformation_features": 32},
+    ],
+    "object_parameters_encoder": [
+        {"background": None, "architecture": "model.static_object_parameters_encoder", "objects_count": 1,
+         "translation_range": _ZERO_RANGE, "rotation_range": _ZERO_RANGE},
+        {"background_backplate": None, "architecture": "model.static_object_parameters_encoder", "objects_count": 1,
+         "translation_range": [[[-0.0, 0.0], [20.085, 20.085], [-0.0, 0.0]]], "rotation_range": _ZERO_RANGE},
+        {"player_1": None, "architecture": "model.classic_object_parameters_encoder", "objects_count": 1,
+         "translation_range": [[[-7.5, 7.5], [-20.0, 0.0], [0.01, 0.01]]], "rotation_range": _ZERO_RANGE},
+        {"player_2": None, "architecture": "model.classic_object_parameters_encoder", "objects_count": 1,
+         "translation_range": [[[-7.5, 7.5], [-0.0, 20.0], [0.01, 0.01]]], "rotation_range": _ZERO_RANGE},
+    ],
+}
+
+#: the same sections of the shipped minecraft configuration (configs/minecraft/013_...yaml)
+MINECRAFT_ENCODERS = {
+    "object_encoders": [
+        {"background": None, "architecture": "model.object_encoder_v5", "input_size": [64, 256], "style_features": 32, "deformation_features": 32},
+        {"skybox": None, "architecture": "model.object_encoder_v5", "input_size": [144, 256], "style_features": 32, "deformation_features": 32},
+        {"player_1": None, "architecture": "model.object_encoder_v4", "input_size": [64, 64], "style_features": 32, "deformation_features": 32,
+         "expansion_factor": {"rows": 2.8, "cols": 2}},
+    ],
+    "object_parameters_encoder": [
+        {"background": None, "architecture": "model.static_object_parameters_encoder", "objects_count": 1,
+         "translation_range": _ZERO_RANGE, "rotation_range": _ZERO_RANGE},
+        {"skybox": None, "architecture": "model.static_object_parameters_encoder", "objects_count": 1,
+         "translation_range": _ZERO_RANGE, "rotation_range": _ZERO_RANGE},
+        {"player_1": None, "architecture": "model.object_parameters_encoder_v4", "objects_count": 2, "input_size": [64, 64],
+         "edge_to_center_distance": 0.0, "expansion_factor": {"rows": 2.8, "cols": 2}},
+    ],
+}
+
+
+def _wrap_renderer(focal_multiplier, fix_overlaps, static_models, objects: List[dict], counts: Sequence[int],
+                   sampling_weights, strides=(4, 8)) -> dict:
     return {
         "data": {"focal_length_multiplier": focal_multiplier},
         "model": {
@@ -83,11 +134,13 @@ def _wrap(focal_multiplier, fix_overlaps, static_models, objects: List[dict], co
     }
 
 
-def tennis_config(hierarchical: Optional[Sequence[int]] = None) -> dict:
+def tennis_config(hierarchical: Optional[Sequence[int]] = None, encoders: bool = False) -> dict:
     """Shipped tennis renderer: background (P=4), backplate (P=4), two players (P=32, ray bender).
 
     ``hierarchical=(Pc, Pf)`` is the benchmark override of BASELINE.json configs[1]: every object
-    gets ``use_fine`` with ``Pc`` coarse + ``Pf`` resampled positions."""
+    gets ``use_fine`` with ``Pc`` coarse + ``Pf`` resampled positions.
+    ``encoders=True`` adds the shipped object-encoder / object-parameters-encoder sections, from which
+    ``EnvironmentModel(config)`` builds its CNN encoders itself (otherwise they are injected)."""
     s = 64
     objs = [
         _object("background", [[-30.0, 30.0], [-40.0, 20.585], [-0.5, 0.0]], 4, 4, 5.0, 70.0, s,
@@ -103,7 +156,7 @@ def tennis_config(hierarchical: Optional[Sequence[int]] = None) -> dict:
         pc, pf = hierarchical
         for o in objs:
             o["positions_count_coarse"], o["positions_count_fine"], o["use_fine"] = int(pc), int(pf), True
-    return _wrap(0.51417, False, 2, objs, [1, 1, 1, 1], [0.55, 0.15, 0.15, 0.15])
+    return _wrap(0.51417, False, 2, objs, [1, 1, 1, 1], [0.55, 0.15, 0.15, 0.15], encoders=TENNIS_ENCODERS if encoders else None)
 
 
 def tennis_single_player_config(positions: int = 32) -> dict:
@@ -113,7 +166,7 @@ def tennis_single_player_config(positions: int = 32) -> dict:
     return _wrap(0.51417, False, 0, objs, [1], [1.0])
 
 
-def minecraft_config() -> dict:
+def minecraft_config(encoders: bool = False) -> dict:
     """Shipped minecraft renderer: background (P=16), skybox (P=1, 6-D input, opaque), one player
     model shared by two object instances (P=32, ray bender); overlap fix on (default)."""
     s = 32
@@ -125,7 +178,7 @@ def minecraft_config() -> dict:
         _object("player_1", [[-0.6, 0.6], [-0.0, 2.1], [-1.2, 1.2]], 32, 32, 0.05, 30.0, s,
                 _nerf(NERF_ADAIN), _bender(True)),
     ]
-    return _wrap(0.5, True, 2, objs, [1, 1, 2], [0.0, 0.70, 0.15, 0.15])
+    return _wrap(0.5, True, 2, objs, [1, 1, 2], [0.0, 0.70, 0.15, 0.15], encoders=MINECRAFT_ENCODERS if encoders else None)
 
 
 def reduced_config(base: dict, width=32, layers=4, skip=2, features=16, octaves=4,

@@ -151,6 +151,12 @@ class EnvironmentModel(nn.Module):
         self.object_encoders = nn.ModuleList()
         if object_encoders is not None or object_parameters_encoders is not None:
             self.set_encoders(object_encoders, object_parameters_encoders)
+        elif all("architecture" in e for e in config["model"].get("object_encoders", [{}])) and \
+                all("architecture" in e for e in config["model"].get("object_parameters_encoder", [{}])):
+            # a full configuration (the reference's YAML): build the encoders like the reference's constructor does
+            # (environment_model.py:44-50), from this package's modules
+            from .encoders import create_encoders
+            self.set_encoders(*create_encoders(config))
         self.current_step = 0
         # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
         self._pixel_cache: Dict = {}
