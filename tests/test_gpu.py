@@ -1470,7 +1470,7 @@ def _random_boxes(g, count, images, height, width):
     return torch.cat([index, boxes], dim=-1)
 
 
-@pytest.mark.parametrize("shape,out_size", [((3, 3, 36, 64), (8, 8)), ((2, 5, 72, 128), (16, 64)), ((1, 1, 9, 7), (3, 2))])
+@pytest.mark.parametrize("shape,out_size", [((3, 3, 36, 64), (8, 8)), ((2, 5, 72, 128), (8, 32)), ((1, 1, 9, 7), (3, 2))])
 def test_roi_pool_kernel_matches_oracle(shape, out_size):
     """pr_roi_pool_forward / _backward against the CPU restatement of torchvision.ops.roi_pool: values and argmax positions
     bit for bit (max pooling copies elements), input gradients up to the summation order of the atomic scatter."""
@@ -1501,6 +1501,9 @@ def test_encoders_on_gpu_match_cpu_modules(world):
     from playableenvironments_amd import encoders
     from playableenvironments_amd.environment_model import euler_to_matrix, rigid_inverse
     cfg = configs.tennis_config(encoders=True) if world == "tennis" else configs.minecraft_config(encoders=True)
+    for entry in cfg["model"]["object_encoders"] + cfg["model"]["object_parameters_encoder"]:
+        if "input_size" in entry:      # small crops: the CPU side loops over every bin in Python
+            entry["input_size"] = [32, 64] if entry["architecture"].endswith("v5") else [32, 32]
     scene = (synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene)(batch=2, observations=2, seed=13, image_size=(72, 128))
     b = observation_batch(scene)
     w2c = rigid_inverse(euler_to_matrix(b["camera_rotations"], b["camera_translations"]))
@@ -1530,8 +1533,8 @@ def test_encoders_on_gpu_match_cpu_modules(world):
             got = module.cuda()(*[a.cuda() for a in args])
         for a, c in zip(want, got):
             assert a.shape == c.shape
-            scale = 1.0 + float(a.abs().max()) if a.numel() else 1.0
-            assert float((a - c.cpu()).abs().max()) <= 2e-4 * scale, (entry["architecture"], float((a - c.cpu()).abs().max()))
+            scale = 1.0 + float(a.detach().abs().max()) if a.numel() else 1.0
+            assert float((a.detach() - c.cpu()).abs().max()) <= 2e-4 * scale, (entry["architecture"], float((a - c.cpu()).abs().max()))
 
 
 def test_native_observation_pipeline_end_to_end():
