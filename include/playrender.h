@@ -165,6 +165,23 @@ typedef struct pr_entry_t {
     float* integrated_divergence;             /* (N,R)  zeros (eval) */
 } pr_entry_t;
 
+/* Optional emission of the global entry's integrated features in the layout the reference's CNN decoder consumes
+ * (model/environment_model_multiresolution_backpropagated_decoder.py:67-106, environment_model_backpropagated_autoencoder.py
+ * :128-168): the rays of a call are the concatenation of `groups` row-major grids (the strided grids of a full frame, or
+ * the strided patches of a training call, smallest stride first); group i owns the feature channels
+ * [channel_begin[i], channel_end[i]) and receives them as a channels-first map.  Replaces split_strided_patch_ray_samples /
+ * fold_strided_tensors + split_features_by_layer + permute (two passes over the feature map) by the compositing kernel's
+ * own stores. */
+#define PR_MAX_DECODER_GROUPS 4
+typedef struct pr_decoder_layout_t {
+    int32_t groups;                               /* 0 = off */
+    int32_t rays[PR_MAX_DECODER_GROUPS];          /* rays of each group; their sum must be R */
+    int32_t width[PR_MAX_DECODER_GROUPS];         /* grid width of each group (rays[i] % width[i] == 0) */
+    int32_t channel_begin[PR_MAX_DECODER_GROUPS];
+    int32_t channel_end[PR_MAX_DECODER_GROUPS];
+    float* map[PR_MAX_DECODER_GROUPS];            /* (N, channel_end - channel_begin, rays / width, width) */
+} pr_decoder_layout_t;
+
 typedef struct pr_outputs_t {
     pr_entry_t object[PR_MAX_OBJECTS];
     pr_entry_t global;
@@ -178,6 +195,7 @@ typedef struct pr_outputs_t {
                                                  box / without a bender), input of pr_expected_positions */
     int32_t* head_samples;                    /* (K) number of samples sent through the feature head: evaluated_samples
                                                  unless PR_FLAG_GATE_HEAD skipped the ones with density <= 0 */
+    pr_decoder_layout_t decoder;              /* global.integrated_features additionally in decoder layout (groups = 0: off) */
 } pr_outputs_t;
 
 typedef struct pr_call_t {

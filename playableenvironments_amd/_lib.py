@@ -77,12 +77,22 @@ class Entry(C.Structure):
 ENTRY_FIELDS = [f[0] for f in Entry._fields_]
 
 
+PR_MAX_DECODER_GROUPS = 4
+
+
+class DecoderLayout(C.Structure):
+    _fields_ = [("groups", C.c_int32), ("rays", C.c_int32 * PR_MAX_DECODER_GROUPS), ("width", C.c_int32 * PR_MAX_DECODER_GROUPS),
+                ("channel_begin", C.c_int32 * PR_MAX_DECODER_GROUPS), ("channel_end", C.c_int32 * PR_MAX_DECODER_GROUPS),
+                ("map", C.c_void_p * PR_MAX_DECODER_GROUPS)]
+
+
 class Outputs(C.Structure):
     _fields_ = [
         ("object", Entry * PR_MAX_OBJECTS), ("global_", Entry),
         ("sample_t", C.c_void_p * PR_MAX_OBJECTS), ("sample_sigma", C.c_void_p * PR_MAX_OBJECTS),
         ("sample_slot", C.c_void_p * PR_MAX_OBJECTS), ("evaluated_samples", C.c_void_p), ("normalised_samples", C.c_void_p),
         ("sample_delta", C.c_void_p * PR_MAX_OBJECTS), ("head_samples", C.c_void_p),
+        ("decoder", DecoderLayout),
     ]
 
 

@@ -428,6 +428,35 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
             }
         }
     }
+    if (p.decoder.groups > 0) {
+        // decoder layout: this ray is cell (r / width, r % width) of its group's grid; its channels go to the channels-first
+        // map of the group (neighbouring rays = neighbouring workgroups fill neighbouring columns of every plane)
+        if (CW > 1 && !p.global.integrated_features) {     // the cross-wave sums have not been formed yet
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK; ++c) {
+                if (64 * c >= F) break;
+                __syncthreads();
+                scratch[wave * 64 + lane] = accg[c];
+                __syncthreads();
+                if (wave == 0)
+                    for (int w = 1; w < CW; ++w) accg[c] = __fadd_rn(accg[c], scratch[w * 64 + lane]);
+            }
+        }
+        if (wave == 0) {
+            const int frame = (int)(g / p.rays);
+            int r = (int)(g - (long)frame * p.rays);
+            int grp = 0;
+            while (grp < p.decoder.groups - 1 && r >= p.decoder.rays[grp]) r -= p.decoder.rays[grp++];
+            const int c0 = p.decoder.channel_begin[grp], c1 = p.decoder.channel_end[grp];
+            const size_t cells = (size_t)p.decoder.rays[grp];
+            float* map = p.decoder.map[grp] + (size_t)frame * (c1 - c0) * cells + r;
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch >= c0 && ch < c1 && ch < F) map[(size_t)(ch - c0) * cells] = accg[c];
+            }
+        }
+    }
 }
 
 int launch_composite(const CompositeParams& p, hipStream_t s) {
@@ -438,6 +467,19 @@ int launch_composite(const CompositeParams& p, hipStream_t s) {
     const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * (p.any_divergence ? 7 : 6) * 4 +
                        sizeof(float) * 4 * 64 + (p.fix_overlaps ? (size_t)p.sort_size * 8 : 0);
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing kernel (%d)", p.total_positions);
+    if (p.decoder.groups > 0) {
+        PR_REQUIRE(p.decoder.groups <= PR_MAX_DECODER_GROUPS, "decoder layout: %d groups (max %d)", p.decoder.groups, PR_MAX_DECODER_GROUPS);
+        long sum = 0;
+        for (int i = 0; i < p.decoder.groups; ++i) {
+            PR_REQUIRE(p.decoder.rays[i] > 0 && p.decoder.width[i] > 0 && p.decoder.rays[i] % p.decoder.width[i] == 0,
+                       "decoder layout: group %d has %d rays in rows of %d", i, p.decoder.rays[i], p.decoder.width[i]);
+            PR_REQUIRE(p.decoder.channel_begin[i] >= 0 && p.decoder.channel_begin[i] < p.decoder.channel_end[i] && p.decoder.channel_end[i] <= p.F,
+                       "decoder layout: group %d channel range [%d, %d) outside 0..%d", i, p.decoder.channel_begin[i], p.decoder.channel_end[i], p.F);
+            PR_REQUIRE(p.decoder.map[i] != nullptr, "decoder layout: group %d has no map", i);
+            sum += p.decoder.rays[i];
+        }
+        PR_REQUIRE(sum == p.rays, "decoder layout: the groups hold %ld rays, the call has %d", sum, p.rays);
+    }
     const long total = (long)p.frames * p.rays;
     ProfileScope scope(1, s);
     // four waves per ray once the lists are long enough to keep them busy; short lists (a few dozen entries) stay on one

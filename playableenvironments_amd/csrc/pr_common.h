@@ -283,6 +283,7 @@ struct CompositeParams {
     const float* noise_global;   // (N,R,sumP) or NULL
     CompositeObject obj[PR_MAX_OBJECTS];
     pr_entry_t global;
+    pr_decoder_layout_t decoder;   // global features additionally as channels-first maps per ray group (groups = 0: off)
 };
 int launch_composite(const CompositeParams& p, hipStream_t s);
 

@@ -469,7 +469,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             o.positions = m.positions;
             if (out) o.out = out->object[k];
         }
-        if (out) cp.global = out->global;
+        if (out) {
+            cp.global = out->global;
+            cp.decoder = out->decoder;
+        }
         PR_TRY(launch_composite(cp, s));
 
         // ---- optional exports -------------------------------------------------------------------

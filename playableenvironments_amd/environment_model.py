@@ -315,15 +315,33 @@ class EnvironmentModel(nn.Module):
     # ------------------------------------------------------------------ composer plumbing
     def batchified_composer_call(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                  deformation, object_in_scene, perturb, samples_per_image_batching: int = 0,
-                                 video_indexes=None, canonical_pose: bool = False):
+                                 video_indexes=None, canonical_pose: bool = False, _decoder_layout=None):
         """model/environment_model.py:474-521.  The reference chunks rays (1000 per call in full-frame
         rendering) because it materialises (rays, samples, 192) tensors; the fused renderer does not
         need to, so ``samples_per_image_batching`` is accepted and ignored - the composer splits a
         call only if its scratch would exceed its workspace budget, which is exact."""
+        extra = {} if _decoder_layout is None else {"_decoder_layout": _decoder_layout}
         results = self.object_composer(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                        deformation, object_in_scene, perturb, video_indexes=video_indexes,
-                                       canonical_pose=canonical_pose)
+                                       canonical_pose=canonical_pose, **extra)
         return self.merge_dictionaries([results], dimension=ray_directions.dim() - 2)
+
+    @staticmethod
+    def decoder_layout(height: int, width: int, samples_per_image: int, patch_size: int, patch_stride, features_by_layer):
+        """Ray groups of a strided render for ``ObjectComposer.forward(_decoder_layout=...)``: one group per stride (the
+        strided grids of a full frame, or the strided patches of a training call - RayHelper.sample_all_rays_strided_grid /
+        sample_rays_strided_patch, smallest stride first), group i owning the next ``features_by_layer[i]`` channels
+        (split_features_by_layer, model/environment_model_multiresolution_backpropagated_autoencoder.py:29-61)."""
+        strides = list(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else [int(patch_stride)]
+        counts = [int(c) for c in features_by_layer]
+        if not patch_stride or len(strides) != len(counts):
+            raise ValueError(f"decoder layout: {len(counts)} feature groups need as many strides, got patch_stride={patch_stride}")
+        if patch_size != 0 and samples_per_image != 0:
+            sides = [(patch_size * strides[0]) // s for s in strides]
+            return {"rays": [p * p for p in sides], "width": sides, "channels": counts}
+        if samples_per_image != 0:
+            raise ValueError("decoder layout needs a strided full-frame render or a strided patch")
+        return {"rays": [(height // s) * (width // s) for s in strides], "width": [width // s for s in strides], "channels": counts}
 
     def merge_dictionaries(self, dictionaries: List[Dict], dimension: int):
         merged = {}
@@ -359,12 +377,14 @@ class EnvironmentModel(nn.Module):
                                     object_deformation, object_in_scene, samples_per_image: int, perturb: bool,
                                     samples_per_image_batching: int = 0, upsample_factor: float = 1.0,
                                     patch_size: int = 0, patch_stride=0, canonical_pose: bool = False,
-                                    _ray_range: Tuple[int, int] = None) -> Dict:
+                                    _ray_range: Tuple[int, int] = None, _decoder_features=None) -> Dict:
         """model/environment_model.py:1041-1158; argument shapes documented there.
 
         camera_* (..., O, C, 3); focals (..., O, C); object_* (..., O, 3|S|D, K); object_in_scene (..., O, K).
         ``_ray_range`` (extension): render only the rays [begin, end) of the pixel list - one rank's contiguous share of
-        a frame in ``render_sharded``."""
+        a frame in ``render_sharded``.  ``_decoder_features`` (extension): the decoder's feature count per stride, e.g.
+        [64, 128] - the compositing kernel then also writes ``[type]["global"]["decoder_features"]``, the channels-first
+        per-stride maps ``autoencoder_model.forward_decoder`` takes (see ``decoder_layout``)."""
         rescaled_focals = focals * self.focal_length_multiplier
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
@@ -404,9 +424,15 @@ class EnvironmentModel(nn.Module):
             rows, cols = rows[..., _ray_range[0]:_ray_range[1]], cols[..., _ray_range[0]:_ray_range[1]]
         origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
 
+        layout = None
+        if _decoder_features is not None:
+            if _ray_range is not None:
+                raise ValueError("decoder-layout emission needs all rays of the frame in one call")
+            layout = self.decoder_layout(height, width, samples_per_image, patch_size, patch_stride, _decoder_features)
         results = self.batchified_composer_call(origins, directions, normals, w2o, object_style.unsqueeze(-3),
                                                 object_deformation.unsqueeze(-3), object_in_scene.unsqueeze(-2),
-                                                perturb, samples_per_image_batching, canonical_pose=canonical_pose)
+                                                perturb, samples_per_image_batching, canonical_pose=canonical_pose,
+                                                _decoder_layout=layout)
         results["object_rotation_parameters"] = object_rotation_parameters_o2w
         results["object_translation_parameters"] = object_translation_parameters_o2w
         results["reconstructed_bounding_boxes"] = boxes
@@ -551,7 +577,8 @@ class EnvironmentModel(nn.Module):
                                   bounding_boxes_validity, global_frame_indexes, video_frame_indexes, video_indexes,
                                   samples_per_image: int, perturb: bool, samples_per_image_batching: int = 0,
                                   shuffle_style: bool = False, upsample_factor: float = 1.0, patch_size: int = 0,
-                                  patch_stride: int = 0, align_grid: bool = True, canonical_pose: bool = False) -> Dict:
+                                  patch_stride: int = 0, align_grid: bool = True, canonical_pose: bool = False,
+                                  _decoder_features=None) -> Dict:
         """model/environment_model.py:847-1039; argument shapes documented there.  observations (..., O, C, 3, H, W);
         camera_* (..., O, C, 3); focals (..., O, C); bounding_boxes (..., O, C, 4, dynamic objects);
         bounding_boxes_validity (..., O, C, dynamic objects); *_indexes (bs, O) / (bs).
@@ -604,9 +631,11 @@ class EnvironmentModel(nn.Module):
         distances = self.compute_ray_object_distances(origins, directions, o2w[..., 0, :, :, :])
         present = self._object_in_scene(bounding_boxes_validity, quirk=True)
         expanded_video_indexes, _ = torch.broadcast_tensors(video_indexes.unsqueeze(-1).unsqueeze(-1), origins[..., 0])
+        layout = None if _decoder_features is None else \
+            self.decoder_layout(height, width, samples_per_image, patch_size, patch_stride, _decoder_features)
         results = self.batchified_composer_call(origins, directions, normals, w2o, style.unsqueeze(-3), deformation.unsqueeze(-3),
                                                 present, perturb, samples_per_image_batching, expanded_video_indexes,
-                                                canonical_pose=canonical_pose)
+                                                canonical_pose=canonical_pose, _decoder_layout=layout)
         results["observations"] = sampled_observations
         results["positions"] = sampled_positions
         results["object_rotation_parameters"] = rot

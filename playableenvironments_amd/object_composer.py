@@ -116,6 +116,10 @@ class _RenderFunction(torch.autograd.Function):
                     flat.append(t)
                     if key not in GRAD_KEYS:
                         skip.append(t)
+        ctx.layout = state.get("layout")
+        if ctx.layout is not None:
+            for ty in state["types"]:
+                flat.extend(results[ty]["global"]["decoder_features"])
         ctx.exported = bool(kwargs.get("_export"))
         if ctx.exported:
             # per-sample exports as differentiable outputs: depths and displacement vectors of every object
@@ -162,6 +166,29 @@ class _RenderFunction(torch.autograd.Function):
                         g = g.to(torch.float32).reshape(shape).contiguous()
                         keep.append(g)
                         setattr(entry, key, g.data_ptr())
+        if ctx.layout is not None:
+            # gradients of the decoder-layout maps: the same numbers as global.integrated_features, channels-first per ray group
+            groups = len(ctx.layout["rays"])
+            for ty in st["types"]:
+                extra = None
+                ray0 = ch0 = 0
+                for gi in range(groups):
+                    g = grad_outputs[i]
+                    i += 1
+                    rays_i, channels_i = ctx.layout["rays"][gi], ctx.layout["channels"][gi]
+                    if g is not None:
+                        if extra is None:
+                            extra = torch.zeros((N, R, F), **f32)
+                        extra[:, ray0:ray0 + rays_i, ch0:ch0 + channels_i] = g.to(torch.float32).reshape(N, channels_i, rays_i).transpose(1, 2)
+                    ray0 += rays_i
+                    ch0 += channels_i
+                if extra is not None:
+                    entry = ogs[ty].global_
+                    if entry.integrated_features:
+                        base = next(t for t in keep if t.data_ptr() == entry.integrated_features)
+                        extra = extra + base
+                    keep.append(extra)
+                    entry.integrated_features = extra.data_ptr()
         if ctx.exported:
             for ty in st["types"]:
                 for k in range(K):
@@ -422,13 +449,18 @@ class ObjectComposer(nn.Module):
     def forward(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor, focal_normals: torch.Tensor,
                 transformation_matrix_w2o: torch.Tensor, style: torch.Tensor, deformation: torch.Tensor,
                 object_in_scene: torch.Tensor, perturb: bool, video_indexes: torch.Tensor = None,
-                canonical_pose: bool = False, _noise: Optional[dict] = None, _export: bool = False) -> Dict:
+                canonical_pose: bool = False, _noise: Optional[dict] = None, _export: bool = False,
+                _decoder_layout: Optional[dict] = None) -> Dict:
         """See model/object_composer.py:786-811 for the argument and result documentation.
 
         ray_origins (..., 3); ray_directions (..., R, 3); focal_normals (..., 3) [unused by the
         renderer, as in the reference]; transformation_matrix_w2o (..., 4, 4, K); style (..., S, K);
         deformation (..., D, K); object_in_scene (..., K).  ``_noise`` (extension, optional) replays
-        explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state.
+        explicit noise tensors keyed as in oracle/render_oracle.py; ``_export`` adds per-sample state;
+        ``_decoder_layout`` = {"rays": [R_0, R_1, ...], "width": [w_0, ...], "channels": [c_0, ...]} additionally emits
+        ``global.integrated_features`` as the channels-first maps the reference's CNN decoder consumes (the rays are the
+        concatenation of row-major grids of R_i = h_i * w_i rays; grid i owns the next c_i feature channels):
+        ``results[type]["global"]["decoder_features"]`` = [(..., c_i, h_i, w_i)], written by the compositing kernel.
 
         Autograd: with gradients enabled the call is differentiable (training mode: through the batch statistics of the
         BatchNorm layers; eval mode: with the running statistics as constants, e.g. test-time optimisation) with
@@ -442,11 +474,11 @@ class ObjectComposer(nn.Module):
             # the library launches on the caller's stream: that stream's device has to be the current one
             with torch.cuda.device(ray_directions.device):
                 return self._forward(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                                     object_in_scene, perturb, canonical_pose, _noise, _export)
+                                     object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout)
         raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
 
     def _forward(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                 object_in_scene, perturb, canonical_pose, _noise, _export) -> Dict:
+                 object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout=None) -> Dict:
         K = self.object_id_helper.objects_count
         self._raise_pending_batchnorm_check()
         if transformation_matrix_w2o.size(-1) != K:
@@ -455,7 +487,7 @@ class ObjectComposer(nn.Module):
         if not ray_directions.is_cuda:
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
         args = (ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation, object_in_scene,
-                perturb, canonical_pose, _noise, _export)
+                perturb, canonical_pose, _noise, _export, False, None, _decoder_layout)
         params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
                                                   transformation_matrix_w2o.requires_grad)
@@ -464,7 +496,7 @@ class ObjectComposer(nn.Module):
         kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
                       transformation_matrix_w2o=transformation_matrix_w2o, style=style, deformation=deformation,
                       object_in_scene=object_in_scene, perturb=perturb, canonical_pose=canonical_pose, _noise=_noise,
-                      _export=_export)
+                      _export=_export, _decoder_layout=_decoder_layout)
         return self._render_with_graph(kwargs, K, params)
 
     def _render_with_graph(self, kwargs: dict, K: int, params) -> Dict:
@@ -479,6 +511,12 @@ class ObjectComposer(nn.Module):
                 for key in ENTRY_KEYS:
                     results[ty][name][key] = flat[i]
                     i += 1
+        if kwargs.get("_decoder_layout") is not None:
+            for ty in holder["types"]:
+                maps = results[ty]["global"]["decoder_features"]
+                for j in range(len(maps)):
+                    maps[j] = flat[i]
+                    i += 1
         if kwargs.get("_export"):
             for ty in holder["types"]:
                 samples = results[ty]["_samples"][0]
@@ -488,7 +526,8 @@ class ObjectComposer(nn.Module):
         return results
 
     def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False, _object_ids=None):
+                object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False, _object_ids=None,
+                _decoder_layout=None):
         """The renderer call proper.  Returns (results, state); ``state`` (only with ``_save``) keeps what
         pr_render_backward needs: the call structures, their tensors and the forward workspace.
         ``_object_ids``: render only these object instances (the tensors then carry ``len(_object_ids)`` objects);
@@ -672,6 +711,17 @@ class ObjectComposer(nn.Module):
             chunk = max(1, int(R * budget / need))
             chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
         F = models_c[0].nerf_model.output_features
+        layout = None
+        if _decoder_layout is not None:
+            layout = {k: [int(v) for v in _decoder_layout[k]] for k in ("rays", "width", "channels")}
+            groups = len(layout["rays"])
+            if not (1 <= groups <= _lib.PR_MAX_DECODER_GROUPS) or len(layout["width"]) != groups or len(layout["channels"]) != groups:
+                raise ValueError(f"decoder layout: 1..{_lib.PR_MAX_DECODER_GROUPS} groups with rays / width / channels each, got {_decoder_layout}")
+            if sum(layout["rays"]) != R or sum(layout["channels"]) > F or any(r % w for r, w in zip(layout["rays"], layout["width"])):
+                raise ValueError(f"decoder layout {layout} does not describe {R} rays with {F} feature channels")
+            if chunk != R:
+                raise RuntimeError("decoder-layout emission needs the whole call in one launch (the call was split along the rays "
+                                   "to fit the workspace budget)")
 
         pieces = []
         for r0 in range(0, R, chunk):
@@ -707,6 +757,17 @@ class ObjectComposer(nn.Module):
                     for name in ENTRY_KEYS:
                         setattr(entry, name, e[name].data_ptr())
                     res[f"object_{k}" if k < K else "global"] = e
+                if layout is not None:
+                    begin = 0
+                    maps = []
+                    o.decoder.groups = len(layout["rays"])
+                    for i, (rays_i, width_i, channels_i) in enumerate(zip(layout["rays"], layout["width"], layout["channels"])):
+                        maps.append(torch.empty((N, channels_i, rays_i // width_i, width_i), **f32))
+                        o.decoder.rays[i], o.decoder.width[i] = rays_i, width_i
+                        o.decoder.channel_begin[i], o.decoder.channel_end[i] = begin, begin + channels_i
+                        o.decoder.map[i] = maps[-1].data_ptr()
+                        begin += channels_i
+                    res["_decoder"] = maps
                 if self.training:
                     res["_normalised"] = torch.zeros((K,), dtype=torch.int32, device=dev)
                     o.normalised_samples = res["_normalised"].data_ptr()
@@ -736,7 +797,7 @@ class ObjectComposer(nn.Module):
             if _save:
                 state = dict(call=call, objs=objs, keep=keep + packed_keep + [origins, w2o, sty, dfm, present], workspace=workspace,
                              N=N, R=R, K=K, S=S, D=D, F=F, lead=lead, models=models_c, models_fine=models_f, types=types,
-                             ptot=ptot)
+                             ptot=ptot, layout=layout)
 
         if self.training:
             self.last_normalised_samples = {ty: pieces[0][ty]["_normalised"] for ty in types}
@@ -773,6 +834,8 @@ class ObjectComposer(nn.Module):
                 results[ty][name] = entry
             if _export:
                 results[ty]["_samples"] = [p[ty]["_samples"] for p in pieces]
+            if layout is not None:
+                results[ty]["global"]["decoder_features"] = [m.reshape(lead + list(m.shape[1:])) for m in pieces[0][ty]["_decoder"]]
         results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
         return results, (state if _save else None)
 

@@ -1575,3 +1575,74 @@ def test_native_observation_pipeline_end_to_end():
     assert any(n.startswith("object_encoders.0.final_backbone") for n in touched)
     assert any(n.startswith("object_parameters_encoders.2.rotation_head") for n in touched)
     assert any(n.startswith("object_composer.object_models_coarse.2.nerf_model") for n in touched)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# renderer -> decoder wire format emitted by the compositing kernel
+@pytest.mark.parametrize("mode", ["full_frame", "training_patch"])
+def test_decoder_layout_emission_matches_wire_format(mode):
+    """``decoder_features`` written by k_composite (channels-first map per stride, the stride's own channel slice) against
+    the reference's glue restated in wire_format.py (fold / split by stride, split_features_by_layer, permute), applied to
+    the ray-major integrated features of the SAME call: bit for bit; and the gradient that arrives through the maps equals
+    the gradient that arrives through the ray-major tensor."""
+    from playableenvironments_amd import wire_format as wf
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    cfg = configs.reduced_config(configs.minecraft_config(), **small)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    model = model.cuda().eval()
+    size = (48, 64)
+    scene = synthetic.minecraft_scene(batch=2, observations=2, seed=23, image_size=size)
+    sc = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in scene.items()}
+    args = [sc[k] for k in ("camera_rotations", "camera_translations", "focals")] + [size] + \
+           [sc[k] for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation",
+                            "object_in_scene")]
+    counts = [8, 24]
+    if mode == "full_frame":
+        kw = dict(samples_per_image=0, perturb=False, patch_stride=[4, 8])
+    else:
+        kw = dict(samples_per_image=10, perturb=False, patch_size=8, patch_stride=[4, 8])
+    for a in args:
+        if torch.is_tensor(a) and a.is_floating_point():
+            a.requires_grad_(False)
+    style = args[6].clone().requires_grad_(True)
+    args[6] = style
+    torch.manual_seed(3)
+    out = model(*args[:9], kw["samples_per_image"], kw["perturb"], patch_size=kw.get("patch_size", 0), patch_stride=kw["patch_stride"],
+                _decoder_features=counts, mode="scene_encodings")
+    feats = out["coarse"]["global"]["integrated_features"]                      # (2, 2, 1, R, 32)
+    maps = out["coarse"]["global"]["decoder_features"]
+    if mode == "full_frame":
+        folded = wf.fold_strided_grid_samples(feats, [4, 8], size, dim=3)        # [(.., h, w, F)] per stride
+    else:
+        folded = [wf.strided_patch_ray_samples_to_patch(t) for t in wf.split_strided_patch_ray_samples(feats, 8, [4, 8])]
+    # channels-first slice of stride i (the patch helper already returns (..., C, p, p); the grid fold returns (..., h, w, C))
+    chw = (lambda f, b, c: f[..., b:b + c].movedim(-1, -3)) if mode == "full_frame" else (lambda f, b, c: f[..., b:b + c, :, :])
+    begin = 0
+    for i, (m, f) in enumerate(zip(maps, folded)):
+        want = chw(f, begin, counts[i])
+        assert tuple(m.shape) == tuple(want.shape), (m.shape, want.shape)
+        assert torch.equal(m, want), i
+        begin += counts[i]
+    # gradients: a loss on the maps == the same loss on the corresponding slices of the ray-major features
+    g = torch.Generator().manual_seed(1)
+    probes = [torch.randn(m.shape, generator=g).cuda() for m in maps]
+    sum((m * p).sum() for m, p in zip(maps, probes)).backward()
+    via_maps = style.grad.clone()
+    style.grad = None
+    torch.manual_seed(3)
+    again = model(*args[:9], kw["samples_per_image"], kw["perturb"], patch_size=kw.get("patch_size", 0), patch_stride=kw["patch_stride"],
+                  mode="scene_encodings")
+    feats = again["coarse"]["global"]["integrated_features"]
+    if mode == "full_frame":
+        folded = wf.fold_strided_grid_samples(feats, [4, 8], size, dim=3)
+    else:
+        folded = [wf.strided_patch_ray_samples_to_patch(t) for t in wf.split_strided_patch_ray_samples(feats, 8, [4, 8])]
+    begin, loss = 0, 0.0
+    for i, f in enumerate(folded):
+        loss = loss + (chw(f, begin, counts[i]) * probes[i]).sum()
+        begin += counts[i]
+    loss.backward()
+    assert float(via_maps.abs().max()) > 0
+    assert torch.allclose(via_maps, style.grad, rtol=1e-5, atol=1e-7)
