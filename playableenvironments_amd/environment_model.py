@@ -351,6 +351,11 @@ class EnvironmentModel(nn.Module):
             if torch.is_tensor(dictionaries[0][key]):
                 parts = [d[key] for d in dictionaries]
                 merged[key] = parts[0] if len(parts) == 1 else torch.cat(parts, dim=dimension)
+            elif isinstance(dictionaries[0][key], (list, tuple)):
+                # per-stride maps of the decoder layout: whole-call outputs, never split along the rays
+                if len(dictionaries) != 1:
+                    raise ValueError(f"'{key}' cannot be merged across ray chunks")
+                merged[key] = dictionaries[0][key]
             else:
                 merged[key] = self.merge_dictionaries([d[key] for d in dictionaries], dimension)
         return merged
