@@ -11,6 +11,8 @@
 // compact fp32 rows, so each layer's backward is two dense products - dX = dY.W and dW = dY^T.X (gemm.hip,
 // exact fp32 MFMA) - plus thin elementwise kernels.  Gradient buffers are accumulated into.
 #include "pr_common.h"
+
+#include <algorithm>
 #include "composite_dev.h"
 
 namespace pr {
@@ -830,9 +832,12 @@ namespace pr {
 struct BwdPlan {
     size_t g_feat[PR_MAX_OBJECTS], g_sigma[PR_MAX_OBJECTS], g_t[PR_MAX_OBJECTS], g_dm[PR_MAX_OBJECTS];
     size_t bufA, bufB, act, g_enc, gsr, gdr, g_bent, g_x, g_braw, g_in6, partial, sums, tables;
+    size_t gstack, chain_packed;      // layer-chained backward: per-layer pre-activation gradients, W^T fragments
+    size_t gstack_bytes;              // 0: the chained path is off for this call (too large), layer-by-layer products instead
     size_t bytes;
     size_t max_cap;
 };
+constexpr size_t CHAIN_GSTACK_LIMIT = (size_t)16 << 30;   // calls whose chains would need more scratch go layer by layer
 
 static size_t align_up_b(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -866,7 +871,31 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     bp->g_x = take(sizeof(float) * max_cap * 3);
     bp->g_braw = take(sizeof(float) * max_cap * 3);
     bp->g_in6 = take(sizeof(float) * max_cap * 6);
-    bp->partial = take(sizeof(float) * gemm_tn_scratch_floats(BWD_SPLITS));
+    // layer-chained backward (k_chain_bwd): scratch for the largest chain of the call, one partial region per grouped product
+    size_t gstack_need = 0, packed_need = 0;
+    for (int k = 0; k < c.objects; ++k)
+        for (int t = 0; t < (c.use_fine ? 2 : 1); ++t) {
+            const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+            ModelDims d;
+            PR_TRY(compute_dims(m, &d));
+            const size_t cap = nr * m.positions;
+            gstack_need = std::max(gstack_need, sizeof(float) * cap * d.Wpad * (size_t)(m.backbone_count - 1));
+            packed_need = std::max(packed_need, chain_bwd_packed_bytes(m.backbone_count, d.W, d.enc));
+            if (m.has_bender) {
+                gstack_need = std::max(gstack_need, sizeof(float) * cap * d.BWpad * (size_t)(m.bender_count - 1));
+                packed_need = std::max(packed_need, chain_bwd_packed_bytes(m.bender_count, d.BW, d.bin));
+            }
+        }
+#ifdef PR_BWD_LAYERWISE
+    gstack_need = CHAIN_GSTACK_LIMIT + 1;     // measurement build: one product per layer and launch
+#endif
+    const bool chained = gstack_need <= CHAIN_GSTACK_LIMIT;
+    bp->gstack_bytes = chained ? gstack_need : 0;
+    if (chained) {
+        bp->gstack = take(gstack_need);
+        bp->chain_packed = take(packed_need);
+    }
+    bp->partial = take(sizeof(float) * gemm_tn_scratch_floats(BWD_SPLITS) * (chained ? MAX_TN_GROUP : 1));
     bp->sums = take(sizeof(double) * 2 * MAX_WIDTH);
     bp->tables = take(sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH);
     bp->bytes = off;
@@ -878,6 +907,9 @@ struct GemmCtx {
     int max_rows;
     float* partial;
     hipStream_t s;
+    float* gstack;          // layer-chained path (NULL: layer by layer)
+    float* chain_packed;
+    size_t cap;             // row capacity of the per-layer buffers
 };
 
 static int weight_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, const float* X, int ldx, int n_in, float* dW,
@@ -905,12 +937,59 @@ static int input_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, con
     return launch_gemm_nn(p, g.max_rows, g.s);
 }
 
+// Layer-chained variant of chain_backward: ONE launch for every input-gradient product of the chain (k_chain_bwd keeps
+// the running gradient in LDS), then ONE grouped launch (+ its reduction) for every weight / bias gradient.
+static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, const pr_linear_grad_t* grads, int count, int skip,
+                                int width, int width_pad, const float* acts, size_t act_stride, const float* in0, int ld_in0,
+                                int n_in0, const float* cur, float* g_in) {
+    ChainBwdParams cp;
+    memset(&cp, 0, sizeof(cp));
+    PR_TRY(prepare_chain_bwd(layers, count, skip, width, n_in0, g.chain_packed, &cp, g.s));
+    PR_REQUIRE(cp.Wpad == width_pad && ld_in0 >= cp.in_pad, "backward chain: padded widths %d / %d do not match the saved rows", cp.Wpad, cp.in_pad);
+    cp.total = g.rows;
+    cp.g_last = cur;
+    cp.acts = acts; cp.act_stride = act_stride;
+    cp.gstack = g.gstack; cp.g_stride = g.cap * (size_t)width_pad;
+    cp.g_in = g_in; cp.ld_in = ld_in0;
+    PR_TRY(launch_chain_bwd(cp, g.max_rows, g.s));
+    GemmTNGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    const size_t region = gemm_tn_scratch_floats(BWD_SPLITS);
+    auto add = [&](const float* dY, const float* X, int ldx, int n_in, float* dW, int ldw, float* dbias) -> int {
+        if (!dW) return PR_OK;
+        PR_REQUIRE(grp.count < MAX_TN_GROUP, "backward chain: too many weight-gradient products");
+        GemmTN& p = grp.job[grp.count];
+        p.A = dY; p.lda = width_pad; p.B = X; p.ldb = ldx;
+        p.rows = g.rows; p.ni = width; p.nj = n_in; p.splits = BWD_SPLITS;
+        p.partial = g.partial + (size_t)grp.count * region;
+        p.bias_partial = dbias ? p.partial + (size_t)BWD_SPLITS * 256 * 384 : nullptr;
+        p.bias = dbias;
+        p.C = dW; p.ldc = ldw;
+        ++grp.count;
+        return PR_OK;
+    };
+    for (int l = count - 1; l >= 0; --l) {
+        const float* dY = (l == count - 1) ? cur : g.gstack + (size_t)l * cp.g_stride;
+        PR_REQUIRE(!grads[l].bias || grads[l].weight, "a bias gradient buffer needs its weight gradient buffer");
+        if (l == 0) {
+            PR_TRY(add(dY, in0, ld_in0, n_in0, grads[l].weight, layers[l].in_features, grads[l].bias));
+        } else {
+            PR_TRY(add(dY, acts + (size_t)(l - 1) * act_stride, width_pad, width, grads[l].weight, layers[l].in_features, grads[l].bias));
+            if (l == skip)
+                PR_TRY(add(dY, in0, ld_in0, n_in0, grads[l].weight ? grads[l].weight + width : nullptr, layers[l].in_features, nullptr));
+        }
+    }
+    if (grp.count) PR_TRY(launch_gemm_tn_group(grp, g.s));
+    return PR_OK;
+}
+
 // Backward through a ReLU MLP with one skip concatenation (backbone of the NeRF or of the ray bender).
 // On entry `cur` holds d loss / d pre-activation of the last layer; `acts` are the saved post-ReLU outputs.
 // Returns with the gradient of the network input [PE | extra] accumulated in g_in (n_in0 real columns).
 static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_linear_grad_t* grads, int count, int skip,
                           int width, int width_pad, const float* acts, size_t act_stride, const float* in0, int ld_in0,
                           int n_in0, float* cur, float* other, float* g_in) {
+    if (g.gstack) return chain_backward_fused(g, layers, grads, count, skip, width, width_pad, acts, act_stride, in0, ld_in0, n_in0, cur, g_in);
     bool g_in_written = false;
     for (int l = count - 1; l >= 0; --l) {
         const pr_linear_t& L = layers[l];
@@ -1010,6 +1089,9 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         rc.samples_per_frame = c.rays * P;
         GemmCtx gc;
         gc.rows = totals + k; gc.max_rows = (int)cap; gc.partial = reinterpret_cast<float*>(bws + bp.partial); gc.s = s;
+        gc.gstack = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.gstack) : nullptr;
+        gc.chain_packed = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.chain_packed) : nullptr;
+        gc.cap = cap;
 
         const float* rec_pos = reinterpret_cast<const float*>(fws + sv.rec_pos);
         const float* enc = reinterpret_cast<const float*>(fws + sv.enc);

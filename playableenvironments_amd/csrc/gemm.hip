@@ -188,16 +188,13 @@ __device__ __forceinline__ int tn_chunk(int M, int splits) {
     return (chunk + GK - 1) / GK * GK;
 }
 
-__global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
-    __shared__ __attribute__((aligned(16))) float SA[GK * GLD];   // [sample][i]
-    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];   // [sample][j]
+__device__ __forceinline__ void gemm_tn_body(const GemmTN& p, int tile, int split, float* SA, float* SB) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
     const int tiles_j = (p.nj + GT - 1) / GT;
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
     const int i0 = ti * GT, j0 = tj * GT;
-    const int split = blockIdx.y;
     const int chunk = tn_chunk(M, p.splits);
     const int m_begin = split * chunk;
     if (m_begin >= M && split > 0) return;   // split 0 always writes (M == 0 -> zeros)
@@ -271,8 +268,34 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
     if (p.bias_partial && tj == 0 && tid < GT) p.bias_partial[(size_t)split * rows_p + i0 + tid] = bsum;
 }
 
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(GemmTN p) {
+    __shared__ __attribute__((aligned(16))) float SA[GK * GLD];   // [sample][i]
+    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];   // [sample][j]
+    gemm_tn_body(p, blockIdx.x, blockIdx.y, SA, SB);
+}
+
+// one launch for several products over the same rows: blockIdx.z picks the job; jobs with fewer tiles leave blocks idle
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_group(GemmTNGroup g) {
+    __shared__ __attribute__((aligned(16))) float SA[GK * GLD];
+    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];
+    const GemmTN& p = g.job[blockIdx.z];
+    const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+    if ((int)blockIdx.x >= tiles) return;
+    gemm_tn_body(p, blockIdx.x, blockIdx.y, SA, SB);
+}
+
+__device__ __forceinline__ void gemm_tn_reduce_body(const GemmTN& p, long idx);
+
 // C[i][j] += sum_s P[s][i][j] in split order; bias[i] += sum_s PB[s][i]
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(GemmTN p) {
+    gemm_tn_reduce_body(p, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce_group(GemmTNGroup g) {
+    gemm_tn_reduce_body(g.job[blockIdx.y], (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+__device__ __forceinline__ void gemm_tn_reduce_body(const GemmTN& p, long idx) {
     const int M = *p.rows;
     const int chunk = tn_chunk(M, p.splits);
     int active = (M + chunk - 1) / chunk;
@@ -280,7 +303,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(GemmTN p) {
     const int tiles_j = (p.nj + GT - 1) / GT;
     const int ldp = tiles_j * GT;
     const int rows_p = ((p.ni + GT - 1) / GT) * GT;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx < (long)p.ni * p.nj) {
         const int i = (int)(idx / p.nj), j = (int)(idx - (long)i * p.nj);
         const float* __restrict__ src = p.partial + (size_t)i * ldp + j;
@@ -320,6 +342,28 @@ int launch_gemm_tn(const GemmTN& p, hipStream_t s) {
     PR_LAUNCH_CHECK();
     const long n = (long)p.ni * p.nj;
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+int launch_gemm_tn_group(const GemmTNGroup& g, hipStream_t s) {
+    PR_REQUIRE(g.count >= 1 && g.count <= MAX_TN_GROUP, "gemm_tn group: %d jobs", g.count);
+    int max_tiles = 0;
+    long max_elems = 0;
+    for (int q = 0; q < g.count; ++q) {
+        const GemmTN& p = g.job[q];
+        PR_REQUIRE(p.ni <= 256 && p.nj <= 384, "gemm_tn: %d x %d exceeds the partial buffer", p.ni, p.nj);
+        PR_REQUIRE((p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 &&
+                   p.lda >= ((p.ni + 3) & ~3) && p.ldb >= ((p.nj + 3) & ~3), "gemm_tn: operands must be 16-byte aligned rows");
+        PR_REQUIRE(p.splits == g.job[0].splits && p.rows == g.job[0].rows && p.partial, "gemm_tn group: jobs must share rows and splits");
+        const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+        if (tiles > max_tiles) max_tiles = tiles;
+        if ((long)p.ni * p.nj > max_elems) max_elems = (long)p.ni * p.nj;
+    }
+    ProfileScope scope(3, s);
+    hipLaunchKernelGGL(k_gemm_tn_group, dim3(max_tiles, g.job[0].splits, g.count), dim3(256), 0, s, g);
+    PR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gemm_tn_reduce_group, dim3((unsigned)((max_elems + 255) / 256), g.count), dim3(256), 0, s, g);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }

@@ -120,6 +120,7 @@ struct PackJob {
     int col_off;
     int k_real, n_real, kq, nblk;
     int count;      // elements of dst
+    int transposed; // kind 0: element (n, k) is read from src[k * in_total + col_off + n] (the backward chain's W^T)
 };
 constexpr int MAX_PACK_JOBS = 56;
 struct PackJobs {
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
             const int nb = rest / j.kq;
             const int n = nb * 32 + (lane & 31);
             const int k = (lane >> 5) * 4 * j.kq + 4 * q + e;
-            if (n < j.n_real && k < j.k_real) v = j.src[(size_t)n * j.in_total + j.col_off + k];
+            if (n < j.n_real && k < j.k_real)
+                v = j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k];
         } else if (j.kind == 2) {
             // split fragments: per (column block, 16-wide K step): 64 lanes x 8 halves "hi", then the same for
             // "lo" = w - hi (mostly an fp16 subnormal: the matrix pipe takes those exactly).  Lane l holds W[nb*32 + (l & 31)][16 s + 8 (l >> 5) + e], e = 0..7.
@@ -188,6 +190,7 @@ static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real
     j.kq = kpad / 8;
     j.nblk = npad / 32;
     j.count = seg_floats(j.nblk, kpad);
+    j.transposed = 0;
     return PR_OK;
 }
 
@@ -204,6 +207,7 @@ static int add_vec(PackJobs* js, const float* src, int rows, int row_real, int r
     j.kq = row_pad;
     j.nblk = 0;
     j.count = rows * row_pad;
+    j.transposed = 0;
     return PR_OK;
 }
 
@@ -443,7 +447,9 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     PR_MFMA(acc, a.z, b.z); \
     PR_MFMA(acc, a.w, b.w)
 
-__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc);
+template <bool BWD = false>
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
+                                          const BwdEpilogue* bwd = nullptr);
 
 // Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
 //   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
@@ -555,7 +561,9 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     }
 }
 
-__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc) {
+template <bool BWD>
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
+                                          const BwdEpilogue* bwd) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
@@ -577,7 +585,7 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     }
     for (int sidx = 0; sidx < L.nseg; ++sidx) {
         const Seg& sg = L.seg[sidx];
-        if (sg.src == 1 && sidx > 0) {
+        if (!BWD && sg.src == 1 && sidx > 0) {
             // second K segment of a skip layer: its operand is the network input, re-encoded over the
             // (now dead) activations of the first segment
             __syncthreads();
@@ -655,6 +663,68 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     return;   // measurement build: no barriers, no epilogue (results are wrong)
 #endif
     PR_PHASE(3);
+    if (BWD) {
+        // Backward chain (k_chain_bwd): the tile holds d loss / d pre-activation of a layer, the product is its input
+        // gradient.  EPI_BWD_GLOBAL: the rows go straight to global memory (the gradient of the network input: X keeps the
+        // operand, which the next product of the same layer still needs); EPI_BWD_MASK: ReLU backward with the saved
+        // post-ReLU activation of the previous layer as the mask (a bit image of the tile in LDS), result back into X.
+        const int rows_valid = bwd->rows_valid;
+        if (L.epi == EPI_BWD_GLOBAL) {
+            if (active) {
+                for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+                    const int col = (blk ? cbB : cbA) * 32 + r;
+                    const f32x16& lo = blk ? a10 : a00;
+                    const f32x16& hi = blk ? a11 : a01;
+                    if (col < bwd->n_real) {
+                        // one base pointer per lane, row offsets are wave-uniform multiples of the leading dimension
+                        float* base = bwd->gout + (size_t)(tile_base + 4 * half) * bwd->ldg + col;
+                        const int ldg = bwd->ldg;
+                        const int limit = rows_valid - 4 * half;       // rows of this lane: PR_ACC_ROW(i) (+ 32) < limit
+                        float old_lo[16], old_hi[16];
+                        if (bwd->accumulate) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                old_lo[i] = PR_ACC_ROW(i) < limit ? base[PR_ACC_ROW(i) * ldg] : 0.f;
+                                old_hi[i] = PR_ACC_ROW(i) + 32 < limit ? base[(PR_ACC_ROW(i) + 32) * ldg] : 0.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) old_lo[i] = old_hi[i] = 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            if (PR_ACC_ROW(i) < limit) base[PR_ACC_ROW(i) * ldg] = lo[i] + old_lo[i];
+                            if (PR_ACC_ROW(i) + 32 < limit) base[(PR_ACC_ROW(i) + 32) * ldg] = hi[i] + old_hi[i];
+                        }
+                    }
+                }
+            }
+            return;    // X untouched: no barrier needed
+        }
+        __syncthreads();  // every wave has finished reading X (and the mask bits of this layer are complete)
+        if (active) {
+            // bit (row, col) of the ReLU mask: byte row * (width / 8) + col / 8 of the tile's bit image (built by
+            // build_relu_mask_bits before the product), bit col % 8
+            const unsigned char* bits = bwd->mask_bits;
+            const int bpr = bwd->mask_bytes_per_row;
+            for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+                const int col = (blk ? cbB : cbA) * 32 + r;
+                const f32x16& lo = blk ? a10 : a00;
+                const f32x16& hi = blk ? a11 : a01;
+                float* x0 = S.X + (4 * half) * LDX + col;
+                const unsigned char* b0 = bits + (4 * half) * bpr + (col >> 3);
+                const int bit = col & 7;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = PR_ACC_ROW(i);
+                    x0[ro * LDX] = ((b0[ro * bpr] >> bit) & 1) ? lo[i] : 0.f;
+                    x0[(ro + 32) * LDX] = ((b0[(ro + 32) * bpr] >> bit) & 1) ? hi[i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
     __syncthreads();  // every wave has finished reading X
     PR_PHASE(4);
 #if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 8)
@@ -1350,6 +1420,143 @@ int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const Packe
     h6.n_real = d.F;
     h6.bias = base + l.h6_bias_off;
     h6.epi = EPI_FEATURES;
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward chain of a ReLU MLP with one skip concatenation (NeRF backbone, ray bender): the input gradients of ALL its
+// layers in one launch.  A persistent workgroup owns a 64-sample tile: G = d loss / d pre-activation of the last layer is
+// loaded into X; for l = count - 1 .. 1:  dX = G . W_l[:, :width]  on the matrix cores (W^T as fragment-ordered segments,
+// packed per backward call), masked with the saved post-ReLU activation of layer l - 1 -> the new G, which stays in LDS
+// for the next layer and is written once to `gstack[l - 1]` for the weight-gradient products (one grouped launch over
+// all layers afterwards).  The input parts of the skip layer and of layer 0 go straight to `g_in` (store, then
+// accumulate).  Compared with one dX GEMM per layer this removes a read of dY and a separate mask pass per layer, and
+// - what matters for calls with a few thousand samples per object - 2 x count launches whose tiles fill a fraction of
+// the chip for a fraction of a round each.
+// ---------------------------------------------------------------------------------------------
+// ReLU mask of a tile as one bit per element: bit (row, col) = saved post-ReLU activation > 0.  Coalesced 16-byte loads of the
+// 64 x width activation rows, eight columns -> one byte of the bit image (2 KB at width 256; it lives in Smem::pos, which
+// the backward chain does not use otherwise).  Rows beyond the tile's real rows get zero bits.
+__device__ __forceinline__ void build_relu_mask_bits(unsigned char* bits, const float* acts, int ld, int width_pad, int tile_base,
+                                                     int rows_valid) {
+    const int c8n = width_pad >> 3;
+    for (int idx = threadIdx.x; idx < TILE_M * c8n; idx += MLP_THREADS) {
+        const int row = idx / c8n, c8 = idx - row * c8n;
+        unsigned int byte = 0;
+        if (row < rows_valid) {
+            const float* src = acts + (size_t)(tile_base + row) * ld + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            byte = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u) |
+                   (b.x > 0.f ? 16u : 0u) | (b.y > 0.f ? 32u : 0u) | (b.z > 0.f ? 64u : 0u) | (b.w > 0.f ? 128u : 0u);
+        }
+        bits[idx] = (unsigned char)byte;
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd(ChainBwdParams c) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = *c.total;
+    const MlpParams& unused = *reinterpret_cast<const MlpParams*>(smem_raw);   // never dereferenced by run_layer<true>
+    EncRegs enc;
+    const int w4 = c.Wpad >> 2;
+    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+        const int tile_base = tile * TILE_M;
+        const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
+        if (tid < TILE_M) S.flags[tid] = tid < rows_valid ? 1 : 0;
+        // G of the last layer
+        for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+            const int row = idx / w4, c4 = (idx - row * w4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_valid) v = *reinterpret_cast<const float4*>(c.g_last + (size_t)(tile_base + row) * c.Wpad + c4);
+            *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
+        }
+        __syncthreads();
+        BwdEpilogue e;
+        e.rows_valid = rows_valid;
+        e.mask_bits = reinterpret_cast<const unsigned char*>(S.pos);
+        e.mask_bytes_per_row = c.Wpad >> 3;
+        bool g_in_written = false;
+        for (int l = c.count - 1; l >= 1; --l) {
+            // the ReLU mask of this layer's input (layer l - 1's output) -> bits, visible after the barrier inside run_layer
+            build_relu_mask_bits(reinterpret_cast<unsigned char*>(S.pos), c.acts + (size_t)(l - 1) * c.act_stride, c.Wpad, c.Wpad,
+                                 tile_base, rows_valid);
+            if (l == c.skip) {
+                e.gout = c.g_in; e.ldg = c.ld_in; e.accumulate = 0; e.n_real = c.in_real;
+                run_layer<true>(c.in0_skip, S, unused, tile_base, 0, enc, &e);
+                g_in_written = true;
+            }
+            e.gout = nullptr; e.n_real = c.W;
+            run_layer<true>(c.act_layers[l], S, unused, tile_base, 0, enc, &e);
+            // the pre-activation gradient of layer l - 1, for its weight-gradient product
+            write_tile_rows(S, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, false);
+        }
+        e.gout = c.g_in; e.ldg = c.ld_in; e.accumulate = g_in_written ? 1 : 0; e.n_real = c.in_real;
+        run_layer<true>(c.in0_first, S, unused, tile_base, 0, enc, &e);
+        __syncthreads();   // the next tile's loads overwrite X and the flags
+    }
+}
+
+static size_t chain_packed_floats(int count, int Wpad, int in_pad) {
+    return (size_t)(count - 1) * seg_floats(Wpad / 32, Wpad) + 2 * (size_t)seg_floats(in_pad / 32, Wpad);
+}
+
+size_t chain_bwd_packed_bytes(int count, int width, int in_features) {
+    return sizeof(float) * chain_packed_floats(count, round_up(width, 32), round_up(in_features, 32));
+}
+
+// Packs W_l^T of every layer of the chain (fragment order of run_layer) into `packed` and fills the layer tables of `c`.
+int prepare_chain_bwd(const pr_linear_t* layers, int count, int skip, int width, int in_features, float* packed,
+                      ChainBwdParams* c, hipStream_t s) {
+    const int Wpad = round_up(width, 32), in_pad = round_up(in_features, 32);
+    PR_REQUIRE(count >= 2 && count <= PR_MAX_LAYERS && Wpad <= MAX_WIDTH && in_pad <= MAX_ENC, "backward chain: unsupported shape");
+    PackJobs jobs;
+    jobs.n = 0;
+    jobs.seg_kind = 0;
+    float* at = packed;
+    auto seg = [&](const pr_linear_t& lin, int col_off, int n_real, int npad, Layer* L) -> int {
+        // out[m][n] = sum_k G[m][k] W[k][col_off + n]:  K = the layer's outputs (width), N = its inputs
+        PR_TRY(add_seg(&jobs, lin, col_off, width, Wpad, npad, at));
+        PackJob& j = jobs.job[jobs.n - 1];
+        j.n_real = n_real;
+        j.transposed = 1;
+        memset(L, 0, sizeof(*L));
+        L->seg[0] = Seg{at, Wpad / 8, 0};
+        L->nseg = 1;
+        L->nblk = npad / 32;
+        L->n_real = n_real;
+        at += seg_floats(npad / 32, Wpad);
+        return PR_OK;
+    };
+    for (int l = 1; l < count; ++l) {
+        PR_REQUIRE(layers[l].out_features == width && layers[l].in_features == (l == skip ? width + in_features : width),
+                   "backward chain: layer %d has shape (%d, %d)", l, layers[l].out_features, layers[l].in_features);
+        PR_TRY(seg(layers[l], 0, width, Wpad, &c->act_layers[l]));
+        c->act_layers[l].epi = EPI_BWD_MASK;
+    }
+    PR_REQUIRE(skip >= 1 && skip < count, "backward chain: skip layer %d", skip);
+    PR_TRY(seg(layers[skip], width, in_features, in_pad, &c->in0_skip));
+    c->in0_skip.epi = EPI_BWD_GLOBAL;
+    PR_REQUIRE(layers[0].out_features == width && layers[0].in_features == in_features, "backward chain: first layer shape");
+    PR_TRY(seg(layers[0], 0, in_features, in_pad, &c->in0_first));
+    c->in0_first.epi = EPI_BWD_GLOBAL;
+    c->count = count; c->skip = skip; c->W = width; c->Wpad = Wpad; c->in_pad = in_pad; c->in_real = in_features;
+    hipLaunchKernelGGL(k_pack, dim3(64, jobs.n), dim3(256), 0, s, jobs);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+int launch_chain_bwd(const ChainBwdParams& c, int max_rows, hipStream_t s) {
+    if (max_rows <= 0) return PR_OK;
+    int cu_count = 0;
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_chain_bwd), (int)sizeof(Smem), &cu_count));
+    const int max_tiles = (max_rows + TILE_M - 1) / TILE_M;
+    const int resident = cu_count * MLP_BLOCKS_PER_CU;
+    ProfileScope scope(2, s);
+    hipLaunchKernelGGL(k_chain_bwd, dim3(max_tiles < resident ? max_tiles : resident), dim3(MLP_THREADS), sizeof(Smem), s, c);
+    PR_LAUNCH_CHECK();
     return PR_OK;
 }
 

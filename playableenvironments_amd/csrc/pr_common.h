@@ -57,7 +57,7 @@ struct Seg {
     int src;            // 0 = activation buffer X, 1 = encoding buffer E
 };
 
-enum Epilogue { EPI_RELU = 0, EPI_ADAIN_RELU = 1, EPI_FEATURES = 2 };
+enum Epilogue { EPI_RELU = 0, EPI_ADAIN_RELU = 1, EPI_FEATURES = 2, EPI_BWD_MASK = 3, EPI_BWD_GLOBAL = 4 };
 
 struct Layer {
     Seg seg[2];
@@ -68,6 +68,31 @@ struct Layer {
     int adain_off;      // offset (floats) of [g | b] of this layer inside one AdaIN table row
     int n_real;         // real out features
 };
+
+// Epilogue operands of the backward chain kernel (run_layer<true>, mlp.hip).
+struct BwdEpilogue {
+    const unsigned char* mask_bits; int mask_bytes_per_row;   // EPI_BWD_MASK: bit image (LDS) of "saved activation > 0" of the tile
+    float* gout; int ldg;         // EPI_BWD_GLOBAL: destination rows in global memory
+    int accumulate;               // EPI_BWD_GLOBAL: add to the destination
+    int n_real;                   // real (unpadded) width of the product
+    int rows_valid;               // real rows of the tile
+};
+
+// Backward chain of a ReLU MLP with one skip concatenation: all input-gradient products in one launch (k_chain_bwd).
+struct ChainBwdParams {
+    const int32_t* total;
+    int count, skip, W, Wpad, in_pad, in_real;
+    Layer act_layers[PR_MAX_LAYERS];   // l = 1 .. count - 1: W_l[:, :W]^T
+    Layer in0_skip, in0_first;         // W_skip[:, W:]^T and W_0^T (gradient of the network input)
+    const float* g_last;               // (cap, Wpad) d loss / d pre-activation of the last layer
+    const float* acts; size_t act_stride;   // saved post-ReLU outputs of layers 0 .. count - 1, (cap, Wpad) each
+    float* gstack; size_t g_stride;    // out: pre-activation gradients of layers 0 .. count - 2, (cap, Wpad) each
+    float* g_in; int ld_in;            // out: gradient of the network input (cap, ld_in)
+};
+size_t chain_bwd_packed_bytes(int count, int width, int in_features);
+int prepare_chain_bwd(const pr_linear_t* layers, int count, int skip, int width, int in_features, float* packed,
+                      ChainBwdParams* c, hipStream_t s);
+int launch_chain_bwd(const ChainBwdParams& c, int max_rows, hipStream_t s);
 
 // Offsets (in floats) inside the packed buffer of one model.
 struct PackedLayout {
@@ -358,6 +383,13 @@ struct GemmTN {            // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += s
 };
 int launch_gemm_tn(const GemmTN& p, hipStream_t s);
 size_t gemm_tn_scratch_floats(int splits);
+// Several weight-gradient products over the same sample rows in one launch (+ one reduction launch): the layers of a chain.
+constexpr int MAX_TN_GROUP = 16;
+struct GemmTNGroup {
+    GemmTN job[MAX_TN_GROUP];      // .partial / .bias_partial: one scratch region of gemm_tn_scratch_floats(splits) per job
+    int count;
+};
+int launch_gemm_tn_group(const GemmTNGroup& g, hipStream_t s);
 
 // Hutchinson divergence estimate e^T (d delta / d x) e of the ray bender (object_composer.py:582-601) as a
 // forward-mode derivative through the saved bender activations; writes the dense (N,R,P) array `div`.
