@@ -1481,8 +1481,10 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd(Ch
         bool g_in_written = false;
         for (int l = c.count - 1; l >= 1; --l) {
             // the ReLU mask of this layer's input (layer l - 1's output) -> bits, visible after the barrier inside run_layer
+#if !(defined(PR_CHAIN_ABLATE) && (PR_CHAIN_ABLATE & 2))     // measurement builds: 2 = no mask bits, 1 = no gradient write-out
             build_relu_mask_bits(reinterpret_cast<unsigned char*>(S.pos), c.acts + (size_t)(l - 1) * c.act_stride, c.Wpad, c.Wpad,
                                  tile_base, rows_valid);
+#endif
             if (l == c.skip) {
                 e.gout = c.g_in; e.ldg = c.ld_in; e.accumulate = 0; e.n_real = c.in_real;
                 run_layer<true>(c.in0_skip, S, unused, tile_base, 0, enc, &e);
@@ -1491,7 +1493,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd(Ch
             e.gout = nullptr; e.n_real = c.W;
             run_layer<true>(c.act_layers[l], S, unused, tile_base, 0, enc, &e);
             // the pre-activation gradient of layer l - 1, for its weight-gradient product
+#if !(defined(PR_CHAIN_ABLATE) && (PR_CHAIN_ABLATE & 1))
             write_tile_rows(S, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, false);
+#endif
         }
         e.gout = c.g_in; e.ldg = c.ld_in; e.accumulate = g_in_written ? 1 : 0; e.n_real = c.in_real;
         run_layer<true>(c.in0_first, S, unused, tile_base, 0, enc, &e);
