@@ -67,6 +67,15 @@ typedef enum pr_status {
                                        PR_FLAG_TRAIN_BN (batch statistics need every row), PR_FLAG_SAVE_FOR_BACKWARD and
                                        PR_FLAG_NAIVE_MLP. */
 
+#define PR_FLAG_DEVICE_NOISE 128u    /* with PR_FLAG_PERTURB (and for the Hutchinson probes of training calls): every noise tensor whose
+                                       pointer in pr_noise_t is NULL is GENERATED inside the kernels that consume it - a
+                                       counter-based generator (Philox4x32-10) keyed by pr_call_t.noise_seed and the tensor's
+                                       stream id, indexed by the element index, so pr_render_backward regenerates exactly
+                                       the forward pass's values and no (N,R,P) noise tensor is materialised (the reference
+                                       draws them with torch.rand / torch.randn: utils/lib_3d/ray_helper.py:1275,1380,
+                                       model/object_composer.py:553,597,751).  pr_noise_fill writes the same values to a
+                                       tensor (tests replay them through the explicit path and the oracle). */
+
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
     const float* weight;
@@ -217,7 +226,10 @@ typedef struct pr_call_t {
     const float* linspace_fine[PR_MAX_OBJECTS];   /* torch.linspace(0,1,Pf_k) */
     int32_t positions_fine[PR_MAX_OBJECTS];       /* Pf_k (resampled positions, use_fine only) */
     pr_noise_t noise_coarse;
-    pr_noise_t noise_fine;           /* only .integrate / .integrate_global are read */
+    pr_noise_t noise_fine;           /* only .integrate / .integrate_global / .divergence are read */
+    uint64_t noise_seed;             /* PR_FLAG_DEVICE_NOISE: seed of the call's generated noise */
+    int32_t noise_ray_offset;        /* PR_FLAG_DEVICE_NOISE, calls that are a ray range [offset, offset + R) of a larger */
+    int32_t noise_total_rays;        /* render of noise_total_rays rays per frame (0 = this call is the whole render) */
 } pr_call_t;
 
 /* Workspace bytes pr_render_forward needs for this call (host computation, no device work). */
@@ -318,6 +330,14 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, 
 int pr_expected_positions(int32_t frames, int32_t rays, int32_t objects, int32_t object_index, int32_t positions,
                           const float* ray_origins, const float* ray_directions, const float* w2o, const float* t,
                           const float* weights, const float* delta, float* expected, void* stream);
+
+/*
+ * The values PR_FLAG_DEVICE_NOISE generates for one noise tensor, written out: element i of the tensor with `kind`
+ * (0 stratified jitter U[0,1), 1 coarse density noise N(0,1), 2 inverse-CDF positions U[0,1), 3 per-object density noise
+ * N(0,1), 4 merged-list density noise N(0,1), 5 Hutchinson probes N(0,1)) of model type `type` (0 coarse / 1 fine) and
+ * object `object`.  count elements, fp32.
+ */
+int pr_noise_fill(uint64_t seed, int32_t kind, int32_t type, int32_t object, int64_t count, float* out, void* stream);
 
 /*
  * Region-of-interest max pooling: the crop the reference's object encoders and pose estimators take from the

@@ -20,6 +20,7 @@ PR_FLAG_NAIVE_MLP = 8
 PR_FLAG_TRAIN_BN = 16
 PR_FLAG_SAVE_FOR_BACKWARD = 32
 PR_FLAG_GATE_HEAD = 64
+PR_FLAG_DEVICE_NOISE = 128
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
 PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect
@@ -105,6 +106,7 @@ class Call(C.Structure):
         ("linspace_coarse", C.c_void_p * PR_MAX_OBJECTS), ("linspace_fine", C.c_void_p * PR_MAX_OBJECTS),
         ("positions_fine", C.c_int32 * PR_MAX_OBJECTS),
         ("noise_coarse", Noise), ("noise_fine", Noise),
+        ("noise_seed", C.c_uint64), ("noise_ray_offset", C.c_int32), ("noise_total_rays", C.c_int32),
     ]
 
 
@@ -152,6 +154,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_expected_positions": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_noise_fill": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "pr_roi_pool_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_roi_pool_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,

@@ -29,7 +29,7 @@ struct CompositeBwdObject {
     const int32_t* slot;
     const float* dispmag;    // or NULL
     const float* feat;       // compact rows
-    const float* noise;      // integrate noise (N,R,P) or NULL
+    NoiseRef noise;          // integrate noise (N,R,P) or absent
     int positions;
     pr_entry_grads_t g;      // gradients of results["object_k"]
     float* g_feat;           // (cap, F) compact rows, every in-box row is written
@@ -44,7 +44,7 @@ struct CompositeBwdParams {
     int total_positions;
     int sort_size;
     const float* ray_directions;
-    const float* noise_global;
+    NoiseRef noise_global;
     CompositeBwdObject obj[PR_MAX_OBJECTS];
     pr_entry_grads_t global;
 };
@@ -80,15 +80,16 @@ __device__ __forceinline__ void transmittance_scan(const float* al, float* Tj, f
 // Backward of integrate() over one sample list of the ray.  sorted = false: entries off .. off + n in
 // order; sorted = true: the merged list in key order.  Adds into gs / gt / gd (per concatenation entry).
 __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdSmem& sm, bool sorted, int off, int n,
-                                               const float* noise, float norm, const pr_entry_grads_t& g, long ray,
+                                               const NoiseRef& noise, float norm, const pr_entry_grads_t& g, long ray,
                                                float* weights_out, int lane) {
+    const bool noisy = noise_present(noise);
     const int F = p.F;
     auto entry_of = [&](int j) -> int { return sorted ? (int)sm.key[j] : off + j; };
     for (int j = lane; j < n; j += 64) {
         const int e = entry_of(j);
         const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
         float raw = sm.sg[e];
-        if (noise) raw = __fadd_rn(raw, noise[j]);
+        if (noisy) raw = __fadd_rn(raw, noise_normal(noise, ray, n, j));
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
     }
     __syncthreads();
@@ -149,7 +150,7 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
         const float dist = __fmul_rn(dt, norm);
         float raw = sm.sg[e];
-        if (noise) raw = __fadd_rn(raw, noise[j]);
+        if (noisy) raw = __fadd_rn(raw, noise_normal(noise, ray, n, j));
         const float s = raw > 0.f ? raw : 0.f;
         const float E = expf(__fmul_rn(-s, dist));
         const float da = sm.dw[j];
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     for (int k = 0; k < p.objects; ++k) {
         const CompositeBwdObject& o = p.obj[k];
         const int P = o.positions;
-        entry_backward(p, sm, false, off, P, o.noise ? o.noise + (size_t)g * P : nullptr, norm, o.g, g, sm.wo, lane);
+        entry_backward(p, sm, false, off, P, o.noise, norm, o.g, g, sm.wo, lane);
         off += P;
     }
     // ---- overlap fix: carved static samples are constants (sigma = -10, t = 0, |delta| = 0) -----------
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
         order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64, wide);
     }
-    entry_backward(p, sm, true, 0, PT, p.noise_global ? p.noise_global + (size_t)g * PT : nullptr, norm, p.global, g, sm.wg, lane);
+    entry_backward(p, sm, true, 0, PT, p.noise_global, norm, p.global, g, sm.wg, lane);
 
     // ---- write the per-sample gradients ----------------------------------------------------------------
     const int F = p.F;
@@ -691,7 +692,7 @@ struct GeometryBwd {
     float lo[3], hi[3];
     float z_near_min, z_far_max;
     const float* linspace;
-    const float* jitter;
+    NoiseRef jitter;
     const float* t;          // (N,R,P) forward sample depths
     const int32_t* slot;     // (N,R,P)
     const float* g_t;        // (N,R,P) from the compositing backward
@@ -777,8 +778,8 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
             }
             const float s_i = p.linspace[ci];
             float An = 1.0f - s_i, Bf = s_i;
-            if (p.jitter) {
-                const float u = p.jitter[cbase + ci];
+            if (noise_present(p.jitter)) {
+                const float u = noise_uniform(p.jitter, (long)(cbase / Pc), Pc, ci);
                 const float s_lo = ci > 0 ? 0.5f * (p.linspace[ci - 1] + s_i) : s_i;
                 const float s_hi = ci < Pc - 1 ? 0.5f * (p.linspace[ci + 1] + s_i) : s_i;
                 Bf = s_lo + (s_hi - s_lo) * u;
@@ -1038,7 +1039,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         o.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
         o.dispmag = m.has_bender ? reinterpret_cast<const float*>(fws + tp.dispmag[k]) : nullptr;
         o.feat = reinterpret_cast<const float*>(fws + tp.feat[k]);
-        o.noise = noise.integrate[k];
+        o.noise = perturb_noise(noise.integrate[k], c, NOISE_INTEGRATE, t, k);
         o.positions = m.positions;
         o.g = grads.object[k];
         o.g_feat = reinterpret_cast<float*>(bws + bp.g_feat[k]);
@@ -1053,7 +1054,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     while (ss < total_positions) ss <<= 1;
     cp.sort_size = ss;
     cp.ray_directions = c.ray_directions;
-    cp.noise_global = noise.integrate_global;
+    cp.noise_global = perturb_noise(noise.integrate_global, c, NOISE_INTEGRATE_GLOBAL, t, 0);
     cp.global = grads.global;
     PR_TRY(launch_composite_bwd(cp, s));
 
@@ -1229,7 +1230,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             }
             gb.z_near_min = m.z_near_min; gb.z_far_max = m.z_far_max;
             gb.linspace = c.linspace_coarse[k];
-            gb.jitter = c.noise_coarse.jitter[k];
+            gb.jitter = perturb_noise(c.noise_coarse.jitter[k], c, NOISE_JITTER, 0, k);
             if (t) {
                 gb.t_coarse = reinterpret_cast<const float*>(fws + plan.type[0].t[k]);
                 gb.pc = objs[k].coarse.positions;
@@ -1302,14 +1303,22 @@ namespace pr {
 
 // tangent of the bender input [annealed PE(x / size) | deformation] along e: d v_a = e_a / size_a;
 // sin slot: 2^k cos_saved d v ; cos slot: -2^k sin_saved d v (the saved values carry the annealing weight)
-__global__ __launch_bounds__(256) void k_div_tangent_in(const int32_t* total, const int32_t* rec_flat, const float* noise,
+// the three probe components of compact sample `flat` (flat = ray * P + sample): element (flat % P) * 3 + a of ray flat / P
+__device__ __forceinline__ void probe_of(const NoiseRef& noise, int flat, int positions, float* e) {
+    const long ray = flat / positions;
+    const int sample = flat - (int)ray * positions;
+    for (int a = 0; a < 3; ++a) e[a] = noise_normal(noise, ray, positions * 3, sample * 3 + a);
+}
+
+__global__ __launch_bounds__(256) void k_div_tangent_in(const int32_t* total, const int32_t* rec_flat, NoiseRef noise, int positions,
                                                         const float* bin, int ld, int benc, int octaves, float s0, float s1,
                                                         float s2, float* t0) {
     const int M = *total;
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     const float size[3] = {s0, s1, s2};
-    const float* e = noise + (size_t)rec_flat[m] * 3;
+    float e[3];
+    probe_of(noise, rec_flat[m], positions, e);
     const float* b = bin + (size_t)m * ld;
     float* t = t0 + (size_t)m * ld;
     float dv[3];
@@ -1331,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_div_tangent_in(const int32_t* total, co
 // div = sum_a e_a (J e)_a with (J e)_a = size_a * (W_out t)_a where the clamp passes the network output,
 // -e_a where delta = lo - x or hi - x, 0 in canonical pose
 __global__ __launch_bounds__(256) void k_div_out(const int32_t* total, const int32_t* rec_flat, const int32_t* row_flags,
-                                                 const float* noise, const float* tlast, int ld, int width, const float* w_out,
+                                                 NoiseRef noise, int positions, const float* tlast, int ld, int width, const float* w_out,
                                                  const float* braw, const float* pos, float lo0, float lo1, float lo2, float hi0,
                                                  float hi1, float hi2, int canonical, float* div) {
     const int M = *total;
@@ -1339,7 +1348,8 @@ __global__ __launch_bounds__(256) void k_div_out(const int32_t* total, const int
     if (m >= M || !(row_flags[m] & 1)) return;
     const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
     const int flat = rec_flat[m];
-    const float* e = noise + (size_t)flat * 3;
+    float e[3];
+    probe_of(noise, flat, positions, e);
     const float* t = tlast + (size_t)m * ld;
     float tan[3] = {0.f, 0.f, 0.f};
     for (int c = 0; c < width; ++c) {
@@ -1368,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_div_out(const int32_t* total, const int
 int launch_divergence(const DivergenceParams& p, hipStream_t s) {
     if (p.max_rows <= 0) return PR_OK;
     const int blocks = (p.max_rows + 255) / 256;
-    hipLaunchKernelGGL(k_div_tangent_in, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.noise, p.bin, p.bin_pad, p.benc,
+    hipLaunchKernelGGL(k_div_tangent_in, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.noise, p.positions, p.bin, p.bin_pad, p.benc,
                        p.b_octaves, p.hi[0] - p.lo[0], p.hi[1] - p.lo[1], p.hi[2] - p.lo[2], p.t0);
     PR_LAUNCH_CHECK();
     float* cur = p.ta;
@@ -1400,7 +1410,7 @@ int launch_divergence(const DivergenceParams& p, hipStream_t s) {
         cur = other;
         other = tmp;
     }
-    hipLaunchKernelGGL(k_div_out, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.row_flags, p.noise, prev, p.BWpad, p.BW,
+    hipLaunchKernelGGL(k_div_out, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.row_flags, p.noise, p.positions, prev, p.BWpad, p.BW,
                        p.out_head.weight, p.braw, p.rec_pos, p.lo[0], p.lo[1], p.lo[2], p.hi[0], p.hi[1], p.hi[2], p.canonical, p.div);
     PR_LAUNCH_CHECK();
     return PR_OK;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
         for (int i = lane; i < P; i += 64) {
             const float dt = (i < P - 1) ? __fsub_rn(sm.tt[off + i + 1], sm.tt[off + i]) : 1e10f;
             float raw = sm.sg[off + i];
-            if (o.noise) raw = __fadd_rn(raw, o.noise[base + i]);
+            if (noise_present(o.noise)) raw = __fadd_rn(raw, noise_normal(o.noise, g, P, i));
             const float a = alpha_of(raw, __fmul_rn(dt, norm));
             sm.al[off + i] = a;
             if (use_div) adiv += a * sm.dv[off + i];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
             dt = __fsub_rn(sm.tt[en], sm.tt[e]);
         }
         float raw = sm.sg[e];
-        if (p.noise_global) raw = __fadd_rn(raw, p.noise_global[gbase + j]);
+        if (noise_present(p.noise_global)) raw = __fadd_rn(raw, noise_normal(p.noise_global, g, PT, j));
         sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
         if (use_div) gdiv += sm.al[j] * sm.dv[e];
     }

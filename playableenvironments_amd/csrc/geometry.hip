@@ -180,11 +180,11 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
             if (live && i < P) {
                 const float t_cur = t_at(i);
                 float t = t_cur;
-                if (p.jitter != nullptr) {
+                if (noise_present(p.jitter)) {
                     // mid points, upper = [mids, t_last], lower = [t_0, mids]   (:1267-1275)
                     const float upper = (i < P - 1) ? __fdiv_rn(__fadd_rn(t_at(i + 1), t_cur), 2.0f) : t_cur;
                     const float lower = (i > 0) ? __fdiv_rn(__fadd_rn(t_cur, t_at(i - 1)), 2.0f) : t_cur;
-                    t = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), p.jitter[base + i]));
+                    t = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), noise_uniform(p.jitter, wave_first + r, P, i)));
                 }
                 p.t[base + i] = t;
                 p.sigma[base + i] = p.empty_alpha;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size
     __syncthreads();
     for (int i = lane; i < Pc; i += 64) {
         float raw = valid ? p.sigma_coarse[cbase + i] : p.empty_alpha;
-        if (p.alpha_noise) raw = __fadd_rn(raw, p.alpha_noise[cbase + i]);
+        if (noise_present(p.alpha_noise)) raw = __fadd_rn(raw, noise_normal(p.alpha_noise, g, Pc, i));
         const float dt = (i < Pc - 1) ? __fsub_rn(tc[i + 1], tc[i]) : 1e10f;
         const float dist = __fmul_rn(dt, norm);
         const float relu = raw > 0.f ? raw : 0.f;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size
     const int ncdf = Pc - 1;
     for (int i = lane; i < sort_size; i += 64) key[i] = (i < Pc) ? tc[i] : __builtin_inff();
     for (int f = lane; f < Pf; f += 64) {
-        const float u = p.u_random ? p.u_random[(size_t)g * Pf + f] : p.u_fixed[f];
+        const float u = noise_present(p.u_random) ? noise_uniform(p.u_random, g, Pf, f) : p.u_fixed[f];
         // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
         int lo_i = 0, hi_i = ncdf;
         while (lo_i < hi_i) {

@@ -196,6 +196,53 @@ struct MlpParams {
 static inline int adain_row_floats(const ModelDims& d) { return 2 * d.Wpad + 2 * d.W2pad; }
 
 // ---------------------------------------------------------------------------------------------
+// Noise sources.  A noise tensor of the reference (torch.rand / torch.randn draws: stratified jitter, density noise, inverse-
+// CDF positions, Hutchinson probes) is either an explicit device array (replayed draws: parity tests, the oracle's order) or
+// - PR_FLAG_DEVICE_NOISE - a counter-based generator evaluated where the value is needed: Philox4x32-10 keyed by
+// (call seed, stream id), counter = element index, so the backward pass regenerates exactly what the forward pass used
+// and nothing of size (N, R, P) is materialised.  Stream ids: kind * 16 + model type * 8 + object.
+// ---------------------------------------------------------------------------------------------
+enum NoiseKind { NOISE_JITTER = 0, NOISE_ALPHA = 1, NOISE_PDF = 2, NOISE_INTEGRATE = 3, NOISE_INTEGRATE_GLOBAL = 4, NOISE_DIVERGENCE = 5 };
+
+struct NoiseRef {
+    const float* ptr;            // explicit values, or NULL
+    unsigned int key0, key1;     // Philox key of the stream (generate != 0)
+    int generate;                // 1: values come from the generator
+    int rays, ray_offset, total_rays;   // ray r of frame n of this call is ray (ray_offset + r) of total_rays in the stream's index space
+};
+
+static inline unsigned long long noise_mix(unsigned long long x) {   // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static inline NoiseRef make_noise(const float* ptr, const pr_call_t& c, int kind, int type, int object) {
+    NoiseRef n;
+    memset(&n, 0, sizeof(n));
+    n.ptr = ptr;
+    n.rays = c.rays;
+    n.ray_offset = c.noise_ray_offset;
+    n.total_rays = c.noise_total_rays > 0 ? c.noise_total_rays : c.rays;
+    if (!ptr && (c.flags & PR_FLAG_DEVICE_NOISE)) {
+        const unsigned long long k = noise_mix(c.noise_seed ^ noise_mix((unsigned long long)(kind * 16 + type * 8 + object) + 1));
+        n.key0 = (unsigned int)k;
+        n.key1 = (unsigned int)(k >> 32);
+        n.generate = 1;
+    }
+    return n;
+}
+
+// noise of the perturbation path (jitter, density noise, inverse-CDF positions): explicit tensors are used whenever given,
+// generated values only with PR_FLAG_PERTURB
+static inline NoiseRef perturb_noise(const float* ptr, const pr_call_t& c, int kind, int type, int object) {
+    NoiseRef n = make_noise(ptr, c, kind, type, object);
+    if (!(c.flags & PR_FLAG_PERTURB)) n.generate = 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage launchers (each enqueues on `stream`, returns pr_status)
 // ---------------------------------------------------------------------------------------------
 struct PlaceParams {
@@ -207,7 +254,7 @@ struct PlaceParams {
     float lo[3], hi[3];
     float z_near_min, z_far_max, empty_alpha;
     const float* linspace;        // (P)
-    const float* jitter;          // (N,R,P) or NULL
+    NoiseRef jitter;              // U[0,1) per sample (N,R,P), or absent
     float* t;                     // (N,R,P) out
     float* sigma;                 // (N,R,P) out, filled with empty_alpha
     float* dispmag;               // (N,R,P) out zeros or NULL
@@ -244,9 +291,9 @@ struct ResampleParams {
     float empty_alpha;
     const float* t_coarse;        // (N,R,Pc)
     const float* sigma_coarse;    // (N,R,Pc)
-    const float* alpha_noise;     // (N,R,Pc) or NULL
+    NoiseRef alpha_noise;         // N(0,1) (N,R,Pc) or absent
     const float* u_fixed;         // linspace(0,1,Pf) (Pf)
-    const float* u_random;        // (N,R,Pf) or NULL
+    NoiseRef u_random;            // U[0,1) (N,R,Pf) or absent
     float* t_fine;                // (N,R,Pc+Pf) out
     float* sigma_fine;            // (N,R,Pc+Pf) out, filled with empty_alpha
     float* dispmag_fine;          // or NULL
@@ -294,7 +341,7 @@ struct CompositeObject {
     const float* divergence;  // (N,R,P) Hutchinson divergence estimate, or NULL (zeros)
     const float* dispmag;   // or NULL
     const float* feat;      // compact rows
-    const float* noise;     // integrate noise (N,R,P) or NULL
+    NoiseRef noise;         // integrate noise (N,R,P) or absent
     int positions;
     pr_entry_t out;
 };
@@ -305,7 +352,7 @@ struct CompositeParams {
     int total_positions;         // sum P_k
     int sort_size;               // next pow2 >= total_positions
     const float* ray_directions; // (N,R,3) world
-    const float* noise_global;   // (N,R,sumP) or NULL
+    NoiseRef noise_global;       // (N,R,sumP) or absent
     CompositeObject obj[PR_MAX_OBJECTS];
     pr_entry_t global;
     pr_decoder_layout_t decoder;   // global features additionally as channels-first maps per ray group (groups = 0: off)
@@ -396,7 +443,8 @@ int launch_gemm_tn_group(const GemmTNGroup& g, hipStream_t s);
 struct DivergenceParams {
     const int32_t* total; int max_rows;
     const int32_t* rec_flat; const int32_t* row_flags; const float* rec_pos;
-    const float* noise;            // (N,R,P,3)
+    NoiseRef noise;                // N(0,1) (N,R,P,3)
+    int positions;                 // P (index space of the probes)
     const float* bin; int bin_pad, benc, b_octaves;
     const float* bacts; size_t bact_stride; int BW, BWpad, b_count, b_skip, bin_real;
     const pr_linear_t* layers; pr_linear_t out_head;
@@ -422,6 +470,49 @@ struct ProfileScope {
 // Device helpers
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): 128-bit counter, 64-bit key.
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0,
+                                              unsigned int k1, unsigned int* out) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned int n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ bool noise_present(const NoiseRef& n) { return n.ptr != nullptr || n.generate != 0; }
+
+// element index of (ray g of THIS call, element e of `per_ray`) in the noise tensor's own index space: calls that were split
+// along the rays address the rows of the unsplit tensor
+__device__ __forceinline__ unsigned long long noise_index(const NoiseRef& n, long g, int per_ray, int e) {
+    if (n.total_rays == n.rays) return (unsigned long long)g * per_ray + e;
+    const long frame = g / n.rays, r = g - frame * n.rays;
+    return (unsigned long long)(frame * n.total_rays + n.ray_offset + r) * per_ray + e;
+}
+
+__device__ __forceinline__ float noise_uniform(const NoiseRef& n, long g, int per_ray, int e) {   // U[0, 1)
+    if (n.ptr) return n.ptr[(size_t)g * per_ray + e];      // explicit tensors arrive already sliced to the call's rays
+    const unsigned long long idx = noise_index(n, g, per_ray, e);
+    unsigned int x[4];
+    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, n.key0, n.key1, x);
+    return (float)(x[0] >> 8) * 5.9604644775390625e-8f;   // 24 random bits * 2^-24
+}
+
+__device__ __forceinline__ float noise_normal(const NoiseRef& n, long g, int per_ray, int e) {    // N(0, 1), Box-Muller
+    if (n.ptr) return n.ptr[(size_t)g * per_ray + e];
+    const unsigned long long idx = noise_index(n, g, per_ray, e);
+    unsigned int x[4];
+    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, n.key0, n.key1, x);
+    const float u1 = (float)((x[0] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
+    const float u2 = (float)(x[1] >> 8) * 5.9604644775390625e-8f;          // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864769f * u2);
+}
+
 // torch.min / torch.max / clamp propagate NaN; fminf/fmaxf do not.
 __device__ __forceinline__ float nan_min(float a, float b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }

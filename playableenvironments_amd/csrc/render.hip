@@ -102,7 +102,8 @@ int validate_call(const pr_call_t& c, const pr_object_t* objs) {
                        "object %d: fine model positions %d != %d + %d", k, objs[k].fine.positions, m.positions,
                        c.positions_fine[k]);
             PR_REQUIRE(objs[k].packed_fine != nullptr, "object %d: packed fine weights missing", k);
-            PR_REQUIRE(c.linspace_fine[k] != nullptr || c.noise_coarse.pdf[k] != nullptr,
+            PR_REQUIRE(c.linspace_fine[k] != nullptr || c.noise_coarse.pdf[k] != nullptr ||
+                           ((c.flags & PR_FLAG_DEVICE_NOISE) && (c.flags & PR_FLAG_PERTURB)),
                        "object %d: linspace_fine missing", k);
             PR_REQUIRE((long)c.frames * c.rays * (long)objs[k].fine.positions < (1L << 31), "too many samples in one call");
         }
@@ -283,7 +284,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 bbox_split(m, pp.lo, pp.hi, nullptr);
                 pp.z_near_min = m.z_near_min; pp.z_far_max = m.z_far_max; pp.empty_alpha = m.empty_space_alpha;
                 pp.linspace = c.linspace_coarse[k];
-                pp.jitter = c.noise_coarse.jitter[k];
+                pp.jitter = perturb_noise(c.noise_coarse.jitter[k], c, NOISE_JITTER, 0, k);
                 pp.t = t_arr; pp.sigma = sigma; pp.dispmag = dispmag; pp.block_sums = block_sums;
                 PR_TRY(launch_place_coarse(pp, s));
             } else {
@@ -298,9 +299,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 rp.empty_alpha = m.empty_space_alpha;
                 rp.t_coarse = reinterpret_cast<const float*>(ws + cp.t[k]);
                 rp.sigma_coarse = reinterpret_cast<const float*>(ws + cp.sigma[k]);
-                rp.alpha_noise = c.noise_coarse.alpha[k];
+                rp.alpha_noise = perturb_noise(c.noise_coarse.alpha[k], c, NOISE_ALPHA, 0, k);
                 rp.u_fixed = c.linspace_fine[k];
-                rp.u_random = c.noise_coarse.pdf[k];
+                rp.u_random = perturb_noise(c.noise_coarse.pdf[k], c, NOISE_PDF, 0, k);
                 rp.t_fine = t_arr; rp.sigma_fine = sigma; rp.dispmag_fine = dispmag; rp.block_sums = block_sums;
                 PR_TRY(launch_resample(rp, s));
             }
@@ -418,12 +419,16 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     const size_t cap_rows = (size_t)c.frames * c.rays * P;
                     float* div = reinterpret_cast<float*>(ws + sv.div);
                     PR_CHECK_HIP(hipMemsetAsync(div, 0, sizeof(float) * cap_rows, s));
-                    if (noise.divergence[k]) {
+                    // probes: explicit, or generated for training calls with a graph (the reference draws them whenever it
+                    // trains with a graph, object_composer.py:597)
+                    NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
+                    if (!(c.flags & PR_FLAG_TRAIN_BN)) probes.generate = 0;
+                    if (probes.ptr || probes.generate) {
                         DivergenceParams dp;
                         memset(&dp, 0, sizeof(dp));
                         dp.total = totals + k; dp.max_rows = (int)cap_rows;
                         dp.rec_flat = rec_flat; dp.row_flags = mp.row_flags; dp.rec_pos = rec_pos;
-                        dp.noise = noise.divergence[k];
+                        dp.noise = probes; dp.positions = P;
                         dp.bin = mp.save_bin; dp.bin_pad = d.bin_pad; dp.benc = d.benc; dp.b_octaves = m.bender_octaves;
                         dp.bacts = mp.save_bact; dp.bact_stride = mp.save_bact_stride; dp.BW = d.BW; dp.BWpad = d.BWpad;
                         dp.b_count = m.bender_count; dp.b_skip = m.bender_skip; dp.bin_real = d.bin;
@@ -452,7 +457,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         while (ss < total_positions) ss <<= 1;
         cp.sort_size = ss;
         cp.ray_directions = c.ray_directions;
-        cp.noise_global = noise.integrate_global;
+        cp.noise_global = perturb_noise(noise.integrate_global, c, NOISE_INTEGRATE_GLOBAL, t, 0);
         for (int k = 0; k < K; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             PR_REQUIRE(m.output_features == cp.F, "all objects must share output_features");
@@ -465,7 +470,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                                ? reinterpret_cast<const float*>(ws + tp.saved[k].div) : nullptr;
             if (o.divergence) cp.any_divergence = 1;
             o.feat = reinterpret_cast<const float*>(ws + tp.feat[k]);
-            o.noise = noise.integrate[k];
+            o.noise = perturb_noise(noise.integrate[k], c, NOISE_INTEGRATE, t, k);
             o.positions = m.positions;
             if (out) o.out = out->object[k];
         }
@@ -523,6 +528,32 @@ extern "C" int pr_render_forward(const pr_call_t* call, const pr_object_t* objec
     PR_REQUIRE(((uintptr_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     const pr_outputs_t* outs[2] = {coarse, fine};
     return pr::render(*call, objects, outs, static_cast<char*>(workspace), plan, (hipStream_t)stream);
+}
+
+namespace pr {
+__global__ __launch_bounds__(256) void k_noise_fill(NoiseRef n, int normal, long count, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256)
+        out[i] = normal ? noise_normal(n, i, 1, 0) : noise_uniform(n, i, 1, 0);
+}
+}  // namespace pr
+
+extern "C" int pr_noise_fill(uint64_t seed, int32_t kind, int32_t type, int32_t object, int64_t count, float* out, void* stream) {
+    PR_REQUIRE(kind >= 0 && kind <= 5 && (type == 0 || type == 1) && object >= 0 && object < PR_MAX_OBJECTS, "pr_noise_fill: bad stream");
+    if (count <= 0) return PR_OK;
+    PR_REQUIRE(out != nullptr, "pr_noise_fill: NULL output");
+    pr_call_t c;
+    memset(&c, 0, sizeof(c));
+    c.flags = PR_FLAG_DEVICE_NOISE | PR_FLAG_PERTURB;
+    c.noise_seed = seed;
+    c.rays = 1;
+    pr::NoiseRef n = pr::make_noise(nullptr, c, kind, type, object);
+    n.rays = n.total_rays = 1;      // element i is "ray i, element 0 of 1": the flat tensor index
+    const int normal = (kind == pr::NOISE_JITTER || kind == pr::NOISE_PDF) ? 0 : 1;
+    const long blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(pr::k_noise_fill, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, (hipStream_t)stream, n, normal,
+                       (long)count, out);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
 }
 
 extern "C" int pr_profile_enable(int enable) {

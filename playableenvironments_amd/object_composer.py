@@ -272,6 +272,12 @@ class ObjectComposer(nn.Module):
         self.gate_feature_head = True
         #: device tensors (K,) per model type: samples that entered the BatchNorm batch statistics of the last training call
         self.last_normalised_samples: Dict[str, torch.Tensor] = {}
+        #: where the random draws of perturbed / training calls come from when no explicit ``_noise`` is replayed:
+        #: "device" - generated inside the kernels that consume them (PR_FLAG_DEVICE_NOISE: Philox4x32-10 keyed by a per-call
+        #: seed, regenerated by the backward pass; nothing of size (N, R, P) is materialised); "torch" - torch.rand / torch.randn
+        #: tensors as in round 1.  The per-call seed is drawn from torch's CPU generator (torch.manual_seed makes runs repeatable).
+        self.noise_source = "device"
+        self.last_noise_seed: Optional[int] = None
         #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
         #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
         #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
@@ -625,8 +631,19 @@ class ObjectComposer(nn.Module):
         types = ["coarse"] + (["fine"] if use_fine else [])
         ptot = {"coarse": pc, "fine": [a + b for a, b in zip(pc, pf)]}
         noise: Dict[str, torch.Tensor] = {}
+        if self.noise_source not in ("device", "torch"):
+            raise ValueError(f"unknown noise_source {self.noise_source!r} (expected 'device' or 'torch')")
+        needs_noise = perturb or (_save and self.training)
+        device_noise = needs_noise and _noise is None and self.noise_source == "device"
+        noise_seed = 0
+        if device_noise:
+            flags |= _lib.PR_FLAG_DEVICE_NOISE
+            noise_seed = int(torch.empty((), dtype=torch.int64).random_())      # CPU generator: no device synchronisation
+            self.last_noise_seed = noise_seed
 
         def get(name, shape, normal):
+            if device_noise:
+                return                     # generated in the kernels
             if _noise is not None and _noise.get(name) is not None:
                 t = _noise[name].to(**f32).reshape(shape).contiguous()
             else:
@@ -659,6 +676,8 @@ class ObjectComposer(nn.Module):
             call.static_objects = helper.static_objects_count if _object_ids is None else 0
             call.use_fine = 1 if use_fine else 0
             call.flags = flags
+            call.noise_seed = noise_seed
+            call.noise_ray_offset, call.noise_total_rays = r0, R
             call.precision = self._precision_code(_save)
             d = dirs if (r0 == 0 and r1 == R) else dirs[:, r0:r1].contiguous()
             keep.append(d)

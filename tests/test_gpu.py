@@ -1646,3 +1646,137 @@ def test_decoder_layout_emission_matches_wire_format(mode):
     loss.backward()
     assert float(via_maps.abs().max()) > 0
     assert torch.allclose(via_maps, style.grad, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# in-kernel noise (PR_FLAG_DEVICE_NOISE): Philox4x32-10 streams instead of materialised torch.rand / torch.randn tensors
+def _noise_fill(seed, kind, ty, obj, shape):
+    import ctypes as C
+    from playableenvironments_amd import _lib
+    out = torch.empty(shape, dtype=torch.float32, device="cuda")
+    _lib.check(_lib.load().pr_noise_fill(C.c_uint64(seed), kind, ty, obj, out.numel(), out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "pr_noise_fill")
+    return out
+
+
+def test_generated_noise_distributions():
+    """The generator's streams: uniform and normal moments, a Kolmogorov-Smirnov bound, no correlation between neighbouring
+    elements or between streams, reproducibility, and dependence on the seed."""
+    n = 1 << 20
+    u = _noise_fill(1234, 0, 0, 0, (n,)).double().cpu()
+    z = _noise_fill(1234, 3, 0, 2, (n,)).double().cpu()
+    z2 = _noise_fill(1234, 3, 1, 2, (n,)).double().cpu()          # another stream
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
+    assert abs(float(z.mean())) < 4e-3 and abs(float(z.var()) - 1.0) < 6e-3
+    assert abs(float((z ** 3).mean())) < 2e-2 and abs(float((z ** 4).mean()) - 3.0) < 6e-2
+    srt, _ = torch.sort(u)
+    ks = float((srt - torch.arange(1, n + 1, dtype=torch.float64) / n).abs().max())
+    assert ks < 1.95 / n ** 0.5                                     # 0.1 % level
+    phi = 0.5 * (1 + torch.erf(torch.sort(z)[0] / 2 ** 0.5))
+    assert float((phi - torch.arange(1, n + 1, dtype=torch.float64) / n).abs().max()) < 1.95 / n ** 0.5
+    corr = lambda a, b: float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std()))
+    assert abs(corr(u[:-1], u[1:])) < 5e-3 and abs(corr(z[:-1], z[1:])) < 5e-3 and abs(corr(z, z2)) < 5e-3
+    assert torch.equal(z, _noise_fill(1234, 3, 0, 2, (n,)).double().cpu())
+    assert not torch.equal(z, _noise_fill(1235, 3, 0, 2, (n,)).double().cpu())
+
+
+@pytest.mark.parametrize("name", ["tennis_hierarchical", "minecraft"])
+def test_generated_noise_render_equals_explicit_replay(name):
+    """A perturbed render with in-kernel noise == the same render with the explicit-noise path fed the tensors pr_noise_fill
+    writes for that seed (bit for bit), and therefore == the oracle replaying them (fp32 tolerance): the in-kernel generator
+    sits behind the same arithmetic the parity tests cover."""
+    make_cfg, make_scene, n, bias = CASES[name]
+    cfg, scene = make_cfg(), make_scene()
+    comp = build(cfg, alpha_bias=bias).cuda()
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
+    gin = [v.cuda() for v in inputs]
+    with torch.no_grad():
+        torch.manual_seed(77)
+        generated = comp(*gin, True)
+        seed = comp.last_noise_seed
+        again_seed = None
+        torch.manual_seed(77)
+        again = comp(*gin, True)
+        again_seed = comp.last_noise_seed
+    assert seed == again_seed
+    lay = ro.ObjectLayout(cfg)
+    K = lay.objects_count
+    N, R = 1, gin[1].size(-2)
+    for v in gin[1].shape[:-2]:
+        N *= v
+    pc = [cfg["model"]["object_models"][lay.model_of_object[k]]["positions_count_coarse"] for k in range(K)]
+    pf = [cfg["model"]["object_models"][lay.model_of_object[k]]["positions_count_fine"] for k in range(K)]
+    fine = "fine" in generated
+    explicit = {}
+    for k in range(K):
+        explicit[f"jitter_{k}"] = _noise_fill(seed, 0, 0, k, (N, R, pc[k]))
+        explicit[f"alpha_{k}"] = _noise_fill(seed, 1, 0, k, (N, R, pc[k]))
+        if fine:
+            explicit[f"pdf_{k}"] = _noise_fill(seed, 2, 0, k, (N, R, pf[k]))
+        explicit[f"int_coarse_{k}"] = _noise_fill(seed, 3, 0, k, (N, R, pc[k]))
+        if fine:
+            explicit[f"int_fine_{k}"] = _noise_fill(seed, 3, 1, k, (N, R, pc[k] + pf[k]))
+    explicit["int_coarse_global"] = _noise_fill(seed, 4, 0, 0, (N, R, sum(pc)))
+    if fine:
+        explicit["int_fine_global"] = _noise_fill(seed, 4, 1, 0, (N, R, sum(pc) + sum(pf)))
+    with torch.no_grad():
+        replay = comp(*gin, True, _noise=explicit)
+        lead = list(gin[1].shape[:-2])
+        cpu_noise = {k: v.cpu().reshape(lead + list(v.shape[1:])) for k, v in explicit.items()}
+        sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+        want = ro.composer_forward(cfg, sd, *inputs, True, noise=cpu_noise, stable_merge=True)
+    for ty in [t for t in ("coarse", "fine") if t in generated]:
+        for entry in generated[ty]:
+            for key in ("integrated_features", "opacity", "depth", "weights"):
+                a, b, c = generated[ty][entry][key], replay[ty][entry][key], again[ty][entry][key]
+                assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (ty, entry, key)
+                assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(c)), (ty, entry, key)
+    assert_close(want, generated, rtol=1e-3, atol=1e-4) if fine else assert_close(want, generated)
+    with torch.no_grad():                              # another seed, another image
+        other = comp(*gin, True)
+    assert comp.last_noise_seed != seed
+    assert not torch.equal(other["coarse"]["global"]["opacity"], generated["coarse"]["global"]["opacity"])
+
+
+def test_generated_noise_training_gradients_match_explicit_replay():
+    """Training step with in-kernel noise (jitter, density noise, Hutchinson probes regenerated by pr_render_backward) against
+    the same step with the generator's values replayed as explicit tensors: identical results and identical gradients."""
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    scene = synthetic.minecraft_scene(batch=2, seed=19)
+    inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 12))]
+    results = []
+    seed = None
+    for mode in ("device", "explicit"):
+        comp = build(cfg, alpha_bias=3.0).cuda().train()
+        o, d, n, w2o, sty, dfm, ins = [v.clone() for v in inputs]
+        sty.requires_grad_(True)
+        w2o.requires_grad_(True)
+        lay = ro.ObjectLayout(cfg)
+        K, N, R = lay.objects_count, 2, d.size(-2)
+        pc = [cfg["model"]["object_models"][lay.model_of_object[k]]["positions_count_coarse"] for k in range(K)]
+        if mode == "device":
+            torch.manual_seed(5)
+            out = comp(o, d, n, w2o, sty, dfm, ins, True)
+            seed = comp.last_noise_seed
+        else:
+            explicit = {}
+            for k in range(K):
+                explicit[f"jitter_{k}"] = _noise_fill(seed, 0, 0, k, (N, R, pc[k]))
+                explicit[f"alpha_{k}"] = _noise_fill(seed, 1, 0, k, (N, R, pc[k]))
+                explicit[f"int_coarse_{k}"] = _noise_fill(seed, 3, 0, k, (N, R, pc[k]))
+                explicit[f"div_coarse_{k}"] = _noise_fill(seed, 5, 0, k, (N, R, pc[k], 3))
+            explicit["int_coarse_global"] = _noise_fill(seed, 4, 0, 0, (N, R, sum(pc)))
+            out = comp(o, d, n, w2o, sty, dfm, ins, True, _noise=explicit)
+        g = out["coarse"]["global"]
+        (g["integrated_features"].square().mean() + g["opacity"].mean() + g["depth"].mean() * 0.01).backward()
+        grads = {name: p.grad.clone() for name, p in comp.named_parameters() if p.grad is not None}
+        results.append((out, sty.grad.clone(), w2o.grad.clone(), grads))
+    (a, sa, wa, ga), (b, sb, wb, gb) = results
+    for key in ("integrated_features", "opacity", "depth", "integrated_divergence", "integrated_displacements_magnitude"):
+        assert torch.equal(a["coarse"]["global"][key], b["coarse"]["global"][key]), key
+    assert float(a["coarse"]["global"]["integrated_divergence"].abs().max()) > 0
+    # (the pose / style gradients are accumulated with atomics: equal up to the summation order, run to run)
+    close = lambda x, y: torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()))
+    assert close(sa, sb) and close(wa, wb)
+    assert set(ga) == set(gb) and all(close(ga[k], gb[k]) for k in ga)
