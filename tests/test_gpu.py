@@ -1645,7 +1645,8 @@ def test_decoder_layout_emission_matches_wire_format(mode):
         begin += counts[i]
     loss.backward()
     assert float(via_maps.abs().max()) > 0
-    assert torch.allclose(via_maps, style.grad, rtol=1e-5, atol=1e-7)
+    # (style gradients are accumulated with atomics: equal up to the summation order)
+    assert torch.allclose(via_maps, style.grad, rtol=1e-4, atol=1e-6 * float(style.grad.abs().max()))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
