@@ -238,7 +238,7 @@ class _RenderFunction(torch.autograd.Function):
 class ObjectComposer(nn.Module):
 
     #: upper limit for the per-call scratch (MLP feature rows dominate); larger calls are split along the ray dimension,
-    #: which is exact because rays are independent.  The effective budget of a call is the smaller of this and 90 % of
+    #: which is exact because rays are independent.  The effective budget of a call is the smaller of this and 80 % of
     #: the device memory that is free (or held by this module's own workspace / torch's cache) at call time.
     max_workspace_bytes = 96 << 30
 
@@ -434,7 +434,7 @@ class ObjectComposer(nn.Module):
 
     def _workspace_budget(self, dev, need: int) -> int:
         """Scratch bytes a call may use: ``max_workspace_bytes``, and - when the call needs more than the workspace this
-        module already holds - at most 90 % of what the device can still provide (free memory + torch's cached blocks +
+        module already holds - at most 80 % of what the device can still provide (free memory + torch's cached blocks +
         the workspace that would be released first)."""
         cap = int(self.max_workspace_bytes)
         held = self._workspace.numel() if (self._workspace is not None and self._workspace.device == dev) else 0
@@ -442,7 +442,7 @@ class ObjectComposer(nn.Module):
             return cap          # fits the workspace that is already allocated: no device query on the hot path
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        return max(1 << 20, min(cap, int(0.9 * (free + cached + held))))
+        return max(1 << 20, min(cap, int(0.8 * (free + cached + held))))   # the result tensors need room too
 
     def _linspace_for(self, count: int, device) -> torch.Tensor:
         key = (count, str(device))
@@ -729,6 +729,10 @@ class ObjectComposer(nn.Module):
         if need > budget and R > 1:
             chunk = max(1, int(R * budget / need))
             chunk = max(256, chunk // 256 * 256) if chunk >= 256 else chunk
+            # part of the scratch does not shrink with the rays (the pending stacks of the gated head, per-frame tables):
+            # step down until a chunk really fits
+            while chunk > 256 and workspace_bytes(build_call(0, chunk)) > budget:
+                chunk = max(256, int(chunk * 0.8) // 256 * 256)
         F = models_c[0].nerf_model.output_features
         layout = None
         if _decoder_layout is not None:

@@ -1781,3 +1781,66 @@ def test_generated_noise_training_gradients_match_explicit_replay():
     close = lambda x, y: torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()))
     assert close(sa, sb) and close(wa, wb)
     assert set(ga) == set(gb) and all(close(ga[k], gb[k]) for k in ga)
+
+
+def test_autograd_node_guards():
+    """What torch's own saved-tensor machinery would catch for a torch graph: a second backward through a freed renderer call
+    and an in-place parameter update between forward and backward raise clear errors (pr_render_backward reads the
+    parameter storages and the forward workspace in place); a render at the other precision between forward and backward
+    (which repacks the weights) does not disturb the pending backward."""
+    cfg = configs.reduced_config(configs.tennis_config(), **SMALL_NETS)
+    comp = build(cfg).cuda().train()
+    inputs = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=3), pixels=grid_pixels(256, 256, 10))]
+    inputs[4] = inputs[4].clone().requires_grad_(True)
+
+    def render():
+        torch.manual_seed(1)
+        return comp(*inputs, False)["coarse"]["global"]["integrated_features"].square().mean()
+
+    loss = render()
+    loss.backward()
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    loss = render()
+    with torch.no_grad():
+        next(comp.parameters()).mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+    # reference gradient, then the same with an evaluation render at the other precision squeezed in between
+    comp.zero_grad()
+    inputs[4].grad = None
+    render().backward()
+    want = inputs[4].grad.clone()
+    inputs[4].grad = None
+    loss = render()
+    comp.eval()
+    comp.precision = "f16x3"
+    with torch.no_grad():
+        comp(*[t.detach() for t in inputs], False)
+    comp.precision = "fp32"
+    comp.train()
+    loss.backward()
+    assert torch.allclose(inputs[4].grad, want, rtol=1e-4, atol=1e-6 * float(want.abs().max()))
+
+
+def test_workspace_budget_follows_free_memory(monkeypatch):
+    """The scratch budget of a call is capped by what the device can still provide (free memory as the driver reports it +
+    torch's cached blocks + the module's own workspace): with little memory reported free a full-frame render is split along
+    the rays (exactly) instead of asking for the full scratch."""
+    cfg = configs.tennis_config()
+    comp = build(cfg).cuda()
+    inputs = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=1234))]
+    with torch.no_grad():
+        want = comp(*inputs, False)["coarse"]["global"]["integrated_features"].clone()
+    full = comp._workspace.numel()
+    comp._workspace = None
+    torch.cuda.empty_cache()
+    total = torch.cuda.mem_get_info()[1]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (256 << 20, total))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
+    assert comp._workspace_budget(inputs[1].device, full) <= 256 << 20
+    with torch.no_grad():
+        got = comp(*inputs, False)["coarse"]["global"]["integrated_features"]
+    assert comp._workspace.numel() < full // 4                   # the call was split into ray chunks
+    assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
