@@ -357,6 +357,13 @@ def check_samplers():
         torch.manual_seed(1)
         b = rs.strided_patch_pixels(boxes, weights, h, w, patch, strides)
         ok &= torch.equal(d_ref, pick(a)) and torch.equal(a, b) and torch.equal(rs.positions_from_indices(b, h, w), p_ref)
+        for fn in (lambda: RayHelper.sample_rays_strided_patch(dirs, obs, patch, strides, boxes, weights, align_grid=False),
+                   lambda: rs.strided_patch_pixels(boxes, weights, h, w, patch, strides, align_grid=False)):
+            try:                 # the unaligned variant is refused by the reference (ray_helper.py:269-270) - and here, with its message
+                fn()
+                ok = False
+            except Exception as e:
+                ok &= str(e) == "Align grid is required for patched ray sampling."
     torch.manual_seed(2)
     d_ref, _, p_ref = RayHelper.sample_rays_weighted(dirs, obs, 300, boxes, weights)
     torch.manual_seed(2)

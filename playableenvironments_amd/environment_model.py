@@ -555,12 +555,13 @@ class EnvironmentModel(nn.Module):
                 "object_rotation_parameters": rot, "object_translation_parameters": tr, "object_style": style,
                 "object_deformation": deformation, "object_in_scene": present[..., 0, :]}
 
-    def _select_pixels(self, boxes, lead, height, width, samples_per_image, patch_size, patch_stride, device):
+    def _select_pixels(self, boxes, lead, height, width, samples_per_image, patch_size, patch_stride, device, align_grid=True):
         """The four pixel-selection branches of the reference (environment_model.py:949-958): flat pixel indices (..., R)
         per frame, or a shared (R,) list for the static selections."""
         flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
         if patch_size != 0 and samples_per_image != 0:
-            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
+            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride,
+                                                    align_grid=align_grid)
             return idx.reshape(lead + [-1])
         if samples_per_image == 0:
             strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)
@@ -591,13 +592,10 @@ class EnvironmentModel(nn.Module):
         What the trainers call (training/trainer.py).  Poses, style and deformation come from the injected encoders; the
         span between them and the result dictionary - camera rays, box projection, pixel selection with the ground-truth
         pixels gathered alongside, ray-object distances, the composer - is this package's (HIP renderer; batched,
-        synchronisation-free host math).  Differences from the reference, all in what it accepts: ``align_grid=False``
-        raises (the patch sampler of this package implements the aligned variant every shipped configuration uses), so do
-        the disabled-by-default camera offsets and the optional image decoder."""
+        synchronisation-free host math).  Differences from the reference, all in what it accepts: the
+        disabled-by-default learnable camera offsets and the optional image decoder raise (``align_grid=False`` with a patch
+        raises in the reference too)."""
         self._require_encoders()
-        if patch_size != 0 and samples_per_image != 0 and not align_grid:
-            raise NotImplementedError("sample_rays_strided_patch(align_grid=False) is not implemented; every caller of the "
-                                      "reference passes align_grid=True")
         if self.use_image_decoder:
             raise NotImplementedError("config['model']['image_decoder'] (compute_decoded_image, environment_model.py:708-741) "
                                       "is not part of this package")
@@ -622,7 +620,8 @@ class EnvironmentModel(nn.Module):
         axes = self.compute_object_axes_projection(o2w, w2c.detach(), render_focals.detach(), height, width)
 
         # pixel selection; the ground-truth pixels and the normalised positions are gathered with the same indices
-        idx = self._select_pixels(boxes, lead, height, width, samples_per_image, patch_size, patch_stride, observations.device)
+        idx = self._select_pixels(boxes, lead, height, width, samples_per_image, patch_size, patch_stride, observations.device,
+                                  align_grid=align_grid)
         rows, cols = ray_sampling.split_indices(idx, width)
         hwc = observations.movedim(-3, -1).reshape(lead + [height * width, observations.size(-3)])
         full = idx if idx.dim() > 1 else idx.expand(lead + [idx.numel()])

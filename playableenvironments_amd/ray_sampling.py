@@ -89,11 +89,14 @@ def sample_pixels_uniform(frames: int, height: int, width: int, samples_per_imag
 
 
 def strided_patch_pixels(bounding_boxes: torch.Tensor, weights: Sequence[float], height: int, width: int,
-                         patch_size: int, strides) -> torch.Tensor:
-    """RayHelper.sample_rays_strided_patch with align_grid=True (ray_helper.py:236-431): one
+                         patch_size: int, strides, align_grid: bool = True) -> torch.Tensor:
+    """RayHelper.sample_rays_strided_patch (ray_helper.py:236-431; ``align_grid=False`` raises, as the reference does at
+    :269-270): one
     box-weighted random centre per frame, clamped so the patch stays inside the image and aligned to the
     grid of the largest stride; then a ``p_i x p_i`` grid per stride (p_i = patch * s_0 / s_i), strides
     concatenated smallest first, row-major.  Returns (N, sum p_i^2) flat pixel indices."""
+    if not align_grid:
+        raise Exception("Align grid is required for patched ray sampling.")
     if patch_size % 2 != 0:
         raise Exception("Patch size must be a multiple of 2")
     if not isinstance(strides, collections.abc.Sequence):
