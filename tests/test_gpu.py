@@ -1844,3 +1844,25 @@ def test_workspace_budget_follows_free_memory(monkeypatch):
         got = comp(*inputs, False)["coarse"]["global"]["integrated_features"]
     assert comp._workspace.numel() < full // 4                   # the call was split into ray chunks
     assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+
+
+def test_generated_noise_is_independent_of_ray_chunking():
+    """A perturbed render split along the rays (workspace budget) draws the noise of the UNSPLIT tensors (noise_ray_offset /
+    noise_total_rays): identical to the unsplit render for the same seed, also for a multi-frame call."""
+    cfg = configs.tennis_config(hierarchical=(16, 32))
+    comp = build(cfg).cuda()
+    scene = synthetic.tennis_scene(batch=2, seed=7)
+    inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 48))]
+    with torch.no_grad():
+        torch.manual_seed(11)
+        whole = comp(*inputs, True)
+        seed = comp.last_noise_seed
+        comp.max_workspace_bytes = 192 << 20           # forces several ray chunks
+        comp._workspace = None
+        torch.manual_seed(11)
+        chunked = comp(*inputs, True)
+    assert comp.last_noise_seed == seed and comp._workspace.numel() <= 192 << 20
+    for ty in ("coarse", "fine"):
+        for entry in ("global", "object_0", "object_3"):
+            for key in ("integrated_features", "opacity", "depth", "weights"):
+                assert torch.equal(torch.nan_to_num(whole[ty][entry][key]), torch.nan_to_num(chunked[ty][entry][key])), (ty, entry, key)
