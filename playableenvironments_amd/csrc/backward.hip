@@ -942,7 +942,7 @@ static int input_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, con
 // the running gradient in LDS), then ONE grouped launch (+ its reduction) for every weight / bias gradient.
 static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, const pr_linear_grad_t* grads, int count, int skip,
                                 int width, int width_pad, const float* acts, size_t act_stride, const float* in0, int ld_in0,
-                                int n_in0, const float* cur, float* g_in) {
+                                int n_in0, const float* cur, float* g_in, const unsigned char* bits) {
     ChainBwdParams cp;
     memset(&cp, 0, sizeof(cp));
     PR_TRY(prepare_chain_bwd(layers, count, skip, width, n_in0, g.chain_packed, &cp, g.s));
@@ -950,6 +950,7 @@ static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, con
     cp.total = g.rows;
     cp.g_last = cur;
     cp.acts = acts; cp.act_stride = act_stride;
+    cp.bits = bits; cp.bits_stride = g.cap * (size_t)(width_pad / 8);
     cp.gstack = g.gstack; cp.g_stride = g.cap * (size_t)width_pad;
     cp.g_in = g_in; cp.ld_in = ld_in0;
     PR_TRY(launch_chain_bwd(cp, g.max_rows, g.s));
@@ -989,8 +990,8 @@ static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, con
 // Returns with the gradient of the network input [PE | extra] accumulated in g_in (n_in0 real columns).
 static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_linear_grad_t* grads, int count, int skip,
                           int width, int width_pad, const float* acts, size_t act_stride, const float* in0, int ld_in0,
-                          int n_in0, float* cur, float* other, float* g_in) {
-    if (g.gstack) return chain_backward_fused(g, layers, grads, count, skip, width, width_pad, acts, act_stride, in0, ld_in0, n_in0, cur, g_in);
+                          int n_in0, float* cur, float* other, float* g_in, const unsigned char* bits) {
+    if (g.gstack) return chain_backward_fused(g, layers, grads, count, skip, width, width_pad, acts, act_stride, in0, ld_in0, n_in0, cur, g_in, bits);
     bool g_in_written = false;
     for (int l = count - 1; l >= 0; --l) {
         const pr_linear_t& L = layers[l];
@@ -1163,7 +1164,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         PR_LAUNCH_CHECK();
         // ---- backbone -------------------------------------------------------------------------------
         PR_TRY(chain_backward(gc, m.backbone, G.backbone, nb, m.skip_layer_idx, d.W, d.Wpad, acts, act_stride, enc, d.enc_pad,
-                              d.enc, bufB, bufA, g_enc));
+                              d.enc, bufB, bufA, g_enc, reinterpret_cast<const unsigned char*>(fws + sv.bits)));
         // ---- positional encoding ----------------------------------------------------------------------
         const float* gx_final = nullptr;
         if (m.kind == 0) {
@@ -1192,7 +1193,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
                                d.BWpad, d.BW, m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
             PR_LAUNCH_CHECK();
             PR_TRY(chain_backward(gc, m.bender, G.bender, bc, m.bender_skip, d.BW, d.BWpad, bacts, bact_stride, bin, d.bin_pad,
-                                  d.bin, bufA, bufB, g_enc));
+                                  d.bin, bufA, bufB, g_enc, reinterpret_cast<const unsigned char*>(fws + sv.bbits)));
             hipLaunchKernelGGL(k_pe_bwd, dim3(row_blocks), dim3(256), 0, s, rc, bin, g_enc, d.bin_pad, 3, m.bender_octaves, size[0],
                                size[1], size[2], 1, g_x, 3, 1);
             PR_LAUNCH_CHECK();

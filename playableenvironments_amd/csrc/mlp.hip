@@ -938,6 +938,22 @@ __device__ __forceinline__ void gated_head_flush(Smem& S, const MlpParams& p, in
     head_on_tile(S, p, enc, pending);
 }
 
+// ReLU mask of the tile staged in X as a bit image: byte (row, c8) = bits of columns 8 c8 .. 8 c8 + 7 ("activation > 0"),
+// rows of width / 8 bytes in compact-row order - 2 KB per tile and layer, which the backward chain loads instead of the
+// 64 KB of activations.
+__device__ __forceinline__ void write_tile_bits(const Smem& S, unsigned char* dst, int width_pad, int tile_base) {
+    const int c8n = width_pad >> 3;
+    for (int idx = threadIdx.x; idx < TILE_M * c8n; idx += MLP_THREADS) {
+        const int row = idx / c8n, c8 = idx - row * c8n;
+        if (!(S.flags[row] & 1)) continue;
+        const float4 a = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8);
+        const float4 b = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8 + 4);
+        const unsigned int byte = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u) |
+                                  (b.x > 0.f ? 16u : 0u) | (b.y > 0.f ? 32u : 0u) | (b.z > 0.f ? 64u : 0u) | (b.w > 0.f ? 128u : 0u);
+        dst[(size_t)(tile_base + row) * c8n + c8] = (unsigned char)byte;
+    }
+}
+
 // Per-channel sum and sum of squares of the alive rows of the tile staged in X -> global double
 // accumulators (one atomic per channel and tile); the number of alive rows is counted alongside.
 __device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams& p) {
@@ -962,7 +978,11 @@ __device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams&
     __syncthreads();
 }
 
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) {
+// TRAIN = false: the evaluation kernel (everything fused, optional sigma gate) - what the benchmark runs; none of the
+// training-only code (saved activations, ReLU bit images, phase 1 of the batch-statistics launches) is compiled into it.
+// TRAIN = true: phase 1 of the phased launches (train-mode BatchNorm and / or PR_FLAG_SAVE_FOR_BACKWARD).
+template <bool TRAIN>
+__device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
@@ -1014,11 +1034,12 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         if (p.has_bender) {
             fill_bender_input(S, p, enc, false);
             __syncthreads();
-            if (p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
+            if (TRAIN && p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
                 run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc);
-                if (p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
+                if (TRAIN && p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
                     write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
+                    if (p.save_bbits) write_tile_bits(S, p.save_bbits + (size_t)l * p.save_bbits_stride, p.BWpad, tile_base);
                     __syncthreads();
                 }
             }
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                 row_dots(S, s, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
                 if ((tid & 7) != 0) continue;
                 float d[3], bent[3];
-                if (p.save_braw && (S.flags[s] & 1))
+                if (TRAIN && p.save_braw && (S.flags[s] & 1))
                     for (int a = 0; a < 3; ++a) p.save_braw[(size_t)(tile_base + s) * 3 + a] = out[a];
                 for (int a = 0; a < 3; ++a) {
                     const float x = S.pos[s * 8 + a];
@@ -1044,7 +1065,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
                     if (p.dispmag)
                         p.dispmag[S.flat[s]] = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])),
                                                                __fmul_rn(d[2], d[2])));
-                    if (p.save_delta)
+                    if (TRAIN && p.save_delta)
                         for (int a = 0; a < 3; ++a) p.save_delta[(size_t)(tile_base + s) * 3 + a] = d[a];
                     if (p.delta_dense)
                         for (int a = 0; a < 3; ++a) p.delta_dense[(size_t)S.flat[s] * 3 + a] = d[a];
@@ -1060,13 +1081,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
         fill_nerf_input(S, p, enc, false);
         __syncthreads();
         PR_PHASE(2);
-        if (p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false);
+        if (TRAIN && p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false);
 
         // ---- backbone ---------------------------------------------------------------------------
         for (int l = 0; l < p.n_backbone; ++l) {
             run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
-            if (p.save_act) {
+            if (TRAIN && p.save_act) {
                 write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
+                if (p.save_bits) write_tile_bits(S, p.save_bits + (size_t)l * p.save_bits_stride, p.Wpad, tile_base);
                 __syncthreads();
             }
         }
@@ -1092,11 +1114,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
 
         PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
-        if (p.phase == 0 && p.gate) {
+        if (!TRAIN && p.gate) {
             __syncthreads();   // the liveness bits are complete
             pending = gated_head(S, p, tile_base, pending, enc);
             PR_PHASE(8);
-        } else if (p.phase == 0) {
+        } else if (!TRAIN) {
             for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer(p.layers[l], S, p, tile_base, 0, enc);
             PR_PHASE(15);
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
@@ -1113,8 +1135,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(Mlp
             accumulate_stats(S, p);
         }
     }
-    if (p.phase == 0 && p.gate) gated_head_flush(S, p, pending, enc);
+    if (!TRAIN && p.gate) gated_head_flush(S, p, pending, enc);
 }
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) { mlp_tile_loop<false>(p); }
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train(MlpParams p) { mlp_tile_loop<true>(p); }
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
 // affine built from the BATCH statistics + ReLU, run the next head matmul.
@@ -1308,7 +1333,9 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
     }
     const MlpParams& pd = p;
     int cu_count = 0;
-    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(pd.phase >= 2 ? k_mlp_head : k_mlp_mfma), (int)sizeof(Smem), &cu_count));
+    const void* kernel = pd.phase >= 2 ? reinterpret_cast<const void*>(k_mlp_head)
+                         : (pd.phase == 1 ? reinterpret_cast<const void*>(k_mlp_mfma_train) : reinterpret_cast<const void*>(k_mlp_mfma));
+    PR_TRY(prepare_kernel(kernel, (int)sizeof(Smem), &cu_count));
     int resident = cu_count * MLP_BLOCKS_PER_CU;
     if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;   // the pending stacks of the gated head are sized for this
     const int grid = max_tiles < resident ? max_tiles : resident;
@@ -1316,6 +1343,8 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
     ProfileScope scope(0, s);
     if (pd.phase >= 2) {
         hipLaunchKernelGGL(k_mlp_head, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
+    } else if (pd.phase == 1) {
+        hipLaunchKernelGGL(k_mlp_mfma_train, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
     } else {
         hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, pd);
     }
@@ -1482,8 +1511,25 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd(Ch
         for (int l = c.count - 1; l >= 1; --l) {
             // the ReLU mask of this layer's input (layer l - 1's output) -> bits, visible after the barrier inside run_layer
 #if !(defined(PR_CHAIN_ABLATE) && (PR_CHAIN_ABLATE & 2))     // measurement builds: 2 = no mask bits, 1 = no gradient write-out
-            build_relu_mask_bits(reinterpret_cast<unsigned char*>(S.pos), c.acts + (size_t)(l - 1) * c.act_stride, c.Wpad, c.Wpad,
-                                 tile_base, rows_valid);
+            if (c.bits) {
+                // the forward pass left the bit image of this tile and layer behind: 64 x (width / 8) contiguous bytes
+                const int bytes = TILE_M * (c.Wpad >> 3);
+                const unsigned char* src = c.bits + (size_t)(l - 1) * c.bits_stride + (size_t)tile_base * (c.Wpad >> 3);
+                const int live_bytes = rows_valid * (c.Wpad >> 3);
+                for (int i = tid * 8; i < bytes; i += MLP_THREADS * 8) {
+                    unsigned long long v = 0ull;
+                    if (i + 8 <= live_bytes) {
+                        v = *reinterpret_cast<const unsigned long long*>(src + i);
+                    } else {
+                        // the word straddles the end of the tile's real rows (rows narrower than 8 bytes): byte by byte
+                        for (int b = 0; b < 8 && i + b < live_bytes; ++b) v |= (unsigned long long)src[i + b] << (8 * b);
+                    }
+                    *reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(S.pos) + i) = v;
+                }
+            } else {
+                build_relu_mask_bits(reinterpret_cast<unsigned char*>(S.pos), c.acts + (size_t)(l - 1) * c.act_stride, c.Wpad, c.Wpad,
+                                     tile_base, rows_valid);
+            }
 #endif
             if (l == c.skip) {
                 e.gout = c.g_in; e.ldg = c.ld_in; e.accumulate = 0; e.n_real = c.in_real;

@@ -86,6 +86,7 @@ struct ChainBwdParams {
     Layer in0_skip, in0_first;         // W_skip[:, W:]^T and W_0^T (gradient of the network input)
     const float* g_last;               // (cap, Wpad) d loss / d pre-activation of the last layer
     const float* acts; size_t act_stride;   // saved post-ReLU outputs of layers 0 .. count - 1, (cap, Wpad) each
+    const unsigned char* bits; size_t bits_stride;   // their ReLU masks as bit images (cap, Wpad / 8 bytes) each, written by the forward pass
     float* gstack; size_t g_stride;    // out: pre-activation gradients of layers 0 .. count - 2, (cap, Wpad) each
     float* g_in; int ld_in;            // out: gradient of the network input (cap, ld_in)
 };
@@ -178,6 +179,10 @@ struct MlpParams {
     float* save_bin;             // (cap, bin_pad) bender input [annealed PE | deformation]
     float* save_bact;            // b_count blocks of (cap, BWpad)
     size_t save_bact_stride;
+    unsigned char* save_bits;    // n_backbone blocks of (cap, Wpad / 8) bytes: bit c of row r = (post-ReLU activation > 0), the
+    size_t save_bits_stride;     // ReLU masks the backward chain reads instead of the activations (bytes between the blocks)
+    unsigned char* save_bbits;   // the same for the bender layers, (cap, BWpad / 8)
+    size_t save_bbits_stride;
     float* save_braw;            // (cap, 3) bender head output before * size and the clamp
     float* save_delta;           // (cap, 3) final displacement (after clamp / canonical_pose)
     float* delta_dense;          // (N,R,P,3) the same, scattered to the sample grid (optional export)
@@ -369,7 +374,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s);
     } while (0)
 
 struct SavedPlan {   // PR_FLAG_SAVE_FOR_BACKWARD: per object instance and model type
-    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta, div;
+    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta, div, bits, bbits;
 };
 struct TypePlan {
     size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
