@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -13,7 +14,7 @@ namespace pr {
 // Kernel timing
 // ---------------------------------------------------------------------------------------------
 struct ProfileRecord { int category; hipEvent_t start, stop; };
-static bool g_profile_on = false;
+static std::atomic<bool> g_profile_on{false};   // bench-only switch; launches read it relaxed, no lock on the product path
 static std::vector<ProfileRecord> g_profile;
 static std::mutex g_profile_mutex;
 
@@ -38,7 +39,7 @@ int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count) {
 }
 
 ProfileScope::ProfileScope(int category, hipStream_t s) : category_(category), stream_(s), start_(nullptr), active_(false) {
-    if (!g_profile_on) return;
+    if (!g_profile_on.load(std::memory_order_relaxed)) return;
     if (hipEventCreate(&start_) != hipSuccess) return;
     if (hipEventRecord(start_, stream_) != hipSuccess) {
         (void)hipEventDestroy(start_);
@@ -563,7 +564,7 @@ extern "C" int pr_noise_fill(uint64_t seed, int32_t kind, int32_t type, int32_t 
 }
 
 extern "C" int pr_profile_enable(int enable) {
-    pr::g_profile_on = enable != 0;
+    pr::g_profile_on.store(enable != 0, std::memory_order_relaxed);
     return PR_OK;
 }
 
