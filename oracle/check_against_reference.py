@@ -589,6 +589,81 @@ def check_observation_modes():
     return ok
 
 
+def check_camera_offsets():
+    """Learnable per-frame camera offsets: the product's one-table CameraParametersStorage against the reference's
+    one-parameter-per-entry module (checkpoint keys, strict load, values in train / eval), then the observation-driven modes
+    with the offsets switched on (incl. the scene-encoding-only mode, which adds the ROTATION offsets to the focals)."""
+    from model.layers.camera_parameters_storage import CameraParametersStorage as RefStorage
+    from playableenvironments_amd import environment_model as em
+    from playableenvironments_amd.modules import CameraParametersStorage
+    ok = True
+    torch.manual_seed(5)
+    ref_store = RefStorage(6, 2)
+    for q in ref_store.parameters():
+        q.data.normal_(0, 0.01)
+    mine_store = CameraParametersStorage(6, 2)
+    same_keys = list(ref_store.state_dict()) == list(mine_store.state_dict())
+    mine_store.load_state_dict(ref_store.state_dict(), strict=True)
+    frames = torch.tensor([[0, 5, 2], [3, 3, 1]])
+    same_values = True
+    for train in (True, False):
+        ref_store.train(train), mine_store.train(train)
+        same_values &= all(torch.equal(a, b) for a, b in zip(ref_store(frames), mine_store(frames)))
+    g_ref = torch.autograd.grad(sum((o * (i + 1)).sum() for i, o in enumerate(ref_store.train()(frames))), list(ref_store.parameters()),
+                                allow_unused=True)
+    g_ref = [torch.zeros(7) if g is None else g for g in g_ref]
+    g_mine, = torch.autograd.grad(sum((o * (i + 1)).sum() for i, o in enumerate(mine_store.train()(frames))), [mine_store.table])
+    same_grads = torch.equal(torch.stack(g_ref), g_mine)
+    print(f"[camera offsets, storage] same checkpoint keys={same_keys} same values={same_values} same gradients={same_grads}")
+    ok &= same_keys and same_values and same_grads
+
+    original_camera_rays = em.camera_rays
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    try:
+        cfg = configs.reduced_config(configs.tennis_config(), **small)
+        cfg["model"]["enable_camera_parameters_offsets"] = True
+        cfg["model"]["camera_parameters_memory_size"] = 8
+        scene = synthetic.tennis_scene(batch=2, observations=2, seed=3, image_size=(48, 64))
+        ref, mine, batch = observation_mode_setup(cfg, "tennis", scene)
+        ref.enable_camera_parameters_offsets = True
+        ref.camera_parameters_offsets = RefStorage(8, mine.training_cameras_count)
+        for q in ref.camera_parameters_offsets.parameters():
+            q.data.normal_(0, 0.002)
+        sd = ref.camera_parameters_offsets.state_dict()
+        mine.camera_parameters_offsets.load_state_dict(sd, strict=True)
+        want_keys = ["camera_parameters_offsets." + k for k in sd]
+        got_keys = [k for k in mine.state_dict() if k.startswith("camera_parameters_offsets.")]
+        print(f"[camera offsets, EnvironmentModel] checkpoint keys as the reference's: {want_keys == got_keys}")
+        ok &= want_keys == got_keys
+        ref.camera_parameters_offsets.train(), mine.camera_parameters_offsets.train()     # offsets read; BatchNorm stays in eval
+        args = [batch[k] for k in OBS_KEYS]
+        for label, kw in (("strided grid", dict(samples_per_image=0, perturb=False, patch_stride=[4, 8])),
+                          ("full frame", None), ("scene encoding only", dict(mode="observations_scene_encoding_only"))):
+            outs = []
+            for model in (ref, mine):
+                torch.manual_seed(11)
+                try:
+                    with torch.no_grad():
+                        if kw is None:
+                            outs.append(model.render_full_frame_from_observations(*[a.clone() for a in args], False))
+                        else:
+                            outs.append(model(*[a.clone() for a in args], **kw))
+                except Exception as e:       # the focal quirk broadcasts (..., C) with (..., C, 3): an error for most shapes
+                    outs.append(type(e))
+            if isinstance(outs[0], type) or isinstance(outs[1], type):
+                same = isinstance(outs[0], type) and isinstance(outs[1], type)
+                print(f"[camera offsets, {label}] reference raises {outs[0]}, product raises {outs[1]}: {'same' if same else 'DIFFERENT'}")
+                ok &= same
+                continue
+            rep = _compare_nested(outs[0], outs[1])
+            bad = {k: v[0] for k, v in rep.items() if not v[1]}
+            print(f"[camera offsets, {label}] fields={len(rep)} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}")
+            ok &= not bad
+    finally:
+        em.camera_rays = original_camera_rays
+    return ok
+
+
 def check_encoders():
     """playableenvironments_amd.encoders against the reference's encoder modules on CPU: identical state_dict keys / shapes,
     and - with the reference's weights loaded and the region-of-interest crop of BOTH sides served by the CPU restatement
@@ -821,6 +896,7 @@ def main():
     # (with use_fine the reference's own backward raises: compute_expected_positions keeps a view of the coarse weights
     # that sample_pdf later modifies in place - there is no reference gradient to pin for hierarchical configurations)
     ok &= check_observation_modes()
+    ok &= check_camera_offsets()
     ok &= check_encoders()
     ok &= check_boundary_signatures()
     ok &= check_configs_against_yaml()

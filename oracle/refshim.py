@@ -20,6 +20,8 @@ import importlib.abc
 import importlib.machinery
 import os
 import sys
+
+sys.dont_write_bytecode = True     # importing the reference must not leave __pycache__ files in its (read-only) tree
 import types
 
 import numpy as np

@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ray_sampling
+from .modules import CameraParametersStorage
 from .object_composer import ObjectComposer, ObjectIDsHelper
 
 
@@ -143,6 +144,11 @@ class EnvironmentModel(nn.Module):
         self.use_weighted_sampling = config["model"].get("use_weighted_sampling", False)
         self.sampling_weights = config["model"].get("sampling_weights", None)
         self.enable_camera_parameters_offsets = config["model"].get("enable_camera_parameters_offsets", False)
+        # always constructed, like the reference (environment_model.py:36-39): its entries are part of the checkpoint
+        cameras = config.get("training", {}).get("batching", {}).get("allowed_cameras", [0])
+        self.training_cameras_count = len(cameras)
+        self.camera_parameters_offsets = CameraParametersStorage(config["model"].get("camera_parameters_memory_size", 1),
+                                                                 self.training_cameras_count)
         self.use_image_decoder = "image_decoder" in config["model"]
         self.object_composer = ObjectComposer(config)
         self.object_id_helper = ObjectIDsHelper(config)
@@ -193,12 +199,18 @@ class EnvironmentModel(nn.Module):
                 "EnvironmentModel(config, object_encoders=..., object_parameters_encoders=...) or set_encoders(...), or "
                 "encode the scene elsewhere and call mode='scene_encodings'")
 
-    def _corrected_cameras(self, camera_rotations, camera_translations, focals, global_frame_indexes):
-        if self.enable_camera_parameters_offsets:
-            raise NotImplementedError("learnable per-frame camera offsets (enable_camera_parameters_offsets, "
-                                      "model/layers/camera_parameters_storage.py) are disabled in both shipped configurations "
-                                      "and are not part of this package")
-        return camera_rotations, camera_translations, focals
+    def get_camera_offsets_parameters(self):
+        return self.camera_parameters_offsets.parameters()
+
+    def _corrected_cameras(self, camera_rotations, camera_translations, focals, global_frame_indexes, focal_quirk=False):
+        """Adds the learnable per-frame camera offsets (environment_model.py:891-897, 1235-1241, 1408-1414).
+        ``focal_quirk``: the scene-encoding-only mode adds the ROTATION offsets to the focals (environment_model.py:798);
+        kept as the reference has it, broadcasting rules and all."""
+        if not self.enable_camera_parameters_offsets:
+            return camera_rotations, camera_translations, focals
+        rotation_offsets, translation_offsets, focal_offsets = self.camera_parameters_offsets(global_frame_indexes)
+        return (camera_rotations + rotation_offsets, camera_translations + translation_offsets,
+                focals + (rotation_offsets if focal_quirk else focal_offsets))
 
     # ------------------------------------------------------------------ modes
     def forward(self, *args, mode="observations", **kwargs):
@@ -538,7 +550,7 @@ class EnvironmentModel(nn.Module):
         """Scene encoding only (mode="observations_scene_encoding_only"; environment_model.py:772-845)."""
         self._require_encoders()
         camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
-                                                                                global_frame_indexes)
+                                                                                global_frame_indexes, focal_quirk=True)
         rescaled_focals = focals * self.focal_length_multiplier
         height, width = observations.size(-2), observations.size(-1)
         c2w = euler_to_matrix(camera_rotations, camera_translations)
@@ -592,9 +604,8 @@ class EnvironmentModel(nn.Module):
         What the trainers call (training/trainer.py).  Poses, style and deformation come from the injected encoders; the
         span between them and the result dictionary - camera rays, box projection, pixel selection with the ground-truth
         pixels gathered alongside, ray-object distances, the composer - is this package's (HIP renderer; batched,
-        synchronisation-free host math).  Differences from the reference, all in what it accepts: the
-        disabled-by-default learnable camera offsets and the optional image decoder raise (``align_grid=False`` with a patch
-        raises in the reference too)."""
+        synchronisation-free host math).  Difference from the reference, in what it accepts: the optional
+        image decoder raises (``align_grid=False`` with a patch raises in the reference too)."""
         self._require_encoders()
         if self.use_image_decoder:
             raise NotImplementedError("config['model']['image_decoder'] (compute_decoded_image, environment_model.py:708-741) "

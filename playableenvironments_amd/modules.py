@@ -240,3 +240,63 @@ class RayBendingStyleNerfModel(nn.Module):
 
 
 OBJECT_MODEL_CLASSES = {"model.nerf_models.ray_bending_style_nerf_model": RayBendingStyleNerfModel}
+
+
+class CameraParametersStorage(nn.Module):
+    """Learnable per-frame corrections of the measured cameras: 3 rotation, 3 translation and 1 focal offset per
+    (frame, camera), zero-initialised, read only in training mode (zeros in evaluation), translations scaled by 10 and
+    focals by 1000 (model/layers/camera_parameters_storage.py:9-67 over model/layers/indexed_storage.py:9-58).
+
+    The reference keeps one 7-vector ``nn.Parameter`` per entry and picks them in a Python loop with ``.item()``; here the
+    table is ONE ``(entries, 7)`` parameter read with one device gather.  The checkpoint format is the reference's
+    (``storage.storage.{entry}`` -> ``(7,)``): rows are split / joined when a state dict is written / read."""
+
+    features_count = 7
+
+    def __init__(self, storage_size: int, cameras_count: int):
+        super().__init__()
+        self.storage_size = int(storage_size)
+        self.cameras_count = int(cameras_count)
+        self.camera_adjusted_storage_size = self.storage_size * self.cameras_count
+        self.table = nn.Parameter(torch.zeros(self.camera_adjusted_storage_size, self.features_count))
+
+    def forward(self, frame_indexes: torch.Tensor):
+        steps = torch.arange(self.cameras_count, device=frame_indexes.device) * self.storage_size
+        entries = frame_indexes.unsqueeze(-1) + steps                       # (..., cameras): frame + camera * storage_size
+        if self.training:
+            rows = self.table[entries.long()]
+            rotation, translation, focal = rows[..., :3], rows[..., 3:6], rows[..., 6]
+        else:
+            shape = list(entries.shape)
+            rotation = torch.zeros(shape + [3], dtype=torch.float32, device=frame_indexes.device)
+            translation = torch.zeros(shape + [3], dtype=torch.float32, device=frame_indexes.device)
+            focal = torch.zeros(shape, dtype=torch.float32, device=frame_indexes.device)
+        return rotation, translation * 10, focal * 1000
+
+    # ---- the reference's checkpoint layout
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        for entry in range(self.camera_adjusted_storage_size):
+            row = self.table[entry]
+            destination[f"{prefix}storage.storage.{entry}"] = row if keep_vars else row.detach().clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        rows = []
+        for entry in range(self.camera_adjusted_storage_size):
+            key = f"{prefix}storage.storage.{entry}"
+            if key in state_dict:
+                value = state_dict[key]
+                if tuple(value.shape) != (self.features_count,):
+                    error_msgs.append(f"size mismatch for {key}: copying a param with shape {tuple(value.shape)} from "
+                                      f"checkpoint, the shape in current model is ({self.features_count},).")
+                    continue
+                rows.append((entry, value))
+            elif strict:
+                missing_keys.append(key)
+        if strict:
+            for key in state_dict:
+                if key.startswith(prefix) and key not in {f"{prefix}storage.storage.{e}"
+                                                           for e in range(self.camera_adjusted_storage_size)}:
+                    unexpected_keys.append(key)
+        with torch.no_grad():
+            for entry, value in rows:
+                self.table[entry].copy_(value)

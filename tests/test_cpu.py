@@ -888,3 +888,44 @@ def test_batch_packs_into_one_arena_and_keeps_the_reference_tuple():
     assert len(args) == 9 and torch.equal(args[1], b["camera_rotations"]) and torch.equal(args[8], b["video_indexes"])
     with pytest.raises(Exception, match="Object poses"):
         batch.to_object_poses_tuple(cuda=False)
+
+
+def test_camera_parameters_storage_checkpoint_layout_and_values():
+    """Learnable camera offsets (model/layers/camera_parameters_storage.py): one table here, the reference's
+    one-parameter-per-entry checkpoint keys outside; entry = frame + camera * storage_size; x10 / x1000 scales; zeros
+    outside training.  (The comparison with the imported reference module is in oracle/check_against_reference.py.)"""
+    from playableenvironments_amd.modules import CameraParametersStorage
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    store = CameraParametersStorage(4, 2)
+    sd = store.state_dict()
+    assert list(sd) == [f"storage.storage.{i}" for i in range(8)] and all(v.shape == (7,) for v in sd.values())
+    sd = {k: torch.full((7,), float(i + 1)) for i, k in enumerate(sd)}
+    store.load_state_dict(sd, strict=True)
+    frames = torch.tensor([[1, 3]])
+    rot, tr, focal = store.train()(frames)
+    assert rot.shape == (1, 2, 2, 3) and focal.shape == (1, 2, 2)
+    assert torch.equal(rot[0, :, :, 0], torch.tensor([[2., 6.], [4., 8.]]))          # (frame, camera) -> entry + 1
+    assert torch.equal(tr, rot * 10) and torch.equal(focal, rot[..., 0] * 1000)
+    assert all(float(o.abs().max()) == 0 for o in store.eval()(frames))
+    with pytest.raises(RuntimeError, match="Missing key"):
+        store.load_state_dict({k: v for k, v in sd.items() if not k.endswith(".3")}, strict=True)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        store.load_state_dict(dict(sd, **{"storage.storage.8": torch.zeros(7)}), strict=True)
+
+    cfg = configs.reduced_config(configs.tennis_config(), width=32, layers=2, skip=1, features=8, octaves=2,
+                                 bender_width=16, bender_layers=2, bender_skip=1, bender_octaves=2)
+    cfg["model"]["enable_camera_parameters_offsets"] = True
+    cfg["model"]["camera_parameters_memory_size"] = 3
+    model = EnvironmentModel(cfg)
+    assert [k for k in model.state_dict() if k.startswith("camera_parameters_offsets.")] == \
+        [f"camera_parameters_offsets.storage.storage.{i}" for i in range(3)]
+    with torch.no_grad():
+        model.camera_parameters_offsets.table.copy_(torch.arange(21.).reshape(3, 7) * 1e-3)
+    rotations, translations, focals = torch.zeros(1, 2, 1, 3), torch.zeros(1, 2, 1, 3), torch.full((1, 2, 1), 100.)
+    model.train()
+    r, t, f = model._corrected_cameras(rotations, translations, focals, torch.tensor([[2, 0]]))
+    assert torch.allclose(r[0, 0, 0], torch.tensor([14., 15., 16.]) * 1e-3) and torch.allclose(t[0, 1, 0], torch.tensor([3., 4., 5.]) * 1e-2)
+    assert torch.allclose(f[0, :, 0], torch.tensor([100. + 20., 100. + 6.]))
+    model.eval()
+    r, t, f = model._corrected_cameras(rotations, translations, focals, torch.tensor([[2, 0]]))
+    assert torch.equal(r, rotations) and torch.equal(f, focals)
