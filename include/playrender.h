@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PR_ABI_VERSION 2
+#define PR_ABI_VERSION 3
 #define PR_MAX_OBJECTS 8
 #define PR_MAX_LAYERS 12
 #define PR_MAX_OCTAVES 16
@@ -75,6 +75,13 @@ typedef enum pr_status {
                                        draws them with torch.rand / torch.randn: utils/lib_3d/ray_helper.py:1275,1380,
                                        model/object_composer.py:553,597,751).  pr_noise_fill writes the same values to a
                                        tensor (tests replay them through the explicit path and the oracle). */
+
+#define PR_FLAG_DIVERGENCE_GRAD 256u /* pr_backward_workspace_size / pr_render_backward: gradients of integrated_divergence are
+                                       given (pr_entry_grads_t.integrated_divergence); the backward pass then differentiates the
+                                       Hutchinson estimate e^T (d delta / dx) e through the ray bender (the reference's double
+                                       backward, object_composer.py:582-601 with create_graph=True): one more pass over the
+                                       bender with the probe tangents in place of the activations.  Sizes the tangent stack
+                                       inside the backward workspace; ignored by pr_render_forward. */
 
 /* One nn.Linear in the reference layout: weight (out_features, in_features) row-major, bias (out) or NULL. */
 typedef struct pr_linear_t {
@@ -263,6 +270,9 @@ typedef struct pr_entry_grads_t {
     const float* weights;                             /* (N,R,P) per object, (N,R,sum P) in merged order for the global
                                                          entry: consumers of the compositing weights themselves
                                                          (compute_expected_positions, object_composer.py:603-622) */
+    const float* integrated_divergence;               /* (N,R); read with PR_FLAG_DIVERGENCE_GRAD only: flows into the Hutchinson
+                                                         estimate (ray bender weights, sample positions), the alphas are
+                                                         detached there (object_composer.py:768-769) */
 } pr_entry_grads_t;
 
 typedef struct pr_output_grads_t {

@@ -21,6 +21,7 @@ PR_FLAG_TRAIN_BN = 16
 PR_FLAG_SAVE_FOR_BACKWARD = 32
 PR_FLAG_GATE_HEAD = 64
 PR_FLAG_DEVICE_NOISE = 128
+PR_FLAG_DIVERGENCE_GRAD = 256
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
 PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect
@@ -112,7 +113,8 @@ class Call(C.Structure):
 
 class EntryGrads(C.Structure):
     _fields_ = [("integrated_features", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
-                ("integrated_displacements_magnitude", C.c_void_p), ("weights", C.c_void_p)]
+                ("integrated_displacements_magnitude", C.c_void_p), ("weights", C.c_void_p),
+                ("integrated_divergence", C.c_void_p)]
 
 
 GRAD_FIELDS = [f[0] for f in EntryGrads._fields_]
@@ -190,8 +192,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pr_abi_version() != 2:
-        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 2 (rebuild: make -C playableenvironments_amd/csrc)")
+    if lib.pr_abi_version() != 3:
+        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 3 (rebuild: make -C playableenvironments_amd/csrc)")
     _LIB = lib
     return lib
 

@@ -37,12 +37,15 @@ struct CompositeBwdObject {
     float* g_t;              // (N,R,P)
     float* g_dm;             // (N,R,P) or NULL
     const float* g_sample_t; // (N,R,P) gradient of the exported sample depths, or NULL
+    const float* divergence; // (N,R,P) the forward pass's Hutchinson estimates (PR_FLAG_DIVERGENCE_GRAD), or NULL
+    float* g_div;            // (N,R,P) d loss / d divergence estimate, or NULL
 };
 struct CompositeBwdParams {
     int frames, rays, objects, static_objects, F;
     int fix_overlaps;
     int total_positions;
     int sort_size;
+    int div_grad;            // gradients of integrated_divergence are given: one more per-entry LDS column
     const float* ray_directions;
     NoiseRef noise_global;
     CompositeBwdObject obj[PR_MAX_OBJECTS];
@@ -51,7 +54,7 @@ struct CompositeBwdParams {
 
 struct BwdSmem {
     unsigned int* key;
-    float *tt, *sg, *dm, *wo, *wg, *al, *gs, *gt, *gd, *Tj, *wv, *dw, *dd;
+    float *tt, *sg, *dm, *wo, *wg, *al, *gs, *gt, *gd, *Tj, *wv, *dw, *dd, *gv;
     int *sl, *mk;
 };
 
@@ -90,7 +93,11 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         const float dt = (j < n - 1) ? __fsub_rn(sm.tt[entry_of(j + 1)], sm.tt[e]) : 1e10f;
         float raw = sm.sg[e];
         if (noisy) raw = __fadd_rn(raw, noise_normal(noise, ray, n, j));
-        sm.al[j] = alpha_of(raw, __fmul_rn(dt, norm));
+        const float a = alpha_of(raw, __fmul_rn(dt, norm));
+        sm.al[j] = a;
+        // integrated_divergence = mean_j (alpha_j |div_j|), alphas detached (object_composer.py:768-769); carved entries
+        // of the merged list carry div = 0
+        if (p.div_grad && g.integrated_divergence && !sm.mk[e]) sm.gv[e] += g.integrated_divergence[ray] * a / (float)n;
     }
     __syncthreads();
     transmittance_scan(sm.al, sm.Tj, sm.wv, n, lane);
@@ -191,6 +198,11 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     sm.dd = fp; fp += A;
     sm.sl = reinterpret_cast<int*>(fp); fp += A;
     sm.mk = reinterpret_cast<int*>(fp); fp += A;
+    sm.gv = nullptr;
+    if (p.div_grad) {
+        sm.gv = fp;
+        fp += A;
+    }
     // 64-bit sort scratch of the calls that always take the bitonic network (overlap fix); 4 S + 60 A bytes precede it
     unsigned long long* wide = p.fix_overlaps ? reinterpret_cast<unsigned long long*>(fp) : nullptr;
 
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
             sm.gd[off + i] = 0.f;
             sm.mk[off + i] = 0;
             sm.wg[off + i] = 0.f;
+            if (p.div_grad) sm.gv[off + i] = 0.f;
         }
         off += P;
     }
@@ -293,6 +306,10 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
             o.g_sigma[base + i] = sm.gs[off + i];
             o.g_t[base + i] = sm.gt[off + i] + (o.g_sample_t ? o.g_sample_t[base + i] : 0.f);
             if (o.g_dm) o.g_dm[base + i] = sm.gd[off + i];
+            if (o.g_div) {     // d |div| / d div (0 at 0, like torch.abs)
+                const float dv = o.divergence[base + i];
+                o.g_div[base + i] = dv > 0.f ? sm.gv[off + i] : (dv < 0.f ? -sm.gv[off + i] : 0.f);
+            }
         }
         float gFo[MAX_FCHUNK_B];
 #pragma unroll
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
 
 static int launch_composite_bwd(const CompositeBwdParams& p, hipStream_t s) {
     PR_REQUIRE(p.F <= 64 * MAX_FCHUNK_B, "output_features %d exceeds %d", p.F, 64 * MAX_FCHUNK_B);
-    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * 15 * 4 +
+    const size_t lds = (size_t)p.sort_size * 4 + (size_t)((p.total_positions + 63) & ~63) * (p.div_grad ? 16 : 15) * 4 +
                        (p.fix_overlaps ? (size_t)p.sort_size * 8 : 0);
     PR_REQUIRE(lds <= 156 * 1024, "too many samples per ray for the compositing backward kernel (%d)", p.total_positions);
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_composite_bwd), 156 * 1024, nullptr));   // the block-wide vote of order_entries owns a little static LDS
@@ -582,7 +599,8 @@ __global__ __launch_bounds__(256) void k_bender_out_bwd(RowCtx r, const float* g
 }
 
 // Bender head (3, BW), no bias: d act = (g_braw . W) masked by act > 0 ; dW[a][c] += sum_m g_braw[m][a] act[m][c]
-__global__ __launch_bounds__(256) void k_bender_head_bwd(RowCtx r, const float* g_braw, const float* act, int ld, int width,
+// `x`: left factor of dW when it is not the activation itself (the probe tangents of the divergence estimate)
+__global__ __launch_bounds__(256) void k_bender_head_bwd(RowCtx r, const float* g_braw, const float* act, const float* x, int ld, int width,
                                                          const float* w_out, int w_ld, float* g_act, float* dw) {
     __shared__ float sh[3][4][64];
     const int M = *r.total;
@@ -597,9 +615,10 @@ __global__ __launch_bounds__(256) void k_bender_head_bwd(RowCtx r, const float* 
             for (int m = m0 + rg; m < m1; m += 4) {
                 const float g0 = g_braw[(size_t)m * 3], g1 = g_braw[(size_t)m * 3 + 1], g2 = g_braw[(size_t)m * 3 + 2];
                 const float a = act[(size_t)m * ld + c];
-                a0 = fmaf(g0, a, a0);
-                a1 = fmaf(g1, a, a1);
-                a2 = fmaf(g2, a, a2);
+                const float xv = x ? x[(size_t)m * ld + c] : a;
+                a0 = fmaf(g0, xv, a0);
+                a1 = fmaf(g1, xv, a1);
+                a2 = fmaf(g2, xv, a2);
                 g_act[(size_t)m * ld + c] = a > 0.f ? fmaf(g0, w0, fmaf(g1, w1, g2 * w2)) : 0.f;
             }
         }
@@ -823,6 +842,65 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
     }
 }
 
+// ---- gradient of the Hutchinson divergence estimate (object_composer.py:582-601, create_graph=True) -----------------
+// the three probe components of compact sample `flat` (flat = ray * P + sample): element (flat % P) * 3 + a of ray flat / P
+__device__ __forceinline__ void probe_of(const NoiseRef& noise, int flat, int positions, float* e) {
+    const long ray = flat / positions;
+    const int sample = flat - (int)ray * positions;
+    for (int a = 0; a < 3; ++a) e[a] = noise_normal(noise, ray, positions * 3, sample * 3 + a);
+}
+
+// div = sum_a e_a (J e)_a, (J e)_a = size_a (W_out t_last)_a where the clamp passes the network's output (a constant
+// otherwise): d loss / d (W_out t_last)_a = g_div e_a size_a there, 0 elsewhere.  Written as the "raw output" gradient
+// the bender head's backward takes.
+__global__ __launch_bounds__(256) void k_div_out_bwd(RowCtx r, NoiseRef noise, int positions, const float* g_div, const float* braw,
+                                                     const float* pos, float lo0, float lo1, float lo2, float hi0, float hi1,
+                                                     float hi2, int canonical, float* g_out) {
+    const int M = *r.total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    const int flat = r.rec_flat[m];
+    const bool real = (r.row_flags[m] & 1) != 0 && !canonical;
+    const float gd = real ? g_div[flat] : 0.f;
+    float e[3] = {0.f, 0.f, 0.f};
+    if (gd != 0.f) probe_of(noise, flat, positions, e);
+    for (int a = 0; a < 3; ++a) {
+        const float x = pos[(size_t)m * 3 + a];
+        const float size = hi[a] - lo[a];
+        const float pre = braw[(size_t)m * 3 + a] * size;
+        const float lob = lo[a] - x, hib = hi[a] - x;
+        const float m1 = pre > lob ? pre : lob;
+        const bool passes = !(m1 > hib) && pre >= lob;
+        g_out[(size_t)m * 3 + a] = passes ? gd * e[a] * size : 0.f;
+    }
+}
+
+// The tangent of the bender input along the probe: t[a] = dv_a, t[sin slot] = 2^k c dv_a, t[cos slot] = -2^k s dv_a with
+// dv_a = e_a / size_a and (s, c) the saved (annealed) encoding values.  d s / d v = 2^k c, d c / d v = -2^k s, so
+// d loss / d v_a = - sum_k 4^k dv_a (g[sin slot] s + g[cos slot] c); added to the position gradient (/ size_a).
+__global__ __launch_bounds__(256) void k_div_tangent_in_bwd(RowCtx r, NoiseRef noise, int positions, const float* bin, const float* g_t0,
+                                                            int ld, int octaves, float s0, float s1, float s2, float* g_x) {
+    const int M = *r.total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M || !(r.row_flags[m] & 1)) return;
+    const float size[3] = {s0, s1, s2};
+    float e[3];
+    probe_of(noise, r.rec_flat[m], positions, e);
+    const float* b = bin + (size_t)m * ld;
+    const float* g = g_t0 + (size_t)m * ld;
+    for (int a = 0; a < 3; ++a) {
+        const float dv = e[a] / size[a];
+        float acc = 0.f;
+        for (int k = 0; k < octaves; ++k) {
+            const float f = ldexpf(1.0f, k);
+            const int sn = 3 + k * 6 + a, cs = sn + 3;
+            acc = fmaf(-f * f * dv, fmaf(g[sn], b[sn], g[cs] * b[cs]), acc);
+        }
+        g_x[(size_t)m * 3 + a] += acc / size[a];
+    }
+}
+
 }  // namespace pr
 
 // ---------------------------------------------------------------------------------------------
@@ -835,6 +913,8 @@ struct BwdPlan {
     size_t bufA, bufB, act, g_enc, gsr, gdr, g_bent, g_x, g_braw, g_in6, partial, sums, tables;
     size_t gstack, chain_packed;      // layer-chained backward: per-layer pre-activation gradients, W^T fragments
     size_t gstack_bytes;              // 0: the chained path is off for this call (too large), layer-by-layer products instead
+    size_t g_div[PR_MAX_OBJECTS];     // PR_FLAG_DIVERGENCE_GRAD: d loss / d Hutchinson estimate (N,R,P) of the bender objects
+    size_t div_t0, div_stack;         //   probe tangents of the bender input and of every bender layer's output
     size_t bytes;
     size_t max_cap;
 };
@@ -887,6 +967,22 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
                 packed_need = std::max(packed_need, chain_bwd_packed_bytes(m.bender_count, d.BW, d.bin));
             }
         }
+    if (c.flags & PR_FLAG_DIVERGENCE_GRAD) {
+        size_t t0_need = 0, stack_need = 0;
+        for (int k = 0; k < c.objects; ++k)
+            for (int t = 0; t < (c.use_fine ? 2 : 1); ++t) {
+                const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+                if (!m.has_bender) continue;
+                ModelDims d;
+                PR_TRY(compute_dims(m, &d));
+                const size_t cap = nr * m.positions;
+                t0_need = std::max(t0_need, sizeof(float) * cap * d.bin_pad);
+                stack_need = std::max(stack_need, sizeof(float) * cap * d.BWpad * (size_t)m.bender_count);
+                if (!bp->g_div[k]) bp->g_div[k] = take(sizeof(float) * nr * std::max(objs[k].coarse.positions, c.use_fine ? objs[k].fine.positions : 0));
+            }
+        bp->div_t0 = take(t0_need);
+        bp->div_stack = take(stack_need);
+    }
 #ifdef PR_BWD_LAYERWISE
     gstack_need = CHAIN_GSTACK_LIMIT + 1;     // measurement build: one product per layer and launch
 #endif
@@ -911,6 +1007,11 @@ struct GemmCtx {
     float* gstack;          // layer-chained path (NULL: layer by layer)
     float* chain_packed;
     size_t cap;             // row capacity of the per-layer buffers
+    // chain_backward with other left factors for the weight gradients than the saved activations (the probe tangents of
+    // the divergence estimate): dW_l += dY_l^T X_l with X_0 = dw_in0, X_l = dw_acts + (l - 1) dw_stride; no bias gradients
+    const float* dw_acts;
+    size_t dw_stride;
+    const float* dw_in0;
 };
 
 static int weight_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, const float* X, int ldx, int n_in, float* dW,
@@ -970,15 +1071,20 @@ static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, con
         ++grp.count;
         return PR_OK;
     };
+    const bool sub = g.dw_acts != nullptr;
+    const float* x_acts = sub ? g.dw_acts : acts;
+    const size_t x_stride = sub ? g.dw_stride : act_stride;
+    const float* x_in0 = sub ? g.dw_in0 : in0;
     for (int l = count - 1; l >= 0; --l) {
         const float* dY = (l == count - 1) ? cur : g.gstack + (size_t)l * cp.g_stride;
         PR_REQUIRE(!grads[l].bias || grads[l].weight, "a bias gradient buffer needs its weight gradient buffer");
+        float* dbias = sub ? nullptr : grads[l].bias;
         if (l == 0) {
-            PR_TRY(add(dY, in0, ld_in0, n_in0, grads[l].weight, layers[l].in_features, grads[l].bias));
+            PR_TRY(add(dY, x_in0, ld_in0, n_in0, grads[l].weight, layers[l].in_features, dbias));
         } else {
-            PR_TRY(add(dY, acts + (size_t)(l - 1) * act_stride, width_pad, width, grads[l].weight, layers[l].in_features, grads[l].bias));
+            PR_TRY(add(dY, x_acts + (size_t)(l - 1) * x_stride, width_pad, width, grads[l].weight, layers[l].in_features, dbias));
             if (l == skip)
-                PR_TRY(add(dY, in0, ld_in0, n_in0, grads[l].weight ? grads[l].weight + width : nullptr, layers[l].in_features, nullptr));
+                PR_TRY(add(dY, x_in0, ld_in0, n_in0, grads[l].weight ? grads[l].weight + width : nullptr, layers[l].in_features, nullptr));
         }
     }
     if (grp.count) PR_TRY(launch_gemm_tn_group(grp, g.s));
@@ -993,16 +1099,20 @@ static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_
                           int n_in0, float* cur, float* other, float* g_in, const unsigned char* bits) {
     if (g.gstack) return chain_backward_fused(g, layers, grads, count, skip, width, width_pad, acts, act_stride, in0, ld_in0, n_in0, cur, g_in, bits);
     bool g_in_written = false;
+    const bool sub = g.dw_acts != nullptr;
+    const float* x_in0 = sub ? g.dw_in0 : in0;
     for (int l = count - 1; l >= 0; --l) {
         const pr_linear_t& L = layers[l];
         const float* prev = l > 0 ? acts + (size_t)(l - 1) * act_stride : nullptr;
+        const float* x_prev = (sub && l > 0) ? g.dw_acts + (size_t)(l - 1) * g.dw_stride : prev;
+        float* dbias = sub ? nullptr : grads[l].bias;
         if (l == 0) {
-            PR_TRY(weight_grad(g, cur, width_pad, width, in0, ld_in0, n_in0, grads[l].weight, L.in_features, grads[l].bias));
+            PR_TRY(weight_grad(g, cur, width_pad, width, x_in0, ld_in0, n_in0, grads[l].weight, L.in_features, dbias));
             PR_TRY(input_grad(g, cur, width_pad, width, L.weight, L.in_features, n_in0, g_in, ld_in0, g_in_written, nullptr, 0));
         } else {
-            PR_TRY(weight_grad(g, cur, width_pad, width, prev, width_pad, width, grads[l].weight, L.in_features, grads[l].bias));
+            PR_TRY(weight_grad(g, cur, width_pad, width, x_prev, width_pad, width, grads[l].weight, L.in_features, dbias));
             if (l == skip) {
-                PR_TRY(weight_grad(g, cur, width_pad, width, in0, ld_in0, n_in0,
+                PR_TRY(weight_grad(g, cur, width_pad, width, x_in0, ld_in0, n_in0,
                                    grads[l].weight ? grads[l].weight + width : nullptr, L.in_features, nullptr));
                 PR_TRY(input_grad(g, cur, width_pad, width, L.weight + width, L.in_features, n_in0, g_in, ld_in0, false, nullptr, 0));
                 g_in_written = true;
@@ -1026,9 +1136,19 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     const int F = objs[0].coarse.output_features;
     PR_REQUIRE(F % 16 == 0, "backward: output_features %d must be a multiple of 16", F);
 
+    // gradients of integrated_divergence flow only where the forward pass estimated a divergence: differentiable calls in
+    // training mode (render.hip), objects with a ray bender, probes explicit or generated
+    bool div_grad = (c.flags & PR_FLAG_DIVERGENCE_GRAD) && (c.flags & PR_FLAG_TRAIN_BN);
+    if (div_grad) {
+        bool any = grads.global.integrated_divergence != nullptr;
+        for (int k = 0; k < K; ++k) any |= grads.object[k].integrated_divergence != nullptr;
+        div_grad = any;
+    }
+
     // ---- compositing backward ---------------------------------------------------------------------
     CompositeBwdParams cp;
     memset(&cp, 0, sizeof(cp));
+    cp.div_grad = div_grad ? 1 : 0;
     cp.frames = c.frames; cp.rays = c.rays; cp.objects = K; cp.static_objects = c.static_objects; cp.F = F;
     cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
     int total_positions = 0;
@@ -1048,6 +1168,10 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         o.g_t = reinterpret_cast<float*>(bws + bp.g_t[k]);
         o.g_dm = m.has_bender ? reinterpret_cast<float*>(bws + bp.g_dm[k]) : nullptr;
         o.g_sample_t = grads.sample_t[k];
+        if (div_grad && m.has_bender) {
+            o.divergence = reinterpret_cast<const float*>(fws + tp.saved[k].div);
+            o.g_div = reinterpret_cast<float*>(bws + bp.g_div[k]);
+        }
         total_positions += m.positions;
     }
     cp.total_positions = total_positions;
@@ -1094,6 +1218,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         gc.gstack = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.gstack) : nullptr;
         gc.chain_packed = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.chain_packed) : nullptr;
         gc.cap = cap;
+        gc.dw_acts = nullptr; gc.dw_stride = 0; gc.dw_in0 = nullptr;
 
         const float* rec_pos = reinterpret_cast<const float*>(fws + sv.rec_pos);
         const float* enc = reinterpret_cast<const float*>(fws + sv.enc);
@@ -1190,7 +1315,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             PR_LAUNCH_CHECK();
             const int bc = m.bender_count;
             hipLaunchKernelGGL(k_bender_head_bwd, dim3(grid_blk, (d.BW + 63) / 64), dim3(256), 0, s, rc, g_braw, bacts + (size_t)(bc - 1) * bact_stride,
-                               d.BWpad, d.BW, m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
+                               nullptr, d.BWpad, d.BW, m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
             PR_LAUNCH_CHECK();
             PR_TRY(chain_backward(gc, m.bender, G.bender, bc, m.bender_skip, d.BW, d.BWpad, bacts, bact_stride, bin, d.bin_pad,
                                   d.bin, bufA, bufB, g_enc, reinterpret_cast<const unsigned char*>(fws + sv.bbits)));
@@ -1201,6 +1326,49 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
                 hipLaunchKernelGGL(k_deformation_bwd, dim3(grid_blk), dim3(64), 0, s, rc, g_enc, d.bin_pad, d.benc,
                                    m.deformation_features, out.deformation + (size_t)k * m.deformation_features,
                                    K * m.deformation_features);
+                PR_LAUNCH_CHECK();
+            }
+            // ---- Hutchinson divergence: div = e^T J e is linear in the bender's weights along the probe tangents
+            // t_0 = d input / dx . e, t_{l+1} = relu'(z_l) (W_l t_l), div = sum_a e_a size_a (W_out t_last)_a  (where the
+            // clamp passes the network's output).  Its backward is the SAME chain with the tangents in place of the
+            // activations as left factors of the weight gradients (the ReLU masks are piecewise constant), and the
+            // input's tangent depends on the position through the encoding's derivative only.
+            NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
+            if (div_grad && (probes.ptr || probes.generate)) {
+                float* t0 = reinterpret_cast<float*>(bws + bp.div_t0);
+                float* tstack = reinterpret_cast<float*>(bws + bp.div_stack);
+                const size_t tstride = cap * d.BWpad;
+                DivergenceParams dp;
+                memset(&dp, 0, sizeof(dp));
+                dp.total = totals + k; dp.max_rows = (int)cap;
+                dp.rec_flat = rc.rec_flat; dp.row_flags = rc.row_flags; dp.rec_pos = rec_pos;
+                dp.noise = probes; dp.positions = P;
+                dp.bin = bin; dp.bin_pad = d.bin_pad; dp.benc = d.benc; dp.b_octaves = m.bender_octaves;
+                dp.bacts = bacts; dp.bact_stride = bact_stride; dp.BW = d.BW; dp.BWpad = d.BWpad;
+                dp.b_count = bc; dp.b_skip = m.bender_skip; dp.bin_real = d.bin;
+                dp.layers = m.bender; dp.out_head = m.bender_out; dp.braw = braw;
+                for (int a = 0; a < 3; ++a) {
+                    dp.lo[a] = lo[a];
+                    dp.hi[a] = hi[a];
+                }
+                dp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+                dp.t0 = t0; dp.tstack = tstack; dp.tstride = tstride;
+                dp.div = nullptr;                                   // tangents only
+                PR_TRY(launch_divergence(dp, s));
+                const float* g_div = reinterpret_cast<const float*>(bws + bp.g_div[k]);
+                hipLaunchKernelGGL(k_div_out_bwd, dim3(row_blocks), dim3(256), 0, s, rc, probes, P, g_div, braw, rec_pos, lo[0], lo[1],
+                                   lo[2], hi[0], hi[1], hi[2], dp.canonical, g_braw);
+                PR_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_bender_head_bwd, dim3(grid_blk, (d.BW + 63) / 64), dim3(256), 0, s, rc, g_braw,
+                                   bacts + (size_t)(bc - 1) * bact_stride, tstack + (size_t)(bc - 1) * tstride, d.BWpad, d.BW,
+                                   m.bender_out.weight, d.BW, bufA, G.bender_out.weight);
+                PR_LAUNCH_CHECK();
+                GemmCtx tc = gc;
+                tc.dw_acts = tstack; tc.dw_stride = tstride; tc.dw_in0 = t0;
+                PR_TRY(chain_backward(tc, m.bender, G.bender, bc, m.bender_skip, d.BW, d.BWpad, bacts, bact_stride, bin, d.bin_pad,
+                                      d.bin, bufA, bufB, g_enc, reinterpret_cast<const unsigned char*>(fws + sv.bbits)));
+                hipLaunchKernelGGL(k_div_tangent_in_bwd, dim3(row_blocks), dim3(256), 0, s, rc, probes, P, bin, g_enc, d.bin_pad,
+                                   m.bender_octaves, size[0], size[1], size[2], g_x);
                 PR_LAUNCH_CHECK();
             }
             gx_final = g_x;
@@ -1304,13 +1472,6 @@ namespace pr {
 
 // tangent of the bender input [annealed PE(x / size) | deformation] along e: d v_a = e_a / size_a;
 // sin slot: 2^k cos_saved d v ; cos slot: -2^k sin_saved d v (the saved values carry the annealing weight)
-// the three probe components of compact sample `flat` (flat = ray * P + sample): element (flat % P) * 3 + a of ray flat / P
-__device__ __forceinline__ void probe_of(const NoiseRef& noise, int flat, int positions, float* e) {
-    const long ray = flat / positions;
-    const int sample = flat - (int)ray * positions;
-    for (int a = 0; a < 3; ++a) e[a] = noise_normal(noise, ray, positions * 3, sample * 3 + a);
-}
-
 __global__ __launch_bounds__(256) void k_div_tangent_in(const int32_t* total, const int32_t* rec_flat, NoiseRef noise, int positions,
                                                         const float* bin, int ld, int benc, int octaves, float s0, float s1,
                                                         float s2, float* t0) {
@@ -1382,11 +1543,12 @@ int launch_divergence(const DivergenceParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_div_tangent_in, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.noise, p.positions, p.bin, p.bin_pad, p.benc,
                        p.b_octaves, p.hi[0] - p.lo[0], p.hi[1] - p.lo[1], p.hi[2] - p.lo[2], p.t0);
     PR_LAUNCH_CHECK();
-    float* cur = p.ta;
+    float* cur = p.tstack ? p.tstack : p.ta;
     float* other = p.tb;
     const float* prev = p.t0;
     for (int l = 0; l < p.b_count; ++l) {
         const pr_linear_t& L = p.layers[l];
+        if (p.tstack) cur = p.tstack + (size_t)l * p.tstride;     // every layer's tangent is kept (backward of the estimate)
         GemmNN g;
         memset(&g, 0, sizeof(g));
         g.rows = p.total; g.C = cur; g.ldc = p.BWpad; g.n = p.BW;
@@ -1411,6 +1573,7 @@ int launch_divergence(const DivergenceParams& p, hipStream_t s) {
         cur = other;
         other = tmp;
     }
+    if (!p.div) return PR_OK;
     hipLaunchKernelGGL(k_div_out, dim3(blocks), dim3(256), 0, s, p.total, p.rec_flat, p.row_flags, p.noise, p.positions, prev, p.BWpad, p.BW,
                        p.out_head.weight, p.braw, p.rec_pos, p.lo[0], p.lo[1], p.lo[2], p.hi[0], p.hi[1], p.hi[2], p.canonical, p.div);
     PR_LAUNCH_CHECK();

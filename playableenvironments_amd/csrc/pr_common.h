@@ -457,7 +457,8 @@ struct DivergenceParams {
     float lo[3], hi[3];
     int canonical;
     float* t0; float* ta; float* tb;   // scratch: (cap, bin_pad), (cap, BWpad) x 2
-    float* div;                    // (N,R,P), zero-initialised by the caller
+    float* tstack; size_t tstride; // or: every layer's tangent kept, layer l at tstack + l * tstride (ta / tb unused)
+    float* div;                    // (N,R,P), zero-initialised by the caller; NULL: tangents only
 };
 int launch_divergence(const DivergenceParams& p, hipStream_t s);
 

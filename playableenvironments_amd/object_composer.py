@@ -90,7 +90,7 @@ def _linear(layer: Optional[nn.Linear]) -> _lib.Linear:
     return s
 
 
-GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude", "weights")
+GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacements_magnitude", "weights", "integrated_divergence")
 
 
 class _RenderFunction(torch.autograd.Function):
@@ -166,6 +166,8 @@ class _RenderFunction(torch.autograd.Function):
                         g = g.to(torch.float32).reshape(shape).contiguous()
                         keep.append(g)
                         setattr(entry, key, g.data_ptr())
+                        if key == "integrated_divergence":      # the double backward of the Hutchinson estimate
+                            st["call"].flags |= _lib.PR_FLAG_DIVERGENCE_GRAD
         if ctx.layout is not None:
             # gradients of the decoder-layout maps: the same numbers as global.integrated_features, channels-first per ray group
             groups = len(ctx.layout["rays"])
@@ -471,11 +473,11 @@ class ObjectComposer(nn.Module):
         Autograd: with gradients enabled the call is differentiable (training mode: through the batch statistics of the
         BatchNorm layers; eval mode: with the running statistics as constants, e.g. test-time optimisation) with
         respect to the parameters, ``style``, ``deformation`` and ``transformation_matrix_w2o`` through
-        ``integrated_features``, ``opacity``, ``depth`` and ``integrated_displacements_magnitude`` of every
-        entry (pr_render_backward).  ``integrated_divergence`` carries the Hutchinson estimate of the reference
-        (object_composer.py:582-601) in that mode.  Not differentiated: the camera rays (dataset inputs in the
-        reference's trainers), ``weights``/``disparity`` (no consumer) and ``integrated_divergence`` (its loss weight
-        is 0 in the shipped configurations; a second-order pass would be needed)."""
+        ``integrated_features``, ``opacity``, ``depth``, ``integrated_displacements_magnitude`` and
+        ``integrated_divergence`` of every entry (pr_render_backward).  ``integrated_divergence`` carries the Hutchinson
+        estimate of the reference (object_composer.py:582-601) in training mode; its gradient (the reference's double
+        backward) is one more pass over the ray bender with the probe tangents in place of the activations.  Not
+        differentiated: the camera rays (dataset inputs in the reference's trainers) and ``disparity`` (no consumer)."""
         if ray_directions.is_cuda:
             # the library launches on the caller's stream: that stream's device has to be the current one
             with torch.cuda.device(ray_directions.device):

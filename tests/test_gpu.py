@@ -500,6 +500,40 @@ def test_backward_matches_oracle_autograd(name, perturb):
     assert nonzero > 40
 
 
+@pytest.mark.parametrize("name,perturb,alone", [("tennis", False, True), ("tennis", True, False), ("minecraft", True, True),
+                                                ("minecraft", False, False), ("tennis_hierarchical", False, False)])
+def test_backward_of_the_divergence_estimate(name, perturb, alone):
+    """Gradient of integrated_divergence - the reference's DOUBLE backward through the ray bender
+    (compute_approximate_divergence with create_graph=True, object_composer.py:582-601; mean(alpha.detach() |div|), :768-769)
+    - against torch.autograd through the oracle with the same probes.  ``alone``: the loss reads integrated_divergence
+    only, so every non-zero gradient below comes from the second-order pass (ray bender weights, object poses; nothing
+    reaches the NeRF backbones, the style or the deformation codes: the estimate is piecewise linear in them)."""
+    if name == "minecraft":
+        cfg, scene, n, bias = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS), synthetic.minecraft_scene(), 16, 3.0
+    elif name == "tennis_hierarchical":
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
+    else:
+        cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
+    keys = ("integrated_divergence",) if alone else GRAD_KEYS + ("integrated_divergence",)
+    grads = _gradients(cfg, scene, n, bias, perturb, keys=keys)
+    tol = 1e-3 if name == "tennis_hierarchical" else 2e-4
+    bad, bender, elsewhere = {}, 0, 0
+    for k, (a, b) in grads.items():
+        scale = float(a.abs().max())
+        if "ray_bender" in k and scale > 0:
+            bender += 1
+        elif scale > 0 and k not in ("w2o",):
+            elsewhere += 1
+        err = float((a - b).abs().max())
+        if err > tol * scale + 1e-9:
+            bad[k] = (err, scale)
+    assert not bad, bad
+    assert bender >= 4 and float(grads["w2o"][0].abs().max()) > 0      # 3 layers + the output head of every bender model
+    if alone:
+        assert elsewhere == 0, [k for k, (a, _) in grads.items() if float(a.abs().max()) > 0 and "ray_bender" not in k]
+
+
 @pytest.mark.parametrize("name,perturb", [("tennis", False), ("minecraft", True), ("tennis_hierarchical", False)])
 def test_backward_of_the_compositing_weights(name, perturb):
     """pr_entry_grads_t.weights: a loss that reads the compositing weights themselves - per object, and the merged list of
@@ -1770,13 +1804,15 @@ def test_generated_noise_training_gradients_match_explicit_replay():
             explicit["int_coarse_global"] = _noise_fill(seed, 4, 0, 0, (N, R, sum(pc)))
             out = comp(o, d, n, w2o, sty, dfm, ins, True, _noise=explicit)
         g = out["coarse"]["global"]
-        (g["integrated_features"].square().mean() + g["opacity"].mean() + g["depth"].mean() * 0.01).backward()
+        # (the divergence term exercises the probes regenerated inside the second-order pass of pr_render_backward)
+        (g["integrated_features"].square().mean() + g["opacity"].mean() + g["depth"].mean() * 0.01 +
+         g["integrated_divergence"].mean() * 10 + out["coarse"]["object_2"]["integrated_divergence"].mean()).backward()
         grads = {name: p.grad.clone() for name, p in comp.named_parameters() if p.grad is not None}
         results.append((out, sty.grad.clone(), w2o.grad.clone(), grads))
     (a, sa, wa, ga), (b, sb, wb, gb) = results
     for key in ("integrated_features", "opacity", "depth", "integrated_divergence", "integrated_displacements_magnitude"):
         assert torch.equal(a["coarse"]["global"][key], b["coarse"]["global"][key]), key
-    assert float(a["coarse"]["global"]["integrated_divergence"].abs().max()) > 0
+    assert float(a["coarse"]["global"]["integrated_divergence"].detach().abs().max()) > 0
     # (the pose / style gradients are accumulated with atomics: equal up to the summation order, run to run)
     close = lambda x, y: torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()))
     assert close(sa, sb) and close(wa, wb)
