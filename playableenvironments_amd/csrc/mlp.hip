@@ -16,6 +16,8 @@
 // runs on the accumulator registers.  v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain.
 #include "pr_common.h"
 
+#include <cstddef>
+
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -334,7 +336,8 @@ constexpr int HEAD_SIGMA = MAX_WIDTH + 8;   // sigma weights (Wpad) + bias
 constexpr int HEAD_BENDER = 0;              // the 3-row bender head is read from L2 (players are few)
 struct Smem {
     int uniform_frame;       // every row of the tile belongs to the same frame
-    int pad_[3];
+    int next_tile;           // the tile this workgroup claimed for its next iteration (dynamic tile order)
+    int pad_[2];
     float head_w[HEAD_SIGMA + HEAD_BENDER];
     float X[TILE_M * LDX];   // activations; columns [0, K) also hold a layer's input encoding while it is needed
     float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
@@ -346,6 +349,8 @@ struct Smem {
     int src[TILE_M];         // gated head: slot of the workgroup's pending stack a tile row is exchanged with (-1: none)
 };
 static_assert(sizeof(Smem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "the workgroups of one CU must fit its LDS");
+static_assert(offsetof(Smem, head_w) % 16 == 0 && offsetof(Smem, X) % 16 == 0 && offsetof(Smem, pos) % 16 == 0,
+              "16-byte LDS reads of the activation tile");
 
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -995,9 +1000,20 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     __syncthreads();
     int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head), uniform across the workgroup
     EncRegs enc;       // this thread's share of the current network input (see fill_encoding)
-    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+    // Tile order: the first tile of a workgroup is its block index; evaluation launches claim every further tile from a
+    // device counter (one atomic per tile, issued at the top of the previous tile and consumed after its first barrier),
+    // so that a workgroup that drew cheaper tiles (sigma-gated head) or a faster CU simply takes more of them.  S.next_tile
+    // is written after a tile's first barrier and read when the tile ends.
+#ifdef PR_MLP_STATIC_TILES
+    const bool dynamic_tiles = false;     // measurement build: strided tile order
+#else
+    const bool dynamic_tiles = !TRAIN && p.tile_counter != nullptr;
+#endif
+    for (int tile = blockIdx.x; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         PR_PHASE_T0();
+        int claimed = 0;
+        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
         if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
         if (tid < TILE_M) {
@@ -1028,6 +1044,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         }
         __syncthreads();
         if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;   // visible after the next barrier
+        if (tid == 0) S.next_tile = dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x;   // read at the end of the tile
         PR_PHASE(0);
 
         // ---- ray bender -----------------------------------------------------------------------

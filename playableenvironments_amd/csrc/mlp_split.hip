@@ -12,6 +12,8 @@
 // two fp16 planes.  Selected with pr_call_t.precision = PR_PRECISION_F16X3; eval-mode only.
 #include "pr_common.h"
 
+#include <cstddef>
+
 namespace pr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,7 +28,8 @@ constexpr int LDSTAGE = 260;         // floats per row when the activation plane
 
 struct SmemH {
     int uniform_frame;
-    int pad_[3];
+    int next_tile;           // the tile claimed for this workgroup's next iteration (see mlp.hip)
+    int pad_[2];
     float head_w[MAX_WIDTH + 8];          // sigma head weights + bias
     _Float16 Xh[STILE_M * LDH];            // activations, hi plane
     _Float16 Xl[STILE_M * LDH];            // activations, lo plane (scaled by 2^11)
@@ -39,6 +42,8 @@ struct SmemH {
 };
 static_assert(sizeof(_Float16) * 2 * STILE_M * LDH >= sizeof(float) * STILE_M * LDSTAGE, "staging tile must fit the activation planes");
 static_assert(sizeof(SmemH) * SBLOCKS_PER_CU <= 158 * 1024, "the workgroups of one CU must fit its LDS");
+static_assert(offsetof(SmemH, head_w) % 16 == 0 && offsetof(SmemH, Xh) % 16 == 0 && offsetof(SmemH, Xl) % 16 == 0,
+              "16-byte LDS reads of the activation planes");
 
 #ifndef PR_SPLIT_ABLATE
 #define PR_SPLIT_ABLATE 0   // profiling builds only: 1 = no weight re-loads, 2 = no activation re-loads, 8 = no epilogue
@@ -468,9 +473,17 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
     for (int i = tid; i <= p.Wpad; i += STHREADS) S.head_w[i] = p.sigma_w[i];
     __syncthreads();
     int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head)
-    for (int tile = blockIdx.x; tile * STILE_M < total; tile += gridDim.x) {
+    // dynamic tile order, as in k_mlp_mfma: further tiles are claimed from a device counter, one tile ahead
+#ifdef PR_MLP_STATIC_TILES
+    const bool dynamic_tiles = false;
+#else
+    const bool dynamic_tiles = p.tile_counter != nullptr;
+#endif
+    for (int tile = blockIdx.x; tile * STILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * STILE_M;
         PR_PHASE_T0();
+        int claimed = 0;
+        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
         if (tid == 0) S.uniform_frame = 1;
         if (tid < STILE_M) {
             const int idx = tile_base + tid;
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
         }
         __syncthreads();
         if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        if (tid == 0) S.next_tile = dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x;
         PR_PHASE(0);
 
         if (p.has_bender) {

@@ -191,6 +191,7 @@ struct MlpParams {
     float* pend_act;             // (MAX_RESIDENT_TILES, TILE_M, Wpad floats) per-workgroup stacks of pending live rows
     int32_t* pend_meta;          // (MAX_RESIDENT_TILES, TILE_M, 2) [compact feature row, frame] of the pending rows
     int32_t* head_count;         // device counter: rows sent through the feature head (NULL = not counted)
+    int32_t* tile_counter;       // zeroed device counter: tiles beyond the first of a workgroup are claimed from it (NULL: strided)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
@@ -382,7 +383,8 @@ struct TypePlan {
     size_t feat[PR_MAX_OBJECTS];
     int positions[PR_MAX_OBJECTS];
     size_t totals;  // K ints
-    size_t head_counts;  // K ints: rows sent through the feature head (sigma-gated head)
+    size_t head_counts;  // PR_MAX_OBJECTS ints: rows sent through the feature head (sigma-gated head), then PR_MAX_OBJECTS tile
+                         // counters of the evaluation launches (one fill zeroes both)
     SavedPlan saved[PR_MAX_OBJECTS];
 };
 struct Plan {

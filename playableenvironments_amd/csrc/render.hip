@@ -152,7 +152,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     for (int t = 0; t < ntypes; ++t) {
         TypePlan& tp = plan->type[t];
         tp.totals = take(sizeof(int32_t) * PR_MAX_OBJECTS);
-        tp.head_counts = take(sizeof(int32_t) * PR_MAX_OBJECTS);
+        tp.head_counts = take(sizeof(int32_t) * 2 * PR_MAX_OBJECTS);
         for (int k = 0; k < c.objects; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             ModelDims d;
@@ -252,7 +252,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         const TypePlan& tp = plan.type[t];
         int32_t* totals = reinterpret_cast<int32_t*>(ws + tp.totals);
         int32_t* head_counts = reinterpret_cast<int32_t*>(ws + tp.head_counts);
-        if (gate) PR_CHECK_HIP(hipMemsetAsync(head_counts, 0, sizeof(int32_t) * PR_MAX_OBJECTS, s));
+        PR_CHECK_HIP(hipMemsetAsync(head_counts, 0, sizeof(int32_t) * 2 * PR_MAX_OBJECTS, s));
         const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
         int total_positions = 0;
         for (int k = 0; k < K; ++k) {
@@ -350,6 +350,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 mp.pend_act = reinterpret_cast<float*>(ws + plan.pend_act);
                 mp.pend_meta = reinterpret_cast<int32_t*>(ws + plan.pend_meta);
                 mp.head_count = head_counts + k;
+                mp.tile_counter = head_counts + PR_MAX_OBJECTS + k;
             }
             if (outs[t] && outs[t]->sample_delta[k]) {
                 PR_CHECK_HIP(hipMemsetAsync(outs[t]->sample_delta[k], 0, sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
