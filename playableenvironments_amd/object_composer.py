@@ -133,6 +133,9 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grad_outputs):
+        if ctx.state is None:
+            raise RuntimeError("Trying to backward through the renderer call a second time: its saved activations (the forward "
+                               "workspace) have already been freed.  Render again, or sum the losses before calling backward().")
         # the library launches on the caller's stream: that stream's device has to be the current one
         with torch.cuda.device(ctx.state["workspace"].device):
             return _RenderFunction._backward(ctx, *grad_outputs)
@@ -140,9 +143,6 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, *grad_outputs):
         st, composer = ctx.state, ctx.composer
-        if st is None:
-            raise RuntimeError("Trying to backward through the renderer call a second time: its saved activations (the forward "
-                               "workspace) have already been freed.  Render again, or sum the losses before calling backward().")
         if tuple(p._version for p in composer.parameters()) != ctx.versions:
             raise RuntimeError("one of the composer's parameters was modified in place between the renderer's forward and "
                                "backward calls (pr_render_backward reads the parameter storages): call backward() before "

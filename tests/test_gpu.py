@@ -1837,6 +1837,11 @@ def test_autograd_node_guards():
     loss.backward()
     with pytest.raises(RuntimeError, match="second time"):
         loss.backward()
+    # retain_graph keeps torch's own nodes alive: the second pass reaches the renderer's node, which has freed its workspace
+    loss = render()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="renderer call a second time"):
+        loss.backward()
     loss = render()
     with torch.no_grad():
         next(comp.parameters()).mul_(1.0)
