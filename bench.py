@@ -195,6 +195,47 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     }
 
 
+def minecraft_leg(dev, lib, frames=20):
+    """BASELINE.json configs[2]: the shipped minecraft renderer (background P=16, skybox P=1, two players P=32 that share one
+    model, static / dynamic overlap fix), one 256x256 frame, evaluation - both precisions, with the MLP / compositing share."""
+    from playableenvironments_amd import configs, synthetic
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    cfg = configs.minecraft_config()
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.eval().to(dev)
+    size = (256, 256)
+    scene = to_device(synthetic.minecraft_scene(seed=1234, image_size=size), dev)
+    out = {"workload": "shipped minecraft renderer, 256x256 frame, 4 objects, 16 + 1 + 32 + 32 samples/ray, overlap fix, eval - "
+                       "BASELINE.json configs[2]"}
+    for precision in ("fp32", "f16x3"):
+        model.object_composer.precision = precision
+
+        def step():
+            with torch.no_grad():
+                return model(*scene_args(scene, size), 0, False, mode="scene_encodings")
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / frames
+        lib.pr_profile_enable(1)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+        lib.pr_profile_enable(0)
+        ms, _ = profile_arrays()
+        lib.pr_profile_collect(ms, _)
+        out[precision] = {"ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1.0 / dt, 1),
+                          "mrays_per_s": round(size[0] * size[1] / dt / 1e6, 3), "mlp_ms": round(ms[0] / 5, 3),
+                          "composite_ms": round(ms[1] / 5, 3)}
+    return out
+
+
 def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, frames=8):
     """BASELINE.json configs[3]: a batch of 8 DISTINCT seeded frames sharded over the ranks with
     EnvironmentModel.render_sharded (parallel.shard_frames), the rendered feature maps gathered with one collective.
@@ -258,6 +299,7 @@ def main():
                     help="fp32 = exact fp32 MFMA (default, the headline); f16x3 = fp32 emulated with three fp16 MFMAs")
     ap.add_argument("--no-split-precision", action="store_true", help="skip the secondary f16x3 measurement")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
+    ap.add_argument("--no-minecraft", action="store_true", help="skip the secondary configs[2] (minecraft) measurement")
     ap.add_argument("--no-distinct-frames", action="store_true", help="skip the 8-distinct-frames legs (configs[3])")
     ap.add_argument("--no-reference-graph", action="store_true", help="skip the same-GPU PyTorch op graph measurement")
     ap.add_argument("--no-gate", action="store_true", help="disable the sigma-gated feature head (measurement)")
@@ -503,6 +545,8 @@ def main():
         del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
+    if rank == 0 and world == 1 and not args.no_minecraft:
+        result["config2_minecraft_256"] = minecraft_leg(dev, lib)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
     if rank == 0:
