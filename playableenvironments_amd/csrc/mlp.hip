@@ -986,12 +986,20 @@ __device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams&
 // TRAIN = false: the evaluation kernel (everything fused, optional sigma gate) - what the benchmark runs; none of the
 // training-only code (saved activations, ReLU bit images, phase 1 of the batch-statistics launches) is compiled into it.
 // TRAIN = true: phase 1 of the phased launches (train-mode BatchNorm and / or PR_FLAG_SAVE_FOR_BACKWARD).
-template <bool TRAIN>
+// GROUP = true: one of several objects evaluated by the same launch (k_mlp_mfma_group) - the workgroups walk through the
+// objects in order, EVERY tile is claimed from the object's counter, and a workgroup that finds an object's tiles
+// exhausted moves on to the next object at once: small objects do not pay a launch of their own (a launch lasts at
+// least one tile time and ends with idle CUs) and the tail of one object overlaps the start of the next.
+template <bool TRAIN, bool GROUP>
 __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
+    if (GROUP) {
+        __syncthreads();   // every wave has left the previous object's last tile (head weights, flags, X are reused)
+        if (tid == 0) S.next_tile = atomicAdd(p.tile_counter, 1);
+    }
     // stage the small head weights once: [0, Wpad] sigma weights + bias, then 3 rows of the bender head
     for (int i = tid; i <= p.Wpad; i += MLP_THREADS) S.head_w[i] = p.sigma_w[i];
     const bool bender_head_staged = p.has_bender && 3 * p.BWpad <= HEAD_BENDER;
@@ -1005,11 +1013,12 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     // so that a workgroup that drew cheaper tiles (sigma-gated head) or a faster CU simply takes more of them.  S.next_tile
     // is written after a tile's first barrier and read when the tile ends.
 #ifdef PR_MLP_STATIC_TILES
-    const bool dynamic_tiles = false;     // measurement build: strided tile order
+    const bool dynamic_tiles = GROUP;     // measurement build: strided tile order
 #else
-    const bool dynamic_tiles = !TRAIN && p.tile_counter != nullptr;
+    const bool dynamic_tiles = GROUP || (!TRAIN && p.tile_counter != nullptr);
 #endif
-    for (int tile = blockIdx.x; tile * TILE_M < total; tile = S.next_tile) {
+    // (GROUP: the first claim was parked in LDS before the barrier that follows the head-weight staging)
+    for (int tile = GROUP ? S.next_tile : (int)blockIdx.x; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         PR_PHASE_T0();
         int claimed = 0;
@@ -1044,7 +1053,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         }
         __syncthreads();
         if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;   // visible after the next barrier
-        if (tid == 0) S.next_tile = dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x;   // read at the end of the tile
+        if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);   // read at the end of the tile
         PR_PHASE(0);
 
         // ---- ray bender -----------------------------------------------------------------------
@@ -1155,8 +1164,18 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     if (!TRAIN && p.gate) gated_head_flush(S, p, pending, enc);
 }
 
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) { mlp_tile_loop<false>(p); }
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train(MlpParams p) { mlp_tile_loop<true>(p); }
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) { mlp_tile_loop<false, false>(p); }
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train(MlpParams p) { mlp_tile_loop<true, false>(p); }
+// Several objects, one launch.  One copy of the tile loop per job slot: the parameters of a slot are kernel arguments at
+// constant offsets, exactly as in k_mlp_mfma (a table indexed at run time would turn every parameter into a memory load
+// and every pointer into a flat pointer - measured: 3 % slower).
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                                   int count) {
+    mlp_tile_loop<false, true>(j0);
+    if (count > 1) mlp_tile_loop<false, true>(j1);
+    if (count > 2) mlp_tile_loop<false, true>(j2);
+    if (count > 3) mlp_tile_loop<false, true>(j3);
+}
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
 // affine built from the BATCH statistics + ReLU, run the next head matmul.
@@ -1376,6 +1395,33 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
         fprintf(stderr, "\n");
     }
 #endif
+    return PR_OK;
+}
+
+int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s) {
+    PR_REQUIRE(count >= 1, "grouped MLP launch: no jobs");
+    static thread_local MlpGroupParams g;     // 18 KB: not on the stack
+    for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
+        const int n = count - begin < MLP_GROUP_MAX ? count - begin : MLP_GROUP_MAX;
+        long max_tiles = 0;
+        for (int j = 0; j < n; ++j) {
+            const MlpParams& q = host_jobs[begin + j];
+            PR_REQUIRE(q.phase == 0 && q.tile_counter, "grouped MLP launch: evaluation launches with a tile counter only");
+            PR_REQUIRE(!q.gate || (q.pend_act && q.pend_meta), "gated head: pending buffers missing");
+            max_tiles += ((long)max_rows[begin + j] + TILE_M - 1) / TILE_M;
+            g.jobs[j] = q;
+        }
+        if (max_tiles <= 0) continue;
+        int cu_count = 0;
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_mfma_group), (int)sizeof(Smem), &cu_count));
+        int resident = cu_count * MLP_BLOCKS_PER_CU;
+        if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;
+        const int grid = max_tiles < resident ? (int)max_tiles : resident;
+        g.count = n;
+        ProfileScope scope(0, s);
+        hipLaunchKernelGGL(k_mlp_mfma_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        PR_LAUNCH_CHECK();
+    }
     return PR_OK;
 }
 

@@ -198,6 +198,15 @@ struct MlpParams {
     float* feat;                 // compact (cap, F)
 };
 
+// Grouped launch of the fused MLP: up to MLP_GROUP_MAX object models, one persistent launch (k_mlp_mfma_group in mlp.hip).
+// The job descriptors travel BY VALUE in the kernel argument segment and are addressed with constant indices, like the
+// single launch's parameters.
+constexpr int MLP_GROUP_MAX = 4;
+struct MlpGroupParams {
+    MlpParams jobs[MLP_GROUP_MAX];
+    int count;
+};
+
 // AdaIN table row layout for one (frame, object): g1[Wpad] b1[Wpad] g2[W2pad] b2[W2pad]
 static inline int adain_row_floats(const ModelDims& d) { return 2 * d.Wpad + 2 * d.W2pad; }
 
@@ -321,6 +330,8 @@ struct FoldParams {
 int launch_adain_fold(const FoldParams& p, hipStream_t s);
 
 int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s);
+// evaluation launches of several objects as one
+int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s);
 int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s);   // PR_PRECISION_F16X3, eval only
 
 // BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
@@ -395,6 +406,7 @@ struct Plan {
     // train-mode BatchNorm scratch (shared by all objects, they are processed one after the other)
     size_t h1, h2, row_flags, stats, stat_count, batch_stats;
     size_t div_t0, div_ta, div_tb;   // divergence tangent scratch
+    size_t rec_pos_k[PR_MAX_OBJECTS], rec_flat_k[PR_MAX_OBJECTS];   // grouped evaluation launches (group_active)
     size_t bytes;
     int nblocks256;
 };
@@ -402,7 +414,9 @@ struct Plan {
 // that device's number of compute units.  Function attributes are per device: a process may drive several.
 int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count);
 int validate_call(const pr_call_t& c, const pr_object_t* objs);
+bool group_active(const pr_call_t& c);
 bool gate_active(const pr_call_t& c);
+bool group_active(const pr_call_t& c);
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size);
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,

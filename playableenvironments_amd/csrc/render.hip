@@ -195,6 +195,16 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     }
     plan->rec_pos = take(sizeof(float) * 3 * max_cap);
     plan->rec_flat = take(sizeof(int32_t) * max_cap);
+    if (group_active(c)) {
+        // one launch evaluates every object of a model type: each object keeps its own compact sample records
+        // (the coarse and the fine pass of an object share them: the coarse launch has finished before the fine fill)
+        for (int k = 0; k < c.objects; ++k) {
+            size_t cap = nr * objs[k].coarse.positions;
+            if (c.use_fine && nr * objs[k].fine.positions > cap) cap = nr * objs[k].fine.positions;
+            plan->rec_pos_k[k] = take(sizeof(float) * 3 * cap);
+            plan->rec_flat_k[k] = take(sizeof(int32_t) * cap);
+        }
+    }
     if (gate_active(c)) {   // per-workgroup stacks of pending live rows (sigma-gated head)
         plan->pend_act = take(sizeof(float) * (size_t)MAX_RESIDENT_TILES * TILE_M * MAX_WIDTH);
         plan->pend_meta = take(sizeof(int32_t) * (size_t)MAX_RESIDENT_TILES * TILE_M * 2);
@@ -229,6 +239,16 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     return PR_OK;
 }
 
+// Evaluation calls on the exact-fp32 kernel run the objects of a model type as ONE grouped launch (k_mlp_mfma_group).
+bool group_active(const pr_call_t& c) {
+#ifdef PR_MLP_UNGROUPED
+    return false;      // measurement build: one launch per object
+#else
+    return !(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD | PR_FLAG_NAIVE_MLP)) && c.precision != PR_PRECISION_F16X3 &&
+           c.objects > 1;
+#endif
+}
+
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size) {
     for (int a = 0; a < 3; ++a) {
         lo[a] = m.bbox[2 * a];
@@ -247,6 +267,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
     int32_t* rec_flat = reinterpret_cast<int32_t*>(ws + plan.rec_flat);
     const bool naive = (c.flags & PR_FLAG_NAIVE_MLP) != 0;
     const bool gate = gate_active(c);
+    const bool grouped = group_active(c);
+    MlpParams jobs[PR_MAX_OBJECTS];
+    int job_rows[PR_MAX_OBJECTS];
 
     for (int t = 0; t < ntypes; ++t) {
         const TypePlan& tp = plan.type[t];
@@ -275,6 +298,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             if (save) {
                 rec_pos = reinterpret_cast<float*>(ws + sv.rec_pos);
                 rec_flat = reinterpret_cast<int32_t*>(ws + sv.rec_flat);
+            } else if (grouped) {
+                rec_pos = reinterpret_cast<float*>(ws + plan.rec_pos_k[k]);
+                rec_flat = reinterpret_cast<int32_t*>(ws + plan.rec_flat_k[k]);
             }
 
             // ---- sample placement --------------------------------------------------------------
@@ -350,8 +376,8 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 mp.pend_act = reinterpret_cast<float*>(ws + plan.pend_act);
                 mp.pend_meta = reinterpret_cast<int32_t*>(ws + plan.pend_meta);
                 mp.head_count = head_counts + k;
-                mp.tile_counter = head_counts + PR_MAX_OBJECTS + k;
             }
+            mp.tile_counter = head_counts + PR_MAX_OBJECTS + k;
             if (outs[t] && outs[t]->sample_delta[k]) {
                 PR_CHECK_HIP(hipMemsetAsync(outs[t]->sample_delta[k], 0, sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
                 if (m.has_bender) mp.delta_dense = outs[t]->sample_delta[k];
@@ -360,7 +386,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             const int max_tiles = (int)cap;   // rows: every launcher derives its own tile count
             if (!(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD))) {
                 PR_TRY(launch_adain_fold(fo, s));
-                if (c.precision == PR_PRECISION_F16X3 && !naive)
+                if (grouped) {
+                    jobs[k] = mp;            // launched together once every object of the type is prepared
+                    job_rows[k] = max_tiles;
+                } else if (c.precision == PR_PRECISION_F16X3 && !naive)
                     PR_TRY(launch_mlp_split(mp, max_tiles, s));
                 else
                     PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
@@ -452,6 +481,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 }
             }
         }
+
+        if (grouped)
+            PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
 
         // ---- compositing ------------------------------------------------------------------------
         const pr_outputs_t* out = outs[t];
