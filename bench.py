@@ -14,14 +14,14 @@ is not already running under it, so both ``python bench.py --gpus 8`` and
 ``python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`` work.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the fused fp32-MFMA MLP,
-``k_mlp_mfma``): FLOPs per launch / average launch duration measured with HIP events on the launch
-stream.  Two FLOP counts are given: ``algorithmic`` (in-box samples x FLOP/sample of the
+``k_mlp_mfma_group`` - the tile loop of ``k_mlp_mfma``, one launch per model type for its four objects): FLOPs per launch /
+average launch duration measured with HIP events on the launch stream.  Two FLOP counts are given: ``algorithmic`` (in-box samples x FLOP/sample of the
 object's networks - what the reference evaluates) and ``executed`` (minus the feature-head FLOPs of the
 samples whose density is <= 0, which the sigma-gated head skips exactly); ``achieved`` uses the EXECUTED
 count.  Secondary legs, none of which is the headline: the split-precision kernel, the same-GPU PyTorch
 op graph of the reference (``reference_graph_on_gpu``), PSNR against the CPU oracle, 8 distinct frames
 sharded over the ranks (BASELINE.json configs[3]), a data-parallel training step (configs[4], with its own
-roofline), configs[0] at full size, and ``cpu_baseline``: the CPU oracle (a restatement of the reference's
+roofline), configs[0] at full size, configs[2] (the shipped minecraft renderer), and ``cpu_baseline``: the CPU oracle (a restatement of the reference's
 PyTorch op graph, 1000-ray chunks like the reference's full-frame path) on bounded ray subsets of the same
 frame on this box's host cores with 1 / 16 / all threads.
 """
@@ -492,7 +492,7 @@ def main():
                         "launched_by": "torch.distributed.run" if world > 1 else "single process"},
         "roofline": {
             "bound": "mfma",
-            "kernel": "k_mlp_mfma (fused fp32 MFMA MLP, all launches of one step)",
+            "kernel": "k_mlp_mfma_group (fused fp32 MFMA MLP; one launch per model type evaluates its four objects; all launches of one step)",
             "achieved": round(achieved, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",

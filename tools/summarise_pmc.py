@@ -30,14 +30,19 @@ for name, counters in sorted(per.items()):
     entry = {k: v for k, v in counters.items()}
     entry["dispatches"] = max(len(calls[(name, k)]) for k in counters)
     out["kernels"][name] = entry
-for kernel in ("pr::k_mlp_mfma", "pr::k_composite<4>"):
+# the evaluation MLP runs as k_mlp_mfma_group (every object of a model type in one launch; one object: k_mlp_mfma)
+for kernel in ("pr::k_mlp_mfma_group", "pr::k_mlp_mfma", "pr::k_composite<4>"):
     k = out["kernels"].get(kernel)
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        continue
+    if kernel == "pr::k_mlp_mfma" and "k_mlp_mfma" in out:
         continue
     launches = k["dispatches"]
     fetch = k["FETCH_SIZE"] * 1024.0
     write = k["WRITE_SIZE"] * 1024.0
-    out[kernel.split("::")[1].split("<")[0]] = {
+    key = "k_mlp_mfma" if "k_mlp_mfma" in kernel else kernel.split("::")[1].split("<")[0]
+    out[key] = {
+        "kernel": kernel,
         "launches_per_render": launches / out["renders"],
         "fetch_bytes_per_render_raw": fetch / out["renders"],
         "fetch_bytes_per_render_corrected_x2": 2 * fetch / out["renders"],
@@ -46,5 +51,5 @@ for kernel in ("pr::k_mlp_mfma", "pr::k_composite<4>"):
     }
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k and k.get("GRBM_GUI_ACTIVE"):
         # the SQ counter is summed over the 1024 SIMDs (4 per CU x 256 CUs), GRBM_GUI_ACTIVE over the 8 XCDs
-        out[kernel.split("::")[1].split("<")[0]]["mfma_busy_fraction"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
+        out[key]["mfma_busy_fraction"] = (k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (k["GRBM_GUI_ACTIVE"] / 8.0)
 print(json.dumps(out, indent=1))
