@@ -283,12 +283,15 @@ static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const
 // and eval-mode BatchNorm1d(affine=False) folded in:  y = h * g + b  with
 //   g = scale / sqrt(running_var + eps),  b = bias - running_mean * g       (adain.py:47,58-59)
 // ---------------------------------------------------------------------------------------------
+// (one thread per channel, the channels of a frame spread over gridDim.y workgroups; the style dot products keep their
+// left-to-right fmaf order, the weight rows are read 16 bytes at a time with eight loads in flight - as a scalar loop the
+// kernel was one L2 round trip per style feature: 30 us for 49 k multiply-adds)
 __global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) {
     const int n = blockIdx.x;
     const float* style = p.style + ((size_t)n * p.objects + p.object_index) * p.S;
     float* row = p.table + (size_t)n * p.row_floats;
     const int total = p.Wpad + p.W2pad;
-    for (int c = threadIdx.x; c < total; c += 256) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < total; c += gridDim.y * 256) {
         const bool first = c < p.Wpad;
         const int ch = first ? c : c - p.Wpad;
         const int width = first ? p.W : p.W2;
@@ -300,7 +303,26 @@ __global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) {
             float scale = a.bias[ch], bias = a.bias[width + ch];
             const float* ws = a.weight + (size_t)ch * p.S;
             const float* wb = a.weight + (size_t)(width + ch) * p.S;
-            for (int s = 0; s < p.S; ++s) {
+            int s = 0;
+            if ((p.S & 3) == 0 && ((reinterpret_cast<size_t>(a.weight) | reinterpret_cast<size_t>(style)) & 15) == 0) {
+                for (; s + 16 <= p.S; s += 16) {
+                    float4 w1[4], w2[4], v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w1[q] = *reinterpret_cast<const float4*>(ws + s + 4 * q);
+                        w2[q] = *reinterpret_cast<const float4*>(wb + s + 4 * q);
+                        v[q] = *reinterpret_cast<const float4*>(style + s + 4 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        scale = fmaf(w1[q].x, v[q].x, scale); bias = fmaf(w2[q].x, v[q].x, bias);
+                        scale = fmaf(w1[q].y, v[q].y, scale); bias = fmaf(w2[q].y, v[q].y, bias);
+                        scale = fmaf(w1[q].z, v[q].z, scale); bias = fmaf(w2[q].z, v[q].z, bias);
+                        scale = fmaf(w1[q].w, v[q].w, scale); bias = fmaf(w2[q].w, v[q].w, bias);
+                    }
+                }
+            }
+            for (; s < p.S; ++s) {
                 scale = fmaf(ws[s], style[s], scale);
                 bias = fmaf(wb[s], style[s], bias);
             }
@@ -324,7 +346,7 @@ int launch_adain_fold(const FoldParams& p, hipStream_t s) {
                "AdaIN parameters missing");
     PR_REQUIRE(p.affine1.out_features == 2 * p.W && p.affine1.in_features == p.S, "features_head.1 affine shape");
     PR_REQUIRE(p.affine4.out_features == 2 * p.W2 && p.affine4.in_features == p.S, "features_head.4 affine shape");
-    hipLaunchKernelGGL(k_adain_fold, dim3(p.frames), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_adain_fold, dim3(p.frames, (p.Wpad + p.W2pad + 255) / 256), dim3(256), 0, s, p);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }
