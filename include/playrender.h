@@ -310,6 +310,12 @@ typedef struct pr_input_grads_t {
     float* deformation;      /* (N,K,D)  accumulated; or NULL */
     pr_model_grads_t model[PR_MAX_OBJECTS];   /* per object instance (coarse models) */
     pr_model_grads_t model_fine[PR_MAX_OBJECTS]; /* fine models (use_fine calls only) */
+    /* gradients of the camera rays (NULL = not wanted): what learnable camera parameters are trained through
+       (model/layers/camera_parameters_storage.py; the reference's rays are torch tensors with a graph,
+       utils/lib_3d/ray_helper.py:15-52, 1203-1227).  Sample positions x = o + d t, the slab-test depths, the skybox input
+       and the sample spacings dt |d| all depend on them. */
+    float* ray_origins;      /* (N,3)   accumulated; or NULL */
+    float* ray_directions;   /* (N,R,3) accumulated; or NULL */
 } pr_input_grads_t;
 
 int pr_backward_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes);

@@ -659,6 +659,23 @@ def check_camera_offsets():
             bad = {k: v[0] for k, v in rep.items() if not v[1]}
             print(f"[camera offsets, {label}] fields={len(rep)} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}")
             ok &= not bad
+        # the gradient of a rendering loss with respect to the offsets, through the rays (reference autograd on both sides:
+        # the reference's composer there, the oracle behind the product's host path here; the HIP backward's ray gradients
+        # are compared with the oracle's on the GPU)
+        grads = []
+        for model in (ref, mine):
+            model.zero_grad()
+            torch.manual_seed(11)
+            out = model(*[a.clone() for a in args], samples_per_image=0, perturb=False, patch_stride=[4, 8])
+            out["coarse"]["global"]["integrated_features"].square().mean().backward()
+            if model is ref:
+                grads.append(torch.stack([torch.zeros(7) if q.grad is None else q.grad for q in ref.camera_parameters_offsets.parameters()]))
+            else:
+                grads.append(mine.camera_parameters_offsets.table.grad.clone())
+        scale = float(grads[0].abs().max())
+        diff = float((grads[0] - grads[1]).abs().max())
+        print(f"[camera offsets, gradient of a rendering loss] max|grad|={scale:.3e} worst|diff|={diff:.3e}")
+        ok &= scale > 0 and diff <= 2e-3 * scale
     finally:
         em.camera_rays = original_camera_rays
     return ok

@@ -139,7 +139,7 @@ class ModelGrads(C.Structure):
 
 class InputGrads(C.Structure):
     _fields_ = [("w2o", C.c_void_p), ("style", C.c_void_p), ("deformation", C.c_void_p), ("model", ModelGrads * PR_MAX_OBJECTS),
-                ("model_fine", ModelGrads * PR_MAX_OBJECTS)]
+                ("model_fine", ModelGrads * PR_MAX_OBJECTS), ("ray_origins", C.c_void_p), ("ray_directions", C.c_void_p)]
 
 
 # every exported symbol of include/playrender.h : (restype, argtypes)

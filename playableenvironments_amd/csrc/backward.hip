@@ -50,6 +50,7 @@ struct CompositeBwdParams {
     NoiseRef noise_global;
     CompositeBwdObject obj[PR_MAX_OBJECTS];
     pr_entry_grads_t global;
+    float* g_norm;           // (N,R) d loss / d |d| through the sample spacings dt |d| of every entry, or NULL
 };
 
 struct BwdSmem {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void transmittance_scan(const float* al, float* Tj, f
 // order; sorted = true: the merged list in key order.  Adds into gs / gt / gd (per concatenation entry).
 __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdSmem& sm, bool sorted, int off, int n,
                                                const NoiseRef& noise, float norm, const pr_entry_grads_t& g, long ray,
-                                               float* weights_out, int lane) {
+                                               float* weights_out, int lane, float& g_norm) {
     const bool noisy = noise_present(noise);
     const int F = p.F;
     auto entry_of = [&](int j) -> int { return sorted ? (int)sm.key[j] : off + j; };
@@ -162,6 +163,7 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         const float E = expf(__fmul_rn(-s, dist));
         const float da = sm.dw[j];
         sm.dd[j] = (j < n - 1) ? da * s * E * norm : 0.f;
+        if (j < n - 1) g_norm = fmaf(da * s * E, dt, g_norm);     // alpha_j = 1 - exp(-s dt |d|)
         if (!sm.mk[e]) {
             if (raw > 0.f) sm.gs[e] += da * dist * E;
             sm.gt[e] += gD * sm.wv[j];
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     const float* d = p.ray_directions + (size_t)g * 3;
     const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
     const int PT = p.total_positions;
+    float g_norm = 0.f;      // this lane's share of d loss / d |d|
 
     int off = 0;
     for (int k = 0; k < p.objects; ++k) {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
     for (int k = 0; k < p.objects; ++k) {
         const CompositeBwdObject& o = p.obj[k];
         const int P = o.positions;
-        entry_backward(p, sm, false, off, P, o.noise, norm, o.g, g, sm.wo, lane);
+        entry_backward(p, sm, false, off, P, o.noise, norm, o.g, g, sm.wo, lane, g_norm);
         off += P;
     }
     // ---- overlap fix: carved static samples are constants (sigma = -10, t = 0, |delta| = 0) -----------
@@ -287,7 +290,11 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
         for (int k = 0; k < p.objects; ++k) counts[k] = p.obj[k].positions;
         order_entries(sm.key, sm.tt, counts, p.objects, PT, S, !p.fix_overlaps, lane, 64, wide);
     }
-    entry_backward(p, sm, true, 0, PT, p.noise_global, norm, p.global, g, sm.wg, lane);
+    entry_backward(p, sm, true, 0, PT, p.noise_global, norm, p.global, g, sm.wg, lane, g_norm);
+    if (p.g_norm) {
+        const float total = wave_sum(g_norm);
+        if (lane == 0) p.g_norm[g] = total;
+    }
 
     // ---- write the per-sample gradients ----------------------------------------------------------------
     const int F = p.F;
@@ -717,7 +724,10 @@ struct GeometryBwd {
     const float* g_t;        // (N,R,P) from the compositing backward
     const float* g_x;        // (cap,3) rows: d loss / d x (object frame), or NULL
     const float* g_in6;      // skybox: (cap,6) rows: d loss / d [o / size, d / |d|]
-    float* d_w2o;            // (N,K,3,4)
+    float* d_w2o;            // (N,K,3,4), or NULL
+    float* d_ray_origins;    // (N,3) accumulated, or NULL
+    float* d_ray_directions; // (N,R,3) accumulated (launches of one stream follow each other: plain read-modify-write), or NULL
+    const float* g_norm;     // (N,R) d loss / d |d_world| from the compositing backward: added by ONE launch per model type
     // hierarchical pass: `positions` = Pc + Pf merged depths; the entries that are coarse depths (matched by value
     // against t_coarse, both lists are sorted) carry the near / far dependence, the resampled ones are constants
     const float* t_coarse;   // (N,R,Pc) or NULL (coarse pass)
@@ -725,13 +735,13 @@ struct GeometryBwd {
 };
 
 __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
-    __shared__ float red[12 * 4];
+    __shared__ float red[15 * 4];
     const int n = blockIdx.y;                              // frame
     const int ray = blockIdx.x * 256 + threadIdx.x;
     const long g = (long)n * p.rays + ray;
-    float dM[12];
+    float dM[15];            // 12 matrix entries, then the frame's ray origin
 #pragma unroll
-    for (int i = 0; i < 12; ++i) dM[i] = 0.f;
+    for (int i = 0; i < 15; ++i) dM[i] = 0.f;
     if (ray < p.rays) {
         const float* M = p.w2o + ((size_t)n * p.objects + p.object_index) * 12;
         const float* ow = p.ray_origins + (size_t)n * 3;
@@ -827,18 +837,37 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
             for (int j = 0; j < 3; ++j) dM[i * 4 + j] = go[i] * ow[j] + gd[i] * dw[j];
             dM[i * 4 + 3] = go[i];
         }
+        // world-frame ray: o = M[:, :3] ow + M[:, 3], d = M[:, :3] dw  ->  d ow = M^T go, d dw = M^T gd (+ the |d| term)
+        if (p.d_ray_origins)
+            for (int j = 0; j < 3; ++j) dM[12 + j] = M[j] * go[0] + M[4 + j] * go[1] + M[8 + j] * go[2];
+        if (p.d_ray_directions) {
+            float gn = 0.f, nrm = 1.f;
+            if (p.g_norm) {
+                gn = p.g_norm[g];
+                nrm = sqrtf(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+            }
+            for (int j = 0; j < 3; ++j) {
+                float v = M[j] * gd[0] + M[4 + j] * gd[1] + M[8 + j] * gd[2];
+                if (p.g_norm) v = fmaf(gn, dw[j] / nrm, v);
+                p.d_ray_directions[(size_t)g * 3 + j] += v;
+            }
+        }
     }
     // block reduction (blockIdx.y = frame), then one atomic per matrix entry
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 15; ++i) {
         const float v = wave_sum(dM[i]);
         if (lane == 0) red[i * 4 + wave] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
+    if (threadIdx.x < 15) {
         const float v = red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3];
-        atomicAdd(p.d_w2o + ((size_t)n * p.objects + p.object_index) * 12 + threadIdx.x, v);
+        if (threadIdx.x < 12) {
+            if (p.d_w2o) atomicAdd(p.d_w2o + ((size_t)n * p.objects + p.object_index) * 12 + threadIdx.x, v);
+        } else if (p.d_ray_origins) {
+            atomicAdd(p.d_ray_origins + (size_t)n * 3 + (threadIdx.x - 12), v);
+        }
     }
 }
 
@@ -913,6 +942,7 @@ struct BwdPlan {
     size_t bufA, bufB, act, g_enc, gsr, gdr, g_bent, g_x, g_braw, g_in6, partial, sums, tables;
     size_t gstack, chain_packed;      // layer-chained backward: per-layer pre-activation gradients, W^T fragments
     size_t gstack_bytes;              // 0: the chained path is off for this call (too large), layer-by-layer products instead
+    size_t g_norm, g_norm_bytes;      // (N,R) d loss / d |d| (ray gradients)
     size_t g_div[PR_MAX_OBJECTS];     // PR_FLAG_DIVERGENCE_GRAD: d loss / d Hutchinson estimate (N,R,P) of the bender objects
     size_t div_t0, div_stack;         //   probe tangents of the bender input and of every bender layer's output
     size_t bytes;
@@ -942,6 +972,8 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
         bp->g_dm[k] = take(sizeof(float) * cap);
     }
     bp->max_cap = max_cap;
+    bp->g_norm_bytes = sizeof(float) * nr;
+    bp->g_norm = take(bp->g_norm_bytes);
     bp->bufA = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->bufB = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->act = take(sizeof(float) * max_cap * MAX_WIDTH);
@@ -1181,6 +1213,9 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     cp.ray_directions = c.ray_directions;
     cp.noise_global = perturb_noise(noise.integrate_global, c, NOISE_INTEGRATE_GLOBAL, t, 0);
     cp.global = grads.global;
+    const bool ray_grads = out.ray_origins != nullptr || out.ray_directions != nullptr;
+    float* g_norm = (out.ray_directions && bp.g_norm_bytes) ? reinterpret_cast<float*>(bws + bp.g_norm) : nullptr;
+    cp.g_norm = g_norm;
     PR_TRY(launch_composite_bwd(cp, s));
 
     // ---- per object -------------------------------------------------------------------------------
@@ -1388,7 +1423,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             PR_LAUNCH_CHECK();
         }
         // ---- sample placement -> object pose -----------------------------------------------------------------
-        if (out.w2o) {
+        if (out.w2o || ray_grads) {
             GeometryBwd gb;
             memset(&gb, 0, sizeof(gb));
             gb.frames = c.frames; gb.rays = c.rays; gb.positions = P; gb.objects = K; gb.object_index = k; gb.kind = m.kind;
@@ -1410,6 +1445,9 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             gb.g_x = gx_final;
             gb.g_in6 = m.kind == 1 ? g_in6 : nullptr;
             gb.d_w2o = out.w2o;
+            gb.d_ray_origins = out.ray_origins;
+            gb.d_ray_directions = out.ray_directions;
+            gb.g_norm = (k == 0) ? g_norm : nullptr;
             hipLaunchKernelGGL(k_geometry_bwd, dim3((c.rays + 255) / 256, c.frames), dim3(256), 0, s, gb);
             PR_LAUNCH_CHECK();
         }

@@ -90,6 +90,9 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     Returns origins (..., 3), directions (..., R, 3), focal normals (..., 3)."""
     if not c2w.is_cuda:
         raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+    if torch.is_grad_enabled() and (c2w.requires_grad or (torch.is_tensor(focals) and focals.requires_grad)):
+        # learnable camera parameters (camera_parameters_offsets): the rays carry a graph back to them
+        return _CameraRays.apply(c2w, focals, height, width, rows, cols)
     lead = list(c2w.shape[:-2])
     n = int(math.prod(lead)) if lead else 1
     dev = c2w.device
@@ -111,6 +114,46 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
                                       cols.data_ptr(), origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
                                       torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
     return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
+
+
+class _CameraRays(torch.autograd.Function):
+    """``camera_rays`` with a backward pass: d_cam = ((col - W/2) / f, -(row - H/2) / f, -1), d_world = R d_cam, o = t,
+    focal normal = -R[:, 2] (ray_helper.py:15-52, 1203-1227), differentiated with respect to the camera matrix and the
+    focal length - the path learnable camera offsets (model/layers/camera_parameters_storage.py) are trained through."""
+
+    @staticmethod
+    def forward(ctx, c2w, focals, height, width, rows, cols):
+        with torch.no_grad():
+            origins, directions, normals = camera_rays(c2w, focals, height, width, rows, cols)
+        ctx.save_for_backward(c2w, focals, rows, cols)
+        ctx.size = (height, width)
+        return origins, directions, normals
+
+    @staticmethod
+    def backward(ctx, g_origins, g_directions, g_normals):
+        c2w, focals, rows, cols = ctx.saved_tensors
+        height, width = ctx.size
+        lead = list(c2w.shape[:-2])
+        f = torch.broadcast_to(focals.to(torch.float32), lead).unsqueeze(-1)                     # (..., 1)
+        u = (cols.to(torch.float32) - width / 2).to(c2w.device)                                   # (R) or (..., R)
+        v = -(rows.to(torch.float32) - height / 2).to(c2w.device)
+        g_c2w = torch.zeros_like(c2w, dtype=torch.float32)
+        g_f = None
+        if g_directions is not None:
+            g_d = g_directions.to(torch.float32)
+            d_cam = torch.stack([u / f, v / f, -torch.ones_like(u / f)], dim=-1)                 # (..., R, 3)
+            g_c2w[..., :3, :3] = torch.einsum("...ri,...rj->...ij", g_d, d_cam)                   # d_world_i = R_ij d_cam_j
+            g_cam = torch.einsum("...ri,...ij->...rj", g_d, c2w[..., :3, :3].to(torch.float32))   # R^T g
+            g_f = -((g_cam[..., 0] * u + g_cam[..., 1] * v) / (f * f)).sum(-1)
+        if g_origins is not None:
+            g_c2w[..., :3, 3] = g_origins.to(torch.float32)
+        if g_normals is not None:
+            g_c2w[..., :3, 2] -= g_normals.to(torch.float32)
+        if g_f is not None:
+            while g_f.dim() > focals.dim():                     # focals broadcast over leading dimensions
+                g_f = g_f.sum(0)
+            g_f = g_f.reshape(focals.shape).to(focals.dtype)
+        return g_c2w.to(c2w.dtype), g_f, None, None, None, None
 
 
 def camera_rays_at_positions(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int, positions: torch.Tensor,

@@ -95,13 +95,16 @@ GRAD_KEYS = ("integrated_features", "opacity", "depth", "integrated_displacement
 
 class _RenderFunction(torch.autograd.Function):
     """autograd node of one renderer call: forward = pr_render_forward with PR_FLAG_SAVE_FOR_BACKWARD,
-    backward = pr_render_backward.  Inputs after the bookkeeping arguments: transformation_matrix_w2o, style,
-    deformation, then every trainable parameter of the composer."""
+    backward = pr_render_backward.  Inputs after the bookkeeping arguments: ray_origins, ray_directions (differentiated only
+    when they carry a graph: learnable camera parameters), transformation_matrix_w2o, style, deformation, then every
+    trainable parameter of the composer."""
 
     @staticmethod
-    def forward(ctx, composer, kwargs, holder, w2o, style, deformation, *params):
+    def forward(ctx, composer, kwargs, holder, ray_origins, ray_directions, w2o, style, deformation, *params):
         results, state = composer._render(**kwargs, _save=True)
         ctx.composer, ctx.state, ctx.params = composer, state, params
+        ctx.ray_shapes = (ray_origins.shape, ray_directions.shape)
+        ctx.ray_grads = ray_origins.requires_grad or ray_directions.requires_grad
         # the backward pass reads the parameter storages in place: an in-place update between forward and backward
         # (an optimiser step, a GAN-style second network update) must raise, as torch's saved-tensor check would
         ctx.versions = tuple(p._version for p in composer.parameters())
@@ -213,6 +216,10 @@ class _RenderFunction(torch.autograd.Function):
         d_style = torch.zeros((N, K, S), **f32)
         d_def = torch.zeros((N, K, D), **f32)
         ig.w2o, ig.style, ig.deformation = d_w2o.data_ptr(), d_style.data_ptr(), d_def.data_ptr()
+        d_ray_o = d_ray_d = None
+        if ctx.ray_grads:
+            d_ray_o, d_ray_d = torch.zeros((N, 3), **f32), torch.zeros((N, R, 3), **f32)
+            ig.ray_origins, ig.ray_directions = d_ray_o.data_ptr(), d_ray_d.data_ptr()
         for k in range(K):
             ig.model[k] = composer._model_grad_struct(st["models"][k], grads)
             if "fine" in st["types"]:
@@ -234,7 +241,9 @@ class _RenderFunction(torch.autograd.Function):
         g_style = d_style.permute(0, 2, 1).reshape(lead + [S, K]).sum_to_size(s_shape)
         g_def = d_def.permute(0, 2, 1).reshape(lead + [D, K]).sum_to_size(d_shape)
         ctx.state = None   # releases the forward workspace
-        return (None, None, None, g_w2o, g_style, g_def) + tuple(grads[id(p)] for p in ctx.params)
+        if ctx.ray_grads:
+            d_ray_o, d_ray_d = d_ray_o.reshape(ctx.ray_shapes[0]), d_ray_d.reshape(ctx.ray_shapes[1])
+        return (None, None, None, d_ray_o, d_ray_d, g_w2o, g_style, g_def) + tuple(grads[id(p)] for p in ctx.params)
 
 
 class ObjectComposer(nn.Module):
@@ -476,8 +485,9 @@ class ObjectComposer(nn.Module):
         ``integrated_features``, ``opacity``, ``depth``, ``integrated_displacements_magnitude`` and
         ``integrated_divergence`` of every entry (pr_render_backward).  ``integrated_divergence`` carries the Hutchinson
         estimate of the reference (object_composer.py:582-601) in training mode; its gradient (the reference's double
-        backward) is one more pass over the ray bender with the probe tangents in place of the activations.  Not
-        differentiated: the camera rays (dataset inputs in the reference's trainers) and ``disparity`` (no consumer)."""
+        backward) is one more pass over the ray bender with the probe tangents in place of the activations.  ``ray_origins`` /
+        ``ray_directions`` are differentiated when they carry a graph (learnable camera parameters; dataset inputs otherwise).
+        Not differentiated: ``focal_normals`` (unused by the reference's composer too) and ``disparity`` (no consumer)."""
         if ray_directions.is_cuda:
             # the library launches on the caller's stream: that stream's device has to be the current one
             with torch.cuda.device(ray_directions.device):
@@ -498,7 +508,8 @@ class ObjectComposer(nn.Module):
                 perturb, canonical_pose, _noise, _export, False, None, _decoder_layout)
         params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
-                                                  transformation_matrix_w2o.requires_grad)
+                                                  transformation_matrix_w2o.requires_grad or ray_origins.requires_grad or
+                                                  ray_directions.requires_grad)
         if not wants_grad:
             return self._render(*args)[0]
         kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
@@ -510,8 +521,8 @@ class ObjectComposer(nn.Module):
     def _render_with_graph(self, kwargs: dict, K: int, params) -> Dict:
         """One differentiable renderer call: the tensors of the result dictionary are the outputs of the autograd node."""
         holder = {}
-        flat = _RenderFunction.apply(self, kwargs, holder, kwargs["transformation_matrix_w2o"], kwargs["style"],
-                                     kwargs["deformation"], *params)
+        flat = _RenderFunction.apply(self, kwargs, holder, kwargs["ray_origins"], kwargs["ray_directions"],
+                                     kwargs["transformation_matrix_w2o"], kwargs["style"], kwargs["deformation"], *params)
         results = holder["results"]
         i = 0
         for ty in holder["types"]:

@@ -410,8 +410,9 @@ def _probe_loss(results, probes, K):
     return total
 
 
-def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True):
-    """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``."""
+def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True, rays=False):
+    """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``; ``rays``: also
+    with respect to the camera rays (ray_origins, ray_directions)."""
     comp = build(cfg, alpha_bias=bias).train(training)
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
     o, d, nrm, w2o, sty, dfm, ins = inputs
@@ -421,9 +422,10 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     for k in names:
         sd[k].requires_grad_(True)
     ref_in = [t.clone().requires_grad_(True) for t in (w2o, sty, dfm)]
+    ref_rays = [t.clone().requires_grad_(rays) for t in (o, d)]
     rec = {}
     torch.manual_seed(123)
-    want = ro.composer_forward(cfg, sd, o, d, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=training,
+    want = ro.composer_forward(cfg, sd, *ref_rays, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=training,
                                record_noise=rec, stable_merge=True)
     gen = torch.Generator().manual_seed(7)
     probes = {(ty, nm, key): torch.randn(want[ty][nm][key].shape, generator=gen)
@@ -435,7 +437,8 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
         if any(f in k for f in frozen):
             p.requires_grad_(False)
     hip_in = [t.clone().cuda().requires_grad_(True) for t in (w2o, sty, dfm)]
-    got = comp(o.cuda(), d.cuda(), nrm.cuda(), *hip_in, ins.cuda(), perturb, canonical_pose=canonical, _noise=rec)
+    hip_rays = [t.clone().cuda().requires_grad_(rays) for t in (o, d)]
+    got = comp(*hip_rays, nrm.cuda(), *hip_in, ins.cuda(), perturb, canonical_pose=canonical, _noise=rec)
     _probe_loss(got, probes, K).backward()
     torch.cuda.synchronize()
     # forward fields of the differentiable call, incl. the Hutchinson divergence (replayed probes)
@@ -452,6 +455,9 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     hip = {k: params[k].grad for k in names}
     for label, a, b in zip(("w2o", "style", "deformation"), ref_in, hip_in):
         ref[label], hip[label] = a.grad, b.grad
+    if rays:
+        for label, a, b in zip(("ray_origins", "ray_directions"), ref_rays, hip_rays):
+            ref[label], hip[label] = a.grad, b.grad
     out = {}
     for k in ref:
         b = hip[k].detach().cpu() if hip[k] is not None else None
@@ -498,6 +504,36 @@ def test_backward_matches_oracle_autograd(name, perturb):
             bad[k] = (err, scale)
     assert not bad, bad
     assert nonzero > 40
+
+
+@pytest.mark.parametrize("name,perturb", [("tennis", False), ("tennis_frames", True), ("minecraft", True), ("tennis_hierarchical", False)])
+def test_backward_to_the_camera_rays(name, perturb):
+    """d loss / d ray_origins and d ray_directions - what learnable camera parameters are trained through (the reference's rays
+    are torch tensors with a graph: ray_helper.py:15-52, 1203-1227) - against torch.autograd through the oracle: sample
+    positions o + d t, the slab-test depths, the skybox's [o / size, d / |d|] input and the spacings dt |d| of every entry
+    all depend on the rays.  (The other gradients of the same call are compared as well: asking for the ray gradients must
+    not disturb them.)"""
+    if name == "minecraft":
+        cfg, scene, n, bias = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS), synthetic.minecraft_scene(), 16, 3.0
+    elif name == "tennis_frames":
+        cfg, scene, n, bias = (configs.reduced_config(configs.tennis_config(), **SMALL_NETS),
+                               synthetic.tennis_scene(batch=2, observations=2, seed=3), 12, 2.0)
+    elif name == "tennis_hierarchical":
+        cfg = configs.reduced_config(configs.enable_fine(configs.tennis_config()), positions=HIER_POSITIONS, **SMALL_NETS)
+        scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
+    else:
+        cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
+    grads = _gradients(cfg, scene, n, bias, perturb, rays=True)
+    tol = 1e-3 if name == "tennis_hierarchical" else 2e-4
+    bad = {}
+    for k, (a, b) in grads.items():
+        scale = float(a.abs().max())
+        err = float((a - b).abs().max())
+        # the origin of a frame sums the contributions of all its rays and samples: compare at the scale of the summands
+        if err > tol * (scale if k != "ray_origins" else max(scale, float(grads["ray_directions"][0].abs().max()))) + 1e-9:
+            bad[k] = (err, scale)
+    assert not bad, bad
+    assert float(grads["ray_origins"][0].abs().max()) > 0 and float(grads["ray_directions"][0].abs().max()) > 0
 
 
 @pytest.mark.parametrize("name,perturb,alone", [("tennis", False, True), ("tennis", True, False), ("minecraft", True, True),
@@ -1170,6 +1206,7 @@ import glob
 import numpy as np
 
 from tests.helpers import observation_batch, stand_in_encoders
+from playableenvironments_amd import ray_sampling  # noqa: E402
 
 OBS_KEYS = ("observations", "camera_rotations", "camera_translations", "focals", "bounding_boxes", "bounding_boxes_validity",
             "global_frame_indexes", "video_frame_indexes", "video_indexes")
@@ -1302,6 +1339,72 @@ def test_observation_mode_gradients_reach_the_encoders():
     assert any(n.startswith("object_parameters_encoders.") and float(g.abs().sum()) > 0 for n, g in grads.items())
     assert any(n.startswith("object_composer.") and float(g.abs().sum()) > 0 for n, g in grads.items())
     assert all(torch.isfinite(g).all() for g in grads.values())
+
+
+def test_camera_rays_are_differentiable_for_learnable_cameras():
+    """camera_rays with a graph (c2w / focals require gradients): the HIP kernel's values, and a backward pass equal to
+    torch.autograd through the closed form d_cam = ((col - W/2)/f, -(row - H/2)/f, -1), d = R d_cam, o = t, normal = -R[:, 2]."""
+    g = torch.Generator().manual_seed(3)
+    c2w = em.euler_to_matrix(torch.rand(2, 3, 3, generator=g) - 0.5, torch.randn(2, 3, 3, generator=g)).cuda()
+    focals = (torch.rand(2, 3, generator=g) * 100 + 150).cuda()
+    height, width = 40, 56
+    idx = torch.randint(0, height * width, (2, 3, 37), generator=g).cuda()
+    rows, cols = ray_sampling.split_indices(idx, width)
+    probes = [torch.randn(s, generator=g).cuda() for s in ((2, 3, 3), (2, 3, 37, 3), (2, 3, 3))]
+    a_c2w, a_f = c2w.clone().requires_grad_(True), focals.clone().requires_grad_(True)
+    outs = em.camera_rays(a_c2w, a_f, height, width, rows, cols)
+    with torch.no_grad():
+        plain = em.camera_rays(c2w, focals, height, width, rows, cols)
+    assert all(torch.equal(x, y) for x, y in zip(outs, plain))
+    sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+    b_c2w, b_f = c2w.clone().requires_grad_(True), focals.clone().requires_grad_(True)
+    f = b_f.unsqueeze(-1)
+    d_cam = torch.stack([(cols.float() - width / 2) / f, -(rows.float() - height / 2) / f, -torch.ones_like(cols.float())], -1)
+    ref = (b_c2w[..., :3, 3], torch.einsum("...ij,...rj->...ri", b_c2w[..., :3, :3], d_cam), -b_c2w[..., :3, 2])
+    assert all(torch.allclose(x, y, rtol=1e-5, atol=1e-5) for x, y in zip(outs, ref))
+    sum((o * p).sum() for o, p in zip(ref, probes)).backward()
+    assert torch.allclose(a_c2w.grad, b_c2w.grad, rtol=1e-4, atol=1e-4 * float(b_c2w.grad.abs().max()))
+    assert torch.allclose(a_f.grad, b_f.grad, rtol=1e-4, atol=1e-4 * float(b_f.grad.abs().max()))
+
+
+def test_learnable_camera_offsets_receive_gradients_through_the_render():
+    """enable_camera_parameters_offsets (model/layers/camera_parameters_storage.py): in training mode the observation-driven
+    forward adds the per-frame offsets to the measured cameras, the rays are generated with a graph, and the loss on the
+    rendered features reaches the offset table through pr_render_backward's ray gradients - for the (frame, camera) entries
+    the batch used and for those only; in evaluation mode the offsets are zero and nothing requires the ray gradients."""
+    size = (48, 64)
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    cfg = configs.reduced_config(configs.tennis_config(), **small)
+    cfg["model"]["enable_camera_parameters_offsets"] = True
+    cfg["model"]["camera_parameters_memory_size"] = 16
+    model = em.EnvironmentModel(cfg, *stand_in_encoders(cfg, "tennis"))
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    model = model.cuda()
+    b = {k: v.cuda() for k, v in observation_batch(synthetic.tennis_scene(batch=2, observations=2, seed=7, image_size=size)).items()}
+    b["global_frame_indexes"] = torch.tensor([[3, 4], [9, 3]], device="cuda")
+    with torch.no_grad():
+        model.camera_parameters_offsets.table.normal_(0, 1e-3)
+    args = [b[k] for k in OBS_KEYS]
+    model.eval()
+    model.camera_parameters_offsets.train()          # offsets on; BatchNorm keeps its running statistics (small random patches)
+    torch.manual_seed(5)
+    out = model(*args, samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8])
+    out["coarse"]["global"]["integrated_features"].square().mean().backward()
+    grad = model.camera_parameters_offsets.table.grad
+    assert grad is not None and torch.isfinite(grad).all()
+    used = sorted(set(b["global_frame_indexes"].flatten().tolist()))
+    touched = sorted(torch.nonzero(grad.abs().sum(-1) > 0).flatten().tolist())
+    assert touched == used, (touched, used)
+    assert all(float(grad[used][:, c].abs().max()) > 0 for c in range(7))       # rotation, translation and focal offsets
+    # the offsets change the render (translations scaled by 10, focals by 1000)
+    with torch.no_grad():
+        torch.manual_seed(5)
+        base = model(*args, samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8])
+        model.camera_parameters_offsets.eval()
+        torch.manual_seed(5)
+        plain = model(*args, samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8])
+    assert torch.equal(base["coarse"]["global"]["integrated_features"], out["coarse"]["global"]["integrated_features"].detach())
+    assert not torch.equal(base["coarse"]["global"]["integrated_features"], plain["coarse"]["global"]["integrated_features"])
 
 
 def test_missing_encoders_raise():
