@@ -275,9 +275,9 @@ class CameraParametersStorage(nn.Module):
 
     # ---- the reference's checkpoint layout
     def _save_to_state_dict(self, destination, prefix, keep_vars):
-        for entry in range(self.camera_adjusted_storage_size):
-            row = self.table[entry]
-            destination[f"{prefix}storage.storage.{entry}"] = row if keep_vars else row.detach().clone()
+        rows = self.table if keep_vars else self.table.detach().clone()
+        for entry, row in enumerate(rows.unbind(0)):
+            destination[f"{prefix}storage.storage.{entry}"] = row
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         rows = []
@@ -293,10 +293,10 @@ class CameraParametersStorage(nn.Module):
             elif strict:
                 missing_keys.append(key)
         if strict:
-            for key in state_dict:
-                if key.startswith(prefix) and key not in {f"{prefix}storage.storage.{e}"
-                                                           for e in range(self.camera_adjusted_storage_size)}:
-                    unexpected_keys.append(key)
-        with torch.no_grad():
-            for entry, value in rows:
-                self.table[entry].copy_(value)
+            own = {f"{prefix}storage.storage.{e}" for e in range(self.camera_adjusted_storage_size)}
+            unexpected_keys.extend(key for key in state_dict if key.startswith(prefix) and key not in own)
+        if rows:
+            with torch.no_grad():       # one scatter instead of one copy per entry (tables hold tens of thousands of frames)
+                index = torch.tensor([entry for entry, _ in rows], device=self.table.device)
+                values = torch.stack([value.detach().to(device=self.table.device, dtype=self.table.dtype) for _, value in rows])
+                self.table.index_copy_(0, index, values)
