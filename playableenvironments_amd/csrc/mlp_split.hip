@@ -465,21 +465,28 @@ __device__ __forceinline__ void gated_head_flush_h(SmemH& S, const MlpParams& p,
     head_on_tile_h(S, p, pending);
 }
 
-__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) {
+// GROUP: one of several objects evaluated by the same launch (k_mlp_split_group), as in mlp.hip: every tile is claimed from
+// the object's counter and a workgroup that finds an object's tiles exhausted moves on to the next object.
+template <bool GROUP>
+__device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
+    if (GROUP) {
+        __syncthreads();   // every wave has left the previous object's last tile
+        if (tid == 0) S.next_tile = atomicAdd(p.tile_counter, 1);
+    }
     for (int i = tid; i <= p.Wpad; i += STHREADS) S.head_w[i] = p.sigma_w[i];
     __syncthreads();
     int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head)
     // dynamic tile order, as in k_mlp_mfma: further tiles are claimed from a device counter, one tile ahead
 #ifdef PR_MLP_STATIC_TILES
-    const bool dynamic_tiles = false;
+    const bool dynamic_tiles = GROUP;
 #else
-    const bool dynamic_tiles = p.tile_counter != nullptr;
+    const bool dynamic_tiles = GROUP || p.tile_counter != nullptr;
 #endif
-    for (int tile = blockIdx.x; tile * STILE_M < total; tile = S.next_tile) {
+    for (int tile = GROUP ? S.next_tile : (int)blockIdx.x; tile * STILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * STILE_M;
         PR_PHASE_T0();
         int claimed = 0;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
         }
         __syncthreads();
         if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
-        if (tid == 0) S.next_tile = dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x;
+        if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);
         PR_PHASE(0);
 
         if (p.has_bender) {
@@ -609,6 +616,42 @@ __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParam
         PR_PHASE(8);
     }
     if (p.gate) gated_head_flush_h(S, p, pending);
+}
+
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) { split_tile_loop<false>(p); }
+// one copy of the tile loop per job slot: parameters as kernel arguments at constant offsets (see k_mlp_mfma_group)
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                                int count) {
+    split_tile_loop<true>(j0);
+    if (count > 1) split_tile_loop<true>(j1);
+    if (count > 2) split_tile_loop<true>(j2);
+    if (count > 3) split_tile_loop<true>(j3);
+}
+
+int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s) {
+    PR_REQUIRE(count >= 1, "grouped MLP launch: no jobs");
+    static thread_local MlpGroupParams g;     // 18 KB: not on the stack
+    for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
+        const int n = count - begin < MLP_GROUP_MAX ? count - begin : MLP_GROUP_MAX;
+        long max_tiles = 0;
+        for (int j = 0; j < n; ++j) {
+            const MlpParams& q = host_jobs[begin + j];
+            PR_REQUIRE(q.phase == 0 && q.tile_counter, "grouped MLP launch: evaluation launches with a tile counter only");
+            PR_REQUIRE(!q.gate || (q.pend_act && q.pend_meta), "gated head: pending buffers missing");
+            max_tiles += ((long)max_rows[begin + j] + STILE_M - 1) / STILE_M;
+            g.jobs[j] = q;
+        }
+        if (max_tiles <= 0) continue;
+        int cu_count = 0;
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_split_group), (int)sizeof(SmemH), &cu_count));
+        int resident = cu_count * SBLOCKS_PER_CU;
+        if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;
+        const int grid = max_tiles < resident ? (int)max_tiles : resident;
+        ProfileScope scope(0, s);
+        hipLaunchKernelGGL(k_mlp_split_group, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        PR_LAUNCH_CHECK();
+    }
+    return PR_OK;
 }
 
 int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {

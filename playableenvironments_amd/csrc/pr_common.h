@@ -333,6 +333,7 @@ int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_mod
 // evaluation launches of several objects as one
 int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s);
 int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s);   // PR_PRECISION_F16X3, eval only
+int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s);
 
 // BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
 // running statistics updated in place with momentum 0.1 and the unbiased variance, num_batches_tracked += 1

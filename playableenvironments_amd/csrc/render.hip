@@ -239,13 +239,12 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     return PR_OK;
 }
 
-// Evaluation calls on the exact-fp32 kernel run the objects of a model type as ONE grouped launch (k_mlp_mfma_group).
+// Evaluation calls run the objects of a model type as ONE grouped launch (k_mlp_mfma_group / k_mlp_split_group).
 bool group_active(const pr_call_t& c) {
 #ifdef PR_MLP_UNGROUPED
     return false;      // measurement build: one launch per object
 #else
-    return !(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD | PR_FLAG_NAIVE_MLP)) && c.precision != PR_PRECISION_F16X3 &&
-           c.objects > 1;
+    return !(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD | PR_FLAG_NAIVE_MLP)) && c.objects > 1;
 #endif
 }
 
@@ -482,8 +481,12 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             }
         }
 
-        if (grouped)
-            PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
+        if (grouped) {
+            if (c.precision == PR_PRECISION_F16X3)
+                PR_TRY(launch_mlp_split_group(jobs, job_rows, K, s));
+            else
+                PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
+        }
 
         // ---- compositing ------------------------------------------------------------------------
         const pr_outputs_t* out = outs[t];
