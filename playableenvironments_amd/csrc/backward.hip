@@ -361,6 +361,8 @@ struct RowCtx {
     const int32_t* rec_flat;
     const int32_t* row_flags;
     int samples_per_frame;
+    const uint8_t* in_scene;     // (N,K) base offset to this object; stride K: the densities of an absent object are constants
+    int in_scene_stride;
 };
 
 // gathers the dense sigma / |delta| gradients to rows and clears the feature gradients of unused rows
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(256) void k_gather_rows(RowCtx r, const float* g_si
         const int fl = r.row_flags[m];
         const int flat = r.rec_flat[m];
         if (threadIdx.x == 0) {
-            gsr[m] = ((fl & 3) == 3) ? g_sigma[flat] : 0.f;
+            const bool present = r.in_scene[(size_t)(flat / r.samples_per_frame) * r.in_scene_stride] != 0;
+            gsr[m] = ((fl & 3) == 3 && present) ? g_sigma[flat] : 0.f;
             if (gdr) gdr[m] = (fl & 1) ? g_dm[flat] : 0.f;
         }
         if ((fl & 3) != 3)
@@ -1067,6 +1070,11 @@ static int input_grad(const GemmCtx& g, const float* dY, int ldy, int n_out, con
     memset(&p, 0, sizeof(p));
     p.A = dY; p.lda = ldy; p.B = W; p.ldb = ldw; p.C = dX; p.ldc = ldx;
     p.rows = g.rows; p.n = n_in; p.k = n_out; p.accumulate = accumulate ? 1 : 0;
+    if (n_out & 15) {      // the product walks K in 16-deep slabs: the tail reads padding columns of dY as zeros
+        p.k = (n_out + 15) & ~15;
+        p.k_valid = n_out;
+        PR_REQUIRE(ldy >= p.k, "input gradient: %d output columns in rows of %d floats", n_out, ldy);
+    }
     p.mask = mask; p.ldm = ldm;
     return launch_gemm_nn(p, g.max_rows, g.s);
 }
@@ -1248,6 +1256,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         rc.rec_flat = reinterpret_cast<const int32_t*>(fws + sv.rec_flat);
         rc.row_flags = reinterpret_cast<const int32_t*>(fws + sv.row_flags);
         rc.samples_per_frame = c.rays * P;
+        rc.in_scene = c.object_in_scene + k; rc.in_scene_stride = K;
         GemmCtx gc;
         gc.rows = totals + k; gc.max_rows = (int)cap; gc.partial = reinterpret_cast<float*>(bws + bp.partial); gc.s = s;
         gc.gstack = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.gstack) : nullptr;

@@ -59,15 +59,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nn(GemmNN p) {
         float4 ra[4];
         float rb[16];
         auto fetch = [&](int k0) {
+            const int kv = p.k_valid ? p.k_valid : p.k;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + arow + 32 * i;
-                ra[i] = (row < M && k0 + 4 * ak4 < p.k)
-                            ? *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + k0 + 4 * ak4)
+                const int ka = k0 + 4 * ak4;
+                ra[i] = (row < M && ka < kv)
+                            ? *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + ka)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                // columns of A beyond k_valid are padding that nobody has to have written: 0 x garbage must stay 0
+                if (ka + 3 >= kv) {
+                    if (ka + 1 >= kv) ra[i].y = 0.f;
+                    if (ka + 2 >= kv) ra[i].z = 0.f;
+                    if (ka + 3 >= kv) ra[i].w = 0.f;
+                }
             }
             const bool ncol = n0 + bn < p.n;
-            const int kv = p.k_valid ? p.k_valid : p.k;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = k0 + bk + 2 * i;

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
                 const float x = __fadd_rn(w.o[0], __fmul_rn(w.d[0], t));
                 const float y = __fadd_rn(w.o[1], __fmul_rn(w.d[1], t));
                 const float z = __fadd_rn(w.o[2], __fmul_rn(w.d[2], t));
-                inside = w.valid && in_box(x, y, z, p.lo, p.hi);
+                inside = in_box(x, y, z, p.lo, p.hi);   // absent objects too: the reference evaluates their samples (near = far = 0, clamped) and
+                                                        // only overrides their densities afterwards (object_composer.py:546-547)
             }
             ray_count += __popcll(L.mine(__ballot(inside)));
         }
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
         *x = __fadd_rn(w.o[0], __fmul_rn(w.d[0], t));
         *y = __fadd_rn(w.o[1], __fmul_rn(w.d[1], t));
         *z = __fadd_rn(w.o[2], __fmul_rn(w.d[2], t));
-        return w.valid && in_box(*x, *y, *z, p.lo, p.hi);
+        return in_box(*x, *y, *z, p.lo, p.hi);    // (absent objects included, see k_place_coarse)
     };
     int count = 0;
     walk([&](int r0, int r, bool live, const WaveRay& w, size_t base) {
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64) void k_resample(ResampleParams p, int sort_size
         const float x = __fadd_rn(ray.o[0], __fmul_rn(ray.d[0], t));
         const float y = __fadd_rn(ray.o[1], __fmul_rn(ray.d[1], t));
         const float z = __fadd_rn(ray.o[2], __fmul_rn(ray.d[2], t));
-        if (valid && in_box(x, y, z, p.lo, p.hi)) ++count;
+        if (in_box(x, y, z, p.lo, p.hi)) ++count;      // (absent objects included, see k_place_coarse)
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) count += __shfl_down(count, d, 64);

@@ -1148,15 +1148,16 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
                 float sg;
                 row_dots(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
                 if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) {
-                    const float sv = sg + S.head_w[p.Wpad];
+                    const float sv = p.in_scene[(size_t)S.frame[s] * p.in_scene_stride] ? sg + S.head_w[p.Wpad] : p.empty_alpha;
                     p.sigma[S.flat[s]] = sv;
                     if (!(sv <= 0.f)) S.flags[s] |= 4;   // a NaN density stays live (relu(NaN) = NaN in the reference)
                 }
             }
         } else if (tid < TILE_M) {
             if (S.flags[tid] & 1) {
-                p.sigma[S.flat[tid]] = 10.0f;
-                S.flags[tid] |= 4;
+                const bool present = p.in_scene[(size_t)S.frame[tid] * p.in_scene_stride] != 0;
+                p.sigma[S.flat[tid]] = present ? 10.0f : p.empty_alpha;
+                if (present || !(p.empty_alpha <= 0.f)) S.flags[tid] |= 4;
             }
         }
 
@@ -1359,9 +1360,9 @@ __global__ __launch_bounds__(64) void k_mlp_naive(MlpParams p, pr_object_model_t
     if (p.kind == 0) {
         float sg;
         naive_linear(m.alpha_head, h, &sg, false);
-        if (alive) p.sigma[flat] = sg;
+        if (alive) p.sigma[flat] = p.in_scene[(size_t)frame * p.in_scene_stride] ? sg : p.empty_alpha;
     } else {
-        p.sigma[flat] = 10.0f;
+        p.sigma[flat] = p.in_scene[(size_t)frame * p.in_scene_stride] ? 10.0f : p.empty_alpha;
     }
     const float* tab = p.adain + (size_t)frame * p.adain_stride;
     const int W2 = m.layers_width / 2;
@@ -1584,7 +1585,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd(Ch
         for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
             const int row = idx / w4, c4 = (idx - row * w4) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < rows_valid) v = *reinterpret_cast<const float4*>(c.g_last + (size_t)(tile_base + row) * c.Wpad + c4);
+            // (columns beyond the real width are padding that the producers of g_last do not write)
+            if (row < rows_valid && c4 < c.W) v = *reinterpret_cast<const float4*>(c.g_last + (size_t)(tile_base + row) * c.Wpad + c4);
             *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
         }
         __syncthreads();

@@ -565,15 +565,16 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
                 float sg;
                 row_dots_h(S, s, S.head_w, p.Wpad, p.Wpad, 1, &sg);
                 if ((tid & 7) == 0 && (S.flags[s] & 3) == 3) {
-                    const float sv = sg + S.head_w[p.Wpad];
+                    const float sv = p.in_scene[(size_t)S.frame[s] * p.in_scene_stride] ? sg + S.head_w[p.Wpad] : p.empty_alpha;
                     p.sigma[S.flat[s]] = sv;
                     if (!(sv <= 0.f)) S.flags[s] |= 4;
                 }
             }
         } else if (tid < STILE_M) {
             if (S.flags[tid] & 1) {
-                p.sigma[S.flat[tid]] = 10.0f;
-                S.flags[tid] |= 4;
+                const bool present = p.in_scene[(size_t)S.frame[tid] * p.in_scene_stride] != 0;
+                p.sigma[S.flat[tid]] = present ? 10.0f : p.empty_alpha;
+                if (present || !(p.empty_alpha <= 0.f)) S.flags[tid] |= 4;
             }
         }
 

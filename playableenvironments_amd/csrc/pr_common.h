@@ -140,6 +140,8 @@ struct MlpParams {
     int canonical;
     float lo[3], hi[3], size[3];
     float empty_alpha;
+    const uint8_t* in_scene;     // (N,K) base offset to this object: the density of an absent object's samples is empty_alpha
+    int in_scene_stride;         // K                               (object_composer.py:546-547: overridden AFTER the network ran)
     // skybox inputs
     const float* ray_directions; // (N,R,3)
     const float* ray_origins;    // (N,3)

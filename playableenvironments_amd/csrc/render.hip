@@ -364,6 +364,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             mp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
             bbox_split(m, mp.lo, mp.hi, mp.size);
             mp.empty_alpha = m.empty_space_alpha;
+            mp.in_scene = c.object_in_scene + k; mp.in_scene_stride = K;
             mp.ray_directions = c.ray_directions; mp.ray_origins = c.ray_origins;
             mp.w2o = c.w2o + (size_t)k * 12; mp.w2o_stride = K * 12;
             mp.deformation = c.deformation + (size_t)k * m.deformation_features;

@@ -25,6 +25,15 @@ def composer_inputs(config, scene, strides=None, pixels=None):
             scene["object_in_scene"].unsqueeze(-2))
 
 
+def poison_device_memory():
+    """Leaves NaN bit patterns in the blocks torch's caching allocator hands out next (the renderer's workspaces are
+    ``torch.empty``): a kernel that reads scratch it never wrote - padded columns, rows beyond the compacted count - then
+    produces NaNs instead of passing by luck on fresh (zero) pages."""
+    blocks = [torch.full((64 << 20,), float("nan"), device="cuda") for _ in range(4)]
+    small = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 10, 1 << 14, 1 << 18, 1 << 20, 1 << 22) for _ in range(4)]
+    del blocks, small
+
+
 def compare_results(want, got, rtol, atol, path="", out=None):
     """NaN-aware comparison of two composer result dicts; ``weights`` are compared after sorting
     (tie order inside equal-t groups is unspecified in the reference).  Returns {field: (maxdiff, ok)}."""
