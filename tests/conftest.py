@@ -20,3 +20,15 @@ def built_library():
         import __graft_entry__
         __graft_entry__.build()
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_device_memory(request):
+    """GPU tests start on NaN-poisoned allocator blocks (tests/helpers.poison_device_memory): the renderer's workspaces are
+    ``torch.empty``, and scratch that a kernel reads without anybody having written it must not pass by luck on fresh pages."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            from tests.helpers import poison_device_memory
+            poison_device_memory()
+    yield

@@ -162,8 +162,28 @@ def main():
             continue
         try:
             poison()
-            comp = build(cfg, seed=i, alpha_bias=bias)
+            precision = "f16x3" if rng.random() < 0.3 else "fp32"
+            comp = build(cfg, seed=i, alpha_bias=bias, precision=precision)
+            label += f" {precision}"
             want, got = run_both(cfg, comp, inputs, perturb=flags["perturb"], canonical=flags["canonical"])
+            # the same call split along the rays by a small workspace budget must give the same bits (rays are independent)
+            if not flags["perturb"] and rng.random() < 0.5:
+                budget = type(comp).max_workspace_bytes
+                try:
+                    comp.max_workspace_bytes = 24 << 20
+                    with torch.no_grad():
+                        again = comp(*[v.cuda() for v in inputs], False, canonical_pose=flags["canonical"])
+                finally:
+                    comp.max_workspace_bytes = budget
+                for ty in got:
+                    if not isinstance(got[ty], dict):
+                        continue
+                    for name in got[ty]:
+                        if not isinstance(got[ty][name], dict):
+                            continue
+                        for key, v in got[ty][name].items():
+                            if torch.is_tensor(v) and not torch.equal(torch.nan_to_num(v), torch.nan_to_num(again[ty][name][key])):
+                                raise AssertionError(f"chunked render differs in {ty}.{name}.{key}")
             tol = dict(rtol=2e-3, atol=5e-4) if hierarchical else dict(rtol=1e-4, atol=1e-5)
             rep = compare_results(want, got, **tol)
             bad = {k: f"{v[0]:.2e}" for k, v in rep.items() if not v[1]}
