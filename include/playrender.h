@@ -338,6 +338,26 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, 
                    float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
 
 /*
+ * Pose matrices: (rotation (x, y, z Euler angles, radians), translation) -> the 4x4 transform [R t; 0 1] with R = Ry (Rx Rz)
+ * (Transformations3D.homogeneous_rotation_translation, utils/lib_3d/transformations_3d.py:69-96) and its inverse
+ * [R^T  -R^T t; 0 1] (the reference calls torch.inverse on it: environment_model.py:221, :1078).  rotations, translations
+ * (count,3); matrices, inverses (count,4,4).  Used for the cameras (c2w / w2c) and the objects (o2w / w2o) of a call.
+ */
+int pr_pose_matrices(int32_t count, const float* rotations, const float* translations, float* matrices, float* inverses,
+                     void* stream);
+
+/*
+ * Projects object-frame points into the cameras of their frame (EnvironmentModel.compute_object_bounding_boxes /
+ * compute_object_axes_projection, model/environment_model.py:234-404).  points (K,P,3); o2w (F,K,4,4); w2c (F,C,4,4);
+ * focals (F,C) -> projected (F,C,P,2,K): image coordinates normalised to [0,1] ((v + size/2) / size, x right, y down).
+ * boxes (F,C,4,K) [left, top, right, bottom] or NULL: with boxes, points behind the camera do not bound the box and both
+ * outputs are clamped to [0,1]; without, the projections are left as they are (the axes variant).
+ */
+int pr_project_points(int32_t frames, int32_t cameras, int32_t objects, int32_t points_per_object, const float* points,
+                      const float* o2w, const float* w2c, const float* focals, int32_t height, int32_t width,
+                      float* projected, float* boxes, void* stream);
+
+/*
  * ObjectComposer.compute_expected_positions (model/object_composer.py:603-622) for object `object_index` of a call:
  *   expected[n][r] = sum_i w_i (o + d t_i + delta_i) / (sum_i w_i + 1e-8)      (object frame)
  * with o, d the w2o-transformed ray (RayHelper.transform_rays), t / weights (N,R,P) as produced by pr_render_forward

@@ -166,6 +166,9 @@ SYMBOLS = {
     "pr_probe_mfma_f32": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "pr_probe_mfma_f16": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "pr_abi_version": (C.c_int, []),
+    "pr_pose_matrices": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_project_points": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_last_error": (C.c_char_p, []),
     "pr_device_info": (C.c_int, [c_int32_p, c_int32_p, C.c_char_p, C.c_size_t]),
 }

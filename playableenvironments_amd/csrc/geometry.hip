@@ -518,6 +518,143 @@ extern "C" int pr_expected_positions(int32_t frames, int32_t rays, int32_t objec
     return PR_OK;
 }
 
+namespace pr {
+// (rotation, translation) -> [R t; 0 1] with R = Ry (Rx Rz) and its rigid inverse [R^T  -R^T t; 0 1], one thread per matrix:
+// Transformations3D.homogeneous_rotation_translation (utils/lib_3d/transformations_3d.py:69-96) and the torch.inverse the
+// reference applies to it (environment_model.py:221, :1078).  As torch ops this is ~30 launches per call (six sin / cos,
+// stacks, two 3 x 3 products, slice assignments, the inverse's product and concatenations) for a few hundred FLOPs.
+__global__ void k_pose_matrices(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
+                                float* __restrict__ matrices, float* __restrict__ inverses) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float ax = rotations[i * 3 + 0], ay = rotations[i * 3 + 1], az = rotations[i * 3 + 2];
+    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    const float rx[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
+    const float ry[9] = {cy, 0.f, sy, 0.f, 1.f, 0.f, -sy, 0.f, cy};
+    const float rz[9] = {cz, -sz, 0.f, sz, cz, 0.f, 0.f, 0.f, 1.f};
+    float xz[9], r[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(rx[a * 3 + k], rz[k * 3 + b]));
+            xz[a * 3 + b] = acc;
+        }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            float acc = 0.f;
+            for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(ry[a * 3 + k], xz[k * 3 + b]));
+            r[a * 3 + b] = acc;
+        }
+    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
+    float* m = matrices + (size_t)i * 16;
+    float* v = inverses + (size_t)i * 16;
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) {
+            m[a * 4 + b] = r[a * 3 + b];
+            v[a * 4 + b] = r[b * 3 + a];
+        }
+        m[a * 4 + 3] = t[a];
+        float acc = 0.f;
+        for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(r[k * 3 + a], t[k]));
+        v[a * 4 + 3] = -acc;
+    }
+    for (int b = 0; b < 3; ++b) m[12 + b] = v[12 + b] = 0.f;
+    m[15] = v[15] = 1.f;
+}
+}  // namespace pr
+
+namespace pr {
+// Projection of object-frame points into the cameras of their frame (EnvironmentModel.compute_object_bounding_boxes /
+// compute_object_axes_projection, model/environment_model.py:234-404): world = R_o2w p + t, cam = R_w2c world + t,
+// image-plane (x right, y down, relative to the image centre) = (-cam.x / cam.z f, cam.y / cam.z f), normalised to
+// (v + size / 2) / size.  One 64-lane workgroup per (frame, camera, object); with `boxes` the lanes also reduce the
+// points to [left, top, right, bottom], points behind the camera (cam.z > 0) counting as +-1e20, and both outputs are
+// clamped to [0, 1] (the bounding-box variant); without, the points are left unclamped (the axes variant).
+__global__ __launch_bounds__(64) void k_project_points(int frames, int cameras, int objects, int npoints, const float* __restrict__ points,
+                                                      const float* __restrict__ o2w, const float* __restrict__ w2c,
+                                                      const float* __restrict__ focals, float width, float height,
+                                                      float* __restrict__ out_points, float* __restrict__ boxes) {
+    const int k = blockIdx.x % objects;
+    const int c = (blockIdx.x / objects) % cameras;
+    const int f = blockIdx.x / (objects * cameras);
+    const int lane = threadIdx.x;
+    const float* mo = o2w + ((size_t)f * objects + k) * 16;
+    const float* mc = w2c + ((size_t)f * cameras + c) * 16;
+    const float focal = focals[(size_t)f * cameras + c];
+    float lo_x = 1e20f, lo_y = 1e20f, hi_x = -1e20f, hi_y = -1e20f;
+    for (int i = lane; i < npoints; i += 64) {
+        const float* pt = points + ((size_t)k * npoints + i) * 3;
+        float w[3], cam[3];
+        for (int a = 0; a < 3; ++a)
+            w[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pt[0], mo[a * 4 + 0]), __fmul_rn(pt[1], mo[a * 4 + 1])),
+                                       __fmul_rn(pt[2], mo[a * 4 + 2])), mo[a * 4 + 3]);
+        for (int a = 0; a < 3; ++a)
+            cam[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w[0], mc[a * 4 + 0]), __fmul_rn(w[1], mc[a * 4 + 1])),
+                                         __fmul_rn(w[2], mc[a * 4 + 2])), mc[a * 4 + 3]);
+        const float px = __fmul_rn(__fdiv_rn(-cam[0], cam[2]), focal);
+        const float py = -__fmul_rn(__fdiv_rn(-cam[1], cam[2]), focal);
+        if (boxes) {
+            const bool behind = cam[2] > 0.f;
+            lo_x = fminf(lo_x, behind ? 1e20f : px);
+            lo_y = fminf(lo_y, behind ? 1e20f : py);
+            hi_x = fmaxf(hi_x, behind ? -1e20f : px);
+            hi_y = fmaxf(hi_y, behind ? -1e20f : py);
+        }
+        float nx = __fdiv_rn(__fadd_rn(px, width / 2.0f), width), ny = __fdiv_rn(__fadd_rn(py, height / 2.0f), height);
+        if (boxes) {
+            nx = fminf(fmaxf(nx, 0.f), 1.f);
+            ny = fminf(fmaxf(ny, 0.f), 1.f);
+        }
+        // (frames, cameras, points, 2, objects)
+        float* dst = out_points + ((((size_t)f * cameras + c) * npoints + i) * 2) * objects + k;
+        dst[0] = nx;
+        dst[objects] = ny;
+    }
+    if (boxes) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            lo_x = fminf(lo_x, __shfl_down(lo_x, d, 64));
+            lo_y = fminf(lo_y, __shfl_down(lo_y, d, 64));
+            hi_x = fmaxf(hi_x, __shfl_down(hi_x, d, 64));
+            hi_y = fmaxf(hi_y, __shfl_down(hi_y, d, 64));
+        }
+        if (lane == 0) {
+            const float v[4] = {lo_x, lo_y, hi_x, hi_y};
+            const float size[4] = {width, height, width, height};
+            float* dst = boxes + (((size_t)f * cameras + c) * 4) * objects + k;      // (frames, cameras, 4, objects)
+            for (int a = 0; a < 4; ++a) {
+                const float n = __fdiv_rn(__fadd_rn(v[a], size[a] / 2.0f), size[a]);
+                dst[(size_t)a * objects] = fminf(fmaxf(n, 0.f), 1.f);
+            }
+        }
+    }
+}
+}  // namespace pr
+
+extern "C" int pr_project_points(int32_t frames, int32_t cameras, int32_t objects, int32_t points_per_object, const float* points,
+                                 const float* o2w, const float* w2c, const float* focals, int32_t height, int32_t width,
+                                 float* projected, float* boxes, void* stream) {
+    PR_REQUIRE(frames >= 0 && cameras > 0 && objects > 0 && points_per_object > 0 && height > 0 && width > 0,
+               "pr_project_points: bad sizes");
+    if (frames == 0) return PR_OK;
+    PR_REQUIRE(points && o2w && w2c && focals && projected, "pr_project_points: NULL pointer");
+    hipLaunchKernelGGL(pr::k_project_points, dim3((unsigned)(frames * cameras * objects)), dim3(64), 0, (hipStream_t)stream, frames,
+                       cameras, objects, points_per_object, points, o2w, w2c, focals, (float)width, (float)height, projected, boxes);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+extern "C" int pr_pose_matrices(int32_t count, const float* rotations, const float* translations, float* matrices,
+                                float* inverses, void* stream) {
+    PR_REQUIRE(count >= 0, "pr_pose_matrices: bad count %d", count);
+    if (count == 0) return PR_OK;
+    PR_REQUIRE(rotations && translations && matrices && inverses, "pr_pose_matrices: NULL pointer");
+    hipLaunchKernelGGL(pr::k_pose_matrices, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, count, rotations, translations,
+                       matrices, inverses);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 extern "C" int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, int32_t per_frame_pixels,
                               const float* c2w, const float* focals, const int32_t* rows, const int32_t* cols, float* ray_origins,
                               float* ray_directions, float* focal_normals, void* stream) {

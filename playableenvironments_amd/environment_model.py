@@ -50,6 +50,24 @@ def euler_to_matrix(rotations: torch.Tensor, translations: torch.Tensor) -> torc
     return out
 
 
+def pose_matrices(rotations: torch.Tensor, translations: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``euler_to_matrix`` and ``rigid_inverse`` of the result, (..., 4, 4) each.  Device tensors without a graph take ONE
+    kernel (``pr_pose_matrices``) instead of ~30 torch launches; tensors that carry a graph (learnable poses, camera offsets)
+    and CPU tensors take the differentiable torch ops."""
+    if rotations.is_cuda and not (torch.is_grad_enabled() and (rotations.requires_grad or translations.requires_grad)):
+        lead = list(rotations.shape[:-1])
+        n = int(math.prod(lead)) if lead else 1
+        rot = rotations.detach().to(torch.float32).reshape(n, 3).contiguous()
+        tr = torch.broadcast_to(translations.detach().to(torch.float32), rotations.shape).reshape(n, 3).contiguous()
+        out = torch.empty((2, n, 4, 4), dtype=torch.float32, device=rotations.device)
+        with torch.cuda.device(rotations.device):
+            _lib.check(_lib.load().pr_pose_matrices(n, rot.data_ptr(), tr.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                    torch.cuda.current_stream(rotations.device).cuda_stream), "pr_pose_matrices")
+        return out[0].reshape(lead + [4, 4]), out[1].reshape(lead + [4, 4])
+    m = euler_to_matrix(rotations, translations)
+    return m, rigid_inverse(m)
+
+
 def rigid_inverse(m: torch.Tensor) -> torch.Tensor:
     """Inverse of (..., 4, 4) rigid transforms [R t; 0 1] = [R^T  -R^T t; 0 1].
 
@@ -279,8 +297,7 @@ class EnvironmentModel(nn.Module):
             raise Exception(f"poses given for {object_rotation_parameters_o2w.size(-1)} objects instead of "
                             f"{self.object_id_helper.objects_count}")
         # all K objects in one batch of (..., K, 4, 4) matrices, then back to the reference's trailing object dimension
-        o2w = euler_to_matrix(object_rotation_parameters_o2w.movedim(-1, -2), object_translation_parameters_o2w.movedim(-1, -2))
-        w2o = rigid_inverse(o2w)
+        o2w, w2o = pose_matrices(object_rotation_parameters_o2w.movedim(-1, -2), object_translation_parameters_o2w.movedim(-1, -2))
         return w2o.movedim(-3, -1).unsqueeze(-4), o2w.movedim(-3, -1).unsqueeze(-4)
 
     @staticmethod
@@ -296,6 +313,33 @@ class EnvironmentModel(nn.Module):
         proj = -cam[..., :2] / cam[..., 2:3] * focals.unsqueeze(-1).unsqueeze(-1).unsqueeze(-1)
         proj = torch.stack([proj[..., 0], -proj[..., 1]], dim=-1)
         return proj, cam[..., 2:3]
+
+    @staticmethod
+    def _project_on_device(points: torch.Tensor, o2w: torch.Tensor, w2c: torch.Tensor, focals: torch.Tensor, height: int,
+                           width: int, with_boxes: bool):
+        """``_project`` + normalisation (+ box reduction and clamps) as ONE kernel (pr_project_points) for device tensors without
+        a graph: points (K, P, 3), o2w (..., 4, 4, K), w2c (..., C, 4, 4), focals (..., C) -> projected (..., C, P, 2, K)
+        and, with_boxes, boxes (..., C, 4, K)."""
+        lead = list(w2c.shape[:-3])
+        cameras, K, P = w2c.size(-3), points.size(0), points.size(1)
+        n = int(math.prod(lead)) if lead else 1
+        f32 = dict(dtype=torch.float32, device=w2c.device)
+        mo = o2w.detach().to(torch.float32).movedim(-1, -3).reshape(n, K, 4, 4).contiguous()
+        mc = w2c.detach().to(torch.float32).reshape(n, cameras, 4, 4).contiguous()
+        fc = torch.broadcast_to(focals.detach().to(torch.float32), lead + [cameras]).reshape(n, cameras).contiguous()
+        projected = torch.empty((n, cameras, P, 2, K), **f32)
+        boxes = torch.empty((n, cameras, 4, K), **f32) if with_boxes else None
+        with torch.cuda.device(w2c.device):
+            _lib.check(_lib.load().pr_project_points(n, cameras, K, P, points.contiguous().data_ptr(), mo.data_ptr(), mc.data_ptr(),
+                                                     fc.data_ptr(), height, width, projected.data_ptr(),
+                                                     boxes.data_ptr() if with_boxes else None,
+                                                     torch.cuda.current_stream(w2c.device).cuda_stream), "pr_project_points")
+        projected = projected.reshape(lead + [cameras, P, 2, K])
+        return projected, (boxes.reshape(lead + [cameras, 4, K]) if with_boxes else None)
+
+    @staticmethod
+    def _no_graph(*tensors) -> bool:
+        return all(t.is_cuda for t in tensors) and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
 
     def _image_scale(self, width: int, height: int, like: torch.Tensor) -> torch.Tensor:
         """(4, 1) [width, height, width, height] on the device of ``like`` (uploaded once: a per-call host-to-device copy
@@ -320,6 +364,10 @@ class EnvironmentModel(nn.Module):
         (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
         if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
             transformation_matrix_o2w = transformation_matrix_o2w[..., 0, :, :, :]
+        if self._no_graph(transformation_matrix_o2w, transformation_matrix_w2c, focals):
+            points, boxes = self._project_on_device(self._edge_points(transformation_matrix_o2w.device), transformation_matrix_o2w,
+                                                    transformation_matrix_w2c, focals, height, width, with_boxes=True)
+            return boxes, points
         proj, z = self._project(self._edge_points(transformation_matrix_o2w.device), transformation_matrix_o2w,
                                 transformation_matrix_w2c, focals)                             # (..., C, K, 68, 2)
         behind = (z > 0).expand_as(proj)
@@ -344,6 +392,9 @@ class EnvironmentModel(nn.Module):
             self._axes_point_cache[key] = torch.tensor([(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)],
                                                        device=transformation_matrix_o2w.device)
         pts = self._axes_point_cache[key].unsqueeze(0).expand(self.object_id_helper.objects_count, 4, 3)
+        if self._no_graph(transformation_matrix_o2w, transformation_matrix_w2c, focals):
+            return self._project_on_device(pts, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width,
+                                           with_boxes=False)[0]
         out = self._project(pts, transformation_matrix_o2w, transformation_matrix_w2c, focals)[0].movedim(-3, -1)
         pscale = self._image_scale(width, height, out)[:2]
         return (out + pscale / 2) / pscale
@@ -449,10 +500,9 @@ class EnvironmentModel(nn.Module):
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
 
-        c2w = euler_to_matrix(camera_rotations, camera_translations)
+        c2w, w2c = pose_matrices(camera_rotations, camera_translations)
         w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
                                                               object_translation_parameters_o2w)
-        w2c = rigid_inverse(c2w)
         boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, rescaled_focals * upsample_factor, height, width)
         axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
 
@@ -596,8 +646,7 @@ class EnvironmentModel(nn.Module):
                                                                                 global_frame_indexes, focal_quirk=True)
         rescaled_focals = focals * self.focal_length_multiplier
         height, width = observations.size(-2), observations.size(-1)
-        c2w = euler_to_matrix(camera_rotations, camera_translations)
-        w2c = rigid_inverse(c2w)
+        c2w, w2c = pose_matrices(camera_rotations, camera_translations)
         rot, tr = self.compute_rotation_translation_o2w(observations, w2c.detach(), camera_rotations, rescaled_focals.detach(),
                                                         bounding_boxes, bounding_boxes_validity)
         _, o2w = self.compute_transformation_matrix_w2o_o2w(rot, tr)
@@ -664,8 +713,7 @@ class EnvironmentModel(nn.Module):
         height, width = observations.size(-2), observations.size(-1)
         lead = list(observations.shape[:-3])
 
-        c2w = euler_to_matrix(camera_rotations, camera_translations)
-        w2c = rigid_inverse(c2w)
+        c2w, w2c = pose_matrices(camera_rotations, camera_translations)
         render_focals = rescaled_focals * upsample_factor
         rot, tr = self.compute_rotation_translation_o2w(observations, w2c.detach(), camera_rotations, render_focals.detach(),
                                                         bounding_boxes, bounding_boxes_validity)

@@ -1399,6 +1399,55 @@ def test_observation_mode_gradients_reach_the_encoders():
     assert all(torch.isfinite(g).all() for g in grads.values())
 
 
+def test_pose_matrices_kernel_matches_the_torch_path():
+    """pr_pose_matrices (Euler angles -> [R t; 0 1] and its rigid inverse in one launch; the no-graph path of the cameras and
+    the objects of every call) against euler_to_matrix / rigid_inverse - the torch ops pinned against the reference's
+    homogeneous_rotation_translation + torch.inverse (tests/golden/host/pose_math_*.npz, check_against_reference.py)."""
+    g = torch.Generator().manual_seed(9)
+    rot = ((torch.rand(3, 2, 5, 3, generator=g) - 0.5) * 6.0).cuda()
+    tr = (torch.randn(3, 2, 5, 3, generator=g) * 20).cuda()
+    m, inv = em.pose_matrices(rot, tr)
+    ref_m = em.euler_to_matrix(rot, tr)
+    ref_inv = em.rigid_inverse(ref_m)
+    assert m.shape == ref_m.shape == (3, 2, 5, 4, 4)
+    assert float((m - ref_m).abs().max()) <= 1e-6 and float((inv - ref_inv).abs().max()) <= 2e-5     # |t| ~ 60: 1 ulp = 4e-6
+    eye = torch.eye(4, device="cuda").expand_as(m)
+    assert float((torch.matmul(m, inv) - eye).abs().max()) <= 2e-5
+    # tensors with a graph take the differentiable torch ops
+    rot_g = rot.clone().requires_grad_(True)
+    mg, _ = em.pose_matrices(rot_g, tr)
+    assert mg.requires_grad and torch.equal(mg.detach(), ref_m)
+
+
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_projection_kernel_matches_the_torch_path(world):
+    """pr_project_points (bounding boxes + box points, object axes: one launch each on the no-graph path) against the torch
+    ops of compute_object_bounding_boxes / compute_object_axes_projection, which check_against_reference.py pins against
+    the reference (model/environment_model.py:234-404) - including cameras that see an object partly behind them."""
+    cfg = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
+    model = em.EnvironmentModel(cfg).cuda().eval()
+    scene_fn = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+    sc = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in scene_fn(batch=2, observations=3, seed=13, image_size=(96, 128)).items()}
+    rot, tr = sc["object_rotation_parameters"], sc["object_translation_parameters"].clone()
+    tr[0, 0, :, -1] = sc["camera_translations"][0, 0, 0]          # one object around the camera: points on both sides of it
+    w2o, o2w = model.compute_transformation_matrix_w2o_o2w(rot, tr)
+    c2w, w2c = em.pose_matrices(sc["camera_rotations"], sc["camera_translations"])
+    focals = sc["focals"] * cfg["data"]["focal_length_multiplier"]
+    with torch.no_grad():
+        boxes, points = model.compute_object_bounding_boxes(o2w, w2c, focals, 96, 128)
+        axes = model.compute_object_axes_projection(o2w, w2c, focals, 96, 128)
+    o2w_g = o2w.clone().requires_grad_(True)                      # a graph: the torch ops
+    ref_boxes, ref_points = model.compute_object_bounding_boxes(o2w_g, w2c, focals, 96, 128)
+    ref_axes = model.compute_object_axes_projection(o2w_g, w2c, focals, 96, 128)
+    assert ref_boxes.requires_grad and not boxes.requires_grad
+    for got, want in ((boxes, ref_boxes), (points, ref_points)):
+        assert got.shape == want.shape and float((got - want.detach()).abs().max()) <= 1e-5
+    # (the unclamped axes of the object that sits ON the camera are a division by ~0: compared for the other objects)
+    close = torch.isclose(axes, ref_axes.detach(), rtol=1e-4, atol=1e-4)
+    assert axes.shape == ref_axes.shape and bool(close[..., :-1].all()) and bool(close[1:].all())
+    assert 0.0 < float(boxes.min()) or float(boxes.max()) <= 1.0
+
+
 def test_camera_rays_are_differentiable_for_learnable_cameras():
     """camera_rays with a graph (c2w / focals require gradients): the HIP kernel's values, and a backward pass equal to
     torch.autograd through the closed form d_cam = ((col - W/2)/f, -(row - H/2)/f, -1), d = R d_cam, o = t, normal = -R[:, 2]."""
@@ -1461,7 +1510,9 @@ def test_learnable_camera_offsets_receive_gradients_through_the_render():
         model.camera_parameters_offsets.eval()
         torch.manual_seed(5)
         plain = model(*args, samples_per_image=10, perturb=True, patch_size=8, patch_stride=[4, 8])
-    assert torch.equal(base["coarse"]["global"]["integrated_features"], out["coarse"]["global"]["integrated_features"].detach())
+    # (the render without a graph builds its pose matrices with pr_pose_matrices, the one with a graph with torch ops: ulps apart)
+    assert torch.allclose(base["coarse"]["global"]["integrated_features"], out["coarse"]["global"]["integrated_features"].detach(),
+                          rtol=1e-3, atol=1e-3)
     assert not torch.equal(base["coarse"]["global"]["integrated_features"], plain["coarse"]["global"]["integrated_features"])
 
 
