@@ -1448,6 +1448,38 @@ def test_projection_kernel_matches_the_torch_path(world):
     assert 0.0 < float(boxes.min()) or float(boxes.max()) <= 1.0
 
 
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_two_cameras_equal_two_single_camera_renders(world):
+    """cameras_count > 1 (the reference's (..., observations, cameras, ...) layout: one scene, several cameras; the object
+    tensors carry no camera dimension): every field of camera c equals the single-camera render with that camera, bit for bit -
+    renderer outputs and the projected boxes / box points / axes alike."""
+    cfg = configs.reduced_config(configs.tennis_config() if world == "tennis" else configs.minecraft_config(), **SMALL_NETS)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.0, bender_scale=1e4)
+    model.eval().cuda()
+    fn = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+    size = (64, 96)
+    a = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in fn(batch=2, observations=2, seed=3, image_size=size).items()}
+    b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in fn(batch=2, observations=2, seed=4, image_size=size).items()}
+
+    def run(rotations, translations, focals):
+        with torch.no_grad():
+            return model(rotations, translations, focals, size, a["object_rotation_parameters"], a["object_translation_parameters"],
+                         a["object_style"], a["object_deformation"], a["object_in_scene"], 0, False, patch_stride=[4, 8],
+                         mode="scene_encodings")
+    cams = [(s["camera_rotations"], s["camera_translations"], s["focals"]) for s in (a, b)]
+    both = run(*[torch.cat([cams[0][i], cams[1][i]], dim=2) for i in range(3)])
+    assert both["coarse"]["global"]["integrated_features"].shape[:3] == (2, 2, 2)
+    for c in range(2):
+        one = run(*cams[c])
+        for name in [f"object_{k}" for k in range(4)] + ["global"]:
+            for key in ("integrated_features", "opacity", "depth", "weights"):
+                assert torch.equal(torch.nan_to_num(both["coarse"][name][key][:, :, c:c + 1]), torch.nan_to_num(one["coarse"][name][key])), (c, name, key)
+        for key in ("reconstructed_bounding_boxes", "reconstructed_3d_bounding_boxes", "projected_axes"):
+            assert torch.equal(both[key][:, :, c:c + 1], one[key]), (c, key)
+
+
 def test_camera_rays_are_differentiable_for_learnable_cameras():
     """camera_rays with a graph (c2w / focals require gradients): the HIP kernel's values, and a backward pass equal to
     torch.autograd through the closed form d_cam = ((col - W/2)/f, -(row - H/2)/f, -1), d = R d_cam, o = t, normal = -R[:, 2]."""
