@@ -345,6 +345,9 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, 
  */
 int pr_pose_matrices(int32_t count, const float* rotations, const float* translations, float* matrices, float* inverses,
                      void* stream);
+/* Its backward pass: g_matrices / g_inverses (count,4,4) or NULL -> g_rotations, g_translations (count,3), written. */
+int pr_pose_matrices_backward(int32_t count, const float* rotations, const float* translations, const float* g_matrices,
+                              const float* g_inverses, float* g_rotations, float* g_translations, void* stream);
 
 /*
  * Projects object-frame points into the cameras of their frame (EnvironmentModel.compute_object_bounding_boxes /

@@ -644,6 +644,69 @@ extern "C" int pr_project_points(int32_t frames, int32_t cameras, int32_t object
     return PR_OK;
 }
 
+namespace pr {
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* out) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+__device__ __forceinline__ float mat3_dot(const float* a, const float* b) {
+    float acc = 0.f;
+    for (int i = 0; i < 9; ++i) acc = fmaf(a[i], b[i], acc);
+    return acc;
+}
+
+// Backward of k_pose_matrices: M = [R t; 0 1], M^-1 = [R^T u; 0 1] with u = -R^T t, R = Ry (Rx Rz).
+//   d loss / d R[k][a] = gM[k][a] + gInv[a][k] - t[k] gu[a],  d loss / d t = gM[:, 3] - R gu,
+//   d loss / d angle = <d loss / d R, d R / d angle>  with d R / d x = Ry (Rx' Rz), d R / d y = Ry' (Rx Rz), d R / d z = Ry (Rx Rz').
+__global__ void k_pose_matrices_bwd(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
+                                    const float* __restrict__ g_matrices, const float* __restrict__ g_inverses,
+                                    float* __restrict__ g_rotations, float* __restrict__ g_translations) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float ax = rotations[i * 3 + 0], ay = rotations[i * 3 + 1], az = rotations[i * 3 + 2];
+    const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
+    const float rx[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
+    const float ry[9] = {cy, 0.f, sy, 0.f, 1.f, 0.f, -sy, 0.f, cy};
+    const float rz[9] = {cz, -sz, 0.f, sz, cz, 0.f, 0.f, 0.f, 1.f};
+    const float dx[9] = {0.f, 0.f, 0.f, 0.f, -sx, -cx, 0.f, cx, -sx};
+    const float dy[9] = {-sy, 0.f, cy, 0.f, 0.f, 0.f, -cy, 0.f, -sy};
+    const float dz[9] = {-sz, -cz, 0.f, cz, -sz, 0.f, 0.f, 0.f, 0.f};
+    float xz[9], r[9], tmp[9], d[9];
+    mat3_mul(rx, rz, xz);
+    mat3_mul(ry, xz, r);
+    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
+    const float* gm = g_matrices ? g_matrices + (size_t)i * 16 : nullptr;
+    const float* gv = g_inverses ? g_inverses + (size_t)i * 16 : nullptr;
+    float gu[3] = {0.f, 0.f, 0.f}, gr[9], gt[3];
+    if (gv)
+        for (int a = 0; a < 3; ++a) gu[a] = gv[a * 4 + 3];
+    for (int k = 0; k < 3; ++k) {
+        for (int a = 0; a < 3; ++a) gr[k * 3 + a] = (gm ? gm[k * 4 + a] : 0.f) + (gv ? gv[a * 4 + k] : 0.f) - t[k] * gu[a];
+        gt[k] = (gm ? gm[k * 4 + 3] : 0.f) - (r[k * 3] * gu[0] + r[k * 3 + 1] * gu[1] + r[k * 3 + 2] * gu[2]);
+    }
+    mat3_mul(dx, rz, tmp);
+    mat3_mul(ry, tmp, d);
+    g_rotations[i * 3 + 0] = mat3_dot(gr, d);
+    mat3_mul(dy, xz, d);
+    g_rotations[i * 3 + 1] = mat3_dot(gr, d);
+    mat3_mul(rx, dz, tmp);
+    mat3_mul(ry, tmp, d);
+    g_rotations[i * 3 + 2] = mat3_dot(gr, d);
+    for (int k = 0; k < 3; ++k) g_translations[i * 3 + k] = gt[k];
+}
+}  // namespace pr
+
+extern "C" int pr_pose_matrices_backward(int32_t count, const float* rotations, const float* translations, const float* g_matrices,
+                                         const float* g_inverses, float* g_rotations, float* g_translations, void* stream) {
+    PR_REQUIRE(count >= 0, "pr_pose_matrices_backward: bad count %d", count);
+    if (count == 0) return PR_OK;
+    PR_REQUIRE(rotations && translations && g_rotations && g_translations, "pr_pose_matrices_backward: NULL pointer");
+    hipLaunchKernelGGL(pr::k_pose_matrices_bwd, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, count, rotations,
+                       translations, g_matrices, g_inverses, g_rotations, g_translations);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 extern "C" int pr_pose_matrices(int32_t count, const float* rotations, const float* translations, float* matrices,
                                 float* inverses, void* stream) {
     PR_REQUIRE(count >= 0, "pr_pose_matrices: bad count %d", count);

@@ -50,20 +50,57 @@ def euler_to_matrix(rotations: torch.Tensor, translations: torch.Tensor) -> torc
     return out
 
 
+def _pose_matrices_kernel(rotations: torch.Tensor, translations: torch.Tensor):
+    lead = list(rotations.shape[:-1])
+    n = int(math.prod(lead)) if lead else 1
+    rot = rotations.detach().to(torch.float32).reshape(n, 3).contiguous()
+    tr = torch.broadcast_to(translations.detach().to(torch.float32), rotations.shape).reshape(n, 3).contiguous()
+    out = torch.empty((2, n, 4, 4), dtype=torch.float32, device=rotations.device)
+    with torch.cuda.device(rotations.device):
+        _lib.check(_lib.load().pr_pose_matrices(n, rot.data_ptr(), tr.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                torch.cuda.current_stream(rotations.device).cuda_stream), "pr_pose_matrices")
+    return out[0].reshape(lead + [4, 4]), out[1].reshape(lead + [4, 4]), rot, tr
+
+
+class _PoseMatrices(torch.autograd.Function):
+    """pr_pose_matrices with pr_pose_matrices_backward: poses that carry a graph (object poses from trainable encoders,
+    learnable camera offsets) - as torch ops the conversion and its backward are ~150 launches of a few microseconds."""
+
+    @staticmethod
+    def forward(ctx, rotations, translations):
+        m, inv, rot, tr = _pose_matrices_kernel(rotations, translations)
+        ctx.save_for_backward(rot, tr)
+        ctx.shapes = (rotations.shape, translations.shape, rotations.dtype, translations.dtype)
+        return m, inv
+
+    @staticmethod
+    def backward(ctx, g_m, g_inv):
+        rot, tr = ctx.saved_tensors
+        n = rot.size(0)
+        g_rot, g_tr = torch.empty_like(rot), torch.empty_like(tr)
+        gm = g_m.to(torch.float32).reshape(n, 4, 4).contiguous() if g_m is not None else None
+        gi = g_inv.to(torch.float32).reshape(n, 4, 4).contiguous() if g_inv is not None else None
+        with torch.cuda.device(rot.device):
+            _lib.check(_lib.load().pr_pose_matrices_backward(n, rot.data_ptr(), tr.data_ptr(), gm.data_ptr() if gm is not None else None,
+                                                             gi.data_ptr() if gi is not None else None, g_rot.data_ptr(), g_tr.data_ptr(),
+                                                             torch.cuda.current_stream(rot.device).cuda_stream),
+                       "pr_pose_matrices_backward")
+        rot_shape, tr_shape, rot_dtype, tr_dtype = ctx.shapes
+        g_rot = g_rot.reshape(rot_shape).to(rot_dtype)
+        g_tr = g_tr.reshape(rot_shape)
+        if tuple(tr_shape) != tuple(rot_shape):                  # translations were broadcast against the rotations
+            g_tr = g_tr.sum_to_size(tr_shape)
+        return g_rot, g_tr.to(tr_dtype)
+
+
 def pose_matrices(rotations: torch.Tensor, translations: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``euler_to_matrix`` and ``rigid_inverse`` of the result, (..., 4, 4) each.  Device tensors without a graph take ONE
-    kernel (``pr_pose_matrices``) instead of ~30 torch launches; tensors that carry a graph (learnable poses, camera offsets)
-    and CPU tensors take the differentiable torch ops."""
-    if rotations.is_cuda and not (torch.is_grad_enabled() and (rotations.requires_grad or translations.requires_grad)):
-        lead = list(rotations.shape[:-1])
-        n = int(math.prod(lead)) if lead else 1
-        rot = rotations.detach().to(torch.float32).reshape(n, 3).contiguous()
-        tr = torch.broadcast_to(translations.detach().to(torch.float32), rotations.shape).reshape(n, 3).contiguous()
-        out = torch.empty((2, n, 4, 4), dtype=torch.float32, device=rotations.device)
-        with torch.cuda.device(rotations.device):
-            _lib.check(_lib.load().pr_pose_matrices(n, rot.data_ptr(), tr.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                                    torch.cuda.current_stream(rotations.device).cuda_stream), "pr_pose_matrices")
-        return out[0].reshape(lead + [4, 4]), out[1].reshape(lead + [4, 4])
+    """``euler_to_matrix`` and ``rigid_inverse`` of the result, (..., 4, 4) each.  Device tensors take ONE kernel
+    (``pr_pose_matrices``; with a graph: an autograd node whose backward is one kernel too) instead of ~30 torch launches;
+    CPU tensors take the torch ops (which ``check_against_reference.py`` pins against the reference)."""
+    if rotations.is_cuda:
+        if torch.is_grad_enabled() and (rotations.requires_grad or translations.requires_grad):
+            return _PoseMatrices.apply(rotations, translations)
+        return _pose_matrices_kernel(rotations, translations)[:2]
     m = euler_to_matrix(rotations, translations)
     return m, rigid_inverse(m)
 

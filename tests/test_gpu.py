@@ -1413,10 +1413,19 @@ def test_pose_matrices_kernel_matches_the_torch_path():
     assert float((m - ref_m).abs().max()) <= 1e-6 and float((inv - ref_inv).abs().max()) <= 2e-5     # |t| ~ 60: 1 ulp = 4e-6
     eye = torch.eye(4, device="cuda").expand_as(m)
     assert float((torch.matmul(m, inv) - eye).abs().max()) <= 2e-5
-    # tensors with a graph take the differentiable torch ops
-    rot_g = rot.clone().requires_grad_(True)
-    mg, _ = em.pose_matrices(rot_g, tr)
-    assert mg.requires_grad and torch.equal(mg.detach(), ref_m)
+    # with a graph: the same kernel as an autograd node, its backward (pr_pose_matrices_backward) against torch.autograd
+    # through euler_to_matrix / rigid_inverse; a translation broadcast over a leading dimension gets the summed gradient
+    probes = [torch.randn(m.shape, generator=g).cuda() for _ in range(2)]
+    tr_b = tr[:1].clone()
+    grads = []
+    for fn in (em.pose_matrices, lambda r, t: (lambda mm: (mm, em.rigid_inverse(mm)))(em.euler_to_matrix(r, torch.broadcast_to(t, r.shape)))):
+        rot_g, tr_g = rot.clone().requires_grad_(True), tr_b.clone().requires_grad_(True)
+        mg, ig = fn(rot_g, tr_g)
+        assert mg.requires_grad and mg.shape == ref_m.shape
+        ((mg * probes[0]).sum() + (ig * probes[1]).sum()).backward()
+        grads.append((rot_g.grad.clone(), tr_g.grad.clone()))
+    for a, b in zip(grads[0], grads[1]):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
 
 
 @pytest.mark.parametrize("world", ["tennis", "minecraft"])
