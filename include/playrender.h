@@ -76,6 +76,10 @@ typedef enum pr_status {
                                        model/object_composer.py:553,597,751).  pr_noise_fill writes the same values to a
                                        tensor (tests replay them through the explicit path and the oracle). */
 
+#define PR_FLAG_SIGMOID_FEATURES 512u /* config["model"]["apply_activation"]: the raw features of every sample go through a sigmoid before
+                                        they are composited (object_composer.py:548-549, :573-574; RGB-output models).  Applied
+                                        where the compositing kernel reads a feature row; samples without a row (outside the box:
+                                        raw feature 0) composite sigmoid(0) = 0.5 wherever their weight is not zero. */
 #define PR_FLAG_DIVERGENCE_GRAD 256u /* pr_backward_workspace_size / pr_render_backward: gradients of integrated_divergence are
                                        given (pr_entry_grads_t.integrated_divergence); the backward pass then differentiates the
                                        Hutchinson estimate e^T (d delta / dx) e through the ray bender (the reference's double

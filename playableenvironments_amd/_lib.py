@@ -22,6 +22,7 @@ PR_FLAG_SAVE_FOR_BACKWARD = 32
 PR_FLAG_GATE_HEAD = 64
 PR_FLAG_DEVICE_NOISE = 128
 PR_FLAG_DIVERGENCE_GRAD = 256
+PR_FLAG_SIGMOID_FEATURES = 512
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
 PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect

@@ -46,6 +46,8 @@ struct CompositeBwdParams {
     int total_positions;
     int sort_size;
     int div_grad;            // gradients of integrated_divergence are given: one more per-entry LDS column
+    int sigmoid;             // PR_FLAG_SIGMOID_FEATURES: the composited features are sigmoid(row); samples without a row carry 0.5
+    int Fs;                  // floats between the rows of g_feat (F rounded up to 16: the head products walk K in 16-deep slabs)
     const float* ray_directions;
     NoiseRef noise_global;
     CompositeBwdObject obj[PR_MAX_OBJECTS];
@@ -125,18 +127,22 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         const int e = entry_of(j);
         const int row = sm.sl[e];
         float dot = 0.f;
-        if (has_gf && row >= 0 && sm.Tj[j] != 0.f) {
+        if (has_gf && (row >= 0 || p.sigmoid) && sm.Tj[j] != 0.f) {
             int k = 0, o2 = 0;
             while (k + 1 < p.objects && e >= o2 + p.obj[k].positions) {
                 o2 += p.obj[k].positions;
                 ++k;
             }
-            const float* f = p.obj[k].feat + (size_t)row * F;
+            const float* f = row >= 0 ? p.obj[k].feat + (size_t)row * F : nullptr;
             float part = 0.f;
 #pragma unroll
             for (int c = 0; c < MAX_FCHUNK_B; ++c) {
                 const int ch = lane + 64 * c;
-                if (ch < F) part = fmaf(gF[c], f[ch], part);
+                if (ch < F) {
+                    float v = f ? f[ch] : 0.f;                           // (a sample without a row: raw feature 0)
+                    if (p.sigmoid) v = 1.0f / (1.0f + expf(-v));
+                    part = fmaf(gF[c], v, part);
+                }
             }
             dot = wave_sum(part);
         }
@@ -328,11 +334,21 @@ __global__ __launch_bounds__(64) void k_composite_bwd(CompositeBwdParams p) {
             const int row = sm.sl[off + i];
             if (row < 0) continue;
             const float w1 = sm.wo[off + i], w2 = sm.wg[off + i];
-            float* dst = o.g_feat + (size_t)row * F;
+            float* dst = o.g_feat + (size_t)row * p.Fs;
+            const float* f = o.feat + (size_t)row * F;
 #pragma unroll
             for (int c = 0; c < MAX_FCHUNK_B; ++c) {
                 const int ch = lane + 64 * c;
-                if (ch < F) dst[ch] = fmaf(w1, gFo[c], w2 * gFg[c]);
+                if (ch < F) {
+                    float gv = fmaf(w1, gFo[c], w2 * gFg[c]);
+                    if (p.sigmoid) {                                     // d sigmoid(x) / dx = s (1 - s)
+                        const float sv = 1.0f / (1.0f + expf(-f[ch]));
+                        gv *= sv * (1.0f - sv);
+                    }
+                    dst[ch] = gv;
+                } else if (ch < p.Fs) {
+                    dst[ch] = 0.f;                                       // padding columns of the head products
+                }
             }
         }
         off += P;
@@ -367,7 +383,7 @@ struct RowCtx {
 
 // gathers the dense sigma / |delta| gradients to rows and clears the feature gradients of unused rows
 __global__ __launch_bounds__(256) void k_gather_rows(RowCtx r, const float* g_sigma, const float* g_dm, float* gsr, float* gdr,
-                                                     float* g_feat, int F) {
+                                                     float* g_feat, int F) {   // F: floats per row of g_feat (padded)
     const int M = *r.total;
     for (int m = blockIdx.x; m < M; m += gridDim.x) {
         const int fl = r.row_flags[m];
@@ -969,7 +985,7 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
         const pr_object_model_t& m = c.use_fine ? objs[k].fine : objs[k].coarse;   // the fine pass has more positions
         const size_t cap = nr * m.positions;
         if (cap > max_cap) max_cap = cap;
-        bp->g_feat[k] = take(sizeof(float) * cap * m.output_features);
+        bp->g_feat[k] = take(sizeof(float) * cap * ((m.output_features + 15) & ~15));
         bp->g_sigma[k] = take(sizeof(float) * cap);
         bp->g_t[k] = take(sizeof(float) * cap);
         bp->g_dm[k] = take(sizeof(float) * cap);
@@ -1174,7 +1190,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
     int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
     const int F = objs[0].coarse.output_features;
-    PR_REQUIRE(F % 16 == 0, "backward: output_features %d must be a multiple of 16", F);
+    const int Fs = (F + 15) & ~15;     // row stride of the feature gradients
 
     // gradients of integrated_divergence flow only where the forward pass estimated a divergence: differentiable calls in
     // training mode (render.hip), objects with a ray bender, probes explicit or generated
@@ -1189,6 +1205,8 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     CompositeBwdParams cp;
     memset(&cp, 0, sizeof(cp));
     cp.div_grad = div_grad ? 1 : 0;
+    cp.sigmoid = (c.flags & PR_FLAG_SIGMOID_FEATURES) ? 1 : 0;
+    cp.Fs = Fs;
     cp.frames = c.frames; cp.rays = c.rays; cp.objects = K; cp.static_objects = c.static_objects; cp.F = F;
     cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
     int total_positions = 0;
@@ -1282,15 +1300,15 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         bbox_split(m, lo, hi, size);
 
         hipLaunchKernelGGL(k_gather_rows, dim3(grid_rows), dim3(256), 0, s, rc, g_sigma, g_dm, gsr, m.has_bender ? gdr : nullptr,
-                           g_feat, F);
+                           g_feat, Fs);
         PR_LAUNCH_CHECK();
 
         // ---- feature head, layer 6 -------------------------------------------------------------
         hipLaunchKernelGGL(k_adain_recompute, dim3(grid_rows), dim3(256), 0, s, rc, h2, d.W2pad, d.W2pad, table, table_stride,
                            2 * d.Wpad, 2 * d.Wpad + d.W2pad, actb);
         PR_LAUNCH_CHECK();
-        PR_TRY(weight_grad(gc, g_feat, F, F, actb, d.W2pad, d.W2, G.head6.weight, d.W2, G.head6.bias));
-        PR_TRY(input_grad(gc, g_feat, F, F, m.head6.weight, d.W2, d.W2, bufB, d.W2pad, false, nullptr, 0));
+        PR_TRY(weight_grad(gc, g_feat, Fs, F, actb, d.W2pad, d.W2, G.head6.weight, d.W2, G.head6.bias));
+        PR_TRY(input_grad(gc, g_feat, Fs, F, m.head6.weight, d.W2, d.W2, bufB, d.W2pad, false, nullptr, 0));
         // ---- AdaIN + BatchNorm (batch statistics) 4 -----------------------------------------------
         float* dscale1 = tables;
         float* dbias1 = tables + (size_t)c.frames * MAX_WIDTH;

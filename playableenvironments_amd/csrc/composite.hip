@@ -57,6 +57,8 @@ __device__ __forceinline__ void transmittance_weights(float* al, int n, int lane
 // weights[j] = alpha[j] * prod_{i<j} (...) over al[0..n) by CW waves: wave w scans the contiguous segment
 // [w * seg, (w + 1) * seg) (seg a multiple of 64) from a unit carry, the segment products are exchanged through
 // `totals` and folded in afterwards.
+__device__ __forceinline__ float sigmoid_of(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 template <int CW>
 __device__ __forceinline__ void transmittance_weights_block(float* al, int n, float* totals, int wave, int lane) {
     if (CW == 1) {
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
         const int end = (begin + part < P) ? begin + part : P;
         __syncthreads();
         int count = 0;
+        float bare1 = 0.f, bare2 = 0.f;   // PR_FLAG_SIGMOID_FEATURES: weights of the samples without a feature row (raw feature 0)
         for (int base = begin; base < end; base += 64) {
             const int i = base + lane;
             bool take = false;
@@ -333,6 +336,10 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
                 w1 = sm.wo[off + i];
                 w2 = sm.wg[off + i];
                 take = row >= 0 && (w1 != 0.f || w2 != 0.f);
+                if (p.sigmoid && row < 0) {
+                    bare1 += w1;
+                    bare2 += w2;
+                }
             }
             const unsigned long long m = __ballot(take);
             if (take) {
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
                 for (int c = 0; c < MAX_FCHUNK; ++c) {
                     const int ch = lane + 64 * c;
                     v[u][c] = (ch < F) ? f[ch] : 0.f;
+                    if (p.sigmoid) v[u][c] = sigmoid_of(v[u][c]);
                 }
             }
 #pragma unroll
@@ -381,9 +389,19 @@ __global__ __launch_bounds__(64 * CW) void k_composite(CompositeParams p) {
 #pragma unroll
             for (int c = 0; c < MAX_FCHUNK; ++c) {
                 const int ch = lane + 64 * c;
-                const float v = (ch < F) ? f[ch] : 0.f;
+                float v = (ch < F) ? f[ch] : 0.f;
+                if (p.sigmoid) v = sigmoid_of(v);
                 acco[c] = __fadd_rn(acco[c], __fmul_rn(w1, v));
                 accg[c] = __fadd_rn(accg[c], __fmul_rn(w2, v));
+            }
+        }
+        if (p.sigmoid) {      // sigmoid(0) = 0.5 for the samples that have no row; every lane owns channels, so all of them add
+            bare1 = wave_sum(bare1);
+            bare2 = wave_sum(bare2);
+#pragma unroll
+            for (int c = 0; c < MAX_FCHUNK; ++c) {
+                acco[c] = __fadd_rn(acco[c], 0.5f * bare1);
+                accg[c] = __fadd_rn(accg[c], 0.5f * bare2);
             }
         }
         if (o.out.integrated_features) {

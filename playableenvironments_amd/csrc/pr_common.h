@@ -369,6 +369,7 @@ struct CompositeParams {
     int frames, rays, objects, static_objects, F;
     int fix_overlaps;
     int any_divergence;          // some object carries a divergence estimate (differentiable training calls)
+    int sigmoid;                 // PR_FLAG_SIGMOID_FEATURES
     int total_positions;         // sum P_k
     int sort_size;               // next pow2 >= total_positions
     const float* ray_directions; // (N,R,3) world

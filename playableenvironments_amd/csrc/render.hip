@@ -496,6 +496,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         cp.frames = c.frames; cp.rays = c.rays; cp.objects = K; cp.static_objects = c.static_objects;
         cp.F = objs[0].coarse.output_features;
         cp.fix_overlaps = (c.flags & PR_FLAG_FIX_OVERLAPS) ? 1 : 0;
+        cp.sigmoid = (c.flags & PR_FLAG_SIGMOID_FEATURES) ? 1 : 0;
         cp.total_positions = total_positions;
         int ss = 64;
         while (ss < total_positions) ss <<= 1;

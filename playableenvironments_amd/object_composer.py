@@ -262,9 +262,6 @@ class ObjectComposer(nn.Module):
         if self.object_models_coarse[0].model_config["nerf_model"]["output_features"] != 3 and self.apply_activation:
             raise Exception("The application of activations to the nerf output is requested, but the model seem not "
                             "to output colors directly. Please make sure this is the behavior you desire")
-        if self.apply_activation:
-            raise NotImplementedError("apply_activation=True (sigmoid on raw features) is not implemented in the HIP "
-                                      "renderer; both shipped configurations use False")
         self.object_id_helper = ObjectIDsHelper(self.config)
         #: bumped by set_step / load_state_dict / .to(): captured frame graphs compare it (frame_graph.FrameGraph)
         self.state_epoch = 0
@@ -629,6 +626,8 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_CANONICAL_POSE
         if self.config["model"]["fix_object_overlaps"] and _object_ids is None:
             flags |= _lib.PR_FLAG_FIX_OVERLAPS
+        if self.apply_activation:
+            flags |= _lib.PR_FLAG_SIGMOID_FEATURES
         if self.use_naive_mlp:
             flags |= _lib.PR_FLAG_NAIVE_MLP
         if self.training:

@@ -545,6 +545,45 @@ def test_backward_to_the_camera_rays(name, perturb):
     assert float(grads["ray_origins"][0].abs().max()) > 0 and float(grads["ray_directions"][0].abs().max()) > 0
 
 
+def _rgb_config(world):
+    """Models that output colours directly: 3 features, apply_activation (sigmoid on the raw features of EVERY sample before
+    compositing, object_composer.py:548-549).  An empty-space density close to 0 lets the perturbation noise lift samples
+    outside the boxes: they composite sigmoid(0) = 0.5."""
+    base = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
+    cfg = configs.reduced_config(base, width=64, layers=4, skip=2, features=3, octaves=4, bender_width=32, bender_layers=3,
+                                 bender_skip=1, bender_octaves=3)
+    cfg["model"]["apply_activation"] = True
+    for o in cfg["model"]["object_models"]:
+        o["empty_space_alpha"] = -0.5
+    return cfg
+
+
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_rgb_models_with_sigmoid_features(world):
+    """config["model"]["apply_activation"] = True (the reference allows it for output_features == 3 only): forward fields of
+    both kernels against the oracle, evaluation and perturbed, and every gradient of a training call (sigmoid derivative in
+    the compositing backward, 3-wide feature rows in the head products) against oracle autograd."""
+    cfg = _rgb_config(world)
+    scene = (synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene)(seed=3)
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 20))
+    for precision in ("fp32", "f16x3"):
+        for perturb in (False, True):
+            want, got = run_both(cfg, build(cfg, precision=precision), inputs, perturb=perturb)
+            assert_close(want, got)
+            feats = want["coarse"]["global"]["integrated_features"]
+            assert feats.shape[-1] == 3 and 0.0 < float(feats.max()) <= 1.0 + 1e-6
+    for perturb in (False, True):
+        grads = _gradients(cfg, scene, 16, 2.0 if world == "tennis" else 3.0, perturb, rays=True)
+        bad = {}
+        for k, (a, b) in grads.items():
+            scale = max(float(a.abs().max()), float(grads["ray_directions"][0].abs().max()) if k == "ray_origins" else 0.0)
+            err = float((a - b).abs().max())
+            if not (err <= 2e-4 * scale + 1e-9):
+                bad[k] = (err, scale)
+        assert not bad, bad
+        assert float(grads["object_models_coarse.0.nerf_model.features_head.6.weight"][0].abs().max()) > 0
+
+
 def test_backward_with_padded_widths_on_poisoned_scratch():
     """Widths that are not multiples of 32 (backbone 48 -> padded 64 with a 24-wide second head layer, ray bender 16 -> padded
     32): the padding columns of the backward scratch are written by nobody, and 0 x garbage must stay 0.  The allocator is
