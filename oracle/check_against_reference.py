@@ -884,6 +884,16 @@ def main():
                    perturb=True, training=True, alpha_bias=3.0)[1]
     ok &= run_case("tennis hierarchical TRAIN perturb", th, synthetic.tennis_scene(seed=15),
                    pixels=grid_pixels(256, 256, 16), perturb=True, training=True, alpha_bias=2.0)[1]
+    # models that output colours: 3 features + apply_activation (sigmoid on the raw features of every sample)
+    rgb = dict(width=64, layers=4, skip=2, features=3, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    for label, base_cfg, scene_fn in (("tennis", t, synthetic.tennis_scene), ("minecraft", m, synthetic.minecraft_scene)):
+        rc = configs.reduced_config(base_cfg, **rgb)
+        rc["model"]["apply_activation"] = True
+        for o in rc["model"]["object_models"]:
+            o["empty_space_alpha"] = -0.5
+        ok &= run_case(f"{label} RGB + sigmoid eval", rc, scene_fn(seed=3), pixels=grid_pixels(256, 256, 16), alpha_bias=2.0)[1]
+        ok &= run_case(f"{label} RGB + sigmoid TRAIN perturb", rc, scene_fn(seed=3), pixels=grid_pixels(256, 256, 16), perturb=True,
+                       training=True, alpha_bias=2.0)[1]
     small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1,
                  bender_octaves=3)
     ok &= run_gradient_case("tennis reduced TRAIN gradients", configs.reduced_config(t, **small), synthetic.tennis_scene(),

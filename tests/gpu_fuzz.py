@@ -39,7 +39,14 @@ def random_case(rng):
         # library's argument check) needs static counts <= dynamic counts
         dynamic = min(pc for name, (pc, _) in positions.items() if name.startswith("player"))
         positions = {name: ((min(pc, dynamic), pf) if not name.startswith("player") else (pc, pf)) for name, (pc, pf) in positions.items()}
+    rgb = rng.random() < 0.15          # colour-output models: 3 features through a sigmoid (apply_activation)
+    if rgb:
+        shape["features"] = 3
     cfg = configs.reduced_config(configs.enable_fine(base) if hierarchical else base, positions=positions, **shape)
+    if rgb:
+        cfg["model"]["apply_activation"] = True
+        for o in cfg["model"]["object_models"]:
+            o["empty_space_alpha"] = rng.choice([-3.5, -0.5])
     frames = rng.choice([(1, 1), (1, 2), (2, 1), (3, 1)])
     scene_fn = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
     scene = scene_fn(batch=frames[0], observations=frames[1], seed=rng.randint(0, 10 ** 6))
