@@ -565,6 +565,32 @@ def check_observation_modes():
                 bad = {k: v[0] for k, v in rep.items() if not v[1]}
                 print(f"[observations mode, {world}, {label}] fields={len(rep)} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}")
                 ok &= not bad
+            # optional image decoder (config["model"]["image_decoder"]): stand-in sampler / decoder injected on both sides
+            class _Sampler(torch.nn.Module):
+                def forward(self, feats, positions):
+                    return torch.cat([feats, positions], dim=-1).mean(dim=-2)
+
+            class _Decoder(torch.nn.Module):
+                def forward(self, grid):
+                    return (grid * 2.0).unsqueeze(-1).unsqueeze(-1).expand(list(grid.shape) + [2, 3])
+            for model in (ref, mine):
+                model.use_image_decoder = True
+                model.image_decoder, model.grid_sampler = _Decoder(), _Sampler()
+            se0 = want["scene_encoding"]
+            for label, call in (("observations + image decoder", lambda m: m(*[a.clone() for a in args], samples_per_image=0, perturb=False, patch_stride=[4, 8])),
+                                ("scene encodings + image decoder", lambda m: m(se0["camera_rotations"], se0["camera_translations"], se0["focals"], (48, 64),
+                                                                                se0["object_rotation_parameters"], se0["object_translation_parameters"],
+                                                                                se0["object_style"], se0["object_deformation"], se0["object_in_scene"],
+                                                                                0, False, patch_stride=[4, 8], mode="scene_encodings"))):
+                with torch.no_grad():
+                    a, b = call(ref), call(mine)
+                rep = _compare_nested(a, b)
+                bad = {k: v[0] for k, v in rep.items() if not v[1]}
+                has = "decoded_images" in b["coarse"]["global"] and "decoded_images" in a["coarse"]["global"]
+                print(f"[{label}, {world}] fields={len(rep)} decoded_images present={has} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}")
+                ok &= not bad and has
+            for model in (ref, mine):
+                model.use_image_decoder = False
             # consistency forwards on the scene encoding the observation mode produced
             se = want["scene_encoding"]
             flow = (torch.rand(list(batch["observations"].shape[:-3]) + [2, 48, 64]) - 0.5) * 0.05

@@ -235,7 +235,7 @@ def camera_rays_at_positions(c2w: torch.Tensor, focals: torch.Tensor, height: in
 
 class EnvironmentModel(nn.Module):
 
-    def __init__(self, config, object_encoders=None, object_parameters_encoders=None):
+    def __init__(self, config, object_encoders=None, object_parameters_encoders=None, image_decoder=None, grid_sampler=None):
         super().__init__()
         self.config = config
         self.focal_length_multiplier = config["data"]["focal_length_multiplier"]
@@ -247,7 +247,11 @@ class EnvironmentModel(nn.Module):
         self.training_cameras_count = len(cameras)
         self.camera_parameters_offsets = CameraParametersStorage(config["model"].get("camera_parameters_memory_size", 1),
                                                                  self.training_cameras_count)
+        # config["model"]["image_decoder"] / ["grid_sampler"] (environment_model.py:53-56, 125-149): CNNs outside the renderer's
+        # path; like the encoders they are injected (stock PyTorch modules with the reference's call contracts)
         self.use_image_decoder = "image_decoder" in config["model"]
+        self.image_decoder = image_decoder
+        self.grid_sampler = grid_sampler
         self.object_composer = ObjectComposer(config)
         self.object_id_helper = ObjectIDsHelper(config)
         # the reference's attribute names (environment_model.py:44-50); empty until encoders are injected
@@ -287,6 +291,28 @@ class EnvironmentModel(nn.Module):
         if object_parameters_encoders is not None:
             self.object_parameters_encoders = nn.ModuleList(list(object_parameters_encoders))
         return self
+
+    def set_image_decoder(self, image_decoder, grid_sampler):
+        """``grid_sampler(integrated_features (..., R, F), sampled_positions (..., R, 2)) -> grid`` and
+        ``image_decoder(grid) -> (..., output features, height, width)`` (environment_model.py:733-741)."""
+        self.image_decoder, self.grid_sampler = image_decoder, grid_sampler
+        return self
+
+    def compute_decoded_image(self, composition_results: Dict, sampled_positions: torch.Tensor):
+        """Decodes the composited coarse features into an image, stored as ``coarse.global.decoded_images``
+        (model/environment_model.py:708-741; same exceptions)."""
+        if not self.use_image_decoder:
+            raise Exception("Image decoding was requested, but the use of the image decoder was not configured")
+        if "fine" in composition_results:
+            raise Exception("Image decoding is being used only on the coarse features, but fine features are being computed anyway. "
+                            "Please disable the fine nerf models.")
+        if self.image_decoder is None or self.grid_sampler is None:
+            raise RuntimeError("config['model']['image_decoder'] is set: inject the decoder CNN and the grid sampler with "
+                               "EnvironmentModel(config, ..., image_decoder=..., grid_sampler=...) or set_image_decoder(...) "
+                               "(they are not part of this package)")
+        integrated_features = composition_results["coarse"]["global"]["integrated_features"]
+        sampled_grid = self.grid_sampler(integrated_features, sampled_positions)
+        composition_results["coarse"]["global"]["decoded_images"] = self.image_decoder(sampled_grid)
 
     def _require_encoders(self):
         want = self.object_id_helper.object_models_count
@@ -580,6 +606,11 @@ class EnvironmentModel(nn.Module):
                                                 object_deformation.unsqueeze(-3), object_in_scene.unsqueeze(-2),
                                                 perturb, samples_per_image_batching, canonical_pose=canonical_pose,
                                                 _decoder_layout=layout)
+        if self.use_image_decoder:
+            flat = rows.to(torch.int64) * width + cols.to(torch.int64)
+            flat = flat.to(origins.device)
+            flat = flat if flat.dim() > 1 else flat.expand(lead + [flat.numel()])
+            self.compute_decoded_image(results, ray_sampling.positions_from_indices(flat, height, width))
         results["object_rotation_parameters"] = object_rotation_parameters_o2w
         results["object_translation_parameters"] = object_translation_parameters_o2w
         results["reconstructed_bounding_boxes"] = boxes
@@ -733,12 +764,9 @@ class EnvironmentModel(nn.Module):
         What the trainers call (training/trainer.py).  Poses, style and deformation come from the injected encoders; the
         span between them and the result dictionary - camera rays, box projection, pixel selection with the ground-truth
         pixels gathered alongside, ray-object distances, the composer - is this package's (HIP renderer; batched,
-        synchronisation-free host math).  Difference from the reference, in what it accepts: the optional
-        image decoder raises (``align_grid=False`` with a patch raises in the reference too)."""
+        synchronisation-free host math).  The optional image decoder (config["model"]["image_decoder"]) is an injected
+        module like the encoders (``align_grid=False`` with a patch raises in the reference too)."""
         self._require_encoders()
-        if self.use_image_decoder:
-            raise NotImplementedError("config['model']['image_decoder'] (compute_decoded_image, environment_model.py:708-741) "
-                                      "is not part of this package")
         camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
                                                                                 global_frame_indexes)
         rescaled_focals = focals * self.focal_length_multiplier
@@ -779,6 +807,8 @@ class EnvironmentModel(nn.Module):
         results = self.batchified_composer_call(origins, directions, normals, w2o, style.unsqueeze(-3), deformation.unsqueeze(-3),
                                                 present, perturb, samples_per_image_batching, expanded_video_indexes,
                                                 canonical_pose=canonical_pose, _decoder_layout=layout)
+        if self.use_image_decoder:
+            self.compute_decoded_image(results, sampled_positions)
         results["observations"] = sampled_observations
         results["positions"] = sampled_positions
         results["object_rotation_parameters"] = rot

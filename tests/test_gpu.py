@@ -1596,6 +1596,40 @@ def test_learnable_camera_offsets_receive_gradients_through_the_render():
     assert not torch.equal(base["coarse"]["global"]["integrated_features"], plain["coarse"]["global"]["integrated_features"])
 
 
+def test_image_decoder_hook():
+    """config["model"]["image_decoder"] (compute_decoded_image, environment_model.py:708-741): the decoder CNN and the grid
+    sampler are injected modules; the result gains coarse.global.decoded_images in the observation and the scene-encoding mode;
+    without the modules the call says what to inject, and fine models raise like the reference.  (Values against the
+    reference's own method: check_against_reference.py.)"""
+    cfg, model, b = _observation_model("tennis", (48, 64))
+    model.eval()
+    model.use_image_decoder = True
+    args = [b[k] for k in OBS_KEYS]
+    with torch.no_grad(), pytest.raises(RuntimeError, match="inject"):
+        model(*args, samples_per_image=0, perturb=False, patch_stride=[4, 8])
+
+    class Sampler(torch.nn.Module):
+        def forward(self, feats, positions):
+            return torch.cat([feats, positions], dim=-1).mean(dim=-2)
+
+    class Decoder(torch.nn.Module):
+        def forward(self, grid):
+            return (grid * 2.0).unsqueeze(-1).unsqueeze(-1).expand(list(grid.shape) + [2, 3])
+    model.set_image_decoder(Decoder(), Sampler())
+    with torch.no_grad():
+        out = model(*args, samples_per_image=0, perturb=False, patch_stride=[4, 8])
+        se = out["scene_encoding"]
+        again = model(se["camera_rotations"], se["camera_translations"], se["focals"], (48, 64), se["object_rotation_parameters"],
+                      se["object_translation_parameters"], se["object_style"], se["object_deformation"], se["object_in_scene"],
+                      0, False, patch_stride=[4, 8], mode="scene_encodings")
+    feats, pos = out["coarse"]["global"]["integrated_features"], out["positions"]
+    want = Decoder()(Sampler()(feats, pos))
+    assert torch.equal(out["coarse"]["global"]["decoded_images"], want)
+    assert torch.equal(again["coarse"]["global"]["decoded_images"], want)
+    with pytest.raises(Exception, match="fine features"):
+        model.compute_decoded_image({"coarse": out["coarse"], "fine": out["coarse"]}, pos)
+
+
 def test_missing_encoders_raise():
     cfg = configs.tennis_config()
     model = em.EnvironmentModel(cfg).eval().cuda()
