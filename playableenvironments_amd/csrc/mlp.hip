@@ -1200,6 +1200,14 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_gro
     if (count > 3) mlp_tile_loop<false, true>(j3);
 }
 
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                                         int count) {
+    mlp_tile_loop<true, true>(j0);
+    if (count > 1) mlp_tile_loop<true, true>(j1);
+    if (count > 2) mlp_tile_loop<true, true>(j2);
+    if (count > 3) mlp_tile_loop<true, true>(j3);
+}
+
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
 // affine built from the BATCH statistics + ReLU, run the next head matmul.
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) {
@@ -1429,20 +1437,26 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         long max_tiles = 0;
         for (int j = 0; j < n; ++j) {
             const MlpParams& q = host_jobs[begin + j];
-            PR_REQUIRE(q.phase == 0 && q.tile_counter, "grouped MLP launch: evaluation launches with a tile counter only");
+            PR_REQUIRE((q.phase == 0 || q.phase == 1) && q.phase == host_jobs[0].phase && q.tile_counter,
+                       "grouped MLP launch: evaluation launches or phase 1 of the phased launches, with a tile counter");
             PR_REQUIRE(!q.gate || (q.pend_act && q.pend_meta), "gated head: pending buffers missing");
             max_tiles += ((long)max_rows[begin + j] + TILE_M - 1) / TILE_M;
             g.jobs[j] = q;
         }
         if (max_tiles <= 0) continue;
         int cu_count = 0;
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_mfma_group), (int)sizeof(Smem), &cu_count));
+        const bool train = host_jobs[0].phase == 1;
+        PR_TRY(prepare_kernel(train ? reinterpret_cast<const void*>(k_mlp_mfma_train_group) : reinterpret_cast<const void*>(k_mlp_mfma_group),
+                              (int)sizeof(Smem), &cu_count));
         int resident = cu_count * MLP_BLOCKS_PER_CU;
         if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;
         const int grid = max_tiles < resident ? (int)max_tiles : resident;
         g.count = n;
         ProfileScope scope(0, s);
-        hipLaunchKernelGGL(k_mlp_mfma_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        if (train)
+            hipLaunchKernelGGL(k_mlp_mfma_train_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        else
+            hipLaunchKernelGGL(k_mlp_mfma_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         PR_LAUNCH_CHECK();
     }
     return PR_OK;

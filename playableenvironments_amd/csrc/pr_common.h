@@ -390,7 +390,7 @@ int launch_composite(const CompositeParams& p, hipStream_t s);
     } while (0)
 
 struct SavedPlan {   // PR_FLAG_SAVE_FOR_BACKWARD: per object instance and model type
-    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta, div, bits, bbits;
+    size_t rec_pos, rec_flat, row_flags, enc, act, h1, h2, batch, stat_count, bin, bact, braw, delta, div, bits, bbits, stats;
 };
 struct TypePlan {
     size_t t[PR_MAX_OBJECTS], sigma[PR_MAX_OBJECTS], slot[PR_MAX_OBJECTS], dispmag[PR_MAX_OBJECTS];
@@ -419,6 +419,7 @@ struct Plan {
 int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count);
 int validate_call(const pr_call_t& c, const pr_object_t* objs);
 bool group_active(const pr_call_t& c);
+bool group_train_active(const pr_call_t& c);
 bool gate_active(const pr_call_t& c);
 bool group_active(const pr_call_t& c);
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);

@@ -179,6 +179,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
                 sv.h1 = take(sizeof(float) * cap * d.Wpad);
                 sv.h2 = take(sizeof(float) * cap * d.W2pad);
                 sv.batch = take(sizeof(float) * 4 * MAX_WIDTH);
+                sv.stats = take(sizeof(double) * 4 * MAX_WIDTH);
                 sv.stat_count = take(sizeof(int32_t) * 4);
                 if (m.has_bender) {
                     sv.div = take(sizeof(float) * cap);
@@ -248,6 +249,15 @@ bool group_active(const pr_call_t& c) {
 #endif
 }
 
+// Differentiable calls (everything saved per object) with several objects: phase 1 of the phased launches is grouped as well.
+bool group_train_active(const pr_call_t& c) {
+#ifdef PR_MLP_UNGROUPED
+    return false;
+#else
+    return (c.flags & PR_FLAG_SAVE_FOR_BACKWARD) && !(c.flags & PR_FLAG_NAIVE_MLP) && c.objects > 1;
+#endif
+}
+
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size) {
     for (int a = 0; a < 3; ++a) {
         lo[a] = m.bbox[2 * a];
@@ -269,6 +279,15 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
     const bool grouped = group_active(c);
     MlpParams jobs[PR_MAX_OBJECTS];
     int job_rows[PR_MAX_OBJECTS];
+    // differentiable calls with several objects: phase 1 of every object (the whole network up to the first BatchNorm) runs as
+    // one grouped launch too; what follows it per object (statistics, head phases, divergence) is deferred until after it
+    const bool train_grouped = group_train_active(c);
+    struct TrainJob {
+        MlpParams mp; FoldParams fo; ModelDims d; const pr_object_model_t* m; const SavedPlan* sv;
+        double* stats; int32_t* stat_count; float* batch; float* h1; float* h2; float* rec_pos; int32_t* rec_flat;
+        int k, P, max_tiles; bool frozen, save;
+    };
+    static thread_local TrainJob train_jobs[PR_MAX_OBJECTS];
 
     for (int t = 0; t < ntypes; ++t) {
         const TypePlan& tp = plan.type[t];
@@ -277,6 +296,68 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         PR_CHECK_HIP(hipMemsetAsync(head_counts, 0, sizeof(int32_t) * 2 * PR_MAX_OBJECTS, s));
         const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
         int total_positions = 0;
+        // what follows phase 1 of an object's phased launches (training / differentiable calls): batch statistics, the two head
+        // phases, the divergence estimate
+        auto finish_object = [&](TrainJob& J) -> int {
+            MlpParams& mp = J.mp; FoldParams& fo = J.fo; const ModelDims& d = J.d; const pr_object_model_t& m = *J.m;
+            const SavedPlan& sv = *J.sv;
+            double* stats = J.stats; int32_t* stat_count = J.stat_count; float* batch = J.batch; float* h1 = J.h1; float* h2 = J.h2;
+            float* rec_pos = J.rec_pos; int32_t* rec_flat = J.rec_flat;
+            const int k = J.k, P = J.P, max_tiles = J.max_tiles;
+            const bool frozen = J.frozen, save = J.save;
+            BnFinalizeParams bf;
+            memset(&bf, 0, sizeof(bf));
+            bf.stats = stats; bf.count = stat_count; bf.width = d.W; bf.width_pad = d.Wpad; bf.momentum = 0.1f;
+            bf.frozen = frozen ? 1 : 0;
+            bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
+            bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
+            PR_TRY(launch_bn_finalize(bf, s));
+            fo.bn1_mean = batch; fo.bn1_var = batch + MAX_WIDTH;
+            PR_TRY(launch_adain_fold(fo, s));          // second layer still folded with placeholders
+            mp.phase = 2; mp.h_in = h1; mp.h_in_width = d.Wpad; mp.h_out = h2; mp.h_out_width = d.W2pad;
+            mp.stats = stats + 2 * MAX_WIDTH;
+            PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+            bf.stats = stats + 2 * MAX_WIDTH; bf.width = d.W2; bf.width_pad = d.W2pad;
+            bf.running_mean = m.bn4_mean; bf.running_var = m.bn4_var; bf.num_batches_tracked = (long long*)m.bn4_batches;
+            bf.batch_mean = batch + 2 * MAX_WIDTH; bf.batch_var = batch + 3 * MAX_WIDTH;
+            PR_TRY(launch_bn_finalize(bf, s));
+            fo.bn4_mean = batch + 2 * MAX_WIDTH; fo.bn4_var = batch + 3 * MAX_WIDTH;
+            PR_TRY(launch_adain_fold(fo, s));
+            mp.phase = 3; mp.h_in = h2; mp.h_in_width = d.W2pad; mp.h_out = nullptr;
+            PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+            if (outs[t] && outs[t]->normalised_samples)
+                PR_CHECK_HIP(hipMemcpyAsync(outs[t]->normalised_samples + k, stat_count, sizeof(int32_t),
+                                            hipMemcpyDeviceToDevice, s));
+            if (save && m.has_bender) {
+                // Hutchinson divergence of the displacement field (train mode with a graph; zeros without a probe)
+                const size_t cap_rows = (size_t)c.frames * c.rays * P;
+                float* div = reinterpret_cast<float*>(ws + sv.div);
+                PR_CHECK_HIP(hipMemsetAsync(div, 0, sizeof(float) * cap_rows, s));
+                // probes: explicit, or generated for training calls with a graph (the reference draws them whenever it
+                // trains with a graph, object_composer.py:597)
+                NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
+                if (!(c.flags & PR_FLAG_TRAIN_BN)) probes.generate = 0;
+                if (probes.ptr || probes.generate) {
+                    DivergenceParams dp;
+                    memset(&dp, 0, sizeof(dp));
+                    dp.total = totals + k; dp.max_rows = (int)cap_rows;
+                    dp.rec_flat = rec_flat; dp.row_flags = mp.row_flags; dp.rec_pos = rec_pos;
+                    dp.noise = probes; dp.positions = P;
+                    dp.bin = mp.save_bin; dp.bin_pad = d.bin_pad; dp.benc = d.benc; dp.b_octaves = m.bender_octaves;
+                    dp.bacts = mp.save_bact; dp.bact_stride = mp.save_bact_stride; dp.BW = d.BW; dp.BWpad = d.BWpad;
+                    dp.b_count = m.bender_count; dp.b_skip = m.bender_skip; dp.bin_real = d.bin;
+                    dp.layers = m.bender; dp.out_head = m.bender_out; dp.braw = mp.save_braw;
+                    bbox_split(m, dp.lo, dp.hi, nullptr);
+                    dp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+                    dp.t0 = reinterpret_cast<float*>(ws + plan.div_t0);
+                    dp.ta = reinterpret_cast<float*>(ws + plan.div_ta);
+                    dp.tb = reinterpret_cast<float*>(ws + plan.div_tb);
+                    dp.div = div;
+                    PR_TRY(launch_divergence(dp, s));
+                }
+            }
+            return PR_OK;
+        };
         for (int k = 0; k < K; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             const float* packed = static_cast<const float*>(t ? objs[k].packed_fine : objs[k].packed_coarse);
@@ -400,7 +481,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 // activations h1 / h2 behind for the backward pass - with the running statistics frozen.
                 const bool frozen = !(c.flags & PR_FLAG_TRAIN_BN);
                 PR_REQUIRE(!naive, "the scalar debugging kernel has no train-mode BatchNorm");
-                double* stats = reinterpret_cast<double*>(ws + plan.stats);
+                double* stats = reinterpret_cast<double*>(ws + (save ? sv.stats : plan.stats));
                 int32_t* stat_count = reinterpret_cast<int32_t*>(ws + (save ? sv.stat_count : plan.stat_count));
                 float* batch = reinterpret_cast<float*>(ws + (save ? sv.batch : plan.batch_stats));
                 float* h1 = reinterpret_cast<float*>(ws + (save ? sv.h1 : plan.h1));
@@ -427,59 +508,22 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     }
                 }
                 mp.phase = 1; mp.h_out = h1; mp.h_out_width = d.Wpad; mp.stats = stats;
-                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
-                BnFinalizeParams bf;
-                memset(&bf, 0, sizeof(bf));
-                bf.stats = stats; bf.count = stat_count; bf.width = d.W; bf.width_pad = d.Wpad; bf.momentum = 0.1f;
-                bf.frozen = frozen ? 1 : 0;
-                bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
-                bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
-                PR_TRY(launch_bn_finalize(bf, s));
-                fo.bn1_mean = batch; fo.bn1_var = batch + MAX_WIDTH;
-                PR_TRY(launch_adain_fold(fo, s));          // second layer still folded with placeholders
-                mp.phase = 2; mp.h_in = h1; mp.h_in_width = d.Wpad; mp.h_out = h2; mp.h_out_width = d.W2pad;
-                mp.stats = stats + 2 * MAX_WIDTH;
-                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
-                bf.stats = stats + 2 * MAX_WIDTH; bf.width = d.W2; bf.width_pad = d.W2pad;
-                bf.running_mean = m.bn4_mean; bf.running_var = m.bn4_var; bf.num_batches_tracked = (long long*)m.bn4_batches;
-                bf.batch_mean = batch + 2 * MAX_WIDTH; bf.batch_var = batch + 3 * MAX_WIDTH;
-                PR_TRY(launch_bn_finalize(bf, s));
-                fo.bn4_mean = batch + 2 * MAX_WIDTH; fo.bn4_var = batch + 3 * MAX_WIDTH;
-                PR_TRY(launch_adain_fold(fo, s));
-                mp.phase = 3; mp.h_in = h2; mp.h_in_width = d.W2pad; mp.h_out = nullptr;
-                PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
-                if (outs[t] && outs[t]->normalised_samples)
-                    PR_CHECK_HIP(hipMemcpyAsync(outs[t]->normalised_samples + k, stat_count, sizeof(int32_t),
-                                                hipMemcpyDeviceToDevice, s));
-                if (save && m.has_bender) {
-                    // Hutchinson divergence of the displacement field (train mode with a graph; zeros without a probe)
-                    const size_t cap_rows = (size_t)c.frames * c.rays * P;
-                    float* div = reinterpret_cast<float*>(ws + sv.div);
-                    PR_CHECK_HIP(hipMemsetAsync(div, 0, sizeof(float) * cap_rows, s));
-                    // probes: explicit, or generated for training calls with a graph (the reference draws them whenever it
-                    // trains with a graph, object_composer.py:597)
-                    NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
-                    if (!(c.flags & PR_FLAG_TRAIN_BN)) probes.generate = 0;
-                    if (probes.ptr || probes.generate) {
-                        DivergenceParams dp;
-                        memset(&dp, 0, sizeof(dp));
-                        dp.total = totals + k; dp.max_rows = (int)cap_rows;
-                        dp.rec_flat = rec_flat; dp.row_flags = mp.row_flags; dp.rec_pos = rec_pos;
-                        dp.noise = probes; dp.positions = P;
-                        dp.bin = mp.save_bin; dp.bin_pad = d.bin_pad; dp.benc = d.benc; dp.b_octaves = m.bender_octaves;
-                        dp.bacts = mp.save_bact; dp.bact_stride = mp.save_bact_stride; dp.BW = d.BW; dp.BWpad = d.BWpad;
-                        dp.b_count = m.bender_count; dp.b_skip = m.bender_skip; dp.bin_real = d.bin;
-                        dp.layers = m.bender; dp.out_head = m.bender_out; dp.braw = mp.save_braw;
-                        bbox_split(m, dp.lo, dp.hi, nullptr);
-                        dp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
-                        dp.t0 = reinterpret_cast<float*>(ws + plan.div_t0);
-                        dp.ta = reinterpret_cast<float*>(ws + plan.div_ta);
-                        dp.tb = reinterpret_cast<float*>(ws + plan.div_tb);
-                        dp.div = div;
-                        PR_TRY(launch_divergence(dp, s));
-                    }
+                TrainJob& J = train_jobs[k];
+                J.mp = mp; J.fo = fo; J.d = d; J.m = &m; J.sv = &sv;
+                J.stats = stats; J.stat_count = stat_count; J.batch = batch; J.h1 = h1; J.h2 = h2; J.rec_pos = rec_pos; J.rec_flat = rec_flat;
+                J.k = k; J.P = P; J.max_tiles = max_tiles; J.frozen = frozen; J.save = save;
+                if (train_grouped) {
+                    jobs[k] = mp;
+                    job_rows[k] = max_tiles;
+                } else {
+                    PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                    PR_TRY(finish_object(J));
                 }
             }
+        }
+        if (train_grouped) {
+            PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
+            for (int k = 0; k < K; ++k) PR_TRY(finish_object(train_jobs[k]));
         }
 
         if (grouped) {
