@@ -1210,11 +1210,13 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
 // affine built from the BATCH statistics + ReLU, run the next head matmul.
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) {
+template <bool GROUP>
+__device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
+    if (GROUP) __syncthreads();   // every wave has left the previous object's last tile
     const Layer& prev = p.layers[p.n_backbone + p.phase - 2];   // the layer whose output is h_in
     const Layer& cur = p.layers[p.n_backbone + p.phase - 1];
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
@@ -1254,6 +1256,16 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) { mlp_head_loop<false>(p); }
+// the same phase of several objects in one launch: a workgroup takes its strided share of every object's tiles in turn
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                                   int count) {
+    mlp_head_loop<true>(j0);
+    if (count > 1) mlp_head_loop<true>(j1);
+    if (count > 2) mlp_head_loop<true>(j2);
+    if (count > 3) mlp_head_loop<true>(j3);
 }
 
 __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {
@@ -1437,23 +1449,27 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         long max_tiles = 0;
         for (int j = 0; j < n; ++j) {
             const MlpParams& q = host_jobs[begin + j];
-            PR_REQUIRE((q.phase == 0 || q.phase == 1) && q.phase == host_jobs[0].phase && q.tile_counter,
-                       "grouped MLP launch: evaluation launches or phase 1 of the phased launches, with a tile counter");
+            PR_REQUIRE(q.phase >= 0 && q.phase <= 3 && q.phase == host_jobs[0].phase && (q.phase >= 2 || q.tile_counter),
+                       "grouped MLP launch: one phase for all jobs, a tile counter for the fused / first phase");
             PR_REQUIRE(!q.gate || (q.pend_act && q.pend_meta), "gated head: pending buffers missing");
             max_tiles += ((long)max_rows[begin + j] + TILE_M - 1) / TILE_M;
             g.jobs[j] = q;
         }
         if (max_tiles <= 0) continue;
         int cu_count = 0;
-        const bool train = host_jobs[0].phase == 1;
-        PR_TRY(prepare_kernel(train ? reinterpret_cast<const void*>(k_mlp_mfma_train_group) : reinterpret_cast<const void*>(k_mlp_mfma_group),
-                              (int)sizeof(Smem), &cu_count));
+        const int phase = host_jobs[0].phase;
+        const void* kernel = phase >= 2 ? reinterpret_cast<const void*>(k_mlp_head_group)
+                                        : (phase == 1 ? reinterpret_cast<const void*>(k_mlp_mfma_train_group)
+                                                      : reinterpret_cast<const void*>(k_mlp_mfma_group));
+        PR_TRY(prepare_kernel(kernel, (int)sizeof(Smem), &cu_count));
         int resident = cu_count * MLP_BLOCKS_PER_CU;
         if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;
         const int grid = max_tiles < resident ? (int)max_tiles : resident;
         g.count = n;
         ProfileScope scope(0, s);
-        if (train)
+        if (phase >= 2)
+            hipLaunchKernelGGL(k_mlp_head_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        else if (phase == 1)
             hipLaunchKernelGGL(k_mlp_mfma_train_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else
             hipLaunchKernelGGL(k_mlp_mfma_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);

@@ -298,7 +298,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         int total_positions = 0;
         // what follows phase 1 of an object's phased launches (training / differentiable calls): batch statistics, the two head
         // phases, the divergence estimate
-        auto finish_object = [&](TrainJob& J) -> int {
+        // stage 1: statistics of phase 1 -> phase 2; stage 2: statistics of phase 2 -> phase 3; stage 3: counts, divergence.
+        // `launch`: enqueue the stage's MLP phase here (one object at a time) - false when the caller groups the objects' launches
+        auto finish_object = [&](TrainJob& J, int stage, bool launch) -> int {
             MlpParams& mp = J.mp; FoldParams& fo = J.fo; const ModelDims& d = J.d; const pr_object_model_t& m = *J.m;
             const SavedPlan& sv = *J.sv;
             double* stats = J.stats; int32_t* stat_count = J.stat_count; float* batch = J.batch; float* h1 = J.h1; float* h2 = J.h2;
@@ -307,24 +309,31 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             const bool frozen = J.frozen, save = J.save;
             BnFinalizeParams bf;
             memset(&bf, 0, sizeof(bf));
-            bf.stats = stats; bf.count = stat_count; bf.width = d.W; bf.width_pad = d.Wpad; bf.momentum = 0.1f;
+            bf.count = stat_count; bf.momentum = 0.1f;
             bf.frozen = frozen ? 1 : 0;
-            bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
-            bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
-            PR_TRY(launch_bn_finalize(bf, s));
-            fo.bn1_mean = batch; fo.bn1_var = batch + MAX_WIDTH;
-            PR_TRY(launch_adain_fold(fo, s));          // second layer still folded with placeholders
-            mp.phase = 2; mp.h_in = h1; mp.h_in_width = d.Wpad; mp.h_out = h2; mp.h_out_width = d.W2pad;
-            mp.stats = stats + 2 * MAX_WIDTH;
-            PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
-            bf.stats = stats + 2 * MAX_WIDTH; bf.width = d.W2; bf.width_pad = d.W2pad;
-            bf.running_mean = m.bn4_mean; bf.running_var = m.bn4_var; bf.num_batches_tracked = (long long*)m.bn4_batches;
-            bf.batch_mean = batch + 2 * MAX_WIDTH; bf.batch_var = batch + 3 * MAX_WIDTH;
-            PR_TRY(launch_bn_finalize(bf, s));
-            fo.bn4_mean = batch + 2 * MAX_WIDTH; fo.bn4_var = batch + 3 * MAX_WIDTH;
-            PR_TRY(launch_adain_fold(fo, s));
-            mp.phase = 3; mp.h_in = h2; mp.h_in_width = d.W2pad; mp.h_out = nullptr;
-            PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+            if (stage == 1) {
+                bf.stats = stats; bf.width = d.W; bf.width_pad = d.Wpad;
+                bf.running_mean = m.bn1_mean; bf.running_var = m.bn1_var; bf.num_batches_tracked = (long long*)m.bn1_batches;
+                bf.batch_mean = batch; bf.batch_var = batch + MAX_WIDTH;
+                PR_TRY(launch_bn_finalize(bf, s));
+                fo.bn1_mean = batch; fo.bn1_var = batch + MAX_WIDTH;
+                PR_TRY(launch_adain_fold(fo, s));          // second layer still folded with placeholders
+                mp.phase = 2; mp.h_in = h1; mp.h_in_width = d.Wpad; mp.h_out = h2; mp.h_out_width = d.W2pad;
+                mp.stats = stats + 2 * MAX_WIDTH;
+                if (launch) PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                return PR_OK;
+            }
+            if (stage == 2) {
+                bf.stats = stats + 2 * MAX_WIDTH; bf.width = d.W2; bf.width_pad = d.W2pad;
+                bf.running_mean = m.bn4_mean; bf.running_var = m.bn4_var; bf.num_batches_tracked = (long long*)m.bn4_batches;
+                bf.batch_mean = batch + 2 * MAX_WIDTH; bf.batch_var = batch + 3 * MAX_WIDTH;
+                PR_TRY(launch_bn_finalize(bf, s));
+                fo.bn4_mean = batch + 2 * MAX_WIDTH; fo.bn4_var = batch + 3 * MAX_WIDTH;
+                PR_TRY(launch_adain_fold(fo, s));
+                mp.phase = 3; mp.h_in = h2; mp.h_in_width = d.W2pad; mp.h_out = nullptr;
+                if (launch) PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
+                return PR_OK;
+            }
             if (outs[t] && outs[t]->normalised_samples)
                 PR_CHECK_HIP(hipMemcpyAsync(outs[t]->normalised_samples + k, stat_count, sizeof(int32_t),
                                             hipMemcpyDeviceToDevice, s));
@@ -517,13 +526,20 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     job_rows[k] = max_tiles;
                 } else {
                     PR_TRY(launch_mlp(mp, max_tiles, false, &m, s));
-                    PR_TRY(finish_object(J));
+                    for (int stage = 1; stage <= 3; ++stage) PR_TRY(finish_object(J, stage, true));
                 }
             }
         }
         if (train_grouped) {
-            PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
-            for (int k = 0; k < K; ++k) PR_TRY(finish_object(train_jobs[k]));
+            PR_TRY(launch_mlp_group(jobs, job_rows, K, s));                  // phase 1 of every object
+            for (int stage = 1; stage <= 2; ++stage) {                       // statistics per object, then the next phase of all
+                for (int k = 0; k < K; ++k) {
+                    PR_TRY(finish_object(train_jobs[k], stage, false));
+                    jobs[k] = train_jobs[k].mp;
+                }
+                PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
+            }
+            for (int k = 0; k < K; ++k) PR_TRY(finish_object(train_jobs[k], 3, false));
         }
 
         if (grouped) {
