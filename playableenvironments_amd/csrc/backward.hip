@@ -13,6 +13,7 @@
 #include "pr_common.h"
 
 #include <algorithm>
+#include <mutex>
 #include "composite_dev.h"
 
 namespace pr {
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
             for (int j = 0; j < 3; ++j) {
                 float v = M[j] * gd[0] + M[4 + j] * gd[1] + M[8 + j] * gd[2];
                 if (p.g_norm) v = fmaf(gn, dw[j] / nrm, v);
-                p.d_ray_directions[(size_t)g * 3 + j] += v;
+                atomicAdd(p.d_ray_directions + (size_t)g * 3 + j, v);     // (objects on two lanes may add to the same ray)
             }
         }
     }
@@ -966,7 +967,10 @@ struct BwdPlan {
     size_t div_t0, div_stack;         //   probe tangents of the bender input and of every bender layer's output
     size_t bytes;
     size_t max_cap;
+    int lanes;                        // 2: the per-object scratch exists twice (lane_stride apart): two objects at a time
+    size_t lane_stride;
 };
+constexpr size_t LANE_SCRATCH_LIMIT = (size_t)8 << 30;     // calls whose per-object scratch is larger keep one lane
 constexpr size_t CHAIN_GSTACK_LIMIT = (size_t)16 << 30;   // calls whose chains would need more scratch go layer by layer
 
 static size_t align_up_b(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -993,6 +997,12 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     bp->max_cap = max_cap;
     bp->g_norm_bytes = sizeof(float) * nr;
     bp->g_norm = take(bp->g_norm_bytes);
+    if (c.flags & PR_FLAG_DIVERGENCE_GRAD)
+        for (int k = 0; k < c.objects; ++k)
+            if (objs[k].coarse.has_bender || (c.use_fine && objs[k].fine.has_bender))
+                bp->g_div[k] = take(sizeof(float) * nr * std::max(objs[k].coarse.positions, c.use_fine ? objs[k].fine.positions : 0));
+    // ---- everything below is scratch of ONE object's backward pass: a second copy lets two objects run side by side
+    const size_t lane_begin = off;
     bp->bufA = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->bufB = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->act = take(sizeof(float) * max_cap * MAX_WIDTH);
@@ -1029,7 +1039,6 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
                 const size_t cap = nr * m.positions;
                 t0_need = std::max(t0_need, sizeof(float) * cap * d.bin_pad);
                 stack_need = std::max(stack_need, sizeof(float) * cap * d.BWpad * (size_t)m.bender_count);
-                if (!bp->g_div[k]) bp->g_div[k] = take(sizeof(float) * nr * std::max(objs[k].coarse.positions, c.use_fine ? objs[k].fine.positions : 0));
             }
         bp->div_t0 = take(t0_need);
         bp->div_stack = take(stack_need);
@@ -1046,7 +1055,42 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     bp->partial = take(sizeof(float) * gemm_tn_scratch_floats(BWD_SPLITS) * (chained ? MAX_TN_GROUP : 1));
     bp->sums = take(sizeof(double) * 2 * MAX_WIDTH);
     bp->tables = take(sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH);
+    const size_t lane_bytes = off - lane_begin;
+    bp->lanes = 1;
+#ifndef PR_BWD_ONE_LANE
+    if (c.objects > 1 && lane_bytes <= LANE_SCRATCH_LIMIT) {
+        bp->lanes = 2;
+        bp->lane_stride = lane_bytes;
+        off += lane_bytes;
+    }
+#endif
     bp->bytes = off;
+    return PR_OK;
+}
+
+// Second stream of the backward pass (one per device, created on first use, never destroyed): the per-object parts of
+// different objects are independent between the compositing backward and the end of the call; most of their ~50 launches per
+// object are small, so two objects side by side fill the GPU better than one after the other.  The caller's stream forks
+// into it after the compositing backward and joins it before the call returns - for the caller everything is still
+// enqueued on its own stream.
+static int lane_stream(hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    PR_REQUIRE(dev >= 0 && dev < 64, "device index %d", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[dev]) PR_CHECK_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    *out = streams[dev];
+    return PR_OK;
+}
+
+static int stream_wait(hipStream_t waiter, hipStream_t on) {      // `waiter` continues after everything enqueued on `on` so far
+    hipEvent_t e;
+    PR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    PR_CHECK_HIP(hipEventRecord(e, on));
+    PR_CHECK_HIP(hipStreamWaitEvent(waiter, e, 0));
+    PR_CHECK_HIP(hipEventDestroy(e));                             // released once the recorded work has completed
     return PR_OK;
 }
 
@@ -1184,7 +1228,8 @@ static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_
 
 // backward of one model type (t = 0: coarse models / results["coarse"], 1: fine)
 static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
-                    char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s) {
+                    char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s_caller) {
+    hipStream_t s = s_caller;
     const int K = c.objects;
     const TypePlan& tp = plan.type[t];
     const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
@@ -1245,20 +1290,62 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     PR_TRY(launch_composite_bwd(cp, s));
 
     // ---- per object -------------------------------------------------------------------------------
-    float* bufA = reinterpret_cast<float*>(bws + bp.bufA);
-    float* bufB = reinterpret_cast<float*>(bws + bp.bufB);
-    float* actb = reinterpret_cast<float*>(bws + bp.act);
-    float* g_enc = reinterpret_cast<float*>(bws + bp.g_enc);
-    float* gsr = reinterpret_cast<float*>(bws + bp.gsr);
-    float* gdr = reinterpret_cast<float*>(bws + bp.gdr);
-    float* g_bent = reinterpret_cast<float*>(bws + bp.g_bent);
-    float* g_x = reinterpret_cast<float*>(bws + bp.g_x);
-    float* g_braw = reinterpret_cast<float*>(bws + bp.g_braw);
-    float* g_in6 = reinterpret_cast<float*>(bws + bp.g_in6);
-    double* sums = reinterpret_cast<double*>(bws + bp.sums);
-    float* tables = reinterpret_cast<float*>(bws + bp.tables);
+    // Lanes: objects that share a model (the same gradient buffers are accumulated into) stay on one lane, in order; the
+    // groups go to the lane with the smaller load so far (load = sample capacity, largest group first).
+    int lane_of[PR_MAX_OBJECTS] = {};
+    hipStream_t aux = nullptr;
+    if (bp.lanes == 2) {
+        int group_of[PR_MAX_OBJECTS];
+        size_t group_cost[PR_MAX_OBJECTS] = {};
+        int groups = 0;
+        for (int k = 0; k < K; ++k) {
+            const pr_model_grads_t& Gk = t ? out.model_fine[k] : out.model[k];
+            group_of[k] = -1;
+            for (int q = 0; q < k && group_of[k] < 0; ++q) {
+                const pr_model_grads_t& Gq = t ? out.model_fine[q] : out.model[q];
+                if (Gk.head6.weight && Gk.head6.weight == Gq.head6.weight) group_of[k] = group_of[q];
+            }
+            if (group_of[k] < 0) group_of[k] = groups++;
+            group_cost[group_of[k]] += (size_t)c.frames * c.rays * (t ? objs[k].fine : objs[k].coarse).positions;
+        }
+        size_t load[2] = {0, 0};
+        int group_lane[PR_MAX_OBJECTS];
+        bool done[PR_MAX_OBJECTS] = {};
+        for (int n = 0; n < groups; ++n) {
+            int best = -1;
+            for (int g = 0; g < groups; ++g)
+                if (!done[g] && (best < 0 || group_cost[g] > group_cost[best])) best = g;
+            done[best] = true;
+            group_lane[best] = load[1] < load[0] ? 1 : 0;
+            load[group_lane[best]] += group_cost[best];
+        }
+        bool any = false;
+        for (int k = 0; k < K; ++k) {
+            lane_of[k] = group_lane[group_of[k]];
+            any |= lane_of[k] == 1;
+        }
+        if (any) {
+            PR_TRY(lane_stream(&aux));
+            PR_TRY(stream_wait(aux, s_caller));          // fork: the second lane starts after the compositing backward
+        }
+    }
 
     for (int k = 0; k < K; ++k) {
+        const int lane = aux ? lane_of[k] : 0;
+        hipStream_t s = lane ? aux : s_caller;           // (shadows the caller's stream for this object's launches)
+        char* lws = bws + (size_t)lane * bp.lane_stride;
+        float* bufA = reinterpret_cast<float*>(lws + bp.bufA);
+        float* bufB = reinterpret_cast<float*>(lws + bp.bufB);
+        float* actb = reinterpret_cast<float*>(lws + bp.act);
+        float* g_enc = reinterpret_cast<float*>(lws + bp.g_enc);
+        float* gsr = reinterpret_cast<float*>(lws + bp.gsr);
+        float* gdr = reinterpret_cast<float*>(lws + bp.gdr);
+        float* g_bent = reinterpret_cast<float*>(lws + bp.g_bent);
+        float* g_x = reinterpret_cast<float*>(lws + bp.g_x);
+        float* g_braw = reinterpret_cast<float*>(lws + bp.g_braw);
+        float* g_in6 = reinterpret_cast<float*>(lws + bp.g_in6);
+        double* sums = reinterpret_cast<double*>(lws + bp.sums);
+        float* tables = reinterpret_cast<float*>(lws + bp.tables);
         const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
         const pr_model_grads_t& G = t ? out.model_fine[k] : out.model[k];
         const SavedPlan& sv = tp.saved[k];
@@ -1276,9 +1363,9 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         rc.samples_per_frame = c.rays * P;
         rc.in_scene = c.object_in_scene + k; rc.in_scene_stride = K;
         GemmCtx gc;
-        gc.rows = totals + k; gc.max_rows = (int)cap; gc.partial = reinterpret_cast<float*>(bws + bp.partial); gc.s = s;
-        gc.gstack = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.gstack) : nullptr;
-        gc.chain_packed = bp.gstack_bytes ? reinterpret_cast<float*>(bws + bp.chain_packed) : nullptr;
+        gc.rows = totals + k; gc.max_rows = (int)cap; gc.partial = reinterpret_cast<float*>(lws + bp.partial); gc.s = s;
+        gc.gstack = bp.gstack_bytes ? reinterpret_cast<float*>(lws + bp.gstack) : nullptr;
+        gc.chain_packed = bp.gstack_bytes ? reinterpret_cast<float*>(lws + bp.chain_packed) : nullptr;
         gc.cap = cap;
         gc.dw_acts = nullptr; gc.dw_stride = 0; gc.dw_in0 = nullptr;
 
@@ -1397,8 +1484,8 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             // input's tangent depends on the position through the encoding's derivative only.
             NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
             if (div_grad && (probes.ptr || probes.generate)) {
-                float* t0 = reinterpret_cast<float*>(bws + bp.div_t0);
-                float* tstack = reinterpret_cast<float*>(bws + bp.div_stack);
+                float* t0 = reinterpret_cast<float*>(lws + bp.div_t0);
+                float* tstack = reinterpret_cast<float*>(lws + bp.div_stack);
                 const size_t tstride = cap * d.BWpad;
                 DivergenceParams dp;
                 memset(&dp, 0, sizeof(dp));
@@ -1479,6 +1566,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             PR_LAUNCH_CHECK();
         }
     }
+    if (aux) PR_TRY(stream_wait(s_caller, aux));         // join: the caller's stream continues after both lanes
     return PR_OK;
 }
 
