@@ -189,6 +189,8 @@ def train_step_leg(args, dev, world, rank, dist, lib):
             "evaluated_samples_per_step": [round(c, 1) for c in counts],
             "kernel_ms_per_step": {"forward_mlp": per(0), "forward_composite": per(1), "backward_dx_gemm": per(2),
                                    "backward_dw_gemm": per(3), "backward_composite": per(4)},
+            "kernel_ms_note": "HIP-event time of every launch, summed per category; the backward pass runs its objects on two lanes "
+                              "(two streams), so the backward categories overlap in time and their sum exceeds the wall time",
             "backward_gemm_tflops": round(2.0 * fwd_flops / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms > 0 else None,
             "forward_mlp_tflops": round(fwd_flops / (ms[0] / steps * 1e-3) / 1e12, 2) if ms[0] > 0 else None,
         },
