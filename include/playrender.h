@@ -322,6 +322,11 @@ typedef struct pr_input_grads_t {
     float* ray_directions;   /* (N,R,3) accumulated; or NULL */
 } pr_input_grads_t;
 
+/* Streams: the call is ordered on `stream` like every other entry point - work enqueued on `stream` before the call precedes
+ * it, work enqueued after the call follows all of it.  Inside, calls with several objects run the objects on two lanes: `stream`
+ * and one internal stream per device (created on the first such call, kept for the life of the process), forked from `stream`
+ * after the compositing backward and joined back into it before the call returns (events, no host synchronisation).  Both
+ * workspaces must stay untouched until work enqueued on `stream` after the call would run. */
 int pr_backward_workspace_size(const pr_call_t* call, const pr_object_t* objects, size_t* bytes);
 int pr_render_backward(const pr_call_t* call, const pr_object_t* objects, const pr_output_grads_t* grads_coarse,
                        const pr_output_grads_t* grads_fine /* NULL unless use_fine */, const pr_input_grads_t* out,
