@@ -1,0 +1,559 @@
+// Tile machinery of the fused MLP kernels (mlp.hip) and of the fused backward kernels (train_bwd.hip): the LDS image of a
+// 64-sample tile, one layer on the matrix cores (run_layer), the positional encodings and the tile <-> HBM row movers.
+// Device code only; included by the translation units that instantiate kernels over it.
+#pragma once
+#include "pr_common.h"
+
+#include <cstddef>
+
+namespace pr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Shared memory image of one tile
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_SIGMA = MAX_WIDTH + 8;   // sigma weights (Wpad) + bias
+constexpr int HEAD_BENDER = 0;              // the 3-row bender head is read from L2 (players are few)
+struct Smem {
+    int uniform_frame;       // every row of the tile belongs to the same frame
+    int next_tile;           // the tile this workgroup claimed for its next iteration (dynamic tile order)
+    int pad_[2];
+    float head_w[HEAD_SIGMA + HEAD_BENDER];
+    float X[TILE_M * LDX];   // activations; columns [0, K) also hold a layer's input encoding while it is needed
+    float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
+    int flat[TILE_M];
+    int frame[TILE_M];
+    int flags[TILE_M];       // bit 0: row holds a real sample; bit 1: it passed every AABB test; bit 2 (sigma-gated
+                             // head only): its density is not <= 0, i.e. its feature row can reach a compositing sum
+    int dest[TILE_M];        // gated head: compact feature row a tile row is written to (-1: none)
+    int src[TILE_M];         // gated head: slot of the workgroup's pending stack a tile row is exchanged with (-1: none)
+};
+static_assert(sizeof(Smem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "the workgroups of one CU must fit its LDS");
+static_assert(offsetof(Smem, head_w) % 16 == 0 && offsetof(Smem, X) % 16 == 0 && offsetof(Smem, pos) % 16 == 0,
+              "16-byte LDS reads of the activation tile");
+
+
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// positional encoding element j of input v[din]  (model/positional_encoder.py:54-64)
+__device__ __forceinline__ float pe_element(const float* v, int din, int enc, int j, const float* octave_weights) {
+    if (j < din) return v[j];
+    if (j >= enc) return 0.f;
+    const int jj = j - din;
+    const int k = jj / (2 * din);
+    const int rem = jj - k * 2 * din;
+    const int fn = rem / din;
+    const int ax = rem - fn * din;
+    const float arg = __fmul_rn(ldexpf(1.0f, k), v[ax]);
+#ifdef PR_FAST_TRIG_ABLATION
+    float e = fn ? __cosf(arg) : __sinf(arg);
+#else
+    float e = fn ? cosf(arg) : sinf(arg);
+#endif
+    if (octave_weights) e = __fmul_rn(e, octave_weights[k]);
+    return e;
+}
+
+// Epilogue stores of one 32x32 accumulator block.  Lane (r, half) holds column r and the rows
+// (i & 3) + 8 (i >> 2) + 4 half, i = 0..15: constant LDS offsets from the lane's base pointer.
+#define PR_ACC_ROW(i) (((i) & 3) + 8 * ((i) >> 2))
+
+__device__ __forceinline__ void store_relu(const f32x16& acc, float* base) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) base[PR_ACC_ROW(i) * LDX] = acc[i] > 0.f ? acc[i] : 0.f;
+}
+
+__device__ __forceinline__ void store_adain_uniform(const f32x16& acc, float* base, float g, float b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = fmaf(acc[i], g, b);
+        base[PR_ACC_ROW(i) * LDX] = v > 0.f ? v : 0.f;
+    }
+}
+
+__device__ __forceinline__ void store_adain_rows(const f32x16& acc, Smem& S, const MlpParams& p, int row0, int col,
+                                             int goff, int boff) {
+    // rare path (tiles that straddle two frames): kept out of line and in chunks of four rows so that
+    // it does not inflate the register allocation of the hot loops
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float g[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* tab = p.adain + (size_t)S.frame[row0 + PR_ACC_ROW(4 * c + i)] * p.adain_stride;
+            g[i] = tab[goff];
+            b[i] = tab[boff];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaf(acc[4 * c + i], g[i], b[i]);
+            S.X[(row0 + PR_ACC_ROW(4 * c + i)) * LDX + col] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_plain(const f32x16& acc, float* base) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) base[PR_ACC_ROW(i) * LDX] = acc[i];
+}
+
+#ifdef PR_MLP_TIMING
+// phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase
+__device__ unsigned long long g_mlp_phase[16];
+#define PR_PHASE_T0() unsigned long long _pt = __builtin_amdgcn_s_memtime()
+#define PR_PHASE(idx)                                                                      \
+    do {                                                                                   \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0) atomicAdd(&g_mlp_phase[idx], _n - _pt);                      \
+        _pt = _n;                                                                          \
+    } while (0)
+#else
+#define PR_PHASE_T0() do {} while (0)
+#define PR_PHASE(idx) do {} while (0)
+#endif
+
+struct EncRegs;
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
+
+// One layer on the tile.  All threads of the workgroup call it (workgroup barriers inside).
+//
+// Geometry: the 64-sample tile is two 32-row MFMA blocks; wave w of the FOUR waves owns the 32-column blocks w and
+// w + 4 of the layer for both row blocks - four accumulators that share two activation and two weight fragments
+// per K step (16 MFMAs between operand loads).  Two such workgroups are resident per CU (LDS ~70 KB each), so the
+// serial phases of one tile (record loads, encodings, epilogues, barriers) overlap the other tile's matrix work.
+//
+// `input_kind` says what a segment with src == 1 (the layer's input encoding) means: 0 = NeRF input, 1 = ray-bender
+// input.  The first layer finds it in X already; the skip layer's second segment re-computes it into X[:, 0:K).
+#define PR_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0)
+#define PR_MFMA4(acc, a, b) \
+    PR_MFMA(acc, a.x, b.x); \
+    PR_MFMA(acc, a.y, b.y); \
+    PR_MFMA(acc, a.z, b.z); \
+    PR_MFMA(acc, a.w, b.w)
+
+template <bool BWD = false>
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
+                                          const BwdEpilogue* bwd = nullptr);
+
+// Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
+//   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
+// There is no separate encoding buffer: the encoding is (re)computed into the activation tile right before a
+// layer consumes it - layer 0, and once more for the second K segment of the skip layer - which keeps the
+// workgroup at ~70 KB of LDS, i.e. two independent tiles per CU.
+// 8 threads per row, thread `part` takes the octaves part, part + 8, ... (one sincos per axis).
+// A thread's share of a network input - two tile rows, the octaves part and part + 8, up to 6 input dimensions - kept in
+// registers between the first use of the input (layer 0) and its second (the skip layer's second K segment): the
+// replay writes the values back into X without evaluating the sines and cosines again (VALU work of one resident
+// tile is not hidden behind the other tile's matrix work; it adds to the kernel time).
+constexpr int ENC_ROWS = TILE_M / (MLP_THREADS / 8);
+constexpr int ENC_SLOTS = (PR_MAX_OCTAVES + 7) / 8;
+constexpr int ENC_DIMS = 3;        // positions; the 6-dimensional skybox input is simply evaluated twice
+struct EncRegs {
+    float raw[ENC_ROWS][ENC_DIMS];
+    float sc[ENC_ROWS][ENC_SLOTS][2 * ENC_DIMS];
+};
+static_assert(ENC_ROWS == 2, "fill_encoding keeps two rows per thread");
+
+__device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
+                                              const float* octave_weights, bool normalise, EncRegs& regs, bool replay) {
+    const int part = threadIdx.x & 7;
+    if (din != ENC_DIMS) {
+        for (int s = threadIdx.x >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+            float v[6];
+            for (int a = 0; a < din; ++a) {
+                const float x = S.pos[s * 8 + a];
+                v[a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+            }
+            float* row = S.X + s * LDX;
+            if (part == 0)
+                for (int a = 0; a < din; ++a) row[a] = v[a];
+            if (part == 1)
+                for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
+            for (int k = part; k < octaves; k += 8) {
+                const float f = ldexpf(1.0f, k);
+                const float w = octave_weights ? octave_weights[k] : 1.0f;
+                float* dst = row + din + k * 2 * din;
+                for (int a = 0; a < din; ++a) {
+                    const float arg = __fmul_rn(f, v[a]);
+                    float sn = sinf(arg), cs = cosf(arg);
+                    if (octave_weights) {
+                        sn = __fmul_rn(sn, w);
+                        cs = __fmul_rn(cs, w);
+                    }
+                    dst[a] = sn;
+                    dst[din + a] = cs;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < ENC_ROWS; ++j) {
+        const int s = (threadIdx.x >> 3) + j * (MLP_THREADS / 8);
+        float* row = S.X + s * LDX;
+        if (!replay) {
+#pragma unroll
+            for (int a = 0; a < ENC_DIMS; ++a) {
+                const float x = S.pos[s * 8 + a];
+                regs.raw[j][a] = normalise ? __fdiv_rn(x, p.size[a]) : x;
+            }
+        }
+        if (part == 0) {
+#pragma unroll
+            for (int a = 0; a < ENC_DIMS; ++a) row[a] = regs.raw[j][a];
+        }
+        if (part == 1)
+            for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
+#pragma unroll
+        for (int slot = 0; slot < ENC_SLOTS; ++slot) {
+            const int k = part + 8 * slot;
+            if (k < octaves) {
+                float* dst = row + ENC_DIMS + k * 2 * ENC_DIMS;
+                if (!replay) {
+                    const float f = ldexpf(1.0f, k);
+                    const float w = octave_weights ? octave_weights[k] : 1.0f;
+#pragma unroll
+                    for (int a = 0; a < ENC_DIMS; ++a) {
+                        const float arg = __fmul_rn(f, regs.raw[j][a]);
+                        float sn = sinf(arg), cs = cosf(arg);
+                        if (octave_weights) {
+                            sn = __fmul_rn(sn, w);
+                            cs = __fmul_rn(cs, w);
+                        }
+                        regs.sc[j][slot][a] = sn;
+                        regs.sc[j][slot][ENC_DIMS + a] = cs;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 2 * ENC_DIMS; ++a) dst[a] = regs.sc[j][slot][a];
+            }
+        }
+    }
+}
+
+// input of the NeRF: PE of the (bent, normalised) position / of the skybox's [o / size, d / |d|]
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
+    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0, regs, replay);
+}
+
+// input of the ray bender: [annealed PE(x / size) | deformation code of the sample's frame], zero padded
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
+    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true, regs, replay);
+    for (int idx = threadIdx.x; idx < TILE_M * p.D; idx += MLP_THREADS) {
+        const int s = idx / p.D, j = idx - s * p.D;
+        S.X[s * LDX + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
+    }
+}
+
+template <bool BWD>
+__device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
+                                          const BwdEpilogue* bwd) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int nblk = L.nblk;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    const bool active = cbA < nblk;      // this wave has a first column block
+    const bool two = cbB < nblk;         // ... and a second one
+    PR_PHASE_T0();
+    f32x16 a00, a01, a10, a11;           // [column block A / B][row block 0 / 1]
+    {
+        const float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
+        const float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a00[i] = biasA;
+            a01[i] = biasA;
+            a10[i] = biasB;
+            a11[i] = biasB;
+        }
+    }
+    for (int sidx = 0; sidx < L.nseg; ++sidx) {
+        const Seg& sg = L.seg[sidx];
+        if (!BWD && sg.src == 1 && sidx > 0) {
+            // second K segment of a skip layer: its operand is the network input, re-encoded over the
+            // (now dead) activations of the first segment
+            __syncthreads();
+            if (input_kind == 1) fill_bender_input(S, p, enc, true); else fill_nerf_input(S, p, enc, true);
+            __syncthreads();
+        }
+        if (!active) continue;
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 128)
+        continue;   // measurement build: no matrix work (results are wrong)
+#endif
+        // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
+        __builtin_amdgcn_s_setprio(1);
+        const int kq = sg.kq;   // even (K is padded to a multiple of 16)
+        const float* ap = S.X + r * LDX + half * 4 * kq;
+        const float4* wpA = reinterpret_cast<const float4*>(sg.w) + (size_t)cbA * kq * 64 + lane;
+        // two steps in flight: even/odd fragments live in their own registers and are re-loaded
+        // right after their last use, a full step before they are needed again
+        float4 x0e = *reinterpret_cast<const float4*>(ap);
+        float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
+        float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
+        float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+        float4 wAe = wpA[0], wAo = wpA[64];
+        if (two) {
+            const float4* wpB = reinterpret_cast<const float4*>(sg.w) + (size_t)cbB * kq * 64 + lane;
+            float4 wBe = wpB[0], wBo = wpB[64];
+            for (int q = 0; q < kq; q += 2) {
+                const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                PR_MFMA4(a00, x0e, wAe);
+                PR_MFMA4(a01, x1e, wAe);
+                PR_MFMA4(a10, x0e, wBe);
+                PR_MFMA4(a11, x1e, wBe);
+                wAe = wpA[(size_t)qe * 64];
+                wBe = wpB[(size_t)qe * 64];
+                x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+                PR_MFMA4(a00, x0o, wAo);
+                PR_MFMA4(a01, x1o, wAo);
+                PR_MFMA4(a10, x0o, wBo);
+                PR_MFMA4(a11, x1o, wBo);
+                wAo = wpA[(size_t)qo * 64];
+                wBo = wpB[(size_t)qo * 64];
+                x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
+            for (int q = 0; q < kq; q += 2) {
+                const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+                PR_MFMA4(a00, x0e, wAe);
+                PR_MFMA4(a01, x1e, wAe);
+                wAe = wpA[(size_t)qe * 64];
+                x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+                x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+                PR_MFMA4(a00, x0o, wAo);
+                PR_MFMA4(a01, x1o, wAo);
+                wAo = wpA[(size_t)qo * 64];
+                x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+                x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 4)
+    return;   // measurement build: no barriers, no epilogue (results are wrong)
+#endif
+    PR_PHASE(3);
+    if (BWD) {
+        // Backward chain (k_chain_bwd): the tile holds d loss / d pre-activation of a layer, the product is its input
+        // gradient.  EPI_BWD_GLOBAL: the rows go straight to global memory (the gradient of the network input: X keeps the
+        // operand, which the next product of the same layer still needs); EPI_BWD_MASK: ReLU backward with the saved
+        // post-ReLU activation of the previous layer as the mask (a bit image of the tile in LDS), result back into X.
+        const int rows_valid = bwd->rows_valid;
+        if (L.epi == EPI_BWD_GLOBAL) {
+            if (active) {
+                for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+                    const int col = (blk ? cbB : cbA) * 32 + r;
+                    const f32x16& lo = blk ? a10 : a00;
+                    const f32x16& hi = blk ? a11 : a01;
+                    if (col < bwd->n_real) {
+                        // one base pointer per lane, row offsets are wave-uniform multiples of the leading dimension
+                        float* base = bwd->gout + (size_t)(tile_base + 4 * half) * bwd->ldg + col;
+                        const int ldg = bwd->ldg;
+                        const int limit = rows_valid - 4 * half;       // rows of this lane: PR_ACC_ROW(i) (+ 32) < limit
+                        float old_lo[16], old_hi[16];
+                        if (bwd->accumulate) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                old_lo[i] = PR_ACC_ROW(i) < limit ? base[PR_ACC_ROW(i) * ldg] : 0.f;
+                                old_hi[i] = PR_ACC_ROW(i) + 32 < limit ? base[(PR_ACC_ROW(i) + 32) * ldg] : 0.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) old_lo[i] = old_hi[i] = 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            if (PR_ACC_ROW(i) < limit) base[PR_ACC_ROW(i) * ldg] = lo[i] + old_lo[i];
+                            if (PR_ACC_ROW(i) + 32 < limit) base[(PR_ACC_ROW(i) + 32) * ldg] = hi[i] + old_hi[i];
+                        }
+                    }
+                }
+            }
+            return;    // X untouched: no barrier needed
+        }
+        __syncthreads();  // every wave has finished reading X (and the mask bits of this layer are complete)
+        if (active) {
+            // bit (row, col) of the ReLU mask: byte row * (width / 8) + col / 8 of the tile's bit image (built by
+            // build_relu_mask_bits before the product), bit col % 8
+            const unsigned char* bits = bwd->mask_bits;
+            const int bpr = bwd->mask_bytes_per_row;
+            for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+                const int col = (blk ? cbB : cbA) * 32 + r;
+                const f32x16& lo = blk ? a10 : a00;
+                const f32x16& hi = blk ? a11 : a01;
+                float* x0 = S.X + (4 * half) * LDX + col;
+                const unsigned char* b0 = bits + (4 * half) * bpr + (col >> 3);
+                const int bit = col & 7;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = PR_ACC_ROW(i);
+                    x0[ro * LDX] = ((b0[ro * bpr] >> bit) & 1) ? lo[i] : 0.f;
+                    x0[(ro + 32) * LDX] = ((b0[(ro + 32) * bpr] >> bit) & 1) ? hi[i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    __syncthreads();  // every wave has finished reading X
+    PR_PHASE(4);
+#if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 8)
+    if (false) {   // measurement build: no epilogue (results are wrong)
+#else
+    if (active) {
+#endif
+        for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
+            const int col = (blk ? cbB : cbA) * 32 + r;
+            const f32x16& lo = blk ? a10 : a00;   // rows 0..31
+            const f32x16& hi = blk ? a11 : a01;   // rows 32..63
+            float* x0 = S.X + (4 * half) * LDX + col;
+            if (L.epi == EPI_RELU) {
+                store_relu(lo, x0);
+                store_relu(hi, x0 + 32 * LDX);
+            } else if (L.epi == EPI_ADAIN_RELU) {
+                const int bofs = L.nblk * 32;
+                if (S.uniform_frame) {
+                    const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride + L.adain_off;
+                    const float g = tab[col], b = tab[bofs + col];
+                    store_adain_uniform(lo, x0, g, b);
+                    store_adain_uniform(hi, x0 + 32 * LDX, g, b);
+                } else {
+                    store_adain_rows(lo, S, p, 4 * half, col, L.adain_off + col, L.adain_off + bofs + col);
+                    store_adain_rows(hi, S, p, 4 * half + 32, col, L.adain_off + col, L.adain_off + bofs + col);
+                }
+            } else {
+                // last layer: stage the tile in X, the caller writes it out with coalesced 16-byte stores
+                store_plain(lo, x0);
+                store_plain(hi, x0 + 32 * LDX);
+            }
+        }
+    }
+    PR_PHASE(5);
+    __syncthreads();
+    PR_PHASE(6);
+}
+
+// dot products of every tile row with `nout` (<= 3) weight rows of length `width` (raw, padded),
+// for tile row `s`: 8 threads per row (callers loop s = tid / 8, + MLP_THREADS / 8, ...); the result is valid in all 8.
+__device__ __forceinline__ void row_dots(const Smem& S, int s, const float* w, int width, int wstride, int nout, float* out) {
+    const int part = threadIdx.x & 7;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = part; k < width; k += 8) {
+        const float x = S.X[s * LDX + k];
+        for (int a = 0; a < nout; ++a) acc[a] = fmaf(x, w[a * wstride + k], acc[a]);
+    }
+    for (int a = 0; a < nout; ++a) {
+        float v = acc[a];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        out[a] = v;
+    }
+}
+
+// Tile rows staged in X -> HBM with coalesced 16-byte stores (width % 4 == 0) or scalar stores.
+// zero_dead: rows that failed the second AABB test are written as zeros (feature rows).
+__device__ __forceinline__ void write_tile_rows(const Smem& S, float* dst, int width, int stride, int tile_base, bool zero_dead) {
+    const int tid = threadIdx.x;
+    const float* src = S.X;
+    const int ld = LDX;
+    if ((width & 3) == 0 && (stride & 3) == 0) {
+        const int w4 = width >> 2;
+        for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            const int fl = S.flags[row];
+            if (fl & 1) {
+                float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
+                if (zero_dead && !(fl & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // streamed once, read next by another kernel: keep the rows from evicting the weight fragments in L2
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(dst + (size_t)(tile_base + row) * stride + c));
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TILE_M * width; idx += MLP_THREADS) {
+            const int row = idx / width, c = idx - row * width;
+            const int fl = S.flags[row];
+            if (fl & 1) dst[(size_t)(tile_base + row) * stride + c] = (zero_dead && !(fl & 2)) ? 0.f : src[row * ld + c];
+        }
+    }
+}
+
+// Feature rows staged in X -> HBM rows S.dest[row] (rows with dest < 0 are skipped); see write_tile_rows.
+__device__ __forceinline__ void write_rows_indirect(const Smem& S, float* dst, int width, int stride) {
+    const int tid = threadIdx.x;
+    if ((width & 3) == 0 && (stride & 3) == 0) {
+        const int w4 = width >> 2;
+        for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            const int d = S.dest[row];
+            if (d >= 0) {
+                const float4 v = *reinterpret_cast<const float4*>(S.X + row * LDX + c);
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                f32x4_nt nt = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nt, reinterpret_cast<f32x4_nt*>(dst + (size_t)d * stride + c));
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TILE_M * width; idx += MLP_THREADS) {
+            const int row = idx / width, c = idx - row * width;
+            const int d = S.dest[row];
+            if (d >= 0) dst[(size_t)d * stride + c] = S.X[row * LDX + c];
+        }
+    }
+}
+
+// ReLU mask of the tile staged in X as a bit image: byte (row, c8) = bits of columns 8 c8 .. 8 c8 + 7 ("activation > 0"),
+// rows of width / 8 bytes in compact-row order - 2 KB per tile and layer, which the backward chain loads instead of the
+// 64 KB of activations.
+__device__ __forceinline__ void write_tile_bits(const Smem& S, unsigned char* dst, int width_pad, int tile_base) {
+    const int c8n = width_pad >> 3;
+    for (int idx = threadIdx.x; idx < TILE_M * c8n; idx += MLP_THREADS) {
+        const int row = idx / c8n, c8 = idx - row * c8n;
+        if (!(S.flags[row] & 1)) continue;
+        const float4 a = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8);
+        const float4 b = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8 + 4);
+        const unsigned int byte = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u) |
+                                  (b.x > 0.f ? 16u : 0u) | (b.y > 0.f ? 32u : 0u) | (b.z > 0.f ? 64u : 0u) | (b.w > 0.f ? 128u : 0u);
+        dst[(size_t)(tile_base + row) * c8n + c8] = (unsigned char)byte;
+    }
+}
+
+// ReLU mask of a tile as one bit per element: bit (row, col) = saved post-ReLU activation > 0.  Coalesced 16-byte loads of the
+// 64 x width activation rows, eight columns -> one byte of the bit image (2 KB at width 256; it lives in Smem::pos, which
+// the backward chain does not use otherwise).  Rows beyond the tile's real rows get zero bits.
+__device__ __forceinline__ void build_relu_mask_bits(unsigned char* bits, const float* acts, int ld, int width_pad, int tile_base,
+                                                     int rows_valid) {
+    const int c8n = width_pad >> 3;
+    for (int idx = threadIdx.x; idx < TILE_M * c8n; idx += MLP_THREADS) {
+        const int row = idx / c8n, c8 = idx - row * c8n;
+        unsigned int byte = 0;
+        if (row < rows_valid) {
+            const float* src = acts + (size_t)(tile_base + row) * ld + 8 * c8;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            byte = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u) |
+                   (b.x > 0.f ? 16u : 0u) | (b.y > 0.f ? 32u : 0u) | (b.z > 0.f ? 64u : 0u) | (b.w > 0.f ? 128u : 0u);
+        }
+        bits[idx] = (unsigned char)byte;
+    }
+}
+
+}  // namespace pr
