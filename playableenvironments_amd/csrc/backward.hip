@@ -754,7 +754,7 @@ struct GeometryBwd {
     int pc;
 };
 
-__global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
+__device__ __forceinline__ void geometry_bwd_body(const GeometryBwd& p) {
     __shared__ float red[15 * 4];
     const int n = blockIdx.y;                              // frame
     const int ray = blockIdx.x * 256 + threadIdx.x;
@@ -891,6 +891,8 @@ __global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_geometry_bwd(GeometryBwd p) { geometry_bwd_body(p); }
+
 // ---- gradient of the Hutchinson divergence estimate (object_composer.py:582-601, create_graph=True) -----------------
 // the three probe components of compact sample `flat` (flat = ray * P + sample): element (flat % P) * 3 + a of ray flat / P
 __device__ __forceinline__ void probe_of(const NoiseRef& noise, int flat, int positions, float* e) {
@@ -950,6 +952,194 @@ __global__ __launch_bounds__(256) void k_div_tangent_in_bwd(RowCtx r, NoiseRef n
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row kernels of the grouped backward pass: the objects of a call share every launch (blockIdx.y = job)
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_ROW_JOBS = 2 * PR_MAX_OBJECTS;
+
+// After the NeRF chain: positional-encoding backward of the network input, then - objects with a ray bender - the bender
+// output's backward (k_pe_bwd + k_bender_out_bwd of the per-object path in one pass over the rows).
+struct PostNerfJob {
+    RowCtx r;
+    int kind, has_bender, octaves, ld;          // ld: row stride of enc / g_enc
+    const float* enc; const float* g_enc;
+    float size[3], lo[3], hi[3];
+    float* g_x;                                 // (cap,3) d loss / d object-frame position (kind 0)
+    float* g_in6;                               // (cap,6) d loss / d [o / size, d / |d|] (kind 1)
+    // ray bender
+    const float* g_dm;                          // (N,R,P) d loss / d |delta| from the compositing backward
+    const float* g_delta_dense;                 // (N,R,P,3) gradient of the exported displacement vectors, or NULL
+    const float* delta; const float* braw; const float* pos;
+    int canonical;
+    float* g_braw4;                             // (cap,4) d loss / d raw bender output
+};
+struct PostNerfJobs { PostNerfJob job[MAX_ROW_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_post_nerf_group(PostNerfJobs jobs) {
+    const PostNerfJob& p = jobs.job[blockIdx.y];
+    const int M = *p.r.total;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int fl = p.r.row_flags[m];
+    const bool need = (fl & 3) == 3;
+    const int din = p.kind == 0 ? 3 : 6;
+    const float* e = p.enc + (size_t)m * p.ld;
+    const float* g = p.g_enc + (size_t)m * p.ld;
+    float v[6];
+    for (int a = 0; a < din; ++a) {
+        float acc = 0.f;
+        if (need) {
+            acc = g[a];
+            for (int k = 0; k < p.octaves; ++k) {
+                const int sn = din + k * 2 * din + a, cs = sn + din;
+                acc += ldexpf(1.0f, k) * (e[cs] * g[sn] - e[sn] * g[cs]);
+            }
+            if (p.kind == 0) acc /= p.size[a];
+        }
+        v[a] = acc;
+    }
+    if (p.kind == 1) {
+        for (int a = 0; a < 6; ++a) p.g_in6[(size_t)m * 6 + a] = v[a];
+        return;
+    }
+    if (!p.has_bender) {
+        for (int a = 0; a < 3; ++a) p.g_x[(size_t)m * 3 + a] = v[a];
+        return;
+    }
+    // bent = x + delta, delta = clamp(raw * size, lo - x, hi - x) (* 0 in canonical pose); |delta| feeds integrated_displacements_magnitude
+    const bool real = (fl & 1) != 0;
+    float dl[3], nrm = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        dl[a] = p.delta[(size_t)m * 3 + a];
+        nrm = fmaf(dl[a], dl[a], nrm);
+    }
+    nrm = sqrtf(nrm);
+    const int flat = p.r.rec_flat[m];
+    const float gd = real ? p.g_dm[flat] : 0.f;
+    float gr[3];
+    for (int a = 0; a < 3; ++a) {
+        const float gb = real ? v[a] : 0.f;
+        float g_delta = gb + (nrm > 0.f ? gd * dl[a] / nrm : 0.f);
+        if (real && p.g_delta_dense) g_delta += p.g_delta_dense[(size_t)flat * 3 + a];
+        if (p.canonical) g_delta = 0.f;
+        const float x = p.pos[(size_t)m * 3 + a];
+        const float pre = p.braw[(size_t)m * 3 + a] * (p.hi[a] - p.lo[a]);
+        const float lob = p.lo[a] - x, hib = p.hi[a] - x;
+        const float m1 = pre > lob ? pre : lob;
+        float g_pre = 0.f, gx = gb;
+        if (m1 > hib) gx -= g_delta;
+        else if (pre >= lob) g_pre = g_delta;
+        else gx -= g_delta;
+        p.g_x[(size_t)m * 3 + a] = real ? gx : 0.f;
+        gr[a] = real ? g_pre * (p.hi[a] - p.lo[a]) : 0.f;
+    }
+    *reinterpret_cast<float4*>(p.g_braw4 + (size_t)m * 4) = make_float4(gr[0], gr[1], gr[2], 0.f);
+}
+
+// After the bender chain: positional-encoding backward of the bender input (added to the position gradient) and the
+// deformation code's gradient, summed per frame (k_pe_bwd + k_deformation_bwd of the per-object path).
+struct PostBenderJob {
+    RowCtx r;
+    const float* bin; const float* g_bin; int ld, octaves, benc, D;
+    float size[3];
+    float* g_x;                                 // (cap,3) accumulated
+    float* d_def; int def_stride;               // d deformation of this object, or NULL
+};
+struct PostBenderJobs { PostBenderJob job[MAX_ROW_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_post_bender_group(PostBenderJobs jobs) {
+    __shared__ int sh_frame[2];
+    const PostBenderJob& p = jobs.job[blockIdx.y];
+    const int M = *p.r.total;
+    const int m0 = blockIdx.x * 256;
+    if (m0 >= M) return;
+    const int m = m0 + threadIdx.x;
+    const bool valid = m < M;
+    const bool real = valid && (p.r.row_flags[m] & 1);
+    const float* e = p.bin + (size_t)(valid ? m : m0) * p.ld;
+    const float* g = p.g_bin + (size_t)(valid ? m : m0) * p.ld;
+    if (real) {
+        for (int a = 0; a < 3; ++a) {
+            float acc = g[a];
+            for (int k = 0; k < p.octaves; ++k) {
+                const int sn = 3 + k * 6 + a, cs = sn + 3;
+                acc += ldexpf(1.0f, k) * (e[cs] * g[sn] - e[sn] * g[cs]);
+            }
+            p.g_x[(size_t)m * 3 + a] += acc / p.size[a];
+        }
+    }
+    if (!p.d_def) return;      // (uniform)
+    const int last = (m0 + 255 < M ? m0 + 255 : M - 1);
+    if (threadIdx.x == 0) {
+        sh_frame[0] = p.r.rec_flat[m0] / p.r.samples_per_frame;
+        sh_frame[1] = p.r.rec_flat[last] / p.r.samples_per_frame;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    if (sh_frame[0] == sh_frame[1]) {       // the usual case: the block's rows belong to one frame
+        for (int j = 0; j < p.D; ++j) {
+            const float s = wave_sum(real ? g[p.benc + j] : 0.f);
+            if (lane == 0 && s != 0.f) atomicAdd(p.d_def + (size_t)sh_frame[0] * p.def_stride + j, s);
+        }
+    } else if (real) {
+        const int frame = p.r.rec_flat[m] / p.r.samples_per_frame;
+        for (int j = 0; j < p.D; ++j) atomicAdd(p.d_def + (size_t)frame * p.def_stride + j, g[p.benc + j]);
+    }
+}
+
+struct StyleBwdJob {
+    int width, S;
+    const float* dscale; const float* dbias;    // (frames, MAX_WIDTH)
+    const float* style; int style_stride;
+    const float* A; float* dA; float* db; float* d_style;
+};
+struct StyleBwdJobs { StyleBwdJob job[2 * PR_MAX_OBJECTS]; int frames; };
+
+// k_style_bwd over (frames, MAX_WIDTH) tables for every AdaIN layer of every object (blockIdx.y = job)
+__global__ __launch_bounds__(256) void k_style_bwd_group(StyleBwdJobs jobs) {
+    __shared__ float sh[256];
+    const StyleBwdJob& p = jobs.job[blockIdx.y];
+    const int frames = jobs.frames, width = p.width, S = p.S;
+    const int rows = 2 * width;
+    if ((int)blockIdx.x < frames) {
+        const int f = blockIdx.x;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+            float acc = 0.f;
+            if (s < S)
+                for (int rr = part; rr < rows; rr += 4) {
+                    const float dv = rr < width ? p.dscale[(size_t)f * MAX_WIDTH + rr] : p.dbias[(size_t)f * MAX_WIDTH + rr - width];
+                    acc = fmaf(p.A[(size_t)rr * S + s], dv, acc);
+                }
+            sh[threadIdx.x] = acc;
+            __syncthreads();
+            // (instances that share a model write different d_style rows; the shared dA / db are accumulated with atomics below)
+            if (part == 0 && s < S && p.d_style)      // (both AdaIN layers of an object add to its style row)
+                atomicAdd(p.d_style + (size_t)f * p.style_stride + s, sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+            __syncthreads();
+        }
+        return;
+    }
+    const long idx = (long)(blockIdx.x - frames) * 256 + threadIdx.x;
+    if (idx < (long)rows * S) {
+        const int rr = (int)(idx / S), s = (int)(idx - (long)rr * S);
+        const float* src = rr < width ? p.dscale + rr : p.dbias + (rr - width);
+        float acc = 0.f;
+        for (int f = 0; f < frames; ++f) acc = fmaf(src[(size_t)f * MAX_WIDTH], p.style[(size_t)f * p.style_stride + s], acc);
+        if (p.dA) atomicAdd(p.dA + idx, acc);
+        if (s == 0 && p.db) {
+            float b = 0.f;
+            for (int f = 0; f < frames; ++f) b += src[(size_t)f * MAX_WIDTH];
+            atomicAdd(p.db + rr, b);
+        }
+    }
+}
+
+struct GeometryBwdJobs { GeometryBwd job[PR_MAX_OBJECTS]; };
+__device__ __forceinline__ void geometry_bwd_body(const GeometryBwd& p);
+__global__ __launch_bounds__(256) void k_geometry_bwd_group(GeometryBwdJobs jobs) { geometry_bwd_body(jobs.job[blockIdx.z]); }
+
 }  // namespace pr
 
 // ---------------------------------------------------------------------------------------------
@@ -957,7 +1147,25 @@ __global__ __launch_bounds__(256) void k_div_tangent_in_bwd(RowCtx r, NoiseRef n
 // ---------------------------------------------------------------------------------------------
 namespace pr {
 
+// Scratch of the grouped backward pass (backward_grouped): every object keeps its own buffers, the objects share the launches.
+struct GroupPlan {
+    size_t a2[PR_MAX_OBJECTS], d2[PR_MAX_OBJECTS], a1[PR_MAX_OBJECTS], d1[PR_MAX_OBJECTS];   // head layers: activations / gradients
+    size_t gstack[PR_MAX_OBJECTS], g_enc[PR_MAX_OBJECTS], gsr4[PR_MAX_OBJECTS];
+    size_t g_x[PR_MAX_OBJECTS], g_braw4[PR_MAX_OBJECTS], g_in6[PR_MAX_OBJECTS];
+    size_t bgstack[PR_MAX_OBJECTS], g_benc[PR_MAX_OBJECTS];
+    size_t zero_begin, zero_bytes;           // one fill: batch sums, AdaIN gradient tables, tile / claim counters
+    size_t sums[PR_MAX_OBJECTS];             // doubles: [layer 4: sum | sum sq] [layer 1: sum | sum sq], 2 x MAX_WIDTH each
+    size_t tables[PR_MAX_OBJECTS];           // frames x 4 x MAX_WIDTH floats: dscale1 | dbias1 | dscale2 | dbias2
+    size_t counters;                         // ints: 4 per object, then the 8 claim counters of the weight-gradient launch
+    size_t tn_partial, tn_partial_floats;    // partial tiles of the weight-gradient launch
+    size_t end;                              // first byte behind the grouped scratch
+    bool usable;
+};
+constexpr size_t GROUP_SCRATCH_LIMIT = (size_t)48 << 30;   // larger calls take the per-object path
+
 struct BwdPlan {
+    GroupPlan group;
+    size_t front_bytes;               // per-sample gradients of the compositing backward: used by both paths
     size_t g_feat[PR_MAX_OBJECTS], g_sigma[PR_MAX_OBJECTS], g_t[PR_MAX_OBJECTS], g_dm[PR_MAX_OBJECTS];
     size_t bufA, bufB, act, g_enc, gsr, gdr, g_bent, g_x, g_braw, g_in6, partial, sums, tables;
     size_t gstack, chain_packed;      // layer-chained backward: per-layer pre-activation gradients, W^T fragments
@@ -1003,6 +1211,7 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
                 bp->g_div[k] = take(sizeof(float) * nr * std::max(objs[k].coarse.positions, c.use_fine ? objs[k].fine.positions : 0));
     // ---- everything below is scratch of ONE object's backward pass: a second copy lets two objects run side by side
     const size_t lane_begin = off;
+    bp->front_bytes = off;
     bp->bufA = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->bufB = take(sizeof(float) * max_cap * MAX_WIDTH);
     bp->act = take(sizeof(float) * max_cap * MAX_WIDTH);
@@ -1065,6 +1274,71 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     }
 #endif
     bp->bytes = off;
+    // ---- grouped path: the same front, then per-object buffers for every object at once
+    {
+        GroupPlan& gp = bp->group;
+        size_t goff = lane_begin;
+        auto gtake = [&](size_t bytes) {
+            const size_t at = goff;
+            goff += align_up_b(bytes);
+            return at;
+        };
+        size_t tn_floats = 0;
+        for (int k = 0; k < c.objects; ++k) {
+            size_t cap = 0;
+            int Wp = 0, W2p = 0, encp = 0, nb = 0, BWp = 0, binp = 0, bc = 0;
+            size_t tn_k = 0;
+            for (int t = 0; t < (c.use_fine ? 2 : 1); ++t) {      // the two model types run one after the other on the same scratch
+                const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+                ModelDims d;
+                PR_TRY(compute_dims(m, &d));
+                const size_t cap_t = nr * m.positions;
+                cap = std::max(cap, cap_t);
+                Wp = std::max(Wp, d.Wpad); W2p = std::max(W2p, d.W2pad); encp = std::max(encp, d.enc_pad); nb = std::max(nb, m.backbone_count);
+                if (m.has_bender) { BWp = std::max(BWp, d.BWpad); binp = std::max(binp, d.bin_pad); bc = std::max(bc, m.bender_count); }
+                // partial tiles of every weight-gradient product of the model
+                size_t f = 0;
+                const long rows = (long)cap_t;
+                f += tn_all_partial_floats(d.F, d.W2, rows) + tn_all_partial_floats(d.W2, d.W, rows) + tn_all_partial_floats(d.W, d.W, rows) +
+                     tn_all_partial_floats(1, d.W, rows);
+                f += tn_all_partial_floats(d.W, d.enc, rows) * 2 + tn_all_partial_floats(d.W, d.W, rows) * (size_t)(m.backbone_count - 1);
+                if (m.has_bender)
+                    f += tn_all_partial_floats(3, d.BW, rows) + tn_all_partial_floats(d.BW, d.bin, rows) * 2 +
+                         tn_all_partial_floats(d.BW, d.BW, rows) * (size_t)(m.bender_count - 1);
+                tn_k = std::max(tn_k, f);
+            }
+            tn_floats += tn_k;
+            gp.a2[k] = gtake(sizeof(float) * cap * W2p);
+            gp.d2[k] = gtake(sizeof(float) * cap * W2p);
+            gp.a1[k] = gtake(sizeof(float) * cap * Wp);
+            gp.d1[k] = gtake(sizeof(float) * cap * Wp);
+            gp.gstack[k] = gtake(sizeof(float) * cap * Wp * (size_t)nb);
+            gp.g_enc[k] = gtake(sizeof(float) * cap * encp);
+            gp.gsr4[k] = gtake(sizeof(float) * cap * 4);
+            gp.g_x[k] = gtake(sizeof(float) * cap * 3);
+            gp.g_in6[k] = gtake(sizeof(float) * cap * 6);
+            if (bc) {
+                gp.g_braw4[k] = gtake(sizeof(float) * cap * 4);
+                gp.bgstack[k] = gtake(sizeof(float) * cap * BWp * (size_t)bc);
+                gp.g_benc[k] = gtake(sizeof(float) * cap * binp);
+            }
+        }
+        gp.tn_partial_floats = tn_floats;
+        gp.tn_partial = gtake(sizeof(float) * tn_floats);
+        gp.zero_begin = goff;
+        for (int k = 0; k < c.objects; ++k) {
+            gp.sums[k] = gtake(sizeof(double) * 4 * MAX_WIDTH);
+            gp.tables[k] = gtake(sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH);
+        }
+        gp.counters = gtake(sizeof(int32_t) * (4 * PR_MAX_OBJECTS + 8 * 4));
+        gp.zero_bytes = goff - gp.zero_begin;
+        gp.end = goff;
+        gp.usable = !(c.flags & PR_FLAG_DIVERGENCE_GRAD) && (goff - lane_begin) <= GROUP_SCRATCH_LIMIT;
+#ifdef PR_BWD_PER_OBJECT
+        gp.usable = false;          // measurement build: the per-object path for every call
+#endif
+        if (gp.usable) bp->bytes = goff;     // (the per-object scratch is not needed)
+    }
     return PR_OK;
 }
 
@@ -1226,14 +1500,13 @@ static int chain_backward(const GemmCtx& g, const pr_linear_t* layers, const pr_
     return PR_OK;
 }
 
-// backward of one model type (t = 0: coarse models / results["coarse"], 1: fine)
-static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
-                    char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s_caller) {
-    hipStream_t s = s_caller;
+// compositing backward of one model type: per-sample gradients (feature rows, sigma, t, |delta|, divergence) of every object
+struct CompositeBwdResult { bool div_grad, ray_grads; float* g_norm; };
+static int composite_backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
+                              char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s, CompositeBwdResult* res) {
     const int K = c.objects;
     const TypePlan& tp = plan.type[t];
     const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
-    int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
     const int F = objs[0].coarse.output_features;
     const int Fs = (F + 15) & ~15;     // row stride of the feature gradients
 
@@ -1246,7 +1519,6 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         div_grad = any;
     }
 
-    // ---- compositing backward ---------------------------------------------------------------------
     CompositeBwdParams cp;
     memset(&cp, 0, sizeof(cp));
     cp.div_grad = div_grad ? 1 : 0;
@@ -1284,10 +1556,26 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
     cp.ray_directions = c.ray_directions;
     cp.noise_global = perturb_noise(noise.integrate_global, c, NOISE_INTEGRATE_GLOBAL, t, 0);
     cp.global = grads.global;
-    const bool ray_grads = out.ray_origins != nullptr || out.ray_directions != nullptr;
-    float* g_norm = (out.ray_directions && bp.g_norm_bytes) ? reinterpret_cast<float*>(bws + bp.g_norm) : nullptr;
-    cp.g_norm = g_norm;
-    PR_TRY(launch_composite_bwd(cp, s));
+    res->div_grad = div_grad;
+    res->ray_grads = out.ray_origins != nullptr || out.ray_directions != nullptr;
+    res->g_norm = (out.ray_directions && bp.g_norm_bytes) ? reinterpret_cast<float*>(bws + bp.g_norm) : nullptr;
+    cp.g_norm = res->g_norm;
+    return launch_composite_bwd(cp, s);
+}
+
+// backward of one model type (t = 0: coarse models / results["coarse"], 1: fine), one object after the other on two lanes
+static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
+                    char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s_caller) {
+    const int K = c.objects;
+    const TypePlan& tp = plan.type[t];
+    const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
+    int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
+    const int F = objs[0].coarse.output_features;
+    const int Fs = (F + 15) & ~15;     // row stride of the feature gradients
+    CompositeBwdResult cr;
+    PR_TRY(composite_backward(c, objs, t, grads, out, fws, plan, bws, bp, s_caller, &cr));
+    const bool div_grad = cr.div_grad, ray_grads = cr.ray_grads;
+    float* g_norm = cr.g_norm;
 
     // ---- per object -------------------------------------------------------------------------------
     // Lanes: objects that share a model (the same gradient buffers are accumulated into) stay on one lane, in order; the
@@ -1299,11 +1587,13 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         size_t group_cost[PR_MAX_OBJECTS] = {};
         int groups = 0;
         for (int k = 0; k < K; ++k) {
-            const pr_model_grads_t& Gk = t ? out.model_fine[k] : out.model[k];
+            // instances of one model (the same parameter storages) accumulate into the same gradient buffers - whichever of
+            // them are trainable - with plain read-modify-writes: they stay on one lane
+            const pr_object_model_t& Mk = t ? objs[k].fine : objs[k].coarse;
             group_of[k] = -1;
             for (int q = 0; q < k && group_of[k] < 0; ++q) {
-                const pr_model_grads_t& Gq = t ? out.model_fine[q] : out.model[q];
-                if (Gk.head6.weight && Gk.head6.weight == Gq.head6.weight) group_of[k] = group_of[q];
+                const pr_object_model_t& Mq = t ? objs[q].fine : objs[q].coarse;
+                if (Mk.backbone[0].weight == Mq.backbone[0].weight) group_of[k] = group_of[q];
             }
             if (group_of[k] < 0) group_of[k] = groups++;
             group_cost[group_of[k]] += (size_t)c.frames * c.rays * (t ? objs[k].fine : objs[k].coarse).positions;
@@ -1330,6 +1620,9 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         }
     }
 
+    // (a lambda: whatever happens inside - a failed launch, an unsupported configuration - the second lane is joined back
+    // into the caller's stream before the call returns)
+    auto run_objects = [&]() -> int {
     for (int k = 0; k < K; ++k) {
         const int lane = aux ? lane_of[k] : 0;
         hipStream_t s = lane ? aux : s_caller;           // (shadows the caller's stream for this object's launches)
@@ -1566,7 +1859,319 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             PR_LAUNCH_CHECK();
         }
     }
-    if (aux) PR_TRY(stream_wait(s_caller, aux));         // join: the caller's stream continues after both lanes
+    return PR_OK;
+    };
+    int status = run_objects();
+    if (aux) {                                           // join: the caller's stream continues after both lanes
+        const int joined = stream_wait(s_caller, aux);
+        if (status == PR_OK) status = joined;
+    }
+    return status;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Grouped backward pass of one model type: the objects of the call share every launch.
+//   compositing backward -> head phase 1 -> head phase 2 -> NeRF chains (head layer 0 and the sigma head fused in) -> row
+//   kernel (positional encoding, bender output) -> bender chains -> row kernel (bender encoding, deformation) -> EVERY weight
+//   gradient of every object (one launch + its reduction) -> style affines -> sample placement
+// ---------------------------------------------------------------------------------------------
+static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, const pr_output_grads_t& grads, const pr_input_grads_t& out,
+                            char* fws, const Plan& plan, char* bws, const BwdPlan& bp, hipStream_t s) {
+    const int K = c.objects;
+    const TypePlan& tp = plan.type[t];
+    const GroupPlan& gp = bp.group;
+    int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
+    const int F = objs[0].coarse.output_features;
+    const int Fs = (F + 15) & ~15;
+    PR_CHECK_HIP(hipMemsetAsync(bws + gp.zero_begin, 0, gp.zero_bytes, s));
+    CompositeBwdResult cr;
+    PR_TRY(composite_backward(c, objs, t, grads, out, fws, plan, bws, bp, s, &cr));
+
+    static thread_local HeadBwdJob h1[PR_MAX_OBJECTS], h2[PR_MAX_OBJECTS];
+    static thread_local ChainBwdJob cn[PR_MAX_OBJECTS], cb[PR_MAX_OBJECTS];
+    static thread_local PostNerfJobs pn;
+    static thread_local PostBenderJobs pb;
+    static thread_local StyleBwdJobs sj;
+    static thread_local GeometryBwdJobs gj;
+    constexpr int MAX_TN_JOBS_CALL = PR_MAX_OBJECTS * 24;     // 13 products per NeRF + 8 per ray bender
+    static thread_local TnJob tn_jobs[MAX_TN_JOBS_CALL];
+    static thread_local TnAll tn;
+    long rows[PR_MAX_OBJECTS], rows_b[PR_MAX_OBJECTS], tn_rows[MAX_TN_JOBS_CALL];
+    int tn_count = 0;
+    int benders = 0, style_jobs = 0;
+    int style_blocks = 0;
+    int32_t* counters = reinterpret_cast<int32_t*>(bws + gp.counters);
+    float* tn_at = reinterpret_cast<float*>(bws + gp.tn_partial);
+    size_t tn_used = 0;
+    memset(&sj, 0, sizeof(sj));
+    sj.frames = c.frames;
+    long max_cap = 0;
+
+    for (int k = 0; k < K; ++k) {
+        const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+        const pr_model_grads_t& G = t ? out.model_fine[k] : out.model[k];
+        const float* packed = static_cast<const float*>(t ? objs[k].packed_fine : objs[k].packed_coarse);
+        const SavedPlan& sv = tp.saved[k];
+        ModelDims d;
+        PackedLayout l;
+        PR_TRY(compute_dims(m, &d));
+        PR_TRY(compute_layout(m, d, &l));
+        PR_REQUIRE(d.Fpad % 16 == 0 && Fs <= d.Fpad, "backward: feature rows of %d floats", Fs);
+        const int P = m.positions;
+        const size_t cap = (size_t)c.frames * c.rays * P;
+        rows[k] = (long)cap;
+        if ((long)cap > max_cap) max_cap = (long)cap;
+        RowCtx rc;
+        rc.total = totals + k;
+        rc.rec_flat = reinterpret_cast<const int32_t*>(fws + sv.rec_flat);
+        rc.row_flags = reinterpret_cast<const int32_t*>(fws + sv.row_flags);
+        rc.samples_per_frame = c.rays * P;
+        rc.in_scene = c.object_in_scene + k; rc.in_scene_stride = K;
+        const float* rec_pos = reinterpret_cast<const float*>(fws + sv.rec_pos);
+        const float* enc = reinterpret_cast<const float*>(fws + sv.enc);
+        const float* acts = reinterpret_cast<const float*>(fws + sv.act);
+        const size_t act_stride = cap * d.Wpad;
+        const float* h1v = reinterpret_cast<const float*>(fws + sv.h1);
+        const float* h2v = reinterpret_cast<const float*>(fws + sv.h2);
+        const float* batch = reinterpret_cast<const float*>(fws + sv.batch);
+        const int32_t* stat_count = reinterpret_cast<const int32_t*>(fws + sv.stat_count);
+        const float* table = reinterpret_cast<const float*>(fws + tp.adain[k]);
+        const int table_stride = adain_row_floats(d);
+        float* g_feat = reinterpret_cast<float*>(bws + bp.g_feat[k]);
+        float* a2 = reinterpret_cast<float*>(bws + gp.a2[k]);
+        float* d2 = reinterpret_cast<float*>(bws + gp.d2[k]);
+        float* a1 = reinterpret_cast<float*>(bws + gp.a1[k]);
+        float* d1 = reinterpret_cast<float*>(bws + gp.d1[k]);
+        float* gstack = reinterpret_cast<float*>(bws + gp.gstack[k]);
+        float* g_enc = reinterpret_cast<float*>(bws + gp.g_enc[k]);
+        float* gsr4 = reinterpret_cast<float*>(bws + gp.gsr4[k]);
+        float* g_x = reinterpret_cast<float*>(bws + gp.g_x[k]);
+        float* g_in6 = reinterpret_cast<float*>(bws + gp.g_in6[k]);
+        double* sums = reinterpret_cast<double*>(bws + gp.sums[k]);
+        float* tables = reinterpret_cast<float*>(bws + gp.tables[k]);
+        float* dscale1 = tables;
+        float* dbias1 = tables + (size_t)c.frames * MAX_WIDTH;
+        float* dscale2 = tables + (size_t)c.frames * 2 * MAX_WIDTH;
+        float* dbias2 = tables + (size_t)c.frames * 3 * MAX_WIDTH;
+        const int frozen = (c.flags & PR_FLAG_TRAIN_BN) ? 0 : 1;
+        float lo[3], hi[3], size[3];
+        bbox_split(m, lo, hi, size);
+        const int nb = m.backbone_count;
+
+        // ---- feature head, phases 1 and 2 ------------------------------------------------------------
+        HeadBwdJob& a = h1[k];
+        memset(&a, 0, sizeof(a));
+        a.total = totals + k; a.rec_flat = rc.rec_flat; a.row_flags = rc.row_flags; a.samples_per_frame = rc.samples_per_frame;
+        a.phase = 1; a.frozen = frozen; a.stat_count = stat_count; a.eps = m.bn_eps;
+        a.table = table; a.table_stride = table_stride; a.goff = 2 * d.Wpad; a.boff = 2 * d.Wpad + d.W2pad;
+        a.g_in = g_feat; a.ld_gin = Fs; a.k_real = F; a.kpad = d.Fpad;
+        a.wt = Seg{packed + l.t_h6, d.Fpad / 8, 0}; a.nblk = d.W2pad / 32;
+        a.h = h2v; a.ld = d.W2pad; a.mean = batch + 2 * MAX_WIDTH; a.var = batch + 3 * MAX_WIDTH; a.width = d.W2;
+        a.a_out = a2; a.d_out = d2; a.sums = sums; a.dscale = dscale2; a.dbias = dbias2;
+        a.tile_counter = counters + 4 * k;
+        HeadBwdJob& b = h2[k];
+        b = a;
+        b.phase = 2;
+        b.goff = 0; b.boff = d.Wpad;
+        b.g_in = nullptr;
+        b.d_in = d2; b.h_in = h2v; b.mean_in = batch + 2 * MAX_WIDTH; b.var_in = batch + 3 * MAX_WIDTH; b.sums_in = sums; b.width_in = d.W2;
+        b.kpad = d.W2pad;
+        b.wt = Seg{packed + l.t_h3, d.W2pad / 8, 0}; b.nblk = d.Wpad / 32;
+        b.h = h1v; b.ld = d.Wpad; b.mean = batch; b.var = batch + MAX_WIDTH; b.width = d.W;
+        b.a_out = a1; b.d_out = d1; b.sums = sums + 2 * MAX_WIDTH; b.dscale = dscale1; b.dbias = dbias1;
+        b.tile_counter = counters + 4 * k + 1;
+
+        // ---- NeRF chain ---------------------------------------------------------------------------------
+        ChainBwdJob& n = cn[k];
+        memset(&n, 0, sizeof(n));
+        n.total = totals + k; n.rec_flat = rc.rec_flat; n.row_flags = rc.row_flags; n.samples_per_frame = rc.samples_per_frame;
+        n.entry = 1;
+        n.d1 = d1; n.h1 = h1v; n.mean1 = batch; n.var1 = batch + MAX_WIDTH; n.sums1 = sums + 2 * MAX_WIDTH;
+        n.stat_count = stat_count; n.frozen = frozen; n.eps = m.bn_eps;
+        n.w0t = Seg{packed + l.t_h0, d.Wpad / 8, 0};
+        n.g_sigma = reinterpret_cast<const float*>(bws + bp.g_sigma[k]);
+        n.in_scene = rc.in_scene; n.in_scene_stride = K;
+        n.w_sigma = m.kind == 0 ? m.alpha_head.weight : nullptr;
+        n.gsr4 = gsr4;
+        n.count = nb; n.skip = m.skip_layer_idx; n.W = d.W; n.Wpad = d.Wpad; n.in_pad = d.enc_pad; n.in_real = d.enc;
+        for (int i = 1; i < nb; ++i) n.act_t[i] = Seg{packed + l.t_n_act[i], d.Wpad / 8, 0};
+        n.in0_skip = Seg{packed + l.t_n_skip, d.Wpad / 8, 0};
+        n.in0_first = Seg{packed + l.t_n_first, d.Wpad / 8, 0};
+        n.bits = reinterpret_cast<const unsigned char*>(fws + sv.bits); n.bits_stride = cap * (size_t)(d.Wpad / 8);
+        n.gstack = gstack; n.g_stride = cap * (size_t)d.Wpad;
+        n.g_in = g_enc; n.ld_in = d.enc_pad;
+        n.tile_counter = counters + 4 * k + 2;
+
+        // ---- rows after the NeRF chain ---------------------------------------------------------------------
+        PostNerfJob& q = pn.job[k];
+        memset(&q, 0, sizeof(q));
+        q.r = rc; q.kind = m.kind; q.has_bender = m.has_bender; q.octaves = m.octaves; q.ld = d.enc_pad;
+        q.enc = enc; q.g_enc = g_enc;
+        for (int ax = 0; ax < 3; ++ax) { q.size[ax] = size[ax]; q.lo[ax] = lo[ax]; q.hi[ax] = hi[ax]; }
+        q.g_x = g_x; q.g_in6 = g_in6;
+
+        // ---- weight gradients --------------------------------------------------------------------------------
+        auto add = [&](const float* dY, int ldy, int ni, const float* X, int ldx, int nj, float* dW, int ldw, float* dbias) -> int {
+            if (!dW) {
+                PR_REQUIRE(!dbias, "a bias gradient buffer needs its weight gradient buffer");
+                return PR_OK;
+            }
+            PR_REQUIRE(tn_count < MAX_TN_JOBS_CALL, "backward: too many weight-gradient products");
+            TnJob& j = tn_jobs[tn_count];
+            memset(&j, 0, sizeof(j));
+            j.A = dY; j.lda = ldy; j.B = X; j.ldb = ldx; j.C = dW; j.ldc = ldw; j.bias = dbias;
+            j.rows = totals + k; j.ni = ni; j.nj = nj;
+            const size_t need = tn_all_partial_floats(ni, nj, (long)cap);
+            PR_REQUIRE(tn_used + need <= gp.tn_partial_floats, "backward: weight-gradient scratch exhausted");
+            j.partial = tn_at + tn_used;
+            tn_used += need;
+            tn_rows[tn_count] = (long)cap;
+            ++tn_count;
+            return PR_OK;
+        };
+        PR_TRY(add(g_feat, Fs, F, a2, d.W2pad, d.W2, G.head6.weight, d.W2, G.head6.bias));
+        PR_TRY(add(d2, d.W2pad, d.W2, a1, d.Wpad, d.W, G.head3.weight, d.W, nullptr));
+        const float* act_last = acts + (size_t)(nb - 1) * act_stride;
+        PR_TRY(add(d1, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr));
+        if (m.kind == 0) PR_TRY(add(gsr4, 4, 1, act_last, d.Wpad, d.W, G.alpha_head.weight, d.W, G.alpha_head.bias));
+        for (int i = nb - 1; i >= 0; --i) {
+            const float* dY = gstack + (size_t)i * n.g_stride;
+            const int inf = m.backbone[i].in_features;
+            if (i == 0) {
+                PR_TRY(add(dY, d.Wpad, d.W, enc, d.enc_pad, d.enc, G.backbone[i].weight, inf, G.backbone[i].bias));
+            } else {
+                PR_TRY(add(dY, d.Wpad, d.W, acts + (size_t)(i - 1) * act_stride, d.Wpad, d.W, G.backbone[i].weight, inf, G.backbone[i].bias));
+                if (i == m.skip_layer_idx)
+                    PR_TRY(add(dY, d.Wpad, d.W, enc, d.enc_pad, d.enc, G.backbone[i].weight ? G.backbone[i].weight + d.W : nullptr, inf, nullptr));
+            }
+        }
+
+        // ---- ray bender ----------------------------------------------------------------------------------------
+        if (m.has_bender) {
+            PR_REQUIRE(m.kind == 0, "backward: a skybox model with a ray bender is not supported");
+            const float* bin = reinterpret_cast<const float*>(fws + sv.bin);
+            const float* bacts = reinterpret_cast<const float*>(fws + sv.bact);
+            const size_t bact_stride = cap * d.BWpad;
+            float* g_braw4 = reinterpret_cast<float*>(bws + gp.g_braw4[k]);
+            float* bgstack = reinterpret_cast<float*>(bws + gp.bgstack[k]);
+            float* g_benc = reinterpret_cast<float*>(bws + gp.g_benc[k]);
+            const int bc = m.bender_count;
+            q.g_dm = reinterpret_cast<const float*>(bws + bp.g_dm[k]);
+            q.g_delta_dense = grads.sample_delta[k];
+            q.delta = reinterpret_cast<const float*>(fws + sv.delta);
+            q.braw = reinterpret_cast<const float*>(fws + sv.braw);
+            q.pos = rec_pos;
+            q.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+            q.g_braw4 = g_braw4;
+            ChainBwdJob& e = cb[benders];
+            memset(&e, 0, sizeof(e));
+            e.total = totals + k; e.rec_flat = rc.rec_flat; e.row_flags = rc.row_flags; e.samples_per_frame = rc.samples_per_frame;
+            e.entry = 0;
+            e.g_braw4 = g_braw4; e.w_out = m.bender_out.weight; e.w_out_ld = d.BW;
+            e.count = bc; e.skip = m.bender_skip; e.W = d.BW; e.Wpad = d.BWpad; e.in_pad = d.bin_pad; e.in_real = d.bin;
+            for (int i = 1; i < bc; ++i) e.act_t[i] = Seg{packed + l.t_b_act[i], d.BWpad / 8, 0};
+            e.in0_skip = Seg{packed + l.t_b_skip, d.BWpad / 8, 0};
+            e.in0_first = Seg{packed + l.t_b_first, d.BWpad / 8, 0};
+            e.bits = reinterpret_cast<const unsigned char*>(fws + sv.bbits); e.bits_stride = cap * (size_t)(d.BWpad / 8);
+            e.gstack = bgstack; e.g_stride = cap * (size_t)d.BWpad;
+            e.g_in = g_benc; e.ld_in = d.bin_pad;
+            e.tile_counter = counters + 4 * k + 3;
+            rows_b[benders] = (long)cap;
+            PostBenderJob& w = pb.job[benders];
+            memset(&w, 0, sizeof(w));
+            w.r = rc; w.bin = bin; w.g_bin = g_benc; w.ld = d.bin_pad; w.octaves = m.bender_octaves; w.benc = d.benc;
+            w.D = m.deformation_features;
+            for (int ax = 0; ax < 3; ++ax) w.size[ax] = size[ax];
+            w.g_x = g_x;
+            w.d_def = out.deformation ? out.deformation + (size_t)k * m.deformation_features : nullptr;
+            w.def_stride = K * m.deformation_features;
+            ++benders;
+            PR_TRY(add(g_braw4, 4, 3, bacts + (size_t)(bc - 1) * bact_stride, d.BWpad, d.BW, G.bender_out.weight, d.BW, nullptr));
+            for (int i = bc - 1; i >= 0; --i) {
+                const float* dY = bgstack + (size_t)i * e.g_stride;
+                const int inf = m.bender[i].in_features;
+                if (i == 0) {
+                    PR_TRY(add(dY, d.BWpad, d.BW, bin, d.bin_pad, d.bin, G.bender[i].weight, inf, G.bender[i].bias));
+                } else {
+                    PR_TRY(add(dY, d.BWpad, d.BW, bacts + (size_t)(i - 1) * bact_stride, d.BWpad, d.BW, G.bender[i].weight, inf, G.bender[i].bias));
+                    if (i == m.bender_skip)
+                        PR_TRY(add(dY, d.BWpad, d.BW, bin, d.bin_pad, d.bin, G.bender[i].weight ? G.bender[i].weight + d.BW : nullptr, inf, nullptr));
+                }
+            }
+        }
+
+        // ---- style affines -------------------------------------------------------------------------------------
+        {
+            const int S = m.style_features;
+            StyleBwdJob& s1 = sj.job[style_jobs++];
+            s1.width = d.W; s1.S = S; s1.dscale = dscale1; s1.dbias = dbias1;
+            s1.style = c.style + (size_t)k * S; s1.style_stride = K * S;
+            s1.A = m.affine1.weight; s1.dA = G.affine1.weight; s1.db = G.affine1.bias;
+            s1.d_style = out.style ? out.style + (size_t)k * S : nullptr;
+            StyleBwdJob& s2 = sj.job[style_jobs++];
+            s2 = s1;
+            s2.width = d.W2; s2.dscale = dscale2; s2.dbias = dbias2;
+            s2.A = m.affine4.weight; s2.dA = G.affine4.weight; s2.db = G.affine4.bias;
+            const int blocks = c.frames + (int)(((long)2 * d.W * S + 255) / 256);
+            if (blocks > style_blocks) style_blocks = blocks;
+        }
+
+        // ---- sample placement -> object pose, camera rays ----------------------------------------------------------
+        {
+            GeometryBwd& gb = gj.job[k];
+            memset(&gb, 0, sizeof(gb));
+            gb.frames = c.frames; gb.rays = c.rays; gb.positions = P; gb.objects = K; gb.object_index = k; gb.kind = m.kind;
+            gb.ray_origins = c.ray_origins; gb.ray_directions = c.ray_directions; gb.w2o = c.w2o; gb.in_scene = c.object_in_scene;
+            for (int ax = 0; ax < 3; ++ax) { gb.lo[ax] = lo[ax]; gb.hi[ax] = hi[ax]; }
+            gb.z_near_min = m.z_near_min; gb.z_far_max = m.z_far_max;
+            gb.linspace = c.linspace_coarse[k];
+            gb.jitter = perturb_noise(c.noise_coarse.jitter[k], c, NOISE_JITTER, 0, k);
+            if (t) {
+                gb.t_coarse = reinterpret_cast<const float*>(fws + plan.type[0].t[k]);
+                gb.pc = objs[k].coarse.positions;
+            }
+            gb.t = reinterpret_cast<const float*>(fws + tp.t[k]);
+            gb.slot = reinterpret_cast<const int32_t*>(fws + tp.slot[k]);
+            gb.g_t = reinterpret_cast<const float*>(bws + bp.g_t[k]);
+            gb.g_x = m.kind == 0 ? g_x : nullptr;
+            gb.g_in6 = m.kind == 1 ? g_in6 : nullptr;
+            gb.d_w2o = out.w2o;
+            gb.d_ray_origins = out.ray_origins;
+            gb.d_ray_directions = out.ray_directions;
+            gb.g_norm = (k == 0) ? cr.g_norm : nullptr;
+        }
+    }
+
+    PR_TRY(launch_head_bwd_group(h1, rows, K, s));
+    PR_TRY(launch_head_bwd_group(h2, rows, K, s));
+    PR_TRY(launch_chain_bwd_group(cn, rows, K, s));
+    const int row_blocks = (int)((max_cap + 255) / 256);
+    if (row_blocks > 0) {
+        hipLaunchKernelGGL(k_post_nerf_group, dim3(row_blocks, K), dim3(256), 0, s, pn);
+        PR_LAUNCH_CHECK();
+    }
+    if (benders) {
+        PR_TRY(launch_chain_bwd_group(cb, rows_b, benders, s));
+        long cap_b = 0;
+        for (int i = 0; i < benders; ++i) cap_b = std::max(cap_b, rows_b[i]);
+        hipLaunchKernelGGL(k_post_bender_group, dim3((unsigned)((cap_b + 255) / 256), benders), dim3(256), 0, s, pb);
+        PR_LAUNCH_CHECK();
+    }
+    // every weight gradient of the call: one launch (+ its reduction) per TN_ALL_MAX products, each with its own claim counters;
+    // instances of one model that land in different launches accumulate one after the other (same stream)
+    for (int begin = 0, chunk = 0; begin < tn_count; begin += TN_ALL_MAX, ++chunk) {
+        tn.count = std::min(TN_ALL_MAX, tn_count - begin);
+        memcpy(tn.job, tn_jobs + begin, sizeof(TnJob) * tn.count);
+        tn.counters = counters + 4 * PR_MAX_OBJECTS + 8 * chunk;
+        PR_TRY(launch_gemm_tn_all(tn, tn_rows + begin, s));
+    }
+    hipLaunchKernelGGL(k_style_bwd_group, dim3(style_blocks, style_jobs), dim3(256), 0, s, sj);
+    PR_LAUNCH_CHECK();
+    if (out.w2o || cr.ray_grads) {
+        hipLaunchKernelGGL(k_geometry_bwd_group, dim3((c.rays + 255) / 256, c.frames, K), dim3(256), 0, s, gj);
+        PR_LAUNCH_CHECK();
+    }
     return PR_OK;
 }
 
@@ -1610,11 +2215,13 @@ extern "C" int pr_render_backward(const pr_call_t* call, const pr_object_t* obje
         return PR_ERR_WORKSPACE;
     }
     PR_REQUIRE((((uintptr_t)forward_workspace | (uintptr_t)backward_workspace) & 255) == 0, "workspaces must be 256-byte aligned");
-    PR_TRY(pr::backward(*call, objects, 0, *grads, *out, static_cast<char*>(forward_workspace), plan,
-                        static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
+    // calls with gradients of the divergence estimate, or whose scratch would not fit, take the per-object path
+    auto pass = bp.group.usable ? pr::backward_grouped : pr::backward;
+    PR_TRY(pass(*call, objects, 0, *grads, *out, static_cast<char*>(forward_workspace), plan,
+                static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
     if (call->use_fine)
-        PR_TRY(pr::backward(*call, objects, 1, *grads_fine, *out, static_cast<char*>(forward_workspace), plan,
-                            static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
+        PR_TRY(pass(*call, objects, 1, *grads_fine, *out, static_cast<char*>(forward_workspace), plan,
+                    static_cast<char*>(backward_workspace), bp, (hipStream_t)stream));
     return PR_OK;
 }
 

@@ -333,6 +333,231 @@ __device__ __forceinline__ void gemm_tn_reduce_body(const GemmTN& p, long idx) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Every weight-gradient product of a backward pass in ONE launch (+ one reduction launch): all layers of all objects.
+//
+// A persistent grid (two workgroups per CU).  Work items are (job, split, tile): job = one dW = dY^T . X product, split = a
+// range of TN_ALL_CHUNK sample rows (the sample counts live on the device, so the decomposition is computed by every workgroup
+// from the jobs' row counts), tile = a 128 x 128 block of the gradient.  The tiles of one (job, split) pair read the same dY
+// and X rows: pairs are dealt to the 8 XCDs (pair index mod 8 - workgroup b runs on XCD b mod 8) and the workgroups of an
+// XCD claim that XCD's items from its own counter, tile index fastest, so that the tiles of a pair run at the same time on
+// CUs that share an L2 and the operands come from HBM once.  Every pair owns TN_ALL_TILES claim slots (the largest tile
+// count: the 256 x 384 skip layers); slots beyond a job's tile count are empty claims.
+// The reduction adds the partial tiles in split order and - object instances that share a model accumulate into the same
+// buffers - walks the jobs of a destination in job order (chain_next), so the gradients are bit-reproducible.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_all_splits(int M) {
+    const int s = (M + TN_ALL_CHUNK - 1) / TN_ALL_CHUNK;
+    return s < 1 ? 1 : s;        // split 0 always exists (M == 0: zeros)
+}
+
+__device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split, float* SA, float* SB) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
+    const int M = *p.rows;
+    const int tiles_j = (p.nj + GT - 1) / GT;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * GT, j0 = tj * GT;
+    const int m_begin = split * TN_ALL_CHUNK;
+    const int m_end = (m_begin + TN_ALL_CHUNK < M) ? m_begin + TN_ALL_CHUNK : M;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float bsum = 0.f;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const bool acol = i0 + 4 * c4 < ((p.ni + 3) & ~3), bcol = j0 + 4 * c4 < ((p.nj + 3) & ~3);
+    float4 ra[4], rb[4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rr + 8 * i;
+            const bool live = m < m_end;
+            ra[i] = (live && acol) ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + i0 + 4 * c4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = (live && bcol) ? *reinterpret_cast<const float4*>(p.B + (size_t)m * p.ldb + j0 + 4 * c4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&SA[(rr + 8 * i) * GLD + 4 * c4]) = ra[i];
+            *reinterpret_cast<float4*>(&SB[(rr + 8 * i) * GLD + 4 * c4]) = rb[i];
+        }
+    };
+    if (m_begin < m_end) {
+        fetch(m_begin);
+        stage();
+    }
+    __syncthreads();
+    for (int m0 = m_begin; m0 < m_end; m0 += GK) {
+        const bool more = m0 + GK < m_end;
+        if (more) fetch(m0 + GK);
+        if (p.bias_partial && tj == 0 && tid < GT) {
+#pragma unroll
+            for (int q = 0; q < GK; ++q) bsum += SA[q * GLD + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a0 = SA[(kk + half) * GLD + wr * 64 + r];
+            const float a1 = SA[(kk + half) * GLD + wr * 64 + 32 + r];
+            const float b0 = SB[(kk + half) * GLD + wc * 64 + r];
+            const float b1 = SB[(kk + half) * GLD + wc * 64 + 32 + r];
+            PR_MFMA32(acc[0][0], a0, b0);
+            PR_MFMA32(acc[0][1], a0, b1);
+            PR_MFMA32(acc[1][0], a1, b0);
+            PR_MFMA32(acc[1][1], a1, b1);
+        }
+        __syncthreads();
+        if (more) stage();
+        __syncthreads();
+    }
+    const int ldp = tiles_j * GT;
+    const int rows_p = ((p.ni + GT - 1) / GT) * GT;
+    float* P = p.partial + (size_t)split * rows_p * ldp;
+#pragma unroll
+    for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = j0 + wc * 64 + cb * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                P[(size_t)row * ldp + col] = acc[rb2][cb][i];
+            }
+        }
+    if (p.bias_partial && tj == 0 && tid < GT) p.bias_partial[(size_t)split * rows_p + i0 + tid] = bsum;
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_all(TnAll g) {
+    __shared__ __attribute__((aligned(16))) float SA[GK * GLD];
+    __shared__ __attribute__((aligned(16))) float SB[GK * GLD];
+    __shared__ int pair_begin[TN_ALL_MAX + 1];    // first (job, split) pair of every job
+    __shared__ int claimed;
+    const int tid = threadIdx.x;
+    // the decomposition follows the jobs' row counts, which live on the device: every workgroup derives it on its own
+    if (tid < g.count) pair_begin[tid + 1] = tn_all_splits(*g.job[tid].rows);
+    __syncthreads();
+    if (tid == 0) {
+        int at = 0;
+        for (int q = 0; q < g.count; ++q) {
+            const int n = pair_begin[q + 1];
+            pair_begin[q] = at;
+            at += n;
+        }
+        pair_begin[g.count] = at;
+    }
+    __syncthreads();
+    const int total_pairs = pair_begin[g.count];
+    const int xcd = blockIdx.x & 7;
+    int job = 0;
+    for (;;) {
+        if (tid == 0) claimed = atomicAdd(g.counters + xcd, 1);
+        __syncthreads();
+        const int c = claimed;
+        __syncthreads();           // everyone has read the claim before thread 0 overwrites it
+        const int pair = (c / TN_ALL_TILES) * 8 + xcd;
+        if (pair >= total_pairs) break;
+        const int tile = c % TN_ALL_TILES;
+        while (pair >= pair_begin[job + 1]) ++job;      // claims of an XCD are increasing
+        const TnJob& p = g.job[job];
+        const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+        if (tile >= tiles) continue;
+        tn_all_tile(p, tile, pair - pair_begin[job], SA, SB);
+        __syncthreads();           // the slabs are reused by the next item
+    }
+}
+
+// C[i][j] += sum over the jobs of this destination (job order), sum over their splits (split order); the same for the biases
+__global__ __launch_bounds__(256) void k_gemm_tn_all_reduce(TnAll g) {
+    const TnJob& head = g.job[blockIdx.y];
+    if (!head.head) return;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tiles_j = (head.nj + GT - 1) / GT;
+    const int ldp = tiles_j * GT;
+    const int rows_p = ((head.ni + GT - 1) / GT) * GT;
+    const size_t stride = (size_t)rows_p * ldp;
+    if (idx < (long)head.ni * head.nj) {
+        const int i = (int)(idx / head.nj), j = (int)(idx - (long)i * head.nj);
+        float v = 0.f;
+        for (int q = blockIdx.y; q >= 0; q = g.job[q].chain_next) {
+            const TnJob& p = g.job[q];
+            const int active = tn_all_splits(*p.rows);
+            const float* __restrict__ src = p.partial + (size_t)i * ldp + j;
+            int s = 0;
+            for (; s + 8 <= active; s += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(s + u) * stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; s < active; ++s) v += src[(size_t)s * stride];
+        }
+        head.C[(size_t)i * head.ldc + j] += v;
+    }
+    if (head.bias && idx < head.ni) {
+        float v = 0.f;
+        for (int q = blockIdx.y; q >= 0; q = g.job[q].chain_next) {
+            const TnJob& p = g.job[q];
+            if (!p.bias_partial) continue;
+            const int active = tn_all_splits(*p.rows);
+            for (int s = 0; s < active; ++s) v += p.bias_partial[(size_t)s * rows_p + idx];
+        }
+        head.bias[idx] += v;
+    }
+}
+
+size_t tn_all_partial_floats(int ni, int nj, long max_rows) {
+    const size_t rows_p = (size_t)((ni + GT - 1) / GT) * GT, ldp = (size_t)((nj + GT - 1) / GT) * GT;
+    size_t splits = (size_t)((max_rows + TN_ALL_CHUNK - 1) / TN_ALL_CHUNK);
+    if (splits < 1) splits = 1;
+    return splits * (rows_p * ldp + rows_p);
+}
+
+// Links the jobs that accumulate into the same gradient buffer (chain_next / head) and launches the two kernels.
+// `counters`: 8 zeroed ints.
+int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
+    if (g.count <= 0) return PR_OK;
+    PR_REQUIRE(g.count <= TN_ALL_MAX && g.counters, "gemm_tn_all: %d jobs", g.count);
+    long max_elems = 0;
+    for (int q = 0; q < g.count; ++q) {
+        TnJob& p = g.job[q];
+        PR_REQUIRE(p.ni >= 1 && p.nj >= 1 && p.ni <= 256 && p.nj <= 384, "gemm_tn_all: %d x %d exceeds the tile slots", p.ni, p.nj);
+        PR_REQUIRE((p.lda & 3) == 0 && (p.ldb & 3) == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 &&
+                   p.lda >= ((p.ni + 3) & ~3) && p.ldb >= ((p.nj + 3) & ~3), "gemm_tn_all: operands must be 16-byte aligned rows");
+        PR_REQUIRE(p.C && p.partial && p.rows, "gemm_tn_all: NULL pointer");
+        PR_REQUIRE(((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT) <= TN_ALL_TILES, "gemm_tn_all: too many tiles");
+        // bias partials follow the weight partials of the job's region
+        const size_t rows_p = (size_t)((p.ni + GT - 1) / GT) * GT, ldp = (size_t)((p.nj + GT - 1) / GT) * GT;
+        size_t splits = (size_t)((max_rows[q] + TN_ALL_CHUNK - 1) / TN_ALL_CHUNK);
+        if (splits < 1) splits = 1;
+        p.bias_partial = p.bias ? p.partial + splits * rows_p * ldp : nullptr;
+        p.chain_next = -1;
+        p.head = 1;
+        if ((long)p.ni * p.nj > max_elems) max_elems = (long)p.ni * p.nj;
+    }
+    // the LAST job of a destination is its head and walks back through the earlier ones: the additions run in job order
+    // reversed - any fixed order is reproducible
+    for (int q = 0; q < g.count; ++q)
+        for (int e = q - 1; e >= 0; --e)
+            if (g.job[e].C == g.job[q].C) {
+                PR_REQUIRE(g.job[e].ni == g.job[q].ni && g.job[e].nj == g.job[q].nj && g.job[e].ldc == g.job[q].ldc &&
+                           g.job[e].bias == g.job[q].bias, "gemm_tn_all: jobs of one destination differ in shape");
+                g.job[q].chain_next = e;
+                g.job[e].head = 0;
+                break;
+            }
+    int cus = 0;
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all), 0, &cus));
+    ProfileScope scope(3, s);
+    hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * 2), dim3(256), 0, s, g);
+    PR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gemm_tn_all_reduce, dim3((unsigned)((max_elems + 255) / 256), g.count), dim3(256), 0, s, g);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 size_t gemm_tn_scratch_floats(int splits) {
     // largest gradient: 256 x 384 (skip layer) partial tiles + bias partials
     return (size_t)splits * (256 * 384 + 256);

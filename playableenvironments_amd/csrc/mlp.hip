@@ -103,6 +103,31 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
     off += seg_floats(d.Fpad / 32, d.W2pad);
     l->h6_bias_off = off;
     off += d.Fpad;
+    // transposed segments of the backward pass: K = the layer's outputs, N = its inputs
+    if (m.has_bender) {
+        for (int j = 1; j < m.bender_count; ++j) {
+            l->t_b_act[j] = off;
+            off += seg_floats(d.BWpad / 32, d.BWpad);
+        }
+        l->t_b_skip = off;
+        off += seg_floats(d.bin_pad / 32, d.BWpad);
+        l->t_b_first = off;
+        off += seg_floats(d.bin_pad / 32, d.BWpad);
+    }
+    for (int i = 1; i < m.backbone_count; ++i) {
+        l->t_n_act[i] = off;
+        off += seg_floats(d.Wpad / 32, d.Wpad);
+    }
+    l->t_n_skip = off;
+    off += seg_floats(d.enc_pad / 32, d.Wpad);
+    l->t_n_first = off;
+    off += seg_floats(d.enc_pad / 32, d.Wpad);
+    l->t_h0 = off;
+    off += seg_floats(d.Wpad / 32, d.Wpad);
+    l->t_h3 = off;
+    off += seg_floats(d.Wpad / 32, d.W2pad);
+    l->t_h6 = off;
+    off += seg_floats(d.W2pad / 32, d.Fpad);
     l->total = off;
     return PR_OK;
 }
@@ -124,7 +149,7 @@ struct PackJob {
     int count;      // elements of dst
     int transposed; // kind 0: element (n, k) is read from src[k * in_total + col_off + n] (the backward chain's W^T)
 };
-constexpr int MAX_PACK_JOBS = 56;
+constexpr int MAX_PACK_JOBS = 112;
 struct PackJobs {
     PackJob job[MAX_PACK_JOBS];
     int n;
@@ -193,6 +218,17 @@ static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real
     j.nblk = npad / 32;
     j.count = seg_floats(j.nblk, kpad);
     j.transposed = 0;
+    return PR_OK;
+}
+
+// W^T of a Linear as a segment: out[m][n] = sum_k G[m][k] W[k][col_off + n] - K = the layer's outputs (k_real of kpad), N = n_real
+// of its inputs starting at column col_off (npad)
+static int add_seg_t(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int n_real, int npad, float* dst) {
+    PR_TRY(add_seg(js, lin, col_off, k_real, kpad, npad, dst));
+    PackJob& j = js->job[js->n - 1];
+    j.kind = 0;            // fp32 fragments in every packing (differentiable calls run on the exact kernel)
+    j.n_real = n_real;
+    j.transposed = 1;
     return PR_OK;
 }
 
@@ -275,6 +311,20 @@ static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const
     PR_TRY(add_seg(js, m.head3, 0, d.W, d.Wpad, d.W2pad, base + l.h3_off));
     PR_TRY(add_seg(js, m.head6, 0, d.W2, d.W2pad, d.Fpad, base + l.h6_off));
     PR_TRY(add_vec(js, m.head6.bias, 1, d.F, d.F, d.Fpad, base + l.h6_bias_off));
+    if (js->seg_kind != 0) return PR_OK;      // the backward pass runs on the fp32 packing only
+    if (m.has_bender) {
+        for (int j = 1; j < m.bender_count; ++j)
+            PR_TRY(add_seg_t(js, m.bender[j], 0, d.BW, d.BWpad, d.BW, d.BWpad, base + l.t_b_act[j]));
+        PR_TRY(add_seg_t(js, m.bender[m.bender_skip], d.BW, d.BW, d.BWpad, d.bin, d.bin_pad, base + l.t_b_skip));
+        PR_TRY(add_seg_t(js, m.bender[0], 0, d.BW, d.BWpad, d.bin, d.bin_pad, base + l.t_b_first));
+    }
+    for (int i = 1; i < m.backbone_count; ++i)
+        PR_TRY(add_seg_t(js, m.backbone[i], 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t_n_act[i]));
+    PR_TRY(add_seg_t(js, m.backbone[m.skip_layer_idx], d.W, d.W, d.Wpad, d.enc, d.enc_pad, base + l.t_n_skip));
+    PR_TRY(add_seg_t(js, m.backbone[0], 0, d.W, d.Wpad, d.enc, d.enc_pad, base + l.t_n_first));
+    PR_TRY(add_seg_t(js, m.head0, 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t_h0));
+    PR_TRY(add_seg_t(js, m.head3, 0, d.W2, d.W2pad, d.W, d.Wpad, base + l.t_h3));
+    PR_TRY(add_seg_t(js, m.head6, 0, d.F, d.Fpad, d.W2, d.W2pad, base + l.t_h6));
     return PR_OK;
 }
 

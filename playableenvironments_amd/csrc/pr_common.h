@@ -106,7 +106,10 @@ struct PackedLayout {
     int n_bias_off[PR_MAX_LAYERS];
     int sigma_off;                     // raw copy (Wpad) + bias at [Wpad]
     int h0_off, h3_off, h6_off, h6_bias_off;
-    // AdaIN affine (raw copies): affine1 W (2W x S) + b (2W), bn1 mean/var ...
+    // backward pass (fp32 packing only): W^T as fragment-ordered segments, out[m][n] = sum_k G[m][k] W[k][col_off + n]
+    int t_b_act[PR_MAX_LAYERS], t_b_skip, t_b_first;   // bender chain: W_l[:, :BW]^T (l >= 1), W_skip[:, BW:]^T, W_0^T
+    int t_n_act[PR_MAX_LAYERS], t_n_skip, t_n_first;   // NeRF backbone chain
+    int t_h0, t_h3, t_h6;                              // head0^T (W -> W), head3^T (W/2 -> W), head6^T (F -> W/2)
     int total;
 };
 
@@ -463,6 +466,83 @@ struct GemmTNGroup {
     int count;
 };
 int launch_gemm_tn_group(const GemmTNGroup& g, hipStream_t s);
+
+// Fused tile kernels of the backward pass (train_bwd.hip).  One job = one object instance of one model type.
+struct HeadBwdJob {                 // feature-head backward, phase 1 (head layer 6 -> AdaIN 4) or 2 (head layer 3 -> AdaIN 1)
+    const int32_t* total;           // device scalar: evaluated rows
+    const int32_t* rec_flat;        // (cap) flat sample index of a row
+    const int32_t* row_flags;       // (cap) bit 0 real sample, bit 1 passed the second AABB test
+    int samples_per_frame;
+    int phase;
+    int frozen;                     // eval-mode BatchNorm: the statistics are constants
+    const int32_t* stat_count;      // rows that entered the batch statistics
+    float eps;
+    const float* table; int table_stride;   // AdaIN table rows (frames) of the object; [g | b] of this phase's layer at goff / boff
+    int goff, boff;
+    // the operand.  phase 1: feature-row gradients of the compositing backward (rows of dead samples are cleared in place)
+    float* g_in; int ld_gin, k_real;
+    // phase 2: d loss / d x_hat of head layer 4 (phase 1's d_out) -> BatchNorm backward with the batch terms -> back in place
+    float* d_in; const float* h_in;
+    const float* mean_in; const float* var_in; const double* sums_in; int width_in;
+    int kpad;                       // padded width of the operand (multiple of 16; phase 2: the row stride of d_in / h_in)
+    Seg wt; int nblk;               // W^T fragments (K = kpad, N = nblk * 32): head6^T / head3^T
+    // the layer that is differentiated
+    const float* h; int ld;         // its raw (pre-BatchNorm) activations (cap, ld), ld = nblk * 32
+    const float* mean; const float* var;
+    int width;                      // real channels
+    float* a_out;                   // (cap, ld) relu(AdaIN(h)), recomputed: right factor of the product's weight gradient
+    float* d_out;                   // (cap, ld) d loss / d x_hat
+    double* sums;                   // [sum d x_hat (ld) | sum d x_hat x_hat (ld)], zeroed by the caller
+    float* dscale; float* dbias;    // (frames, MAX_WIDTH) d loss / d AdaIN scale / bias, zeroed by the caller
+    int32_t* tile_counter;          // zeroed
+};
+int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int count, hipStream_t s);
+
+struct ChainBwdJob {                // backward chain of a ReLU MLP with one skip concatenation, entry fused in
+    const int32_t* total; const int32_t* rec_flat; const int32_t* row_flags; int samples_per_frame;
+    int entry;                      // 1: NeRF backbone behind head layer 0 and the sigma head; 0: ray bender behind its output head
+    // entry 1: d loss / d x_hat of head layer 1 (phase 2's d_out) -> BatchNorm backward (in place) -> . head0 -> + sigma path
+    float* d1; const float* h1; const float* mean1; const float* var1; const double* sums1;
+    const int32_t* stat_count; int frozen; float eps;
+    Seg w0t;
+    const float* g_sigma;           // (N,R,P) d loss / d sigma from the compositing backward
+    const uint8_t* in_scene; int in_scene_stride;
+    const float* w_sigma;           // raw alpha_head.weight (W), NULL: no sigma head (skybox)
+    float* gsr4;                    // (cap, 4) out: [d loss / d sigma, 0, 0, 0] per row (left factor of the sigma head's gradient), or NULL
+    // entry 0: d loss / d raw bender output (cap, 4) and the raw output head (3, w_out_ld)
+    const float* g_braw4; const float* w_out; int w_out_ld;
+    // the chain
+    int count, skip, W, Wpad, in_pad, in_real;
+    Seg act_t[PR_MAX_LAYERS];       // l = 1 .. count - 1: W_l[:, :W]^T
+    Seg in0_skip, in0_first;        // W_skip[:, W:]^T and W_0^T
+    const unsigned char* bits; size_t bits_stride;   // ReLU masks of layers 0 .. count - 1 (bit images written by the forward pass)
+    float* gstack; size_t g_stride; // out: pre-activation gradients of layers 0 .. count - 1, (cap, Wpad) each
+    float* g_in; int ld_in;         // out: gradient of the network input (cap, ld_in)
+    int32_t* tile_counter;          // zeroed
+};
+int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int count, hipStream_t s);
+
+// Every weight-gradient product of a backward pass in one launch (k_gemm_tn_all in gemm.hip): the products of all layers of
+// all objects as (job, split of TN_ALL_CHUNK sample rows, 128 x 128 tile) work items of a persistent grid.
+constexpr int TN_ALL_MAX = 96;         // jobs per launch
+constexpr int TN_ALL_CHUNK = 2048;     // sample rows per split
+constexpr int TN_ALL_TILES = 6;        // claim slots per (job, split): the tiles of the largest gradient (256 x 384)
+struct TnJob {             // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += sum_m A[m][i]
+    const float* A; const float* B;
+    float* C; float* bias;             // bias: or NULL
+    const int32_t* rows;               // device scalar: number of sample rows
+    float* partial;                    // tn_all_partial_floats(ni, nj, row capacity) floats: [split][tile rows][tile cols], then the bias partials
+    float* bias_partial;               // (set by the launcher)
+    int lda, ldb, ldc, ni, nj;
+    int chain_next, head;              // (set by the launcher) jobs that share a destination: reduced together, in job order
+};
+struct TnAll {
+    TnJob job[TN_ALL_MAX];
+    int count;
+    int32_t* counters;                 // 8 zeroed ints: the per-XCD claim counters
+};
+size_t tn_all_partial_floats(int ni, int nj, long max_rows);
+int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s);
 
 // Hutchinson divergence estimate e^T (d delta / d x) e of the ray bender (object_composer.py:582-601) as a
 // forward-mode derivative through the saved bender activations; writes the dense (N,R,P) array `div`.

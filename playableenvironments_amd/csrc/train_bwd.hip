@@ -1,6 +1,642 @@
-// Fused tile kernels of the training step's backward pass (feature-head backward phases, grouped backward chains).
+// Fused tile kernels of the training step's backward pass (the reference: torch.autograd through
+// model/nerf_models/adain_style_nerf_model.py:106-145, model/layers/adain.py:39-61, positional_ray_bender_model.py:81-163).
+//
+// A persistent workgroup of 4 waves owns a tile of 64 evaluated samples, the forward kernel's tile (mlp_tile.h): the running
+// gradient lives in LDS as X[64][260] and every product is  out = X . W^T-fragments  on the fp32 matrix cores.  The objects
+// of a call share the launches (up to four job slots per launch; every tile is claimed from the job's counter), so that a
+// small object neither pays launches of its own nor leaves the chip idle behind a large one.
+//
+//   k_head_bwd_group    phase 1: g_feat . W6 -> AdaIN / ReLU / normalisation backward of head layer 4 -> d x_hat (+ batch sums)
+//                       phase 2: BatchNorm backward (batch terms from phase 1's sums) -> . W3 -> the same for head layer 1
+//   k_chain_bwd_group   NeRF:   BatchNorm backward -> . W0 (+ sigma head) -> ReLU mask -> the backbone chain, layer by layer
+//                       bender: output head -> ReLU mask -> the bender chain
+//
+// Every pre-activation gradient is written once (the left factor of that layer's weight-gradient product, k_gemm_tn_all),
+// next to the recomputed post-AdaIN activations (the right factors of the head layers).
 #include "pr_common.h"
 #include "mlp_tile.h"
 
 namespace pr {
+
+struct BSmem {
+    float X[TILE_M * LDX];                          // the running gradient / the product's operand
+    float cst[4][MAX_WIDTH];                        // BatchNorm backward on load: mean, rstd, mean(dxh), mean(dxh xh) per channel
+    float ws[MAX_WIDTH];                            // sigma head weights / rows 0..2: bender output head (3 x BWpad <= 3 x 128 ... see use)
+    unsigned char bits[TILE_M * MAX_WIDTH / 8];     // ReLU mask of the current product's output, one bit per element
+    float gsr[TILE_M];                              // d loss / d sigma of the tile rows
+    int flat[TILE_M], frame[TILE_M], flags[TILE_M];
+    int uniform_frame, next_tile, pad_[2];
+};
+static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
+static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0 && offsetof(BSmem, bits) % 16 == 0, "16-byte LDS accesses");
+
+#define PR_ROWS_OF(i, half, rb) (PR_ACC_ROW(i) + 4 * (half) + 32 * (rb))
+
+__device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = b[i] = c[i] = d[i] = 0.f;
+}
+
+// The K loop of one fragment-ordered segment over the operand tile in X (run_layer's loop, mlp_tile.h: two steps in flight,
+// even / odd fragments in their own registers).  a0x: column block `wave`, a1x: column block `wave + 4`; x0 / x1: row blocks.
+__device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                              f32x16& a11) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    if (cbA >= nblk) return;
+    const bool two = cbB < nblk;
+    __builtin_amdgcn_s_setprio(1);
+    const int kq = sg.kq;
+    const float* ap = X + r * LDX + half * 4 * kq;
+    const float4* wpA = reinterpret_cast<const float4*>(sg.w) + (size_t)cbA * kq * 64 + lane;
+    float4 x0e = *reinterpret_cast<const float4*>(ap);
+    float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
+    float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
+    float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    float4 wAe = wpA[0], wAo = wpA[64];
+    if (two) {
+        const float4* wpB = reinterpret_cast<const float4*>(sg.w) + (size_t)cbB * kq * 64 + lane;
+        float4 wBe = wpB[0], wBo = wpB[64];
+        for (int q = 0; q < kq; q += 2) {
+            const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+            PR_MFMA4(a00, x0e, wAe);
+            PR_MFMA4(a01, x1e, wAe);
+            PR_MFMA4(a10, x0e, wBe);
+            PR_MFMA4(a11, x1e, wBe);
+            wAe = wpA[(size_t)qe * 64];
+            wBe = wpB[(size_t)qe * 64];
+            x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+            x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+            PR_MFMA4(a00, x0o, wAo);
+            PR_MFMA4(a01, x1o, wAo);
+            PR_MFMA4(a10, x0o, wBo);
+            PR_MFMA4(a11, x1o, wBo);
+            wAo = wpA[(size_t)qo * 64];
+            wBo = wpB[(size_t)qo * 64];
+            x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+            x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    } else {
+        for (int q = 0; q < kq; q += 2) {
+            const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
+            PR_MFMA4(a00, x0e, wAe);
+            PR_MFMA4(a01, x1e, wAe);
+            wAe = wpA[(size_t)qe * 64];
+            x0e = *reinterpret_cast<const float4*>(ap + 4 * qe);
+            x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qe);
+            PR_MFMA4(a00, x0o, wAo);
+            PR_MFMA4(a01, x1o, wAo);
+            wAo = wpA[(size_t)qo * 64];
+            x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
+            x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// rows of X -> rows of a (cap, ld) array, 16-byte stores; only the tile's real rows
+__device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int width_pad, int ld, int tile_base, int rows_valid) {
+    const int w4 = width_pad >> 2;
+    for (int idx = threadIdx.x; idx < TILE_M * w4; idx += MLP_THREADS) {
+        const int row = idx / w4, c = (idx - row * w4) * 4;
+        if (row < rows_valid) {
+            const float4 v = *reinterpret_cast<const float4*>(X + row * LDX + c);
+            *reinterpret_cast<float4*>(dst + (size_t)(tile_base + row) * ld + c) = v;
+        }
+    }
+}
+
+// the bit image of one saved ReLU mask of the tile (64 x width / 8 contiguous bytes, written by the forward pass) -> S.bits
+__device__ __forceinline__ void load_tile_bits(unsigned char* dst, const unsigned char* src_layer, int width_pad, int tile_base, int rows_valid) {
+    const int bpr = width_pad >> 3;
+    const int bytes = TILE_M * bpr;
+    const unsigned char* src = src_layer + (size_t)tile_base * bpr;
+    const int live_bytes = rows_valid * bpr;
+    for (int i = threadIdx.x * 8; i < bytes; i += MLP_THREADS * 8) {
+        unsigned long long v = 0ull;
+        if (i + 8 <= live_bytes) {
+            v = *reinterpret_cast<const unsigned long long*>(src + i);
+        } else {
+            for (int b = 0; b < 8 && i + b < live_bytes; ++b) v |= (unsigned long long)src[i + b] << (8 * b);
+        }
+        *reinterpret_cast<unsigned long long*>(dst + i) = v;
+    }
+}
+
+// ReLU backward of a product: X[row][col] = mask bit ? acc : 0  (the callers put barriers around it)
+__device__ __forceinline__ void store_masked(BSmem& S, int nblk, int width_pad, const f32x16& a00, const f32x16& a01, const f32x16& a10,
+                                             const f32x16& a11) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int bpr = width_pad >> 3;
+    for (int blk = 0; blk < 2; ++blk) {
+        const int cb = wave + blk * MLP_WAVES;
+        if (cb >= nblk) break;
+        const int col = cb * 32 + r;
+        const f32x16& lo = blk ? a10 : a00;
+        const f32x16& hi = blk ? a11 : a01;
+        float* x0 = S.X + (4 * half) * LDX + col;
+        const unsigned char* b0 = S.bits + (4 * half) * bpr + (col >> 3);
+        const int bit = col & 7;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ro = PR_ACC_ROW(i);
+            x0[ro * LDX] = ((b0[ro * bpr] >> bit) & 1) ? lo[i] : 0.f;
+            x0[(ro + 32) * LDX] = ((b0[(ro + 32) * bpr] >> bit) & 1) ? hi[i] : 0.f;
+        }
+    }
+}
+
+// a product's rows straight to global memory (the gradient of a network input: X keeps its operand)
+__device__ __forceinline__ void store_global(float* gout, int ldg, int n_real, int nblk, int tile_base, int rows_valid, bool accumulate,
+                                             const f32x16& a00, const f32x16& a01, const f32x16& a10, const f32x16& a11) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    for (int blk = 0; blk < 2; ++blk) {
+        const int cb = wave + blk * MLP_WAVES;
+        if (cb >= nblk) break;
+        const int col = cb * 32 + r;
+        if (col >= n_real) continue;
+        const f32x16& lo = blk ? a10 : a00;
+        const f32x16& hi = blk ? a11 : a01;
+        float* base = gout + (size_t)(tile_base + 4 * half) * ldg + col;
+        const int limit = rows_valid - 4 * half;
+        float old_lo[16], old_hi[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            old_lo[i] = (accumulate && PR_ACC_ROW(i) < limit) ? base[PR_ACC_ROW(i) * ldg] : 0.f;
+            old_hi[i] = (accumulate && PR_ACC_ROW(i) + 32 < limit) ? base[(PR_ACC_ROW(i) + 32) * ldg] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (PR_ACC_ROW(i) < limit) base[PR_ACC_ROW(i) * ldg] = lo[i] + old_lo[i];
+            if (PR_ACC_ROW(i) + 32 < limit) base[(PR_ACC_ROW(i) + 32) * ldg] = hi[i] + old_hi[i];
+        }
+    }
+}
+
+// per-channel constants of a BatchNorm backward -> S.cst: mean, 1 / sqrt(var + eps), mean(dxh), mean(dxh xh) (0 when frozen)
+__device__ __forceinline__ void stage_bn_constants(BSmem& S, const float* mean, const float* var, const double* sums, int width,
+                                                   int width_pad, const int32_t* count, float eps, int frozen) {
+    const double n = (double)*count;
+    for (int c = threadIdx.x; c < width_pad; c += MLP_THREADS) {
+        const bool live = c < width;
+        S.cst[0][c] = live ? mean[c] : 0.f;
+        S.cst[1][c] = live ? 1.0f / sqrtf(var[c] + eps) : 0.f;
+        S.cst[2][c] = (live && !frozen) ? (float)(sums[c] / n) : 0.f;
+        S.cst[3][c] = (live && !frozen) ? (float)(sums[width_pad + c] / n) : 0.f;
+    }
+}
+
+// BatchNorm (batch statistics) backward of the tile while it is loaded: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh)) for the rows
+// that entered the statistics, 0 otherwise -> X, and back to `d` in place (the left factor of the layer's weight gradient)
+__device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float* h, int width_pad, int tile_base, int rows_valid) {
+    const int w4 = width_pad >> 2;
+    for (int idx = threadIdx.x; idx < TILE_M * w4; idx += MLP_THREADS) {
+        const int row = idx / w4, c = (idx - row * w4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows_valid) {
+            if ((S.flags[row] & 3) == 3) {
+                const size_t at = (size_t)(tile_base + row) * width_pad + c;
+                const float4 g = *reinterpret_cast<const float4*>(d + at);
+                const float4 hv = *reinterpret_cast<const float4*>(h + at);
+                const float4 mu = *reinterpret_cast<const float4*>(&S.cst[0][c]);
+                const float4 rs = *reinterpret_cast<const float4*>(&S.cst[1][c]);
+                const float4 m1 = *reinterpret_cast<const float4*>(&S.cst[2][c]);
+                const float4 m2 = *reinterpret_cast<const float4*>(&S.cst[3][c]);
+                v.x = rs.x * (g.x - m1.x - (hv.x - mu.x) * rs.x * m2.x);
+                v.y = rs.y * (g.y - m1.y - (hv.y - mu.y) * rs.y * m2.y);
+                v.z = rs.z * (g.z - m1.z - (hv.z - mu.z) * rs.z * m2.z);
+                v.w = rs.w * (g.w - m1.w - (hv.w - mu.w) * rs.w * m2.w);
+            }
+            *reinterpret_cast<float4*>(d + (size_t)(tile_base + row) * width_pad + c) = v;
+        }
+        *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
+    }
+}
+
+// records of the tile: flat sample index, frame, row flags (0 beyond the real rows)
+__device__ __forceinline__ void load_tile_records(BSmem& S, const int32_t* rec_flat, const int32_t* row_flags, int samples_per_frame,
+                                                  int tile_base, int total) {
+    const int tid = threadIdx.x;
+    if (tid == 0) S.uniform_frame = 1;
+    if (tid < TILE_M) {
+        const int idx = tile_base + tid;
+        const bool valid = idx < total;
+        const int flat = rec_flat[valid ? idx : tile_base];
+        S.flat[tid] = flat;
+        S.frame[tid] = flat / samples_per_frame;
+        S.flags[tid] = valid ? row_flags[idx] : 0;
+    }
+}
+
+// running sums of one lane's columns across the tiles of a workgroup
+struct ColumnSums {
+    double s1[2], s2[2];     // sum dxh, sum dxh xh  (column blocks A / B)
+    float ds[2], db[2];      // d scale, d bias of `frame`
+    int frame;
+};
+
+__device__ __forceinline__ void flush_frame_sums(ColumnSums& cs, float* dscale, float* dbias, int nblk, int width) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (cs.frame >= 0 && lane < 32) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int col = (wave + blk * MLP_WAVES) * 32 + lane;
+            if (wave + blk * MLP_WAVES < nblk && col < width) {
+                atomicAdd(dscale + (size_t)cs.frame * MAX_WIDTH + col, cs.ds[blk]);
+                atomicAdd(dbias + (size_t)cs.frame * MAX_WIDTH + col, cs.db[blk]);
+            }
+        }
+    }
+    cs.ds[0] = cs.ds[1] = cs.db[0] = cs.db[1] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Feature-head backward, phases 1 and 2
+// ---------------------------------------------------------------------------------------------
+template <int UNUSED = 0>
+__device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int total = *p.total;
+    __syncthreads();       // every wave has left the previous job's last tile
+    if (tid == 0) S.next_tile = atomicAdd(p.tile_counter, 1);
+    if (p.phase == 2) stage_bn_constants(S, p.mean_in, p.var_in, p.sums_in, p.width_in, p.kpad, p.stat_count, p.eps, p.frozen);
+    // this lane's columns of the layer that is differentiated: statistics of its BatchNorm
+    float mu[2], rstd[2];
+    bool live_col[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int col = (wave + blk * MLP_WAVES) * 32 + r;
+        live_col[blk] = (wave + blk * MLP_WAVES) < p.nblk && col < p.width;
+        mu[blk] = live_col[blk] ? p.mean[col] : 0.f;
+        rstd[blk] = live_col[blk] ? 1.0f / sqrtf(p.var[col] + p.eps) : 0.f;
+    }
+    ColumnSums cs;
+    cs.s1[0] = cs.s1[1] = cs.s2[0] = cs.s2[1] = 0.0;
+    cs.ds[0] = cs.ds[1] = cs.db[0] = cs.db[1] = 0.f;
+    cs.frame = -1;
+    __syncthreads();
+    for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
+        const int tile_base = tile * TILE_M;
+        const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
+        int claimed = 0;
+        if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
+        load_tile_records(S, p.rec_flat, p.row_flags, p.samples_per_frame, tile_base, total);
+        __syncthreads();
+        if (tid < TILE_M && tid < rows_valid && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
+        if (tid == 0) S.next_tile = claimed;
+        // ---- the operand: the incoming gradient of the layer's output ---------------------------------
+        if (p.phase == 1) {
+            // feature-row gradients from the compositing backward; rows that failed the second AABB test produced zeros in
+            // the forward pass: their gradient is cleared here (it also feeds the bias gradient's column sums)
+            const int k4 = p.kpad >> 2;
+            for (int idx = tid; idx < TILE_M * k4; idx += MLP_THREADS) {
+                const int row = idx / k4, c = (idx - row * k4) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows_valid && c < p.ld_gin) {
+                    float* src = p.g_in + (size_t)(tile_base + row) * p.ld_gin + c;
+                    if ((S.flags[row] & 3) == 3) {
+                        v = *reinterpret_cast<const float4*>(src);
+                        if (c + 3 >= p.k_real) {       // padding columns of the rows
+                            if (c + 0 >= p.k_real) v.x = 0.f;
+                            if (c + 1 >= p.k_real) v.y = 0.f;
+                            if (c + 2 >= p.k_real) v.z = 0.f;
+                            if (c + 3 >= p.k_real) v.w = 0.f;
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(src) = v;
+                    }
+                }
+                *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
+            }
+        } else {
+            load_bn_backward(S, p.d_in, p.h_in, p.kpad, tile_base, rows_valid);
+        }
+        __syncthreads();
+        f32x16 a00, a01, a10, a11;
+        zero4(a00, a01, a10, a11);
+        tile_products(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+        __syncthreads();      // every wave has finished reading X
+        // ---- AdaIN + ReLU backward, normalisation backward up to the batch terms -------------------------
+        //   y = h g[frame] + b[frame] (g = scale rstd), a = relu(y);  dy = (y > 0) d a;  d scale += dy xh, d bias += dy;
+        //   d xh = dy scale;  the batch terms mean(d xh), mean(d xh xh) are applied by the next phase
+        const bool uniform = S.uniform_frame != 0;
+        if (uniform) {
+            const int frame0 = S.frame[0];
+            if (frame0 != cs.frame) {
+                flush_frame_sums(cs, p.dscale, p.dbias, p.nblk, p.width);
+                cs.frame = frame0;
+            }
+            // rows of this lane that entered the statistics: bit ro of `mine` <-> tile row ro + 4 half
+            const unsigned long long mine = __ballot((S.flags[lane] & 3) == 3) >> (4 * half);
+            const float* tab = p.table + (size_t)frame0 * p.table_stride;
+            const int limit = rows_valid - 4 * half;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int cb = wave + blk * MLP_WAVES;
+                if (cb >= p.nblk) continue;
+                const int col = cb * 32 + r;
+                const f32x16& lo = blk ? a10 : a00;
+                const f32x16& hi = blk ? a11 : a01;
+                const bool live = live_col[blk];
+                const float g = live ? tab[p.goff + col] : 0.f, b = live ? tab[p.boff + col] : 0.f;
+                const float scale = live ? g / rstd[blk] : 0.f;
+                // one base pointer per lane; the row offsets are wave-uniform multiples of the leading dimension
+                const float* hb = p.h + (size_t)(tile_base + 4 * half) * p.ld + col;
+                float* ab = p.a_out + (size_t)(tile_base + 4 * half) * p.ld + col;
+                float* xb = S.X + (4 * half) * LDX + col;
+                const int ld = p.ld;
+                double s1 = 0.0, s2 = 0.0;
+                float ds = 0.f, db = 0.f;
+                // four rows at a time (loads, arithmetic, stores), fenced: unrolled as a whole the loads of a block are
+                // hoisted together and the kernel spills
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        float hv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ro = PR_ACC_ROW(4 * ch + q) + 32 * rb;
+                            hv[q] = (live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int ro = PR_ACC_ROW(4 * ch + q) + 32 * rb;
+                            const float acc = rb ? hi[4 * ch + q] : lo[4 * ch + q];
+                            float a = 0.f, dxh = 0.f;
+                            if (live && ((mine >> ro) & 1ull)) {
+                                const float y = fmaf(hv[q], g, b);
+                                a = y > 0.f ? y : 0.f;
+                                const float dy = y > 0.f ? acc : 0.f;
+                                const float xh = (hv[q] - mu[blk]) * rstd[blk];
+                                dxh = dy * scale;
+                                s1 += (double)dxh;
+                                s2 += (double)dxh * (double)xh;
+                                ds = fmaf(dy, xh, ds);
+                                db += dy;
+                            }
+                            xb[ro * LDX] = dxh;
+                            if (ro < limit) ab[ro * ld] = a;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // the two halves of the wave hold the same column: combine
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                ds += __shfl_xor(ds, 32, 64);
+                db += __shfl_xor(db, 32, 64);
+                cs.s1[blk] += s1;
+                cs.s2[blk] += s2;
+                cs.ds[blk] += ds;
+                cs.db[blk] += db;
+            }
+        } else {
+            // a tile that straddles two frames (a handful per call): the raw products go through X, one thread per column
+            for (int blk = 0; blk < 2; ++blk) {
+                const int cb = wave + blk * MLP_WAVES;
+                if (cb >= p.nblk) break;
+                const f32x16& lo = blk ? a10 : a00;
+                const f32x16& hi = blk ? a11 : a01;
+                float* xb = S.X + (4 * half) * LDX + cb * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    xb[PR_ACC_ROW(i) * LDX] = lo[i];
+                    xb[(PR_ACC_ROW(i) + 32) * LDX] = hi[i];
+                }
+            }
+            __syncthreads();
+            for (int col = tid; col < p.nblk * 32; col += MLP_THREADS) {
+                const bool live = col < p.width;
+                const float m = live ? p.mean[col] : 0.f, rs = live ? 1.0f / sqrtf(p.var[col] + p.eps) : 0.f;
+                double s1 = 0.0, s2 = 0.0;
+                for (int row = 0; row < TILE_M; ++row) {
+                    float a = 0.f, dxh = 0.f;
+                    if (live && (S.flags[row] & 3) == 3) {
+                        const float* tab = p.table + (size_t)S.frame[row] * p.table_stride;
+                        const float g = tab[p.goff + col], b = tab[p.boff + col];
+                        const float hv = p.h[(size_t)(tile_base + row) * p.ld + col];
+                        const float y = fmaf(hv, g, b);
+                        a = y > 0.f ? y : 0.f;
+                        const float dy = y > 0.f ? S.X[row * LDX + col] : 0.f;
+                        const float xh = (hv - m) * rs;
+                        dxh = dy * (g / rs);
+                        s1 += (double)dxh;
+                        s2 += (double)dxh * (double)xh;
+                        if (dy != 0.f) {
+                            atomicAdd(p.dscale + (size_t)S.frame[row] * MAX_WIDTH + col, dy * xh);
+                            atomicAdd(p.dbias + (size_t)S.frame[row] * MAX_WIDTH + col, dy);
+                        }
+                    }
+                    S.X[row * LDX + col] = dxh;
+                    if (row < rows_valid) p.a_out[(size_t)(tile_base + row) * p.ld + col] = a;
+                }
+                if (live && !p.frozen && (s1 != 0.0 || s2 != 0.0)) {
+                    atomicAdd(p.sums + col, s1);
+                    atomicAdd(p.sums + p.nblk * 32 + col, s2);
+                }
+            }
+        }
+        __syncthreads();
+        store_tile_rows(S.X, p.d_out, p.nblk * 32, p.ld, tile_base, rows_valid);
+        __syncthreads();      // the next tile overwrites X and the records
+    }
+    flush_frame_sums(cs, p.dscale, p.dbias, p.nblk, p.width);
+    if (lane < 32 && !p.frozen) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int col = (wave + blk * MLP_WAVES) * 32 + lane;
+            if (live_col[blk] && (cs.s1[blk] != 0.0 || cs.s2[blk] != 0.0)) {
+                atomicAdd(p.sums + col, cs.s1[blk]);
+                atomicAdd(p.sums + p.nblk * 32 + col, cs.s2[blk]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
+                                                                                   int count) {
+    head_bwd_loop(j0);
+    if (count > 1) head_bwd_loop(j1);
+    if (count > 2) head_bwd_loop(j2);
+    if (count > 3) head_bwd_loop(j3);
+}
+
+int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int count, hipStream_t s) {
+    static thread_local HeadBwdJob g[MLP_GROUP_MAX];
+    for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
+        const int n = count - begin < MLP_GROUP_MAX ? count - begin : MLP_GROUP_MAX;
+        long max_tiles = 0;
+        for (int j = 0; j < n; ++j) {
+            g[j] = jobs[begin + j];
+            PR_REQUIRE(g[j].tile_counter && (g[j].kpad % 16) == 0 && g[j].nblk >= 1 && g[j].nblk <= 8, "head backward: bad job");
+            max_tiles += (max_rows[begin + j] + TILE_M - 1) / TILE_M;
+        }
+        if (max_tiles <= 0) continue;
+        int cus = 0;
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_head_bwd_group), (int)sizeof(BSmem), &cus));
+        const long resident = (long)cus * MLP_BLOCKS_PER_CU;
+        ProfileScope scope(2, s);
+        hipLaunchKernelGGL(k_head_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                           g[0], g[1], g[2], g[3], n);
+        PR_LAUNCH_CHECK();
+    }
+    return PR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward chain of a ReLU MLP with one skip concatenation, with its entry fused in
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int total = *c.total;
+    const int nblk = c.Wpad >> 5, in_nblk = c.in_pad >> 5;
+    __syncthreads();
+    if (tid == 0) S.next_tile = atomicAdd(c.tile_counter, 1);
+    if (c.entry == 1) {
+        stage_bn_constants(S, c.mean1, c.var1, c.sums1, c.W, c.Wpad, c.stat_count, c.eps, c.frozen);
+        for (int i = tid; i < c.Wpad; i += MLP_THREADS) S.ws[i] = (c.w_sigma && i < c.W) ? c.w_sigma[i] : 0.f;
+    }
+    __syncthreads();
+    for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
+        const int tile_base = tile * TILE_M;
+        const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
+        int claimed = 0;
+        if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
+        load_tile_records(S, c.rec_flat, c.row_flags, c.samples_per_frame, tile_base, total);
+        load_tile_bits(S.bits, c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
+        __syncthreads();
+        if (tid == 0) S.next_tile = claimed;
+        f32x16 a00, a01, a10, a11;
+        if (c.entry == 1) {
+            // NeRF: normalisation backward of head layer 1, . W0, + the density's path through the sigma head, ReLU mask of
+            // the backbone's last layer
+            if (tid < TILE_M) {
+                float gs = 0.f;
+                if (tid < rows_valid && (S.flags[tid] & 3) == 3 && c.w_sigma &&
+                    c.in_scene[(size_t)S.frame[tid] * c.in_scene_stride] != 0)
+                    gs = c.g_sigma[S.flat[tid]];
+                S.gsr[tid] = gs;
+                if (tid < rows_valid && c.gsr4) *reinterpret_cast<float4*>(c.gsr4 + (size_t)(tile_base + tid) * 4) = make_float4(gs, 0.f, 0.f, 0.f);
+            }
+            load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid);
+            __syncthreads();
+            zero4(a00, a01, a10, a11);
+            tile_products(c.w0t, nblk, S.X, a00, a01, a10, a11);
+            __syncthreads();
+            for (int blk = 0; blk < 2; ++blk) {
+                const int cb = wave + blk * MLP_WAVES;
+                if (cb >= nblk) break;
+                const float w = S.ws[cb * 32 + r];
+                f32x16& lo = blk ? a10 : a00;
+                f32x16& hi = blk ? a11 : a01;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    lo[i] = fmaf(S.gsr[PR_ROWS_OF(i, half, 0)], w, lo[i]);
+                    hi[i] = fmaf(S.gsr[PR_ROWS_OF(i, half, 1)], w, hi[i]);
+                }
+            }
+            store_masked(S, nblk, c.Wpad, a00, a01, a10, a11);
+        } else {
+            // ray bender: G = (g_raw . W_out) masked by the last layer's ReLU
+            const int w4 = c.Wpad >> 2;
+            const int bpr = c.Wpad >> 3;
+            for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
+                const int row = idx / w4, c4 = (idx - row * w4) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows_valid) {
+                    const float4 g = *reinterpret_cast<const float4*>(c.g_braw4 + (size_t)(tile_base + row) * 4);
+                    const unsigned int mb = S.bits[row * bpr + (c4 >> 3)] >> (c4 & 7);
+                    float out[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = c4 + e;
+                        float acc = 0.f;
+                        if (col < c.W && ((mb >> e) & 1u))
+                            acc = fmaf(g.x, c.w_out[col], fmaf(g.y, c.w_out[c.w_out_ld + col], g.z * c.w_out[2 * c.w_out_ld + col]));
+                        out[e] = acc;
+                    }
+                    v = make_float4(out[0], out[1], out[2], out[3]);
+                }
+                *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
+            }
+        }
+        __syncthreads();
+        store_tile_rows(S.X, c.gstack + (size_t)(c.count - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+        bool g_in_written = false;
+        for (int l = c.count - 1; l >= 1; --l) {
+            // ReLU mask of this layer's input (layer l - 1's output); visible after the barrier that follows the product
+            load_tile_bits(S.bits, c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
+            if (l == c.skip) {
+                zero4(a00, a01, a10, a11);
+                tile_products(c.in0_skip, in_nblk, S.X, a00, a01, a10, a11);
+                store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, false, a00, a01, a10, a11);
+                g_in_written = true;
+            }
+            zero4(a00, a01, a10, a11);
+            tile_products(c.act_t[l], nblk, S.X, a00, a01, a10, a11);
+            __syncthreads();
+            store_masked(S, nblk, c.Wpad, a00, a01, a10, a11);
+            __syncthreads();
+            store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+        }
+        zero4(a00, a01, a10, a11);
+        tile_products(c.in0_first, in_nblk, S.X, a00, a01, a10, a11);
+        store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, g_in_written, a00, a01, a10, a11);
+        __syncthreads();   // the next tile overwrites X, the bits and the records
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
+                                                                                    int count) {
+    chain_bwd_loop(j0);
+    if (count > 1) chain_bwd_loop(j1);
+    if (count > 2) chain_bwd_loop(j2);
+    if (count > 3) chain_bwd_loop(j3);
+}
+
+int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int count, hipStream_t s) {
+    static thread_local ChainBwdJob g[MLP_GROUP_MAX];
+    for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
+        const int n = count - begin < MLP_GROUP_MAX ? count - begin : MLP_GROUP_MAX;
+        long max_tiles = 0;
+        for (int j = 0; j < n; ++j) {
+            g[j] = jobs[begin + j];
+            PR_REQUIRE(g[j].tile_counter && g[j].count >= 2 && g[j].count <= PR_MAX_LAYERS && g[j].skip >= 1 && g[j].skip < g[j].count,
+                       "backward chain: bad job");
+            max_tiles += (max_rows[begin + j] + TILE_M - 1) / TILE_M;
+        }
+        if (max_tiles <= 0) continue;
+        int cus = 0;
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_chain_bwd_group), (int)sizeof(BSmem), &cus));
+        const long resident = (long)cus * MLP_BLOCKS_PER_CU;
+        ProfileScope scope(2, s);
+        hipLaunchKernelGGL(k_chain_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                           g[0], g[1], g[2], g[3], n);
+        PR_LAUNCH_CHECK();
+    }
+    return PR_OK;
+}
+
 }  // namespace pr

@@ -201,9 +201,10 @@ def test_packed_and_workspace_sizes_on_host(built_library):
     comp, s = _model_struct_host(cfg["model"]["object_models"][2], 32)
     size = C.c_size_t()
     assert built_library.pr_packed_size(C.byref(s), C.byref(size)) == 0
-    # fragment-ordered copy is the padded weight count: between 1x and 1.2x of the raw parameters
+    # fragment-ordered copy = the padded weights for the forward kernels, plus every matrix once more as W^T fragments for
+    # the backward chains (biases and the small heads are not repeated): between 1.9x and 2.4x of the raw parameters
     raw = sum(p.numel() for n, p in comp.named_parameters() if "affine_transform" not in n) * 4
-    assert raw <= size.value <= 1.2 * raw
+    assert 1.9 * raw <= size.value <= 2.4 * raw
     call = _lib.Call()
     call.frames, call.rays, call.objects = 1, 1000, 1
     for f in ("ray_origins", "ray_directions", "w2o", "style", "deformation", "object_in_scene"):
