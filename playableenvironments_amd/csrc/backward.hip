@@ -117,13 +117,61 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         __syncthreads();
         return;
     }
+    // d loss / d w_j = gF . f_j + gO + gD t_j + gW_j
+    if (has_gf && !p.sigmoid && (F & 3) == 0 && F <= 256) {
+        // four entries at a time: 16 lanes per feature row (16-byte loads, up to four per lane), one reduction over the 16-lane
+        // groups for all four dot products - the rows of a ray are read with four requests in flight instead of one after the other
+        const int grp = lane >> 4, sub = lane & 15;
+        const int f4n = F >> 2;
+        float4 gF4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int q = sub + 16 * c;
+            gF4[c] = q < f4n ? *reinterpret_cast<const float4*>(g.integrated_features + (size_t)ray * F + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            const int j = j0 + grp;
+            const float* f = nullptr;
+            int e = 0;
+            if (j < n) {
+                e = entry_of(j);
+                const int row = sm.sl[e];
+                if (row >= 0 && sm.Tj[j] != 0.f) {
+                    int k = 0, o2 = 0;
+                    while (k + 1 < p.objects && e >= o2 + p.obj[k].positions) {
+                        o2 += p.obj[k].positions;
+                        ++k;
+                    }
+                    f = p.obj[k].feat + (size_t)row * F;
+                }
+            }
+            float4 fv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = sub + 16 * c;
+                fv[c] = (f && q < f4n) ? *reinterpret_cast<const float4*>(f + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                part = fmaf(gF4[c].x, fv[c].x, part);
+                part = fmaf(gF4[c].y, fv[c].y, part);
+                part = fmaf(gF4[c].z, fv[c].z, part);
+                part = fmaf(gF4[c].w, fv[c].w, part);
+            }
+            part += __shfl_xor(part, 8, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 1, 64);
+            if (sub == 0 && j < n) sm.dw[j] = part + gO + gD * sm.tt[e] + (gW ? gW[j] : 0.f);
+        }
+    } else {
     float gF[MAX_FCHUNK_B];
 #pragma unroll
     for (int c = 0; c < MAX_FCHUNK_B; ++c) {
         const int ch = lane + 64 * c;
         gF[c] = (has_gf && ch < F) ? g.integrated_features[(size_t)ray * F + ch] : 0.f;
     }
-    // d loss / d w_j
     for (int j = 0; j < n; ++j) {
         const int e = entry_of(j);
         const int row = sm.sl[e];
@@ -149,14 +197,26 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
         }
         if (lane == 0) sm.dw[j] = dot + gO + gD * sm.tt[e] + (gW ? gW[j] : 0.f);
     }
+    }
     __syncthreads();
-    // d loss / d alpha_j = dw_j T_j - (sum_{i>j} dw_i w_i) / (1 - alpha_j + 1e-10)
-    if (lane == 0) {
-        float suffix = 0.f;
-        for (int j = n - 1; j >= 0; --j) {
-            const float dwj = sm.dw[j];
-            sm.dw[j] = dwj * sm.Tj[j] - suffix / __fadd_rn(__fsub_rn(1.0f, sm.al[j]), 1e-10f);
-            suffix = fmaf(dwj, sm.wv[j], suffix);
+    // d loss / d alpha_j = dw_j T_j - (sum_{i>j} dw_i w_i) / (1 - alpha_j + 1e-10): suffix sums by 64-entry blocks from the end of the
+    // list (a wave-level scan per block, the blocks chained through `carry`)
+    {
+        float carry = 0.f;
+        for (int base = ((n - 1) / 64) * 64; base >= 0; base -= 64) {
+            const int j = base + lane;
+            const float dwj = j < n ? sm.dw[j] : 0.f;
+            float incl = j < n ? dwj * sm.wv[j] : 0.f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_down(incl, d, 64);
+                if (lane + d < 64) incl += o;
+            }
+            float excl = __shfl_down(incl, 1, 64);
+            if (lane == 63) excl = 0.f;
+            const float total = __shfl(incl, 0, 64);
+            if (j < n) sm.dw[j] = dwj * sm.Tj[j] - (excl + carry) / __fadd_rn(__fsub_rn(1.0f, sm.al[j]), 1e-10f);
+            carry += total;
         }
     }
     __syncthreads();
@@ -976,16 +1036,39 @@ struct PostNerfJob {
 };
 struct PostNerfJobs { PostNerfJob job[MAX_ROW_JOBS]; };
 
+// 64 rows per workgroup: the rows' encodings and encoding gradients go through LDS (whole rows with 16-byte loads - a thread
+// that walks its own row in global memory touches a different cache line per load), then one thread per row.
+constexpr int POST_ROWS = 64;
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld, int m0, int rows) {   // dst[row][ld + 1]
+    const int l4 = ld >> 2;
+    for (int idx = threadIdx.x; idx < POST_ROWS * l4; idx += 256) {
+        const int row = idx / l4, c = (idx - row * l4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) v = *reinterpret_cast<const float4*>(src + (size_t)(m0 + row) * ld + c);
+        float* d = dst + row * (ld + 1) + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_post_nerf_group(PostNerfJobs jobs) {
+    extern __shared__ float post_smem[];
     const PostNerfJob& p = jobs.job[blockIdx.y];
     const int M = *p.r.total;
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    const int m0 = blockIdx.x * POST_ROWS;
+    if (m0 >= M) return;
+    const int rows = M - m0 < POST_ROWS ? M - m0 : POST_ROWS;
+    float* se = post_smem;
+    float* sg = post_smem + POST_ROWS * (p.ld + 1);
+    stage_rows(se, p.enc, p.ld, m0, rows);
+    stage_rows(sg, p.g_enc, p.ld, m0, rows);
+    __syncthreads();
+    if ((int)threadIdx.x >= rows) return;
+    const int m = m0 + threadIdx.x;
     const int fl = p.r.row_flags[m];
     const bool need = (fl & 3) == 3;
     const int din = p.kind == 0 ? 3 : 6;
-    const float* e = p.enc + (size_t)m * p.ld;
-    const float* g = p.g_enc + (size_t)m * p.ld;
+    const float* e = se + threadIdx.x * (p.ld + 1);
+    const float* g = sg + threadIdx.x * (p.ld + 1);
     float v[6];
     for (int a = 0; a < din; ++a) {
         float acc = 0.f;
@@ -1049,42 +1132,49 @@ struct PostBenderJob {
 struct PostBenderJobs { PostBenderJob job[MAX_ROW_JOBS]; };
 
 __global__ __launch_bounds__(256) void k_post_bender_group(PostBenderJobs jobs) {
+    extern __shared__ float post_smem[];
     __shared__ int sh_frame[2];
     const PostBenderJob& p = jobs.job[blockIdx.y];
     const int M = *p.r.total;
-    const int m0 = blockIdx.x * 256;
+    const int m0 = blockIdx.x * POST_ROWS;
     if (m0 >= M) return;
-    const int m = m0 + threadIdx.x;
-    const bool valid = m < M;
-    const bool real = valid && (p.r.row_flags[m] & 1);
-    const float* e = p.bin + (size_t)(valid ? m : m0) * p.ld;
-    const float* g = p.g_bin + (size_t)(valid ? m : m0) * p.ld;
-    if (real) {
-        for (int a = 0; a < 3; ++a) {
-            float acc = g[a];
-            for (int k = 0; k < p.octaves; ++k) {
-                const int sn = 3 + k * 6 + a, cs = sn + 3;
-                acc += ldexpf(1.0f, k) * (e[cs] * g[sn] - e[sn] * g[cs]);
-            }
-            p.g_x[(size_t)m * 3 + a] += acc / p.size[a];
-        }
-    }
-    if (!p.d_def) return;      // (uniform)
-    const int last = (m0 + 255 < M ? m0 + 255 : M - 1);
+    const int rows = M - m0 < POST_ROWS ? M - m0 : POST_ROWS;
+    float* se = post_smem;
+    float* sg = post_smem + POST_ROWS * (p.ld + 1);
+    stage_rows(se, p.bin, p.ld, m0, rows);
+    stage_rows(sg, p.g_bin, p.ld, m0, rows);
     if (threadIdx.x == 0) {
         sh_frame[0] = p.r.rec_flat[m0] / p.r.samples_per_frame;
-        sh_frame[1] = p.r.rec_flat[last] / p.r.samples_per_frame;
+        sh_frame[1] = p.r.rec_flat[m0 + rows - 1] / p.r.samples_per_frame;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    if (sh_frame[0] == sh_frame[1]) {       // the usual case: the block's rows belong to one frame
-        for (int j = 0; j < p.D; ++j) {
-            const float s = wave_sum(real ? g[p.benc + j] : 0.f);
-            if (lane == 0 && s != 0.f) atomicAdd(p.d_def + (size_t)sh_frame[0] * p.def_stride + j, s);
+    const int t = threadIdx.x;
+    if (t < rows) {
+        const int m = m0 + t;
+        if (p.r.row_flags[m] & 1) {
+            const float* e = se + t * (p.ld + 1);
+            const float* g = sg + t * (p.ld + 1);
+            for (int a = 0; a < 3; ++a) {
+                float acc = g[a];
+                for (int k = 0; k < p.octaves; ++k) {
+                    const int sn = 3 + k * 6 + a, cs = sn + 3;
+                    acc += ldexpf(1.0f, k) * (e[cs] * g[sn] - e[sn] * g[cs]);
+                }
+                p.g_x[(size_t)m * 3 + a] += acc / p.size[a];
+            }
         }
-    } else if (real) {
-        const int frame = p.r.rec_flat[m] / p.r.samples_per_frame;
-        for (int j = 0; j < p.D; ++j) atomicAdd(p.d_def + (size_t)frame * p.def_stride + j, g[p.benc + j]);
+    } else if (p.d_def && t >= 64 && t - 64 < p.D) {
+        // d deformation[frame][j] += sum over the frame's rows of g_bin[m][benc + j]: wave 1 walks the tile's column j
+        const int j = t - 64;
+        const bool uniform = sh_frame[0] == sh_frame[1];
+        float acc = 0.f;
+        for (int row = 0; row < rows; ++row) {
+            if (!(p.r.row_flags[m0 + row] & 1)) continue;
+            const float gv = sg[row * (p.ld + 1) + p.benc + j];
+            if (uniform) acc += gv;
+            else atomicAdd(p.d_def + (size_t)(p.r.rec_flat[m0 + row] / p.r.samples_per_frame) * p.def_stride + j, gv);
+        }
+        if (uniform && acc != 0.f) atomicAdd(p.d_def + (size_t)sh_frame[0] * p.def_stride + j, acc);
     }
 }
 
@@ -1907,6 +1997,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
     memset(&sj, 0, sizeof(sj));
     sj.frames = c.frames;
     long max_cap = 0;
+    int max_ld_n = 0, max_ld_b = 0;      // widest encoding rows (LDS of the row kernels)
 
     for (int k = 0; k < K; ++k) {
         const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
@@ -2008,6 +2099,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         memset(&q, 0, sizeof(q));
         q.r = rc; q.kind = m.kind; q.has_bender = m.has_bender; q.octaves = m.octaves; q.ld = d.enc_pad;
         q.enc = enc; q.g_enc = g_enc;
+        if (d.enc_pad > max_ld_n) max_ld_n = d.enc_pad;
         for (int ax = 0; ax < 3; ++ax) { q.size[ax] = size[ax]; q.lo[ax] = lo[ax]; q.hi[ax] = hi[ax]; }
         q.g_x = g_x; q.g_in6 = g_in6;
 
@@ -2082,6 +2174,8 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
             memset(&w, 0, sizeof(w));
             w.r = rc; w.bin = bin; w.g_bin = g_benc; w.ld = d.bin_pad; w.octaves = m.bender_octaves; w.benc = d.benc;
             w.D = m.deformation_features;
+            if (d.bin_pad > max_ld_b) max_ld_b = d.bin_pad;
+            PR_REQUIRE(w.D <= 192, "backward: %d deformation features", w.D);
             for (int ax = 0; ax < 3; ++ax) w.size[ax] = size[ax];
             w.g_x = g_x;
             w.d_def = out.deformation ? out.deformation + (size_t)k * m.deformation_features : nullptr;
@@ -2146,16 +2240,19 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
     PR_TRY(launch_head_bwd_group(h1, rows, K, s));
     PR_TRY(launch_head_bwd_group(h2, rows, K, s));
     PR_TRY(launch_chain_bwd_group(cn, rows, K, s));
-    const int row_blocks = (int)((max_cap + 255) / 256);
+    const int row_blocks = (int)((max_cap + POST_ROWS - 1) / POST_ROWS);
     if (row_blocks > 0) {
-        hipLaunchKernelGGL(k_post_nerf_group, dim3(row_blocks, K), dim3(256), 0, s, pn);
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_nerf_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
+        hipLaunchKernelGGL(k_post_nerf_group, dim3(row_blocks, K), dim3(256), sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_n + 1), s, pn);
         PR_LAUNCH_CHECK();
     }
     if (benders) {
         PR_TRY(launch_chain_bwd_group(cb, rows_b, benders, s));
         long cap_b = 0;
         for (int i = 0; i < benders; ++i) cap_b = std::max(cap_b, rows_b[i]);
-        hipLaunchKernelGGL(k_post_bender_group, dim3((unsigned)((cap_b + 255) / 256), benders), dim3(256), 0, s, pb);
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_bender_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
+        hipLaunchKernelGGL(k_post_bender_group, dim3((unsigned)((cap_b + POST_ROWS - 1) / POST_ROWS), benders), dim3(256),
+                           sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_b + 1), s, pb);
         PR_LAUNCH_CHECK();
     }
     // every weight gradient of the call: one launch (+ its reduction) per TN_ALL_MAX products, each with its own claim counters;

@@ -18,6 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef PR_GEMM_ABLATE
 #define PR_GEMM_ABLATE 0       // timing builds only: 1 = no epilogue, 2 = no operand re-fetch, 4 = no MFMA
 #endif
+#ifndef PR_TNALL_ABLATE
+#define PR_TNALL_ABLATE 0      // timing builds only (k_gemm_tn_all): 1 = no partial write-out, 2 = no operand re-fetch, 4 = no MFMA
+#endif
 constexpr int GT = 128;        // output tile edge
 constexpr int GK = 32;         // reduction slab depth
 constexpr int GLD = 160;       // LDS row stride (floats)
@@ -391,27 +394,50 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
     }
     __syncthreads();
     for (int m0 = m_begin; m0 < m_end; m0 += GK) {
-        const bool more = m0 + GK < m_end;
+        const bool more = (m0 + GK < m_end) && !(PR_TNALL_ABLATE & 2);
         if (more) fetch(m0 + GK);
         if (p.bias_partial && tj == 0 && tid < GT) {
 #pragma unroll
             for (int q = 0; q < GK; ++q) bsum += SA[q * GLD + tid];
         }
+        // two steps in flight: the fragments of the even / odd steps live in their own registers and are re-loaded right after
+        // their last use, a full step before they are needed again (with one register set the LDS reads of a step wait for the
+        // previous step's MFMAs to have consumed their operands: 75 % of the matrix rate)
+        {
+            const float* pa = SA + half * GLD + wr * 64 + r;
+            const float* pb = SB + half * GLD + wc * 64 + r;
+            float a0e = pa[0], a1e = pa[32], b0e = pb[0], b1e = pb[32];
+            float a0o = pa[2 * GLD], a1o = pa[2 * GLD + 32], b0o = pb[2 * GLD], b1o = pb[2 * GLD + 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // both fragment sets are requested before the first MFMA
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-            const float a0 = SA[(kk + half) * GLD + wr * 64 + r];
-            const float a1 = SA[(kk + half) * GLD + wr * 64 + 32 + r];
-            const float b0 = SB[(kk + half) * GLD + wc * 64 + r];
-            const float b1 = SB[(kk + half) * GLD + wc * 64 + 32 + r];
-            PR_MFMA32(acc[0][0], a0, b0);
-            PR_MFMA32(acc[0][1], a0, b1);
-            PR_MFMA32(acc[1][0], a1, b0);
-            PR_MFMA32(acc[1][1], a1, b1);
+            for (int kk = 0; kk < ((PR_TNALL_ABLATE & 4) ? 4 : GK); kk += 4) {
+                PR_MFMA32(acc[0][0], a0e, b0e);
+                PR_MFMA32(acc[0][1], a0e, b1e);
+                PR_MFMA32(acc[1][0], a1e, b0e);
+                PR_MFMA32(acc[1][1], a1e, b1e);
+                if (kk + 4 < GK) {
+                    a0e = pa[(kk + 4) * GLD]; a1e = pa[(kk + 4) * GLD + 32];
+                    b0e = pb[(kk + 4) * GLD]; b1e = pb[(kk + 4) * GLD + 32];
+                }
+                PR_MFMA32(acc[0][0], a0o, b0o);
+                PR_MFMA32(acc[0][1], a0o, b1o);
+                PR_MFMA32(acc[1][0], a1o, b0o);
+                PR_MFMA32(acc[1][1], a1o, b1o);
+                if (kk + 6 < GK) {
+                    a0o = pa[(kk + 6) * GLD]; a1o = pa[(kk + 6) * GLD + 32];
+                    b0o = pb[(kk + 6) * GLD]; b1o = pb[(kk + 6) * GLD + 32];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
         }
         __syncthreads();
         if (more) stage();
         __syncthreads();
     }
+    if ((PR_TNALL_ABLATE & 1) && acc[0][0][0] != 123.456f) return;
     const int ldp = tiles_j * GT;
     const int rows_p = ((p.ni + GT - 1) / GT) * GT;
     float* P = p.partial + (size_t)split * rows_p * ldp;
@@ -429,7 +455,10 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
     if (p.bias_partial && tj == 0 && tid < GT) p.bias_partial[(size_t)split * rows_p + i0 + tid] = bsum;
 }
 
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_all(TnAll g) {
+#ifndef PR_TNALL_WGS
+#define PR_TNALL_WGS 2            // resident workgroups per CU
+#endif
+__global__ __launch_bounds__(256, PR_TNALL_WGS) void k_gemm_tn_all(TnAll g) {
     __shared__ __attribute__((aligned(16))) float SA[GK * GLD];
     __shared__ __attribute__((aligned(16))) float SB[GK * GLD];
     __shared__ int pair_begin[TN_ALL_MAX + 1];    // first (job, split) pair of every job
@@ -551,7 +580,7 @@ int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
     int cus = 0;
     PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all), 0, &cus));
     ProfileScope scope(3, s);
-    hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * 2), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * PR_TNALL_WGS), dim3(256), 0, s, g);
     PR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gemm_tn_all_reduce, dim3((unsigned)((max_elems + 255) / 256), g.count), dim3(256), 0, s, g);
     PR_LAUNCH_CHECK();

@@ -17,6 +17,10 @@
 #include "pr_common.h"
 #include "mlp_tile.h"
 
+#ifndef PR_TRAINFWD_ABLATE
+#define PR_TRAINFWD_ABLATE 0    // timing builds only (training forward): 1 = no activation saves, 2 = no ReLU bit images, 4 = no batch statistics
+#endif
+
 #include <cstddef>
 
 #include <stdarg.h>
@@ -661,8 +665,8 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         for (int l = 0; l < p.n_backbone; ++l) {
             run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
             if (TRAIN && p.save_act) {
-                write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
-                if (p.save_bits) write_tile_bits(S, p.save_bits + (size_t)l * p.save_bits_stride, p.Wpad, tile_base);
+                if (!(PR_TRAINFWD_ABLATE & 1)) write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
+                if (p.save_bits && !(PR_TRAINFWD_ABLATE & 2)) write_tile_bits(S, p.save_bits + (size_t)l * p.save_bits_stride, p.Wpad, tile_base);
                 __syncthreads();
             }
         }
@@ -707,7 +711,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             run_layer(raw, S, p, tile_base, 0, enc);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
-            accumulate_stats(S, p);
+            if (!(PR_TRAINFWD_ABLATE & 4)) accumulate_stats(S, p); else __syncthreads();
         }
     }
     if (!TRAIN && p.gate) gated_head_flush(S, p, pending, enc);

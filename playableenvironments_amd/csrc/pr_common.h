@@ -525,7 +525,10 @@ int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int co
 // Every weight-gradient product of a backward pass in one launch (k_gemm_tn_all in gemm.hip): the products of all layers of
 // all objects as (job, split of TN_ALL_CHUNK sample rows, 128 x 128 tile) work items of a persistent grid.
 constexpr int TN_ALL_MAX = 96;         // jobs per launch
-constexpr int TN_ALL_CHUNK = 2048;     // sample rows per split
+#ifndef PR_TNALL_CHUNK
+#define PR_TNALL_CHUNK 2048
+#endif
+constexpr int TN_ALL_CHUNK = PR_TNALL_CHUNK;     // sample rows per split
 constexpr int TN_ALL_TILES = 6;        // claim slots per (job, split): the tiles of the largest gradient (256 x 384)
 struct TnJob {             // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += sum_m A[m][i]
     const float* A; const float* B;

@@ -30,6 +30,9 @@ struct BSmem {
 static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
 static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0 && offsetof(BSmem, bits) % 16 == 0, "16-byte LDS accesses");
 
+#ifndef PR_CHAINGRP_ABLATE
+#define PR_CHAINGRP_ABLATE 0    // timing builds only (k_chain_bwd_group): 1 = no gradient write-out, 2 = no mask bits, 4 = no MFMA
+#endif
 #define PR_ROWS_OF(i, half, rb) (PR_ACC_ROW(i) + 4 * (half) + 32 * (rb))
 
 __device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
@@ -46,6 +49,7 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
     const int cbA = wave, cbB = wave + MLP_WAVES;
     if (cbA >= nblk) return;
     const bool two = cbB < nblk;
+    if (PR_CHAINGRP_ABLATE & 4) return;
     __builtin_amdgcn_s_setprio(1);
     const int kq = sg.kq;
     const float* ap = X + r * LDX + half * 4 * kq;
@@ -154,6 +158,11 @@ __device__ __forceinline__ void store_masked(BSmem& S, int nblk, int width_pad, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ro = PR_ACC_ROW(i);
+            if (PR_CHAINGRP_ABLATE & 2) {
+                x0[ro * LDX] = lo[i];
+                x0[(ro + 32) * LDX] = hi[i];
+                continue;
+            }
             x0[ro * LDX] = ((b0[ro * bpr] >> bit) & 1) ? lo[i] : 0.f;
             x0[(ro + 32) * LDX] = ((b0[(ro + 32) * bpr] >> bit) & 1) ? hi[i] : 0.f;
         }
@@ -587,7 +596,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         bool g_in_written = false;
         for (int l = c.count - 1; l >= 1; --l) {
             // ReLU mask of this layer's input (layer l - 1's output); visible after the barrier that follows the product
-            load_tile_bits(S.bits, c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
+            if (!(PR_CHAINGRP_ABLATE & 2)) load_tile_bits(S.bits, c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
             if (l == c.skip) {
                 zero4(a00, a01, a10, a11);
                 tile_products(c.in0_skip, in_nblk, S.X, a00, a01, a10, a11);
@@ -599,7 +608,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             __syncthreads();
             store_masked(S, nblk, c.Wpad, a00, a01, a10, a11);
             __syncthreads();
-            store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+            if (!(PR_CHAINGRP_ABLATE & 1)) store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
         }
         zero4(a00, a01, a10, a11);
         tile_products(c.in0_first, in_nblk, S.X, a00, a01, a10, a11);

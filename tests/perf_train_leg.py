@@ -17,6 +17,9 @@ from playableenvironments_amd import _lib  # noqa: E402
 
 
 def main():
+    # PR_PERF_LIB: a measurement build of the library (make EXTRA=-D... OUT=...), for A/B timings on one box
+    if os.environ.get("PR_PERF_LIB"):
+        _lib.library_path = lambda: os.path.abspath(os.environ["PR_PERF_LIB"])
     args = types.SimpleNamespace(steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20,
                                  warmup=int(sys.argv[2]) if len(sys.argv) > 2 else 5)
     dev = torch.device("cuda", 0)
