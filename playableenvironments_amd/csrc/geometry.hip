@@ -143,7 +143,7 @@ struct RayLanes {
     }
 };
 
-__global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
+__device__ __forceinline__ void place_coarse_body(const PlaceParams& p) {
     __shared__ int lds[4];
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
@@ -204,6 +204,11 @@ __global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) {
     if (threadIdx.x == 0) p.block_sums[blockIdx.x] = block_total;
 }
 
+__global__ __launch_bounds__(256) void k_place_coarse(PlaceParams p) { place_coarse_body(p); }
+// the objects of a call in one launch: blockIdx.y = object
+struct PlaceGroup { PlaceParams p[PR_MAX_OBJECTS]; };
+__global__ __launch_bounds__(256) void k_place_coarse_group(PlaceGroup g) { place_coarse_body(g.p[blockIdx.y]); }
+
 int launch_place_coarse(const PlaceParams& p, hipStream_t s) {
     const long total = (long)p.frames * p.rays;
     const int blocks = (int)((total + 255) / 256);
@@ -215,8 +220,8 @@ int launch_place_coarse(const PlaceParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // Exclusive scan of the per-block in-box counts (single workgroup; n is a few thousand at most).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan_blocks(const int32_t* __restrict__ sums, int32_t* __restrict__ offsets,
-                                                    int32_t* __restrict__ total, int n) {
+__device__ __forceinline__ void scan_blocks_body(const int32_t* __restrict__ sums, int32_t* __restrict__ offsets,
+                                                 int32_t* __restrict__ total, int n) {
     __shared__ int lds[4];
     int carry = 0;
     for (int start = 0; start < n; start += 256) {
@@ -230,6 +235,15 @@ __global__ __launch_bounds__(256) void k_scan_blocks(const int32_t* __restrict__
     if (threadIdx.x == 0) *total = carry;
 }
 
+__global__ __launch_bounds__(256) void k_scan_blocks(const int32_t* __restrict__ sums, int32_t* __restrict__ offsets,
+                                                    int32_t* __restrict__ total, int n) {
+    scan_blocks_body(sums, offsets, total, n);
+}
+struct ScanGroup { const int32_t* sums[PR_MAX_OBJECTS]; int32_t* offsets[PR_MAX_OBJECTS]; int32_t* total[PR_MAX_OBJECTS]; int n; };
+__global__ __launch_bounds__(256) void k_scan_blocks_group(ScanGroup g) {
+    scan_blocks_body(g.sums[blockIdx.x], g.offsets[blockIdx.x], g.total[blockIdx.x], g.n);
+}
+
 int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, s, sums, offsets, total, n);
     PR_LAUNCH_CHECK();
@@ -240,7 +254,7 @@ int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hi
 // Compaction: the in-box samples, in flat (frame, ray, sample) order - the same order in which the
 // reference's boolean-mask indexing compacts them (ray_bending_style_nerf_model.py:180-186).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill(FillParams p) {
+__device__ __forceinline__ void fill_body(const FillParams& p) {
     __shared__ int lds[4];
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
@@ -302,6 +316,37 @@ __global__ __launch_bounds__(256) void k_fill(FillParams p) {
             slot += __popcll(mask);
         }
     });
+}
+
+__global__ __launch_bounds__(256) void k_fill(FillParams p) { fill_body(p); }
+struct FillGroup { FillParams p[PR_MAX_OBJECTS]; };
+__global__ __launch_bounds__(256) void k_fill_group(FillGroup g) { fill_body(g.p[blockIdx.y]); }
+
+// Coarse placement, block scan and compaction of `count` objects as three launches (each object with its own block sums /
+// offsets and total): PlaceParams::block_sums, FillParams::block_offsets and totals[k] say where.
+int launch_placement_group(const PlaceParams* pp, const FillParams* fp, int32_t* const* totals, int count, hipStream_t s) {
+    if (count <= 0) return PR_OK;
+    PR_REQUIRE(count <= PR_MAX_OBJECTS, "placement group: %d objects", count);
+    static thread_local PlaceGroup pg;
+    static thread_local FillGroup fg;
+    ScanGroup sg;
+    const long total = (long)pp[0].frames * pp[0].rays;
+    const int blocks = (int)((total + 255) / 256);
+    for (int k = 0; k < count; ++k) {
+        pg.p[k] = pp[k];
+        fg.p[k] = fp[k];
+        sg.sums[k] = pp[k].block_sums;
+        sg.offsets[k] = const_cast<int32_t*>(fp[k].block_offsets);
+        sg.total[k] = totals[k];
+    }
+    sg.n = blocks;
+    hipLaunchKernelGGL(k_place_coarse_group, dim3(blocks, count), dim3(256), 0, s, pg);
+    PR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_blocks_group, dim3(count), dim3(256), 0, s, sg);
+    PR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fill_group, dim3(blocks, count), dim3(256), 0, s, fg);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
 }
 
 int launch_fill(const FillParams& p, hipStream_t s) {

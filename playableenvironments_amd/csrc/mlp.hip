@@ -820,6 +820,64 @@ __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {
     }
 }
 
+// k_bn_finalize and the fold of THAT layer's statistics into the AdaIN table, for every object of a training call in one
+// launch (blockIdx.y = object): a thread owns one channel - batch statistics, running-statistics update, then
+// [scale | bias] = affine(style) of every frame folded with them (the arithmetic of k_bn_finalize / k_adain_fold).
+__global__ __launch_bounds__(256) void k_bn_fold_group(BnFoldJobs jobs) {
+    const BnFoldJob& p = jobs.job[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && p.normalised_out) *p.normalised_out = *p.count;
+    if (c >= p.width_pad) return;
+    float mean_f = 0.f, var_f = 0.f;
+    if (c < p.width) {
+        if (p.frozen) {
+            mean_f = p.running_mean[c];
+            var_f = p.running_var[c];
+        } else {
+            const double n = (double)*p.count;
+            const double mean = p.stats[c] / n;
+            double var = p.stats[p.width_pad + c] / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double unbiased = var * n / (n - 1.0);
+            mean_f = (float)mean;
+            var_f = (float)var;
+            if (n > 1.0) {
+                p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+                p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+                if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+            }
+        }
+        p.batch_mean[c] = mean_f;
+        p.batch_var[c] = var_f;
+    }
+    const float* ws = p.affine.weight + (size_t)c * p.S;
+    const float* wb = p.affine.weight + (size_t)(p.width + c) * p.S;
+    const float inv = 1.0f / sqrtf(var_f + p.eps);
+    for (int n = 0; n < p.frames; ++n) {
+        float g = 0.f, b = 0.f;
+        if (c < p.width) {
+            const float* style = p.style + (size_t)n * p.style_stride;
+            float scale = p.affine.bias[c], bias = p.affine.bias[p.width + c];
+            for (int q = 0; q < p.S; ++q) {
+                scale = fmaf(ws[q], style[q], scale);
+                bias = fmaf(wb[q], style[q], bias);
+            }
+            g = scale * inv;
+            b = bias - mean_f * g;
+        }
+        float* row = p.table + (size_t)n * p.row_floats;
+        row[p.g_off + c] = g;
+        row[p.b_off + c] = b;
+    }
+}
+
+int launch_bn_fold_group(const BnFoldJobs& jobs, int count, hipStream_t s) {
+    if (count <= 0) return PR_OK;
+    hipLaunchKernelGGL(k_bn_fold_group, dim3((MAX_WIDTH + 255) / 256, count), dim3(256), 0, s, jobs);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 int launch_bn_finalize(const BnFinalizeParams& p, hipStream_t s) {
     PR_REQUIRE(p.running_mean && p.running_var && p.batch_mean && p.batch_var && p.stats && p.count, "bn finalize: NULL pointer");
     hipLaunchKernelGGL(k_bn_finalize, dim3((p.width + 255) / 256), dim3(256), 0, s, p);

@@ -296,6 +296,7 @@ struct FillParams {
     int32_t* slot;                // (N,R,P) compact row or -1
 };
 int launch_fill(const FillParams& p, hipStream_t s);
+int launch_placement_group(const PlaceParams* pp, const FillParams* fp, int32_t* const* totals, int count, hipStream_t s);
 
 // exclusive scan of n block sums (single workgroup), writes total to *total
 int launch_scan(const int32_t* sums, int32_t* offsets, int32_t* total, int n, hipStream_t s);
@@ -357,6 +358,39 @@ struct BnFinalizeParams {
 };
 int launch_bn_finalize(const BnFinalizeParams& p, hipStream_t s);
 
+// batch statistics of one AdaIN layer + their fold into the AdaIN table (k_bn_fold_group: every object of a training call)
+struct BnFoldJob {
+    const double* stats; const int32_t* count; int width, width_pad; float momentum;
+    float* running_mean; float* running_var; long long* num_batches_tracked;
+    float* batch_mean; float* batch_var; int frozen;
+    const float* style; int style_stride, S, frames;      // style code of frame n: style + n * style_stride
+    pr_linear_t affine; float eps;
+    float* table; int row_floats, g_off, b_off;           // table row n: [.. g (g_off) .. b (b_off) ..]
+    int32_t* normalised_out;                              // or NULL: receives the number of rows in the statistics
+};
+struct BnFoldJobs { BnFoldJob job[PR_MAX_OBJECTS]; };
+int launch_bn_fold_group(const BnFoldJobs& jobs, int count, hipStream_t s);
+
+// Hutchinson divergence estimate of the ray benders of a training call as one tile kernel (k_div_chain_group, train_bwd.hip):
+// the tangent of the bender input along the probe goes through the bender's layers like the sample itself (the forward
+// fragments, the saved ReLU bit images as masks), the 3-wide output head and the clamp cases follow per row.
+struct DivChainJob {
+    const int32_t* total; const int32_t* rec_flat; const int32_t* row_flags; const float* rec_pos;
+    NoiseRef noise; int positions;
+    const float* bin; int bin_pad, benc, b_octaves;
+    const unsigned char* bbits; size_t bbits_stride;
+    int BW, BWpad, b_count, b_skip;
+    Seg seg0[PR_MAX_LAYERS]; Seg seg1;          // forward fragments: first K segment of every layer, second segment of the skip layer
+    const float* w_out;                         // packed raw copy of the output head (3, BWpad)
+    const float* braw;
+    float lo[3], hi[3];
+    int canonical;
+    float* div;                                 // (N,R,P), zeroed by the caller
+    int32_t* tile_counter;                      // zeroed
+};
+bool div_chain_supported(int BWpad, int bin_pad);
+int launch_div_chain_group(const DivChainJob* jobs, const long* max_rows, int count, hipStream_t s);
+
 struct CompositeObject {
     const float* t;
     const float* sigma;
@@ -402,7 +436,9 @@ struct TypePlan {
     int positions[PR_MAX_OBJECTS];
     size_t totals;  // K ints
     size_t head_counts;  // PR_MAX_OBJECTS ints: rows sent through the feature head (sigma-gated head), then PR_MAX_OBJECTS tile
-                         // counters of the evaluation launches (one fill zeroes both)
+                         // counters of the evaluation launches, then PR_MAX_OBJECTS tile counters of the divergence launch
+    size_t zero_begin, zero_bytes;   // ONE fill per model type: the counters above, the batch-statistics accumulators and the
+                                     // divergence arrays of every object
     SavedPlan saved[PR_MAX_OBJECTS];
 };
 struct Plan {

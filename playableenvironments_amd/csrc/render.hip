@@ -143,8 +143,8 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     };
     const size_t nr = (size_t)c.frames * c.rays;
     plan->nblocks256 = (int)((nr + 255) / 256);
-    plan->block_sums = take(sizeof(int32_t) * plan->nblocks256);
-    plan->block_offsets = take(sizeof(int32_t) * plan->nblocks256);
+    plan->block_sums = take(sizeof(int32_t) * plan->nblocks256 * c.objects);       // one region per object: the objects of a
+    plan->block_offsets = take(sizeof(int32_t) * plan->nblocks256 * c.objects);    // call are placed / compacted by shared launches
     size_t max_cap = 0;
     size_t feat_bytes[2] = {0, 0};
     size_t div_t0 = 0, div_t = 0;   // divergence tangent scratch (shared by the bender objects)
@@ -152,7 +152,17 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
     for (int t = 0; t < ntypes; ++t) {
         TypePlan& tp = plan->type[t];
         tp.totals = take(sizeof(int32_t) * PR_MAX_OBJECTS);
-        tp.head_counts = take(sizeof(int32_t) * 2 * PR_MAX_OBJECTS);
+        tp.zero_begin = off;
+        tp.head_counts = take(sizeof(int32_t) * 3 * PR_MAX_OBJECTS);
+        if (c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD))
+            for (int k = 0; k < c.objects; ++k) {
+                const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
+                SavedPlan& sv = tp.saved[k];
+                sv.stats = take(sizeof(double) * 4 * MAX_WIDTH);
+                sv.stat_count = take(sizeof(int32_t) * 4);
+                if ((c.flags & PR_FLAG_SAVE_FOR_BACKWARD) && m.has_bender) sv.div = take(sizeof(float) * nr * m.positions);
+            }
+        tp.zero_bytes = off - tp.zero_begin;
         for (int k = 0; k < c.objects; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             ModelDims d;
@@ -179,10 +189,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
                 sv.h1 = take(sizeof(float) * cap * d.Wpad);
                 sv.h2 = take(sizeof(float) * cap * d.W2pad);
                 sv.batch = take(sizeof(float) * 4 * MAX_WIDTH);
-                sv.stats = take(sizeof(double) * 4 * MAX_WIDTH);
-                sv.stat_count = take(sizeof(int32_t) * 4);
                 if (m.has_bender) {
-                    sv.div = take(sizeof(float) * cap);
                     if (cap * d.bin_pad > div_t0) div_t0 = cap * d.bin_pad;
                     if (cap * d.BWpad > div_t) div_t = cap * d.BWpad;
                     sv.bin = take(sizeof(float) * cap * d.bin_pad);
@@ -214,8 +221,6 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
         plan->h1 = take(sizeof(float) * max_cap * MAX_WIDTH);
         plan->h2 = take(sizeof(float) * max_cap * (MAX_WIDTH / 2 + 32));
         plan->row_flags = take(sizeof(int32_t) * max_cap);
-        plan->stats = take(sizeof(double) * 4 * MAX_WIDTH);
-        plan->stat_count = take(sizeof(int32_t) * 4);
         plan->batch_stats = take(sizeof(float) * 4 * MAX_WIDTH);
     }
     // coarse and fine feature rows share one arena: the coarse rows are dead once the coarse
@@ -270,8 +275,13 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                   hipStream_t s) {
     const int ntypes = c.use_fine ? 2 : 1;
     const int K = c.objects;
-    int32_t* block_sums = reinterpret_cast<int32_t*>(ws + plan.block_sums);
-    int32_t* block_offsets = reinterpret_cast<int32_t*>(ws + plan.block_offsets);
+    int32_t* block_sums_all = reinterpret_cast<int32_t*>(ws + plan.block_sums);
+    int32_t* block_offsets_all = reinterpret_cast<int32_t*>(ws + plan.block_offsets);
+    // coarse placement / block scan / compaction of several objects: three launches for all of them
+    const bool place_grouped = c.objects > 1 && ((c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || group_active(c));   // (every object has its own sample records)
+    static thread_local PlaceParams place_jobs[PR_MAX_OBJECTS];
+    static thread_local FillParams fill_jobs[PR_MAX_OBJECTS];
+    int32_t* total_ptrs[PR_MAX_OBJECTS];
     float* rec_pos = reinterpret_cast<float*>(ws + plan.rec_pos);
     int32_t* rec_flat = reinterpret_cast<int32_t*>(ws + plan.rec_flat);
     const bool naive = (c.flags & PR_FLAG_NAIVE_MLP) != 0;
@@ -293,7 +303,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         const TypePlan& tp = plan.type[t];
         int32_t* totals = reinterpret_cast<int32_t*>(ws + tp.totals);
         int32_t* head_counts = reinterpret_cast<int32_t*>(ws + tp.head_counts);
-        PR_CHECK_HIP(hipMemsetAsync(head_counts, 0, sizeof(int32_t) * 2 * PR_MAX_OBJECTS, s));
+        // one fill: feature-head / tile counters, and - training / differentiable calls - every object's batch-statistics
+        // accumulators and divergence array
+        PR_CHECK_HIP(hipMemsetAsync(ws + tp.zero_begin, 0, tp.zero_bytes, s));
         const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
         int total_positions = 0;
         // what follows phase 1 of an object's phased launches (training / differentiable calls): batch statistics, the two head
@@ -340,8 +352,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             if (save && m.has_bender) {
                 // Hutchinson divergence of the displacement field (train mode with a graph; zeros without a probe)
                 const size_t cap_rows = (size_t)c.frames * c.rays * P;
-                float* div = reinterpret_cast<float*>(ws + sv.div);
-                PR_CHECK_HIP(hipMemsetAsync(div, 0, sizeof(float) * cap_rows, s));
+                float* div = reinterpret_cast<float*>(ws + sv.div);      // (zeroed by the fill at the top of the type)
                 // probes: explicit, or generated for training calls with a graph (the reference draws them whenever it
                 // trains with a graph, object_composer.py:597)
                 NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
@@ -367,6 +378,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             }
             return PR_OK;
         };
+        for (int pass = (place_grouped && t == 0) ? 0 : 1; pass < 2; ++pass) {
+        // pass 0 (grouped coarse placement only): collect the placement / compaction jobs of every object and launch them;
+        // pass 1: everything else per object
+        if (pass == 1 && place_grouped && t == 0) PR_TRY(launch_placement_group(place_jobs, fill_jobs, total_ptrs, K, s));
         for (int k = 0; k < K; ++k) {
             const pr_object_model_t& m = t ? objs[k].fine : objs[k].coarse;
             const float* packed = static_cast<const float*>(t ? objs[k].packed_fine : objs[k].packed_coarse);
@@ -375,7 +390,10 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             PR_TRY(compute_dims(m, &d));
             PR_TRY(compute_layout(m, d, &l));
             const int P = m.positions;
-            total_positions += P;
+            if (pass == 1) total_positions += P;
+            int32_t* block_sums = block_sums_all + (size_t)k * plan.nblocks256;
+            int32_t* block_offsets = block_offsets_all + (size_t)k * plan.nblocks256;
+            const bool placed = place_grouped && t == 0;     // pass 0 has placed and compacted this object
             float* t_arr = reinterpret_cast<float*>(ws + tp.t[k]);
             float* sigma = reinterpret_cast<float*>(ws + tp.sigma[k]);
             int32_t* slot = reinterpret_cast<int32_t*>(ws + tp.slot[k]);
@@ -404,7 +422,8 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 pp.linspace = c.linspace_coarse[k];
                 pp.jitter = perturb_noise(c.noise_coarse.jitter[k], c, NOISE_JITTER, 0, k);
                 pp.t = t_arr; pp.sigma = sigma; pp.dispmag = dispmag; pp.block_sums = block_sums;
-                PR_TRY(launch_place_coarse(pp, s));
+                if (pass == 0) place_jobs[k] = pp;
+                else if (!placed) PR_TRY(launch_place_coarse(pp, s));
             } else {
                 const TypePlan& cp = plan.type[0];
                 ResampleParams rp;
@@ -423,7 +442,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 rp.t_fine = t_arr; rp.sigma_fine = sigma; rp.dispmag_fine = dispmag; rp.block_sums = block_sums;
                 PR_TRY(launch_resample(rp, s));
             }
-            PR_TRY(launch_scan(block_sums, block_offsets, totals + k, plan.nblocks256, s));
+            if (pass == 1 && !placed) PR_TRY(launch_scan(block_sums, block_offsets, totals + k, plan.nblocks256, s));
 
             // ---- compaction --------------------------------------------------------------------
             FillParams fp;
@@ -433,7 +452,12 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             fp.in_scene = c.object_in_scene;
             bbox_split(m, fp.lo, fp.hi, nullptr);
             fp.t = t_arr; fp.block_offsets = block_offsets; fp.rec_pos = rec_pos; fp.rec_flat = rec_flat; fp.slot = slot;
-            PR_TRY(launch_fill(fp, s));
+            if (pass == 0) {
+                fill_jobs[k] = fp;
+                total_ptrs[k] = totals + k;
+                continue;
+            }
+            if (!placed) PR_TRY(launch_fill(fp, s));
 
             // ---- style affine + BatchNorm fold; fused MLP ---------------------------------------
             FoldParams fo;
@@ -490,13 +514,11 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 // activations h1 / h2 behind for the backward pass - with the running statistics frozen.
                 const bool frozen = !(c.flags & PR_FLAG_TRAIN_BN);
                 PR_REQUIRE(!naive, "the scalar debugging kernel has no train-mode BatchNorm");
-                double* stats = reinterpret_cast<double*>(ws + (save ? sv.stats : plan.stats));
-                int32_t* stat_count = reinterpret_cast<int32_t*>(ws + (save ? sv.stat_count : plan.stat_count));
+                double* stats = reinterpret_cast<double*>(ws + sv.stats);               // (zeroed by the fill above)
+                int32_t* stat_count = reinterpret_cast<int32_t*>(ws + sv.stat_count);
                 float* batch = reinterpret_cast<float*>(ws + (save ? sv.batch : plan.batch_stats));
                 float* h1 = reinterpret_cast<float*>(ws + (save ? sv.h1 : plan.h1));
                 float* h2 = reinterpret_cast<float*>(ws + (save ? sv.h2 : plan.h2));
-                PR_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 4 * MAX_WIDTH, s));
-                PR_CHECK_HIP(hipMemsetAsync(stat_count, 0, sizeof(int32_t) * 4, s));
                 mp.row_flags = reinterpret_cast<int32_t*>(ws + (save ? sv.row_flags : plan.row_flags));
                 mp.stat_count = stat_count;
                 if (save) {
@@ -530,16 +552,79 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 }
             }
         }
+        }   // pass
         if (train_grouped) {
             PR_TRY(launch_mlp_group(jobs, job_rows, K, s));                  // phase 1 of every object
-            for (int stage = 1; stage <= 2; ++stage) {                       // statistics per object, then the next phase of all
+            static thread_local BnFoldJobs bj;
+            for (int stage = 1; stage <= 2; ++stage) {                       // statistics + fold of all objects, then their next phase
                 for (int k = 0; k < K; ++k) {
-                    PR_TRY(finish_object(train_jobs[k], stage, false));
-                    jobs[k] = train_jobs[k].mp;
+                    TrainJob& J = train_jobs[k];
+                    const pr_object_model_t& m = *J.m;
+                    BnFoldJob& b = bj.job[k];
+                    memset(&b, 0, sizeof(b));
+                    b.count = J.stat_count; b.momentum = 0.1f; b.frozen = J.frozen ? 1 : 0;
+                    b.style = c.style + (size_t)k * m.style_features; b.style_stride = K * m.style_features; b.S = m.style_features;
+                    b.frames = c.frames; b.eps = m.bn_eps;
+                    b.table = const_cast<float*>(J.mp.adain); b.row_floats = J.mp.adain_stride;
+                    if (stage == 1) {
+                        b.stats = J.stats; b.width = J.d.W; b.width_pad = J.d.Wpad;
+                        b.running_mean = m.bn1_mean; b.running_var = m.bn1_var; b.num_batches_tracked = (long long*)m.bn1_batches;
+                        b.batch_mean = J.batch; b.batch_var = J.batch + MAX_WIDTH;
+                        b.affine = m.affine1; b.g_off = 0; b.b_off = J.d.Wpad;
+                        J.mp.phase = 2; J.mp.h_in = J.h1; J.mp.h_in_width = J.d.Wpad; J.mp.h_out = J.h2; J.mp.h_out_width = J.d.W2pad;
+                        J.mp.stats = J.stats + 2 * MAX_WIDTH;
+                    } else {
+                        b.stats = J.stats + 2 * MAX_WIDTH; b.width = J.d.W2; b.width_pad = J.d.W2pad;
+                        b.running_mean = m.bn4_mean; b.running_var = m.bn4_var; b.num_batches_tracked = (long long*)m.bn4_batches;
+                        b.batch_mean = J.batch + 2 * MAX_WIDTH; b.batch_var = J.batch + 3 * MAX_WIDTH;
+                        b.affine = m.affine4; b.g_off = 2 * J.d.Wpad; b.b_off = 2 * J.d.Wpad + J.d.W2pad;
+                        b.normalised_out = (outs[t] && outs[t]->normalised_samples) ? outs[t]->normalised_samples + k : nullptr;
+                        J.mp.phase = 3; J.mp.h_in = J.h2; J.mp.h_in_width = J.d.W2pad; J.mp.h_out = nullptr;
+                    }
+                    PR_REQUIRE(b.affine.weight && b.affine.bias && b.running_mean && b.running_var, "AdaIN parameters missing");
+                    jobs[k] = J.mp;
                 }
+                PR_TRY(launch_bn_fold_group(bj, K, s));
                 PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
             }
-            for (int k = 0; k < K; ++k) PR_TRY(finish_object(train_jobs[k], 3, false));
+            // Hutchinson divergence of the displacement fields (train mode with a graph): the ray benders of the call as one launch
+            static thread_local DivChainJob dj[PR_MAX_OBJECTS];
+            long div_rows[PR_MAX_OBJECTS];
+            int div_jobs = 0;
+            for (int k = 0; k < K; ++k) {
+                TrainJob& J = train_jobs[k];
+                const pr_object_model_t& m = *J.m;
+                if (!(J.save && m.has_bender)) continue;
+                NoiseRef probes = make_noise(noise.divergence[k], c, NOISE_DIVERGENCE, t, k);
+                if (!(c.flags & PR_FLAG_TRAIN_BN)) probes.generate = 0;
+                if (!(probes.ptr || probes.generate)) continue;
+                if (!div_chain_supported(J.d.BWpad, J.d.bin_pad)) {
+                    PR_TRY(finish_object(J, 3, false));          // (unusually wide bender: one product per layer)
+                    continue;
+                }
+                PackedLayout l;
+                PR_TRY(compute_layout(m, J.d, &l));
+                const float* packed = static_cast<const float*>(t ? objs[k].packed_fine : objs[k].packed_coarse);
+                const size_t cap_rows = (size_t)c.frames * c.rays * J.P;
+                DivChainJob& q = dj[div_jobs];
+                memset(&q, 0, sizeof(q));
+                q.total = totals + k; q.rec_flat = J.rec_flat; q.row_flags = J.mp.row_flags; q.rec_pos = J.rec_pos;
+                q.noise = probes; q.positions = J.P;
+                q.bin = J.mp.save_bin; q.bin_pad = J.d.bin_pad; q.benc = J.d.benc; q.b_octaves = m.bender_octaves;
+                q.bbits = J.mp.save_bbits; q.bbits_stride = J.mp.save_bbits_stride;
+                q.BW = J.d.BW; q.BWpad = J.d.BWpad; q.b_count = m.bender_count; q.b_skip = m.bender_skip;
+                for (int j = 0; j < m.bender_count; ++j) q.seg0[j] = Seg{packed + l.b_seg_off[j][0], (j == 0 ? J.d.bin_pad : J.d.BWpad) / 8, 0};
+                q.seg1 = Seg{packed + l.b_seg_off[m.bender_skip][1], J.d.bin_pad / 8, 0};
+                q.w_out = packed + l.b_out_off;
+                q.braw = J.mp.save_braw;
+                bbox_split(m, q.lo, q.hi, nullptr);
+                q.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
+                q.div = reinterpret_cast<float*>(ws + J.sv->div);
+                q.tile_counter = head_counts + 2 * PR_MAX_OBJECTS + k;
+                div_rows[div_jobs] = (long)cap_rows;
+                ++div_jobs;
+            }
+            if (div_jobs) PR_TRY(launch_div_chain_group(dj, div_rows, div_jobs, s));
         }
 
         if (grouped) {

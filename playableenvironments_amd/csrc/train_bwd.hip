@@ -648,4 +648,143 @@ int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int co
     return PR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hutchinson divergence estimate (object_composer.py:582-601): forward-mode derivative of the ray bender along the probe
+//   t_0 = d input / d x . e,  t_{l+1} = relu'(z_l) (W_l t_l),  div = sum_a e_a (J e)_a
+// The tangent tile lives in X[:, 0:BWpad), the input tangent t_0 beside it in X[:, BWpad + 4 ...) (the skip layer needs it again).
+// ---------------------------------------------------------------------------------------------
+bool div_chain_supported(int BWpad, int bin_pad) { return BWpad + 4 + bin_pad <= LDX && bin_pad <= BWpad + 4; }
+
+__device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = *c.total;
+    const int nblk = c.BWpad >> 5;
+    const int T0 = c.BWpad + 4;
+    float* probe = &S.cst[0][0];           // [row][4]: the probe of the row's sample
+    float size[3];
+    for (int a = 0; a < 3; ++a) size[a] = c.hi[a] - c.lo[a];
+    __syncthreads();
+    if (tid == 0) S.next_tile = atomicAdd(c.tile_counter, 1);
+    __syncthreads();
+    for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
+        const int tile_base = tile * TILE_M;
+        const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
+        int claimed = 0;
+        if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
+        if (tid < TILE_M) {
+            const bool valid = tid < rows_valid;
+            const int flat = c.rec_flat[valid ? tile_base + tid : tile_base];
+            S.flat[tid] = flat;
+            S.flags[tid] = valid ? c.row_flags[tile_base + tid] : 0;
+            const long ray = flat / c.positions;
+            const int sample = flat - (int)ray * c.positions;
+            for (int a = 0; a < 3; ++a) probe[tid * 4 + a] = valid ? noise_normal(c.noise, ray, c.positions * 3, sample * 3 + a) : 0.f;
+        }
+        // the saved bender input of the tile -> X[:, 0:bin_pad)
+        const int b4 = c.bin_pad >> 2;
+        for (int idx = tid; idx < TILE_M * b4; idx += MLP_THREADS) {
+            const int row = idx / b4, c4 = (idx - row * b4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_valid) v = *reinterpret_cast<const float4*>(c.bin + (size_t)(tile_base + row) * c.bin_pad + c4);
+            *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
+        }
+        __syncthreads();
+        if (tid == 0) S.next_tile = claimed;
+        // t_0: element a: e_a / size_a; sin slot: 2^k cos_saved dv_a; cos slot: -2^k sin_saved dv_a; 0 beyond the encoding
+        for (int idx = tid; idx < TILE_M * c.bin_pad; idx += MLP_THREADS) {
+            const int row = idx / c.bin_pad, j = idx - row * c.bin_pad;
+            float v = 0.f;
+            if (j < c.benc) {
+                const float* b = S.X + row * LDX;
+                if (j < 3) {
+                    v = probe[row * 4 + j] / size[j];
+                } else {
+                    const int k = (j - 3) / 6, rem = (j - 3) - 6 * k;
+                    const float f = ldexpf(1.0f, k);
+                    if (rem < 3) v = f * b[j + 3] * (probe[row * 4 + rem] / size[rem]);
+                    else v = -f * b[j - 3] * (probe[row * 4 + rem - 3] / size[rem - 3]);
+                }
+            }
+            S.X[row * LDX + T0 + j] = v;
+        }
+        __syncthreads();
+        for (int l = 0; l < c.b_count; ++l) {
+            load_tile_bits(S.bits, c.bbits + (size_t)l * c.bbits_stride, c.BWpad, tile_base, rows_valid);
+            f32x16 a00, a01, a10, a11;
+            zero4(a00, a01, a10, a11);
+            tile_products(c.seg0[l], nblk, l == 0 ? S.X + T0 : S.X, a00, a01, a10, a11);
+            if (l == c.b_skip) tile_products(c.seg1, nblk, S.X + T0, a00, a01, a10, a11);
+            __syncthreads();
+            store_masked(S, nblk, c.BWpad, a00, a01, a10, a11);
+            __syncthreads();
+        }
+        // output head and the clamp cases, 8 threads per row
+        for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
+            const int part = tid & 7;
+            float tan[3] = {0.f, 0.f, 0.f};
+            for (int k = part; k < c.BW; k += 8) {
+                const float x = S.X[s * LDX + k];
+                for (int a = 0; a < 3; ++a) tan[a] = fmaf(x, c.w_out[a * c.BWpad + k], tan[a]);
+            }
+            for (int a = 0; a < 3; ++a) {
+                float v = tan[a];
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                tan[a] = v;
+            }
+            if (part != 0 || !(S.flags[s] & 1)) continue;
+            const int m = tile_base + s;
+            float acc = 0.f;
+            for (int a = 0; a < 3; ++a) {
+                const float e = probe[s * 4 + a];
+                const float x = c.rec_pos[(size_t)m * 3 + a];
+                const float pre = c.braw[(size_t)m * 3 + a] * size[a];
+                const float lob = c.lo[a] - x, hib = c.hi[a] - x;
+                const float m1 = pre > lob ? pre : lob;
+                float je;
+                if (m1 > hib) je = -e;
+                else if (pre >= lob) je = size[a] * tan[a];
+                else je = -e;
+                if (c.canonical) je = 0.f;
+                acc = fmaf(e, je, acc);
+            }
+            c.div[S.flat[s]] = acc;
+        }
+        __syncthreads();   // the next tile overwrites X, the probes and the records
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_div_chain_group(DivChainJob j0, DivChainJob j1, DivChainJob j2, DivChainJob j3,
+                                                                                    int count) {
+    div_chain_loop(j0);
+    if (count > 1) div_chain_loop(j1);
+    if (count > 2) div_chain_loop(j2);
+    if (count > 3) div_chain_loop(j3);
+}
+
+int launch_div_chain_group(const DivChainJob* jobs, const long* max_rows, int count, hipStream_t s) {
+    static thread_local DivChainJob g[MLP_GROUP_MAX];
+    for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
+        const int n = count - begin < MLP_GROUP_MAX ? count - begin : MLP_GROUP_MAX;
+        long max_tiles = 0;
+        for (int j = 0; j < n; ++j) {
+            g[j] = jobs[begin + j];
+            PR_REQUIRE(g[j].tile_counter && div_chain_supported(g[j].BWpad, g[j].bin_pad), "divergence chain: bad job");
+            max_tiles += (max_rows[begin + j] + TILE_M - 1) / TILE_M;
+        }
+        if (max_tiles <= 0) continue;
+        int cus = 0;
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_div_chain_group), (int)sizeof(BSmem), &cus));
+        const long resident = (long)cus * MLP_BLOCKS_PER_CU;
+        ProfileScope scope(2, s);
+        hipLaunchKernelGGL(k_div_chain_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                           g[0], g[1], g[2], g[3], n);
+        PR_LAUNCH_CHECK();
+    }
+    return PR_OK;
+}
+
 }  // namespace pr
