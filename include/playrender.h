@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PR_ABI_VERSION 3
+#define PR_ABI_VERSION 4
 #define PR_MAX_OBJECTS 8
 #define PR_MAX_LAYERS 12
 #define PR_MAX_OCTAVES 16
@@ -241,6 +241,10 @@ typedef struct pr_call_t {
     uint64_t noise_seed;             /* PR_FLAG_DEVICE_NOISE: seed of the call's generated noise */
     int32_t noise_ray_offset;        /* PR_FLAG_DEVICE_NOISE, calls that are a ray range [offset, offset + R) of a larger */
     int32_t noise_total_rays;        /* render of noise_total_rays rays per frame (0 = this call is the whole render) */
+    const uint64_t* noise_seed_device; /* PR_FLAG_DEVICE_NOISE: NULL, or the seed as ONE device word that the kernels read when they run
+                                        (noise_seed is then ignored): a call recorded into a HIP graph draws fresh noise on
+                                        every replay if the word is rewritten between replays.  pr_render_backward must find the
+                                        value its forward call saw. */
 } pr_call_t;
 
 /* Workspace bytes pr_render_forward needs for this call (host computation, no device work). */

@@ -109,6 +109,7 @@ class Call(C.Structure):
         ("positions_fine", C.c_int32 * PR_MAX_OBJECTS),
         ("noise_coarse", Noise), ("noise_fine", Noise),
         ("noise_seed", C.c_uint64), ("noise_ray_offset", C.c_int32), ("noise_total_rays", C.c_int32),
+        ("noise_seed_device", C.c_void_p),
     ]
 
 
@@ -198,8 +199,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pr_abi_version() != 3:
-        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 3 (rebuild: make -C playableenvironments_amd/csrc)")
+    if lib.pr_abi_version() != 4:
+        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 4 (rebuild: make -C playableenvironments_amd/csrc)")
     _LIB = lib
     return lib
 

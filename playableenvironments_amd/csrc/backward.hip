@@ -1784,7 +1784,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         float* dbias1 = tables + (size_t)c.frames * MAX_WIDTH;
         float* dscale2 = tables + (size_t)c.frames * 2 * MAX_WIDTH;
         float* dbias2 = tables + (size_t)c.frames * 3 * MAX_WIDTH;
-        PR_CHECK_HIP(hipMemsetAsync(tables, 0, sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH, s));
+        PR_TRY(launch_zero_fill(tables, sizeof(float) * (size_t)c.frames * 4 * MAX_WIDTH, s));
         AdainBwd ab;
         memset(&ab, 0, sizeof(ab));
         ab.r = rc; ab.h = h2; ab.ld = d.W2pad; ab.width = d.W2; ab.table = table; ab.table_stride = table_stride;
@@ -1792,7 +1792,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         ab.mean = batch + 2 * MAX_WIDTH; ab.var = batch + 3 * MAX_WIDTH; ab.eps = m.bn_eps;
         ab.g = bufB; ab.sums = sums; ab.dscale = dscale2; ab.dbias = dbias2; ab.count = stat_count;
         ab.frozen = (c.flags & PR_FLAG_TRAIN_BN) ? 0 : 1;
-        PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
+        PR_TRY(launch_zero_fill(sums, sizeof(double) * 2 * MAX_WIDTH, s));
         hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk, (d.W2 + 63) / 64), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
@@ -1806,7 +1806,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
         // ---- AdaIN + BatchNorm 1 ------------------------------------------------------------------
         ab.h = h1; ab.ld = d.Wpad; ab.width = d.W; ab.goff = 0; ab.boff = d.Wpad;
         ab.mean = batch; ab.var = batch + MAX_WIDTH; ab.g = bufA; ab.dscale = dscale1; ab.dbias = dbias1;
-        PR_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * MAX_WIDTH, s));
+        PR_TRY(launch_zero_fill(sums, sizeof(double) * 2 * MAX_WIDTH, s));
         hipLaunchKernelGGL(k_adain_bwd_reduce, dim3(grid_blk, (d.W + 63) / 64), dim3(256), 0, s, ab);
         PR_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_adain_bwd_apply, dim3(grid_rows), dim3(256), 0, s, ab);
@@ -1974,7 +1974,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
     int32_t* totals = reinterpret_cast<int32_t*>(fws + tp.totals);
     const int F = objs[0].coarse.output_features;
     const int Fs = (F + 15) & ~15;
-    PR_CHECK_HIP(hipMemsetAsync(bws + gp.zero_begin, 0, gp.zero_bytes, s));
+    PR_TRY(launch_zero_fill(bws + gp.zero_begin, gp.zero_bytes, s));
     CompositeBwdResult cr;
     PR_TRY(composite_backward(c, objs, t, grads, out, fws, plan, bws, bp, s, &cr));
 

@@ -535,7 +535,7 @@ int launch_resample(const ResampleParams& p, hipStream_t s) {
     PR_REQUIRE(p.pc >= 3, "hierarchical sampling needs at least 3 coarse positions (got %d)", p.pc);
     const long total = (long)p.frames * p.rays;
     const int nblocks256 = (int)((total + 255) / 256);
-    PR_CHECK_HIP(hipMemsetAsync(p.block_sums, 0, sizeof(int32_t) * nblocks256, s));
+    PR_TRY(launch_zero_fill(p.block_sums, sizeof(int32_t) * nblocks256, s));
     int sort_size = next_pow2(p.pc + p.pf);
     if (sort_size < 64) sort_size = 64;
     const size_t lds = sizeof(float) * (4 * (size_t)p.pc + 2 * (size_t)sort_size);   // inputs + sort keys + merged list

@@ -229,9 +229,11 @@ struct NoiseRef {
     unsigned int key0, key1;     // Philox key of the stream (generate != 0)
     int generate;                // 1: values come from the generator
     int rays, ray_offset, total_rays;   // ray r of frame n of this call is ray (ray_offset + r) of total_rays in the stream's index space
+    const unsigned long long* seed_dev; // the call's seed as a device word (pr_call_t.noise_seed_device), or NULL: key0 / key1 are final
+    unsigned long long salt;            // with seed_dev: key = mix(*seed_dev ^ salt), what the host computes from noise_seed otherwise
 };
 
-static inline unsigned long long noise_mix(unsigned long long x) {   // splitmix64 finaliser
+__host__ __device__ static inline unsigned long long noise_mix(unsigned long long x) {   // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
@@ -246,9 +248,11 @@ static inline NoiseRef make_noise(const float* ptr, const pr_call_t& c, int kind
     n.ray_offset = c.noise_ray_offset;
     n.total_rays = c.noise_total_rays > 0 ? c.noise_total_rays : c.rays;
     if (!ptr && (c.flags & PR_FLAG_DEVICE_NOISE)) {
-        const unsigned long long k = noise_mix(c.noise_seed ^ noise_mix((unsigned long long)(kind * 16 + type * 8 + object) + 1));
+        n.salt = noise_mix((unsigned long long)(kind * 16 + type * 8 + object) + 1);
+        const unsigned long long k = noise_mix(c.noise_seed ^ n.salt);
         n.key0 = (unsigned int)k;
         n.key1 = (unsigned int)(k >> 32);
+        n.seed_dev = reinterpret_cast<const unsigned long long*>(c.noise_seed_device);
         n.generate = 1;
     }
     return n;
@@ -456,6 +460,8 @@ struct Plan {
 // Once per (kernel, device): raises the kernel's dynamic LDS limit on the CURRENT device; *cu_count (optional) receives
 // that device's number of compute units.  Function attributes are per device: a process may drive several.
 int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count);
+// zero `bytes` bytes (a multiple of 4, 4-byte aligned) with a kernel on `s`
+int launch_zero_fill(void* dst, size_t bytes, hipStream_t s);
 int validate_call(const pr_call_t& c, const pr_object_t* objs);
 bool group_active(const pr_call_t& c);
 bool group_train_active(const pr_call_t& c);
@@ -641,19 +647,32 @@ __device__ __forceinline__ unsigned long long noise_index(const NoiseRef& n, lon
     return (unsigned long long)(frame * n.total_rays + n.ray_offset + r) * per_ray + e;
 }
 
+// Philox key of a stream: fixed by the host from pr_call_t.noise_seed, or derived here from the seed word on the device
+__device__ __forceinline__ void noise_key(const NoiseRef& n, unsigned int* k0, unsigned int* k1) {
+    *k0 = n.key0;
+    *k1 = n.key1;
+    if (n.seed_dev) {
+        const unsigned long long k = noise_mix(*n.seed_dev ^ n.salt);
+        *k0 = (unsigned int)k;
+        *k1 = (unsigned int)(k >> 32);
+    }
+}
+
 __device__ __forceinline__ float noise_uniform(const NoiseRef& n, long g, int per_ray, int e) {   // U[0, 1)
     if (n.ptr) return n.ptr[(size_t)g * per_ray + e];      // explicit tensors arrive already sliced to the call's rays
     const unsigned long long idx = noise_index(n, g, per_ray, e);
-    unsigned int x[4];
-    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, n.key0, n.key1, x);
+    unsigned int x[4], k0, k1;
+    noise_key(n, &k0, &k1);
+    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, k0, k1, x);
     return (float)(x[0] >> 8) * 5.9604644775390625e-8f;   // 24 random bits * 2^-24
 }
 
 __device__ __forceinline__ float noise_normal(const NoiseRef& n, long g, int per_ray, int e) {    // N(0, 1), Box-Muller
     if (n.ptr) return n.ptr[(size_t)g * per_ray + e];
     const unsigned long long idx = noise_index(n, g, per_ray, e);
-    unsigned int x[4];
-    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, n.key0, n.key1, x);
+    unsigned int x[4], k0, k1;
+    noise_key(n, &k0, &k1);
+    philox4x32_10((unsigned int)idx, (unsigned int)(idx >> 32), 0u, 0u, k0, k1, x);
     const float u1 = (float)((x[0] >> 8) + 1u) * 5.9604644775390625e-8f;   // (0, 1]
     const float u2 = (float)(x[1] >> 8) * 5.9604644775390625e-8f;          // [0, 1)
     return sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795864769f * u2);

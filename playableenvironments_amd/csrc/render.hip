@@ -38,6 +38,30 @@ int prepare_kernel(const void* kernel, int lds_bytes, int* cu_count) {
     return PR_OK;
 }
 
+// Every zero fill of the library is this kernel, never hipMemsetAsync: recorded into a HIP graph a memset becomes a memset NODE,
+// and on ROCm 7.0.2 memset nodes stop executing after a few back-to-back replays followed by a host synchronisation (with the
+// runtime's AQL packet capture on; DESIGN.md "Recorded training step") - a kernel node does not.
+__global__ __launch_bounds__(256) void k_zero_fill(uint4* dst16, size_t n16, uint32_t* tail, size_t ntail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst16[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ntail; i += (size_t)gridDim.x * 256) tail[i] = 0u;
+}
+
+int launch_zero_fill(void* dst, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return PR_OK;
+    PR_REQUIRE((bytes & 3) == 0 && ((uintptr_t)dst & 3) == 0, "zero fill: %zu bytes at a misaligned address", bytes);
+    // 16-byte stores where the address allows them, 4-byte stores for the rest (and for small misaligned regions as a whole)
+    const bool aligned = ((uintptr_t)dst & 15) == 0;
+    const size_t n16 = aligned ? bytes / 16 : 0;
+    const size_t ntail = (bytes - n16 * 16) / 4;
+    size_t blocks = ((n16 > ntail ? n16 : ntail) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint4*>(dst), n16,
+                       reinterpret_cast<uint32_t*>(static_cast<char*>(dst) + n16 * 16), ntail);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
 ProfileScope::ProfileScope(int category, hipStream_t s) : category_(category), stream_(s), start_(nullptr), active_(false) {
     if (!g_profile_on.load(std::memory_order_relaxed)) return;
     if (hipEventCreate(&start_) != hipSuccess) return;
@@ -305,7 +329,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         int32_t* head_counts = reinterpret_cast<int32_t*>(ws + tp.head_counts);
         // one fill: feature-head / tile counters, and - training / differentiable calls - every object's batch-statistics
         // accumulators and divergence array
-        PR_CHECK_HIP(hipMemsetAsync(ws + tp.zero_begin, 0, tp.zero_bytes, s));
+        PR_TRY(launch_zero_fill(ws + tp.zero_begin, tp.zero_bytes, s));
         const pr_noise_t& noise = t ? c.noise_fine : c.noise_coarse;
         int total_positions = 0;
         // what follows phase 1 of an object's phased launches (training / differentiable calls): batch statistics, the two head
@@ -493,7 +517,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             }
             mp.tile_counter = head_counts + PR_MAX_OBJECTS + k;
             if (outs[t] && outs[t]->sample_delta[k]) {
-                PR_CHECK_HIP(hipMemsetAsync(outs[t]->sample_delta[k], 0, sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
+                PR_TRY(launch_zero_fill(outs[t]->sample_delta[k], sizeof(float) * 3 * (size_t)c.frames * c.rays * P, s));
                 if (m.has_bender) mp.delta_dense = outs[t]->sample_delta[k];
             }
             const size_t cap = (size_t)c.frames * c.rays * P;

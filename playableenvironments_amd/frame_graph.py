@@ -12,12 +12,25 @@ the weights (re-capture after an optimiser step or ``load_state_dict``), the com
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
 
 SCENE_KEYS = ("camera_rotations", "camera_translations", "focals", "object_rotation_parameters",
               "object_translation_parameters", "object_style", "object_deformation", "object_in_scene")
+
+#: ROCm 7.0.2, HIP runtime with AQL packet capture (its default): replays of a recorded TRAINING step go wrong once the host has
+#: synchronised between them - the graph's memset nodes stop executing (torch's multi-block reductions, ``x.mean()`` /
+#: ``x.sum()``, zero their semaphores with one: the loss freezes, accumulators keep stale values, gradients explode).  Measured
+#: with tests/perf_train_graph.py; neither one replay in flight at a time nor waiting on events avoids it.  With the capture
+#: path off the replays are correct (tests/graph_step_check.py) - and cost what eager launches cost on the device side, so
+#: what a recording buys is HOST time.  The switch has to be in the environment before the process makes its first HIP call.
+GRAPH_RUNTIME_SWITCH = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+def graph_runtime_is_safe() -> bool:
+    return os.environ.get(GRAPH_RUNTIME_SWITCH[0]) == GRAPH_RUNTIME_SWITCH[1]
 
 
 class FrameGraph:
@@ -83,3 +96,49 @@ class FrameGraph:
             self.inputs[k].copy_(src, non_blocking=True)
         self.graph.replay()
         return self.results
+
+
+class GraphedStep:
+    """A whole training iteration - renderer forward, loss, ``backward()``, optimiser step - recorded once as a HIP graph
+    and replayed: ``step_fn()`` (no arguments; it reads its inputs from tensors that stay in place, e.g. a ``Batch`` arena
+    the caller copies every new batch into) is run ``warmup`` times on a side stream, recorded, and every ``replay()``
+    re-runs the recorded launches - the renderer's ~40 and the few hundred small torch kernels around them - with one host call.
+    On ROCm 7.0.2 this buys host time only, and needs a runtime switch (``GRAPH_RUNTIME_SWITCH`` above).
+
+    What makes the renderer recordable: the library never allocates, synchronises or reads anything back, launches on the
+    caller's stream, and draws the noise of a recorded call from a seed WORD on the device (``pr_call_t.noise_seed_device``,
+    filled by torch's device generator inside the graph), so that every replay perturbs differently and its backward
+    pass regenerates exactly its own forward pass's noise.  The pixel samplers draw on the device too (ray_sampling.py).
+
+    Requirements on ``step_fn``: fixed shapes; no host synchronisation (``.item()``, ``.cpu()``); an optimiser built with
+    ``capturable=True``; ``optimizer.zero_grad(set_to_none=True)`` inside it (gradients then live in the graph's pool).
+    A recorded training call cannot raise from its replays: the BatchNorm sample-count check of ``ObjectComposer`` is left
+    to the caller (``ObjectComposer.last_normalised_samples``).  Whatever ``step_fn`` returns is returned by ``replay()``
+    as the same (static) tensors, overwritten by the next replay.
+
+    >>> opt = torch.optim.Adam(params, lr=1e-4, capturable=True, fused=True)
+    >>> step = GraphedStep(lambda: train_iteration(batch_arena, model, opt))
+    >>> for batch in loader: batch_arena.copy_from(batch); loss = step.replay()"""
+
+    def __init__(self, step_fn, warmup: int = 3, device=None):
+        if not graph_runtime_is_safe():
+            raise RuntimeError(f"GraphedStep needs {GRAPH_RUNTIME_SWITCH[0]}={GRAPH_RUNTIME_SWITCH[1]} in the environment before the first HIP "
+                               "call of the process: with the runtime's AQL packet capture, replays of a recorded training step "
+                               "compute garbage once the host has synchronised between them (ROCm 7.0.2; see frame_graph.py)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):      # packs weights, sizes workspaces, creates optimiser state, raises LDS limits
+                step_fn()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = step_fn()
+        self.replays = 0
+
+    def replay(self):
+        self.graph.replay()
+        self.replays += 1
+        return self.outputs

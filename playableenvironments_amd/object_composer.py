@@ -285,7 +285,12 @@ class ObjectComposer(nn.Module):
         #: seed, regenerated by the backward pass; nothing of size (N, R, P) is materialised); "torch" - torch.rand / torch.randn
         #: tensors as in round 1.  The per-call seed is drawn from torch's CPU generator (torch.manual_seed makes runs repeatable).
         self.noise_source = "device"
-        self.last_noise_seed: Optional[int] = None
+        #: where the seed of a call's generated noise lives: "host" = drawn from torch's CPU generator and handed over by value
+        #: (no device work), "device" = one word drawn by torch's DEVICE generator that the kernels read when they run - what a
+        #: call recorded into a HIP graph needs to draw fresh noise on every replay (chosen automatically while a stream is
+        #: being captured; see frame_graph.GraphedStep)
+        self.noise_seed_source = "host"
+        self.last_noise_seed = None      # int ("host") or a one-element int64 device tensor ("device")
         #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
         #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
         #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
@@ -296,6 +301,8 @@ class ObjectComposer(nn.Module):
         self._pending_bn_check: Optional[tuple] = None
 
     def _raise_pending_batchnorm_check(self):
+        if torch.cuda.is_current_stream_capturing():
+            return     # (no event waits while a graph is recorded: the check stays pending for the next eager call)
         pending, self._pending_bn_check = self._pending_bn_check, None
         if pending is None:
             return
@@ -448,6 +455,8 @@ class ObjectComposer(nn.Module):
         held = self._workspace.numel() if (self._workspace is not None and self._workspace.device == dev) else 0
         if need <= min(cap, held):
             return cap          # fits the workspace that is already allocated: no device query on the hot path
+        if torch.cuda.is_current_stream_capturing():
+            return cap          # (no device queries while a graph is recorded: the warm-up calls have sized the call already)
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         return max(1 << 20, min(cap, int(0.8 * (free + cached + held))))   # the result tensors need room too
@@ -648,10 +657,20 @@ class ObjectComposer(nn.Module):
         needs_noise = perturb or (_save and self.training)
         device_noise = needs_noise and _noise is None and self.noise_source == "device"
         noise_seed = 0
+        seed_word = None
+        capturing = torch.cuda.is_current_stream_capturing()
         if device_noise:
             flags |= _lib.PR_FLAG_DEVICE_NOISE
-            noise_seed = int(torch.empty((), dtype=torch.int64).random_())      # CPU generator: no device synchronisation
-            self.last_noise_seed = noise_seed
+            if self.noise_seed_source not in ("host", "device"):
+                raise ValueError(f"unknown noise_seed_source {self.noise_seed_source!r} (expected 'host' or 'device')")
+            if self.noise_seed_source == "device" or capturing:
+                # one word per call (the backward pass of THIS call regenerates the forward's values from it, whatever other
+                # calls run in between), drawn by the device generator: part of the graph when the call is captured
+                seed_word = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+                self.last_noise_seed = seed_word
+            else:
+                noise_seed = int(torch.empty((), dtype=torch.int64).random_())      # CPU generator: no device synchronisation
+                self.last_noise_seed = noise_seed
 
         def get(name, shape, normal):
             if device_noise:
@@ -689,6 +708,9 @@ class ObjectComposer(nn.Module):
             call.use_fine = 1 if use_fine else 0
             call.flags = flags
             call.noise_seed = noise_seed
+            if seed_word is not None:
+                call.noise_seed_device = seed_word.data_ptr()
+                keep.append(seed_word)
             call.noise_ray_offset, call.noise_total_rays = r0, R
             call.precision = self._precision_code(_save)
             d = dirs if (r0 == 0 and r1 == R) else dirs[:, r0:r1].contiguous()
@@ -836,7 +858,9 @@ class ObjectComposer(nn.Module):
 
         if self.training:
             self.last_normalised_samples = {ty: pieces[0][ty]["_normalised"] for ty in types}
-        if self.training and self.batchnorm_check == "deferred":
+        if self.training and capturing:
+            pass       # a recorded call cannot raise from its replays: the counts stay in last_normalised_samples for the caller
+        elif self.training and self.batchnorm_check == "deferred":
             counts = torch.cat([pieces[0][ty]["_normalised"] for ty in types])
             host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
             host.copy_(counts, non_blocking=True)

@@ -4,6 +4,7 @@ the C ABI, against the CPU oracle and the reference-generated golden vectors.
 Tolerance (fp32 path, exact-fp32 MFMA): rtol 1e-4, atol 1e-5 on every result field, NaNs in the
 same places.  Sample depths and AABB decisions must be bit-identical."""
 import os
+import sys
 
 import pytest
 import torch
@@ -1066,6 +1067,20 @@ def test_eight_object_instances():
         big[6] = torch.cat([big[6], big[6][..., :1]], -1)
         with torch.no_grad():
             c9(*big, False)            # nine instances: rejected (PR_MAX_OBJECTS)
+
+
+def test_recorded_training_step_equals_eager_steps():
+    """frame_graph.GraphedStep: forward + loss + backward + Adam recorded once as a HIP graph and replayed (batches of
+    back-to-back replays with host synchronisations between them) leaves the parameters where the same eager iterations leave
+    them; with perturbation every replay draws its own noise seed on the device.  Runs in its own process: the runtime switch
+    that keeps the memset nodes of a recorded graph alive on ROCm 7.0.2 has to be in the environment before the first HIP call."""
+    import subprocess
+    from playableenvironments_amd.frame_graph import GRAPH_RUNTIME_SWITCH
+    env = dict(os.environ)
+    env[GRAPH_RUNTIME_SWITCH[0]] = GRAPH_RUNTIME_SWITCH[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_step_check.py")
+    done = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0 and "GRAPH STEP OK" in done.stdout, done.stdout[-2000:] + done.stderr[-4000:]
 
 
 def test_frame_graph_replay_is_bit_identical():
