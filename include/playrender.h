@@ -351,6 +351,17 @@ int pr_camera_rays(int32_t frames, int32_t rays, int32_t height, int32_t width, 
                    float* ray_origins, float* ray_directions, float* focal_normals, void* stream);
 
 /*
+ * Strided patch pixels (RayHelper.sample_rays_strided_patch, utils/lib_3d/ray_helper.py:236-431): per frame one random patch
+ * centre drawn from the bounding-box weight image (object k adds weights[k] / area_k over its pixel-aligned box), clamped into
+ * the image and aligned to the grid of the largest stride; then for every stride s_i (ascending) a p_i x p_i pixel grid with
+ * p_i = patch_size * s_0 / s_i, row-major, strides concatenated: rows / cols (N, sum p_i^2) int32.  boxes (N,4,K) normalised
+ * [left, top, right, bottom]; weights (K); u (N) the uniform draws in [0, 1), one per frame.
+ */
+int pr_patch_pixels(int32_t frames, int32_t objects, int32_t height, int32_t width, int32_t patch_size, int32_t stride_count,
+                    const int32_t* strides /* host */, const float* boxes, const float* weights, const float* u,
+                    int32_t* rows, int32_t* cols, void* stream);
+
+/*
  * Pose matrices: (rotation (x, y, z Euler angles, radians), translation) -> the 4x4 transform [R t; 0 1] with R = Ry (Rx Rz)
  * (Transformations3D.homogeneous_rotation_translation, utils/lib_3d/transformations_3d.py:69-96) and its inverse
  * [R^T  -R^T t; 0 1] (the reference calls torch.inverse on it: environment_model.py:221, :1078).  rotations, translations

@@ -564,6 +564,122 @@ extern "C" int pr_expected_positions(int32_t frames, int32_t rays, int32_t objec
 }
 
 namespace pr {
+// ---------------------------------------------------------------------------------------------
+// RayHelper.sample_rays_strided_patch (utils/lib_3d/ray_helper.py:236-431) on the device: per frame one box-weighted random
+// centre, clamped so that the patch stays inside the image and aligned to the grid of the largest stride, then a p_i x p_i pixel
+// grid per stride (p_i = patch * s_0 / s_i), strides concatenated smallest first, row-major.  The reference builds the weight
+// image (every object adds w_k / area_k over its pixel-aligned box), normalises, takes its cumulative sum and looks the draw up;
+// the weight image is a sum of K box indicators, so its row-major prefix sum has a closed form and the lookup is a binary search
+// with O(K) per probe - nothing of size H x W is touched, ~80 small tensor ops become one launch.
+// ---------------------------------------------------------------------------------------------
+struct PatchPixelsParams {
+    int frames, objects, height, width, patch, nstrides;
+    int strides[4];
+    const float* boxes;      // (N, 4, K) normalised [left, top, right, bottom]
+    const float* weights;    // (K)
+    const float* u;          // (N) uniform draws
+    int32_t* rows; int32_t* cols;   // (N, R)
+    int rays;
+};
+
+__global__ __launch_bounds__(256) void k_patch_pixels(PatchPixelsParams p) {
+    __shared__ int start[2];
+    const int n = blockIdx.x;
+    const int H = p.height, W = p.width, K = p.objects;
+    const int s0 = p.strides[0], sm = p.strides[p.nstrides - 1];
+    if (threadIdx.x == 0) {
+        float left[PR_MAX_OBJECTS], right[PR_MAX_OBJECTS], top[PR_MAX_OBJECTS], bottom[PR_MAX_OBJECTS], per[PR_MAX_OBJECTS];
+        for (int k = 0; k < K; ++k) {
+            const float* b = p.boxes + (size_t)n * 4 * K + k;
+            left[k] = fminf(fmaxf(floorf(b[0] * W), 0.f), (float)W);
+            top[k] = fminf(fmaxf(floorf(b[K] * H), 0.f), (float)H);
+            right[k] = fminf(fmaxf(ceilf(b[2 * K] * W), 0.f), (float)W);
+            bottom[k] = fminf(fmaxf(ceilf(b[3 * K] * H), 0.f), (float)H);
+            per[k] = p.weights[k] / ((right[k] - left[k]) * (bottom[k] - top[k]));       // inf / nan for an empty box, as the reference
+        }
+        // inclusive prefix sum of the weight image up to flat pixel i (row-major)
+        auto prefix = [&](long i) -> double {
+            const int r = (int)(i / W), c = (int)(i - (long)r * W);
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double w = right[k] - left[k];
+                const double full = fmin((double)r, (double)bottom[k]) - top[k];          // complete rows of the box above row r
+                double count = full > 0.0 ? full * w : 0.0;
+                if (r >= top[k] && r < bottom[k]) {
+                    const double part = fmin((double)(c + 1), (double)right[k]) - left[k];
+                    if (part > 0.0) count += part;
+                }
+                if (count > 0.0) acc += (double)per[k] * count;
+            }
+            return acc;
+        };
+        const long total_px = (long)H * W;
+        const double total = prefix(total_px - 1);
+        long idx = total_px - 1;     // a weight image that does not normalise (empty boxes): the lookup runs off the end and is clamped
+        if (total > 0.0 && total < 1e300) {
+            const double target = (double)p.u[n] * total;
+            long lo = 0, hi = total_px - 1;
+            while (lo < hi) {                        // first pixel whose cumulative weight reaches the draw
+                const long mid = (lo + hi) >> 1;
+                if (prefix(mid) >= target) hi = mid; else lo = mid + 1;
+            }
+            idx = lo;
+        }
+        const int half = ((p.patch * s0) / sm) / 2;
+        int row = (int)(idx / W), col = (int)(idx - (long)row * W);
+        row = min(max(row, half * sm), H - sm * (half - 1) - 1);
+        col = min(max(col, half * sm), W - sm * (half - 1) - 1);
+        // snap the patch start to the grid of the largest stride (offset sm / 2), towards the reference's side (:372-396)
+        auto align = [&](int st) {
+            const int h = sm / 2, d = st % sm;
+            if (d == h) return st;
+            return st >= h ? st - (d + h) % sm : st + (sm + h - d);
+        };
+        start[0] = align(row - half * sm);
+        start[1] = align(col - half * sm);
+    }
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < p.nstrides; ++q) {
+        const int s = p.strides[q], size = (p.patch * s0) / s, off = sm / 2 - s / 2;
+        for (int i = threadIdx.x; i < size * size; i += 256) {
+            const int a = i / size, b = i - a * size;
+            p.rows[(size_t)n * p.rays + base + i] = start[0] - off + a * s;
+            p.cols[(size_t)n * p.rays + base + i] = start[1] - off + b * s;
+        }
+        base += size * size;
+    }
+}
+}  // namespace pr
+
+extern "C" int pr_patch_pixels(int32_t frames, int32_t objects, int32_t height, int32_t width, int32_t patch_size, int32_t stride_count,
+                               const int32_t* strides, const float* boxes, const float* weights, const float* u, int32_t* rows,
+                               int32_t* cols, void* stream) {
+    PR_REQUIRE(frames > 0 && objects >= 1 && objects <= PR_MAX_OBJECTS && height > 0 && width > 0, "pr_patch_pixels: bad sizes");
+    PR_REQUIRE(stride_count >= 1 && stride_count <= 4 && strides, "pr_patch_pixels: 1..4 strides");
+    PR_REQUIRE(boxes && weights && u && rows && cols, "pr_patch_pixels: NULL pointer");
+    PR_REQUIRE(patch_size > 0 && patch_size % 2 == 0, "Patch size must be a multiple of 2");
+    pr::PatchPixelsParams p;
+    memset(&p, 0, sizeof(p));
+    p.frames = frames; p.objects = objects; p.height = height; p.width = width; p.patch = patch_size; p.nstrides = stride_count;
+    int rays = 0;
+    for (int q = 0; q < stride_count; ++q) {
+        PR_REQUIRE(strides[q] > 0 && (q == 0 || strides[q] >= strides[q - 1]), "pr_patch_pixels: strides must ascend");
+        p.strides[q] = strides[q];
+    }
+    PR_REQUIRE((patch_size * strides[0]) % (2 * strides[stride_count - 1]) == 0,
+               "Patch size is not compatible with the chosen strides. Make patch size divisible by a higher power of 2");
+    for (int q = 0; q < stride_count; ++q) {
+        const int size = (patch_size * strides[0]) / strides[q];
+        rays += size * size;
+    }
+    p.boxes = boxes; p.weights = weights; p.u = u; p.rows = rows; p.cols = cols; p.rays = rays;
+    hipLaunchKernelGGL(pr::k_patch_pixels, dim3(frames), dim3(256), 0, (hipStream_t)stream, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+namespace pr {
 // (rotation, translation) -> [R t; 0 1] with R = Ry (Rx Rz) and its rigid inverse [R^T  -R^T t; 0 1], one thread per matrix:
 // Transformations3D.homogeneous_rotation_translation (utils/lib_3d/transformations_3d.py:69-96) and the torch.inverse the
 // reference applies to it (environment_model.py:221, :1078).  As torch ops this is ~30 launches per call (six sin / cos,

@@ -572,8 +572,8 @@ class EnvironmentModel(nn.Module):
         lead = list(camera_rotations.shape[:-1])
         flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
         if patch_size != 0 and samples_per_image != 0:
-            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
-            rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
+            rows, cols = ray_sampling.strided_patch_rows_cols(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride)
+            rows, cols = rows.reshape(lead + [-1]), cols.reshape(lead + [-1])
         elif samples_per_image == 0:
             # static pixel lists (every pixel, or the strided grids): built once per (size, strides, device)
             strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)
@@ -732,8 +732,13 @@ class EnvironmentModel(nn.Module):
         per frame, or a shared (R,) list for the static selections."""
         flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
         if patch_size != 0 and samples_per_image != 0:
-            idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride,
-                                                    align_grid=align_grid)
+            if flat_boxes.is_cuda:
+                rows, cols = ray_sampling.strided_patch_rows_cols(flat_boxes, self.sampling_weights, height, width, patch_size,
+                                                                  patch_stride, align_grid=align_grid)
+                idx = rows.to(torch.int64) * width + cols.to(torch.int64)
+            else:
+                idx = ray_sampling.strided_patch_pixels(flat_boxes, self.sampling_weights, height, width, patch_size, patch_stride,
+                                                        align_grid=align_grid)
             return idx.reshape(lead + [-1])
         if samples_per_image == 0:
             strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)

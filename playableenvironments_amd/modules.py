@@ -141,7 +141,9 @@ class _AnnealableEncoderState(nn.Module):
         self.register_buffer("current_step", torch.zeros((), dtype=torch.int))
 
     def set_step(self, current_step: int):
-        self.current_step = self.current_step * 0 + current_step
+        # in place: the buffer keeps its storage and its version counter moves, which is what the composer's host-side caches of
+        # the octave weights key on (a fresh tensor per call could come back at a recycled address with version 0)
+        self.current_step.fill_(current_step)
 
     def annealing_weights(self) -> torch.Tensor:
         """(1 - cos(pi clamp(step * octaves / num_steps - k, 0, 1))) / 2  (annealable_positional_encoder.py:59-63)."""

@@ -107,7 +107,7 @@ class _RenderFunction(torch.autograd.Function):
         ctx.ray_grads = ray_origins.requires_grad or ray_directions.requires_grad
         # the backward pass reads the parameter storages in place: an in-place update between forward and backward
         # (an optimiser step, a GAN-style second network update) must raise, as torch's saved-tensor check would
-        ctx.versions = tuple(p._version for p in composer.parameters())
+        ctx.versions = tuple(p._version for p in composer._parameter_list())
         ctx.shapes = (w2o.shape, style.shape, deformation.shape)
         ctx.set_materialize_grads(False)      # outputs the loss does not read arrive as None, not as zero tensors
         holder["results"], holder["types"] = results, state["types"]
@@ -146,7 +146,7 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, *grad_outputs):
         st, composer = ctx.state, ctx.composer
-        if tuple(p._version for p in composer.parameters()) != ctx.versions:
+        if tuple(p._version for p in composer._parameter_list()) != ctx.versions:
             raise RuntimeError("one of the composer's parameters was modified in place between the renderer's forward and "
                                "backward calls (pr_render_backward reads the parameter storages): call backward() before "
                                "the optimiser step")
@@ -266,6 +266,9 @@ class ObjectComposer(nn.Module):
         #: bumped by set_step / load_state_dict / .to(): captured frame graphs compare it (frame_graph.FrameGraph)
         self.state_epoch = 0
         self._packed: Dict[tuple, tuple] = {}
+        self._param_lists: Dict[int, list] = {}      # id(module) -> list(module.parameters())
+        self._structs: Dict[tuple, tuple] = {}       # (id(model), positions) -> (key, pr_object_model_t)
+        self._budget_ok = 0                          # largest workspace size a device query has granted
         self._annealing: Dict[int, tuple] = {}
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
@@ -339,8 +342,21 @@ class ObjectComposer(nn.Module):
         self._annealing.clear()
         self.state_epoch += 1
 
+    def _parameter_list(self, module=None) -> list:
+        """``list(module.parameters())`` (module = None: the composer), cached: walking the module tree costs ~0.3 ms per call and
+        a training step asks five times.  Dropped with the other storage-derived caches (``_apply``, ``load_state_dict``)."""
+        key = id(self if module is None else module)
+        cached = self._param_lists.get(key)
+        if cached is None:
+            cached = list((self if module is None else module).parameters())
+            self._param_lists[key] = cached
+        return cached
+
     def _drop_device_caches(self):
         """Everything derived from parameter / buffer storages or tied to a device."""
+        self._param_lists.clear()
+        self._structs.clear()
+        self._budget_ok = 0
         self._packed.clear()
         self._annealing.clear()
         self._linspace.clear()
@@ -359,6 +375,21 @@ class ObjectComposer(nn.Module):
 
     # ------------------------------------------------------------------ marshalling
     def _model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
+        """The model's pr_object_model_t (raw parameter / buffer pointers, shapes, octave weights), cached per (model, positions):
+        rebuilt when the storages may have moved (state_epoch), the annealing step changed, or the first / last parameter is
+        not where it was (a re-assigned ``nn.Parameter``)."""
+        params = self._parameter_list(model)
+        step = model.ray_bender.positional_encoder.current_step if model.ray_bender.has_weights else None
+        key = (self.state_epoch, params[0].data_ptr(), params[-1].data_ptr(),
+               None if step is None else (step.data_ptr(), step._version))
+        cached = self._structs.get((id(model), positions))
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        s = self._build_model_struct(model, positions)
+        self._structs[(id(model), positions)] = (key, s)
+        return s
+
+    def _build_model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
         cfg = model.model_config
         nerf, bender = model.nerf_model, model.ray_bender
         s = _lib.ObjectModel()
@@ -432,7 +463,7 @@ class ObjectComposer(nn.Module):
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int,
                         differentiable: bool = False) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
-        params = list(model.parameters())
+        params = self._parameter_list(model)
         precision = self._precision_code(differentiable)
         key = tuple((p.data_ptr(), p._version) for p in params)
         slot = (id(model), precision)   # one buffer per precision: a render at the other precision never evicts this one
@@ -453,13 +484,16 @@ class ObjectComposer(nn.Module):
         the workspace that would be released first)."""
         cap = int(self.max_workspace_bytes)
         held = self._workspace.numel() if (self._workspace is not None and self._workspace.device == dev) else 0
-        if need <= min(cap, held):
-            return cap          # fits the workspace that is already allocated: no device query on the hot path
+        if need <= min(cap, max(held, self._budget_ok)):
+            return cap          # fits what is already allocated / what a device query has granted before: no query on the hot path
         if torch.cuda.is_current_stream_capturing():
             return cap          # (no device queries while a graph is recorded: the warm-up calls have sized the call already)
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        return max(1 << 20, min(cap, int(0.8 * (free + cached + held))))   # the result tensors need room too
+        budget = max(1 << 20, min(cap, int(0.8 * (free + cached + held))))   # the result tensors need room too
+        if need <= budget:
+            self._budget_ok = need       # (a training loop asks for the same size every step; reset with the other caches)
+        return budget
 
     def _linspace_for(self, count: int, device) -> torch.Tensor:
         key = (count, str(device))
@@ -512,7 +546,7 @@ class ObjectComposer(nn.Module):
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
         args = (ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation, object_in_scene,
                 perturb, canonical_pose, _noise, _export, False, None, _decoder_layout)
-        params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        params = [p for p in self._parameter_list() if p.requires_grad] if torch.is_grad_enabled() else []
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
                                                   transformation_matrix_w2o.requires_grad or ray_origins.requires_grad or
                                                   ray_directions.requires_grad)
@@ -932,7 +966,7 @@ class ObjectComposer(nn.Module):
             shape = lead + [ray_directions.size(-2), model.model_config["positions_count_coarse"]]
             shared = torch.randn(shape, dtype=torch.float32, device=ray_directions.device)
             noise = {"alpha_0": shared, "int_coarse_0": shared}
-        params = [p for p in self.parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        params = [p for p in self._parameter_list() if p.requires_grad] if torch.is_grad_enabled() else []
         wants_grad = torch.is_grad_enabled() and (bool(params) or style.requires_grad or deformation.requires_grad or
                                                   transformation_matrix_w2o.requires_grad)
         if wants_grad:

@@ -107,8 +107,16 @@ def strided_patch_pixels(bounding_boxes: torch.Tensor, weights: Sequence[float],
     sizes = [(patch_size * s0) // s for s in strides]
     half = sizes[-1] // 2
     mask = _weight_masks(bounding_boxes, weights, height, width, guard_zero_area=False)
-    dev = mask.device
     centres = _sample_cdf(mask, 1)[:, 0]                                       # (N,) flat pixel index, stays on the device
+    return patch_pixels_around(centres, height, width, patch_size, strides)
+
+
+def patch_pixels_around(centres: torch.Tensor, height: int, width: int, patch_size: int, strides) -> torch.Tensor:
+    """The pixel grids of ``strided_patch_pixels`` for given patch centres (N,) (flat pixel indices)."""
+    s0, sm = strides[0], strides[-1]
+    sizes = [(patch_size * s0) // s for s in strides]
+    half = sizes[-1] // 2
+    dev = centres.device
     row = torch.div(centres, width, rounding_mode="floor")
     col = centres - row * width
     # min(hi, max(lo, x)): the patch stays inside the image
@@ -131,6 +139,41 @@ def strided_patch_pixels(bounding_boxes: torch.Tensor, weights: Sequence[float],
         c = (start_c - off).unsqueeze(1) + steps
         parts.append((r.unsqueeze(2) * width + c.unsqueeze(1)).reshape(r.size(0), size * size))
     return torch.cat(parts, dim=1)
+
+
+def strided_patch_rows_cols(bounding_boxes: torch.Tensor, weights: Sequence[float], height: int, width: int,
+                            patch_size: int, strides, align_grid: bool = True, _u: torch.Tensor = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``strided_patch_pixels`` as (rows, cols) int32 tensors of shape (N, sum p_i^2).  Device tensors take ONE launch
+    (``pr_patch_pixels``: the weight image's cumulative sum in closed form, one uniform draw per frame from torch's device
+    generator) instead of ~80 small tensor ops; host tensors go through ``strided_patch_pixels`` (index-for-index the
+    reference's sampler under a shared seed - the draws of the two routes differ)."""
+    if not bounding_boxes.is_cuda:
+        return split_indices(strided_patch_pixels(bounding_boxes, weights, height, width, patch_size, strides, align_grid), width)
+    if not align_grid:
+        raise Exception("Align grid is required for patched ray sampling.")
+    if patch_size % 2 != 0:
+        raise Exception("Patch size must be a multiple of 2")
+    if not isinstance(strides, collections.abc.Sequence):
+        strides = [strides]
+    strides = [int(v) for v in strides]
+    if (patch_size * strides[0]) % (2 * strides[-1]) != 0:
+        raise Exception("Patch size is not compatible with the chosen strides. Make patch size divisible by a higher power of 2")
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    bb = bounding_boxes.detach().to(torch.float32).contiguous()
+    n, _, k = bb.shape
+    dev = bb.device
+    rays = sum(((patch_size * strides[0]) // s) ** 2 for s in strides)
+    u = torch.rand((n,), device=dev) if _u is None else _u.to(device=dev, dtype=torch.float32).contiguous()
+    rows = torch.empty((n, rays), dtype=torch.int32, device=dev)
+    cols = torch.empty((n, rays), dtype=torch.int32, device=dev)
+    w = _object_weights(weights, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pr_patch_pixels(n, k, height, width, patch_size, len(strides), (C.c_int32 * len(strides))(*strides),
+                                       bb.data_ptr(), w.data_ptr(), u.data_ptr(), rows.data_ptr(), cols.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "pr_patch_pixels")
+    return rows, cols
 
 
 _ALIGNMENT_TABLES = {}

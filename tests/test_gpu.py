@@ -1069,6 +1069,34 @@ def test_eight_object_instances():
             c9(*big, False)            # nine instances: rejected (PR_MAX_OBJECTS)
 
 
+def test_patch_pixel_kernel_matches_the_tensor_route():
+    """pr_patch_pixels (one launch: closed-form cumulative sum of the box weight image + binary search) against the tensor-op route
+    of ray_sampling (weight image, cumulative sum, searchsorted - the reference's RayHelper.sample_rays_strided_patch) for the
+    SAME uniform draws: identical pixel lists, centres inside and outside the boxes, patches clamped at every image border."""
+    from playableenvironments_amd import ray_sampling as rs
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    weights = [0.2, 0.1, 0.35, 0.35]
+    for (h, w, patch, strides) in ((288, 512, 48, [4, 8]), (96, 160, 16, [2, 4]), (64, 64, 8, [4])):
+        n, k = 64, 4
+        lo = torch.rand((n, 2, k), device=dev) * 0.7
+        ext = torch.rand((n, 2, k), device=dev) * 0.3 + 0.02
+        boxes = torch.cat([lo, (lo + ext).clamp(max=1.0)], dim=1)              # (N, 4, K) [left, top, right, bottom]
+        boxes[:, :, 3] = torch.tensor([0.0, 0.0, 1.0, 1.0], device=dev)        # one object covers the frame: corners get drawn too
+        u = torch.rand((n,), device=dev)
+        u[:4] = torch.tensor([0.0, 1e-7, 0.9999999, 0.5], device=dev)
+        rows, cols = rs.strided_patch_rows_cols(boxes, weights, h, w, patch, strides, _u=u)
+        mask = rs._weight_masks(boxes, weights, h, w, guard_zero_area=False).double()
+        cdf = torch.cumsum(mask, dim=1)
+        centres = torch.searchsorted(cdf, (u.double() * cdf[:, -1]).unsqueeze(1)).clamp(max=h * w - 1)[:, 0]
+        want = rs.patch_pixels_around(centres, h, w, patch, strides)
+        got = rows.to(torch.int64) * w + cols.to(torch.int64)
+        same = (got == want).all(dim=1)
+        # a draw that lands within rounding of a pixel's cumulative weight may resolve to the neighbouring pixel
+        assert int((~same).sum()) <= 1, (int((~same).sum()), h, w)
+        assert int(rows.min()) >= 0 and int(rows.max()) < h and int(cols.min()) >= 0 and int(cols.max()) < w
+
+
 def test_recorded_training_step_equals_eager_steps():
     """frame_graph.GraphedStep: forward + loss + backward + Adam recorded once as a HIP graph and replayed (batches of
     back-to-back replays with host synchronisations between them) leaves the parameters where the same eager iterations leave
