@@ -1515,7 +1515,8 @@ static int chain_backward_fused(const GemmCtx& g, const pr_linear_t* layers, con
     cp.total = g.rows;
     cp.g_last = cur;
     cp.acts = acts; cp.act_stride = act_stride;
-    cp.bits = bits; cp.bits_stride = g.cap * (size_t)(width_pad / 8);
+    (void)bits;      // (the forward pass's bit images are column words for the grouped chain; this path builds its masks from the activations)
+    cp.bits = nullptr; cp.bits_stride = 0;
     cp.gstack = g.gstack; cp.g_stride = g.cap * (size_t)width_pad;
     cp.g_in = g_in; cp.ld_in = ld_in0;
     PR_TRY(launch_chain_bwd(cp, g.max_rows, g.s));
@@ -2089,7 +2090,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         for (int i = 1; i < nb; ++i) n.act_t[i] = Seg{packed + l.t_n_act[i], d.Wpad / 8, 0};
         n.in0_skip = Seg{packed + l.t_n_skip, d.Wpad / 8, 0};
         n.in0_first = Seg{packed + l.t_n_first, d.Wpad / 8, 0};
-        n.bits = reinterpret_cast<const unsigned char*>(fws + sv.bits); n.bits_stride = cap * (size_t)(d.Wpad / 8);
+        n.bits = reinterpret_cast<const unsigned char*>(fws + sv.bits); n.bits_stride = relu_bits_bytes(cap, d.Wpad);
         n.gstack = gstack; n.g_stride = cap * (size_t)d.Wpad;
         n.g_in = g_enc; n.ld_in = d.enc_pad;
         n.tile_counter = counters + 4 * k + 2;
@@ -2165,7 +2166,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
             for (int i = 1; i < bc; ++i) e.act_t[i] = Seg{packed + l.t_b_act[i], d.BWpad / 8, 0};
             e.in0_skip = Seg{packed + l.t_b_skip, d.BWpad / 8, 0};
             e.in0_first = Seg{packed + l.t_b_first, d.BWpad / 8, 0};
-            e.bits = reinterpret_cast<const unsigned char*>(fws + sv.bbits); e.bits_stride = cap * (size_t)(d.BWpad / 8);
+            e.bits = reinterpret_cast<const unsigned char*>(fws + sv.bbits); e.bits_stride = relu_bits_bytes(cap, d.BWpad);
             e.gstack = bgstack; e.g_stride = cap * (size_t)d.BWpad;
             e.g_in = g_benc; e.ld_in = d.bin_pad;
             e.tile_counter = counters + 4 * k + 3;

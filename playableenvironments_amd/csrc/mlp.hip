@@ -614,12 +614,16 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             __syncthreads();
             if (TRAIN && p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
-                run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc);
-                if (TRAIN && p.save_bact) {   // saved for the backward pass: the post-ReLU activations of every layer
-                    write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
-                    if (p.save_bbits) write_tile_bits(S, p.save_bbits + (size_t)l * p.save_bbits_stride, p.BWpad, tile_base);
-                    __syncthreads();
+                if (TRAIN) {
+                    run_layer<false, true>(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc, nullptr,
+                                           p.save_bbits ? reinterpret_cast<unsigned long long*>(p.save_bbits + (size_t)l * p.save_bbits_stride) +
+                                                              (size_t)tile * p.BWpad : nullptr);
+                } else {
+                    run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc);
                 }
+                // saved for the backward pass: the post-ReLU activations of every layer (the next layer only READS X until the
+                // barrier in front of its epilogue: no barrier needed behind the copy)
+                if (TRAIN && p.save_bact) write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
             }
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
             for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
@@ -663,12 +667,16 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
 
         // ---- backbone ---------------------------------------------------------------------------
         for (int l = 0; l < p.n_backbone; ++l) {
-            run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
-            if (TRAIN && p.save_act) {
-                if (!(PR_TRAINFWD_ABLATE & 1)) write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
-                if (p.save_bits && !(PR_TRAINFWD_ABLATE & 2)) write_tile_bits(S, p.save_bits + (size_t)l * p.save_bits_stride, p.Wpad, tile_base);
-                __syncthreads();
+            if (TRAIN) {
+                run_layer<false, true>(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc, nullptr,
+                                       (p.save_bits && !(PR_TRAINFWD_ABLATE & 2))
+                                           ? reinterpret_cast<unsigned long long*>(p.save_bits + (size_t)l * p.save_bits_stride) + (size_t)tile * p.Wpad
+                                           : nullptr);
+            } else {
+                run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
             }
+            if (TRAIN && p.save_act && !(PR_TRAINFWD_ABLATE & 1))
+                write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
         }
 
         PR_PHASE(15);

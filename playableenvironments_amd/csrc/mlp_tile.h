@@ -133,9 +133,11 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     PR_MFMA(acc, a.z, b.z); \
     PR_MFMA(acc, a.w, b.w)
 
-template <bool BWD = false>
+// BITS (training forward): the ReLU epilogue also leaves the layer's ReLU mask behind as one 64-bit word per column
+// (`bits_out[col]`, bit r = tile row r active) - what the backward chain's lane that owns the column reads instead of activations
+template <bool BWD = false, bool BITS = false>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
-                                          const BwdEpilogue* bwd = nullptr);
+                                          const BwdEpilogue* bwd = nullptr, unsigned long long* bits_out = nullptr);
 
 // Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
 //   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
@@ -247,9 +249,9 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     }
 }
 
-template <bool BWD>
+template <bool BWD, bool BITS>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
-                                          const BwdEpilogue* bwd) {
+                                          const BwdEpilogue* bwd, unsigned long long* bits_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
@@ -426,6 +428,21 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             if (L.epi == EPI_RELU) {
                 store_relu(lo, x0);
                 store_relu(hi, x0 + 32 * LDX);
+                if (BITS && bits_out) {
+                    // this lane holds column `col` for the rows PR_ACC_ROW(i) + 4 half (+ 32): its half of the column's word, the
+                    // other half sits in lane ^ 32
+                    unsigned int mlo = 0u, mhi = 0u;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        mlo |= (lo[i] > 0.f ? 1u : 0u) << PR_ACC_ROW(i);
+                        mhi |= (hi[i] > 0.f ? 1u : 0u) << PR_ACC_ROW(i);
+                    }
+                    mlo <<= 4 * half;
+                    mhi <<= 4 * half;
+                    mlo |= (unsigned int)__shfl_xor((int)mlo, 32, 64);
+                    mhi |= (unsigned int)__shfl_xor((int)mhi, 32, 64);
+                    if (half == 0) bits_out[col] = ((unsigned long long)mhi << 32) | mlo;
+                }
             } else if (L.epi == EPI_ADAIN_RELU) {
                 const int bofs = L.nblk * 32;
                 if (S.uniform_frame) {
@@ -517,22 +534,6 @@ __device__ __forceinline__ void write_rows_indirect(const Smem& S, float* dst, i
             const int d = S.dest[row];
             if (d >= 0) dst[(size_t)d * stride + c] = S.X[row * LDX + c];
         }
-    }
-}
-
-// ReLU mask of the tile staged in X as a bit image: byte (row, c8) = bits of columns 8 c8 .. 8 c8 + 7 ("activation > 0"),
-// rows of width / 8 bytes in compact-row order - 2 KB per tile and layer, which the backward chain loads instead of the
-// 64 KB of activations.
-__device__ __forceinline__ void write_tile_bits(const Smem& S, unsigned char* dst, int width_pad, int tile_base) {
-    const int c8n = width_pad >> 3;
-    for (int idx = threadIdx.x; idx < TILE_M * c8n; idx += MLP_THREADS) {
-        const int row = idx / c8n, c8 = idx - row * c8n;
-        if (!(S.flags[row] & 1)) continue;
-        const float4 a = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8);
-        const float4 b = *reinterpret_cast<const float4*>(S.X + row * LDX + 8 * c8 + 4);
-        const unsigned int byte = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u) |
-                                  (b.x > 0.f ? 16u : 0u) | (b.y > 0.f ? 32u : 0u) | (b.z > 0.f ? 64u : 0u) | (b.w > 0.f ? 128u : 0u);
-        dst[(size_t)(tile_base + row) * c8n + c8] = (unsigned char)byte;
     }
 }
 

@@ -184,8 +184,8 @@ struct MlpParams {
     float* save_bin;             // (cap, bin_pad) bender input [annealed PE | deformation]
     float* save_bact;            // b_count blocks of (cap, BWpad)
     size_t save_bact_stride;
-    unsigned char* save_bits;    // n_backbone blocks of (cap, Wpad / 8) bytes: bit c of row r = (post-ReLU activation > 0), the
-    size_t save_bits_stride;     // ReLU masks the backward chain reads instead of the activations (bytes between the blocks)
+    unsigned char* save_bits;    // n_backbone blocks of relu_bits_bytes(cap, Wpad): per 64-row tile and column one 64-bit word of
+    size_t save_bits_stride;     // (post-ReLU activation > 0) bits - the ReLU masks the backward chain reads (bytes between the blocks)
     unsigned char* save_bbits;   // the same for the bender layers, (cap, BWpad / 8)
     size_t save_bbits_stride;
     float* save_braw;            // (cap, 3) bender head output before * size and the clamp
@@ -211,6 +211,9 @@ struct MlpGroupParams {
     MlpParams jobs[MLP_GROUP_MAX];
     int count;
 };
+
+// bytes of the ReLU bit images of one layer: a 64-bit word per column and 64-row tile (written by the training forward's ReLU epilogues, run_layer<false, true> in mlp_tile.h)
+static inline size_t relu_bits_bytes(size_t rows, int width_pad) { return ((rows + TILE_M - 1) / TILE_M) * (size_t)width_pad * 8; }
 
 // AdaIN table row layout for one (frame, object): g1[Wpad] b1[Wpad] g2[W2pad] b2[W2pad]
 static inline int adain_row_floats(const ModelDims& d) { return 2 * d.Wpad + 2 * d.W2pad; }

@@ -209,7 +209,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
                 sv.row_flags = take(sizeof(int32_t) * cap);
                 sv.enc = take(sizeof(float) * cap * d.enc_pad);
                 sv.act = take(sizeof(float) * cap * d.Wpad * m.backbone_count);
-                sv.bits = take(cap * (d.Wpad / 8) * (size_t)m.backbone_count);
+                sv.bits = take(relu_bits_bytes(cap, d.Wpad) * (size_t)m.backbone_count);
                 sv.h1 = take(sizeof(float) * cap * d.Wpad);
                 sv.h2 = take(sizeof(float) * cap * d.W2pad);
                 sv.batch = take(sizeof(float) * 4 * MAX_WIDTH);
@@ -218,7 +218,7 @@ int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan) {
                     if (cap * d.BWpad > div_t) div_t = cap * d.BWpad;
                     sv.bin = take(sizeof(float) * cap * d.bin_pad);
                     sv.bact = take(sizeof(float) * cap * d.BWpad * m.bender_count);
-                    sv.bbits = take(cap * (d.BWpad / 8) * (size_t)m.bender_count);
+                    sv.bbits = take(relu_bits_bytes(cap, d.BWpad) * (size_t)m.bender_count);
                     sv.braw = take(sizeof(float) * 3 * cap);
                     sv.delta = take(sizeof(float) * 3 * cap);
                 }
@@ -551,13 +551,13 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     mp.save_act = reinterpret_cast<float*>(ws + sv.act);
                     mp.save_act_stride = cap_rows * d.Wpad;
                     mp.save_bits = reinterpret_cast<unsigned char*>(ws + sv.bits);
-                    mp.save_bits_stride = cap_rows * (d.Wpad / 8);
+                    mp.save_bits_stride = relu_bits_bytes(cap_rows, d.Wpad);
                     if (m.has_bender) {
                         mp.save_bin = reinterpret_cast<float*>(ws + sv.bin);
                         mp.save_bact = reinterpret_cast<float*>(ws + sv.bact);
                         mp.save_bact_stride = cap_rows * d.BWpad;
                         mp.save_bbits = reinterpret_cast<unsigned char*>(ws + sv.bbits);
-                        mp.save_bbits_stride = cap_rows * (d.BWpad / 8);
+                        mp.save_bbits_stride = relu_bits_bytes(cap_rows, d.BWpad);
                         mp.save_braw = reinterpret_cast<float*>(ws + sv.braw);
                         mp.save_delta = reinterpret_cast<float*>(ws + sv.delta);
                     }

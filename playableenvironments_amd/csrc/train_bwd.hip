@@ -22,13 +22,12 @@ struct BSmem {
     float X[TILE_M * LDX];                          // the running gradient / the product's operand
     float cst[4][MAX_WIDTH];                        // BatchNorm backward on load: mean, rstd, mean(dxh), mean(dxh xh) per channel
     float ws[MAX_WIDTH];                            // sigma head weights / rows 0..2: bender output head (3 x BWpad <= 3 x 128 ... see use)
-    unsigned char bits[TILE_M * MAX_WIDTH / 8];     // ReLU mask of the current product's output, one bit per element
     float gsr[TILE_M];                              // d loss / d sigma of the tile rows
     int flat[TILE_M], frame[TILE_M], flags[TILE_M];
     int uniform_frame, next_tile, pad_[2];
 };
 static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
-static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0 && offsetof(BSmem, bits) % 16 == 0, "16-byte LDS accesses");
+static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0, "16-byte LDS accesses");
 
 #ifndef PR_CHAINGRP_ABLATE
 #define PR_CHAINGRP_ABLATE 0    // timing builds only (k_chain_bwd_group): 1 = no gradient write-out, 2 = no mask bits, 4 = no MFMA
@@ -123,48 +122,40 @@ __device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int 
     }
 }
 
-// the bit image of one saved ReLU mask of the tile (64 x width / 8 contiguous bytes, written by the forward pass) -> S.bits
-__device__ __forceinline__ void load_tile_bits(unsigned char* dst, const unsigned char* src_layer, int width_pad, int tile_base, int rows_valid) {
-    const int bpr = width_pad >> 3;
-    const int bytes = TILE_M * bpr;
-    const unsigned char* src = src_layer + (size_t)tile_base * bpr;
-    const int live_bytes = rows_valid * bpr;
-    for (int i = threadIdx.x * 8; i < bytes; i += MLP_THREADS * 8) {
-        unsigned long long v = 0ull;
-        if (i + 8 <= live_bytes) {
-            v = *reinterpret_cast<const unsigned long long*>(src + i);
-        } else {
-            for (int b = 0; b < 8 && i + b < live_bytes; ++b) v |= (unsigned long long)src[i + b] << (8 * b);
-        }
-        *reinterpret_cast<unsigned long long*>(dst + i) = v;
-    }
+// The saved ReLU mask of this lane's columns for one product: the forward pass left one 64-bit word per column and tile (bit r =
+// tile row r active), so a lane fetches two words - its columns of the blocks `wave` and `wave + 4` - before the K loop and has
+// them when the epilogue needs them (no LDS image, no load latency behind the product).
+struct ColMasks { unsigned long long a, b; };
+__device__ __forceinline__ ColMasks fetch_col_masks(const unsigned char* bits_layer, int width_pad, int nblk, int tile) {
+    const int wave = threadIdx.x >> 6, r = threadIdx.x & 31;
+    const unsigned long long* words = reinterpret_cast<const unsigned long long*>(bits_layer) + (size_t)tile * width_pad;
+    ColMasks m;
+    m.a = wave < nblk ? words[wave * 32 + r] : 0ull;
+    m.b = wave + MLP_WAVES < nblk ? words[(wave + MLP_WAVES) * 32 + r] : 0ull;
+    return m;
 }
 
 // ReLU backward of a product: X[row][col] = mask bit ? acc : 0  (the callers put barriers around it)
-__device__ __forceinline__ void store_masked(BSmem& S, int nblk, int width_pad, const f32x16& a00, const f32x16& a01, const f32x16& a10,
+__device__ __forceinline__ void store_masked(BSmem& S, int nblk, const ColMasks& masks, const f32x16& a00, const f32x16& a01, const f32x16& a10,
                                              const f32x16& a11) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
-    const int bpr = width_pad >> 3;
+#pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const int cb = wave + blk * MLP_WAVES;
-        if (cb >= nblk) break;
+        if (cb >= nblk) continue;
         const int col = cb * 32 + r;
         const f32x16& lo = blk ? a10 : a00;
         const f32x16& hi = blk ? a11 : a01;
         float* x0 = S.X + (4 * half) * LDX + col;
-        const unsigned char* b0 = S.bits + (4 * half) * bpr + (col >> 3);
-        const int bit = col & 7;
+        unsigned long long mine = (blk ? masks.b : masks.a) >> (4 * half);     // bit ro <-> tile row ro + 4 half
+        if (PR_CHAINGRP_ABLATE & 2) mine = ~0ull;
+        const unsigned int mlo = (unsigned int)mine, mhi = (unsigned int)(mine >> 32);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ro = PR_ACC_ROW(i);
-            if (PR_CHAINGRP_ABLATE & 2) {
-                x0[ro * LDX] = lo[i];
-                x0[(ro + 32) * LDX] = hi[i];
-                continue;
-            }
-            x0[ro * LDX] = ((b0[ro * bpr] >> bit) & 1) ? lo[i] : 0.f;
-            x0[(ro + 32) * LDX] = ((b0[(ro + 32) * bpr] >> bit) & 1) ? hi[i] : 0.f;
+            x0[ro * LDX] = ((mlo >> ro) & 1u) ? lo[i] : 0.f;
+            x0[(ro + 32) * LDX] = ((mhi >> ro) & 1u) ? hi[i] : 0.f;
         }
     }
 }
@@ -534,7 +525,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         int claimed = 0;
         if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
         load_tile_records(S, c.rec_flat, c.row_flags, c.samples_per_frame, tile_base, total);
-        load_tile_bits(S.bits, c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
+        ColMasks masks = fetch_col_masks(c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, nblk, tile);
         __syncthreads();
         if (tid == 0) S.next_tile = claimed;
         f32x16 a00, a01, a10, a11;
@@ -566,29 +557,23 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                     hi[i] = fmaf(S.gsr[PR_ROWS_OF(i, half, 1)], w, hi[i]);
                 }
             }
-            store_masked(S, nblk, c.Wpad, a00, a01, a10, a11);
+            store_masked(S, nblk, masks, a00, a01, a10, a11);
         } else {
-            // ray bender: G = (g_raw . W_out) masked by the last layer's ReLU
-            const int w4 = c.Wpad >> 2;
-            const int bpr = c.Wpad >> 3;
-            for (int idx = tid; idx < TILE_M * w4; idx += MLP_THREADS) {
-                const int row = idx / w4, c4 = (idx - row * w4) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows_valid) {
-                    const float4 g = *reinterpret_cast<const float4*>(c.g_braw4 + (size_t)(tile_base + row) * 4);
-                    const unsigned int mb = S.bits[row * bpr + (c4 >> 3)] >> (c4 & 7);
-                    float out[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = c4 + e;
-                        float acc = 0.f;
-                        if (col < c.W && ((mb >> e) & 1u))
-                            acc = fmaf(g.x, c.w_out[col], fmaf(g.y, c.w_out[c.w_out_ld + col], g.z * c.w_out[2 * c.w_out_ld + col]));
-                        out[e] = acc;
-                    }
-                    v = make_float4(out[0], out[1], out[2], out[3]);
+            // ray bender: G = (g_raw . W_out) masked by the last layer's ReLU; one thread per column, the rows' raw gradients via LDS
+            if (tid < TILE_M) {
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tid < rows_valid) g = *reinterpret_cast<const float4*>(c.g_braw4 + (size_t)(tile_base + tid) * 4);
+                *reinterpret_cast<float4*>(&S.cst[0][tid * 4]) = g;
+            }
+            __syncthreads();
+            for (int col = tid; col < c.Wpad; col += MLP_THREADS) {
+                const bool live = col < c.W;
+                const float w0 = live ? c.w_out[col] : 0.f, w1 = live ? c.w_out[c.w_out_ld + col] : 0.f, w2 = live ? c.w_out[2 * c.w_out_ld + col] : 0.f;
+                const unsigned long long word = reinterpret_cast<const unsigned long long*>(c.bits + (size_t)(c.count - 1) * c.bits_stride)[(size_t)tile * c.Wpad + col];
+                for (int row = 0; row < TILE_M; ++row) {
+                    const float4 g = *reinterpret_cast<const float4*>(&S.cst[0][row * 4]);
+                    S.X[row * LDX + col] = ((word >> row) & 1ull) ? fmaf(g.x, w0, fmaf(g.y, w1, g.z * w2)) : 0.f;
                 }
-                *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
             }
         }
         __syncthreads();
@@ -596,7 +581,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         bool g_in_written = false;
         for (int l = c.count - 1; l >= 1; --l) {
             // ReLU mask of this layer's input (layer l - 1's output); visible after the barrier that follows the product
-            if (!(PR_CHAINGRP_ABLATE & 2)) load_tile_bits(S.bits, c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, tile_base, rows_valid);
+            masks = fetch_col_masks(c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, nblk, tile);
             if (l == c.skip) {
                 zero4(a00, a01, a10, a11);
                 tile_products(c.in0_skip, in_nblk, S.X, a00, a01, a10, a11);
@@ -606,7 +591,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             zero4(a00, a01, a10, a11);
             tile_products(c.act_t[l], nblk, S.X, a00, a01, a10, a11);
             __syncthreads();
-            store_masked(S, nblk, c.Wpad, a00, a01, a10, a11);
+            store_masked(S, nblk, masks, a00, a01, a10, a11);
             __syncthreads();
             if (!(PR_CHAINGRP_ABLATE & 1)) store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
         }
@@ -711,13 +696,13 @@ __device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
         }
         __syncthreads();
         for (int l = 0; l < c.b_count; ++l) {
-            load_tile_bits(S.bits, c.bbits + (size_t)l * c.bbits_stride, c.BWpad, tile_base, rows_valid);
+            const ColMasks masks = fetch_col_masks(c.bbits + (size_t)l * c.bbits_stride, c.BWpad, nblk, tile);
             f32x16 a00, a01, a10, a11;
             zero4(a00, a01, a10, a11);
             tile_products(c.seg0[l], nblk, l == 0 ? S.X + T0 : S.X, a00, a01, a10, a11);
             if (l == c.b_skip) tile_products(c.seg1, nblk, S.X + T0, a00, a01, a10, a11);
             __syncthreads();
-            store_masked(S, nblk, c.BWpad, a00, a01, a10, a11);
+            store_masked(S, nblk, masks, a00, a01, a10, a11);
             __syncthreads();
         }
         // output head and the clamp cases, 8 threads per row
