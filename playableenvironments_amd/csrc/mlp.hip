@@ -511,28 +511,30 @@ __device__ __forceinline__ void gated_head_flush(Smem& S, const MlpParams& p, in
 }
 
 
-// Per-channel sum and sum of squares of the alive rows of the tile staged in X -> global double
-// accumulators (one atomic per channel and tile); the number of alive rows is counted alongside.
-__device__ __forceinline__ void accumulate_stats(const Smem& S, const MlpParams& p) {
-    const int tid = threadIdx.x;
-    for (int c = tid; c < p.h_out_width; c += MLP_THREADS) {
-        double s1 = 0.0, s2 = 0.0;   // double: var = E[x^2] - mean^2 cancels badly in fp32 when |mean| >> std
-        for (int row = 0; row < TILE_M; ++row) {
-            if ((S.flags[row] & 3) == 3) {
-                const double x = (double)S.X[row * LDX + c];
-                s1 += x;
-                s2 = fma(x, x, s2);
-            }
+// The batch-statistics sums of a training launch live in the lanes' registers across the tiles of a workgroup (ColumnStats,
+// filled by run_layer<.., STATS>'s epilogue) and reach the global double accumulators once per workgroup and object: one atomic
+// per column instead of one per column and tile.  The number of rows in the statistics is counted per tile (phase 1 only).
+__device__ __forceinline__ void count_stat_rows(const Smem& S, const MlpParams& p) {
+    if (p.phase == 1 && threadIdx.x < 64) {
+        const int alive = __popcll(__ballot((S.flags[threadIdx.x] & 3) == 3));
+        if (threadIdx.x == 0 && alive) atomicAdd(p.stat_count, alive);
+    }
+}
+
+__device__ __forceinline__ void flush_column_stats(const ColumnStats& cs, const MlpParams& p, int nblk) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane >= 32) return;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int cb = wave + blk * MLP_WAVES;
+        if (cb >= nblk) continue;
+        const int col = cb * 32 + lane;
+        const double s1 = blk ? cs.s1[1] : cs.s1[0], s2 = blk ? cs.s2[1] : cs.s2[0];
+        if (s1 != 0.0 || s2 != 0.0) {
+            atomicAdd(p.stats + col, s1);
+            atomicAdd(p.stats + p.h_out_width + col, s2);
         }
-        atomicAdd(p.stats + c, s1);
-        atomicAdd(p.stats + p.h_out_width + c, s2);
     }
-    if (tid == 0 && p.phase == 1) {
-        int alive = 0;
-        for (int row = 0; row < TILE_M; ++row) alive += (S.flags[row] & 3) == 3;
-        atomicAdd(p.stat_count, alive);
-    }
-    __syncthreads();
 }
 
 // TRAIN = false: the evaluation kernel (everything fused, optional sigma gate) - what the benchmark runs; none of the
@@ -560,6 +562,8 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     __syncthreads();
     int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head), uniform across the workgroup
     EncRegs enc;       // this thread's share of the current network input (see fill_encoding)
+    ColumnStats cstats;   // (training) batch-statistics sums of this lane's columns over the workgroup's tiles
+    cstats.s1[0] = cstats.s1[1] = cstats.s2[0] = cstats.s2[1] = 0.0;
     // Tile order: the first tile of a workgroup is its block index; evaluation launches claim every further tile from a
     // device counter (one atomic per tile, issued at the top of the previous tile and consumed after its first barrier),
     // so that a workgroup that drew cheaper tiles (sigma-gated head) or a faster CU simply takes more of them.  S.next_tile
@@ -716,13 +720,15 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             // their per-channel sums feed the batch statistics
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
-            run_layer(raw, S, p, tile_base, 0, enc);
+            run_layer<false, false, true>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
-            if (!(PR_TRAINFWD_ABLATE & 4)) accumulate_stats(S, p); else __syncthreads();
+            count_stat_rows(S, p);
+            __syncthreads();
         }
     }
     if (!TRAIN && p.gate) gated_head_flush(S, p, pending, enc);
+    if (TRAIN) flush_column_stats(cstats, p, p.layers[p.n_backbone].nblk);
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) { mlp_tile_loop<false, false>(p); }
@@ -757,6 +763,8 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
     if (GROUP) __syncthreads();   // every wave has left the previous object's last tile
     const Layer& prev = p.layers[p.n_backbone + p.phase - 2];   // the layer whose output is h_in
     const Layer& cur = p.layers[p.n_backbone + p.phase - 1];
+    ColumnStats cstats;        // phase 2: batch-statistics sums of this lane's columns over the workgroup's tiles
+    cstats.s1[0] = cstats.s1[1] = cstats.s2[0] = cstats.s2[1] = 0.0;
     for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
         EncRegs enc;   // this thread's share of the current network input (see fill_encoding)
@@ -785,15 +793,16 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
         __syncthreads();
         Layer raw = cur;
         raw.epi = EPI_FEATURES;   // plain store into X
-        run_layer(raw, S, p, tile_base, 0, enc);
+        run_layer<false, false, true>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, p.phase == 2 ? &cstats : nullptr);
         if (p.phase == 2) {
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
-            accumulate_stats(S, p);
+            __syncthreads();
         } else {
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
             __syncthreads();
         }
     }
+    if (p.phase == 2) flush_column_stats(cstats, p, cur.nblk);
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) { mlp_head_loop<false>(p); }

@@ -135,9 +135,13 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
 
 // BITS (training forward): the ReLU epilogue also leaves the layer's ReLU mask behind as one 64-bit word per column
 // (`bits_out[col]`, bit r = tile row r active) - what the backward chain's lane that owns the column reads instead of activations
-template <bool BWD = false, bool BITS = false>
+// STATS (training forward, the raw head layers): the plain-store epilogue also adds the layer's per-column sum and sum of squares
+// over the tile's rows that enter the batch statistics to the lane's running sums (`stats`), straight from the accumulators
+struct ColumnStats { double s1[2], s2[2]; };      // this lane's columns of the blocks `wave` / `wave + 4`
+template <bool BWD = false, bool BITS = false, bool STATS = false>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
-                                          const BwdEpilogue* bwd = nullptr, unsigned long long* bits_out = nullptr);
+                                          const BwdEpilogue* bwd = nullptr, unsigned long long* bits_out = nullptr,
+                                          ColumnStats* stats = nullptr);
 
 // Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
 //   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
@@ -249,9 +253,9 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     }
 }
 
-template <bool BWD, bool BITS>
+template <bool BWD, bool BITS, bool STATS>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
-                                          const BwdEpilogue* bwd, unsigned long long* bits_out) {
+                                          const BwdEpilogue* bwd, unsigned long long* bits_out, ColumnStats* stats) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
@@ -458,6 +462,35 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
                 // last layer: stage the tile in X, the caller writes it out with coalesced 16-byte stores
                 store_plain(lo, x0);
                 store_plain(hi, x0 + 32 * LDX);
+                if (STATS && stats) {
+                    // rows that enter the statistics: bit ro of `mine` <-> tile row ro + 4 half.  double: var = E[x^2] - mean^2
+                    // cancels badly in fp32 when |mean| >> std
+                    const unsigned long long mine = __ballot((S.flags[lane] & 3) == 3) >> (4 * half);
+                    const unsigned int mlo = (unsigned int)mine, mhi = (unsigned int)(mine >> 32);
+                    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if ((mlo >> PR_ACC_ROW(i)) & 1u) {
+                            const double x = (double)lo[i];
+                            s1 += x;
+                            s2 = fma(x, x, s2);
+                        }
+                        if ((mhi >> PR_ACC_ROW(i)) & 1u) {
+                            const double x = (double)hi[i];
+                            s1 += x;
+                            s2 = fma(x, x, s2);
+                        }
+                    }
+                    s1 += __shfl_xor(s1, 32, 64);      // the other half of the column
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (blk == 0) {
+                        stats->s1[0] += s1;
+                        stats->s2[0] += s2;
+                    } else {
+                        stats->s1[1] += s1;
+                        stats->s2[1] += s2;
+                    }
+                }
             }
         }
     }
