@@ -32,6 +32,20 @@ static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0, "
 #ifndef PR_CHAINGRP_ABLATE
 #define PR_CHAINGRP_ABLATE 0    // timing builds only (k_chain_bwd_group): 1 = no gradient write-out, 2 = no mask bits, 4 = no MFMA
 #endif
+#ifdef PR_CHAIN_TIMING
+// phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase of k_chain_bwd_group
+__device__ unsigned long long g_chain_phase[16];
+#define PR_CT0() unsigned long long _ct = __builtin_amdgcn_s_memtime()
+#define PR_CT(idx)                                                                         \
+    do {                                                                                   \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0) atomicAdd(&g_chain_phase[idx], _n - _ct);                    \
+        _ct = _n;                                                                          \
+    } while (0)
+#else
+#define PR_CT0() do {} while (0)
+#define PR_CT(idx) do {} while (0)
+#endif
 #define PR_ROWS_OF(i, half, rb) (PR_ACC_ROW(i) + 4 * (half) + 32 * (rb))
 
 __device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
@@ -523,6 +537,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         const int tile_base = tile * TILE_M;
         const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
         int claimed = 0;
+        PR_CT0();
         if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
         load_tile_records(S, c.rec_flat, c.row_flags, c.samples_per_frame, tile_base, total);
         ColMasks masks = fetch_col_masks(c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, nblk, tile);
@@ -542,9 +557,12 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             }
             load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid);
             __syncthreads();
+            PR_CT(0);
             zero4(a00, a01, a10, a11);
             tile_products(c.w0t, nblk, S.X, a00, a01, a10, a11);
+            PR_CT(1);
             __syncthreads();
+            PR_CT(2);
             for (int blk = 0; blk < 2; ++blk) {
                 const int cb = wave + blk * MLP_WAVES;
                 if (cb >= nblk) break;
@@ -576,29 +594,43 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 }
             }
         }
+        PR_CT(3);
         __syncthreads();
+        PR_CT(4);
         store_tile_rows(S.X, c.gstack + (size_t)(c.count - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+        PR_CT(5);
         bool g_in_written = false;
+        // ReLU mask words of layer l's input (layer l - 1's output), requested a whole layer ahead: behind the weight fragments of a K
+        // loop they would be waited for in issue order (2 KB of a cold tile: HBM latency in front of the first MFMA)
+        ColMasks next = fetch_col_masks(c.bits + (size_t)(c.count - 2) * c.bits_stride, c.Wpad, nblk, tile);
         for (int l = c.count - 1; l >= 1; --l) {
-            // ReLU mask of this layer's input (layer l - 1's output); visible after the barrier that follows the product
-            masks = fetch_col_masks(c.bits + (size_t)(l - 1) * c.bits_stride, c.Wpad, nblk, tile);
+            masks = next;
+            if (l >= 2) next = fetch_col_masks(c.bits + (size_t)(l - 2) * c.bits_stride, c.Wpad, nblk, tile);
             if (l == c.skip) {
                 zero4(a00, a01, a10, a11);
                 tile_products(c.in0_skip, in_nblk, S.X, a00, a01, a10, a11);
                 store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, false, a00, a01, a10, a11);
                 g_in_written = true;
             }
+            PR_CT(6);
             zero4(a00, a01, a10, a11);
             tile_products(c.act_t[l], nblk, S.X, a00, a01, a10, a11);
+            PR_CT(1);
             __syncthreads();
+            PR_CT(2);
             store_masked(S, nblk, masks, a00, a01, a10, a11);
+            PR_CT(3);
             __syncthreads();
+            PR_CT(4);
             if (!(PR_CHAINGRP_ABLATE & 1)) store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
         }
+        PR_CT(5);
         zero4(a00, a01, a10, a11);
         tile_products(c.in0_first, in_nblk, S.X, a00, a01, a10, a11);
         store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, g_in_written, a00, a01, a10, a11);
+        PR_CT(7);
         __syncthreads();   // the next tile overwrites X, the bits and the records
+        PR_CT(8);
     }
 }
 
@@ -609,6 +641,18 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_gr
     if (count > 2) chain_bwd_loop(j2);
     if (count > 3) chain_bwd_loop(j3);
 }
+
+#ifdef PR_CHAIN_TIMING
+extern "C" int pr_debug_chain_phases(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chain_phase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long zero[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_phase), zero, sizeof(zero));
+    }
+    return 0;
+}
+#endif
 
 int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int count, hipStream_t s) {
     static thread_local ChainBwdJob g[MLP_GROUP_MAX];
