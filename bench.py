@@ -129,9 +129,9 @@ def train_step_leg(args, dev, world, rank, dist, lib):
         return out
 
     def step():
-        """eager: one launch per kernel.  A random patch that misses an object leaves its BatchNorm without samples: torch (and the
-        reference) raise; with the deferred check the error concerns the PREVIOUS step (whose update was harmless: no samples,
-        no gradient) and this call simply proceeds - counted, not hidden."""
+        """eager: one launch per kernel.  A random patch that misses an object leaves its BatchNorm with an EMPTY batch, which torch
+        (and therefore the reference) accepts: statistics untouched, no gradient.  Only a batch of exactly one sample raises; the call
+        would be repeated with a new patch and counted (never observed: a ray that meets a box brings all its samples)."""
         opt.zero_grad(set_to_none=True)
         for attempt in range(20):
             try:
@@ -182,10 +182,8 @@ def train_step_leg(args, dev, world, rank, dist, lib):
         "unit": "Mrays/s trained (forward + backward + optimiser step)",
         "ms_per_step": round(step_ms, 3),
         "redrawn_patches": redrawn,
-        "starved_note": "renderer calls repeated inside the timed region: a random patch can miss an object, whose BatchNorm then sees <= 1 sample - "
-                        "torch / the reference raise; with the deferred check the error surfaces at the NEXT call, which is repeated with a new "
-                        "patch (the starved step itself is harmless: the object has no rows, contributes no gradient, its running statistics are "
-                        "left alone)",
+        "starved_note": "renderer calls repeated inside the timed region because an object's train-mode BatchNorm saw exactly one sample "
+                        "(torch / the reference raise for that; a patch that misses an object altogether is an empty batch, which passes)",
         "rays_per_gpu_per_step": rays,
         "workload": "minecraft shipped config, 3 frames/GPU x (48x48 patch @ strides [4, 8] = 2880 rays), perturb, train-mode "
                     "BatchNorm - BASELINE.json configs[4] renderer part",

@@ -958,6 +958,10 @@ def main():
     ok &= check_wire_format()
     ok &= check_ray_object_distances()
     ok &= pose_math_case()
+    # row b2: the reference's own multiresolution subclass, trainer call, evaluator call and a training-shaped iteration on the
+    # swapped base class (oracle/check_dropin.py; `python oracle/check_dropin.py write` records tests/golden/dropin)
+    from oracle import check_dropin
+    ok &= check_dropin.main(write=False)
     print("ALL OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

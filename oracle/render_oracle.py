@@ -309,10 +309,13 @@ def _adain(sd: Dict[str, Tensor], prefix: str, h: Tensor, style: Tensor, trainin
     rm = sd[prefix + "ada_in.normalization.running_mean"]
     rv = sd[prefix + "ada_in.normalization.running_var"]
     if training:
-        if h.size(0) <= 1:
-            raise ValueError("Expected more than 1 value per channel when training")
+        # nn.BatchNorm1d counts the batch first, then torch.nn.functional.batch_norm raises for EXACTLY one value per channel
+        # (_verify_batch_size); an empty batch passes: empty output, running statistics untouched, the counter incremented
         if update_stats:
             sd[prefix + "ada_in.normalization.num_batches_tracked"] += 1
+        if h.size(0) == 1:
+            raise ValueError("Expected more than 1 value per channel when training")
+        if update_stats:
             out = F.batch_norm(h, rm, rv, None, None, True, 0.1, 1e-5)
         else:
             out = F.batch_norm(h, None, None, None, None, True, 0.1, 1e-5)

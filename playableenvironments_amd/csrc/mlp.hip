@@ -830,10 +830,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {
     const double unbiased = var * n / (n - 1.0);   // NaN / inf for n <= 1, where the reference raises
     p.batch_mean[c] = (float)mean;
     p.batch_var[c] = (float)var;
-    if (n > 1.0) {   // torch raises for a single value per channel BEFORE touching the buffers (the host raises after the call)
+    // nn.BatchNorm1d counts every training batch; the running statistics move for batches of two or more rows (an empty batch
+    // leaves them alone, a single row makes torch raise - the host raises after the call)
+    if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+    if (n > 1.0) {
         p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
         p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-        if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
     }
 }
 
@@ -858,10 +860,12 @@ __global__ __launch_bounds__(256) void k_bn_fold_group(BnFoldJobs jobs) {
             const double unbiased = var * n / (n - 1.0);
             mean_f = (float)mean;
             var_f = (float)var;
+            // nn.BatchNorm1d counts every training batch; the running statistics move for batches of two or more rows (an empty
+            // batch leaves them alone, a single row makes torch raise - the host raises after the call)
+            if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
             if (n > 1.0) {
                 p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
                 p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
-                if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
             }
         }
         p.batch_mean[c] = mean_f;

@@ -294,12 +294,12 @@ class ObjectComposer(nn.Module):
         #: being captured; see frame_graph.GraphedStep)
         self.noise_seed_source = "host"
         self.last_noise_seed = None      # int ("host") or a one-element int64 device tensor ("device")
-        #: Train-mode BatchNorm raises when an object call normalises <= 1 sample (torch.nn.functional.batch_norm does,
-        #: the reference does not guard it).  The sample counts live on the device: "eager" (default, the reference's
-        #: behaviour) reads them back before ``forward`` returns - one host synchronisation per training call;
-        #: "deferred" copies them to pinned memory asynchronously and raises the same ValueError at the NEXT call of the
-        #: composer (the affected call itself is harmless: an object without samples contributes nothing and its running
-        #: statistics are left alone), which lets the host run ahead of the device.
+        #: Train-mode BatchNorm raises when an object call normalises exactly ONE sample (torch.nn.functional.batch_norm does,
+        #: the reference does not guard it; an EMPTY batch passes: running statistics untouched, num_batches_tracked + 1).
+        #: The sample counts live on the device: "eager" (default, the reference's behaviour) reads them back before
+        #: ``forward`` returns - one host synchronisation per training call; "deferred" copies them to pinned memory
+        #: asynchronously and raises the same ValueError at the NEXT call of the composer, which lets the host run ahead of
+        #: the device.
         self.batchnorm_check = "eager"
         self._pending_bn_check: Optional[tuple] = None
 
@@ -314,7 +314,7 @@ class ObjectComposer(nn.Module):
         counts = host.tolist()
         for i, ty in enumerate(types):
             cur = counts[i * count:(i + 1) * count]
-            if any(c <= 1 for c in cur):
+            if any(c == 1 for c in cur):      # exactly one: torch.nn.functional.batch_norm raises; an empty batch passes
                 raise ValueError(f"Expected more than 1 value per channel when training, got {cur} evaluated "
                                  f"samples per object ({ty} pass of the previous composer call)")
 
@@ -908,7 +908,7 @@ class ObjectComposer(nn.Module):
             # does not guard against it (model/layers/adain.py:58) - one device read-back per training call
             for ty in types:
                 counts = pieces[0][ty]["_normalised"].cpu().tolist()
-                if any(c <= 1 for c in counts):
+                if any(c == 1 for c in counts):
                     raise ValueError(f"Expected more than 1 value per channel when training, got {counts} evaluated "
                                      f"samples per object ({ty} pass)")
 

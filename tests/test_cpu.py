@@ -610,6 +610,23 @@ def test_wire_format_folds_and_patches():
     assert torch.equal(splitted[1], feats[:, 64:, 64:])
 
 
+def test_wire_format_reproduces_the_reference_subclass_decoder_inputs():
+    """tests/golden/dropin (recorded by oracle/check_dropin.py from the reference's own multiresolution subclass): the
+    ray-major features its composer returned, through this package's glue, are the tensors its decoder received - exactly."""
+    import glob
+    from playableenvironments_amd import wire_format as wf
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dropin", "*.npz")))
+    assert len(paths) >= 2
+    for path in paths:
+        z = np.load(path)
+        meta = ast.literal_eval(bytes(z["meta"]).decode())
+        feats = torch.from_numpy(z["integrated_features"])
+        want = [torch.from_numpy(z[f"decoder_input_{i}"]) for i in range(len(meta["strides"]))]
+        _, patches = wf.decoder_patches(feats, meta["patch_size"], meta["strides"], [w.shape[-3] for w in want])
+        for have, w in zip(patches, want):
+            assert torch.equal(have, w), path
+
+
 def test_wire_format_grid_samplers():
     from playableenvironments_amd import wire_format as wf
     feats = torch.randn(2, 5, 12, 20)

@@ -374,19 +374,34 @@ def test_train_mode_guards():
         comp(*inputs, False)           # differentiable calls are never split: the saved activations must fit
     del comp.max_workspace_bytes
     comp.train()
-    # a camera that sees nothing -> no evaluated sample -> torch's BatchNorm error, as in the reference
+    # a camera that sees nothing -> no evaluated sample: torch's BatchNorm accepts an EMPTY batch (it raises for exactly one
+    # value per channel only - torch.nn.functional._verify_batch_size), so the reference's call goes through with its running
+    # statistics untouched and num_batches_tracked incremented (oracle/check_dropin.py met this with the reference's trainer patch)
     scene = synthetic.tennis_scene(seed=2)
     scene["camera_rotations"][..., 0] = -1.4
     blind = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 4))]
-    with torch.no_grad(), pytest.raises(ValueError):
-        comp(*blind, False)
-    # deferred check: the blind call returns finite results without a host synchronisation, the error surfaces at the
-    # next call of the composer, after which the composer is usable again
-    comp.batchnorm_check = "deferred"
-    with torch.no_grad():
-        out = comp(*blind, False)
+    before = {k: v.clone() for k, v in comp.state_dict().items() if "running_" in k or "num_batches" in k}
+    assert len(before) >= 20
+    for check in ("eager", "deferred"):
+        comp.batchnorm_check = check
+        with torch.no_grad():
+            out = comp(*blind, False)
         assert torch.isfinite(out["coarse"]["global"]["integrated_features"]).all()
-        with pytest.raises(ValueError):
+        assert int(out["coarse"]["_samples"][0]["evaluated"].sum()) == 0
+    after = comp.state_dict()
+    for k, v in before.items():
+        if "num_batches" in k:
+            assert int(after[k]) == int(v) + 2, k
+        else:
+            assert torch.equal(after[k], v), k
+    # exactly one normalised sample (a whole object call of one sample: not reachable with >= 2 positions per ray) is what
+    # raises; the deferred check raises it at the next call of the composer, after which the composer is usable again
+    K = len(cfg["model"]["object_models"])
+    event = torch.cuda.Event()
+    event.record()
+    comp._pending_bn_check = (torch.tensor([7, 1, 5, 0][:K] + [9] * max(0, K - 4)), event, ["coarse"], K)
+    with torch.no_grad():
+        with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
             comp(*inputs, False)
         out = comp(*inputs, False)
         assert torch.isfinite(out["coarse"]["global"]["integrated_features"]).all()
@@ -1408,6 +1423,56 @@ def test_forward_from_observations_matches_reference_fixture(path):
     # the object_in_scene quirk of the reference (static block repeated static_count times): static^2 + dynamic entries
     helper = model.object_id_helper
     assert got["scene_encoding"]["object_in_scene"].shape[-1] == helper.static_objects_count ** 2 + helper.dynamic_objects_count
+
+
+DROPIN_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "dropin", "*.npz")))
+
+
+def test_dropin_fixtures_present():
+    assert len(DROPIN_GOLDEN) >= 2
+
+
+@pytest.mark.parametrize("path", DROPIN_GOLDEN, ids=[os.path.basename(p)[:-4] for p in DROPIN_GOLDEN])
+def test_trainer_patch_decoder_inputs_match_reference_subclass(path):
+    """What the REFERENCE's EnvironmentModelMultiresolutionBackpropagatedDecoder handed to its decoder on the trainer's call
+    (training/trainer_multiresolution_backpropagated_decoder.py:52-53: a strided patch, two strides, 64 + 128 channels) -
+    recorded in the build container by oracle/check_dropin.py from the reference's own subclass, fold / split_features_by_layer
+    glue and autoencoder - against the HIP renderer's ``decoder_features`` for the same dataset tensors, weights, stand-in
+    encoders and patch positions (the fixture's positions replace the random draw)."""
+    z = np.load(path)
+    meta = ast.literal_eval(bytes(z["meta"]).decode())
+    base = configs.tennis_config() if meta["world"] == "tennis" else configs.minecraft_config()
+    cfg = configs.reduced_config(base, features=192, **meta["reduce"])
+    model = em.EnvironmentModel(cfg, *stand_in_encoders(cfg, meta["world"]))
+    model.object_composer.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    model = model.eval().cuda()
+    height, width = meta["image_size"]
+    positions = torch.from_numpy(z["positions"]).cuda()
+    recorded = (torch.round(positions[..., 0] * height) * width + torch.round(positions[..., 1] * width)).to(torch.int64)
+    assert torch.equal(ray_sampling.positions_from_indices(recorded, height, width), positions)
+    model._select_pixels = lambda *a, **k: recorded
+    args = [torch.from_numpy(z["in/" + k]).cuda() for k in OBS_KEYS]
+    patch = meta["patch_size"]
+    counts = [int(z[f"decoder_input_{i}"].shape[-3]) for i in range(len(meta["strides"]))]
+    assert counts == [64, 128]
+    with torch.no_grad():
+        got = model(*args, samples_per_image=patch * patch, perturb=False, shuffle_style=False, patch_size=patch,
+                    patch_stride=meta["strides"], align_grid=True, _decoder_features=counts)
+    assert torch.equal(got["positions"], positions)
+    maps = got["coarse"]["global"]["decoder_features"]
+    assert len(maps) == len(counts)
+    # rendered fields at the renderer's tolerance; the two sides invert their rigid matrices differently (2e-6 apart), so a
+    # ray in a hundred may flip a box decision
+    for i, have in enumerate(maps):
+        want = torch.from_numpy(z[f"decoder_input_{i}"]).cuda()
+        assert tuple(have.shape) == tuple(want.shape), (have.shape, want.shape)
+        bad = ~torch.isclose(want, have, rtol=1e-3, atol=1e-4)
+        pixels = bad.any(-3)
+        assert float(pixels.float().mean()) <= 0.02, (i, float(pixels.float().mean()), float((want - have).abs().max()))
+    want = torch.from_numpy(z["integrated_features"]).cuda()
+    have = got["coarse"]["global"]["integrated_features"]
+    bad = (~torch.isclose(want, have, rtol=1e-3, atol=1e-4)).any(-1)
+    assert float(bad.float().mean()) <= 0.02
 
 
 def _observation_model(world, size, batch=2, observations=2):
