@@ -387,7 +387,7 @@ def test_train_mode_guards():
         with torch.no_grad():
             out = comp(*blind, False)
         assert torch.isfinite(out["coarse"]["global"]["integrated_features"]).all()
-        assert int(out["coarse"]["_samples"][0]["evaluated"].sum()) == 0
+        assert int(comp.last_normalised_samples["coarse"].sum()) == 0
     after = comp.state_dict()
     for k, v in before.items():
         if "num_batches" in k:
@@ -1449,7 +1449,8 @@ def test_trainer_patch_decoder_inputs_match_reference_subclass(path):
     height, width = meta["image_size"]
     positions = torch.from_numpy(z["positions"]).cuda()
     recorded = (torch.round(positions[..., 0] * height) * width + torch.round(positions[..., 1] * width)).to(torch.int64)
-    assert torch.equal(ray_sampling.positions_from_indices(recorded, height, width), positions)
+    # (row / H, col / W: the device's fp32 division may round the last bit differently)
+    assert torch.allclose(ray_sampling.positions_from_indices(recorded, height, width), positions, rtol=0, atol=1e-7)
     model._select_pixels = lambda *a, **k: recorded
     args = [torch.from_numpy(z["in/" + k]).cuda() for k in OBS_KEYS]
     patch = meta["patch_size"]
@@ -1458,7 +1459,7 @@ def test_trainer_patch_decoder_inputs_match_reference_subclass(path):
     with torch.no_grad():
         got = model(*args, samples_per_image=patch * patch, perturb=False, shuffle_style=False, patch_size=patch,
                     patch_stride=meta["strides"], align_grid=True, _decoder_features=counts)
-    assert torch.equal(got["positions"], positions)
+    assert torch.allclose(got["positions"], positions, rtol=0, atol=1e-7)
     maps = got["coarse"]["global"]["decoder_features"]
     assert len(maps) == len(counts)
     # rendered fields at the renderer's tolerance; the two sides invert their rigid matrices differently (2e-6 apart), so a
@@ -2309,6 +2310,7 @@ def test_workspace_budget_follows_free_memory(monkeypatch):
         want = comp(*inputs, False)["coarse"]["global"]["integrated_features"].clone()
     full = comp._workspace.numel()
     comp._workspace = None
+    comp._budget_ok = 0          # (the size a device query has granted before: no second query for it on the hot path)
     torch.cuda.empty_cache()
     total = torch.cuda.mem_get_info()[1]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (256 << 20, total))
