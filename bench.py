@@ -79,6 +79,151 @@ def profile_arrays():
     return (C.c_double * _lib.PR_PROFILE_CATEGORIES)(), (C.c_int32 * _lib.PR_PROFILE_CATEGORIES)()
 
 
+def library_sha256() -> str:
+    """sha256 of the libplayrender.so this process loads: stamped on the bench line and on profiles/*_pmc_summary.json, so that a
+    ``traffic`` figure collected from an older build is detectable."""
+    import hashlib
+    from playableenvironments_amd import _lib
+    with open(_lib.library_path(), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def composer_call_inputs(model, cfg, scene_dev, size):
+    """What EnvironmentModel.forward(mode="scene_encodings") hands to ObjectComposer.forward for every pixel of the frame(s)."""
+    from playableenvironments_amd.environment_model import camera_rays, euler_to_matrix
+    with torch.no_grad():
+        rows = torch.arange(size[0] * size[1], dtype=torch.int32) // size[1]
+        cols = torch.arange(size[0] * size[1], dtype=torch.int32) % size[1]
+        c2w = euler_to_matrix(scene_dev["camera_rotations"], scene_dev["camera_translations"])
+        o, d, n = camera_rays(c2w, scene_dev["focals"] * cfg["data"]["focal_length_multiplier"], size[0], size[1], rows, cols)
+        w2o, _ = model.compute_transformation_matrix_w2o_o2w(scene_dev["object_rotation_parameters"],
+                                                             scene_dev["object_translation_parameters"])
+    return [o, d, n, w2o, scene_dev["object_style"].unsqueeze(-3), scene_dev["object_deformation"].unsqueeze(-3),
+            scene_dev["object_in_scene"].unsqueeze(-2)]
+
+
+def flop_counts(comp, cfg, inputs):
+    """Matmul FLOPs of the MLP launches of one composer call: evaluated samples x FLOP/sample (algorithmic, what the reference
+    computes), minus the feature-head FLOPs of the samples the sigma gate skipped (executed).  One extra call with the sample
+    counters exported."""
+    with torch.no_grad():
+        ex = comp(*inputs, False, _export=True)
+    torch.cuda.synchronize()
+    helper = comp.object_id_helper
+    flops = executed = 0.0
+    evaluated, head_samples = {}, {}
+    for ty in ("coarse", "fine"):
+        if ty not in ex:
+            continue
+        ev = sum(p["evaluated"].cpu() for p in ex[ty]["_samples"])
+        hd = sum(p["head_evaluated"].cpu() for p in ex[ty]["_samples"])
+        evaluated[ty] = [int(v) for v in ev]
+        head_samples[ty] = [int(v) for v in hd]
+        for k in range(helper.objects_count):
+            mcfg = cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)]
+            flops += float(ev[k]) * flops_per_sample(mcfg)
+            executed += float(ev[k]) * flops_per_sample(mcfg) - float(ev[k] - hd[k]) * flops_per_sample(mcfg, head_only=True)
+    return flops, executed, evaluated, head_samples
+
+
+def leg_roofline(comp, cfg, inputs, mlp_ms):
+    """Per-leg roofline of the MLP launches: executed FLOPs of the leg's own frame(s) / HIP-event time of its MLP launches."""
+    flops, executed, evaluated, _ = flop_counts(comp, cfg, inputs)
+    achieved = executed / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "mlp_ms": round(mlp_ms, 3), "flop_executed": executed,
+            "flop_algorithmic": flops, "evaluated_samples": evaluated}
+
+
+def median(values):
+    v = sorted(values)
+    return 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2]) if v else None
+
+
+def event_gaps_ms(events):
+    """Device time between consecutive events of a list recorded at the start of every timed step (+ one at the end)."""
+    return [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+
+
+def shard_balance_leg(model, cfg, scene_dev, size, shards=8, reps=3):
+    """What an N-rank ray-sharded render of ONE frame would hand to each rank, measured at N = 1: the ``shards`` virtual shards of
+    the frame are rendered one after the other on this GPU (composer call on the shard's rays), for contiguous ranges of the
+    pixel list (parallel.shard_range) and for 8 x 8-pixel tiles dealt round robin (parallel.tile_shard_lists).  A sharded frame
+    takes as long as its slowest shard: max / mean of the evaluated samples and of the measured time."""
+    from playableenvironments_amd import parallel
+    comp = model.object_composer
+    inputs = composer_call_inputs(model, cfg, scene_dev, size)
+    total = size[0] * size[1]
+    dev = inputs[1].device
+    schemes = {
+        "contiguous_ranges": [torch.arange(*parallel.shard_range(total, r, shards), device=dev) for r in range(shards)],
+        "tiles_8x8_round_robin": [l.to(dev) for l in parallel.tile_shard_lists([size], shards)],
+    }
+    out = {}
+    for name, lists in schemes.items():
+        samples, times = [], []
+        for idx in lists:
+            sub = list(inputs)
+            sub[1] = inputs[1].index_select(-2, idx)
+            with torch.no_grad():
+                ex = comp(*sub, False, _export=True)           # (warm-up + the sample counts)
+                samples.append(sum(int(p["evaluated"].sum()) for ty in ("coarse", "fine") if ty in ex for p in ex[ty]["_samples"]))
+                gaps = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    comp(*sub, False)
+                    e1.record()
+                    e1.synchronize()
+                    gaps.append(e0.elapsed_time(e1))
+            times.append(median(gaps))
+        mean_s, mean_t = sum(samples) / shards, sum(times) / shards
+        out[name] = {"evaluated_samples_max": max(samples), "evaluated_samples_mean": round(mean_s, 1),
+                     "samples_max_over_mean": round(max(samples) / mean_s, 3) if mean_s else None,
+                     "ms_max": round(max(times), 3), "ms_mean": round(mean_t, 3),
+                     "ms_max_over_mean": round(max(times) / mean_t, 3) if mean_t else None,
+                     "per_shard_samples": samples, "per_shard_ms": [round(t, 3) for t in times]}
+    return out
+
+
+def feature_gather_leg(feats, dist, world, rank, dev, reps=10):
+    """The exchange step of a sharded render on its own: every rank contributes its rendered feature map; once as all_gather
+    (every rank receives the stack) and once as gather(dst=0) (rank 0, the decoder / writer of the evaluation flow, alone)."""
+    if world == 1:
+        return {"world_size": 1, "note": "one rank: no exchange (gather_ray_shards returns the local tensor)"}
+    src = feats.contiguous()
+    nbytes = src.numel() * src.element_size()
+    out = {"world_size": world, "bytes_per_rank": nbytes, "tensor": list(src.shape)}
+    stack = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+    parts = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+
+    def all_gather():
+        dist.all_gather_into_tensor(stack, src)
+
+    def gather_dst0():
+        dist.gather(src, parts, dst=0)
+
+    for name, fn in (("all_gather", all_gather), ("gather_dst0", gather_dst0)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, dist, dev) / reps
+        received = nbytes * (world - 1)
+        out[name] = {"ms": round(dt * 1e3, 3), "bytes_received_per_receiving_rank": received,
+                     "receive_GB_per_s_per_receiving_rank": round(received / dt / 1e9, 2),
+                     "GB_per_s_per_link_if_direct": round(nbytes / dt / 1e9, 2),
+                     "receiving_ranks": world if name == "all_gather" else 1}
+    out["link_note"] = ("xGMI is point to point: with direct transfers each of the (world - 1) links into a receiving rank carries one "
+                        "rank's map (bytes_per_rank) per collective - GB_per_s_per_link_if_direct, against ~153 GB/s per link per direction")
+    return out
+
+
 def max_over_ranks(value, dist, dev):
     if dist is None:
         return value
@@ -106,7 +251,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     # enqueue the backward pass and the next step while the device works
     model.object_composer.batchnorm_check = "deferred"
     size = (288, 512)
-    scene = synthetic.minecraft_scene(batch=3, seed=77, image_size=size)   # same frames on every rank: weak scaling
+    scene = synthetic.minecraft_scene(batch=3, seed=77 + rank, image_size=size)   # every rank trains on its own frames (data parallel)
     sc = to_device(scene, dev)
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
@@ -149,15 +294,18 @@ def train_step_leg(args, dev, world, rank, dist, lib):
             dist.barrier()
         evaluated.zero_()
         retries[0] = 0
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            marks[i].record()
             out = fn()
+        marks[steps].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        return max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev), out
+        return max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev), out, event_gaps_ms(marks)
 
-    dt, out = timed(step)
+    dt, out, gaps = timed(step)
     redrawn = retries[0]
     counts = [int(v) / steps for v in evaluated.cpu()]
     # per-kernel HIP-event times from a second, untimed pass (an event pair around each of the ~100 launches of a step
@@ -181,6 +329,9 @@ def train_step_leg(args, dev, world, rank, dist, lib):
         "value": round(rays * world * steps / dt / 1e6, 4),
         "unit": "Mrays/s trained (forward + backward + optimiser step)",
         "ms_per_step": round(step_ms, 3),
+        "ms_per_step_median": round(median(gaps), 3),
+        "ms_per_step_note": f"ms_per_step = wall time of the {steps} timed steps / {steps} (mean); median = of the device time between the "
+                            "steps' first launches (events on the launch stream, rank 0)",
         "redrawn_patches": redrawn,
         "starved_note": "renderer calls repeated inside the timed region because an object's train-mode BatchNorm saw exactly one sample "
                         "(torch / the reference raise for that; a patch that misses an object altogether is an empty batch, which passes)",
@@ -208,7 +359,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     }
 
 
-def minecraft_leg(dev, lib, frames=20):
+def minecraft_leg(dev, lib, frames=20, balance=False):
     """BASELINE.json configs[2]: the shipped minecraft renderer (background P=16, skybox P=1, two players P=32 that share one
     model, static / dynamic overlap fix), one 256x256 frame, evaluation - both precisions, with the MLP / compositing share."""
     from playableenvironments_amd import configs, synthetic
@@ -246,10 +397,15 @@ def minecraft_leg(dev, lib, frames=20):
         out[precision] = {"ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1.0 / dt, 1),
                           "mrays_per_s": round(size[0] * size[1] / dt / 1e6, 3), "mlp_ms": round(ms[0] / 5, 3),
                           "composite_ms": round(ms[1] / 5, 3)}
+        if precision == "fp32":
+            out["roofline"] = leg_roofline(model.object_composer, cfg, composer_call_inputs(model, cfg, scene, size), ms[0] / 5)
+    model.object_composer.precision = "fp32"
+    if balance:
+        out["shard_balance"] = shard_balance_leg(model, cfg, scene, size)
     return out
 
 
-def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, frames=8):
+def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, frames=8, lib=None):
     """BASELINE.json configs[3]: a batch of 8 DISTINCT seeded frames sharded over the ranks with
     EnvironmentModel.render_sharded (parallel.shard_frames), the rendered feature maps gathered with one collective.
     Unlike the headline's identical frames, distinct frames carry different amounts of work (in-box samples): the batch
@@ -288,7 +444,17 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
         per_rank = [float(p.item()) for p in parts]
     feats = out[ty]["global"]["integrated_features"]
     rays = frames * size[0] * size[1]
+    roofline = None
+    if world == 1 and lib is not None:
+        lib.pr_profile_enable(1)
+        run()
+        torch.cuda.synchronize()
+        lib.pr_profile_enable(0)
+        kernel_ms, _ = profile_arrays()
+        lib.pr_profile_collect(kernel_ms, _)
+        roofline = leg_roofline(model.object_composer, cfg, composer_call_inputs(model, cfg, batch, size), kernel_ms[0])
     return {
+        "roofline": roofline,
         "workload": f"{frames} distinct tennis frames ({label}), {size[0]}x{size[1]}, sharded by frame over {world} rank(s), "
                     "feature maps gathered on every rank",
         "value": round(rays * steps / dt / 1e6, 4),
@@ -304,8 +470,8 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--image", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
@@ -316,7 +482,10 @@ def main():
     ap.add_argument("--no-distinct-frames", action="store_true", help="skip the 8-distinct-frames legs (configs[3])")
     ap.add_argument("--no-reference-graph", action="store_true", help="skip the same-GPU PyTorch op graph measurement")
     ap.add_argument("--no-gate", action="store_true", help="disable the sigma-gated feature head (measurement)")
-    ap.add_argument("--cpu-rays", type=int, default=64, help="the 16-thread CPU baseline renders a cpu_rays x cpu_rays pixel grid")
+    ap.add_argument("--cpu-rays", type=int, default=32, help="the 16-thread CPU baseline renders a cpu_rays x cpu_rays pixel grid "
+                                                             "(2 warm-ups + median of 5)")
+    ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the one full-size (every ray of the frame) CPU run (~200 s)")
+    ap.add_argument("--no-shard-balance", action="store_true", help="skip the virtual-shard balance measurement (N = 1 only)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the main CPU baseline run (all 256 host cores are >50x SLOWER on these small ops)")
     args = ap.parse_args()
@@ -367,14 +536,16 @@ def main():
     comp.precision = args.precision
     comp.gate_feature_head = not args.no_gate
     size = (args.image, args.image)
-    # the same frame on every rank: weak scaling with exactly the same work per GPU (distinct frames per rank are the
-    # "distinct_frames" legs below)
-    scene = synthetic.tennis_scene(seed=1234, image_size=size)
+    # every rank renders ITS OWN frame (seed 1234 + rank; rank 0's is the N = 1 frame): weak scaling over distinct frames, whose
+    # in-box sample counts differ - the step time follows the heaviest.  The identical-frame run (every rank the seed-1234
+    # frame: exactly the same work per GPU) is the labelled secondary "identical_frames".
+    scene = synthetic.tennis_scene(seed=1234 + rank, image_size=size)
     scene_dev = to_device(scene, dev)
+    active = {"scene": scene_dev}
 
     def step():
         with torch.no_grad():
-            out = model(*scene_args(scene_dev, size), 0, False, mode="scene_encodings")
+            out = model(*scene_args(active["scene"], size), 0, False, mode="scene_encodings")
         feats = out["fine"]["global"]["integrated_features"]
         if world > 1:
             # one RCCL collective for the rendered feature maps (50 MB per frame); every rank receives the stack,
@@ -408,9 +579,12 @@ def main():
             dist.barrier()
         lib.pr_profile_enable(1)
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            marks[i].record()
             step()
+        marks[steps].record()
         drain()                      # every gather of the timed steps completes inside the timed region
         torch.cuda.synchronize()
         if world > 1:
@@ -420,9 +594,17 @@ def main():
         kernel_ms, kernel_launches = profile_arrays()
         _lib.check(lib.pr_profile_collect(kernel_ms, kernel_launches), "pr_profile_collect")
         dt = max_over_ranks(dt, dist if world > 1 else None, dev)
+        timed.gaps = event_gaps_ms(marks)
         return dt, kernel_ms, kernel_launches
 
     elapsed, ms, launches = timed(args.steps, args.warmup)
+    step_gaps = timed.gaps
+    identical = None
+    if world > 1:
+        active["scene"] = to_device(synthetic.tennis_scene(seed=1234, image_size=size), dev)
+        same_s, _, _ = timed(max(1, min(args.steps, 5)), 1)
+        active["scene"] = scene_dev
+        identical = same_s / max(1, min(args.steps, 5))
     split = None
     if args.precision == "fp32" and not args.no_split_precision:
         # secondary measurement, never the headline: the same step with the MLP on the split-precision
@@ -432,41 +614,22 @@ def main():
         comp.precision = "fp32"
         split = (split_s, split_ms[0] / max(1, args.steps))
 
-    # FLOPs of the MLP launches of one step: evaluated samples x FLOP/sample (algorithmic), minus the head FLOPs of
-    # the samples the sigma gate skipped (executed)
-    with torch.no_grad():
-        from playableenvironments_amd.environment_model import camera_rays, euler_to_matrix
-        rows = torch.arange(size[0] * size[1], dtype=torch.int32) // size[1]
-        cols = torch.arange(size[0] * size[1], dtype=torch.int32) % size[1]
-        c2w = euler_to_matrix(scene_dev["camera_rotations"], scene_dev["camera_translations"])
-        o, d, n = camera_rays(c2w, scene_dev["focals"] * cfg["data"]["focal_length_multiplier"], size[0], size[1], rows, cols)
-        w2o, _ = model.compute_transformation_matrix_w2o_o2w(scene_dev["object_rotation_parameters"],
-                                                             scene_dev["object_translation_parameters"])
-        ex = comp(o, d, n, w2o, scene_dev["object_style"].unsqueeze(-3), scene_dev["object_deformation"].unsqueeze(-3),
-                  scene_dev["object_in_scene"].unsqueeze(-2), False, _export=True)
-    torch.cuda.synchronize()
-    helper = comp.object_id_helper
-    flops = executed = 0.0
-    evaluated, head_samples = {}, {}
-    for ty in ("coarse", "fine"):
-        ev = sum(p["evaluated"].cpu() for p in ex[ty]["_samples"])
-        hd = sum(p["head_evaluated"].cpu() for p in ex[ty]["_samples"])
-        evaluated[ty] = [int(v) for v in ev]
-        head_samples[ty] = [int(v) for v in hd]
-        for k in range(helper.objects_count):
-            mcfg = cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)]
-            flops += float(ev[k]) * flops_per_sample(mcfg)
-            executed += float(ev[k]) * flops_per_sample(mcfg) - float(ev[k] - hd[k]) * flops_per_sample(mcfg, head_only=True)
+    # FLOPs of the MLP launches of one step (this rank's frame)
+    call_inputs = composer_call_inputs(model, cfg, scene_dev, size)
+    flops, executed, evaluated, head_samples = flop_counts(comp, cfg, call_inputs)
 
     # HBM traffic of the dominant kernel from the committed PMC pass (collected separately: counters
     # cannot ride along with the timed run), and the fp32 MFMA rate this box sustains
     traffic = None
-    traffic_source = None
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    traffic_source = traffic_stamp = None
+    sha = library_sha256()
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_path) and size == (256, 256):
             with open(pmc_path) as f:
-                traffic = json.load(f)["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
+                pmc = json.load(f)
+            traffic = pmc["k_mlp_mfma"]["hbm_bytes_per_launch_avg"]
+            traffic_stamp = pmc.get("library_sha256")
             traffic_source = "profiles/" + name
             break
     probe = {}
@@ -475,6 +638,13 @@ def main():
         _lib.check(lib.pr_probe_mfma_f32(100000, rnd, C.byref(tf), C.byref(pms), None), "pr_probe_mfma_f32")
         probe[name] = round(tf.value, 1)
 
+    distributed = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": backend,
+                   "launched_by": "torch.distributed.run" if world > 1 else "single process"}
+    if world > 1:
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        if backend == "nccl":
+            distributed["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())     # (= RCCL on ROCm)
+            distributed["devices"] = torch.cuda.device_count()
     rays_per_gpu = size[0] * size[1]
     total_rays = rays_per_gpu * world * args.steps
     value = total_rays / elapsed / 1e6
@@ -488,21 +658,24 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step_median": round(median(step_gaps), 3),
+        "ms_per_step_note": f"ms_per_step (and value) = wall time of the {args.steps} timed steps between barrier + synchronize, max over "
+                            f"ranks, / {args.steps}; median = of the device time between the steps' first launches (rank 0)",
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"tennis renderer, {size[0]}x{size[1]} frame per GPU, 4 objects, 64+128 hierarchical samples/ray "
-                        "(coarse+fine networks), eval - BASELINE.json configs[1]",
+            "workload": f"tennis renderer, {size[0]}x{size[1]} frame per GPU (rank r renders the frame of seed 1234 + r), 4 objects, "
+                        "64+128 hierarchical samples/ray (coarse+fine networks), eval - BASELINE.json configs[1]",
             "rays_per_gpu": rays_per_gpu,
             "frames_per_gpu": 1,
             "parallelism": f"frame shard x{world}" + (" + RCCL all_gather of feature maps" if world > 1 else ""),
         },
         "frames_per_s_256x256": round(value * 1e6 / 65536.0, 3),
-        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": backend,
-                        "launched_by": "torch.distributed.run" if world > 1 else "single process"},
+        "library_sha256": sha,
+        "distributed": distributed,
         "roofline": {
             "bound": "mfma",
             "kernel": "k_mlp_mfma_group (fused fp32 MFMA MLP; one launch per model type evaluates its four objects; all launches of one step)",
@@ -512,6 +685,8 @@ def main():
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic,
             "traffic_unit": f"HBM bytes per launch (average over the launches of a step), rocprofv3 PMC passes of tools/collect_pmc.sh, {traffic_source}",
+            "traffic_library_sha256": traffic_stamp,
+            "traffic_from_this_library": bool(traffic_stamp == sha) if traffic is not None else None,
             "peak_measured": probe,
             "flop_per_step": executed,
             "flop_per_step_algorithmic": flops,
@@ -542,11 +717,27 @@ def main():
                     "MFMAs, ~22-bit operands, fp32 accumulation; passes the same oracle/golden parity tolerance; "
                     "reported beside the exact-fp32 headline, not as it",
         }
+    if identical is not None:
+        result["identical_frames"] = {
+            "value": round(rays_per_gpu * world / identical / 1e6, 4), "unit": "Mrays/s", "ms_per_step": round(identical * 1e3, 3),
+            "note": "secondary: every rank renders the SAME frame (seed 1234) - exactly the same work per GPU; the headline's ranks "
+                    "render distinct frames"}
+    final_feats = step()["fine"]["global"]["integrated_features"]
+    drain()
+    result["feature_gather"] = feature_gather_leg(final_feats, dist, world, rank, dev)
+    del final_feats
+    if world == 1 and not args.no_shard_balance:
+        result["shard_balance"] = {
+            "what": "the 8 virtual shards of ONE 256x256 frame rendered one after the other on this GPU (composer calls), contiguous "
+                    "ranges of the pixel list vs 8x8 tiles dealt round robin (render_sharded shard='rays' / 'tiles'); a sharded frame "
+                    "takes as long as its slowest shard",
+            "tennis_hierarchical_64_128": shard_balance_leg(model, cfg, scene_dev, size),
+        }
     if not args.no_distinct_frames:
         steps_d = max(1, min(args.steps, 3))
         result["distinct_frames"] = {
             "hierarchical_64_128": distinct_frames_leg(model, cfg, "hierarchical 64+128, the headline networks", size, dev, world,
-                                                       rank, dist, steps_d),
+                                                       rank, dist, steps_d, lib=lib),
         }
         shipped_cfg = configs.tennis_config()
         torch.manual_seed(0)
@@ -554,12 +745,17 @@ def main():
         synthetic.randomize_module_state(shipped.object_composer, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
         shipped.eval().to(dev)
         result["distinct_frames"]["shipped_p72"] = distinct_frames_leg(shipped, shipped_cfg, "shipped 4+4+32+32 positions - BASELINE.json "
-                                                                       "configs[3]", size, dev, world, rank, dist, max(steps_d, 3))
+                                                                       "configs[3]", size, dev, world, rank, dist, max(steps_d, 3), lib=lib)
+        if "shard_balance" in result:
+            result["shard_balance"]["tennis_shipped"] = shard_balance_leg(
+                shipped, shipped_cfg, to_device(synthetic.tennis_scene(seed=1234, image_size=size), dev), size)
         del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
     if rank == 0 and world == 1 and not args.no_minecraft:
-        result["config2_minecraft_256"] = minecraft_leg(dev, lib)
+        result["config2_minecraft_256"] = minecraft_leg(dev, lib, balance=not args.no_shard_balance)
+        if "shard_balance" in result and "shard_balance" in result["config2_minecraft_256"]:
+            result["shard_balance"]["minecraft_shipped"] = result["config2_minecraft_256"].pop("shard_balance")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
     if rank == 0:
@@ -598,30 +794,52 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     the host cores, the same PyTorch op graph executed by PyTorch-ROCm on this GPU (what north_star's ">= 10x the
     reference PyTorch renderer on one MI355X" compares against), and the PSNR of the HIP result against it."""
     from oracle import render_oracle as ro
-    from playableenvironments_amd import configs, synthetic, ObjectComposer
+    from playableenvironments_amd import configs, synthetic, ObjectComposer, _lib
     from tests.helpers import composer_inputs, grid_pixels
     out = {}
     sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
     n_side = args.cpu_rays
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], n_side))
 
-    # ---- CPU baseline: 16 threads on the n_side^2 subset (the headline figure), 1 thread and all usable cores on smaller ones
+    # ---- CPU baseline: main run = `cpu_threads` threads on the n_side^2 subset, 2 warm-ups + median of 5; 1 thread and all usable
+    # cores once on a smaller subset; one FULL-SIZE run (every ray of the frame) with the main run's threads
     host_cores = os.cpu_count() or 1
     usable = usable_cores()
-    runs = []
-    want = None
-    for threads, side in ((max(1, min(args.cpu_threads, usable)), n_side), (1, max(8, n_side // 4)),
-                          (usable, max(8, n_side // 4))):
+    main_threads = max(1, min(args.cpu_threads, usable))
+
+    def cpu_run(threads, sub):
         torch.set_num_threads(threads)
-        sub = inputs if side == n_side else composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], side))
         with torch.no_grad():
             t0 = time.perf_counter()
             res = ro.batchified_composer_call(cfg, sd, *sub, False, chunk=1000)
-            cpu_s = time.perf_counter() - t0
-        if side == n_side:
-            want = res
-        runs.append({"threads": threads, "rays": side * side, "seconds": round(cpu_s, 2),
-                     "value": round(side * side / cpu_s / 1e6, 7), "unit": "Mrays/s"})
+            return time.perf_counter() - t0, res
+
+    for _ in range(2):
+        cpu_run(main_threads, inputs)
+    timings = []
+    for _ in range(5):
+        cpu_s, want = cpu_run(main_threads, inputs)
+        timings.append(cpu_s)
+    cpu_s = median(timings)
+    runs = [{"threads": main_threads, "rays": n_side * n_side, "seconds": round(cpu_s, 3), "seconds_all": [round(t, 3) for t in timings],
+             "seconds_mean": round(sum(timings) / len(timings), 3), "protocol": "2 warm-ups, median of 5",
+             "value": round(n_side * n_side / cpu_s / 1e6, 7), "unit": "Mrays/s"}]
+    small = max(8, n_side // 2)
+    small_inputs = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], small))
+    for threads in (1, usable):
+        cpu_run(threads, small_inputs)
+        t, _ = cpu_run(threads, small_inputs)
+        runs.append({"threads": threads, "rays": small * small, "seconds": round(t, 3), "protocol": "1 warm-up, 1 run",
+                     "value": round(small * small / t / 1e6, 7), "unit": "Mrays/s"})
+    full_size = None
+    if not args.no_cpu_full_size:
+        every = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], size[0]))
+        assert every[1].size(-2) == size[0] * size[1]
+        t, _ = cpu_run(main_threads, every)
+        full_size = {"rays": size[0] * size[1], "threads": main_threads, "seconds": round(t, 2),
+                     "value": round(size[0] * size[1] / t / 1e6, 7), "unit": "Mrays/s",
+                     "note": "ONE run of the whole frame of the headline workload (every ray, 1000-ray chunks), no extrapolation"}
+        del every
     torch.set_num_threads(max(1, min(args.cpu_threads, host_cores)))
     cpu_model = "unknown"
     try:
@@ -638,9 +856,11 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
         "cores": main_run["threads"],
         "kind": "port",
         "sample": f"{n_side}x{n_side} pixel grid ({n_side * n_side} rays) of the same frame and weights, "
-                  f"oracle/render_oracle.py in 1000-ray chunks, {main_run['seconds']:.1f} s wall, {main_run['threads']} torch threads "
-                  f"of {host_cores} host cores",
+                  f"oracle/render_oracle.py in 1000-ray chunks, 2 warm-ups then the median of 5 runs ({main_run['seconds']:.2f} s), "
+                  f"{main_run['threads']} torch threads of {host_cores} host cores; `full_size` = one run of all "
+                  f"{size[0] * size[1]} rays",
         "runs": runs,
+        "full_size": full_size,
         "extrapolation": "linear in the number of rays (rays are independent; every run renders a uniform pixel grid of the same frame)",
         "cpu_model": cpu_model,
         "host_cores": host_cores,
@@ -671,20 +891,24 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     if not args.no_reference_graph:
         gin = [v.to(dev) for v in inputs]
         gsd = {k: v.to(dev) for k, v in sd.items()}
-        graph = {}
-        for chunk in (1000, 4000):
+        graph, spread = {}, {}
+        for chunk, repeats in ((1000, 5), (4000, 5)):
+            rates = []
             with torch.no_grad():
                 ro.batchified_composer_call(cfg, gsd, *[v[..., :1000, :] if v.dim() == 5 and v.size(-2) > 1000 else v for v in gin],
                                             False, chunk=chunk)   # warm-up
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-            graph[f"chunk_{chunk}"] = round(n_side * n_side / dt / 1e6, 5)
+                for _ in range(repeats):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
+                    torch.cuda.synchronize()
+                    rates.append(n_side * n_side / (time.perf_counter() - t0) / 1e6)
+            graph[f"chunk_{chunk}"] = round(median(rates), 5)
+            spread[f"chunk_{chunk}"] = {"runs": [round(r, 5) for r in rates], "min": round(min(rates), 5), "max": round(max(rates), 5)}
         out["reference_graph_on_gpu"] = {
             "value": graph["chunk_1000"], "unit": "Mrays/s",
             "chunk_4000": graph["chunk_4000"],
+            "protocol": "1 warm-up, median of 5 runs per chunk size", "spread": spread,
             "sample": f"the oracle's restatement of the reference's op graph (materialised per-sample tensors, boolean compaction, "
                       f"sort + gather compose) run by PyTorch-ROCm on this GPU, {n_side * n_side} rays of the same frame, "
                       "1000-ray chunks as render_full_frame_* uses (4000-ray chunks beside it)",
@@ -715,12 +939,22 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
             c1_got = c1(*gin, False)
         torch.cuda.synchronize()
         c1_gpu = (time.perf_counter() - t0) / reps
+        lib = _lib.load()
+        lib.pr_profile_enable(1)
+        for _ in range(5):
+            c1(*gin, False)
+        torch.cuda.synchronize()
+        lib.pr_profile_enable(0)
+        kernel_ms, _counts = profile_arrays()
+        lib.pr_profile_collect(kernel_ms, _counts)
+        c1_roofline = leg_roofline(c1, c1_cfg, gin, kernel_ms[0] / 5)
     diff = float((c1_want["coarse"]["global"]["integrated_features"] - c1_got["coarse"]["global"]["integrated_features"].cpu()).abs().max())
     out["config0_single_player_128"] = {
         "workload": "BASELINE.json configs[0]: 128x128 frame, 1 object (player: NeRF + ray bender), 32 samples/ray, all in the box",
         "hip_mrays_per_s": round(16384 / c1_gpu / 1e6, 4), "hip_ms": round(c1_gpu * 1e3, 3),
         "cpu_oracle_mrays_per_s": round(16384 / c1_cpu / 1e6, 6), "cpu_seconds": round(c1_cpu, 2),
         "cpu_threads": torch.get_num_threads(), "max_abs_diff_features": diff,
+        "roofline": c1_roofline,
     }
     return out
 

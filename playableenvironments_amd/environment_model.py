@@ -556,7 +556,7 @@ class EnvironmentModel(nn.Module):
 
         camera_* (..., O, C, 3); focals (..., O, C); object_* (..., O, 3|S|D, K); object_in_scene (..., O, K).
         ``_ray_range`` (extension): render only the rays [begin, end) of the pixel list - one rank's contiguous share of
-        a frame in ``render_sharded``.  ``_decoder_features`` (extension): the decoder's feature count per stride, e.g.
+        a frame in ``render_sharded`` - or, given an int64 tensor, the listed rays (its share of interleaved tiles).  ``_decoder_features`` (extension): the decoder's feature count per stride, e.g.
         [64, 128] - the compositing kernel then also writes ``[type]["global"]["decoder_features"]``, the channels-first
         per-stride maps ``autoencoder_model.forward_decoder`` takes (see ``decoder_layout``)."""
         rescaled_focals = focals * self.focal_length_multiplier
@@ -593,7 +593,9 @@ class EnvironmentModel(nn.Module):
             idx = ray_sampling.sample_pixels_uniform(flat_boxes.size(0), height, width, samples_per_image, boxes.device)
             rows, cols = ray_sampling.split_indices(idx.reshape(lead + [-1]), width)
 
-        if _ray_range is not None:
+        if _ray_range is not None and torch.is_tensor(_ray_range):
+            rows, cols = rows.index_select(-1, _ray_range), cols.index_select(-1, _ray_range)
+        elif _ray_range is not None:
             rows, cols = rows[..., _ray_range[0]:_ray_range[1]], cols[..., _ray_range[0]:_ray_range[1]]
         origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
 
@@ -969,7 +971,10 @@ class EnvironmentModel(nn.Module):
 
         shard = "frames": the leading (batch) dimension is split over the ranks (``parallel.shard_range``; batches
         that do not divide evenly give ragged shards); "rays": every rank renders a contiguous range of the pixel list
-        of all frames (a single frame across the node); "auto": frames when the batch has at least one frame per rank.
+        of all frames (a single frame across the node); "tiles": every rank renders the 8 x 8 pixel tiles t = rank (mod world)
+        of the frame (``parallel.tile_shard_lists``: contiguous ranges give one rank the sky and another the players, tiles
+        give every rank a sample of the whole frame - balanced evaluated samples); "auto": frames when the batch has at
+        least one frame per rank, tiles otherwise.
         Rays are independent and eval-mode BatchNorm uses the running statistics, so the assembled result is bit-identical
         to the single-GPU render.  Returns ``{type: {entry: {field: tensor}}}`` with the reference's shapes on ``dst``
         (None on the other ranks), on every rank when ``dst`` is None.  Without an initialised process group (or with one
@@ -983,9 +988,9 @@ class EnvironmentModel(nn.Module):
                              "the single-GPU result")
         batch = camera_rotations.size(0)
         if shard == "auto":
-            shard = "frames" if batch >= world else "rays"
-        if shard not in ("frames", "rays"):
-            raise ValueError(f"unknown shard mode {shard!r} (expected 'auto', 'frames' or 'rays')")
+            shard = "frames" if batch >= world else "tiles"
+        if shard not in ("frames", "rays", "tiles"):
+            raise ValueError(f"unknown shard mode {shard!r} (expected 'auto', 'frames', 'rays' or 'tiles')")
         args = [camera_rotations, camera_translations, focals, image_size, object_rotation_parameters_o2w,
                 object_translation_parameters_o2w, object_style, object_deformation, object_in_scene]
         kwargs = dict(upsample_factor=upsample_factor, patch_stride=patch_stride, canonical_pose=canonical_pose,
@@ -1001,11 +1006,19 @@ class EnvironmentModel(nn.Module):
             height, width = int(image_size[0] * upsample_factor), int(image_size[1] * upsample_factor)
             if patch_stride:
                 strides = patch_stride if isinstance(patch_stride, collections.abc.Sequence) else [patch_stride]
-                total = sum((height // s) * (width // s) for s in strides)
+                grids = [(height // s, width // s) for s in strides]
             else:
-                total = height * width
+                grids = [(height, width)]
+            total = sum(h * w for h, w in grids)
             dim = camera_rotations.dim() - 1
-            ray_range = parallel.shard_range(total, rank, world)
+            if shard == "tiles":
+                key = ("tiles", tuple(grids), world, str(camera_rotations.device))
+                if key not in self._pixel_cache:
+                    self._pixel_cache[key] = [l.to(camera_rotations.device) for l in parallel.tile_shard_lists(grids, world)]
+                lists = self._pixel_cache[key]
+                ray_range = lists[rank]
+            else:
+                ray_range = parallel.shard_range(total, rank, world)
         with torch.no_grad():
             local = self(*local_args, 0, perturb, 0, _ray_range=ray_range, **kwargs)
         out: Dict = {}
@@ -1015,7 +1028,10 @@ class EnvironmentModel(nn.Module):
                 continue
             for entry in entries:
                 for field in fields:
-                    full = parallel.gather_ray_shards(local[ty][entry][field], total, dim, dst=dst, group=group)
+                    if shard == "tiles":
+                        full = parallel.gather_indexed_shards(local[ty][entry][field], lists, dim, dst=dst, group=group)
+                    else:
+                        full = parallel.gather_ray_shards(local[ty][entry][field], total, dim, dst=dst, group=group)
                     if receives:
                         out.setdefault(ty, {}).setdefault(entry, {})[field] = full
         return out if receives else None

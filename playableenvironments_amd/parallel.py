@@ -67,6 +67,74 @@ def gather_ray_shards(local: torch.Tensor, total: int, dim: int, dst: Optional[i
     return torch.cat([p.narrow(dim, 0, e - b) for p, (b, e) in zip(parts, sizes)], dim=dim)
 
 
+def tile_shard_lists(grids, world: int, tile: int = 8) -> List[torch.Tensor]:
+    """Round-robin sharding of a frame's rays in ``tile`` x ``tile`` pixel tiles: for the pixel list of a render (``grids`` =
+    [(rows, cols)] - one entry for a full frame, one per stride for the strided grids, concatenated in that order) the int64
+    indices INTO that list each rank renders.  Tile t (row-major over the grid) belongs to rank t % world; within a rank the
+    rays stay tile-major, so that the samples of neighbouring rays (same boxes, similar depths) stay neighbours in the sample
+    lists.  Where contiguous ranges (``shard_range``) hand whole bands of the image to a rank - the sky to one, the players
+    to another - interleaved tiles give every rank a sample of the whole frame: the evaluated-sample counts, which are what
+    the MLP time follows, differ by a few percent instead of a multiple (bench.py ``shard_balance``)."""
+    if world < 1 or tile < 1:
+        raise ValueError(f"bad world/tile {world}/{tile}")
+    lists: List[List[torch.Tensor]] = [[] for _ in range(world)]
+    offset, first_tile = 0, 0
+    for rows, cols in grids:
+        r = torch.arange(rows, dtype=torch.int64)
+        c = torch.arange(cols, dtype=torch.int64)
+        tiles_per_row = (cols + tile - 1) // tile
+        tile_of = (r // tile).unsqueeze(1) * tiles_per_row + (c // tile).unsqueeze(0)          # (rows, cols)
+        flat = (r.unsqueeze(1) * cols + c.unsqueeze(0)).reshape(-1)
+        tile_flat = tile_of.reshape(-1)
+        order = torch.argsort(tile_flat, stable=True)                                        # tile-major, row-major inside
+        owner = (tile_flat[order] + first_tile) % world
+        for k in range(world):
+            lists[k].append(flat[order][owner == k] + offset)
+        offset += rows * cols
+        first_tile += int(tile_of.max()) + 1 if rows * cols else 0
+    return [torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64) for parts in lists]
+
+
+def gather_indexed_shards(local: torch.Tensor, lists: List[torch.Tensor], dim: int, dst: Optional[int] = 0,
+                          group=None) -> Optional[torch.Tensor]:
+    """Reassembles a tensor whose ``dim`` was sharded with index lists (``tile_shard_lists``): rank r holds
+    ``full.index_select(dim, lists[r])``.  ONE collective (padded to the longest shard, like ``gather_ray_shards``) and one
+    scatter of the received rows to their places."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        world, rank = 1, 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if len(lists) != world:
+        raise ValueError(f"{len(lists)} index lists for {world} ranks")
+    if local.size(dim) != lists[rank].numel():
+        raise ValueError("local shard does not match its index list")
+    total = sum(int(l.numel()) for l in lists)
+    if world == 1:
+        parts = [local]
+    else:
+        longest = max(int(l.numel()) for l in lists)
+        buf = local.contiguous()
+        pad = longest - local.size(dim)
+        if pad:
+            shape = list(local.shape)
+            shape[dim] = pad
+            buf = torch.cat([buf, buf.new_zeros(shape)], dim=dim).contiguous()
+        if dst is None:
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(parts, buf, group=group)
+        else:
+            parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+            dist.gather(buf, parts, dst=dst, group=group)
+            if rank != dst:
+                return None
+        parts = [p.narrow(dim, 0, int(l.numel())) for p, l in zip(parts, lists)]
+    shape = list(local.shape)
+    shape[dim] = total
+    full = local.new_empty(shape)
+    full.index_copy_(dim, torch.cat(lists).to(local.device), torch.cat(parts, dim=dim))
+    return full
+
+
 def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None, average: bool = True,
                         bucket_bytes: int = 64 << 20) -> int:
     """Sums (``average``: averages) ``.grad`` of ``parameters`` over the ranks, in place; parameters without a

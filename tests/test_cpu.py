@@ -306,6 +306,14 @@ def _gloo_worker(rank, world, port, total, results):
         ok = torch.equal(everyone, full) and ((rank == 0 and torch.equal(out, full)) or (rank != 0 and out is None))
         frames = parallel.shard_frames(torch.arange(5), rank, world)
         ok = ok and frames.tolist() == ([0, 1, 2] if rank == 0 else [3, 4])
+        # interleaved 8 x 8 tiles of a 20 x 27 frame + its stride-4 grid (ragged edge tiles, unequal shard sizes)
+        lists = parallel.tile_shard_lists([(20, 27), (5, 6)], world)
+        count = 20 * 27 + 5 * 6
+        image = torch.arange(count * 2, dtype=torch.float32).reshape(1, count, 2)
+        mine = image.index_select(1, lists[rank])
+        everyone = parallel.gather_indexed_shards(mine, lists, dim=1, dst=None)
+        first = parallel.gather_indexed_shards(mine, lists, dim=1, dst=0)
+        ok = ok and torch.equal(everyone, image) and ((rank == 0 and torch.equal(first, image)) or (rank != 0 and first is None))
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -370,7 +378,8 @@ def _sharded_render_worker(rank, world, port, results):
         model.object_composer = _FakeComposer(model.object_composer)
         model.eval()
         ok = True
-        for batch, shard, stride in ((3, "auto", 0), (1, "auto", [4, 8]), (3, "rays", 0), (2, "frames", [4, 8])):
+        for batch, shard, stride in ((3, "auto", 0), (1, "auto", [4, 8]), (3, "rays", 0), (2, "frames", [4, 8]), (1, "rays", [4, 8]),
+                                     (2, "tiles", 0), (1, "tiles", [4, 8])):
             scene = synthetic.tennis_scene(batch=batch, observations=2, seed=21, image_size=(16, 24))
             args = [scene[k] for k in ("camera_rotations", "camera_translations", "focals")] + [scene["image_size"]] + \
                    [scene[k] for k in ("object_rotation_parameters", "object_translation_parameters", "object_style",
@@ -476,6 +485,29 @@ def test_gradient_allreduce_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert results[0] and results[1]
+
+
+def test_tile_shard_lists_partition_the_pixel_list():
+    """8 x 8 tiles dealt round robin: every ray belongs to exactly one rank, a tile is never split, consecutive tiles go to
+    consecutive ranks (also across the grids of a strided render), and one rank is the identity."""
+    from playableenvironments_amd import parallel
+    for grids, world in (([(16, 24)], 2), ([(20, 27), (5, 6)], 3), ([(64, 64)], 8), ([(7, 5)], 4)):
+        lists = parallel.tile_shard_lists(grids, world)
+        total = sum(h * w for h, w in grids)
+        assert sorted(torch.cat(lists).tolist()) == list(range(total))
+        offset, first = 0, 0
+        for h, w in grids:
+            per_row = (w + 7) // 8
+            for k, l in enumerate(lists):
+                inside = l[(l >= offset) & (l < offset + h * w)] - offset
+                tiles = (inside // w // 8) * per_row + (inside % w) // 8
+                assert bool(((tiles + first) % world == k).all())
+                assert tiles.tolist() == sorted(tiles.tolist())            # tile-major order inside a rank
+            offset += h * w
+            first += ((h + 7) // 8) * per_row
+    assert torch.equal(parallel.tile_shard_lists([(9, 9)], 1)[0].sort()[0], torch.arange(81))
+    sizes = [l.numel() for l in parallel.tile_shard_lists([(256, 256)], 8)]
+    assert sizes == [8192] * 8
 
 
 def test_shard_range_partitions():

@@ -1899,6 +1899,12 @@ def test_bench_self_launches_two_ranks():
     assert result["value"] > 0 and result["steps"] == 2
     assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == 2
     assert result["train_step"]["parallelism"].startswith("data parallel x2")
+    # the exchange on its own, both collectives, and the identical-frame secondary beside the per-rank frames of the headline
+    gather = result["feature_gather"]
+    assert gather["world_size"] == 2 and gather["bytes_per_rank"] == 64 * 64 * 192 * 4
+    assert gather["all_gather"]["ms"] > 0 and gather["gather_dst0"]["receiving_ranks"] == 1
+    assert result["identical_frames"]["value"] > 0 and "seed 1234 + r" in result["config"]["workload"]
+    assert len(result["library_sha256"]) == 64
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
