@@ -229,8 +229,84 @@ def make_observation_mode(name, world, recipe, scene, alpha_bias, mode_kwargs):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {sum(k.startswith('out/') for k in data)} output tensors")
 
 
+def make_consistency(name, world, recipe, scene, alpha_bias):
+    """Fixture of EnvironmentModel.forward_pose_consistency / forward_keypoint_consistency (model/environment_model.py:1197-1505):
+    the REFERENCE's methods on synthetic dataset tensors, optical flow and keypoints.  Both draw random pixels inside
+    RayHelper.sample_rays_at_object / sample_rays_at_keypoints: what those calls returned is recorded too (``draw/...``), so that
+    the test can replay the same pixels through the product (whose own random stream is the device's) and compare the expected
+    positions, opacities and confidences value for value."""
+    from oracle.check_against_reference import OBS_KEYS, build_reference_environment_model
+    from tests.helpers import observation_batch, stand_in_encoders
+    from utils.lib_3d.ray_helper import RayHelper
+    cfg = recipe_config(recipe)
+    torch.manual_seed(0)
+    composer = refshim.build_reference_composer(copy.deepcopy(cfg))
+    synthetic.randomize_module_state(composer, seed=0, step=20000, alpha_bias=alpha_bias, bender_scale=1e4)
+    ref = build_reference_environment_model(cfg, composer.eval(), *stand_in_encoders(cfg, world)).eval()
+    batch = observation_batch(scene)
+    size = scene["image_size"]
+    lead = list(batch["observations"].shape[:3])
+    g = torch.Generator().manual_seed(1)
+    flow = (torch.rand(lead + [2, size[0], size[1]], generator=g) - 0.5) * 0.05
+    keypoints = torch.rand(lead + [17, 3, 2], generator=g)
+    with torch.no_grad():
+        se = ref(*[batch[k].clone() for k in OBS_KEYS], mode="observations_scene_encoding_only")
+    common = [batch[k] for k in OBS_KEYS[1:]] + [se["object_style"], se["object_deformation"],
+                                                 se["object_rotation_parameters"], se["object_translation_parameters"]]
+    data = {"in/" + k: batch[k].numpy() for k in OBS_KEYS}
+    data.update({"in/optical_flow": flow.numpy(), "in/keypoints": keypoints.numpy()})
+    for k in ("object_style", "object_deformation", "object_rotation_parameters", "object_translation_parameters"):
+        data["se/" + k] = se[k].numpy()
+    for k, v in composer.state_dict().items():
+        data["sd/" + k] = v.numpy()
+    draws = {"object": [], "keypoints": []}
+    originals = (RayHelper.sample_rays_at_object, RayHelper.sample_rays_at_keypoints)
+
+    def spy(kind, fn):
+        def wrapped(*a, **kw):
+            out = fn(*a, **kw)
+            draws[kind].append([t.detach().clone() for t in out])
+            return out
+        return staticmethod(wrapped)
+    RayHelper.sample_rays_at_object = spy("object", originals[0])
+    RayHelper.sample_rays_at_keypoints = spy("keypoints", originals[1])
+    try:
+        torch.manual_seed(13)
+        with torch.no_grad():
+            pose = ref(flow.clone(), *[x.clone() for x in common], 30, False, mode="pose_consistency")
+            kp = ref(batch["observations"].clone(), *[x.clone() for x in common], keypoints.clone(),
+                     batch["bounding_boxes_validity"].clone(), 20, False, mode="keypoint_consistency")
+    finally:
+        RayHelper.sample_rays_at_object, RayHelper.sample_rays_at_keypoints = (staticmethod(f) for f in originals)
+    for kind, calls in draws.items():
+        for i, triple in enumerate(calls):
+            for j, t in enumerate(triple):
+                data[f"draw/{kind}/{i}/{j}"] = t.numpy()
+    for name_, (previous, following) in pose["coarse"].items():
+        for tag, (positions, opacity) in (("previous", previous), ("following", following)):
+            data[f"pose/{name_}/{tag}/positions"] = positions.numpy()
+            data[f"pose/{name_}/{tag}/opacity"] = opacity.numpy()
+    for name_, (positions, confidence, opacity, sampled) in kp["coarse"].items():
+        for tag, t in (("positions", positions), ("confidence", confidence), ("opacity", opacity), ("sampled", sampled)):
+            data[f"keypoint/{name_}/{tag}"] = t.numpy()
+    data["recipe"] = np.frombuffer(repr(recipe).encode(), dtype=np.uint8)
+    data["meta"] = np.frombuffer(repr({"world": world, "image_size": list(size), "pose_samples": 30, "keypoint_samples": 20}).encode(),
+                                 dtype=np.uint8)
+    os.makedirs(os.path.join(OUT, "consistency"), exist_ok=True)
+    path = os.path.join(OUT, "consistency", name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(draws['object'])} + {len(draws['keypoints'])} recorded draws, "
+          f"{sum(k.startswith(('pose/', 'keypoint/')) for k in data)} output tensors")
+
+
 def main():
     refshim.install()
+    if len(sys.argv) > 1 and sys.argv[1] == "consistency":
+        make_consistency("tennis", "tennis", {"base": "tennis", "reduce": REDUCE},
+                         synthetic.tennis_scene(batch=2, observations=3, seed=7, image_size=(48, 64)), 2.0)
+        make_consistency("minecraft", "minecraft", {"base": "minecraft", "reduce": REDUCE},
+                         synthetic.minecraft_scene(batch=1, observations=3, seed=8, image_size=(48, 64)), 3.0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "observations":
         make_observation_mode("tennis_strided_grid", "tennis", {"base": "tennis", "reduce": REDUCE},
                               synthetic.tennis_scene(batch=2, observations=2, seed=3, image_size=(48, 64)), 2.0,

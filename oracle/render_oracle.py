@@ -20,6 +20,10 @@ identical inputs/weights in the build container (max |diff| reported in DESIGN.m
 ``oracle/make_golden.py`` writes reference-generated fixtures to ``tests/golden``; the CPU test
 suite re-checks this module against those fixtures wherever it runs.
 
+Arbitration mode: every tensor this module creates takes torch's DEFAULT dtype, so the same op graph runs in float64 when the
+caller sets ``torch.set_default_dtype(torch.float64)`` and passes double weights / inputs (``tests/helpers.oracle_in_float64``):
+where a test's tolerance is wider than fp32 round-off, |HIP - fp64| is judged against |this module in fp32 - fp64|.
+
 Weights are addressed by the reference's own ``state_dict`` key names
 (``object_models_coarse.<m>.nerf_model.backbone_layers.<i>.weight`` ...), so a reference
 checkpoint (or the product module's ``state_dict()``) can be passed in unchanged.
@@ -59,7 +63,7 @@ class ObjectLayout:
 
 
 def _bbox_tensor(model_cfg: dict, device=None) -> Tensor:
-    return torch.as_tensor(model_cfg["bounding_box"], dtype=torch.float32, device=device)  # (3, 2)
+    return torch.as_tensor(model_cfg["bounding_box"], dtype=torch.get_default_dtype(), device=device)  # (3, 2)
 
 
 # --------------------------------------------------------------------------------------------
@@ -74,7 +78,7 @@ def euler_to_matrix(rotations: Tensor, translations: Tensor) -> Tensor:
     cy, sy = torch.cos(rotations[..., 1]), torch.sin(rotations[..., 1])
     cz, sz = torch.cos(rotations[..., 2]), torch.sin(rotations[..., 2])
     lead = list(rotations.shape[:-1])
-    zeros = lambda: torch.zeros(lead + [3, 3], dtype=torch.float32, device=rotations.device)
+    zeros = lambda: torch.zeros(lead + [3, 3], dtype=torch.get_default_dtype(), device=rotations.device)
     rx, ry, rz = zeros(), zeros(), zeros()
     rx[..., 0, 0] += 1.0
     rx[..., 1, 1] += cx
@@ -92,7 +96,7 @@ def euler_to_matrix(rotations: Tensor, translations: Tensor) -> Tensor:
     rz[..., 1, 0] += sz
     rz[..., 1, 1] += cz
     rot = torch.matmul(ry, torch.matmul(rx, rz))
-    out = torch.zeros(lead + [4, 4], dtype=torch.float32, device=rotations.device)
+    out = torch.zeros(lead + [4, 4], dtype=torch.get_default_dtype(), device=rotations.device)
     out[..., :3, :3] = rot
     out[..., :3, 3] = translations
     out[..., 3, 3] = 1.0
@@ -264,7 +268,7 @@ def annealing_weights(step: Tensor, octaves: int, num_steps: int) -> Tensor:
 
     model/annealable_positional_encoder.py:59-63 (``step`` is the int32 ``current_step`` buffer)."""
     alpha = step * octaves / num_steps
-    k = torch.arange(octaves, dtype=torch.float32, device=step.device)
+    k = torch.arange(octaves, dtype=torch.get_default_dtype(), device=step.device)
     return (1 - torch.cos(math.pi * torch.clamp(alpha - k, min=0.0, max=1.0))) / 2
 
 
@@ -352,8 +356,8 @@ def adain_nerf_forward(sd, prefix, cfg, bbox, empty_alpha, x, style, training, u
 
     model/nerf_models/adain_style_nerf_model.py:106-199."""
     m = x.size(0)
-    feats = torch.zeros((m, cfg["output_features"]), dtype=torch.float32, device=x.device)
-    sigma = torch.ones((m, 1), dtype=torch.float32, device=x.device) * empty_alpha
+    feats = torch.zeros((m, cfg["output_features"]), dtype=torch.get_default_dtype(), device=x.device)
+    sigma = torch.ones((m, 1), dtype=torch.get_default_dtype(), device=x.device) * empty_alpha
     mask = _in_box(x, bbox)
     xs, ss = x[mask, :], style[mask, :]
     size = bbox[:, 1] - bbox[:, 0]
@@ -407,9 +411,9 @@ def object_model_forward(sd: Dict[str, Tensor], prefix: str, model_cfg: dict, po
     f_def = flat(deformation.unsqueeze(-2).expand(lead + [deformation.size(-1)]))
     total = f_pos.size(0)
     dev = positions.device
-    out_f = torch.zeros((total, nerf_cfg["output_features"]), dtype=torch.float32, device=dev)
-    out_s = torch.ones((total,), dtype=torch.float32, device=dev) * empty_alpha
-    out_d = torch.zeros((total, 3), dtype=torch.float32, device=dev)
+    out_f = torch.zeros((total, nerf_cfg["output_features"]), dtype=torch.get_default_dtype(), device=dev)
+    out_s = torch.ones((total,), dtype=torch.get_default_dtype(), device=dev) * empty_alpha
+    out_d = torch.zeros((total, 3), dtype=torch.get_default_dtype(), device=dev)
 
     mask = _in_box(f_pos, bbox)
     xs, os_, ds, ss, es = f_pos[mask, :], f_org[mask, :], f_dir[mask, :], f_sty[mask, :], f_def[mask, :]
@@ -441,7 +445,7 @@ def object_model_forward(sd: Dict[str, Tensor], prefix: str, model_cfg: dict, po
 def position_distances(t: Tensor, directions: Tensor) -> Tensor:
     """dt_i = (t_{i+1} - t_i) |d|, last = 1e10 |d|.  model/object_composer.py:153-178."""
     first = t[..., 1:] - t[..., :-1]
-    last = torch.ones(list(first.shape[:-1]) + [1], dtype=torch.float32, device=t.device) * 1e10
+    last = torch.ones(list(first.shape[:-1]) + [1], dtype=torch.get_default_dtype(), device=t.device) * 1e10
     dist = torch.cat([first, last], dim=-1)
     return dist * torch.linalg.norm(directions[..., None, :], dim=-1)
 

@@ -3,6 +3,8 @@ shapes, sample counts, ray counts, frames, flags and absent objects.      python
 ("backward": the gradients of pr_render_backward against torch.autograd through the oracle instead - training mode, every
 differentiable output probed, camera-ray and divergence gradients included.)
 
+A fixed-seed slice (40 forward + 20 backward cases, seed 0) runs in the driver's suite: tests/test_gpu.py::test_randomized_sweep_slice.
+
 Forward fields are compared at the parity tolerance of the suite; perturbed cases replay the oracle's noise.  Cases whose
 oracle render is ill conditioned by construction (hierarchical resampling) are compared more loosely."""
 import os
@@ -144,23 +146,28 @@ def backward_sweep(cases, rng, only=None):
                     print(f"MISMATCH (worst {worst:.1e}, oracle self-sensitivity {own:.1e})", label, dict(list(bad.items())[:4]))
             else:
                 print("ok", label[:170])
-        except ValueError as e:       # train-mode BatchNorm on <= 1 sample: the reference raises too
+        except ValueError as e:       # train-mode BatchNorm on exactly one sample: the reference raises too
             print("skipped", label[:120], str(e)[:60])
         except Exception:
             failures += 1
             print("ERROR", label)
             traceback.print_exc()
     print(f"{cases} backward cases, {failures} failures")
+    return failures
 
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)
-    if len(sys.argv) > 3 and sys.argv[3] == "backward":
-        return backward_sweep(cases, rng, int(sys.argv[4]) if len(sys.argv) > 4 else None)
-    failures = 0
     only = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    if len(sys.argv) > 3 and sys.argv[3] == "backward":
+        return backward_sweep(cases, rng, only)
+    return forward_sweep(cases, rng, only)
+
+
+def forward_sweep(cases, rng, only=None):
+    failures = 0
     for i in range(cases):
         world, cfg, inputs, flags, hierarchical, shape, positions, frames, n = random_case(rng)
         label = f"case {i}: {world} {shape} positions={positions} frames={frames} rays={n * n} {flags} hierarchical={hierarchical}"
@@ -197,6 +204,16 @@ def main():
             bad = {k: f"{v[0]:.2e}" for k, v in rep.items() if not v[1]}
             if hierarchical:        # the weights of tied / nearly tied merged samples may swap: judged by the integrals
                 bad = {k: v for k, v in bad.items() if not k.endswith("weights")}
+            for key in [k for k in bad if k.endswith("disparity")]:
+                # disparity = 1 / max(eps, depth / opacity) is NaN exactly where the opacity is 0: a ray whose opacity underflows
+                # on one side (< 1e-30) and is exactly 0 on the other differs in NaN-ness only
+                ty, name, _ = key.split(".")
+                a, b = want[ty][name]["disparity"].detach().cpu().float(), got[ty][name]["disparity"].detach().cpu().float()
+                differ = torch.isnan(a) != torch.isnan(b)
+                tiny = (want[ty][name]["opacity"].detach().cpu().abs() < 1e-30) & (got[ty][name]["opacity"].detach().cpu().abs() < 1e-30)
+                rest = ~(torch.isnan(a) | torch.isnan(b))
+                if bool((differ & ~tiny).sum() == 0) and torch.allclose(a[rest], b[rest], **tol):
+                    del bad[key]
             if bad:
                 failures += 1
                 print("MISMATCH", label, bad)
@@ -215,6 +232,7 @@ def main():
             print("ERROR", label)
             traceback.print_exc()
     print(f"{cases} cases, {failures} failures")
+    return failures
 
 
 if __name__ == "__main__":

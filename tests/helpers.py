@@ -1,4 +1,6 @@
 """Shared helpers of the test-suite (tests may use the oracle; the product never does)."""
+import contextlib
+
 import torch
 
 from oracle import render_oracle as ro
@@ -32,6 +34,50 @@ def poison_device_memory():
     blocks = [torch.full((64 << 20,), float("nan"), device="cuda") for _ in range(4)]
     small = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 10, 1 << 14, 1 << 18, 1 << 20, 1 << 22) for _ in range(4)]
     del blocks, small
+
+
+@contextlib.contextmanager
+def oracle_in_float64():
+    """The oracle's op graph in float64 (every tensor it creates takes torch's default dtype): the arbiter where a tolerance
+    is wider than fp32 round-off.  Pass weights / inputs through ``to_double``."""
+    before = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(before)
+
+
+def to_double(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu().double() if x.is_floating_point() else x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: to_double(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(to_double(v) for v in x)
+    return x
+
+
+def arbitrate(exact, oracle32, hip, factor=4.0, floor=1e-6, path="", out=None):
+    """Per field of a composer result: (max |HIP - fp64|, max |fp32 oracle - fp64|, ok) with
+    ok = |HIP - fp64| <= factor x |fp32 oracle - fp64| + floor x max |fp64| - the HIP path may be as far from the exact
+    result as the fp32 restatement of the reference is (times a small factor), not farther."""
+    out = out if out is not None else {}
+    for k in exact:
+        if k in ("pytorch_hook", "extra_outputs") or k.startswith("_"):
+            continue
+        if isinstance(exact[k], dict):
+            arbitrate(exact[k], oracle32[k], hip[k], factor, floor, path + k + ".", out)
+            continue
+        e, a, b = (t.detach().cpu().double() for t in (exact[k], oracle32[k], hip[k]))
+        if k == "weights":
+            e, a, b = torch.sort(e, -1)[0], torch.sort(a, -1)[0], torch.sort(b, -1)[0]
+        clean = lambda t: torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
+        err_hip = float(clean(b - e).abs().max()) if e.numel() else 0.0
+        err_ref = float(clean(a - e).abs().max()) if e.numel() else 0.0
+        scale = float(clean(e).abs().max()) if e.numel() else 0.0
+        out[path + k] = (err_hip, err_ref, err_hip <= factor * err_ref + floor * scale)
+    return out
 
 
 def compare_results(want, got, rtol, atol, path="", out=None):
@@ -160,3 +206,44 @@ def observation_batch(scene, boxes_seed: int = 3, dynamic_objects: int = 2):
     return {"observations": observations, "camera_rotations": cam, "camera_translations": scene["camera_translations"],
             "focals": scene["focals"], "bounding_boxes": boxes, "bounding_boxes_validity": validity,
             "global_frame_indexes": frame, "video_frame_indexes": frame.clone(), "video_indexes": torch.arange(bs)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# forward_pose_consistency / forward_keypoint_consistency against the reference's recorded outputs (tests/golden/consistency,
+# oracle/make_golden.py consistency): shared by the CPU suite (oracle composer behind the product's host logic) and the GPU suite
+CONSISTENCY_KEYS = ("camera_rotations", "camera_translations", "focals", "bounding_boxes", "bounding_boxes_validity",
+                    "global_frame_indexes", "video_frame_indexes", "video_indexes")
+
+
+def run_consistency_fixture(z, model, device, monkeypatch):
+    """Replays the fixture's random draws through ``model`` and returns {label: (reference tensor, product tensor)}."""
+    from playableenvironments_amd import ray_sampling
+    t = lambda name: torch.from_numpy(z[name]).to(device)
+    queues = {"object": [], "keypoints": []}
+    for kind in queues:
+        i = 0
+        while f"draw/{kind}/{i}/0" in z.files:
+            queues[kind].append(tuple(t(f"draw/{kind}/{i}/{j}") for j in range(3)))
+            i += 1
+    assert len(queues["object"]) == 2 and len(queues["keypoints"]) == 2
+    monkeypatch.setattr(ray_sampling, "sample_rays_at_object", lambda *a, **k: queues["object"].pop(0))
+    monkeypatch.setattr(ray_sampling, "sample_rays_at_keypoints", lambda *a, **k: queues["keypoints"].pop(0))
+    common = [t("in/" + k) for k in CONSISTENCY_KEYS] + [t("se/" + k) for k in ("object_style", "object_deformation",
+                                                                                "object_rotation_parameters",
+                                                                                "object_translation_parameters")]
+    with torch.no_grad():
+        pose = model(t("in/optical_flow"), *common, 30, False, mode="pose_consistency")
+        kp = model(t("in/observations"), *common, t("in/keypoints"), t("in/bounding_boxes_validity"), 20, False,
+                   mode="keypoint_consistency")
+    assert not queues["object"] and not queues["keypoints"]
+    pairs = {}
+    for name, (previous, following) in pose["coarse"].items():
+        for tag, (positions, opacity) in (("previous", previous), ("following", following)):
+            pairs[f"pose/{name}/{tag}/positions"] = positions
+            pairs[f"pose/{name}/{tag}/opacity"] = opacity
+    for name, (positions, confidence, opacity, sampled) in kp["coarse"].items():
+        for tag, value in (("positions", positions), ("confidence", confidence), ("opacity", opacity), ("sampled", sampled)):
+            pairs[f"keypoint/{name}/{tag}"] = value
+    recorded = [k for k in z.files if k.startswith(("pose/", "keypoint/"))]
+    assert sorted(recorded) == sorted(pairs), (sorted(recorded), sorted(pairs))
+    return {k: (torch.from_numpy(z[k]), v.detach().cpu()) for k, v in pairs.items()}

@@ -782,6 +782,30 @@ def test_oracle_expected_positions_reproduce_reference_outputs_and_gradients(pat
     assert float(grads["w2o"].abs().max()) > 0 and float(grads["deformation"].abs().max()) > 0
 
 
+CONSISTENCY_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "consistency", "*.npz")))
+
+
+@pytest.mark.parametrize("path", CONSISTENCY_GOLDEN, ids=[os.path.basename(p)[:-4] for p in CONSISTENCY_GOLDEN])
+def test_consistency_forwards_reproduce_reference_outputs(path, monkeypatch):
+    """forward_pose_consistency / forward_keypoint_consistency of the product's host logic with the ORACLE behind its composer,
+    on the pixels the reference drew: the reference's expected positions, opacities, confidences - value for value."""
+    from oracle.check_against_reference import _OracleComposerAdapter
+    from playableenvironments_amd import environment_model as em
+    from tests.helpers import run_consistency_fixture, stand_in_encoders
+    assert len(CONSISTENCY_GOLDEN) >= 2
+    z = np.load(path)
+    meta = ast.literal_eval(bytes(z["meta"]).decode())
+    cfg = recipe_config(ast.literal_eval(bytes(z["recipe"]).decode()))
+    model = em.EnvironmentModel(cfg, *stand_in_encoders(cfg, meta["world"]))
+    model.object_composer.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}, strict=True)
+    model.object_composer = _OracleComposerAdapter(cfg, model.object_composer.eval())
+    pairs = run_consistency_fixture(z, model.eval(), "cpu", monkeypatch)
+    for k, (want, got) in pairs.items():
+        assert want.shape == got.shape, k
+        assert torch.allclose(want, got, rtol=1e-5, atol=5e-6), (k, float((want - got).abs().max()))   # (positions up to 2.2)
+    assert len(pairs) == 16
+
+
 def test_consistency_path_samplers():
     """sample_rays_at / sample_rays_at_object / sample_rays_at_keypoints (ray_helper.py:797-1052; exact equality with the
     reference functions is checked in oracle/check_against_reference.py): closed-form properties."""
