@@ -359,6 +359,164 @@ def train_step_leg(args, dev, world, rank, dist, lib):
     }
 
 
+class _ResidualBlock(torch.nn.Module):
+    """3x3 conv - BatchNorm - ReLU - 3x3 conv - BatchNorm (reflection padding) around a shortcut; a 1x1 conv + BatchNorm
+    shortcut where the channel count changes."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        nn = torch.nn
+        self.body = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(cin, cout, 3, bias=False), nn.BatchNorm2d(cout), nn.ReLU(True),
+                                  nn.ReflectionPad2d(1), nn.Conv2d(cout, cout, 3, bias=False), nn.BatchNorm2d(cout))
+        self.shortcut = None if cin == cout else nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        return (x if self.shortcut is None else self.shortcut(x)) + self.body(x)
+
+
+class StandInDecoder(torch.nn.Module):
+    """Seeded stand-in for the image decoder behind the renderer in BASELINE.json configs[4] (the reference's DecoderV6 with the
+    shipped minecraft settings, model/autoencoder_models/decoder_v6.py:10-96: bottleneck 128 channels at 1/8 resolution, three
+    residual blocks per level, bilinear x2 + 3x3 conv + BatchNorm + ReLU per upsampling, the 1/4-resolution map concatenated as
+    a skip, a 7x7 conv + sigmoid head).  Own code on stock torch.nn (MIOpen convolutions): it exists to put the decoder's
+    launches and its gradient w.r.t. the renderer's maps into the measured step, not to reproduce trained images."""
+
+    def __init__(self, image_channels: int = 3, bottleneck: int = 128, blocks: int = 3, levels=(2, 1)):
+        super().__init__()
+        nn = torch.nn
+        width = bottleneck
+        stages = []
+        for idx, upsamplings in enumerate(reversed(list(levels))):
+            layers = [_ResidualBlock(width * (2 if (b == 0 and idx > 0) else 1), width) for b in range(blocks)]
+            for _ in range(upsamplings):
+                layers += [nn.UpsamplingBilinear2d(scale_factor=2),
+                           nn.Conv2d(width, width // 2, 3, padding=1, padding_mode="reflect", bias=False),
+                           nn.BatchNorm2d(width // 2), nn.ReLU(True)]
+                width //= 2
+            stages.append(nn.Sequential(*layers))
+        self.stages = nn.ModuleList(stages)
+        self.head = nn.Sequential(nn.ReflectionPad2d(3), nn.Conv2d(width, image_channels, 7), nn.Sigmoid())
+
+    def forward(self, maps):
+        """maps: [(N, 64, h/4, w/4), (N, 128, h/8, w/8)] - finest first, as forward_decoder takes them."""
+        x = maps[-1]
+        for i, stage in enumerate(self.stages):
+            x = stage(x)
+            if i != len(self.stages) - 1:
+                x = torch.cat([x, maps[-i - 2]], dim=-3)
+        return self.head(x)
+
+
+def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
+    """BASELINE.json configs[4] end to end in shape: the training step of ``train_step_leg`` with an image decoder behind the
+    renderer - the renderer's per-stride maps -> decoder CNN -> image loss -> backward through the decoder into the maps ->
+    pr_render_backward -> gradient all-reduce -> Adam on both parameter sets.  Two routes for the renderer -> decoder hand-over
+    (SURVEY.md section 8 f-1): "maps" = ``decoder_features`` written channels-first by the compositing kernel, "ray_major" = the
+    reference's route (ray-major integrated_features folded / split / permuted by wire_format, torch ops).  The decoder runs on
+    a side stream (its forward, and therefore its autograd nodes); the dependency chain renderer forward -> decoder forward ->
+    decoder backward -> renderer backward leaves only the decoder's optimiser update to overlap with the renderer's backward."""
+    from playableenvironments_amd import configs, synthetic, parallel
+    from playableenvironments_amd import wire_format as wf
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    cfg = configs.minecraft_config()
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.train().to(dev)
+    model.object_composer.batchnorm_check = "deferred"
+    torch.manual_seed(1)
+    decoder = StandInDecoder().train().to(dev)
+    size = (288, 512)
+    sc = to_device(synthetic.minecraft_scene(batch=3, seed=77 + rank, image_size=size), dev)
+    for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
+        sc[k].requires_grad_(True)
+    render_params = list(model.object_composer.parameters())
+    decoder_params = list(decoder.parameters())
+    opt_render = torch.optim.Adam(render_params, lr=1e-5, fused=True)
+    opt_decoder = torch.optim.Adam(decoder_params, lr=1e-5, fused=True)
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand((3, 3, 192, 192), generator=g).to(dev)
+    side = torch.cuda.Stream(dev)
+    counts = [64, 128]
+    steps, warmup = max(1, args.steps), max(2, args.warmup)
+
+    def make_step(route):
+        def step():
+            opt_render.zero_grad(set_to_none=True)
+            opt_decoder.zero_grad(set_to_none=True)
+            out = model(*scene_args(sc, size), 2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings",
+                        **({"_decoder_features": counts} if route == "maps" else {}))
+            if route == "maps":
+                maps = out["coarse"]["global"]["decoder_features"]
+            else:
+                _, maps = wf.decoder_patches(out["coarse"]["global"]["integrated_features"], 48, [4, 8], counts)
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                image = decoder([m.reshape([-1] + list(m.shape[-3:])) for m in maps])
+                loss = (image - target).square().mean()
+            main.wait_stream(side)
+            loss.backward()
+            parallel.allreduce_gradients(render_params + decoder_params)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                opt_decoder.step()
+            opt_render.step()
+            main.wait_stream(side)
+            return loss
+        return step
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            marks[i].record()
+            fn()
+        marks[steps].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
+        return dt / steps * 1e3, median(event_gaps_ms(marks))
+
+    results = {}
+    for route in ("maps", "ray_major"):
+        mean_ms, median_ms = timed(make_step(route))
+        results[route] = {"ms_per_step": round(mean_ms, 3), "ms_per_step_median": round(median_ms, 3)}
+
+    # the decoder alone on fixed maps (forward + backward to the maps + Adam), for the shares
+    fixed = [torch.randn((3, 64, 48, 48), device=dev, requires_grad=True), torch.randn((3, 128, 24, 24), device=dev, requires_grad=True)]
+
+    def decoder_only():
+        opt_decoder.zero_grad(set_to_none=True)
+        (decoder(fixed) - target).square().mean().backward()
+        opt_decoder.step()
+    decoder_ms, _ = timed(decoder_only)
+    combined = results["maps"]["ms_per_step"]
+    return {
+        "workload": "train_step (minecraft, 3 frames x 2880 rays, perturb, train-mode BatchNorm) + a stand-in decoder with DecoderV6's "
+                    "shipped layer shapes (1.3 M parameters, 64 @ 48x48 + 128 @ 24x24 -> 3 x 192x192 per frame), MSE against seeded "
+                    "images, Adam on both parameter sets - BASELINE.json configs[4] in shape (the reference's decoder weights and "
+                    "perceptual losses are not part of the path)",
+        "value": round(2880 * 3 * world / (combined * 1e-3) / 1e6, 4), "unit": "Mrays/s trained, decoder included",
+        "maps_route": results["maps"], "ray_major_route": results["ray_major"],
+        "route_note": "maps = decoder_features written channels-first per stride by the compositing kernel (and their gradient read by "
+                      "its backward); ray_major = integrated_features + wire_format's fold / split / permute as in the reference's glue",
+        "renderer_only_ms": round(renderer_only_ms, 3), "decoder_only_ms": round(decoder_ms, 3),
+        "renderer_share": round(renderer_only_ms / combined, 3),
+        "overlap_ms": round(renderer_only_ms + decoder_ms - combined, 3),
+        "overlap_note": "renderer_only + decoder_only - combined (positive = hidden time): the decoder runs on a side stream, but the step "
+                        "is one dependency chain (renderer forward -> decoder forward -> decoder backward -> renderer backward), so only "
+                        "the decoder's optimiser update and host enqueue time can hide behind the renderer's backward",
+        "decoder_parameters": sum(p.numel() for p in decoder_params),
+    }
+
+
 def minecraft_leg(dev, lib, frames=20, balance=False):
     """BASELINE.json configs[2]: the shipped minecraft renderer (background P=16, skybox P=1, two players P=32 that share one
     model, static / dynamic overlap fix), one 256x256 frame, evaluation - both precisions, with the MLP / compositing share."""
@@ -752,6 +910,7 @@ def main():
         del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
+        result["train_step_with_decoder"] = train_step_with_decoder_leg(args, dev, world, rank, dist, result["train_step"]["ms_per_step"])
     if rank == 0 and world == 1 and not args.no_minecraft:
         result["config2_minecraft_256"] = minecraft_leg(dev, lib, balance=not args.no_shard_balance)
         if "shard_balance" in result and "shard_balance" in result["config2_minecraft_256"]:
