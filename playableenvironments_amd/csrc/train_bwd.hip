@@ -55,8 +55,32 @@ __device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d
 
 // The K loop of one fragment-ordered segment over the operand tile in X (run_layer's loop, mlp_tile.h: two steps in flight,
 // even / odd fragments in their own registers).  a0x: column block `wave`, a1x: column block `wave + 4`; x0 / x1: row blocks.
+// ``drain``: the operand tile in X is also WRITTEN OUT to global memory while the product runs - one 16-byte chunk per thread and
+// loop iteration (a tile of width Wpad has Wpad / 16 chunks per thread and the loop Wpad / 16 iterations), so that the 64 KB of a
+// tile reach the memory system spread over the K loop instead of as one burst in front of it.
+struct Drain {
+    float* dst;            // row `tile_base` of the (cap, ld) destination; NULL: nothing to write
+    int ld, w4, rows_valid;
+};
+__device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int it) {
+    const int idx = threadIdx.x + it * MLP_THREADS;
+    const int row = idx / d.w4, c = (idx - row * d.w4) * 4;
+    if (row < d.rows_valid) {
+        const float4 v = *reinterpret_cast<const float4*>(X + row * LDX + c);
+        *reinterpret_cast<float4*>(d.dst + (size_t)row * d.ld + c) = v;
+    }
+}
+// every wave runs the loop (so every thread drains its chunks) when the product has at least MLP_WAVES column blocks
+__device__ __forceinline__ bool drains_in_loop(int nblk) {
+#ifdef PR_NO_DRAIN
+    return false;
+#else
+    return nblk >= MLP_WAVES;
+#endif
+}
+
 __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                              f32x16& a11) {
+                                              f32x16& a11, const Drain* drain = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int cbA = wave, cbB = wave + MLP_WAVES;
@@ -93,6 +117,7 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
             wBo = wpB[(size_t)qo * 64];
             x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
             x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+            if (drain) drain_chunk(*drain, X, q >> 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -113,6 +138,7 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
             wAo = wpA[(size_t)qo * 64];
             x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
             x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
+            if (drain) drain_chunk(*drain, X, q >> 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -597,7 +623,18 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         PR_CT(3);
         __syncthreads();
         PR_CT(4);
-        store_tile_rows(S.X, c.gstack + (size_t)(c.count - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+        // G of layer count - 1 is in X: its write-out to the gradient stack (the weight-gradient launch reads it) rides on the next
+        // product's K loop, which reads the same tile (tile_products' drain); products too narrow for that write it first
+        Drain pending{c.gstack + (size_t)(c.count - 1) * c.g_stride + (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad >> 2, rows_valid};
+        auto product = [&](const Seg& sg, int out_blk) {
+            zero4(a00, a01, a10, a11);
+            if (pending.dst && !drains_in_loop(out_blk)) {
+                store_tile_rows(S.X, pending.dst - (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad, tile_base, rows_valid);
+                pending.dst = nullptr;
+            }
+            tile_products(sg, out_blk, S.X, a00, a01, a10, a11, pending.dst ? &pending : nullptr);
+            pending.dst = nullptr;
+        };
         PR_CT(5);
         bool g_in_written = false;
         // ReLU mask words of layer l's input (layer l - 1's output), requested a whole layer ahead: behind the weight fragments of a K
@@ -607,14 +644,12 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             masks = next;
             if (l >= 2) next = fetch_col_masks(c.bits + (size_t)(l - 2) * c.bits_stride, c.Wpad, nblk, tile);
             if (l == c.skip) {
-                zero4(a00, a01, a10, a11);
-                tile_products(c.in0_skip, in_nblk, S.X, a00, a01, a10, a11);
+                product(c.in0_skip, in_nblk);
                 store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, false, a00, a01, a10, a11);
                 g_in_written = true;
             }
             PR_CT(6);
-            zero4(a00, a01, a10, a11);
-            tile_products(c.act_t[l], nblk, S.X, a00, a01, a10, a11);
+            product(c.act_t[l], nblk);
             PR_CT(1);
             __syncthreads();
             PR_CT(2);
@@ -622,11 +657,11 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             PR_CT(3);
             __syncthreads();
             PR_CT(4);
-            if (!(PR_CHAINGRP_ABLATE & 1)) store_tile_rows(S.X, c.gstack + (size_t)(l - 1) * c.g_stride, c.Wpad, c.Wpad, tile_base, rows_valid);
+            if (!(PR_CHAINGRP_ABLATE & 1))
+                pending = Drain{c.gstack + (size_t)(l - 1) * c.g_stride + (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad >> 2, rows_valid};
         }
         PR_CT(5);
-        zero4(a00, a01, a10, a11);
-        tile_products(c.in0_first, in_nblk, S.X, a00, a01, a10, a11);
+        product(c.in0_first, in_nblk);
         store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, g_in_written, a00, a01, a10, a11);
         PR_CT(7);
         __syncthreads();   // the next tile overwrites X, the bits and the records
