@@ -66,8 +66,13 @@ __device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int 
     const int idx = threadIdx.x + it * MLP_THREADS;
     const int row = idx / d.w4, c = (idx - row * d.w4) * 4;
     if (row < d.rows_valid) {
-        const float4 v = *reinterpret_cast<const float4*>(X + row * LDX + c);
-        *reinterpret_cast<float4*>(d.dst + (size_t)row * d.ld + c) = v;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
+#ifdef PR_DRAIN_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
+#else
+        *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
+#endif
     }
 }
 // every wave runs the loop (so every thread drains its chunks) when the product has at least MLP_WAVES column blocks

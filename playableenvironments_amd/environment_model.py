@@ -233,6 +233,34 @@ def camera_rays_at_positions(c2w: torch.Tensor, focals: torch.Tensor, height: in
     return c2w[..., :3, 3], directions, -c2w[..., :3, 2]
 
 
+class _LazyGraph(torch.autograd.Function):
+    """forward = ``fast(*tensors)`` without a graph (one HIP kernel); backward = torch.autograd through ``slow(*tensors)``
+    recomputed on the saved inputs, only if a gradient ever arrives.  For the projected boxes / axes of a training call: the
+    shipped losses do not read them, so the ~40 small tensor ops (and their graph) of the differentiable formulation are not
+    issued per step; a loss that does read them gets exactly the gradients of that formulation."""
+
+    @staticmethod
+    def forward(ctx, fast, slow, *tensors):
+        ctx.slow = slow
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            out = fast(*tensors)
+        return tuple(out) if isinstance(out, (tuple, list)) else out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        inputs = [t.detach().requires_grad_(need) for t, need in zip(ctx.saved_tensors, ctx.needs_input_grad[2:])]
+        with torch.enable_grad():
+            outs = ctx.slow(*inputs)
+            outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
+            pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+            wanted = [t for t in inputs if t.requires_grad]
+            got = torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True) if pairs and wanted else []
+        it = iter(got)
+        return (None, None) + tuple(next(it) if t.requires_grad else None for t in inputs)
+
+
 class EnvironmentModel(nn.Module):
 
     def __init__(self, config, object_encoders=None, object_parameters_encoders=None, image_decoder=None, grid_sampler=None):
@@ -422,7 +450,7 @@ class EnvironmentModel(nn.Module):
                  for k in range(helper.objects_count)], dim=0).to(device)
         return self._edge_point_cache[key]
 
-    def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width):
+    def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width, _lazy=False):
         """Image-plane boxes (..., C, 4, K) [left, top, right, bottom] and projected box points
         (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
         if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
@@ -431,6 +459,12 @@ class EnvironmentModel(nn.Module):
             points, boxes = self._project_on_device(self._edge_points(transformation_matrix_o2w.device), transformation_matrix_o2w,
                                                     transformation_matrix_w2c, focals, height, width, with_boxes=True)
             return boxes, points
+        if not _lazy and transformation_matrix_o2w.is_cuda and transformation_matrix_w2c.is_cuda and torch.is_tensor(focals) and focals.is_cuda:
+            # a graph is wanted: the values from the kernel, the gradients (if a loss ever reads the boxes) from the tensor ops below
+            return _LazyGraph.apply(
+                lambda a, b, c: self.compute_object_bounding_boxes(a, b, c, height, width),
+                lambda a, b, c: self.compute_object_bounding_boxes(a, b, c, height, width, _lazy=True),
+                transformation_matrix_o2w, transformation_matrix_w2c, focals)
         proj, z = self._project(self._edge_points(transformation_matrix_o2w.device), transformation_matrix_o2w,
                                 transformation_matrix_w2c, focals)                             # (..., C, K, 68, 2)
         behind = (z > 0).expand_as(proj)
@@ -445,7 +479,7 @@ class EnvironmentModel(nn.Module):
         points = (points + pscale / 2) / pscale
         return torch.clamp(boxes, min=0.0, max=1.0), torch.clamp(points, min=0.0, max=1.0)
 
-    def compute_object_axes_projection(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width):
+    def compute_object_axes_projection(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width, _lazy=False):
         """Projected origin + unit axes of every object (..., C, 4, 2, K), normalised, not clamped.
         model/environment_model.py:329-404."""
         if transformation_matrix_o2w.dim() > transformation_matrix_w2c.dim():
@@ -458,6 +492,11 @@ class EnvironmentModel(nn.Module):
         if self._no_graph(transformation_matrix_o2w, transformation_matrix_w2c, focals):
             return self._project_on_device(pts, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width,
                                            with_boxes=False)[0]
+        if not _lazy and transformation_matrix_o2w.is_cuda and transformation_matrix_w2c.is_cuda and torch.is_tensor(focals) and focals.is_cuda:
+            return _LazyGraph.apply(
+                lambda a, b, c: self.compute_object_axes_projection(a, b, c, height, width),
+                lambda a, b, c: self.compute_object_axes_projection(a, b, c, height, width, _lazy=True),
+                transformation_matrix_o2w, transformation_matrix_w2c, focals)
         out = self._project(pts, transformation_matrix_o2w, transformation_matrix_w2c, focals)[0].movedim(-3, -1)
         pscale = self._image_scale(width, height, out)[:2]
         return (out + pscale / 2) / pscale

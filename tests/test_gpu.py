@@ -1635,15 +1635,29 @@ def test_projection_kernel_matches_the_torch_path(world):
     with torch.no_grad():
         boxes, points = model.compute_object_bounding_boxes(o2w, w2c, focals, 96, 128)
         axes = model.compute_object_axes_projection(o2w, w2c, focals, 96, 128)
-    o2w_g = o2w.clone().requires_grad_(True)                      # a graph: the torch ops
-    ref_boxes, ref_points = model.compute_object_bounding_boxes(o2w_g, w2c, focals, 96, 128)
-    ref_axes = model.compute_object_axes_projection(o2w_g, w2c, focals, 96, 128)
+    o2w_g = o2w.clone().requires_grad_(True)                      # the differentiable formulation: tensor ops
+    ref_boxes, ref_points = model.compute_object_bounding_boxes(o2w_g, w2c, focals, 96, 128, _lazy=True)
+    ref_axes = model.compute_object_axes_projection(o2w_g, w2c, focals, 96, 128, _lazy=True)
     assert ref_boxes.requires_grad and not boxes.requires_grad
     for got, want in ((boxes, ref_boxes), (points, ref_points)):
         assert got.shape == want.shape and float((got - want.detach()).abs().max()) <= 1e-5
     # (the unclamped axes of the object that sits ON the camera are a division by ~0: compared for the other objects)
     close = torch.isclose(axes, ref_axes.detach(), rtol=1e-4, atol=1e-4)
     assert axes.shape == ref_axes.shape and bool(close[..., :-1].all()) and bool(close[1:].all())
+    # with a graph wanted, the call returns the kernel's values and defers the tensor ops to the backward pass: same values as
+    # the no-graph call bit for bit, the gradients of the differentiable formulation exactly
+    o2w_l = o2w.clone().requires_grad_(True)
+    lazy_boxes, lazy_points = model.compute_object_bounding_boxes(o2w_l, w2c, focals, 96, 128)
+    lazy_axes = model.compute_object_axes_projection(o2w_l, w2c, focals, 96, 128)
+    assert lazy_boxes.requires_grad and torch.equal(lazy_boxes, boxes) and torch.equal(lazy_points, points)
+    assert torch.equal(torch.nan_to_num(lazy_axes), torch.nan_to_num(axes))
+    g = torch.Generator().manual_seed(3)
+    pb, pp = torch.randn(boxes.shape, generator=g).cuda(), torch.randn(points.shape, generator=g).cuda()
+    pa = torch.randn(axes.shape, generator=g).cuda() * close.float()
+    ((ref_boxes * pb).sum() + (ref_points * pp).sum() + (ref_axes * pa).sum()).backward()
+    ((lazy_boxes * pb).sum() + (lazy_points * pp).sum() + (lazy_axes * pa).sum()).backward()
+    assert float(torch.nan_to_num(o2w_g.grad).abs().max()) > 0
+    assert torch.equal(torch.nan_to_num(o2w_l.grad), torch.nan_to_num(o2w_g.grad))
     assert 0.0 < float(boxes.min()) or float(boxes.max()) <= 1.0
 
 
