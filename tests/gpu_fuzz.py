@@ -205,12 +205,13 @@ def forward_sweep(cases, rng, only=None):
             if hierarchical:        # the weights of tied / nearly tied merged samples may swap: judged by the integrals
                 bad = {k: v for k, v in bad.items() if not k.endswith("weights")}
             for key in [k for k in bad if k.endswith("disparity")]:
-                # disparity = 1 / max(eps, depth / opacity) is NaN exactly where the opacity is 0: a ray whose opacity underflows
-                # on one side (< 1e-30) and is exactly 0 on the other differs in NaN-ness only
+                # disparity = 1 / max(eps, depth / opacity) is NaN exactly where the opacity is 0.  1 - exp(-sigma delta) rounds to 0
+                # or to 2^-24 around sigma delta = 2^-25: a ray whose only contribution sits on that boundary has opacity 0 on one
+                # side and 6e-8 on the other (equal at the suite's tolerance) and differs in NaN-ness only
                 ty, name, _ = key.split(".")
                 a, b = want[ty][name]["disparity"].detach().cpu().float(), got[ty][name]["disparity"].detach().cpu().float()
                 differ = torch.isnan(a) != torch.isnan(b)
-                tiny = (want[ty][name]["opacity"].detach().cpu().abs() < 1e-30) & (got[ty][name]["opacity"].detach().cpu().abs() < 1e-30)
+                tiny = (want[ty][name]["opacity"].detach().cpu().abs() < 1e-6) & (got[ty][name]["opacity"].detach().cpu().abs() < 1e-6)
                 rest = ~(torch.isnan(a) | torch.isnan(b))
                 if bool((differ & ~tiny).sum() == 0) and torch.allclose(a[rest], b[rest], **tol):
                     del bad[key]
