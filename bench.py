@@ -880,8 +880,10 @@ def main():
             "value": round(rays_per_gpu * world / identical / 1e6, 4), "unit": "Mrays/s", "ms_per_step": round(identical * 1e3, 3),
             "note": "secondary: every rank renders the SAME frame (seed 1234) - exactly the same work per GPU; the headline's ranks "
                     "render distinct frames"}
-    final_feats = step()["fine"]["global"]["integrated_features"]
-    drain()
+    final_feats = None
+    if world > 1:
+        final_feats = step()["fine"]["global"]["integrated_features"]
+        drain()
     result["feature_gather"] = feature_gather_leg(final_feats, dist, world, rank, dev)
     del final_feats
     if world == 1 and not args.no_shard_balance:

@@ -5,6 +5,7 @@ of these kernels as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescri
 and cross-checked against the algorithmic bytes written (feature rows x row bytes)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -24,6 +25,11 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
 out = {"source": "tools/collect_pmc.sh: rocprofv3 --kernel-trace --pmc <one set per pass> -- python bench.py --steps 1 --warmup 0 "
                  "--no-cpu-baseline --no-train-step --no-split-precision (2 renders: the timed step + the sample-count pass)",
        "renders": 2, "kernels": {}}
+# the library the counters were collected from: bench.py compares it with the library it runs (a stale traffic figure shows)
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "playableenvironments_amd", "libplayrender.so")
+if os.path.exists(lib):
+    with open(lib, "rb") as f:
+        out["library_sha256"] = hashlib.sha256(f.read()).hexdigest()
 for name, counters in sorted(per.items()):
     if not name.startswith("pr::"):
         continue

@@ -1,10 +1,11 @@
-"""Summarises ONE training step out of a rocprofv3 kernel trace of tests/perf_train_step.py:
+"""Summarises ONE training step out of a rocprofv3 kernel trace of bench.py's train_step leg (tests/perf_train_leg.py):
 
-    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tests/perf_train_step.py minecraft 5
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tests/perf_train_leg.py 6 3
     python tools/summarise_train_trace.py <dir>/*/*_kernel_trace.csv > profiles/rNN_train_step_trace_summary.json
 
-A step starts at a coarse-placement launch (pr::k_place_coarse is the first kernel of a renderer call; one call per step)
-and ends before the next one; the LAST complete step (one with a backward pass) of the trace is reported."""
+A step starts at a coarse-placement launch (pr::k_place_coarse[_group] is the first kernel of a renderer call; one call per
+step) and ends before the next one - the optimiser, the loss and the next call's scene set-up launches included; the LAST
+complete step (one with a backward pass) of the trace is reported."""
 import csv
 import json
 import re
@@ -50,7 +51,9 @@ def main(path):
     wall = (rows[b][0] - rows[a][0]) / 1e6
     print(json.dumps({"trace": path.split("/")[-1], "step_wall_ms_call_to_call": round(wall, 3), "launches": len(step),
                       "sum_of_kernel_durations_ms": round(busy, 3), "kernel_time_over_wall": round(busy / wall, 3),
-                      "note": "the backward pass runs its objects on two streams: kernel durations overlap, their sum can exceed the wall time",
+                      "gpu_idle_ms": round(max(0.0, wall - busy), 3),
+                      "note": "one stream: every object of a model type in one grouped launch per phase (round 3); wall = from this step's "
+                              "first launch to the next step's, under the profiler",
                       "kernels": kernels}, indent=1))
 
 
