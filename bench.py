@@ -1050,7 +1050,11 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
 
     # ---- the reference's PyTorch op graph on this GPU (PyTorch-ROCm, 1000-ray chunks like render_full_frame_*)
     if not args.no_reference_graph:
-        gin = [v.to(dev) for v in inputs]
+        # (4096 rays whatever the CPU subset is: with fewer rays the op graph's launches are too small to fill the GPU and the
+        # reference's side would look slower than it is)
+        ref_side = 64
+        ref_inputs = inputs if n_side == ref_side else composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], ref_side))
+        gin = [v.to(dev) for v in ref_inputs]
         gsd = {k: v.to(dev) for k, v in sd.items()}
         graph, spread = {}, {}
         for chunk, repeats in ((1000, 5), (4000, 5)):
@@ -1063,7 +1067,7 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
                     t0 = time.perf_counter()
                     ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
                     torch.cuda.synchronize()
-                    rates.append(n_side * n_side / (time.perf_counter() - t0) / 1e6)
+                    rates.append(ref_side * ref_side / (time.perf_counter() - t0) / 1e6)
             graph[f"chunk_{chunk}"] = round(median(rates), 5)
             spread[f"chunk_{chunk}"] = {"runs": [round(r, 5) for r in rates], "min": round(min(rates), 5), "max": round(max(rates), 5)}
         out["reference_graph_on_gpu"] = {
@@ -1071,7 +1075,7 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
             "chunk_4000": graph["chunk_4000"],
             "protocol": "1 warm-up, median of 5 runs per chunk size", "spread": spread,
             "sample": f"the oracle's restatement of the reference's op graph (materialised per-sample tensors, boolean compaction, "
-                      f"sort + gather compose) run by PyTorch-ROCm on this GPU, {n_side * n_side} rays of the same frame, "
+                      f"sort + gather compose) run by PyTorch-ROCm on this GPU, {ref_side * ref_side} rays of the same frame, "
                       "1000-ray chunks as render_full_frame_* uses (4000-ray chunks beside it)",
             "hip_over_reference_graph": round(gpu_mrays / graph["chunk_1000"], 1) if graph["chunk_1000"] > 0 else None,
             "hip_over_reference_graph_chunk_4000": round(gpu_mrays / graph["chunk_4000"], 1) if graph["chunk_4000"] > 0 else None,

@@ -55,11 +55,13 @@ def _pose_matrices_kernel(rotations: torch.Tensor, translations: torch.Tensor):
     n = int(math.prod(lead)) if lead else 1
     rot = rotations.detach().to(torch.float32).reshape(n, 3).contiguous()
     tr = torch.broadcast_to(translations.detach().to(torch.float32), rotations.shape).reshape(n, 3).contiguous()
-    out = torch.empty((2, n, 4, 4), dtype=torch.float32, device=rotations.device)
+    # (two allocations: as outputs of an autograd node, views of ONE buffer would make an in-place edit of either raise)
+    m = torch.empty((n, 4, 4), dtype=torch.float32, device=rotations.device)
+    inv = torch.empty((n, 4, 4), dtype=torch.float32, device=rotations.device)
     with torch.cuda.device(rotations.device):
-        _lib.check(_lib.load().pr_pose_matrices(n, rot.data_ptr(), tr.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+        _lib.check(_lib.load().pr_pose_matrices(n, rot.data_ptr(), tr.data_ptr(), m.data_ptr(), inv.data_ptr(),
                                                 torch.cuda.current_stream(rotations.device).cuda_stream), "pr_pose_matrices")
-    return out[0].reshape(lead + [4, 4]), out[1].reshape(lead + [4, 4]), rot, tr
+    return m.reshape(lead + [4, 4]), inv.reshape(lead + [4, 4]), rot, tr
 
 
 class _PoseMatrices(torch.autograd.Function):
@@ -145,7 +147,9 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     Returns origins (..., 3), directions (..., R, 3), focal normals (..., 3)."""
     if not c2w.is_cuda:
         raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
-    if torch.is_grad_enabled() and (c2w.requires_grad or (torch.is_tensor(focals) and focals.requires_grad)):
+    if not torch.is_tensor(focals):
+        focals = torch.as_tensor(focals, dtype=torch.float32, device=c2w.device)
+    if torch.is_grad_enabled() and (c2w.requires_grad or focals.requires_grad):
         # learnable camera parameters (camera_parameters_offsets): the rays carry a graph back to them
         return _CameraRays.apply(c2w, focals, height, width, rows, cols)
     lead = list(c2w.shape[:-2])
@@ -205,9 +209,8 @@ class _CameraRays(torch.autograd.Function):
         if g_normals is not None:
             g_c2w[..., :3, 2] -= g_normals.to(torch.float32)
         if g_f is not None:
-            while g_f.dim() > focals.dim():                     # focals broadcast over leading dimensions
-                g_f = g_f.sum(0)
-            g_f = g_f.reshape(focals.shape).to(focals.dtype)
+            # focals broadcast against the cameras' leading dimensions (missing or size-1 dimensions alike)
+            g_f = g_f.sum_to_size(focals.shape).to(focals.dtype) if focals.dim() else g_f.sum().to(focals.dtype)
         return g_c2w.to(c2w.dtype), g_f, None, None, None, None
 
 

@@ -251,7 +251,13 @@ class CameraParametersStorage(nn.Module):
 
     The reference keeps one 7-vector ``nn.Parameter`` per entry and picks them in a Python loop with ``.item()``; here the
     table is ONE ``(entries, 7)`` parameter read with one device gather.  The checkpoint format is the reference's
-    (``storage.storage.{entry}`` -> ``(7,)``): rows are split / joined when a state dict is written / read."""
+    (``storage.storage.{entry}`` -> ``(7,)``): rows are split / joined when a state dict is written / read.
+
+    Optimiser semantics differ from the reference's per-entry parameters (both shipped configurations leave the offsets off):
+    an entry that is not in the batch has ``grad = None`` there and is skipped by the optimiser, here its row of the table's
+    gradient is zero, so Adam still applies its momentum / weight decay to it; and the optimiser state is one tensor, so a
+    reference optimiser checkpoint does not resume.  Train the table with ``torch.optim.SparseAdam`` semantics (or mask the
+    update to the rows of ``frame_indexes``) where that matters."""
 
     features_count = 7
 
