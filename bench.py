@@ -189,7 +189,7 @@ def shard_balance_leg(model, cfg, scene_dev, size, shards=8, reps=3):
 def feature_gather_leg(feats, dist, world, rank, dev, reps=10):
     """The exchange step of a sharded render on its own: every rank contributes its rendered feature map; once as all_gather
     (every rank receives the stack) and once as gather(dst=0) (rank 0, the decoder / writer of the evaluation flow, alone)."""
-    if world == 1:
+    if dist is None:
         return {"world_size": 1, "note": "one rank: no exchange (gather_ray_shards returns the local tensor)"}
     src = feats.contiguous()
     nbytes = src.numel() * src.element_size()
@@ -290,7 +290,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         evaluated.zero_()
         retries[0] = 0
@@ -301,9 +301,9 @@ def train_step_leg(args, dev, world, rank, dist, lib):
             out = fn()
         marks[steps].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
-        return max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev), out, event_gaps_ms(marks)
+        return max_over_ranks(time.perf_counter() - t0, dist, dev), out, event_gaps_ms(marks)
 
     dt, out, gaps = timed(step)
     redrawn = retries[0]
@@ -470,7 +470,7 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
@@ -479,9 +479,9 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
             fn()
         marks[steps].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
-        dt = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
+        dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
         return dt / steps * 1e3, median(event_gaps_ms(marks))
 
     results = {}
@@ -583,7 +583,7 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
 
     run()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     local_ms = 0.0
@@ -591,11 +591,11 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
         out, e0, e1 = run()
         torch.cuda.synchronize()
         local_ms += e0.elapsed_time(e1)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None, dev)
+    dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     per_rank = [local_ms / steps]
-    if world > 1:
+    if dist is not None:
         t = torch.tensor(per_rank, dtype=torch.float64, device=dev)
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
@@ -673,8 +673,13 @@ def main():
     dev = torch.device("cuda", device_index)
     dist = None
     backend = None
-    if world > 1:
+    # PR_BENCH_FORCE_DIST: initialise the process group (and run every collective of the multi-rank legs) with ONE rank too -
+    # how the RCCL code path of `--gpus N` is exercised on a one-GPU box
+    multi = world > 1 or bool(os.environ.get("PR_BENCH_FORCE_DIST"))
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -705,7 +710,7 @@ def main():
         with torch.no_grad():
             out = model(*scene_args(active["scene"], size), 0, False, mode="scene_encodings")
         feats = out["fine"]["global"]["integrated_features"]
-        if world > 1:
+        if multi:
             # one RCCL collective for the rendered feature maps (50 MB per frame); every rank receives the stack,
             # rank 0 is the consumer (decoder / writer) in the reference's evaluation flow.  It runs on RCCL's own
             # stream behind this step's kernels and overlaps the NEXT step's rendering; the step after that (or the end
@@ -733,7 +738,7 @@ def main():
             step()
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         lib.pr_profile_enable(1)
         torch.cuda.synchronize()
@@ -745,20 +750,20 @@ def main():
         marks[steps].record()
         drain()                      # every gather of the timed steps completes inside the timed region
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
         lib.pr_profile_enable(0)
         kernel_ms, kernel_launches = profile_arrays()
         _lib.check(lib.pr_profile_collect(kernel_ms, kernel_launches), "pr_profile_collect")
-        dt = max_over_ranks(dt, dist if world > 1 else None, dev)
+        dt = max_over_ranks(dt, dist, dev)
         timed.gaps = event_gaps_ms(marks)
         return dt, kernel_ms, kernel_launches
 
     elapsed, ms, launches = timed(args.steps, args.warmup)
     step_gaps = timed.gaps
     identical = None
-    if world > 1:
+    if multi:
         active["scene"] = to_device(synthetic.tennis_scene(seed=1234, image_size=size), dev)
         same_s, _, _ = timed(max(1, min(args.steps, 5)), 1)
         active["scene"] = scene_dev
@@ -796,12 +801,15 @@ def main():
         _lib.check(lib.pr_probe_mfma_f32(100000, rnd, C.byref(tf), C.byref(pms), None), "pr_probe_mfma_f32")
         probe[name] = round(tf.value, 1)
 
-    distributed = {"world_size": (dist.get_world_size() if world > 1 else 1), "backend": backend,
-                   "launched_by": "torch.distributed.run" if world > 1 else "single process"}
-    if world > 1:
+    distributed = {"world_size": (dist.get_world_size() if multi else 1), "backend": backend,
+                   "launched_by": "torch.distributed.run" if world > 1 else ("single process, process group forced" if multi else "single process")}
+    if multi:
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
         if backend == "nccl":
-            distributed["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())     # (= RCCL on ROCm)
+            try:
+                distributed["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())     # (= RCCL on ROCm)
+            except Exception as e:     # (a build without the query: the backend string above still says what ran)
+                distributed["nccl_version"] = f"unavailable ({type(e).__name__})"
             distributed["devices"] = torch.cuda.device_count()
     rays_per_gpu = size[0] * size[1]
     total_rays = rays_per_gpu * world * args.steps
@@ -881,7 +889,7 @@ def main():
             "note": "secondary: every rank renders the SAME frame (seed 1234) - exactly the same work per GPU; the headline's ranks "
                     "render distinct frames"}
     final_feats = None
-    if world > 1:
+    if multi:
         final_feats = step()["fine"]["global"]["integrated_features"]
         drain()
     result["feature_gather"] = feature_gather_leg(final_feats, dist, world, rank, dev)
@@ -921,7 +929,7 @@ def main():
         result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

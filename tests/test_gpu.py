@@ -1992,6 +1992,29 @@ def test_bench_self_launches_two_ranks():
     assert len(result["library_sha256"]) == 64
 
 
+def test_bench_collectives_through_rccl_with_one_rank():
+    """PR_BENCH_FORCE_DIST=1: bench.py initialises the process group with backend "nccl" (= RCCL) for its single rank and runs
+    every collective of the multi-rank legs (barriers, the max over ranks, all_gather_into_tensor and gather of the feature
+    map, the identical-frame secondary) - the code path of `--gpus 8`, which only the driver can run with 8 devices."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--image", "64",
+                           "--no-cpu-baseline", "--no-split-precision", "--no-minecraft", "--no-distinct-frames", "--no-shard-balance"],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    result = json.loads([line for line in proc.stdout.splitlines() if line.startswith("{")][-1])
+    assert result["distributed"]["backend"] == "nccl" and result["distributed"]["world_size"] == 1
+    assert result["distributed"]["nccl_version"][0].isdigit(), result["distributed"]
+    assert result["feature_gather"]["all_gather"]["ms"] > 0 and result["feature_gather"]["gather_dst0"]["ms"] > 0
+    assert result["identical_frames"]["value"] > 0 and result["train_step"]["value"] > 0
+    assert result["train_step_with_decoder"]["maps_route"]["ms_per_step"] > 0
+
+
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_psnr_against_oracle_headline_config(precision):
     """BASELINE.json's "PSNR vs reference": the reference's formula (evaluation/metrics/psnr.py:10-34,
