@@ -457,7 +457,8 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
                 loss = (image - target).square().mean()
             main.wait_stream(side)
             loss.backward()
-            parallel.allreduce_gradients(render_params + decoder_params)
+            parallel.allreduce_gradients(render_params)         # (the renderer's gradients are one flat buffer: one collective)
+            parallel.allreduce_gradients(decoder_params)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 opt_decoder.step()
