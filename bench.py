@@ -232,6 +232,23 @@ def max_over_ranks(value, dist, dev):
     return float(t.item())
 
 
+def train_traffic():
+    """HBM bytes per training step from the committed PMC passes of tools/collect_pmc_train.sh (all library kernels of a step, and
+    the three largest), with the library stamp they were collected from."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_train_summary.json")
+    if not os.path.exists(path):
+        return {"traffic": None}
+    with open(path) as f:
+        pmc = json.load(f)
+    big = {k.split("::")[1]: int(v["hbm_MB"] * 1e6) for k, v in list(pmc["per_step"].items())[:3]}
+    return {"traffic": int(pmc["hbm_MB_per_step_all_library_kernels"] * 1e6),
+            "traffic_unit": "HBM bytes per training step, all library kernels (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of "
+                            "tools/collect_pmc_train.sh, profiles/r03_pmc_train_summary.json): ~1.4 TB/s over the step - the step is bound "
+                            "by the matrix pipes, not by HBM",
+            "traffic_largest_kernels": big,
+            "traffic_from_this_library": pmc.get("library_sha256") == library_sha256()}
+
+
 def train_step_leg(args, dev, world, rank, dist, lib):
     """Secondary figure (never the headline): one data-parallel training step of the renderer in the shape of
     BASELINE.json configs[4] / SURVEY.md C5 - minecraft, 3 frames per GPU, one 48x48 patch at strides [4, 8] per frame
@@ -348,6 +365,7 @@ def train_step_leg(args, dev, world, rank, dist, lib):
             "flop_per_step": 3.0 * fwd_flops,
             "definition": "3 x forward matmul FLOPs of the evaluated samples (forward + dX + dW) / whole step time "
                           "(incl. compositing, BatchNorm passes, optimiser)",
+            **train_traffic(),
             "evaluated_samples_per_step": [round(c, 1) for c in counts],
             "kernel_ms_per_step": {"forward_mlp": per(0), "forward_composite": per(1), "backward_dx_gemm": per(2),
                                    "backward_dw_gemm": per(3), "backward_composite": per(4)},

@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 bash tools/collect_pmc.sh > "$OUT/${R}_pmc.log" 2>&1
 cp gpurun_out/pmc_summary.json "$OUT/${R}_pmc_summary.json"
 mkdir -p profiles && cp "$OUT/${R}_pmc_summary.json" profiles/${R}_pmc_summary.json      # the bench line below reads it
+bash tools/collect_pmc_train.sh > "$OUT/${R}_pmc_train.log" 2>&1
+cp gpurun_out/pmc_train_summary.json "$OUT/${R}_pmc_train_summary.json"
+cp "$OUT/${R}_pmc_train_summary.json" profiles/${R}_pmc_train_summary.json
 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.err"
 cd /tmp
 rm -rf /tmp/hl /tmp/tr
