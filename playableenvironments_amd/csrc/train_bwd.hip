@@ -375,10 +375,36 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
             load_bn_backward(S, p.d_in, p.h_in, p.kpad, tile_base, rows_valid);
         }
         __syncthreads();
+        // the raw activations the epilogue needs (this lane's column, its 32 rows per column block) are REQUESTED before the
+        // product and arrive while it runs: loaded inside the epilogue, four at a time, their latency was the tile's critical path
+        // (31 TFLOP/s for the two head phases)
+        const unsigned long long mine = __ballot((S.flags[lane] & 3) == 3) >> (4 * half);   // bit ro <-> tile row ro + 4 half
+        auto prefetch = [&](int blk, float (&hv)[32]) {
+            const int cb = wave + blk * MLP_WAVES;
+            const bool live = cb < p.nblk && live_col[blk];
+            const float* hb = p.h + (size_t)(tile_base + 4 * half) * p.ld + cb * 32 + r;
+            const int ld = p.ld;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int ro = PR_ACC_ROW(i & 15) + 32 * (i >> 4);
+                hv[i] = (live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.f;
+            }
+        };
+        float hvA[32], hvB[32];
+#ifndef PR_HEAD_NO_PREFETCH
+        prefetch(0, hvA);
+#endif
         f32x16 a00, a01, a10, a11;
         zero4(a00, a01, a10, a11);
         tile_products(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+#ifndef PR_HEAD_NO_PREFETCH
+        prefetch(1, hvB);
+#endif
         __syncthreads();      // every wave has finished reading X
+#ifdef PR_HEAD_NO_PREFETCH
+        prefetch(0, hvA);
+        prefetch(1, hvB);
+#endif
         // ---- AdaIN + ReLU backward, normalisation backward up to the batch terms -------------------------
         //   y = h g[frame] + b[frame] (g = scale rstd), a = relu(y);  dy = (y > 0) d a;  d scale += dy xh, d bias += dy;
         //   d xh = dy scale;  the batch terms mean(d xh), mean(d xh xh) are applied by the next phase
@@ -389,8 +415,6 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 flush_frame_sums(cs, p.dscale, p.dbias, p.nblk, p.width);
                 cs.frame = frame0;
             }
-            // rows of this lane that entered the statistics: bit ro of `mine` <-> tile row ro + 4 half
-            const unsigned long long mine = __ballot((S.flags[lane] & 3) == 3) >> (4 * half);
             const float* tab = p.table + (size_t)frame0 * p.table_stride;
             const int limit = rows_valid - 4 * half;
 #pragma unroll
@@ -400,49 +424,34 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 const int col = cb * 32 + r;
                 const f32x16& lo = blk ? a10 : a00;
                 const f32x16& hi = blk ? a11 : a01;
+                const float (&hv)[32] = blk ? hvB : hvA;
                 const bool live = live_col[blk];
                 const float g = live ? tab[p.goff + col] : 0.f, b = live ? tab[p.boff + col] : 0.f;
                 const float scale = live ? g / rstd[blk] : 0.f;
                 // one base pointer per lane; the row offsets are wave-uniform multiples of the leading dimension
-                const float* hb = p.h + (size_t)(tile_base + 4 * half) * p.ld + col;
                 float* ab = p.a_out + (size_t)(tile_base + 4 * half) * p.ld + col;
                 float* xb = S.X + (4 * half) * LDX + col;
                 const int ld = p.ld;
                 double s1 = 0.0, s2 = 0.0;
                 float ds = 0.f, db = 0.f;
-                // four rows at a time (loads, arithmetic, stores), fenced: unrolled as a whole the loads of a block are
-                // hoisted together and the kernel spills
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
-                        float hv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int ro = PR_ACC_ROW(4 * ch + q) + 32 * rb;
-                            hv[q] = (live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.f;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int ro = PR_ACC_ROW(4 * ch + q) + 32 * rb;
-                            const float acc = rb ? hi[4 * ch + q] : lo[4 * ch + q];
-                            float a = 0.f, dxh = 0.f;
-                            if (live && ((mine >> ro) & 1ull)) {
-                                const float y = fmaf(hv[q], g, b);
-                                a = y > 0.f ? y : 0.f;
-                                const float dy = y > 0.f ? acc : 0.f;
-                                const float xh = (hv[q] - mu[blk]) * rstd[blk];
-                                dxh = dy * scale;
-                                s1 += (double)dxh;
-                                s2 += (double)dxh * (double)xh;
-                                ds = fmaf(dy, xh, ds);
-                                db += dy;
-                            }
-                            xb[ro * LDX] = dxh;
-                            if (ro < limit) ab[ro * ld] = a;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 32; ++i) {
+                    const int ro = PR_ACC_ROW(i & 15) + 32 * (i >> 4);
+                    const float acc = (i >> 4) ? hi[i & 15] : lo[i & 15];
+                    float a = 0.f, dxh = 0.f;
+                    if (live && ((mine >> ro) & 1ull)) {
+                        const float y = fmaf(hv[i], g, b);
+                        a = y > 0.f ? y : 0.f;
+                        const float dy = y > 0.f ? acc : 0.f;
+                        const float xh = (hv[i] - mu[blk]) * rstd[blk];
+                        dxh = dy * scale;
+                        s1 += (double)dxh;
+                        s2 += (double)dxh * (double)xh;
+                        ds = fmaf(dy, xh, ds);
+                        db += dy;
                     }
+                    xb[ro * LDX] = dxh;
+                    if (ro < limit) ab[ro * ld] = a;
                 }
                 // the two halves of the wave hold the same column: combine
                 s1 += __shfl_xor(s1, 32, 64);
