@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import warnings
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -302,6 +302,12 @@ class ObjectComposer(nn.Module):
         #: the device.
         self.batchnorm_check = "eager"
         self._pending_bn_check: Optional[tuple] = None
+        #: Extension for evaluation renders whose consumer reads the merged ("global") entry only (the evaluators, play.py, the
+        #: decoder): ``None`` (default) = the reference's result schema, every field of every ``object_k`` entry;  a tuple of field
+        #: names = only those fields are computed and returned for the per-object entries (``()``: none - the entries then hold
+        #: ``extra_outputs`` only).  On a shipped 256x256 tennis frame the per-object maps are 4/5 of the compositing kernel's
+        #: 344 MB of output.  Ignored (everything is produced) by differentiable / training calls.
+        self.object_entry_fields: Optional[Tuple[str, ...]] = None
 
     def _raise_pending_batchnorm_check(self):
         if torch.cuda.is_current_stream_capturing():
@@ -684,6 +690,12 @@ class ObjectComposer(nn.Module):
 
         # ---- noise -----------------------------------------------------------------------------
         types = ["coarse"] + (["fine"] if use_fine else [])
+        object_fields = None
+        if self.object_entry_fields is not None and not _save and not self.training:
+            object_fields = tuple(self.object_entry_fields)
+            unknown = [f for f in object_fields if f not in ENTRY_KEYS]
+            if unknown:
+                raise ValueError(f"object_entry_fields: unknown field(s) {unknown}; the fields are {ENTRY_KEYS}")
         ptot = {"coarse": pc, "fine": [a + b for a, b in zip(pc, pf)]}
         noise: Dict[str, torch.Tensor] = {}
         if self.noise_source not in ("device", "torch"):
@@ -835,17 +847,11 @@ class ObjectComposer(nn.Module):
                 res = {}
                 for k in range(K + 1):
                     P = ptot[ty][k] if k < K else sum(ptot[ty])
-                    e = {
-                        "integrated_features": torch.empty((N, rc, F), **f32),
-                        "opacity": torch.empty((N, rc), **f32),
-                        "weights": torch.empty((N, rc, P), **f32),
-                        "depth": torch.empty((N, rc), **f32),
-                        "disparity": torch.empty((N, rc), **f32),
-                        "integrated_displacements_magnitude": torch.empty((N, rc), **f32),
-                        "integrated_divergence": torch.empty((N, rc), **f32),
-                    }
+                    shapes = {"integrated_features": (N, rc, F), "weights": (N, rc, P)}
+                    wanted = ENTRY_KEYS if (k == K or object_fields is None) else object_fields
+                    e = {name: torch.empty(shapes.get(name, (N, rc)), **f32) for name in ENTRY_KEYS if name in wanted}
                     entry = o.object[k] if k < K else o.global_
-                    for name in ENTRY_KEYS:
+                    for name in e:       # (fields that are not wanted stay NULL: the compositing kernel skips them)
                         setattr(entry, name, e[name].data_ptr())
                     res[f"object_{k}" if k < K else "global"] = e
                 if layout is not None:
@@ -919,6 +925,8 @@ class ObjectComposer(nn.Module):
             for name in [f"object_{k}" for k in range(K)] + ["global"]:
                 entry = {}
                 for key in ENTRY_KEYS:
+                    if key not in pieces[0][ty][name]:
+                        continue         # (object_entry_fields: a per-object field nobody asked for)
                     parts = [p[ty][name][key] for p in pieces]
                     t = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
                     entry[key] = t.reshape(lead + list(t.shape[1:]))

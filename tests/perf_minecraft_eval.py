@@ -15,6 +15,8 @@ for precision in ("fp32", "f16x3"):
     synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
     model.eval().cuda()
     model.object_composer.precision = precision
+    if os.environ.get("PR_GLOBAL_ONLY"):          # the evaluation extension: no per-object maps
+        model.object_composer.object_entry_fields = ()
     size = (256, 256)
     scene = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in (synthetic.minecraft_scene if world == "minecraft" else synthetic.tennis_scene)(seed=1234, image_size=size).items()}
 

@@ -2471,3 +2471,31 @@ def test_randomized_sweep_slice(sweep, cases, capsys):
     report = capsys.readouterr().out
     assert failures == 0, report[-4000:]
     assert report.count("ok case") + report.count("ill-conditioned") + report.count("skipped") == cases, report[-2000:]
+
+
+def test_object_entry_fields_extension():
+    """``ObjectComposer.object_entry_fields`` (evaluation extension): the per-object entries carry the requested fields only, the
+    global entry and the requested fields are bit-identical to the full render; differentiable calls ignore the switch."""
+    cfg = configs.tennis_config(hierarchical=(16, 32))
+    comp = build(cfg, alpha_bias=2.0).cuda().eval()
+    inputs = [v.cuda() for v in composer_inputs(cfg, synthetic.tennis_scene(seed=5), pixels=grid_pixels(256, 256, 24))]
+    with torch.no_grad():
+        full = comp(*inputs, False)
+        comp.object_entry_fields = ("opacity", "depth")
+        some = comp(*inputs, False)
+        comp.object_entry_fields = ()
+        none = comp(*inputs, False)
+    for ty in ("coarse", "fine"):
+        for key, value in full[ty]["global"].items():
+            assert torch.equal(torch.nan_to_num(value), torch.nan_to_num(some[ty]["global"][key])), (ty, key)
+            assert torch.equal(torch.nan_to_num(value), torch.nan_to_num(none[ty]["global"][key])), (ty, key)
+        for k in range(4):
+            assert set(some[ty][f"object_{k}"]) == {"opacity", "depth", "extra_outputs"}
+            assert set(none[ty][f"object_{k}"]) == {"extra_outputs"}
+            for key in ("opacity", "depth"):
+                assert torch.equal(full[ty][f"object_{k}"][key], some[ty][f"object_{k}"][key]), (ty, k, key)
+    out = comp(*inputs, False)            # gradients enabled: a differentiable call keeps the full schema
+    assert "integrated_features" in out["coarse"]["object_0"] and out["coarse"]["global"]["integrated_features"].requires_grad
+    comp.object_entry_fields = ("colour",)
+    with torch.no_grad(), pytest.raises(ValueError, match="unknown field"):
+        comp(*inputs, False)
