@@ -1907,7 +1907,7 @@ def test_render_sharded_and_async_gather_rccl_world1():
         model, args = _tennis_model_and_args(batch=2)
         with torch.no_grad():
             whole = model(*args, 0, False, mode="scene_encodings")
-        for shard in ("frames", "rays", "auto"):
+        for shard in ("frames", "rays", "tiles", "auto"):
             out = model.render_sharded(*args, False, shard=shard)
             assert torch.equal(out["coarse"]["global"]["integrated_features"], whole["coarse"]["global"]["integrated_features"])
         feats = whole["coarse"]["global"]["integrated_features"]
@@ -1936,7 +1936,7 @@ def _two_rank_worker(rank, port, results):
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         ok = True
-        for batch, shard in ((3, "frames"), (1, "rays"), (2, "auto")):
+        for batch, shard in ((3, "frames"), (1, "rays"), (2, "auto"), (1, "tiles"), (1, "auto"), (2, "tiles")):
             model, args = _tennis_model_and_args(batch=batch)
             with torch.no_grad():
                 whole = model(*args, 0, False, patch_stride=[4, 8], mode="scene_encodings")
@@ -1949,8 +1949,9 @@ def _two_rank_worker(rank, port, results):
 
 
 def test_render_sharded_two_ranks_on_one_gpu_gloo():
-    """Two ranks (gloo) sharing the box's GPU: frame shards (3 frames over 2 ranks), ray shards of a single frame - the HIP
-    renderer's assembled feature maps equal the unsharded render bit for bit on both ranks."""
+    """Two ranks (gloo) sharing the box's GPU: frame shards (3 frames over 2 ranks), contiguous ray shards and 8 x 8-pixel tiles
+    dealt round robin (a single frame's default) - the HIP renderer's assembled feature maps equal the unsharded render bit for
+    bit on both ranks."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     results = ctx.Manager().dict()
