@@ -510,6 +510,42 @@ def test_tile_shard_lists_partition_the_pixel_list():
     assert sizes == [8192] * 8
 
 
+def test_flattened_parameters_train_like_separate_ones():
+    """parallel.flatten_parameters: names, values and state_dict survive, the views follow the arena (and its version counter),
+    and Adam on the arena produces bit for bit what Adam produces on the separate tensors."""
+    from playableenvironments_amd import parallel
+
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3), torch.nn.BatchNorm1d(3))
+    a, b = make(), make()
+    b[0].bias.requires_grad_(False)
+    a[0].bias.requires_grad_(False)
+    before = {k: v.clone() for k, v in b.state_dict().items()}
+    arena = parallel.flatten_parameters(b)
+    assert arena.numel() == sum(p.numel() for p in b.parameters() if p.requires_grad)
+    assert list(b.state_dict()) == list(before) and all(torch.equal(v, before[k]) for k, v in b.state_dict().items())
+    assert [n for n, _ in a.named_parameters()] == [n for n, _ in b.named_parameters()]
+    opt_a = torch.optim.Adam([p for p in a.parameters() if p.requires_grad], lr=1e-2)
+    opt_b = torch.optim.Adam([arena], lr=1e-2)
+    x = torch.randn(16, 5)
+    for step in range(3):
+        for model, opt in ((a, opt_a), (b, opt_b)):
+            opt.zero_grad(set_to_none=True)
+            for p in model.parameters():
+                p.grad = None
+            model(x).square().mean().backward()
+            if model is b:
+                version = b[2].weight._version
+                parallel.flat_gradient(arena, b)
+            opt.step()
+        assert b[2].weight._version > version          # the views see the arena's in-place update
+        for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(p, q), (step, n)
+    b.load_state_dict(before)                          # checkpoints load into the views
+    assert torch.equal(arena.detach()[:35].view(7, 5), before["0.weight"])
+
+
 def test_shard_range_partitions():
     from playableenvironments_amd.parallel import shard_range
     for total in (0, 1, 7, 8, 65536):

@@ -2500,3 +2500,41 @@ def test_object_entry_fields_extension():
     comp.object_entry_fields = ("colour",)
     with torch.no_grad(), pytest.raises(ValueError, match="unknown field"):
         comp(*inputs, False)
+
+
+def test_parameter_arena_trains_like_separate_tensors():
+    """parallel.flatten_parameters on the HIP composer: the parameters become views of one arena, the packed-weight cache follows
+    the arena's in-place updates (shared version counter), and two SGD steps through pr_render_backward move the parameters as
+    they move with separate tensors (the kernels' atomically accumulated gradients differ by rounding from run to run)."""
+    from playableenvironments_amd import parallel
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    scene = synthetic.minecraft_scene(batch=2, seed=21)
+    inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(256, 256, 12))]
+    models = []
+    for flatten in (False, True):
+        comp = build(cfg, alpha_bias=3.0).cuda().train()
+        names = [n for n, _ in comp.named_parameters()]
+        arena = parallel.flatten_parameters(comp) if flatten else None
+        assert [n for n, _ in comp.named_parameters()] == names
+        opt = torch.optim.SGD([arena] if flatten else list(comp.parameters()), lr=1e-3)
+        losses = []
+        for step in range(3):
+            opt.zero_grad(set_to_none=True)
+            for q in comp.parameters():
+                q.grad = None
+            torch.manual_seed(100 + step)
+            out = comp(*inputs, True)
+            loss = out["coarse"]["global"]["integrated_features"].square().mean()
+            loss.backward()
+            if flatten:
+                parallel.flat_gradient(arena, comp)
+                assert arena.grad.data_ptr() == next(comp.parameters()).grad.data_ptr()      # the shared buffer, no copy
+            opt.step()
+            losses.append(float(loss))
+        models.append((comp, losses))
+    (a, la), (b, lb) = models
+    assert la[0] == lb[0] and all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
+    assert la[2] != la[0]                      # the updates reach the renderer (packed weights rebuilt)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        scale = float(p.abs().max())
+        assert float((p - q).abs().max()) <= 1e-5 * scale + 1e-8, n
