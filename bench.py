@@ -459,10 +459,13 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
     sc = to_device(synthetic.minecraft_scene(batch=3, seed=77 + rank, image_size=size), dev)
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)
+    # both parameter sets as arenas (parallel.flatten_parameters), as in train_step_leg
+    arena_render = parallel.flatten_parameters(model.object_composer)
+    arena_decoder = parallel.flatten_parameters(decoder)
     render_params = list(model.object_composer.parameters())
     decoder_params = list(decoder.parameters())
-    opt_render = torch.optim.Adam(render_params, lr=1e-5, fused=True)
-    opt_decoder = torch.optim.Adam(decoder_params, lr=1e-5, fused=True)
+    opt_render = torch.optim.Adam([arena_render], lr=1e-5, fused=True)
+    opt_decoder = torch.optim.Adam([arena_decoder], lr=1e-5, fused=True)
     g = torch.Generator().manual_seed(5)
     target = torch.rand((3, 3, 192, 192), generator=g).to(dev)
     side = torch.cuda.Stream(dev)
@@ -473,6 +476,10 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
         def step():
             opt_render.zero_grad(set_to_none=True)
             opt_decoder.zero_grad(set_to_none=True)
+            for q in render_params:
+                q.grad = None
+            for q in decoder_params:
+                q.grad = None
             out = model(*scene_args(sc, size), 2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings",
                         **({"_decoder_features": counts} if route == "maps" else {}))
             if route == "maps":
@@ -488,6 +495,8 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
             loss.backward()
             parallel.allreduce_gradients(render_params)         # (the renderer's gradients are one flat buffer: one collective)
             parallel.allreduce_gradients(decoder_params)
+            parallel.flat_gradient(arena_render, model.object_composer)
+            parallel.flat_gradient(arena_decoder, decoder)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 opt_decoder.step()
@@ -524,7 +533,10 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
 
     def decoder_only():
         opt_decoder.zero_grad(set_to_none=True)
+        for q in decoder_params:
+            q.grad = None
         (decoder(fixed) - target).square().mean().backward()
+        parallel.flat_gradient(arena_decoder, decoder)
         opt_decoder.step()
     decoder_ms, _ = timed(decoder_only)
     combined = results["maps"]["ms_per_step"]
