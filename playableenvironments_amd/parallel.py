@@ -217,15 +217,19 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
         raise ValueError("flatten_parameters: the trainable parameters must be fp32 tensors on one device")
     arena = torch.nn.Parameter(torch.cat([p.detach().reshape(-1) for _, p in named]))
     base = arena.detach()          # (shares storage and version counter with the arena)
-    offset = 0
-    for name, p in named:
+    views, offset = {}, 0
+    for _, p in named:
+        views[id(p)] = torch.nn.Parameter(base[offset:offset + p.numel()].view(p.shape), requires_grad=True)
+        offset += p.numel()
+    # every name of a parameter (a tensor registered under two names keeps one view)
+    for name, p in list(module.named_parameters(remove_duplicate=False)):
+        if id(p) not in views:
+            continue
         owner = module
         *path, attr = name.split(".")
         for part in path:
             owner = getattr(owner, part)
-        view = torch.nn.Parameter(base[offset:offset + p.numel()].view(p.shape), requires_grad=True)
-        owner._parameters[attr] = view
-        offset += p.numel()
+        owner._parameters[attr] = views[id(p)]
     for m in module.modules():     # caches derived from the old storages (ObjectComposer)
         drop = getattr(m, "_drop_device_caches", None)
         if callable(drop):
