@@ -5,6 +5,10 @@ differentiable output probed, camera-ray and divergence gradients included.)
 
 A fixed-seed slice (40 forward + 20 backward cases, seed 0) runs in the driver's suite: tests/test_gpu.py::test_randomized_sweep_slice.
 
+A backward case that exceeds the tolerance is classified before it counts as a failure: ill-conditioned (the ORACLE's own gradients
+move that much under a 1e-6 parameter perturbation), a noise kink (relu(sigma + noise) at 0 within fp32 rounding: two other noise
+realisations agree), or arbitrated in float64 (HIP no farther from the oracle's float64 autograd than 4 x the fp32 oracle).
+
 Forward fields are compared at the parity tolerance of the suite; perturbed cases replay the oracle's noise.  Cases whose
 oracle render is ill conditioned by construction (hierarchical resampling) are compared more loosely."""
 import os
@@ -15,7 +19,10 @@ import traceback
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from playableenvironments_amd import configs, synthetic  # noqa: E402
+from playableenvironments_amd import _lib, configs, synthetic  # noqa: E402
+
+if os.environ.get("PR_FUZZ_LIB"):      # a measurement / comparison build of the library (tools/build_variant.sh)
+    _lib.library_path = lambda: os.path.abspath(os.environ["PR_FUZZ_LIB"])
 from tests.helpers import compare_results, composer_inputs, grid_pixels, poison_device_memory as poison  # noqa: E402
 from tests.test_gpu import build, run_both  # noqa: E402
 
@@ -139,8 +146,30 @@ def backward_sweep(cases, rng, only=None):
             if bad:
                 worst = max(float(v[0]) / float(v[1]) for v in bad.values())
                 own = oracle_sensitivity(cfg, scene, n, bias, perturb, keys, rays)
+                def clean_with(seed):     # the same case with another realisation of the perturbation noise
+                    again = _gradients(cfg, scene, n, bias, perturb, keys=keys, rays=rays, min_divergence=0.0, absent=absent, noise_seed=seed)
+                    for k2, (a2, b2) in again.items():
+                        s2 = float(a2.abs().max())
+                        if k2 == "ray_origins":
+                            s2 = max(s2, float(again["ray_directions"][0].abs().max()))
+                        if float((a2 - b2).abs().max()) > (5e-3 if hierarchical else 5e-4) * s2 + 1e-9:
+                            return False
+                    return True
+                def arbitrated():         # the oracle's autograd in float64 as the exact result
+                    exact = _gradients(cfg, scene, n, bias, perturb, keys=keys, rays=rays, min_divergence=0.0, absent=absent, exact=True)
+                    for k2, (a2, b2, e2) in exact.items():
+                        s2 = float(e2.abs().max())
+                        if float((b2.double() - e2).abs().max()) > 4.0 * float((a2.double() - e2).abs().max()) + 1e-5 * s2:
+                            return False
+                    return True
                 if worst <= 20 * own:
                     print(f"ill-conditioned (HIP vs oracle {worst:.1e} relative; the oracle moves {own:.1e} under a 1e-6 parameter perturbation)", label[:120])
+                elif perturb and clean_with(1123) and clean_with(2123):
+                    # relu(sigma + noise) has a kink at 0: a sample whose noisy density sits there within fp32 rounding passes its
+                    # gradient on one side and not on the other (the forward value is continuous) - one realisation in ~100 cases has one
+                    print(f"noise kink (HIP vs oracle {worst:.1e} relative with this noise realisation only: two other realisations agree)", label[:120])
+                elif arbitrated():
+                    print(f"ill-conditioned (HIP vs oracle {worst:.1e} relative; in float64 arbitration the HIP gradients are no farther from the exact ones than 4 x the fp32 oracle's)", label[:120])
                 else:
                     failures += 1
                     print(f"MISMATCH (worst {worst:.1e}, oracle self-sensitivity {own:.1e})", label, dict(list(bad.items())[:4]))
@@ -204,6 +233,13 @@ def forward_sweep(cases, rng, only=None):
             bad = {k: f"{v[0]:.2e}" for k, v in rep.items() if not v[1]}
             if hierarchical:        # the weights of tied / nearly tied merged samples may swap: judged by the integrals
                 bad = {k: v for k, v in bad.items() if not k.endswith("weights")}
+            for key in [k for k in bad if k.endswith("depth")]:
+                # depth = sum w_i t_i with t up to ~60: on a nearly transparent ray alpha = 1 - exp(-sigma delta) carries the
+                # absolute error of 1 ulp(1) = 6e-8 per sample whatever exp is used, i.e. up to ~4e-6 x samples in the depth
+                ty, name, _ = key.split(".")
+                a, b = want[ty][name]["depth"].detach().cpu().float(), got[ty][name]["depth"].detach().cpu().float()
+                if torch.allclose(a, b, rtol=tol["rtol"], atol=5e-5, equal_nan=True):
+                    del bad[key]
             for key in [k for k in bad if k.endswith("disparity")]:
                 # disparity = 1 / max(eps, depth / opacity) is NaN exactly where the opacity is 0.  1 - exp(-sigma delta) rounds to 0
                 # or to 2^-24 around sigma delta = 2^-25: a ray whose only contribution sits on that boundary has opacity 0 on one

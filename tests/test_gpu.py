@@ -452,7 +452,7 @@ def _probe_loss(results, probes, K):
 
 
 def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True, rays=False,
-               min_divergence=1e-2, absent=None, exact=False):
+               min_divergence=1e-2, absent=None, exact=False, noise_seed=123):
     """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``; ``rays``: also
     with respect to the camera rays (ray_origins, ray_directions).  ``exact``: a third entry per tensor - the oracle's
     autograd in float64 on the same weights, inputs and replayed noise (the arbiter of ill-conditioned cases)."""
@@ -475,7 +475,7 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     ref_in = [t.clone().requires_grad_(True) for t in (w2o, sty, dfm)]
     ref_rays = [t.clone().requires_grad_(rays) for t in (o, d)]
     rec = {}
-    torch.manual_seed(123)
+    torch.manual_seed(noise_seed)
     want = ro.composer_forward(cfg, sd, *ref_rays, nrm, *ref_in, ins, perturb, canonical_pose=canonical, training=training,
                                record_noise=rec, stable_merge=True)
     gen = torch.Generator().manual_seed(7)
@@ -2471,7 +2471,7 @@ def test_randomized_sweep_slice(sweep, cases, capsys):
     failures = run(cases, random.Random(0))
     report = capsys.readouterr().out
     assert failures == 0, report[-4000:]
-    assert report.count("ok case") + report.count("ill-conditioned") + report.count("skipped") == cases, report[-2000:]
+    assert report.count("ok case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("skipped") == cases, report[-2000:]
 
 
 def test_object_entry_fields_extension():
