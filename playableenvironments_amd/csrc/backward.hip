@@ -2105,7 +2105,8 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         q.g_x = g_x; q.g_in6 = g_in6;
 
         // ---- weight gradients --------------------------------------------------------------------------------
-        auto add = [&](const float* dY, int ldy, int ni, const float* X, int ldx, int nj, float* dW, int ldw, float* dbias) -> int {
+        auto add = [&](const float* dY, int ldy, int ni, const float* X, int ldx, int nj, float* dW, int ldw, float* dbias,
+                       const float* side_w = nullptr, int side_ld = 0, float* side_grad = nullptr, float* side_bias = nullptr) -> int {
             if (!dW) {
                 PR_REQUIRE(!dbias, "a bias gradient buffer needs its weight gradient buffer");
                 return PR_OK;
@@ -2115,6 +2116,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
             memset(&j, 0, sizeof(j));
             j.A = dY; j.lda = ldy; j.B = X; j.ldb = ldx; j.C = dW; j.ldc = ldw; j.bias = dbias;
             j.rows = totals + k; j.ni = ni; j.nj = nj;
+            if (side_grad) { j.w = side_w; j.ldw = side_ld; j.wgrad = side_grad; j.wbias = side_bias; }
             const size_t need = tn_all_partial_floats(ni, nj, (long)cap);
             PR_REQUIRE(tn_used + need <= gp.tn_partial_floats, "backward: weight-gradient scratch exhausted");
             j.partial = tn_at + tn_used;
@@ -2126,8 +2128,14 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         PR_TRY(add(g_feat, Fs, F, a2, d.W2pad, d.W2, G.head6.weight, d.W2, G.head6.bias));
         PR_TRY(add(d2, d.W2pad, d.W2, a1, d.Wpad, d.W, G.head3.weight, d.W, nullptr));
         const float* act_last = acts + (size_t)(nb - 1) * act_stride;
-        PR_TRY(add(d1, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr));
-        if (m.kind == 0) PR_TRY(add(gsr4, 4, 1, act_last, d.Wpad, d.W, G.alpha_head.weight, d.W, G.alpha_head.bias));
+        // the density head reads the same activations as head layer 0: its (1 x W) gradient rides on that product's tiles as a
+        // weighted column sum (as a product of its own it costs two full tiles per 32 rows)
+        if (m.kind == 0 && G.head0.weight && G.alpha_head.weight) {
+            PR_TRY(add(d1, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr, gsr4, 4, G.alpha_head.weight, G.alpha_head.bias));
+        } else {
+            PR_TRY(add(d1, d.Wpad, d.W, act_last, d.Wpad, d.W, G.head0.weight, d.W, nullptr));
+            if (m.kind == 0) PR_TRY(add(gsr4, 4, 1, act_last, d.Wpad, d.W, G.alpha_head.weight, d.W, G.alpha_head.bias));
+        }
         for (int i = nb - 1; i >= 0; --i) {
             const float* dY = gstack + (size_t)i * n.g_stride;
             const int inf = m.backbone[i].in_features;

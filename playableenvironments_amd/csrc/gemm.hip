@@ -355,7 +355,7 @@ __device__ __forceinline__ int tn_all_splits(int M) {
     return s < 1 ? 1 : s;        // split 0 always exists (M == 0: zeros)
 }
 
-__device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split, float* SA, float* SB) {
+__device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split, float* SA, float* SB, float* SW) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
     const int M = *p.rows;
@@ -367,6 +367,9 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
     f32x16 acc[2][2];
     zero_acc(acc);
     float bsum = 0.f;
+    // side product (p.w): the row weights of a slab travel with it (threads 0 .. 31: one each), LDS copy SW
+    const bool side = p.w != nullptr && ti == 0;
+    float wsum = 0.f, wtot = 0.f, w0 = 0.f, w1 = 0.f;
     const int c4 = tid & 31, rr = tid >> 5;
     const bool acol = i0 + 4 * c4 < ((p.ni + 3) & ~3), bcol = j0 + 4 * c4 < ((p.nj + 3) & ~3);
     // TWO slabs of operand rows in flight in registers (32 rows x 256 columns each): a slab is requested two steps before it is
@@ -375,7 +378,8 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
     const float* __restrict__ gA = p.A + i0 + 4 * c4;
     const float* __restrict__ gB = p.B + j0 + 4 * c4;
     const size_t lda = (size_t)p.lda, ldb = (size_t)p.ldb;
-    auto fetch = [&](float4 (&ra)[4], float4 (&rb)[4], int m0) {
+    auto fetch = [&](float4 (&ra)[4], float4 (&rb)[4], float& wv, int m0) {
+        if (side && tid < GK) wv = (m0 + tid < m_end) ? p.w[(size_t)(m0 + tid) * p.ldw] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + rr + 8 * i;
@@ -384,7 +388,8 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
             rb[i] = (live && bcol) ? *reinterpret_cast<const float4*>(gB + (size_t)m * ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto stage = [&](const float4 (&ra)[4], const float4 (&rb)[4]) {
+    auto stage = [&](const float4 (&ra)[4], const float4 (&rb)[4], float wv) {
+        if (side && tid < GK) SW[tid] = wv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<float4*>(&SA[(rr + 8 * i) * GLD + 4 * c4]) = ra[i];
@@ -396,6 +401,14 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
         if (p.bias_partial && tj == 0 && tid < GT) {
 #pragma unroll
             for (int q = 0; q < GK; ++q) bsum += SA[q * GLD + tid];
+        }
+        if (side && tid >= GT) {          // (the other half of the workgroup: columns tid - GT of the X slab)
+#pragma unroll
+            for (int q = 0; q < GK; ++q) wsum = fmaf(SW[q], SB[q * GLD + tid - GT], wsum);
+            if (tid == GT && tj == 0) {
+#pragma unroll
+                for (int q = 0; q < GK; ++q) wtot += SW[q];
+            }
         }
         // two row pairs in flight: the fragments of the even / odd pairs live in their own registers and are re-loaded right after
         // their last use, a full pair before they are needed again (with one register set the LDS reads of a pair wait for the
@@ -431,23 +444,23 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
     };
     const bool prefetch = !(PR_TNALL_ABLATE & 2);
     if (m_begin < m_end) {
-        fetch(ra0, rb0, m_begin);
-        if (prefetch) fetch(ra1, rb1, m_begin + GK);
-        stage(ra0, rb0);
+        fetch(ra0, rb0, w0, m_begin);
+        if (prefetch) fetch(ra1, rb1, w1, m_begin + GK);
+        stage(ra0, rb0, w0);
     }
     __syncthreads();
     // steps in pairs: slab s is staged from set s % 2, and the set is refilled with slab s + 2 right away
     for (int m0 = m_begin; m0 < m_end; m0 += 2 * GK) {
-        if (prefetch) fetch(ra0, rb0, m0 + 2 * GK);           // (rows beyond m_end read nothing)
+        if (prefetch) fetch(ra0, rb0, w0, m0 + 2 * GK);       // (rows beyond m_end read nothing)
         step();
         __syncthreads();
         if (m0 + GK >= m_end) break;
-        if (prefetch) stage(ra1, rb1);
+        if (prefetch) stage(ra1, rb1, w1);
         __syncthreads();
-        if (prefetch) fetch(ra1, rb1, m0 + 3 * GK);
+        if (prefetch) fetch(ra1, rb1, w1, m0 + 3 * GK);
         step();
         __syncthreads();
-        if (m0 + 2 * GK < m_end && prefetch) stage(ra0, rb0);
+        if (m0 + 2 * GK < m_end && prefetch) stage(ra0, rb0, w0);
         __syncthreads();
     }
     if ((PR_TNALL_ABLATE & 1) && acc[0][0][0] != 123.456f) return;
@@ -466,6 +479,11 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
             }
         }
     if (p.bias_partial && tj == 0 && tid < GT) p.bias_partial[(size_t)split * rows_p + i0 + tid] = bsum;
+    if (side && tid >= GT) {
+        float* W = p.w_partial + (size_t)split * (ldp + 4);
+        W[j0 + tid - GT] = wsum;
+        if (tid == GT && tj == 0) W[ldp] = wtot;
+    }
 }
 
 #ifndef PR_TNALL_WGS
@@ -474,6 +492,7 @@ __device__ __forceinline__ void tn_all_tile(const TnJob& p, int tile, int split,
 __global__ __launch_bounds__(256, PR_TNALL_WGS) void k_gemm_tn_all(TnAll g) {
     __shared__ __attribute__((aligned(16))) float SA[GK * GLD];
     __shared__ __attribute__((aligned(16))) float SB[GK * GLD];
+    __shared__ float SW[GK];
     __shared__ int pair_begin[TN_ALL_MAX + 1];    // first (job, split) pair of every job
     __shared__ int claimed;
     const int tid = threadIdx.x;
@@ -505,7 +524,7 @@ __global__ __launch_bounds__(256, PR_TNALL_WGS) void k_gemm_tn_all(TnAll g) {
         const TnJob& p = g.job[job];
         const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
         if (tile >= tiles) continue;
-        tn_all_tile(p, tile, pair - pair_begin[job], SA, SB);
+        tn_all_tile(p, tile, pair - pair_begin[job], SA, SB, SW);
         __syncthreads();           // the slabs are reused by the next item
     }
 }
@@ -548,13 +567,25 @@ __global__ __launch_bounds__(256) void k_gemm_tn_all_reduce(TnAll g) {
         }
         head.bias[idx] += v;
     }
+    if (head.wgrad && idx <= head.nj) {            // idx == nj: the side product's bias term
+        if (idx == head.nj && !head.wbias) return;
+        float v = 0.f;
+        for (int q = blockIdx.y; q >= 0; q = g.job[q].chain_next) {
+            const TnJob& p = g.job[q];
+            const int active = tn_all_splits(*p.rows);
+            const size_t at = idx < head.nj ? (size_t)idx : (size_t)ldp;
+            for (int s = 0; s < active; ++s) v += p.w_partial[(size_t)s * (ldp + 4) + at];
+        }
+        if (idx < head.nj) head.wgrad[idx] += v;
+        else *head.wbias += v;
+    }
 }
 
 size_t tn_all_partial_floats(int ni, int nj, long max_rows) {
     const size_t rows_p = (size_t)((ni + GT - 1) / GT) * GT, ldp = (size_t)((nj + GT - 1) / GT) * GT;
     size_t splits = (size_t)((max_rows + TN_ALL_CHUNK - 1) / TN_ALL_CHUNK);
     if (splits < 1) splits = 1;
-    return splits * (rows_p * ldp + rows_p);
+    return splits * (rows_p * ldp + rows_p + ldp + 4);      // tiles, bias partials, side-product partials
 }
 
 // Links the jobs that accumulate into the same gradient buffer (chain_next / head) and launches the two kernels.
@@ -575,6 +606,8 @@ int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
         size_t splits = (size_t)((max_rows[q] + TN_ALL_CHUNK - 1) / TN_ALL_CHUNK);
         if (splits < 1) splits = 1;
         p.bias_partial = p.bias ? p.partial + splits * rows_p * ldp : nullptr;
+        p.w_partial = p.w ? p.partial + splits * (rows_p * ldp + rows_p) : nullptr;
+        PR_REQUIRE(!p.w || (p.wgrad && p.ldw >= 1), "gemm_tn_all: side product without a destination");
         p.chain_next = -1;
         p.head = 1;
         if ((long)p.ni * p.nj > max_elems) max_elems = (long)p.ni * p.nj;
@@ -585,7 +618,8 @@ int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
         for (int e = q - 1; e >= 0; --e)
             if (g.job[e].C == g.job[q].C) {
                 PR_REQUIRE(g.job[e].ni == g.job[q].ni && g.job[e].nj == g.job[q].nj && g.job[e].ldc == g.job[q].ldc &&
-                           g.job[e].bias == g.job[q].bias, "gemm_tn_all: jobs of one destination differ in shape");
+                           g.job[e].bias == g.job[q].bias && g.job[e].wgrad == g.job[q].wgrad && g.job[e].wbias == g.job[q].wbias,
+                           "gemm_tn_all: jobs of one destination differ in shape");
                 g.job[q].chain_next = e;
                 g.job[e].head = 0;
                 break;

@@ -581,6 +581,12 @@ struct TnJob {             // C[ni x nj] += sum_m A[m][i] B[m][j] ; bias[i] += s
     const int32_t* rows;               // device scalar: number of sample rows
     float* partial;                    // tn_all_partial_floats(ni, nj, row capacity) floats: [split][tile rows][tile cols], then the bias partials
     float* bias_partial;               // (set by the launcher)
+    // optional side product on the tiles of the first row block: wgrad[j] += sum_m w[m] B[m][j], wbias += sum_m w[m] - the
+    // gradient of a ONE-output layer that reads the same B (the density head beside head layer 0): as a product of its own it
+    // would cost two full 128 x 128 tiles per 32 rows for 256 useful multiply-adds
+    const float* w; int ldw;           // w[m * ldw]
+    float* wgrad; float* wbias;        // (nj) and (1); wbias: or NULL
+    float* w_partial;                  // (set by the launcher)
     int lda, ldb, ldc, ni, nj;
     int chain_next, head;              // (set by the launcher) jobs that share a destination: reduced together, in job order
 };
