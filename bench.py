@@ -300,10 +300,7 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
         """eager: one launch per kernel.  A random patch that misses an object leaves its BatchNorm with an EMPTY batch, which torch
         (and therefore the reference) accepts: statistics untouched, no gradient.  Only a batch of exactly one sample raises; the call
         would be repeated with a new patch and counted (never observed: a ray that meets a box brings all its samples)."""
-        opt.zero_grad(set_to_none=True)
-        if arena:
-            for q in params:
-                q.grad = None
+        opt.zero_grad(set_to_none=True)       # (arena: flat_gradient has moved the views' gradients to the arena)
         for attempt in range(20):
             try:
                 return iteration()
@@ -476,10 +473,6 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
         def step():
             opt_render.zero_grad(set_to_none=True)
             opt_decoder.zero_grad(set_to_none=True)
-            for q in render_params:
-                q.grad = None
-            for q in decoder_params:
-                q.grad = None
             out = model(*scene_args(sc, size), 2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings",
                         **({"_decoder_features": counts} if route == "maps" else {}))
             if route == "maps":
@@ -533,8 +526,6 @@ def train_step_with_decoder_leg(args, dev, world, rank, dist, renderer_only_ms):
 
     def decoder_only():
         opt_decoder.zero_grad(set_to_none=True)
-        for q in decoder_params:
-            q.grad = None
         (decoder(fixed) - target).square().mean().backward()
         parallel.flat_gradient(arena_decoder, decoder)
         opt_decoder.step()
@@ -828,7 +819,7 @@ def main():
     traffic = None
     traffic_source = traffic_stamp = None
     sha = library_sha256()
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_path) and size == (256, 256):
             with open(pmc_path) as f:

@@ -1985,7 +1985,11 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
     static thread_local PostBenderJobs pb;
     static thread_local StyleBwdJobs sj;
     static thread_local GeometryBwdJobs gj;
-    constexpr int MAX_TN_JOBS_CALL = PR_MAX_OBJECTS * 24;     // 13 products per NeRF + 8 per ray bender
+    // products per object: backbone layers + the skip layer's second product + density head + three feature-head layers, and the
+    // same for the ray bender (layers + skip + output head); four launches of TN_ALL_MAX products have claim counters (make_bwd_plan)
+    constexpr int TN_LAUNCHES_MAX = 4;
+    constexpr int MAX_TN_JOBS_CALL = TN_LAUNCHES_MAX * TN_ALL_MAX;
+    static_assert(PR_MAX_OBJECTS * (2 * PR_MAX_LAYERS + 8) <= MAX_TN_JOBS_CALL, "weight-gradient job table smaller than the ABI's largest call");
     static thread_local TnJob tn_jobs[MAX_TN_JOBS_CALL];
     static thread_local TnAll tn;
     long rows[PR_MAX_OBJECTS], rows_b[PR_MAX_OBJECTS], tn_rows[MAX_TN_JOBS_CALL];

@@ -23,7 +23,7 @@ SCENE_KEYS = ("camera_rotations", "camera_translations", "focals", "object_rotat
 #: ROCm 7.0.2, HIP runtime with AQL packet capture (its default): replays of a recorded TRAINING step go wrong once the host has
 #: synchronised between them - the graph's memset nodes stop executing (torch's multi-block reductions, ``x.mean()`` /
 #: ``x.sum()``, zero their semaphores with one: the loss freezes, accumulators keep stale values, gradients explode).  Measured
-#: with tests/perf_train_graph.py; neither one replay in flight at a time nor waiting on events avoids it.  With the capture
+#: with tools/perf/perf_train_graph.py; neither one replay in flight at a time nor waiting on events avoids it.  With the capture
 #: path off the replays are correct (tests/graph_step_check.py) - and cost what eager launches cost on the device side, so
 #: what a recording buys is HOST time.  The switch has to be in the environment before the process makes its first HIP call.
 GRAPH_RUNTIME_SWITCH = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
@@ -111,7 +111,17 @@ class GraphedStep:
     pass regenerates exactly its own forward pass's noise.  The pixel samplers draw on the device too (ray_sampling.py).
 
     Requirements on ``step_fn``: fixed shapes; no host synchronisation (``.item()``, ``.cpu()``); an optimiser built with
-    ``capturable=True``; ``optimizer.zero_grad(set_to_none=True)`` inside it (gradients then live in the graph's pool).
+    ``capturable=True``; ``optimizer.zero_grad(set_to_none=True)`` inside it (gradients then live in the graph's pool; with a
+    parameter arena, ``parallel.flat_gradient`` between ``backward()`` and ``step()`` hands the views' gradients to the arena and
+    clears them, so that the arena's ``zero_grad`` is enough).
+
+    Two things a replay cannot see, handled through ``modules`` (the modules whose ``ObjectComposer`` s the step renders with):
+    (1) replays update the parameters ON THE DEVICE, the Python version counters of the tensors do not move - after every
+    replay the composers forget their packed weight copies (``ObjectComposer.after_graph_replay``), so that an eager
+    evaluation / validation render between replays packs the current weights; (2) the ray benders' annealing weights are
+    computed on the host from ``set_step`` and baked into the recorded kernel arguments - ``replay()`` raises as soon as a
+    composer's ``set_step`` has moved them away from the recorded values (while the annealing schedule is still running,
+    i.e. step < num_steps: record again; afterwards the weights are constant and ``set_step`` is harmless).
     A recorded training call cannot raise from its replays: the BatchNorm sample-count check of ``ObjectComposer`` is left
     to the caller (``ObjectComposer.last_normalised_samples``).  Whatever ``step_fn`` returns is returned by ``replay()``
     as the same (static) tensors, overwritten by the next replay.
@@ -120,7 +130,11 @@ class GraphedStep:
     >>> step = GraphedStep(lambda: train_iteration(batch_arena, model, opt))
     >>> for batch in loader: batch_arena.copy_from(batch); loss = step.replay()"""
 
-    def __init__(self, step_fn, warmup: int = 3, device=None):
+    def __init__(self, step_fn, warmup: int = 3, device=None, modules=()):
+        from .object_composer import ObjectComposer
+        self.composers = []
+        for module in ([modules] if isinstance(modules, torch.nn.Module) else list(modules)):
+            self.composers.extend(m for m in module.modules() if isinstance(m, ObjectComposer) and m not in self.composers)
         if not graph_runtime_is_safe():
             raise RuntimeError(f"GraphedStep needs {GRAPH_RUNTIME_SWITCH[0]}={GRAPH_RUNTIME_SWITCH[1]} in the environment before the first HIP "
                                "call of the process: with the runtime's AQL packet capture, replays of a recorded training step "
@@ -137,8 +151,17 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.outputs = step_fn()
         self.replays = 0
+        self._annealing = [c.annealing_fingerprint() for c in self.composers]
+        for c in self.composers:
+            c.after_graph_replay()         # (the capture itself left packed copies keyed on counters the replays will not move)
 
     def replay(self):
+        for c, recorded in zip(self.composers, self._annealing):
+            if c.annealing_fingerprint() != recorded:
+                raise RuntimeError("the ray benders' annealing weights changed since the step was recorded (set_step / load_state_dict): "
+                                   "they are kernel arguments of the recorded launches - record the step again")
         self.graph.replay()
         self.replays += 1
+        for c in self.composers:
+            c.after_graph_replay()
         return self.outputs

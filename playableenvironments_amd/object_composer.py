@@ -19,6 +19,20 @@ import torch.nn as nn
 from . import _lib
 from .modules import OBJECT_MODEL_CLASSES, RayBendingStyleNerfModel
 
+#: bumped whenever ANY module registers a parameter, buffer or submodule (``module.weight = nn.Parameter(...)``,
+#: ``load_state_dict(assign=True)``, a replaced BatchNorm buffer ...): the composer's cached parameter lists and model structs hold
+#: Python objects and raw pointers, so they are rebuilt when the module tree may have changed under them
+_REGISTRATION_EPOCH = [0]
+
+
+def _bump_registration_epoch(*_args):
+    _REGISTRATION_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
+
 ENTRY_KEYS = ("integrated_features", "opacity", "weights", "depth", "disparity",
               "integrated_displacements_magnitude", "integrated_divergence")
 
@@ -268,8 +282,10 @@ class ObjectComposer(nn.Module):
         self._packed: Dict[tuple, tuple] = {}
         self._param_lists: Dict[int, list] = {}      # id(module) -> list(module.parameters())
         self._structs: Dict[tuple, tuple] = {}       # (id(model), positions) -> (key, pr_object_model_t)
+        self._registration_epoch = _REGISTRATION_EPOCH[0]
         self._budget_ok = 0                          # largest workspace size a device query has granted
         self._annealing: Dict[int, tuple] = {}
+        self._host_step: Optional[int] = 0          # the step last given to set_step (None: the buffers were loaded / moved)
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
@@ -344,19 +360,55 @@ class ObjectComposer(nn.Module):
         for m in self.object_models_fine:
             if m is not None:
                 m.set_step(current_step)
-        # set_step allocates a fresh buffer tensor every time: its (address, version) cannot identify the step
+        # (the step buffers are filled in place: their version counters move, which the host copies of the octave weights key on;
+        # dropping them here as well costs one small read-back at the next render and keeps the rule simple)
         self._annealing.clear()
+        self._host_step = int(current_step)
+        self.state_epoch += 1
+
+    def annealing_fingerprint(self):
+        """The ray benders' octave weights as a function of the step last handed to ``set_step``, computed on the host (no device
+        read): what a recorded call baked into its kernel arguments (``pr_object_model_t.bender_octave_weights``).  ``None`` when
+        the step buffers were last written by something else (``load_state_dict``, ``.to()``)."""
+        if self._host_step is None:
+            return None
+        out = []
+        for m in list(self.object_models_coarse) + [m for m in self.object_models_fine if m is not None]:
+            if m.ray_bender.has_weights:
+                enc = m.ray_bender.positional_encoder
+                alpha = self._host_step * enc.octaves_count / enc.num_steps
+                out.append(tuple((1 - math.cos(math.pi * min(1.0, max(0.0, alpha - k)))) / 2 for k in range(enc.octaves_count)))
+        return tuple(out)
+
+    def after_graph_replay(self):
+        """A replayed HIP graph (frame_graph.GraphedStep) updates parameter storages on the device without moving the Python
+        version counters the packed-weight cache keys on: forget the packed copies, so that the next eager render packs the
+        weights it finds (the graph's own packed buffers live in its memory pool and are re-filled by every replay)."""
+        self._packed.clear()
         self.state_epoch += 1
 
     def _parameter_list(self, module=None) -> list:
         """``list(module.parameters())`` (module = None: the composer), cached: walking the module tree costs ~0.3 ms per call and
         a training step asks five times.  Dropped with the other storage-derived caches (``_apply``, ``load_state_dict``)."""
+        if self._registration_epoch != _REGISTRATION_EPOCH[0]:
+            # some module (re-)registered a parameter / buffer / submodule since the lists were built: they may hold replaced objects
+            self._registration_epoch = _REGISTRATION_EPOCH[0]
+            self._param_lists.clear()
+            self._structs.clear()
         key = id(self if module is None else module)
         cached = self._param_lists.get(key)
         if cached is None:
             cached = list((self if module is None else module).parameters())
             self._param_lists[key] = cached
         return cached
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle (EMA helpers, swa_utils.AveragedModel): the caches hold ctypes structures with raw pointers
+        # (not picklable) and device scratch that a copy must not share
+        state = dict(self.__dict__)
+        state.update(_packed={}, _param_lists={}, _structs={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
+                     _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None, _host_step=None)
+        return state
 
     def _drop_device_caches(self):
         """Everything derived from parameter / buffer storages or tied to a device."""
@@ -365,6 +417,7 @@ class ObjectComposer(nn.Module):
         self._budget_ok = 0
         self._packed.clear()
         self._annealing.clear()
+        self._host_step = None
         self._linspace.clear()
         self._workspace = None
         self.state_epoch += 1
@@ -382,11 +435,12 @@ class ObjectComposer(nn.Module):
     # ------------------------------------------------------------------ marshalling
     def _model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
         """The model's pr_object_model_t (raw parameter / buffer pointers, shapes, octave weights), cached per (model, positions):
-        rebuilt when the storages may have moved (state_epoch), the annealing step changed, or the first / last parameter is
-        not where it was (a re-assigned ``nn.Parameter``)."""
+        rebuilt when the storages may have moved (state_epoch), the annealing step changed, a parameter's storage is not where it
+        was (``p.data = ...``), or any module re-registered a parameter / buffer since (``_parameter_list`` drops the structs then:
+        ``module.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``, replaced BatchNorm buffers)."""
         params = self._parameter_list(model)
         step = model.ray_bender.positional_encoder.current_step if model.ray_bender.has_weights else None
-        key = (self.state_epoch, params[0].data_ptr(), params[-1].data_ptr(),
+        key = (self.state_epoch, tuple(p.data_ptr() for p in params),
                None if step is None else (step.data_ptr(), step._version))
         cached = self._structs.get((id(model), positions))
         if cached is not None and cached[0] == key:
@@ -592,7 +646,7 @@ class ObjectComposer(nn.Module):
 
     def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
                 object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False, _object_ids=None,
-                _decoder_layout=None):
+                _decoder_layout=None, _retry=False):
         """The renderer call proper.  Returns (results, state); ``state`` (only with ``_save``) keeps what
         pr_render_backward needs: the call structures, their tensors and the forward workspace.
         ``_object_ids``: render only these object instances (the tensors then carry ``len(_object_ids)`` objects);
@@ -837,7 +891,17 @@ class ObjectComposer(nn.Module):
             else:
                 if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
                     self._workspace = None
-                    self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                    try:
+                        self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                    except torch.OutOfMemoryError:
+                        # the size was granted by an EARLIER device query (_budget_ok) and memory has become scarce since
+                        # (decoder activations, a second model): forget the grant and take the call again through a fresh query
+                        if self._budget_ok == 0 or _retry:
+                            raise
+                        self._budget_ok = 0
+                        return self._render(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
+                                            deformation, object_in_scene, perturb, canonical_pose, _noise, _export, _save,
+                                            _object_ids, _decoder_layout, _retry=True)
                 workspace = self._workspace
             rc = r1 - r0
             outs = {}

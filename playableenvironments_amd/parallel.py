@@ -205,9 +205,11 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
     becomes a view of it - same names, values, shapes, ``state_dict`` and checkpoint loading - and the arena is returned for the
     optimiser: ``torch.optim.Adam([arena], fused=True)`` updates 170 tensors of the renderer with ONE launch instead of a
     multi-tensor sweep (0.25 ms -> 0.02 ms per step on an MI355X).  Element-wise optimisers (SGD, Adam, AdamW ...) compute exactly
-    what they compute on the separate tensors.  Before ``optimizer.step()`` call ``flat_gradient(arena, module)``: the renderer's
-    backward already leaves its gradients as consecutive views of one buffer (which also travels as one all-reduce), so this
-    costs nothing.  The views share the arena's version counter, so the renderer's packed-weight cache sees every update.
+    what they compute on the separate tensors.  Between ``backward()`` and ``optimizer.step()`` call
+    ``flat_gradient(arena, module)``: the renderer's backward already leaves its gradients as consecutive views of one buffer
+    (which also travels as one all-reduce), so this costs nothing; it hands the gradient over to the arena and clears the views'
+    ``.grad``, which is what makes ``optimizer.zero_grad()`` on the arena sufficient (gradients left on the views would be
+    accumulated into by the next ``backward()``).  The views share the arena's version counter, so the renderer's packed-weight cache sees every update.
     Call it after the module sits on its device; a later ``.to()`` / ``.cuda()`` undoes the aliasing (flatten again)."""
     named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
     if not named:
@@ -239,8 +241,12 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
 
 
 def flat_gradient(arena: torch.nn.Parameter, module: torch.nn.Module) -> None:
-    """Points ``arena.grad`` at the gradients of the module's (flattened) parameters: the buffer they already share when the
-    renderer's backward produced them (no copy), else a concatenation; ``None`` gradients count as zeros."""
+    """Moves the gradients of the module's (flattened) parameters to ``arena.grad``: the buffer they already share when the
+    renderer's backward produced them (no copy), else a concatenation; ``None`` gradients count as zeros.  The arena OWNS the
+    gradient afterwards: every view's ``.grad`` is reset to ``None``, so that ``optimizer.zero_grad()`` - which only knows the
+    arena - really clears the step's gradients and the next ``backward()`` starts from nothing instead of accumulating into
+    the buffer ``arena.grad`` aliases.  Call it after ``backward()`` (and after ``allreduce_gradients``), before
+    ``optimizer.step()``."""
     params = dict(module.named_parameters())
     views = [params[n] for n in arena._flattened_names]
     if all(p.grad is None for p in views):
@@ -251,6 +257,8 @@ def flat_gradient(arena: torch.nn.Parameter, module: torch.nn.Module) -> None:
         arena.grad = shared
     else:
         arena.grad = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in views])
+    for p in views:
+        p.grad = None
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -44,7 +44,7 @@ def run(recorded: bool, perturb: bool, steps: int = 12):
     fn = step
     if recorded:
         comp.noise_seed_source = "device"
-        graph = GraphedStep(step, warmup=1)
+        graph = GraphedStep(step, warmup=1, modules=comp)
         fn = graph.replay
     else:
         step()      # the recorded run's warm-up iteration (recording itself executes nothing)
@@ -56,7 +56,36 @@ def run(recorded: bool, perturb: bool, steps: int = 12):
         if i % 5 == 4:
             torch.cuda.synchronize()
     torch.cuda.synchronize()
-    return [p.detach().clone() for p in params], [float(v) for v in torch.stack(losses)], seeds, [n for n, _ in comp.named_parameters()]
+    result = ([p.detach().clone() for p in params], [float(v) for v in torch.stack(losses)], seeds, [n for n, _ in comp.named_parameters()])
+    if recorded and not perturb:
+        # an eager evaluation render BETWEEN replays must see the weights the replays left on the device (the tensors' version
+        # counters did not move: GraphedStep drops the composer's packed copies after every replay), and the annealing weights a
+        # recorded step baked in make replay() refuse once set_step has moved them
+        def eval_render():
+            comp.eval()
+            with torch.no_grad():
+                feats = comp(o, d, n, w2o, sty.detach(), dfm, ins, False)["coarse"]["global"]["integrated_features"].clone()
+            comp.train()
+            return feats
+        first = eval_render()
+        for _ in range(3):
+            fn()
+        second = eval_render()
+        comp._drop_device_caches()
+        fresh = eval_render()
+        assert not torch.equal(first, second), "an eager render after further replays returned the stale packed weights"
+        assert torch.equal(second, fresh), "eager render between replays differs from a render with freshly packed weights"
+        comp.set_step(20000)
+        fn()                                   # same annealing weights: fine
+        comp.set_step(30000)
+        try:
+            fn()
+        except RuntimeError as e:
+            assert "annealing" in str(e)
+        else:
+            raise AssertionError("replay() accepted a step whose annealing weights differ from the recorded ones")
+        print("eager-between-replays and annealing checks ok")
+    return result
 
 
 def main():

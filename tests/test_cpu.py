@@ -531,13 +531,12 @@ def test_flattened_parameters_train_like_separate_ones():
     x = torch.randn(16, 5)
     for step in range(3):
         for model, opt in ((a, opt_a), (b, opt_b)):
-            opt.zero_grad(set_to_none=True)
-            for p in model.parameters():
-                p.grad = None
+            opt.zero_grad(set_to_none=True)       # (the documented recipe: nothing else clears the views' gradients)
             model(x).square().mean().backward()
             if model is b:
                 version = b[2].weight._version
                 parallel.flat_gradient(arena, b)
+                assert arena.grad is not None and all(p.grad is None for p in b.parameters() if p.requires_grad)
             opt.step()
         assert b[2].weight._version > version          # the views see the arena's in-place update
         for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):

@@ -2519,16 +2519,16 @@ def test_parameter_arena_trains_like_separate_tensors():
         opt = torch.optim.SGD([arena] if flatten else list(comp.parameters()), lr=1e-3)
         losses = []
         for step in range(3):
-            opt.zero_grad(set_to_none=True)
-            for q in comp.parameters():
-                q.grad = None
+            opt.zero_grad(set_to_none=True)      # (arena: the documented recipe - flat_gradient has emptied the views' gradients)
             torch.manual_seed(100 + step)
             out = comp(*inputs, True)
             loss = out["coarse"]["global"]["integrated_features"].square().mean()
             loss.backward()
             if flatten:
+                shared = next(comp.parameters()).grad.data_ptr()
                 parallel.flat_gradient(arena, comp)
-                assert arena.grad.data_ptr() == next(comp.parameters()).grad.data_ptr()      # the shared buffer, no copy
+                assert arena.grad.data_ptr() == shared                                      # the shared buffer, no copy
+                assert all(q.grad is None for q in comp.parameters())                       # ... now owned by the arena
             opt.step()
             losses.append(float(loss))
         models.append((comp, losses))

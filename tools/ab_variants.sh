@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/ab
 for v in "$@"; do
   if [ "$v" = base ]; then lib=""; else lib=build/variants/libplayrender_$v.so; fi
-  PR_PERF_LIB=$lib python tests/perf_train_leg.py 20 5 2>/dev/null | python -c "
+  PR_PERF_LIB=$lib python tools/perf/perf_train_leg.py 20 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['roofline']['kernel_ms_per_step']

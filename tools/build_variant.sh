@@ -1,6 +1,6 @@
 #!/bin/bash
 # Measurement build of the library: tools/build_variant.sh <name> "<extra compiler flags>"  ->  build/variants/libplayrender_<name>.so
-# (work-skipping switches exist at compile time only; run with PR_PERF_LIB=build/variants/libplayrender_<name>.so python tests/perf_train_leg.py)
+# (work-skipping switches exist at compile time only; run with PR_PERF_LIB=build/variants/libplayrender_<name>.so python tools/perf/perf_train_leg.py)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$ROOT/build/variants"

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/pmc_shipped
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 for world in tennis minecraft; do
-  CMD="python $ROOT/tests/perf_minecraft_eval.py $world"
+  CMD="python $ROOT/tools/perf/perf_minecraft_eval.py $world"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$world/stats" -- $CMD > "$OUT/$world.stats.log" 2>&1
   for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
     name=${pass%%:*}; counters=${pass#*:}

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/pmc_train
 rm -rf "$OUT"; mkdir -p "$OUT"
 STEPS=4; WARM=2
-CMD="python $ROOT/tests/perf_train_leg.py $STEPS $WARM"
+CMD="python $ROOT/tools/perf/perf_train_leg.py $STEPS $WARM"
 cd /tmp
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   name=${pass%%:*}; counters=${pass#*:}

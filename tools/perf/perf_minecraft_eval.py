@@ -1,0 +1,48 @@
+"""Manual measurement (GPU box): BASELINE.json configs[2] - the shipped minecraft renderer (background P=16, skybox P=1,
+two players P=32 sharing one model, overlap fix on), one 256x256 frame, eval.  ``python tools/perf/perf_minecraft_eval.py tennis``:
+the shipped tennis renderer (4 + 4 + 32 + 32 positions, configs[3]'s frame) instead."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from playableenvironments_amd import configs, synthetic
+from playableenvironments_amd.environment_model import EnvironmentModel
+
+world = sys.argv[1] if len(sys.argv) > 1 else "minecraft"
+for precision in ("fp32", "f16x3"):
+    cfg = configs.minecraft_config() if world == "minecraft" else configs.tennis_config()
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.eval().cuda()
+    model.object_composer.precision = precision
+    if os.environ.get("PR_GLOBAL_ONLY"):          # the evaluation extension: no per-object maps
+        model.object_composer.object_entry_fields = ()
+    size = (256, 256)
+    scene = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in (synthetic.minecraft_scene if world == "minecraft" else synthetic.tennis_scene)(seed=1234, image_size=size).items()}
+
+    def step():
+        with torch.no_grad():
+            return model(scene["camera_rotations"], scene["camera_translations"], scene["focals"], size, scene["object_rotation_parameters"],
+                         scene["object_translation_parameters"], scene["object_style"], scene["object_deformation"], scene["object_in_scene"],
+                         0, False, mode="scene_encodings")
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    import ctypes
+    from playableenvironments_amd import _lib
+    lib = _lib.load()
+    lib.pr_profile_enable(1)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    lib.pr_profile_enable(0)
+    ms = (ctypes.c_double * _lib.PR_PROFILE_CATEGORIES)(); ln = (ctypes.c_int32 * _lib.PR_PROFILE_CATEGORIES)()
+    lib.pr_profile_collect(ms, ln)
+    print(f"{world} kernels:", {n: (round(ms[i] / 5, 3), ln[i] // 5) for i, n in enumerate(("mlp", "composite"))})
+    print(f"{world} 256x256 eval, {precision}: {dt * 1e3:.2f} ms/frame, {65536 / dt / 1e6:.3f} Mrays/s, {1 / dt:.1f} frames/s")

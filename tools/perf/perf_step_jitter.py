@@ -1,0 +1,32 @@
+"""Manual check (GPU box): per-step wall time of the bench workload, to spot intermittent stalls (allocator, lazy loads)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from playableenvironments_amd import configs, synthetic
+from playableenvironments_amd.environment_model import EnvironmentModel
+
+cfg = configs.tennis_config(hierarchical=(64, 128))
+torch.manual_seed(0)
+model = EnvironmentModel(cfg)
+synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=0.0, bender_scale=1e4)
+model.eval().cuda()
+size = (256, 256)
+scene = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in synthetic.tennis_scene(seed=1234, image_size=size).items()}
+
+def step():
+    with torch.no_grad():
+        return model(scene["camera_rotations"], scene["camera_translations"], scene["focals"], size, scene["object_rotation_parameters"],
+                     scene["object_translation_parameters"], scene["object_style"], scene["object_deformation"], scene["object_in_scene"],
+                     0, False, mode="scene_encodings")
+
+times = []
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    times.append(((t1 - t0) * 1e3, (t2 - t0) * 1e3, torch.cuda.memory_reserved() / 2**30))
+for i, (h, w, m) in enumerate(times):
+    print(f"step {i}: host enqueue {h:7.2f} ms, wall {w:7.2f} ms, reserved {m:.2f} GiB")

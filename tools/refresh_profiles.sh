@@ -21,7 +21,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hl -- p
     --no-train-step --no-split-precision --no-distinct-frames --no-reference-graph --no-minecraft --no-shard-balance \
     > "$OUT/${R}_headline_bench.json" 2> "$OUT/${R}_headline.err"
 cp /tmp/hl/*/*_kernel_stats.csv "$OUT/${R}_headline_kernel_stats.csv"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python $ROOT/tests/perf_train_leg.py 6 3 \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python $ROOT/tools/perf/perf_train_leg.py 6 3 \
     > "$OUT/${R}_train_leg.json" 2> "$OUT/${R}_train_leg.err"
 cp /tmp/tr/*/*_kernel_stats.csv "$OUT/${R}_train_step_kernel_stats.csv"
 cd "$ROOT"

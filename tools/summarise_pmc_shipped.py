@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 root, renders = sys.argv[1], int(sys.argv[2])
-out = {"source": "tools/collect_pmc_shipped.sh (tests/perf_minecraft_eval.py <world>: fp32 then f16x3, 28 renders each)", "renders_per_precision": renders}
+out = {"source": "tools/collect_pmc_shipped.sh (tools/perf/perf_minecraft_eval.py <world>: fp32 then f16x3, 28 renders each)", "renders_per_precision": renders}
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "playableenvironments_amd", "libplayrender.so")
 if os.path.exists(lib):
     with open(lib, "rb") as f:

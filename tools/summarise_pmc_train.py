@@ -27,7 +27,7 @@ for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), 
                 continue
             per[name][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[(name, row["Counter_Name"])].add(row["Dispatch_Id"])
-out = {"source": "tools/collect_pmc_train.sh: rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python tests/perf_train_leg.py",
+out = {"source": "tools/collect_pmc_train.sh: rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python tools/perf/perf_train_leg.py",
        "training_steps_in_run": steps, "per_step": {}}
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "playableenvironments_amd", "libplayrender.so")
 if os.path.exists(lib):

@@ -1,6 +1,6 @@
-"""Summarises ONE training step out of a rocprofv3 kernel trace of bench.py's train_step leg (tests/perf_train_leg.py):
+"""Summarises ONE training step out of a rocprofv3 kernel trace of bench.py's train_step leg (tools/perf/perf_train_leg.py):
 
-    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tests/perf_train_leg.py 6 3
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python tools/perf/perf_train_leg.py 6 3
     python tools/summarise_train_trace.py <dir>/*/*_kernel_trace.csv > profiles/rNN_train_step_trace_summary.json
 
 A step starts at a coarse-placement launch (pr::k_place_coarse[_group] is the first kernel of a renderer call; one call per
