@@ -74,6 +74,11 @@ def to_device(scene, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
 
 
+def _lib_handle():
+    from playableenvironments_amd import _lib
+    return _lib.load()
+
+
 def profile_arrays():
     from playableenvironments_amd import _lib
     return (C.c_double * _lib.PR_PROFILE_CATEGORIES)(), (C.c_int32 * _lib.PR_PROFILE_CATEGORIES)()
@@ -596,6 +601,124 @@ def minecraft_leg(dev, lib, frames=20, balance=False):
     return out
 
 
+def native_eval_frame_leg(dev, lib, frames=200):
+    """The frame the reference's evaluators and play loop actually render: 288 x 512, the strided grids [4, 8] of
+    the autoencoder subclasses (72 x 128 + 36 x 64 = 11 520 rays; environment_model_backpropagated_autoencoder.py:173-236,
+    evaluation/reconstructed_dataset_creator.py:121, model/playable_environment_model.py:281-285), shipped tennis and minecraft
+    renderers, through the PLAIN drop-in calls - ``forward_from_scene_encoding(..., 0, False, 1200, patch_stride=[4, 8])`` and
+    ``forward_from_observations`` (this package's encoders in front) - eager and as a replayed ``FrameGraph``, fp32 and f16x3,
+    with and without a DecoderV6-shaped stand-in behind ``decoder_features``.  Per entry: wall ms per frame of back-to-back frames
+    (what a dataset evaluator sees), the host's issue time per frame, the device time of ONE frame with an idle queue (what the
+    play loop sees: render, show, wait for input), the HIP-event time of the MLP / compositing launches and the MLP roofline."""
+    from playableenvironments_amd import configs, synthetic
+    from playableenvironments_amd.environment_model import EnvironmentModel
+    from playableenvironments_amd.frame_graph import FrameGraph, OBSERVATION_KEYS
+    size = (288, 512)
+    strides = [4, 8]
+    out = {"workload": "288x512 frame, strided grids [4, 8] = 11 520 rays, shipped renderers, eval - the frame of the reference's "
+                       "evaluators / play loop (SURVEY.md C3)",
+           "rays": sum((size[0] // s) * (size[1] // s) for s in strides), "frames_timed": frames}
+
+    def timed(fn, n=frames, warmup=5):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        single = []
+        for _ in range(15):
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            h0 = time.perf_counter()
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            single.append((e0.elapsed_time(e1), (time.perf_counter() - h0) * 1e3))
+        return {"ms_per_frame": round((t2 - t0) / n * 1e3, 3), "host_issue_ms": round((t1 - t0) / n * 1e3, 3),
+                "one_frame_device_ms": round(median([a for a, _ in single]), 3),
+                "one_frame_latency_ms": round(median([b for _, b in single]), 3)}
+
+    for world in ("tennis", "minecraft"):
+        cfg = (configs.tennis_config if world == "tennis" else configs.minecraft_config)(encoders=True)
+        torch.manual_seed(0)
+        model = EnvironmentModel(cfg)
+        synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+        model.eval().to(dev)
+        comp = model.object_composer
+        make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+        scene = to_device(make(seed=1234, image_size=size), dev)
+        batch = to_device(synthetic.observation_batch(make(seed=1234, image_size=size)), dev)
+        decoder = StandInDecoder().to(dev).eval()
+        entry = {}
+        for precision in ("fp32", "f16x3"):
+            comp.precision = precision
+
+            def eager():
+                with torch.no_grad():
+                    return model.forward_from_scene_encoding(*scene_args(scene, size), 0, False, 1200, patch_stride=strides)
+
+            def eager_decoder():
+                with torch.no_grad():
+                    res = model.forward_from_scene_encoding(*scene_args(scene, size), 0, False, 1200, patch_stride=strides,
+                                                            _decoder_features=[64, 128])
+                    maps = res["coarse"]["global"]["decoder_features"]
+                    return decoder([m.reshape([-1] + list(m.shape[-3:])) for m in maps])
+
+            def eager_observations():
+                with torch.no_grad():
+                    return model.forward_from_observations(*[batch[k] for k in OBSERVATION_KEYS], 0, False, 1200, patch_stride=strides)
+
+            cur = {"scene_encoding_eager": timed(eager)}
+            lib.pr_profile_enable(1)
+            for _ in range(10):
+                eager()
+            torch.cuda.synchronize(dev)
+            lib.pr_profile_enable(0)
+            ms, launches = profile_arrays()
+            lib.pr_profile_collect(ms, launches)
+            cur["scene_encoding_eager"].update(mlp_ms=round(ms[0] / 10, 4), composite_ms=round(ms[1] / 10, 4))
+            if precision == "fp32":
+                with torch.no_grad():
+                    inputs = composer_call_inputs_strided(model, cfg, scene, size, strides)
+                cur["roofline"] = leg_roofline(comp, cfg, inputs, ms[0] / 10)
+            graph = FrameGraph(model, scene, size, patch_stride=strides)
+            cur["scene_encoding_frame_graph"] = timed(lambda: graph.render(scene))
+            del graph
+            cur["scene_encoding_eager_with_decoder"] = timed(eager_decoder)
+            cur["observations_eager"] = timed(eager_observations, n=max(20, frames // 4))
+            graph = FrameGraph(model, batch, mode="observations", patch_stride=strides)
+            cur["observations_frame_graph"] = timed(lambda: graph.render(batch), n=max(20, frames // 4))
+            del graph
+            entry[precision] = cur
+        comp.precision = "fp32"
+        out[world] = entry
+        del model, decoder
+    out["note"] = ("ms_per_frame = wall time of back-to-back frames / frames (no synchronisation in the loop: the evaluator's throughput); "
+                   "host_issue_ms = the Python + launch time of a call; one_frame_device_ms / one_frame_latency_ms = first launch to last "
+                   "launch / call to completion of ONE frame on an idle queue (the play loop's latency: host-paced for eager calls); "
+                   "*_frame_graph = the same frame replayed from a captured HIP graph (FrameGraph, bit-identical results); "
+                   "with_decoder = + a DecoderV6-shaped stand-in (bench.StandInDecoder) consuming decoder_features; observations_* = "
+                   "forward_from_observations with this package's CNN encoders in front (PyTorch-ROCm / MIOpen + pr_roi_pool)")
+    return out
+
+
+def composer_call_inputs_strided(model, cfg, scene_dev, size, strides):
+    """composer_call_inputs for the strided grids of a frame."""
+    from playableenvironments_amd.environment_model import camera_rays, euler_to_matrix, strided_grid_pixels
+    rows, cols = strided_grid_pixels(size[0], size[1], strides)
+    c2w = euler_to_matrix(scene_dev["camera_rotations"], scene_dev["camera_translations"])
+    o, d, n = camera_rays(c2w, scene_dev["focals"] * cfg["data"]["focal_length_multiplier"], size[0], size[1], rows, cols)
+    w2o, _ = model.compute_transformation_matrix_w2o_o2w(scene_dev["object_rotation_parameters"],
+                                                         scene_dev["object_translation_parameters"])
+    return [o, d, n, w2o, scene_dev["object_style"].unsqueeze(-3), scene_dev["object_deformation"].unsqueeze(-3),
+            scene_dev["object_in_scene"].unsqueeze(-2)]
+
+
 def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, frames=8, lib=None):
     """BASELINE.json configs[3]: a batch of 8 DISTINCT seeded frames sharded over the ranks with
     EnvironmentModel.render_sharded (parallel.shard_frames), the rendered feature maps gathered with one collective.
@@ -670,6 +793,8 @@ def main():
     ap.add_argument("--no-split-precision", action="store_true", help="skip the secondary f16x3 measurement")
     ap.add_argument("--no-train-step", action="store_true", help="skip the secondary training-step measurement")
     ap.add_argument("--no-minecraft", action="store_true", help="skip the secondary configs[2] (minecraft) measurement")
+    ap.add_argument("--no-native-frame", action="store_true", help="skip the native evaluation frame legs (288x512, strides [4, 8])")
+    ap.add_argument("--only", default=None, help="run ONE secondary leg alone and print its JSON (native_eval_frame | train_step)")
     ap.add_argument("--no-distinct-frames", action="store_true", help="skip the 8-distinct-frames legs (configs[3])")
     ap.add_argument("--no-reference-graph", action="store_true", help="skip the same-GPU PyTorch op graph measurement")
     ap.add_argument("--no-gate", action="store_true", help="disable the sigma-gated feature head (measurement)")
@@ -764,6 +889,14 @@ def main():
         gather.drain(keep=False)
 
     lib = _lib.load()
+    if args.only:
+        if args.only == "native_eval_frame":
+            print(json.dumps({"native_eval_frame": native_eval_frame_leg(dev, lib)}))
+        elif args.only == "train_step":
+            print(json.dumps({"train_step": train_step_leg(args, dev, world, rank, dist, lib)}))
+        else:
+            raise SystemExit(f"--only {args.only}: unknown leg")
+        return
 
     def timed(steps, warmup):
         """warmup untimed steps, then exactly `steps` steps between barrier + synchronize; max over ranks."""
@@ -958,6 +1091,8 @@ def main():
             "ms_per_step": separate["ms_per_step"], "ms_per_step_median": separate["ms_per_step_median"],
             "note": "the same step with torch's fused Adam on the separate parameter tensors (a multi-tensor sweep: ~0.25 ms of 38-workgroup launches)"}
         result["train_step_with_decoder"] = train_step_with_decoder_leg(args, dev, world, rank, dist, result["train_step"]["ms_per_step"])
+    if rank == 0 and world == 1 and not args.no_native_frame:
+        result["native_eval_frame"] = native_eval_frame_leg(dev, lib)
     if rank == 0 and world == 1 and not args.no_minecraft:
         result["config2_minecraft_256"] = minecraft_leg(dev, lib, balance=not args.no_shard_balance)
         if "shard_balance" in result and "shard_balance" in result["config2_minecraft_256"]:

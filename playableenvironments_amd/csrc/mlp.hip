@@ -340,7 +340,7 @@ static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const
 // (one thread per channel, the channels of a frame spread over gridDim.y workgroups; the style dot products keep their
 // left-to-right fmaf order, the weight rows are read 16 bytes at a time with eight loads in flight - as a scalar loop the
 // kernel was one L2 round trip per style feature: 30 us for 49 k multiply-adds)
-__global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) {
+__device__ __forceinline__ void adain_fold_body(const FoldParams& p) {
     const int n = blockIdx.x;
     const float* style = p.style + ((size_t)n * p.objects + p.object_index) * p.S;
     float* row = p.table + (size_t)n * p.row_floats;
@@ -394,6 +394,17 @@ __global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_adain_fold(FoldParams p) { adain_fold_body(p); }
+
+// the objects of an evaluation call in one launch (blockIdx.z = object): a fold is a few microseconds of work, so a launch per
+// object is mostly launch gaps (4 of them = 2 % of a native 11 520-ray evaluation frame)
+struct FoldGroup { FoldParams job[PR_MAX_OBJECTS]; };
+__global__ __launch_bounds__(256) void k_adain_fold_group(FoldGroup g) {
+    const FoldParams& p = g.job[blockIdx.z];
+    if ((int)blockIdx.x >= p.frames || (int)blockIdx.y * 256 >= p.Wpad + p.W2pad) return;
+    adain_fold_body(p);
+}
+
 int launch_adain_fold(const FoldParams& p, hipStream_t s) {
     PR_REQUIRE(p.affine1.weight && p.affine1.bias && p.affine4.weight && p.affine4.bias && p.bn1_mean && p.bn1_var &&
                    p.bn4_mean && p.bn4_var,
@@ -401,6 +412,26 @@ int launch_adain_fold(const FoldParams& p, hipStream_t s) {
     PR_REQUIRE(p.affine1.out_features == 2 * p.W && p.affine1.in_features == p.S, "features_head.1 affine shape");
     PR_REQUIRE(p.affine4.out_features == 2 * p.W2 && p.affine4.in_features == p.S, "features_head.4 affine shape");
     hipLaunchKernelGGL(k_adain_fold, dim3(p.frames, (p.Wpad + p.W2pad + 255) / 256), dim3(256), 0, s, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+int launch_adain_fold_group(const FoldParams* jobs, int count, hipStream_t s) {
+    PR_REQUIRE(count >= 1 && count <= PR_MAX_OBJECTS, "adain fold group: %d objects", count);
+    static thread_local FoldGroup g;
+    int frames = 0, blocks = 0;
+    for (int k = 0; k < count; ++k) {
+        const FoldParams& p = jobs[k];
+        PR_REQUIRE(p.affine1.weight && p.affine1.bias && p.affine4.weight && p.affine4.bias && p.bn1_mean && p.bn1_var &&
+                       p.bn4_mean && p.bn4_var,
+                   "AdaIN parameters missing");
+        PR_REQUIRE(p.affine1.out_features == 2 * p.W && p.affine1.in_features == p.S, "features_head.1 affine shape");
+        PR_REQUIRE(p.affine4.out_features == 2 * p.W2 && p.affine4.in_features == p.S, "features_head.4 affine shape");
+        g.job[k] = p;
+        frames = std::max(frames, p.frames);
+        blocks = std::max(blocks, (p.Wpad + p.W2pad + 255) / 256);
+    }
+    hipLaunchKernelGGL(k_adain_fold_group, dim3(frames, blocks, count), dim3(256), 0, s, g);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }
@@ -537,6 +568,15 @@ __device__ __forceinline__ void flush_column_stats(const ColumnStats& cs, const 
     }
 }
 
+#ifdef PR_MLP_TRACE
+// Measurement build (-DPR_MLP_TRACE): per workgroup of the LAST grouped evaluation launch [start, end of slot 0..3] in 100 MHz ticks
+// and the tiles it took per slot; read back with pr_debug_mlp_trace.
+__device__ unsigned long long g_mlp_trace[1024][12];
+#define PR_TRACE_MARK(i) if (threadIdx.x == 0) g_mlp_trace[blockIdx.x][i] = wall_clock64()
+#else
+#define PR_TRACE_MARK(i)
+#endif
+
 // TRAIN = false: the evaluation kernel (everything fused, optional sigma gate) - what the benchmark runs; none of the
 // training-only code (saved activations, ReLU bit images, phase 1 of the batch-statistics launches) is compiled into it.
 // TRAIN = true: phase 1 of the phased launches (train-mode BatchNorm and / or PR_FLAG_SAVE_FOR_BACKWARD).
@@ -565,9 +605,12 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     ColumnStats cstats;   // (training) batch-statistics sums of this lane's columns over the workgroup's tiles
     cstats.s1[0] = cstats.s1[1] = cstats.s2[0] = cstats.s2[1] = 0.0;
     // Tile order: the first tile of a workgroup is its block index; evaluation launches claim every further tile from a
-    // device counter (one atomic per tile, issued at the top of the previous tile and consumed after its first barrier),
-    // so that a workgroup that drew cheaper tiles (sigma-gated head) or a faster CU simply takes more of them.  S.next_tile
-    // is written after a tile's first barrier and read when the tile ends.
+    // device counter, so that a workgroup that drew cheaper tiles (sigma-gated head) or a faster CU simply takes more of them.
+    // The claim is issued LATE - behind the backbone, in front of the density head (the atomic's latency hides behind that head;
+    // what is left of the tile is the feature head, <= 20 %) - and parked in S.next_tile in front of the barriers of the feature
+    // head: a claim at the top of a tile hoards - on a launch of ~2 tiles per workgroup (the evaluators' 11 520-ray frame:
+    // 933 tiles on 512 workgroups) the first workgroups to reach an object took two of its tiles each, one after the other, while
+    // a third of the chip had nothing left to take and left after one tile (1.08 ms for 0.7 ms of balanced work).
 #ifdef PR_MLP_STATIC_TILES
     const bool dynamic_tiles = GROUP;     // measurement build: strided tile order
 #else
@@ -577,8 +620,13 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     for (int tile = GROUP ? S.next_tile : (int)blockIdx.x; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         PR_PHASE_T0();
+#ifdef PR_MLP_TRACE
+        if (GROUP && !TRAIN && tid == 0) g_mlp_trace[blockIdx.x][5 + (p.positions == 4 ? 0 : 1)] += 1;     // tiles of 4-position / other objects
+#endif
         int claimed = 0;
-        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
+#ifdef PR_MLP_EARLY_CLAIM
+        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);      // measurement build: round 3's claim at the top of the tile
+#endif
         if (tid == 0) S.uniform_frame = 1;
         // ---- load the sample records of the tile --------------------------------------------
         if (tid < TILE_M) {
@@ -609,7 +657,9 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         }
         __syncthreads();
         if (tid < TILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;   // visible after the next barrier
+#ifdef PR_MLP_EARLY_CLAIM
         if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);   // read at the end of the tile
+#endif
         PR_PHASE(0);
 
         // ---- ray bender -----------------------------------------------------------------------
@@ -684,6 +734,9 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         }
 
         PR_PHASE(15);
+#ifndef PR_MLP_EARLY_CLAIM
+        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);      // the next tile of this workgroup (see "Tile order")
+#endif
         // ---- sigma head -------------------------------------------------------------------------
         if (p.kind == 0) {
             for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
@@ -703,6 +756,9 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             }
         }
 
+#ifndef PR_MLP_EARLY_CLAIM
+        if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);   // read at the end of the tile
+#endif
         PR_PHASE(7);
         // ---- style-modulated feature head -------------------------------------------------------
         if (!TRAIN && p.gate) {
@@ -738,11 +794,23 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 // and every pointer into a flat pointer - measured: 3 % slower).
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                    int count) {
+    PR_TRACE_MARK(0);
     mlp_tile_loop<false, true>(j0);
+    PR_TRACE_MARK(1);
     if (count > 1) mlp_tile_loop<false, true>(j1);
+    PR_TRACE_MARK(2);
     if (count > 2) mlp_tile_loop<false, true>(j2);
+    PR_TRACE_MARK(3);
     if (count > 3) mlp_tile_loop<false, true>(j3);
+    PR_TRACE_MARK(4);
 }
+
+#ifdef PR_MLP_TRACE
+extern "C" int pr_debug_mlp_trace(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_trace), sizeof(unsigned long long) * 1024 * 12) == hipSuccess ? 0 : 1;
+}
+#endif
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                          int count) {
@@ -754,8 +822,11 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
 // affine built from the BATCH statistics + ReLU, run the next head matmul.
+// GROUP: `first` is this workgroup's first tile of the object and comes back advanced by the object's tile count (mod grid): the
+// objects of a launch are dealt to the workgroups as ONE round-robin sequence - strided from the block index per object, the
+// workgroups 0 .. (tiles mod grid) of EVERY object took an extra tile (a few objects of a few hundred tiles each on 512 workgroups).
 template <bool GROUP>
-__device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
+__device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
@@ -765,7 +836,12 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
     const Layer& cur = p.layers[p.n_backbone + p.phase - 1];
     ColumnStats cstats;        // phase 2: batch-statistics sums of this lane's columns over the workgroup's tiles
     cstats.s1[0] = cstats.s1[1] = cstats.s2[0] = cstats.s2[1] = 0.0;
-    for (int tile = blockIdx.x; tile * TILE_M < total; tile += gridDim.x) {
+    const int first_tile = first;
+    if (GROUP) {
+        const int tiles = (total + TILE_M - 1) / TILE_M, grid = (int)gridDim.x;
+        first = (first + grid - tiles % grid) % grid;       // the next object continues where this one's round robin stops
+    }
+    for (int tile = first_tile; tile * TILE_M < total; tile += gridDim.x) {
         const int tile_base = tile * TILE_M;
         EncRegs enc;   // this thread's share of the current network input (see fill_encoding)
         if (tid < TILE_M) {
@@ -805,14 +881,18 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p) {
     if (p.phase == 2) flush_column_stats(cstats, p, cur.nblk);
 }
 
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) { mlp_head_loop<false>(p); }
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) {
+    int first = (int)blockIdx.x;
+    mlp_head_loop<false>(p, first);
+}
 // the same phase of several objects in one launch: a workgroup takes its strided share of every object's tiles in turn
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                    int count) {
-    mlp_head_loop<true>(j0);
-    if (count > 1) mlp_head_loop<true>(j1);
-    if (count > 2) mlp_head_loop<true>(j2);
-    if (count > 3) mlp_head_loop<true>(j3);
+    int first = (int)blockIdx.x;
+    mlp_head_loop<true>(j0, first);
+    if (count > 1) mlp_head_loop<true>(j1, first);
+    if (count > 2) mlp_head_loop<true>(j2, first);
+    if (count > 3) mlp_head_loop<true>(j3, first);
 }
 
 __global__ __launch_bounds__(256) void k_bn_finalize(BnFinalizeParams p) {

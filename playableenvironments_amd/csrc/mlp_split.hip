@@ -489,8 +489,7 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
     for (int tile = GROUP ? S.next_tile : (int)blockIdx.x; tile * STILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * STILE_M;
         PR_PHASE_T0();
-        int claimed = 0;
-        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
+        int claimed = 0;      // (claimed late, behind the backbone: see "Tile order" in mlp.hip)
         if (tid == 0) S.uniform_frame = 1;
         if (tid < STILE_M) {
             const int idx = tile_base + tid;
@@ -519,7 +518,6 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         }
         __syncthreads();
         if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
-        if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);
         PR_PHASE(0);
 
         if (p.has_bender) {
@@ -559,6 +557,7 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         PR_PHASE(2);
         for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p, 0);
         PR_PHASE(15);
+        if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 
         if (p.kind == 0) {
             for (int s = tid >> 3; s < STILE_M; s += STHREADS / 8) {
@@ -578,6 +577,7 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
             }
         }
 
+        if (tid == 0) S.next_tile = GROUP ? claimed : (dynamic_tiles ? (int)gridDim.x + claimed : tile + (int)gridDim.x);   // read at the end of the tile
         PR_PHASE(7);
         if (p.gate) {
             __syncthreads();   // the liveness bits are complete

@@ -341,6 +341,7 @@ struct FoldParams {
     int row_floats;
 };
 int launch_adain_fold(const FoldParams& p, hipStream_t s);
+int launch_adain_fold_group(const FoldParams* jobs, int count, hipStream_t s);     // the objects of an evaluation call: one launch
 
 int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s);
 // evaluation launches of several objects as one

@@ -313,6 +313,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
     const bool grouped = group_active(c);
     MlpParams jobs[PR_MAX_OBJECTS];
     int job_rows[PR_MAX_OBJECTS];
+    FoldParams fold_jobs[PR_MAX_OBJECTS];
     // differentiable calls with several objects: phase 1 of every object (the whole network up to the first BatchNorm) runs as
     // one grouped launch too; what follows it per object (statistics, head phases, divergence) is deferred until after it
     const bool train_grouped = group_train_active(c);
@@ -523,11 +524,14 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
             const size_t cap = (size_t)c.frames * c.rays * P;
             const int max_tiles = (int)cap;   // rows: every launcher derives its own tile count
             if (!(c.flags & (PR_FLAG_TRAIN_BN | PR_FLAG_SAVE_FOR_BACKWARD))) {
-                PR_TRY(launch_adain_fold(fo, s));
                 if (grouped) {
-                    jobs[k] = mp;            // launched together once every object of the type is prepared
+                    fold_jobs[k] = fo;       // folded and evaluated together once every object of the type is prepared
+                    jobs[k] = mp;
                     job_rows[k] = max_tiles;
-                } else if (c.precision == PR_PRECISION_F16X3 && !naive)
+                    continue;
+                }
+                PR_TRY(launch_adain_fold(fo, s));
+                if (c.precision == PR_PRECISION_F16X3 && !naive)
                     PR_TRY(launch_mlp_split(mp, max_tiles, s));
                 else
                     PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
@@ -652,6 +656,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         }
 
         if (grouped) {
+            PR_TRY(launch_adain_fold_group(fold_jobs, K, s));
             if (c.precision == PR_PRECISION_F16X3)
                 PR_TRY(launch_mlp_split_group(jobs, job_rows, K, s));
             else

@@ -341,12 +341,10 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
     for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
-        int claimed = 0;
-        if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
+        int claimed = 0;      // (claimed late, behind the tile's product: see "Tile order" in mlp.hip)
         load_tile_records(S, p.rec_flat, p.row_flags, p.samples_per_frame, tile_base, total);
         __syncthreads();
         if (tid < TILE_M && tid < rows_valid && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
-        if (tid == 0) S.next_tile = claimed;
         // ---- the operand: the incoming gradient of the layer's output ---------------------------------
         if (p.phase == 1) {
             // feature-row gradients from the compositing backward; rows that failed the second AABB test produced zeros in
@@ -397,6 +395,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
         f32x16 a00, a01, a10, a11;
         zero4(a00, a01, a10, a11);
         tile_products(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+        if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 #ifndef PR_HEAD_NO_PREFETCH
         prefetch(1, hvB);
 #endif
@@ -509,6 +508,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 }
             }
         }
+        if (tid == 0) S.next_tile = claimed;
         __syncthreads();
         store_tile_rows(S.X, p.d_out, p.nblk * 32, p.ld, tile_base, rows_valid);
         __syncthreads();      // the next tile overwrites X and the records
@@ -576,13 +576,11 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
     for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
-        int claimed = 0;
+        int claimed = 0;      // (claimed late, in front of the chain's last layer: see "Tile order" in mlp.hip)
         PR_CT0();
-        if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
         load_tile_records(S, c.rec_flat, c.row_flags, c.samples_per_frame, tile_base, total);
         ColMasks masks = fetch_col_masks(c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, nblk, tile);
         __syncthreads();
-        if (tid == 0) S.next_tile = claimed;
         f32x16 a00, a01, a10, a11;
         if (c.entry == 1) {
             // NeRF: normalisation backward of head layer 1, . W0, + the density's path through the sigma head, ReLU mask of
@@ -663,6 +661,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 g_in_written = true;
             }
             PR_CT(6);
+            if (l == 1 && tid == 0) claimed = atomicAdd(c.tile_counter, 1);
             product(c.act_t[l], nblk);
             PR_CT(1);
             __syncthreads();
@@ -675,6 +674,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 pending = Drain{c.gstack + (size_t)(l - 1) * c.g_stride + (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad >> 2, rows_valid};
         }
         PR_CT(5);
+        if (tid == 0) S.next_tile = claimed;
         product(c.in0_first, in_nblk);
         store_global(c.g_in, c.ld_in, c.in_real, in_nblk, tile_base, rows_valid, g_in_written, a00, a01, a10, a11);
         PR_CT(7);
@@ -749,8 +749,7 @@ __device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
     for (int tile = S.next_tile; tile * TILE_M < total; tile = S.next_tile) {
         const int tile_base = tile * TILE_M;
         const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
-        int claimed = 0;
-        if (tid == 0) claimed = atomicAdd(c.tile_counter, 1);
+        int claimed = 0;      // (claimed late, in front of the chain's last layer)
         if (tid < TILE_M) {
             const bool valid = tid < rows_valid;
             const int flat = c.rec_flat[valid ? tile_base + tid : tile_base];
@@ -769,7 +768,6 @@ __device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
             *reinterpret_cast<float4*>(S.X + row * LDX + c4) = v;
         }
         __syncthreads();
-        if (tid == 0) S.next_tile = claimed;
         // t_0: element a: e_a / size_a; sin slot: 2^k cos_saved dv_a; cos slot: -2^k sin_saved dv_a; 0 beyond the encoding
         for (int idx = tid; idx < TILE_M * c.bin_pad; idx += MLP_THREADS) {
             const int row = idx / c.bin_pad, j = idx - row * c.bin_pad;
@@ -792,12 +790,14 @@ __device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
             const ColMasks masks = fetch_col_masks(c.bbits + (size_t)l * c.bbits_stride, c.BWpad, nblk, tile);
             f32x16 a00, a01, a10, a11;
             zero4(a00, a01, a10, a11);
+            if (l == c.b_count - 1 && tid == 0) claimed = atomicAdd(c.tile_counter, 1);
             tile_products(c.seg0[l], nblk, l == 0 ? S.X + T0 : S.X, a00, a01, a10, a11);
             if (l == c.b_skip) tile_products(c.seg1, nblk, S.X + T0, a00, a01, a10, a11);
             __syncthreads();
             store_masked(S, nblk, masks, a00, a01, a10, a11);
             __syncthreads();
         }
+        if (tid == 0) S.next_tile = claimed;
         // output head and the clamp cases, 8 threads per row
         for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
             const int part = tid & 7;

@@ -110,13 +110,28 @@ def _expanded_boxes(boxes: torch.Tensor, rows: float, cols: float) -> torch.Tens
     return torch.clamp(torch.stack([left, top, right, boxes[..., 3]], dim=-1), min=0.0, max=1.0)
 
 
+_CONSTANTS: Dict = {}
+
+
+def _constant(values, dtype, device) -> torch.Tensor:
+    """A small constant tensor on ``device``, uploaded ONCE per (values, dtype, device): ``torch.tensor([...], device=...)`` in a
+    forward pass is a copy from pageable host memory - it waits for the stream's queued work on every call and cannot be
+    recorded into a HIP graph.  (The cache holds a handful of 3- and 4-vectors.)"""
+    key = (tuple(float(v) for v in values), dtype, str(device))
+    cached = _CONSTANTS.get(key)
+    if cached is None:
+        cached = torch.tensor([float(v) for v in values], dtype=dtype, device=device)
+        _CONSTANTS[key] = cached
+    return cached
+
+
 def _crop_first_camera(observations: torch.Tensor, boxes: torch.Tensor, input_size, rows: float, cols: float):
     """observations (..., C, 3, H, W), boxes (..., C, 4) normalised -> crops (M, 3, h, w) of the FIRST camera (the
     reference's encoders only look at it), M = prod(...), and the leading dims."""
     obs = observations[..., :1, :, :, :]
     box = _expanded_boxes(boxes[..., :1, :], rows, cols)
     height, width = obs.size(-2), obs.size(-1)
-    scale = torch.tensor([width, height, width, height], dtype=box.dtype, device=box.device)
+    scale = _constant([width, height, width, height], box.dtype, box.device)
     lead = list(obs.shape[:-3])                      # (..., 1)
     flat_obs = obs.reshape([-1] + list(obs.shape[-3:]))
     flat_box = (box * scale).reshape(-1, 4)
@@ -232,8 +247,7 @@ def _ground_plane_feet(transformation_matrix_w2c, focals, bounding_boxes, height
     origin = c2w[..., :3, 3].unsqueeze(-1)                                               # (..., 3, 1)
     steps = -origin[..., up_axis, :] / (dirs[..., up_axis, :] + eps)                     # (..., n)
     points = origin + steps.unsqueeze(-2) * dirs
-    keep = torch.ones(3, dtype=points.dtype, device=points.device)
-    keep[up_axis] = 0.0
+    keep = _constant([0.0 if axis == up_axis else 1.0 for axis in range(3)], points.dtype, points.device)
     return points * keep.view(3, 1), dirs
 
 
@@ -341,7 +355,7 @@ class ObjectParametersEncoderV4(_CropEncoderBase):
                              bounding_boxes_validity):
         height, width = observations.size(-2), observations.size(-1)
         points, dirs = _ground_plane_feet(transformation_matrix_w2c, focals, bounding_boxes, height, width, up_axis=1)
-        flat = dirs * torch.tensor([1.0, 0.0, 1.0], dtype=dirs.dtype, device=dirs.device).view(3, 1)
+        flat = dirs * _constant([1.0, 0.0, 1.0], dirs.dtype, dirs.device).view(3, 1)
         flat = flat / torch.sqrt(flat.pow(2).sum(-2, keepdim=True))
         yaw = self.normalize_range(c2o_rotation_offset[..., 1, :], -(math.pi / 4), +(math.pi / 4))            # (..., n)
         points = points + flat * (self.edge_to_center_distance / torch.cos(yaw)).unsqueeze(-2)

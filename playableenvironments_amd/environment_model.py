@@ -604,11 +604,13 @@ class EnvironmentModel(nn.Module):
         rescaled_focals = focals * self.focal_length_multiplier
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
+        # (x * 1.0 is x bit for bit: the common case issues no launch for it)
+        render_focals = rescaled_focals if upsample_factor == 1.0 else rescaled_focals * upsample_factor
 
         c2w, w2c = pose_matrices(camera_rotations, camera_translations)
         w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
                                                               object_translation_parameters_o2w)
-        boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, rescaled_focals * upsample_factor, height, width)
+        boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, render_focals, height, width)
         axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
 
         lead = list(camera_rotations.shape[:-1])
@@ -639,7 +641,7 @@ class EnvironmentModel(nn.Module):
             rows, cols = rows.index_select(-1, _ray_range), cols.index_select(-1, _ray_range)
         elif _ray_range is not None:
             rows, cols = rows[..., _ray_range[0]:_ray_range[1]], cols[..., _ray_range[0]:_ray_range[1]]
-        origins, directions, normals = camera_rays(c2w, rescaled_focals * upsample_factor, height, width, rows, cols)
+        origins, directions, normals = camera_rays(c2w, render_focals, height, width, rows, cols)
 
         layout = None
         if _decoder_features is not None:
@@ -828,7 +830,7 @@ class EnvironmentModel(nn.Module):
         lead = list(observations.shape[:-3])
 
         c2w, w2c = pose_matrices(camera_rotations, camera_translations)
-        render_focals = rescaled_focals * upsample_factor
+        render_focals = rescaled_focals if upsample_factor == 1.0 else rescaled_focals * upsample_factor
         rot, tr = self.compute_rotation_translation_o2w(observations, w2c.detach(), camera_rotations, render_focals.detach(),
                                                         bounding_boxes, bounding_boxes_validity)
         w2o, o2w = self.compute_transformation_matrix_w2o_o2w(rot, tr)

@@ -33,29 +33,54 @@ def graph_runtime_is_safe() -> bool:
     return os.environ.get(GRAPH_RUNTIME_SWITCH[0]) == GRAPH_RUNTIME_SWITCH[1]
 
 
-class FrameGraph:
-    """Captures ``model(..., mode="scene_encodings")`` once and replays it for new scene encodings of the same shapes.
+OBSERVATION_KEYS = ("observations", "camera_rotations", "camera_translations", "focals", "bounding_boxes", "bounding_boxes_validity",
+                    "global_frame_indexes", "video_frame_indexes", "video_indexes")
 
-    >>> graph = FrameGraph(model, example_scene, image_size=(256, 256))      # model.eval(), tensors on the GPU
+
+class FrameGraph:
+    """Captures an evaluation frame once and replays it for new inputs of the same shapes.
+
+    ``mode="scene_encodings"`` (default): ``model(..., mode="scene_encodings")`` - pose math, ``pr_camera_rays``, the renderer;
+    ``scene`` holds the tensors of ``SCENE_KEYS``.  ``mode="observations"``: ``model.forward_from_observations`` - the CNN
+    encoders / pose estimators in front of it as well (what ``render_full_frame_from_observations`` of the reference's evaluators
+    runs, evaluation/reconstructed_dataset_creator.py:121); ``scene`` holds the tensors of ``OBSERVATION_KEYS`` (``Batch.to_tuple``
+    order without actions / rewards / dones).  ``patch_stride=[4, 8]`` gives the strided grids the reference's autoencoder
+    subclasses render (environment_model_backpropagated_autoencoder.py:173-236); ``decoder_features=[64, 128]`` additionally
+    emits the decoder's channels-first maps.
+
+    >>> graph = FrameGraph(model, example_scene, image_size=(288, 512), patch_stride=[4, 8])     # model.eval(), tensors on the GPU
     >>> results = graph.render(next_scene)                                   # dict of STATIC output tensors
     The result tensors are overwritten by the next ``render``; clone what must survive."""
 
-    def __init__(self, model, scene: Dict[str, torch.Tensor], image_size: Tuple[int, int], perturb: bool = False,
-                 patch_stride=0, upsample_factor: float = 1.0, canonical_pose: bool = False, warmup: int = 2):
+    def __init__(self, model, scene: Dict[str, torch.Tensor], image_size: Tuple[int, int] = None, perturb: bool = False,
+                 patch_stride=0, upsample_factor: float = 1.0, canonical_pose: bool = False, warmup: int = 2,
+                 mode: str = "scene_encodings", decoder_features=None):
         if model.training:
             raise ValueError("FrameGraph replays an evaluation render: call model.eval() first (train-mode BatchNorm updates "
                              "buffers and draws noise on every call)")
         if perturb:
             raise ValueError("perturb=True draws fresh noise on every call, which a captured graph cannot do")
+        if mode not in ("scene_encodings", "observations"):
+            raise ValueError(f"unknown mode {mode!r} (expected 'scene_encodings' or 'observations')")
         self.model = model
-        self.inputs = {k: scene[k].detach().clone() for k in SCENE_KEYS}
+        self.mode = mode
+        self.keys = SCENE_KEYS if mode == "scene_encodings" else OBSERVATION_KEYS
+        self.inputs = {k: scene[k].detach().clone() for k in self.keys}
         device = self.inputs["camera_rotations"].device
         if device.type != "cuda":
             raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
-        self._call = lambda: model(*[self.inputs[k] for k in SCENE_KEYS[:3]], image_size, *[self.inputs[k] for k in SCENE_KEYS[3:]],
-                                   0, False, patch_stride=patch_stride, upsample_factor=upsample_factor,
-                                   canonical_pose=canonical_pose, mode="scene_encodings")
-        # warm-up on a side stream (packs the weights, sizes the workspace, fills the host-side caches), then capture
+        extra = {} if decoder_features is None else {"_decoder_features": list(decoder_features)}
+        if mode == "scene_encodings":
+            if image_size is None:
+                raise ValueError("mode='scene_encodings' needs image_size")
+            self._call = lambda: model(*[self.inputs[k] for k in SCENE_KEYS[:3]], image_size, *[self.inputs[k] for k in SCENE_KEYS[3:]],
+                                       0, False, patch_stride=patch_stride, upsample_factor=upsample_factor,
+                                       canonical_pose=canonical_pose, mode="scene_encodings", **extra)
+        else:
+            self._call = lambda: model(*[self.inputs[k] for k in OBSERVATION_KEYS], 0, False, patch_stride=patch_stride,
+                                       upsample_factor=upsample_factor, canonical_pose=canonical_pose, mode="observations", **extra)
+        # warm-up on a side stream (packs the weights, sizes the workspace, fills the host-side caches, lets the convolution
+        # library pick its algorithms), then capture
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
@@ -66,8 +91,14 @@ class FrameGraph:
         self._workspace = composer._workspace      # the graph writes through this pointer: keep it alive
         self._weights_version = self._signature()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.results = self._call()
+        try:
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.results = self._call()
+        except BaseException:
+            # (a failed capture can take the process down when the half-built graph is destroyed: say why first)
+            import traceback
+            traceback.print_exc()
+            raise
         # the graph also reads the composer's packed weight buffers through raw pointers: hold them, so that a repack
         # (another precision, a differentiable call) can drop them from the composer's cache without freeing them
         self._packed = [entry[1] for entry in composer._packed.values()]
@@ -81,15 +112,17 @@ class FrameGraph:
         (their octave weights are kernel arguments)."""
         composer = self.model.object_composer
         # state_epoch counts set_step / load_state_dict / .to() calls (reading the step buffers back would synchronise)
-        return (tuple((p.data_ptr(), p._version) for p in composer.parameters()), composer.precision,
-                bool(composer.gate_feature_head), composer.state_epoch)
+        owner = composer if self.mode == "scene_encodings" else self.model       # (observations: the encoders' weights too)
+        return (tuple((p.data_ptr(), p._version) for p in owner.parameters()), composer.precision,
+                bool(composer.gate_feature_head), composer.state_epoch,
+                None if composer.object_entry_fields is None else tuple(composer.object_entry_fields))
 
     def render(self, scene: Dict[str, torch.Tensor]) -> Dict:
-        """Copies the scene encoding into the captured input buffers and replays the frame."""
+        """Copies the inputs into the captured buffers and replays the frame."""
         if self._signature() != self._weights_version:
             raise RuntimeError("the composer's parameters, precision or annealing step changed since the frame was captured: "
                                "build a new FrameGraph")
-        for k in SCENE_KEYS:
+        for k in self.keys:
             src = scene[k]
             if src.shape != self.inputs[k].shape:
                 raise ValueError(f"{k}: shape {tuple(src.shape)} differs from the captured {tuple(self.inputs[k].shape)}")

@@ -417,7 +417,6 @@ class ObjectComposer(nn.Module):
         self._budget_ok = 0
         self._packed.clear()
         self._annealing.clear()
-        self._host_step = None
         self._linspace.clear()
         self._workspace = None
         self.state_epoch += 1
@@ -430,6 +429,7 @@ class ObjectComposer(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self._drop_device_caches()
+        self._host_step = None          # (the step buffers now hold the checkpoint's value: unknown to the host until set_step)
         return out
 
     # ------------------------------------------------------------------ marshalling

@@ -185,27 +185,7 @@ def stand_in_encoders(config, world: str, seed: int = 5):
     return enc, par
 
 
-def observation_batch(scene, boxes_seed: int = 3, dynamic_objects: int = 2):
-    """Synthetic dataset tensors for the observation-driven modes on top of a synthetic scene's cameras: smooth images,
-    annotated boxes of the dynamic objects, index tensors.  Returns a dict keyed like Batch.to_tuple()
-    (dataset/batching.py:252-264)."""
-    g = torch.Generator().manual_seed(boxes_seed)
-    cam = scene["camera_rotations"]
-    lead = list(cam.shape[:-1])                                                        # (bs, O, C)
-    h, w = scene["image_size"]
-    yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
-    base = torch.stack([xx, yy, xx * yy], 0)                                           # (3, H, W)
-    tint = torch.rand(lead + [3, 1, 1], generator=g)
-    observations = (base * 0.5 + tint * 0.5).contiguous()
-    centre = 0.3 + 0.4 * torch.rand(lead + [2, dynamic_objects], generator=g)
-    half = 0.05 + 0.1 * torch.rand(lead + [2, dynamic_objects], generator=g)
-    boxes = torch.cat([centre - half, centre + half], dim=-2).clamp(0, 1)              # [left, top, right, bottom]
-    validity = torch.ones(lead + [dynamic_objects], dtype=torch.bool)
-    bs, obs_count = lead[0], lead[1]
-    frame = torch.arange(bs * obs_count).reshape(bs, obs_count)
-    return {"observations": observations, "camera_rotations": cam, "camera_translations": scene["camera_translations"],
-            "focals": scene["focals"], "bounding_boxes": boxes, "bounding_boxes_validity": validity,
-            "global_frame_indexes": frame, "video_frame_indexes": frame.clone(), "video_indexes": torch.arange(bs)}
+from playableenvironments_amd.synthetic import observation_batch  # noqa: E402,F401  (shared with bench.py)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

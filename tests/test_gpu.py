@@ -1217,6 +1217,109 @@ def test_frame_graph_replay_is_bit_identical():
         FrameGraph(model, scenes[0], size)
 
 
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_native_evaluation_frame_matches_oracle(world):
+    """The frame the reference's evaluators and play loop render (environment_model_backpropagated_autoencoder.py:
+    173-236): 288 x 512, strided grids [4, 8] = 72 x 128 + 36 x 64 = 11 520 rays, SHIPPED network sizes.  (1) composer level, the
+    same CPU-built inputs on both sides: every field of every entry within the fp32 tolerance, both kernels; (2) the plain drop-in
+    call ``forward_from_scene_encoding(..., patch_stride=[4, 8])`` (matrices and rays built on the GPU: ulp-level differences may
+    flip a box decision on a handful of rays) against the oracle's own scene-encoding render; (3) the decoder-layout maps are
+    the wire-format fold of the ray-major features, bit for bit; (4) the frame replayed from a FrameGraph is bit-identical."""
+    from playableenvironments_amd.frame_graph import FrameGraph, SCENE_KEYS
+    size, strides = (288, 512), [4, 8]
+    cfg = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
+    make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+    scene = make(seed=1234, image_size=size)
+    model = em.EnvironmentModel(cfg)
+    torch.manual_seed(0)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.eval()
+    comp = model.object_composer
+    inputs = composer_inputs(cfg, scene, strides=strides)
+    assert inputs[1].shape[-2] == 11520
+    sd = {k: v.detach().clone() for k, v in comp.state_dict().items()}
+    args = [scene[k] for k in SCENE_KEYS[:3]] + [size] + [scene[k] for k in SCENE_KEYS[3:]]
+    with torch.no_grad():
+        want = ro.composer_forward(cfg, sd, *inputs, False, stable_merge=True)     # (= the oracle's scene-encoding render)
+    model = model.cuda()
+    gargs = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    gscene = {k: scene[k].cuda() for k in SCENE_KEYS}
+    for precision in ("fp32", "f16x3"):
+        comp.precision = precision
+        with torch.no_grad():
+            got = comp(*[v.cuda() for v in inputs], False)
+            env = model.forward_from_scene_encoding(*gargs, 0, False, 1200, patch_stride=strides, _decoder_features=[64, 128])
+        torch.cuda.synchronize()
+        assert_close(want, got)
+        a = want["coarse"]["global"]["integrated_features"]
+        b = env["coarse"]["global"]["integrated_features"].cpu()
+        assert a.shape == b.shape == (1, 1, 1, 11520, 192)
+        flipped = ((a - b).abs() > ATOL + RTOL * a.abs()).any(-1).float().mean()
+        assert float(flipped) <= 0.005, (precision, float(flipped))
+        # the maps the decoder consumes = the reference's fold_strided_grid_samples + split_features_by_layer + permute
+        maps = env["coarse"]["global"]["decoder_features"]
+        assert [tuple(m.shape[-3:]) for m in maps] == [(64, 72, 128), (128, 36, 64)]
+        feats = env["coarse"]["global"]["integrated_features"]
+        first = feats[..., :72 * 128, 0:64].reshape(1, 1, 1, 72, 128, 64).movedim(-1, -3)
+        second = feats[..., 72 * 128:, 64:192].reshape(1, 1, 1, 36, 64, 128).movedim(-1, -3)
+        assert torch.equal(maps[0], first) and torch.equal(maps[1], second)
+        graph = FrameGraph(model, gscene, size, patch_stride=strides)
+        other = {k: v.cuda() for k, v in make(seed=77, image_size=size).items() if torch.is_tensor(v)}
+        for sc in (other, gscene):
+            replayed = graph.render(sc)
+            with torch.no_grad():
+                eager = model.forward_from_scene_encoding(*[sc[k] for k in SCENE_KEYS[:3]], size, *[sc[k] for k in SCENE_KEYS[3:]],
+                                                          0, False, 1200, patch_stride=strides)
+            torch.cuda.synchronize()
+            for entry in eager["coarse"]:
+                for key in ("integrated_features", "opacity", "depth", "weights", "disparity"):
+                    x, y = replayed["coarse"][entry][key], eager["coarse"][entry][key]
+                    assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)), (precision, entry, key)
+            for key in ("reconstructed_bounding_boxes", "reconstructed_3d_bounding_boxes", "projected_axes"):
+                assert torch.equal(replayed[key], eager[key]), key
+        del graph
+    comp.precision = "fp32"
+
+
+def test_frame_graph_of_the_observation_mode_is_bit_identical():
+    """FrameGraph(mode="observations"): the evaluators' ``render_full_frame_from_observations`` span - this package's CNN encoders
+    and pose estimators, roi_pool crops, pose math, rays, renderer - captured once and replayed for another batch: every tensor
+    of the result dictionary equals the eager call's, bit for bit (native 288 x 512 frame, strides [4, 8], two frames)."""
+    from playableenvironments_amd.frame_graph import FrameGraph, OBSERVATION_KEYS
+    small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
+    cfg = configs.reduced_config(configs.minecraft_config(encoders=True), **small)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    model = model.cuda().eval()
+    size = (288, 512)
+    batches = [{k: v.cuda() for k, v in synthetic.observation_batch(synthetic.minecraft_scene(batch=2, seed=s, image_size=size),
+                                                                    boxes_seed=s).items()} for s in (3, 4)]
+    graph = FrameGraph(model, batches[0], mode="observations", patch_stride=[4, 8])
+
+    def flat(d, prefix=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, prefix + k + "/")
+            elif isinstance(v, (list, tuple)):
+                for i, t in enumerate(v):
+                    yield f"{prefix}{k}/{i}", t
+            elif torch.is_tensor(v):
+                yield prefix + k, v
+    for b in (batches[1], batches[0]):
+        replayed = dict(flat(graph.render(b)))
+        with torch.no_grad():
+            eager = dict(flat(model(*[b[k] for k in OBSERVATION_KEYS], 0, False, 1200, patch_stride=[4, 8])))
+        torch.cuda.synchronize()
+        assert sorted(replayed) == sorted(eager) and len(eager) > 50
+        for k in eager:
+            assert torch.equal(torch.nan_to_num(replayed[k].float(), nan=-7.0), torch.nan_to_num(eager[k].float(), nan=-7.0)), k
+    with torch.no_grad():
+        next(model.object_encoders[0].parameters()).add_(1e-3)           # the encoders' weights are part of the signature
+    with pytest.raises(RuntimeError, match="changed since the frame was captured"):
+        graph.render(batches[0])
+
+
 def test_two_cameras_per_observation():
     """cameras_count = 2: the object tensors carry a singleton camera dimension that broadcasts against (..., O, C) rays
     (model/environment_model.py:1041-1158 shapes).  The reference itself only runs with one camera (its boolean-mask

@@ -1,0 +1,53 @@
+"""Manual check (GPU box): host synchronisations (and therefore un-capturable operations) of the evaluation calls -
+torch.cuda.set_sync_debug_mode("error") around forward_from_scene_encoding / forward_from_observations of both shipped worlds."""
+import os
+import sys
+import traceback
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from playableenvironments_amd import configs, synthetic  # noqa: E402
+from playableenvironments_amd.environment_model import EnvironmentModel  # noqa: E402
+from playableenvironments_amd.frame_graph import OBSERVATION_KEYS  # noqa: E402
+
+dev = torch.device("cuda", 0)
+size = (288, 512)
+for world in ("tennis", "minecraft"):
+    cfg = (configs.tennis_config if world == "tennis" else configs.minecraft_config)(encoders=True)
+    torch.manual_seed(0)
+    model = EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
+    model.eval().to(dev)
+    make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+    scene = bench.to_device(make(seed=1234, image_size=size), dev)
+    batch = bench.to_device(synthetic.observation_batch(make(seed=1234, image_size=size)), dev)
+    calls = {
+        "scene_encoding": lambda: model.forward_from_scene_encoding(*bench.scene_args(scene, size), 0, False, 1200, patch_stride=[4, 8]),
+        "observations": lambda: model.forward_from_observations(*[batch[k] for k in OBSERVATION_KEYS], 0, False, 1200, patch_stride=[4, 8]),
+    }
+    for name, fn in calls.items():
+        with torch.no_grad():
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("error")
+            try:
+                fn()
+                print(world, name, "no synchronisation")
+            except Exception:
+                print(world, name, "SYNCHRONISES:")
+                traceback.print_exc()
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    fn()
+                print(world, name, "captures")
+            except Exception:
+                print(world, name, "CAPTURE FAILS:")
+                traceback.print_exc()
+            torch.cuda.synchronize()

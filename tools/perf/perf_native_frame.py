@@ -15,11 +15,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
-from playableenvironments_amd import configs, synthetic  # noqa: E402
+from playableenvironments_amd import _lib, configs, synthetic  # noqa: E402
 from playableenvironments_amd.environment_model import EnvironmentModel  # noqa: E402
 
 
-def build(world: str, dev):
+def build(world: str, dev, batch: int = 1):
     cfg = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
     torch.manual_seed(0)
     model = EnvironmentModel(cfg)
@@ -27,16 +27,21 @@ def build(world: str, dev):
     model.eval().to(dev)
     size = (288, 512)
     make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
-    scene = bench.to_device(make(seed=1234, image_size=size), dev)
+    scene = bench.to_device(make(batch=batch, seed=1234, image_size=size), dev)
     return cfg, model, scene, size
 
 
 def main():
+    if os.environ.get("PR_PERF_LIB"):      # a measurement build of the library (tools/build_variant.sh), for A/B timings on one box
+        _lib.library_path = lambda: os.path.abspath(os.environ["PR_PERF_LIB"])
     world = sys.argv[1] if len(sys.argv) > 1 else "tennis"
     precision = sys.argv[2] if len(sys.argv) > 2 else "fp32"
     dev = torch.device("cuda", 0)
-    cfg, model, scene, size = build(world, dev)
+    batch = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("batch=")), 1)
+    cfg, model, scene, size = build(world, dev, batch)
     model.object_composer.precision = precision
+    if "nogate" in sys.argv:
+        model.object_composer.gate_feature_head = False
 
     def step():
         with torch.no_grad():
@@ -69,6 +74,19 @@ def main():
         torch.cuda.synchronize()
         single.append(e0.elapsed_time(e1))
     print(f"  one frame, first launch to last (host-paced): median {bench.median(single):.3f} ms")
+    lib = bench._lib_handle()
+    lib.pr_profile_enable(1)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    lib.pr_profile_enable(0)
+    ms, launches = bench.profile_arrays()
+    lib.pr_profile_collect(ms, launches)
+    with torch.no_grad():
+        inputs = bench.composer_call_inputs_strided(model, cfg, scene, size, [4, 8])
+    roof = bench.leg_roofline(model.object_composer, cfg, inputs, ms[0] / 10)
+    print(f"  mlp {ms[0] / 10:.3f} ms, composite {ms[1] / 10:.3f} ms, executed {roof['flop_executed'] / 1e9:.1f} GFLOP (algorithmic "
+          f"{roof['flop_algorithmic'] / 1e9:.1f}), {roof['achieved']} TFLOP/s = {roof['frac']} of peak; evaluated {roof['evaluated_samples']}")
     if "profile" in sys.argv:
         pr = cProfile.Profile()
         pr.enable()

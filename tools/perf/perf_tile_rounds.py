@@ -23,6 +23,9 @@ def main():
     comp.gate_feature_head = False
     full = [v.to(dev) for v in composer_inputs(cfg, synthetic.single_player_scene(image_size=(128, 128)))]
     flop = bench.flops_per_sample(cfg["model"]["object_models"][0])
+    # "thrash": a 512 MB elementwise pass between the launches evicts the packed weights (2.9 MB) from every XCD's L2 - what the
+    # other objects' weights and feature rows do to an object's weights in a multi-object frame
+    thrash = torch.zeros(128 << 20, dtype=torch.float32, device=dev) if "thrash" in sys.argv else None
     for rounds in (1.0, 1.1, 2.0, 2.1, 4.0, 4.5, 5.0, 5.1, 5.5, 6.0, 8.0, 8.1, 16.0, 16.1):
         tiles = int(round(rounds * 512))
         rays = tiles * 2
@@ -35,6 +38,8 @@ def main():
             lib.pr_profile_enable(1)
             n = 10
             for _ in range(n):
+                if thrash is not None:
+                    thrash.add_(1.0)
                 comp(*inputs, False)
             torch.cuda.synchronize()
             lib.pr_profile_enable(0)
