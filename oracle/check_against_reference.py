@@ -651,6 +651,32 @@ def check_observation_modes():
                 bad = {k: v[0] for k, v in rep.items() if not v[1]}
                 print(f"[{label}, {world}] fields={len(rep)} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}")
                 ok &= not bad
+            # TRAINING mode with ray chunks (environment_model.py:474-521): the reference runs its composer once per chunk of
+            # samples_per_image_batching rays, so every chunk normalises with its own batch statistics and the running statistics /
+            # num_batches_tracked advance once per chunk; the product's batchified_composer_call has to do the same
+            ref.train(), mine.train()
+            before = {k: v.clone() for k, v in ref.object_composer.state_dict().items()}
+            kw = dict(samples_per_image=0, perturb=False, patch_stride=[4, 8], samples_per_image_batching=100)
+            torch.manual_seed(14)
+            with torch.no_grad():
+                a = ref(*[x.clone() for x in args], **kw)
+            torch.manual_seed(14)
+            with torch.no_grad():
+                b = mine(*[x.clone() for x in args], **kw)
+            rep = _compare_nested(a, b)
+            bad = {k: v[0] for k, v in rep.items() if not v[1]}
+            sd_ref, sd_mine = ref.object_composer.state_dict(), mine.object_composer.inner.state_dict()
+            moved = [k for k in sd_ref if not torch.equal(sd_ref[k], before[k])]
+            counters = {k: int(sd_ref[k] - before[k]) for k in sd_ref if k.endswith("num_batches_tracked")}
+            stat = max(float((sd_ref[k].double() - sd_mine[k].double()).abs().max()) for k in sd_ref)
+            same_counters = all(torch.equal(sd_ref[k], sd_mine[k]) for k in counters)
+            chunks = -(-a["coarse"]["global"]["opacity"].size(-1) // 100)
+            print(f"[train mode, {chunks} ray chunks, {world}] fields={len(rep)} worst|diff|={max(v[0] for v in rep.values()):.2e} failing={bad}; "
+                  f"{len(moved)} buffers moved, counters advanced by {sorted(set(counters.values()))} on both sides: {same_counters}, "
+                  f"buffer max|diff| {stat:.2e}")
+            # (a model shared by two object instances counts twice per chunk)
+            ok &= not bad and same_counters and min(counters.values()) == chunks and stat < 1e-4
+            ref.eval(), mine.eval()
     finally:
         em.camera_rays = original_camera_rays
     return ok

@@ -150,6 +150,29 @@ def build_pair(world, cfg, seed=0, alpha_bias=2.0):
     return ref, mine
 
 
+class _Float32Draws:
+    """Inside the float64 arbitration run the random draws (perturbation noise, patch positions) have to be the float32 run's:
+    torch.rand / torch.randn under a float64 default dtype consume the generator differently.  Draws without an explicit dtype
+    are made in float32 and widened."""
+    NAMES = ("rand", "randn", "rand_like", "randn_like")
+
+    def __enter__(self):
+        self.saved = {n: getattr(torch, n) for n in self.NAMES}
+        for n, fn in self.saved.items():
+            def draw(*a, _fn=fn, _like=n.endswith("_like"), **k):
+                if k.get("dtype") is not None:
+                    return _fn(*a, **k)
+                if _like:
+                    return _fn(a[0].float(), *a[1:], **k).to(a[0].dtype)
+                return _fn(*a, dtype=torch.float32, **k).to(torch.get_default_dtype())
+            setattr(torch, n, draw)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.saved.items():
+            setattr(torch, n, fn)
+
+
 def compare(want, got, path="", report=None):
     from oracle.check_against_reference import _compare_nested
     return _compare_nested(want, got, path, report=report)
@@ -272,26 +295,47 @@ def run_world(world, reduce, image_size, patch, write):
             grads["mine"] = iteration("mine", mine, seed)
             break
         # The two sides differ by the last bits of their pose matrices (closed-form rigid inverse vs LU, 2e-6) and the shipped 8 x 256
-        # networks amplify that in single tensors (ReLU / box decisions flip): per group the yardstick is the
-        # relative L2 difference of ALL its gradients, per tensor the difference relative to the group's largest gradient.
-        worst, l2 = 0.0, {}
+        # networks amplify that in single tensors (ReLU / box decisions flip).  Which side is off is decided
+        # in FLOAT64: the same iteration - same seed, same draws - through the product's host logic with the oracle behind it and
+        # every module widened is the exact result; per tensor the product's gradient may be as far from it as the reference's
+        # is (x 4, + 1e-6 of the group's largest gradient), not farther.  The relative L2 figures are printed beside it.
+        from tests.helpers import oracle_in_float64, to_double
+        mine.load_state_dict(states["mine"])
+        mine.double()
+        saved_args = args
+        try:
+            with oracle_in_float64(), _Float32Draws():
+                args = to_double([a.clone() for a in saved_args])
+                grads["exact"] = iteration("mine", mine, seed)
+        finally:
+            args = saved_args
+            mine.float()
+            mine.load_state_dict(states["mine"])
+        worst, l2, farther = 0.0, {}, {}
+        err = {"ref": 0.0, "mine": 0.0}
         for group in ("composer", "decoder", "running"):
-            assert set(grads["ref"][group]) == set(grads["mine"][group]) and grads["ref"][group], group
-            scale = max(float(t.abs().max()) for t in grads["ref"][group].values())
+            assert set(grads["ref"][group]) == set(grads["mine"][group]) == set(grads["exact"][group]) and grads["ref"][group], group
+            scale = max(float(t.abs().max()) for t in grads["exact"][group].values())
             num = den = 0.0
             for n in grads["ref"][group]:
-                a, b = grads["ref"][group][n], grads["mine"][group][n]
+                a, b, e = grads["ref"][group][n].double(), grads["mine"][group][n].double(), grads["exact"][group][n].double()
                 worst = max(worst, float((a - b).abs().max()) / max(float(a.abs().max()), 1e-2 * scale, 1e-12))
-                num += float((a - b).double().square().sum())
-                den += float(a.double().square().sum())
+                num += float((a - b).square().sum())
+                den += float(a.square().sum())
+                err_ref, err_mine = float((a - e).abs().max()), float((b - e).abs().max())
+                err["ref"], err["mine"] = max(err["ref"], err_ref / max(scale, 1e-300)), max(err["mine"], err_mine / max(scale, 1e-300))
+                if err_mine > 4.0 * err_ref + 1e-6 * scale:
+                    farther[f"{group}.{n}"] = (err_mine, err_ref)
             l2[group] = (num / max(den, 1e-300)) ** 0.5
         same_loss = abs(float(grads["ref"]["loss"]) - float(grads["mine"]["loss"])) <= 1e-5 * abs(float(grads["ref"]["loss"]))
-        print(f"[drop-in, {tag}: training-shaped iteration] loss {float(grads['ref']['loss']):.6f} / {float(grads['mine']['loss']):.6f}, "
+        print(f"[drop-in, {tag}: training-shaped iteration] loss {float(grads['ref']['loss']):.6f} / {float(grads['mine']['loss']):.6f} "
+              f"(float64: {float(grads['exact']['loss']):.6f}), "
               f"{len(grads['ref']['composer'])} renderer + {len(grads['ref']['decoder'])} decoder gradients, BatchNorm running statistics: "
               f"relative L2 difference renderer {l2['composer']:.2e}, decoder {l2['decoder']:.2e}, statistics {l2['running']:.2e}; "
               f"worst tensor {worst:.2e}")
-        limit = 2e-3 if reduce else 2e-2
-        ok &= same_loss and max(l2.values()) < limit and worst < 10 * limit
+        print(f"    float64 arbitration: worst error relative to the group's largest gradient - reference {err['ref']:.2e}, swapped model "
+              f"{err['mine']:.2e}; tensors where the swapped model is farther than 4 x the reference: {farther}")
+        ok &= same_loss and not farther
     finally:
         em.camera_rays = original_camera_rays
     return ok
@@ -305,6 +349,7 @@ def main(write=False):
     ok &= run_world("minecraft", True, (64, 96), 8, write)
     # the shipped network sizes, trainer call + evaluator call on a small frame
     ok &= run_world("minecraft", False, (48, 64), 4, False)
+    ok &= run_world("tennis", False, (48, 64), 4, False)
     print("DROP-IN " + ("OK" if ok else "FAILED"))
     return ok
 

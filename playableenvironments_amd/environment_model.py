@@ -527,15 +527,32 @@ class EnvironmentModel(nn.Module):
     def batchified_composer_call(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                  deformation, object_in_scene, perturb, samples_per_image_batching: int = 0,
                                  video_indexes=None, canonical_pose: bool = False, _decoder_layout=None):
-        """model/environment_model.py:474-521.  The reference chunks rays (1000 per call in full-frame
-        rendering) because it materialises (rays, samples, 192) tensors; the fused renderer does not
-        need to, so ``samples_per_image_batching`` is accepted and ignored - the composer splits a
-        call only if its scratch would exceed its workspace budget, which is exact."""
+        """model/environment_model.py:474-521.  The reference chunks rays (1000 per call in full-frame rendering) because it
+        materialises (rays, samples, 192) tensors; the fused renderer does not need to.  In EVALUATION mode
+        ``samples_per_image_batching`` is therefore accepted and ignored - rays are independent and the BatchNorm layers use
+        their running statistics, so one call returns what the chunked calls return (the composer splits a call only if its
+        scratch would exceed its workspace budget).  In TRAINING mode the chunks are part of the semantics: the reference runs
+        the composer once per chunk, so every chunk normalises with ITS OWN batch statistics, and the running statistics and
+        ``num_batches_tracked`` advance once per chunk - reproduced here chunk for chunk (TensorBatchifier.batchify:
+        consecutive ranges of ``samples_per_image_batching`` rays, the last one shorter)."""
         extra = {} if _decoder_layout is None else {"_decoder_layout": _decoder_layout}
+        dimension = ray_directions.dim() - 2
+        rays = ray_directions.size(dimension)
+        if self.object_composer.training and 0 < samples_per_image_batching < rays:
+            if _decoder_layout is not None:
+                raise ValueError("decoder-layout emission needs all rays of the call in one composer call "
+                                 "(training mode with samples_per_image_batching > 0 runs one call per ray chunk)")
+            chunks = []
+            for begin in range(0, rays, samples_per_image_batching):
+                current = ray_directions.narrow(dimension, begin, min(samples_per_image_batching, rays - begin))
+                chunks.append(self.object_composer(ray_origins, current, focal_normals, transformation_matrix_w2o, style,
+                                                   deformation, object_in_scene, perturb, video_indexes=video_indexes,
+                                                   canonical_pose=canonical_pose))
+            return self.merge_dictionaries(chunks, dimension=dimension)
         results = self.object_composer(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                        deformation, object_in_scene, perturb, video_indexes=video_indexes,
                                        canonical_pose=canonical_pose, **extra)
-        return self.merge_dictionaries([results], dimension=ray_directions.dim() - 2)
+        return self.merge_dictionaries([results], dimension=dimension)
 
     @staticmethod
     def decoder_layout(height: int, width: int, samples_per_image: int, patch_size: int, patch_stride, features_by_layer):

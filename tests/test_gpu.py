@@ -388,6 +388,49 @@ def test_train_mode_batchnorm_forward(name):
     comp.eval()
 
 
+def test_train_mode_ray_chunks_normalise_per_chunk():
+    """``samples_per_image_batching`` in TRAINING mode (environment_model.py:474-521): the reference evaluates its composer once
+    per chunk of rays, so every chunk is normalised with its own batch statistics and the running statistics and
+    ``num_batches_tracked`` advance once per chunk.  HIP renderer behind the product's ``batchified_composer_call`` against the
+    oracle's chunked call (pinned against the reference's in check_against_reference.py): features at the train-mode tolerance,
+    buffers to 1e-4, counters exactly - and different from the unchunked call, which is what evaluation mode may ignore."""
+    cfg = configs.reduced_config(configs.minecraft_config(), **SMALL_NETS)
+    scene = synthetic.minecraft_scene(batch=2, seed=31, image_size=(48, 64))
+    inputs = composer_inputs(cfg, scene, strides=[4, 8])                      # 240 rays
+    comp = build(cfg, alpha_bias=3.0)
+    sd = {k: v.detach().clone() for k, v in comp.state_dict().items()}
+    with torch.no_grad():
+        want = ro.batchified_composer_call(cfg, sd, *inputs, False, chunk=100, training=True)     # updates sd in place
+    model = em.EnvironmentModel(cfg)
+    model.object_composer.load_state_dict(comp.state_dict())
+    model = model.cuda().train()
+    with torch.no_grad():
+        got = model.batchified_composer_call(*[v.cuda() for v in inputs], False, samples_per_image_batching=100)
+    torch.cuda.synchronize()
+    rep = compare_results(want, got, rtol=1e-3, atol=2e-4)
+    bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
+    assert not bad, bad
+    after = model.object_composer.state_dict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(after[k]) == int(v) and int(v) in (3, 6), (k, int(after[k]), int(v))
+        elif "running_" in k:
+            assert torch.allclose(after[k].cpu(), v, rtol=1e-4, atol=1e-6), k
+    # one call over all rays is a different computation in training mode (one set of statistics, one counter step)
+    model.object_composer.load_state_dict(comp.state_dict())
+    with torch.no_grad():
+        whole = model.batchified_composer_call(*[v.cuda() for v in inputs], False, samples_per_image_batching=0)
+    counters = [int(v) for k, v in model.object_composer.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert set(counters) <= {1, 2}
+    assert not torch.allclose(whole["coarse"]["global"]["integrated_features"], got["coarse"]["global"]["integrated_features"], rtol=1e-3, atol=2e-4)
+    # evaluation mode: the chunk size changes nothing
+    model.eval()
+    with torch.no_grad():
+        a = model.batchified_composer_call(*[v.cuda() for v in inputs], False, samples_per_image_batching=100)
+        b = model.batchified_composer_call(*[v.cuda() for v in inputs], False, samples_per_image_batching=0)
+    assert torch.equal(a["coarse"]["global"]["integrated_features"], b["coarse"]["global"]["integrated_features"])
+
+
 def test_train_mode_guards():
     cfg = configs.tennis_config()
     comp = build(cfg).cuda()
@@ -2566,6 +2609,9 @@ def test_generated_noise_is_independent_of_ray_chunking():
 # ---------------------------------------------------------------------------------------------------------------------
 # a fixed-seed slice of the randomized sweep (tests/gpu_fuzz.py: random network shapes, sample counts, frames, flags, absent
 # objects, both precisions; forward fields and every gradient against the oracle)
+SWEEP_OK_FLOOR_FORWARD, SWEEP_OK_FLOOR_BACKWARD = 30, 14      # recorded on the GPU box: see test_randomized_sweep_slice
+
+
 @pytest.mark.parametrize("sweep,cases", [("forward", 40), ("backward", 20)])
 def test_randomized_sweep_slice(sweep, cases, capsys):
     import random
@@ -2574,7 +2620,14 @@ def test_randomized_sweep_slice(sweep, cases, capsys):
     failures = run(cases, random.Random(0))
     report = capsys.readouterr().out
     assert failures == 0, report[-4000:]
-    assert report.count("ok case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("skipped") == cases, report[-2000:]
+    plain = report.count("ok case")
+    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("skipped")
+    assert plain + classified == cases, report[-2000:]
+    # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floors = the
+    # plain-ok counts of seed 0 when the check was introduced (round 4: forward 40 / 40 of which hierarchical cases may need the
+    # float64 arbitration, backward 17 / 20), minus a margin of two cases for run-to-run differences of atomically accumulated sums
+    floor = {"forward": SWEEP_OK_FLOOR_FORWARD, "backward": SWEEP_OK_FLOOR_BACKWARD}[sweep]
+    assert plain >= floor, (plain, floor, report[-3000:])
 
 
 def test_object_entry_fields_extension():
