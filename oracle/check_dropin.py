@@ -158,17 +158,22 @@ class _Float32Draws:
 
     def __enter__(self):
         self.saved = {n: getattr(torch, n) for n in self.NAMES}
+        self.multinomial = torch.multinomial
+        # (the weighted pixel / patch samplers: a float64 probability tensor walks the generator differently)
+        torch.multinomial = lambda weights, *a, _fn=self.multinomial, **k: _fn(weights.float(), *a, **k)
         for n, fn in self.saved.items():
             def draw(*a, _fn=fn, _like=n.endswith("_like"), **k):
-                if k.get("dtype") is not None:
-                    return _fn(*a, **k)
+                wanted = k.pop("dtype", None)
+                if wanted is not None and wanted != torch.float64:
+                    return _fn(*a, dtype=wanted, **k)
                 if _like:
                     return _fn(a[0].float(), *a[1:], **k).to(a[0].dtype)
-                return _fn(*a, dtype=torch.float32, **k).to(torch.get_default_dtype())
+                return _fn(*a, dtype=torch.float32, **k).to(torch.float64 if wanted is not None else torch.get_default_dtype())
             setattr(torch, n, draw)
         return self
 
     def __exit__(self, *exc):
+        torch.multinomial = self.multinomial
         for n, fn in self.saved.items():
             setattr(torch, n, fn)
 

@@ -323,6 +323,18 @@ class EnvironmentModel(nn.Module):
             self.object_parameters_encoders = nn.ModuleList(list(object_parameters_encoders))
         return self
 
+    def create_object_encoders(self) -> List[nn.Module]:
+        """One style / deformation encoder per object model, from ``config["model"]["object_encoders"]``
+        (model/environment_model.py:109-123; built by this package's ``encoders`` module)."""
+        from .encoders import create_encoders
+        return create_encoders(self.config)[0]
+
+    def create_object_parameters_encoders(self) -> List[nn.Module]:
+        """One pose encoder per object model, from ``config["model"]["object_parameters_encoder"]``
+        (model/environment_model.py:93-107)."""
+        from .encoders import create_encoders
+        return create_encoders(self.config)[1]
+
     def set_image_decoder(self, image_decoder, grid_sampler):
         """``grid_sampler(integrated_features (..., R, F), sampled_positions (..., R, 2)) -> grid`` and
         ``image_decoder(grid) -> (..., output features, height, width)`` (environment_model.py:733-741)."""
@@ -354,8 +366,23 @@ class EnvironmentModel(nn.Module):
                 "EnvironmentModel(config, object_encoders=..., object_parameters_encoders=...) or set_encoders(...), or "
                 "encode the scene elsewhere and call mode='scene_encodings'")
 
+    def get_object_encoder_parameters(self):
+        """model/environment_model.py:67-68 (the trainers give the object encoders their own parameter group)."""
+        return self.object_encoders.parameters()
+
     def get_camera_offsets_parameters(self):
+        """model/environment_model.py:70-71 (the trainers' second optimiser)."""
         return self.camera_parameters_offsets.parameters()
+
+    def get_main_parameters(self, additional_excluded_parameters=None):
+        """Every parameter that belongs neither to the object encoders nor to the camera offsets, minus the names in
+        ``additional_excluded_parameters`` (how the autoencoder subclasses take their CNN out: their override calls this one) -
+        what ``Trainer.get_optimizer`` hands to Adam (model/environment_model.py:73-91, training/trainer.py:105-111)."""
+        excluded = set(["object_encoders." + name for name, _ in self.object_encoders.named_parameters()] +
+                       ["camera_parameters_offsets." + name for name, _ in self.camera_parameters_offsets.named_parameters()])
+        if additional_excluded_parameters is not None:
+            excluded = excluded.union(additional_excluded_parameters)
+        return [p for name, p in self.named_parameters() if name not in excluded]
 
     def _corrected_cameras(self, camera_rotations, camera_translations, focals, global_frame_indexes, focal_quirk=False):
         """Adds the learnable per-frame camera offsets (environment_model.py:891-897, 1235-1241, 1408-1414).
