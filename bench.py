@@ -288,12 +288,16 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
     K = comp.object_id_helper.objects_count
     evaluated = torch.zeros((K,), dtype=torch.int64, device=dev)
     retries = [0]
+    # the all-reduce of the renderer's flat gradient buffer starts inside backward() (behind pr_render_backward's launches, in front
+    # of whatever autograd still has to walk: the pose / style producers) and is waited for in front of the optimiser step
+    overlap = parallel.OverlappedGradientAllReduce(comp) if dist is not None else None
 
     def iteration():
         out = model(*scene_args(sc, size), 2880, True, 0, patch_size=48, patch_stride=[4, 8], mode="scene_encodings")
         loss = out["coarse"]["global"]["integrated_features"].square().mean()
         loss.backward()
-        parallel.allreduce_gradients(params)
+        if overlap is None or overlap.finish() == 0:
+            parallel.allreduce_gradients(params)
         if arena:
             parallel.flat_gradient(flat, comp)
         opt.step()
@@ -345,6 +349,8 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
     lib.pr_profile_enable(0)
     ms, launches = profile_arrays()
     _lib.check(lib.pr_profile_collect(ms, launches), "pr_profile_collect")
+    if overlap is not None:
+        overlap.remove()
     rays = int(out["coarse"]["global"]["opacity"].numel())
     helper = comp.object_id_helper
     fwd_flops = sum(counts[k] * flops_per_sample(cfg["model"]["object_models"][helper.model_idx_by_object_idx(k)])
@@ -366,7 +372,8 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
         "rays_per_gpu_per_step": rays,
         "workload": "minecraft shipped config, 3 frames/GPU x (48x48 patch @ strides [4, 8] = 2880 rays), perturb, train-mode "
                     "BatchNorm - BASELINE.json configs[4] renderer part",
-        "parallelism": f"data parallel x{world}" + (", one flat RCCL all_reduce of the parameter gradients" if world > 1 else ""),
+        "parallelism": f"data parallel x{world}" + (", one flat RCCL all_reduce of the parameter gradients started inside backward() "
+                                                     "(parallel.OverlappedGradientAllReduce)" if world > 1 else ""),
         "optimizer": ("torch.optim.Adam(fused=True) on the composer's parameter arena (parallel.flatten_parameters: one launch; the same "
                       "element-wise update as on the separate tensors)") if arena else "torch.optim.Adam(fused=True) on the 170 separate parameter tensors",
         "roofline": {
@@ -732,8 +739,9 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
     def run():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = model.render_sharded(*scene_args(batch, size), False, shard="frames" if frames >= world else "rays",
-                                   fields=("integrated_features",))
+        # the evaluation flow: rank 0 is the consumer of the rendered maps (decoder / writer) - one gather to it, not an all-gather
+        out = model.render_sharded(*scene_args(batch, size), False, shard="frames" if frames >= world else "tiles",
+                                   fields=("integrated_features",), dst=0)
         e1.record()
         return out, e0, e1
 
@@ -756,7 +764,7 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         per_rank = [float(p.item()) for p in parts]
-    feats = out[ty]["global"]["integrated_features"]
+    feats = out[ty]["global"]["integrated_features"] if out is not None else None      # (rank 0 holds the assembled maps)
     rays = frames * size[0] * size[1]
     roofline = None
     if world == 1 and lib is not None:
@@ -770,14 +778,14 @@ def distinct_frames_leg(model, cfg, label, size, dev, world, rank, dist, steps, 
     return {
         "roofline": roofline,
         "workload": f"{frames} distinct tennis frames ({label}), {size[0]}x{size[1]}, sharded by frame over {world} rank(s), "
-                    "feature maps gathered on every rank",
+                    "feature maps gathered on rank 0 (gather(dst=0): the evaluator's consumer)",
         "value": round(rays * steps / dt / 1e6, 4),
         "unit": "Mrays/s (whole batch, strong scaling over a fixed batch)",
         "frames_per_s": round(frames * steps / dt, 3),
         "ms_per_batch": round(dt / steps * 1e3, 3),
         "per_rank_ms": [round(v, 3) for v in per_rank],
         "max_rank_ms": round(max(per_rank), 3),
-        "gathered_shape": list(feats.shape),
+        "gathered_shape": list(feats.shape) if feats is not None else None,
     }
 
 
@@ -836,6 +844,8 @@ def main():
     multi = world > 1 or bool(os.environ.get("PR_BENCH_FORCE_DIST"))
     if multi:
         import torch.distributed as dist
+        # (NCCL_DEBUG=VERSION makes RCCL print a version banner on STDOUT, which has to stay the one JSON line: the version is
+        # reported through torch.cuda.nccl.version() below; with NCCL_DEBUG_FILE set by the caller its lines are copied as well)
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -977,6 +987,13 @@ def main():
             except Exception as e:     # (a build without the query: the backend string above still says what ran)
                 distributed["nccl_version"] = f"unavailable ({type(e).__name__})"
             distributed["devices"] = torch.cuda.device_count()
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: cuda:{device_index} {torch.cuda.get_device_properties(dev).name}")
+        distributed["rank_devices"] = names
+        debug_file = os.environ.get("NCCL_DEBUG_FILE")
+        if debug_file and os.path.exists(debug_file.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))):
+            with open(debug_file.replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))) as f:
+                distributed["nccl_debug_version"] = [line.strip() for line in f if "version" in line.lower()][:4]
     rays_per_gpu = size[0] * size[1]
     total_rays = rays_per_gpu * world * args.steps
     value = total_rays / elapsed / 1e6
@@ -1086,10 +1103,11 @@ def main():
         del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
-        separate = train_step_leg(args, dev, world, rank, dist, lib, arena=False)
-        result["train_step"]["separate_parameter_tensors"] = {
-            "ms_per_step": separate["ms_per_step"], "ms_per_step_median": separate["ms_per_step_median"],
-            "note": "the same step with torch's fused Adam on the separate parameter tensors (a multi-tensor sweep: ~0.25 ms of 38-workgroup launches)"}
+        if world == 1:      # (a comparison leg: not repeated on every GPU count of a scaling run)
+            separate = train_step_leg(args, dev, world, rank, dist, lib, arena=False)
+            result["train_step"]["separate_parameter_tensors"] = {
+                "ms_per_step": separate["ms_per_step"], "ms_per_step_median": separate["ms_per_step_median"],
+                "note": "the same step with torch's fused Adam on the separate parameter tensors (a multi-tensor sweep: ~0.25 ms of 38-workgroup launches)"}
         result["train_step_with_decoder"] = train_step_with_decoder_leg(args, dev, world, rank, dist, result["train_step"]["ms_per_step"])
     if rank == 0 and world == 1 and not args.no_native_frame:
         result["native_eval_frame"] = native_eval_frame_leg(dev, lib)
@@ -1228,37 +1246,57 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     out["psnr_db"] = {**psnr, "against": "CPU oracle (pinned bitwise to the reference), fine.global.integrated_features rescaled "
                       f"to [0, 1] on the {n_side * n_side}-ray subset; 80 dB is the formula's ceiling (its 1e-8 floor)"}
 
-    # ---- the reference's PyTorch op graph on this GPU (PyTorch-ROCm, 1000-ray chunks like render_full_frame_*)
+    # ---- the reference's PyTorch op graph on this GPU (PyTorch-ROCm): EVERY ray of the frame, at the reference's own chunk size
+    # (1000 rays: an RTX 8000 memory limit, model/environment_model.py:584) and at the chunk sizes a 288 GB part allows - the honest
+    # same-GPU baseline is the FASTEST of them
     if not args.no_reference_graph:
-        # (4096 rays whatever the CPU subset is: with fewer rays the op graph's launches are too small to fill the GPU and the
-        # reference's side would look slower than it is)
-        ref_side = 64
-        ref_inputs = inputs if n_side == ref_side else composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], ref_side))
+        ref_inputs = composer_inputs(cfg, scene)
         gin = [v.to(dev) for v in ref_inputs]
         gsd = {k: v.to(dev) for k, v in sd.items()}
-        graph, spread = {}, {}
-        for chunk, repeats in ((1000, 5), (4000, 5)):
+        rays_total = size[0] * size[1]
+        graph, spread, skipped = {}, {}, {}
+        with torch.no_grad():       # warm-up: kernels of every shape class compiled / loaded
+            ro.batchified_composer_call(cfg, gsd, *[v[..., :1000, :] if v.dim() == 5 and v.size(-2) > 1000 else v for v in gin], False, chunk=1000)
+        for chunk in (1000, 4000, 16384, 65536):
+            if chunk > rays_total:
+                continue
+            # materialised tensors of the op graph: ~12 live (chunk, 192 positions, 256) fp32 tensors per object pass + the merged
+            # (chunk, 768, 192) feature gathers
+            need = chunk * (12 * 192 * 256 * 4 + 3 * 768 * 192 * 4)
+            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            if need > 0.8 * free:
+                skipped[f"chunk_{chunk}"] = f"estimated {need / 2**30:.0f} GiB of materialised tensors, {free / 2**30:.0f} GiB available"
+                continue
             rates = []
-            with torch.no_grad():
-                ro.batchified_composer_call(cfg, gsd, *[v[..., :1000, :] if v.dim() == 5 and v.size(-2) > 1000 else v for v in gin],
-                                            False, chunk=chunk)   # warm-up
-                for _ in range(repeats):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
-                    torch.cuda.synchronize()
-                    rates.append(ref_side * ref_side / (time.perf_counter() - t0) / 1e6)
+            try:
+                with torch.no_grad():
+                    for i in range(6):                 # first run = warm-up of this chunk size's allocations
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        ro.batchified_composer_call(cfg, gsd, *gin, False, chunk=chunk)
+                        torch.cuda.synchronize()
+                        if i:
+                            rates.append(rays_total / (time.perf_counter() - t0) / 1e6)
+            except torch.OutOfMemoryError as e:
+                skipped[f"chunk_{chunk}"] = "out of memory: " + str(e)[:120]
+                torch.cuda.empty_cache()
+                continue
             graph[f"chunk_{chunk}"] = round(median(rates), 5)
             spread[f"chunk_{chunk}"] = {"runs": [round(r, 5) for r in rates], "min": round(min(rates), 5), "max": round(max(rates), 5)}
+            torch.cuda.empty_cache()
+        del gin, gsd
+        torch.cuda.empty_cache()
+        fastest = max(graph, key=graph.get)
         out["reference_graph_on_gpu"] = {
-            "value": graph["chunk_1000"], "unit": "Mrays/s",
-            "chunk_4000": graph["chunk_4000"],
-            "protocol": "1 warm-up, median of 5 runs per chunk size", "spread": spread,
+            "value": graph[fastest], "unit": "Mrays/s", "fastest": fastest,
+            "by_chunk": graph, "skipped": skipped,
+            "protocol": "all rays of the frame; per chunk size 1 warm-up run, then the median of 5 runs", "spread": spread,
             "sample": f"the oracle's restatement of the reference's op graph (materialised per-sample tensors, boolean compaction, "
-                      f"sort + gather compose) run by PyTorch-ROCm on this GPU, {ref_side * ref_side} rays of the same frame, "
-                      "1000-ray chunks as render_full_frame_* uses (4000-ray chunks beside it)",
-            "hip_over_reference_graph": round(gpu_mrays / graph["chunk_1000"], 1) if graph["chunk_1000"] > 0 else None,
-            "hip_over_reference_graph_chunk_4000": round(gpu_mrays / graph["chunk_4000"], 1) if graph["chunk_4000"] > 0 else None,
+                      f"sort + gather compose) run by PyTorch-ROCm on this GPU on all {rays_total} rays of the same frame; chunk_1000 is "
+                      "what render_full_frame_* uses (an RTX 8000 memory limit), the larger chunks are what this GPU's memory allows",
+            "hip_over_reference_graph": round(gpu_mrays / graph[fastest], 2),
+            "hip_over_reference_graph_note": "exact-fp32 headline / the FASTEST chunk size of the reference's graph on this GPU",
+            "hip_over_reference_graph_by_chunk": {k: round(gpu_mrays / v, 2) for k, v in graph.items()},
         }
 
     # ---- BASELINE.json configs[0] at full size: one 128x128 frame, one player object, 32 samples per ray, every

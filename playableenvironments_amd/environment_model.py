@@ -167,6 +167,10 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     origins = torch.empty((n, 3), dtype=torch.float32, device=dev)
     dirs = torch.empty((n, r, 3), dtype=torch.float32, device=dev)
     normals = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    if n * r == 0:
+        # an empty pixel list (a rank whose share of a small frame's tiles is empty): origins / normals from the matrices, no launch
+        origins, normals = m[:, :, 3].clone(), -m[:, :, 2]
+        return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
     lib = _lib.load()
     with torch.cuda.device(dev):      # the launch goes to the current device: it has to be the tensors' device
         _lib.check(lib.pr_camera_rays(n, r, height, width, 1 if per_frame else 0, m.data_ptr(), f.data_ptr(), rows.data_ptr(),

@@ -247,6 +247,8 @@ class _RenderFunction(torch.autograd.Function):
                                           st["workspace"].data_ptr(),
                                           st["workspace"].numel(), scratch.data_ptr(), scratch.numel(), stream),
                    "pr_render_backward")
+        for hook in composer.gradient_hooks:
+            hook(flat)
         lead = st["lead"]
         w_shape, s_shape, d_shape = ctx.shapes
         g_w2o = torch.zeros((N, 4, 4, K), **f32)
@@ -324,6 +326,10 @@ class ObjectComposer(nn.Module):
         #: ``extra_outputs`` only).  On a shipped 256x256 tennis frame the per-object maps are 4/5 of the compositing kernel's
         #: 344 MB of output.  Ignored (everything is produced) by differentiable / training calls.
         self.object_entry_fields: Optional[Tuple[str, ...]] = None
+        #: callables invoked by the autograd node of a differentiable call with the flat fp32 buffer that every parameter gradient
+        #: of the call is a view of, right after ``pr_render_backward`` is enqueued (parallel.OverlappedGradientAllReduce starts the
+        #: gradient all-reduce from here, so that it overlaps the rest of ``backward()``)
+        self.gradient_hooks: List = []
 
     def _raise_pending_batchnorm_check(self):
         if torch.cuda.is_current_stream_capturing():
@@ -406,7 +412,7 @@ class ObjectComposer(nn.Module):
         # copy.deepcopy / pickle (EMA helpers, swa_utils.AveragedModel): the caches hold ctypes structures with raw pointers
         # (not picklable) and device scratch that a copy must not share
         state = dict(self.__dict__)
-        state.update(_packed={}, _param_lists={}, _structs={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
+        state.update(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
                      _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None, _host_step=None)
         return state
 

@@ -182,6 +182,46 @@ def allreduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None, av
     return len(buckets)
 
 
+class OverlappedGradientAllReduce:
+    """Starts the all-reduce of the renderer's parameter gradients from INSIDE ``backward()``: ``ObjectComposer``'s autograd node
+    calls its ``gradient_hooks`` with the flat buffer all its parameter gradients are views of, as soon as ``pr_render_backward`` is
+    enqueued - i.e. before autograd walks on into whatever produced the renderer's inputs (the object / pose encoders' CNN backward in
+    the reference's trainers, training/trainer.py).  The collective runs on the backend's stream behind the renderer's kernels and
+    overlaps that tail; ``finish()`` (call it where ``allreduce_gradients`` would go, before ``optimizer.step()``) waits for it and
+    averages.  One flat message: a ring over point-to-point xGMI links is per-link bound, few large collectives are the cheap ones.
+
+    >>> overlap = OverlappedGradientAllReduce(model.object_composer)
+    >>> loss.backward(); overlap.finish(); allreduce_gradients(other_parameters); optimizer.step()"""
+
+    def __init__(self, composer, group=None, average: bool = True):
+        self.group, self.average = group, average
+        self.pending: List[tuple] = []
+        self.launched = 0
+        composer.gradient_hooks.append(self._launch)
+        self._composer = composer
+
+    def _launch(self, flat: torch.Tensor) -> None:
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+        self.launched += 1
+
+    def finish(self) -> int:
+        """Waits for the collectives started since the last call (the current stream waits, not the host) and averages; returns
+        how many there were."""
+        done = len(self.pending)
+        for work, flat in self.pending:
+            work.wait()
+            if self.average:
+                flat /= dist.get_world_size(self.group)
+        self.pending = []
+        return done
+
+    def remove(self) -> None:
+        if self._launch in self._composer.gradient_hooks:
+            self._composer.gradient_hooks.remove(self._launch)
+
+
 def _shared_gradient_buffer(params: List[torch.nn.Parameter]):
     """The flat fp32 tensor behind the gradients when they are consecutive contiguous views of one storage (what
     ObjectComposer's backward produces), else None."""

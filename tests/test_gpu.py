@@ -2074,41 +2074,80 @@ def test_render_sharded_and_async_gather_rccl_world1():
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, port, results):
+def _rank_worker(rank, world, port, results):
     import torch.distributed as dist
+    from playableenvironments_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ok = True
-        for batch, shard in ((3, "frames"), (1, "rays"), (2, "auto"), (1, "tiles"), (1, "auto"), (2, "tiles")):
+        cases = ((3, "frames"), (1, "rays"), (2, "auto"), (1, "tiles"), (1, "auto"), (2, "tiles")) if world == 2 else \
+                ((8, "frames"), (11, "frames"), (1, "tiles"), (1, "rays"), (3, "auto"))
+        for batch, shard in cases:
             model, args = _tennis_model_and_args(batch=batch)
             with torch.no_grad():
                 whole = model(*args, 0, False, patch_stride=[4, 8], mode="scene_encodings")
             out = model.render_sharded(*args, False, patch_stride=[4, 8], shard=shard, fields=("integrated_features", "opacity"))
             for field in ("integrated_features", "opacity"):
                 ok = ok and torch.equal(out["coarse"]["global"][field], whole["coarse"]["global"][field])
+            # the evaluator's flow: only the consumer rank receives the maps
+            only = model.render_sharded(*args, False, patch_stride=[4, 8], shard=shard, fields=("integrated_features",), dst=0)
+            ok = ok and ((only is None) if rank else torch.equal(only["coarse"]["global"]["integrated_features"],
+                                                                  whole["coarse"]["global"]["integrated_features"]))
+        # data-parallel training step: every rank differentiates its own frame, the flat gradient buffer is reduced by a collective
+        # started inside backward() (parallel.OverlappedGradientAllReduce); result = the mean of the ranks' single-rank gradients
+        model, _ = _tennis_model_and_args(batch=1)
+        comp = model.object_composer.train()
+        overlap = parallel.OverlappedGradientAllReduce(comp)
+        cfg = comp.config
+
+        def gradients(frame, reduce):
+            scene = synthetic.tennis_scene(seed=900 + frame, image_size=(32, 48))
+            inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(32, 48, 10))]
+            for q in comp.parameters():
+                q.grad = None
+            state = {k: v.clone() for k, v in comp.state_dict().items()}
+            out = comp(*inputs, False)
+            out["coarse"]["global"]["integrated_features"].square().mean().backward()
+            started = overlap.finish() if reduce else len(overlap.pending)
+            if not reduce:
+                for work, _ in overlap.pending:      # (single-rank reference passes: complete and discard the collective)
+                    work.wait()
+                overlap.pending = []
+            comp.load_state_dict(state)              # (train-mode BatchNorm moved the running statistics)
+            return torch.cat([q.grad.reshape(-1) for q in comp.parameters()]).clone(), started
+        mine, started = gradients(rank, reduce=True)
+        ok = ok and started == 1
+        overlap.remove()
+        singles = [gradients(r, reduce=False)[0] for r in range(world)]
+        want = torch.stack(singles).mean(0)
+        scale = float(want.abs().max())
+        ok = ok and float((mine - want).abs().max()) <= 2e-5 * scale
         results[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
 
 
-def test_render_sharded_two_ranks_on_one_gpu_gloo():
-    """Two ranks (gloo) sharing the box's GPU: frame shards (3 frames over 2 ranks), contiguous ray shards and 8 x 8-pixel tiles
-    dealt round robin (a single frame's default) - the HIP renderer's assembled feature maps equal the unsharded render bit for
-    bit on both ranks."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_render_sharded_ranks_on_one_gpu_gloo(world):
+    """Two / eight ranks (gloo) sharing the box's GPU - what the driver's 8-GPU run does with one GPU each: frame shards (ragged:
+    3 frames over 2 ranks, 11 over 8), contiguous ray shards and 8 x 8-pixel tiles dealt round robin (a single frame's default),
+    gathered on every rank and on rank 0 only - the HIP renderer's assembled feature maps equal the unsharded render bit for bit
+    on every rank; and a data-parallel step whose gradient all-reduce starts inside backward() returns the mean of the ranks'
+    single-rank gradients."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     results = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, results)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, results)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
-    assert results[0] and results[1]
+    assert all(results[r] for r in range(world)), dict(results)
 
 
 def test_bench_self_launches_two_ranks():
