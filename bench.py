@@ -254,7 +254,7 @@ def train_traffic():
             "traffic_from_this_library": pmc.get("library_sha256") == library_sha256()}
 
 
-def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
+def train_step_leg(args, dev, world, rank, dist, lib, arena=True, precision="fp32"):
     """Secondary figure (never the headline): one data-parallel training step of the renderer in the shape of
     BASELINE.json configs[4] / SURVEY.md C5 - minecraft, 3 frames per GPU, one 48x48 patch at strides [4, 8] per frame
     (2880 rays), perturb=True, train-mode BatchNorm, forward + backward (pr_render_backward) + gradient all-reduce
@@ -278,6 +278,7 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True):
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
     comp = model.object_composer
+    comp.precision = precision      # "f16x3": split-precision backward products (bf16 triples) behind the exact fp32 forward
     # the optimiser works on the composer's parameter ARENA (parallel.flatten_parameters: every parameter a view of one flat
     # tensor - names, state_dict and values unchanged; Adam is element-wise, so the update is bit for bit the per-tensor one):
     # one fused launch instead of a multi-tensor sweep over 170 tensors.  arena=False: torch's Adam on the separate tensors.

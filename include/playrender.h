@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PR_ABI_VERSION 4
+#define PR_ABI_VERSION 5
 #define PR_MAX_OBJECTS 8
 #define PR_MAX_LAYERS 12
 #define PR_MAX_OCTAVES 16
@@ -80,6 +80,12 @@ typedef enum pr_status {
                                         they are composited (object_composer.py:548-549, :573-574; RGB-output models).  Applied
                                         where the compositing kernel reads a feature row; samples without a row (outside the box:
                                         raw feature 0) composite sigmoid(0) = 0.5 wherever their weight is not zero. */
+#define PR_FLAG_SPLIT_BACKWARD 1024u /* differentiable calls (with PR_FLAG_SAVE_FOR_BACKWARD, on the forward AND the backward call; ABI 5):
+                                       the matrix products of pr_render_backward in split precision - every fp32 operand as three bf16
+                                       terms (exactly: 8 + 8 + 8 mantissa bits, fp32 exponent range), a product as the six bf16 MFMAs
+                                       whose terms are >= 2^-16 of it (the dropped terms are one fp32 rounding); fp32 accumulation.  The
+                                       forward pass and the packed weights stay PR_PRECISION_FP32.  Products that have no split kernel
+                                       run the exact fp32 one. */
 #define PR_FLAG_DIVERGENCE_GRAD 256u /* pr_backward_workspace_size / pr_render_backward: gradients of integrated_divergence are
                                        given (pr_entry_grads_t.integrated_divergence); the backward pass then differentiates the
                                        Hutchinson estimate e^T (d delta / dx) e through the ray bender (the reference's double

@@ -23,6 +23,7 @@ PR_FLAG_GATE_HEAD = 64
 PR_FLAG_DEVICE_NOISE = 128
 PR_FLAG_DIVERGENCE_GRAD = 256
 PR_FLAG_SIGMOID_FEATURES = 512
+PR_FLAG_SPLIT_BACKWARD = 1024
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
 PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect
@@ -201,8 +202,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.pr_abi_version() != 4:
-        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 4 (rebuild: make -C playableenvironments_amd/csrc)")
+    if lib.pr_abi_version() != 5:
+        raise RuntimeError(f"libplayrender ABI version {lib.pr_abi_version()} != 5 (rebuild: make -C playableenvironments_amd/csrc)")
     _LIB = lib
     return lib
 

@@ -2274,6 +2274,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         tn.count = std::min(TN_ALL_MAX, tn_count - begin);
         memcpy(tn.job, tn_jobs + begin, sizeof(TnJob) * tn.count);
         tn.counters = counters + 4 * PR_MAX_OBJECTS + 8 * chunk;
+        tn.split_precision = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 1 : 0;
         PR_TRY(launch_gemm_tn_all(tn, tn_rows + begin, s));
     }
     hipLaunchKernelGGL(k_style_bwd_group, dim3(style_blocks, style_jobs), dim3(256), 0, s, sj);

@@ -529,6 +529,230 @@ __global__ __launch_bounds__(256, PR_TNALL_WGS) void k_gemm_tn_all(TnAll g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same work item in SPLIT precision (pr_call_t.precision = PR_PRECISION_F16X3 on a differentiable call): every fp32 operand
+// as THREE bf16 terms, x = b1 + b2 + b3 EXACTLY (each term the truncated top 8 significant bits of what is left: 8 + 8 + 8 = the 24
+// bits of an fp32 mantissa, with the fp32 exponent range - gradients of 1e-7 are as well represented as activations of 1, which
+// an fp16 pair is not), and a product as the SIX bf16 MFMAs whose terms are >= 2^-16 of it:
+//     a b ~ a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2        (dropped: a2 b3 + a3 b2 + a3 b3 <= 3 x 2^-24 |a b|, one fp32 rounding)
+// v_mfma_f32_32x32x16_bf16 multiplies exactly and accumulates in fp32; it retires 16 K-values in 32 cycles where the fp32 pipe
+// needs 8 x 64: six of them cost 192 against 512 cycles.  The reduction index of dW = dY^T X is the SLOW dimension of both
+// operands in memory; the bf16 MFMA wants eight consecutive K-values per lane, so a slab is transposed on its way into LDS:
+// planes T[column][k] (80-byte rows: five 16-byte slots, conflict-free b128 fragment reads), a thread's four rows of a column
+// = four consecutive k (one 8-byte store per plane and column; the same k permutation for both operands), slots rotated by
+// (column >> 4) & 3 so that the 32 lanes of a store instruction spread over the banks.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TROW = 80;                       // bytes per LDS row of a plane: 32 k-values + one 16-byte pad slot
+constexpr int TPLANE = GT * TROW;              // one plane of one operand
+#define PR_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
+
+// x = b1 + b2 + b3 (bf16 terms in the high halves of p1, p2, p3)
+__device__ __forceinline__ void bf16_split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(p1);          // exact
+    p2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(p2);         // exact; at most 8 significant bits are left
+    p3 = __float_as_uint(r2);
+}
+
+__device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int split, unsigned char* T, float* RED) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
+    const int M = *p.rows;
+    const int tiles_j = (p.nj + GT - 1) / GT;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * GT, j0 = tj * GT;
+    const int m_begin = split * TN_ALL_CHUNK;
+    const int m_end = (m_begin + TN_ALL_CHUNK < M) ? m_begin + TN_ALL_CHUNK : M;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const bool want_bias = p.bias_partial && tj == 0;
+    const bool side = p.w != nullptr && ti == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f}, wtot = 0.f;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const bool acol = i0 + 4 * c4 < ((p.ni + 3) & ~3), bcol = j0 + 4 * c4 < ((p.nj + 3) & ~3);
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    float w0[4], w1[4];
+    const float* __restrict__ gA = p.A + i0 + 4 * c4;
+    const float* __restrict__ gB = p.B + j0 + 4 * c4;
+    const size_t lda = (size_t)p.lda, ldb = (size_t)p.ldb;
+    auto fetch = [&](float4 (&ra)[4], float4 (&rb)[4], float (&wv)[4], int m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + rr + 8 * i;
+            const bool live = m < m_end;
+            ra[i] = (live && acol) ? *reinterpret_cast<const float4*>(gA + (size_t)m * lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = (live && bcol) ? *reinterpret_cast<const float4*>(gB + (size_t)m * ldb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (side) wv[i] = live ? p.w[(size_t)m * p.ldw] : 0.f;
+        }
+    };
+    // the three planes of one operand: column c (of the tile), this thread's four k = 4 rr .. 4 rr + 3
+    auto put = [&](unsigned char* planes, int c, float v0, float v1, float v2, float v3) {
+        unsigned a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
+        bf16_split3(v0, a1, a2, a3);
+        bf16_split3(v1, b1, b2, b3);
+        bf16_split3(v2, c1, c2, c3);
+        bf16_split3(v3, d1, d2, d3);
+        const int at = c * TROW + ((((rr >> 1) + (c >> 4)) & 3) << 4) + ((rr & 1) << 3);
+        // (v_perm_b32: the high halves of two words side by side)
+        *reinterpret_cast<uint2*>(planes + at) = make_uint2(__builtin_amdgcn_perm(b1, a1, 0x07060302u), __builtin_amdgcn_perm(d1, c1, 0x07060302u));
+        *reinterpret_cast<uint2*>(planes + TPLANE + at) = make_uint2(__builtin_amdgcn_perm(b2, a2, 0x07060302u), __builtin_amdgcn_perm(d2, c2, 0x07060302u));
+        *reinterpret_cast<uint2*>(planes + 2 * TPLANE + at) = make_uint2(__builtin_amdgcn_perm(b3, a3, 0x07060302u), __builtin_amdgcn_perm(d3, c3, 0x07060302u));
+    };
+    auto stage = [&](const float4 (&ra)[4], const float4 (&rb)[4], const float (&wv)[4]) {
+        put(T, 4 * c4 + 0, ra[0].x, ra[1].x, ra[2].x, ra[3].x);
+        put(T, 4 * c4 + 1, ra[0].y, ra[1].y, ra[2].y, ra[3].y);
+        put(T, 4 * c4 + 2, ra[0].z, ra[1].z, ra[2].z, ra[3].z);
+        put(T, 4 * c4 + 3, ra[0].w, ra[1].w, ra[2].w, ra[3].w);
+        put(T + 3 * TPLANE, 4 * c4 + 0, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
+        put(T + 3 * TPLANE, 4 * c4 + 1, rb[0].y, rb[1].y, rb[2].y, rb[3].y);
+        put(T + 3 * TPLANE, 4 * c4 + 2, rb[0].z, rb[1].z, rb[2].z, rb[3].z);
+        put(T + 3 * TPLANE, 4 * c4 + 3, rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bsum[0] += ra[i].x; bsum[1] += ra[i].y; bsum[2] += ra[i].z; bsum[3] += ra[i].w; }
+        }
+        if (side) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wsum[0] = fmaf(wv[i], rb[i].x, wsum[0]); wsum[1] = fmaf(wv[i], rb[i].y, wsum[1]);
+                wsum[2] = fmaf(wv[i], rb[i].z, wsum[2]); wsum[3] = fmaf(wv[i], rb[i].w, wsum[3]);
+                wtot += wv[i];
+            }
+        }
+    };
+    // fragment addresses: lane (r, half) of block `blk` reads column base + blk * 32 + r, logical slot 2 kb + half
+    const int colA0 = wr * 64 + r, colB0 = wc * 64 + r;
+    auto step = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int ca = colA0 + blk * 32, cb = colB0 + blk * 32;
+                const int oa = ca * TROW + (((2 * kb + half + (ca >> 4)) & 3) << 4);
+                const int ob = cb * TROW + (((2 * kb + half + (cb >> 4)) & 3) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a[blk][pl] = *reinterpret_cast<const bf16x8*>(T + pl * TPLANE + oa);
+                    b[blk][pl] = *reinterpret_cast<const bf16x8*>(T + (3 + pl) * TPLANE + ob);
+                }
+            }
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    // smallest terms first
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[cb][1]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][2]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][2], b[cb][0]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][1]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[cb][0]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][0]);
+                }
+        }
+    };
+    if (m_begin < m_end) {
+        fetch(ra0, rb0, w0, m_begin);
+        fetch(ra1, rb1, w1, m_begin + GK);
+        stage(ra0, rb0, w0);
+    }
+    __syncthreads();
+    for (int m0 = m_begin; m0 < m_end; m0 += 2 * GK) {
+        fetch(ra0, rb0, w0, m0 + 2 * GK);       // (rows beyond m_end read nothing)
+        step();
+        __syncthreads();
+        if (m0 + GK >= m_end) break;
+        stage(ra1, rb1, w1);
+        __syncthreads();
+        fetch(ra1, rb1, w1, m0 + 3 * GK);
+        step();
+        __syncthreads();
+        if (m0 + 2 * GK < m_end) stage(ra0, rb0, w0);
+        __syncthreads();
+    }
+    const int ldp = tiles_j * GT;
+    const int rows_p = ((p.ni + GT - 1) / GT) * GT;
+    float* P = p.partial + (size_t)split * rows_p * ldp;
+#pragma unroll
+    for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = j0 + wc * 64 + cb * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                P[(size_t)row * ldp + col] = acc[rb2][cb][i];
+            }
+        }
+    // column sums kept per thread (its 4 columns, the rows it staged): added over the 8 row groups in a fixed order
+    if (want_bias || side) {
+        __syncthreads();
+        float* R = RED;                                  // [8 row groups][128 columns] bias, then the same for the side product
+        if (want_bias) for (int e = 0; e < 4; ++e) R[rr * GT + 4 * c4 + e] = bsum[e];
+        if (side) {
+            for (int e = 0; e < 4; ++e) R[8 * GT + rr * GT + 4 * c4 + e] = wsum[e];
+            if (c4 == 0) R[16 * GT + rr] = wtot;
+        }
+        __syncthreads();
+        if (want_bias && tid < GT) {
+            float v = 0.f;
+            for (int g8 = 0; g8 < 8; ++g8) v += R[g8 * GT + tid];
+            p.bias_partial[(size_t)split * rows_p + i0 + tid] = v;
+        }
+        if (side && tid >= GT) {
+            float* W = p.w_partial + (size_t)split * (ldp + 4);
+            float v = 0.f;
+            for (int g8 = 0; g8 < 8; ++g8) v += R[8 * GT + g8 * GT + tid - GT];
+            W[j0 + tid - GT] = v;
+            if (tid == GT && tj == 0) {
+                float t = 0.f;
+                for (int g8 = 0; g8 < 8; ++g8) t += R[16 * GT + g8];
+                W[ldp] = t;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_all_bf16(TnAll g) {
+    __shared__ __attribute__((aligned(16))) unsigned char T[6 * TPLANE];
+    __shared__ float RED[16 * GT + 8];
+    __shared__ int pair_begin[TN_ALL_MAX + 1];
+    __shared__ int claimed;
+    const int tid = threadIdx.x;
+    if (tid < g.count) pair_begin[tid + 1] = tn_all_splits(*g.job[tid].rows);
+    __syncthreads();
+    if (tid == 0) {
+        int at = 0;
+        for (int q = 0; q < g.count; ++q) {
+            const int n = pair_begin[q + 1];
+            pair_begin[q] = at;
+            at += n;
+        }
+        pair_begin[g.count] = at;
+    }
+    __syncthreads();
+    const int total_pairs = pair_begin[g.count];
+    const int xcd = blockIdx.x & 7;
+    int job = 0;
+    for (;;) {
+        if (tid == 0) claimed = atomicAdd(g.counters + xcd, 1);
+        __syncthreads();
+        const int c = claimed;
+        __syncthreads();
+        const int pair = (c / TN_ALL_TILES) * 8 + xcd;
+        if (pair >= total_pairs) break;
+        const int tile = c % TN_ALL_TILES;
+        while (pair >= pair_begin[job + 1]) ++job;
+        const TnJob& p = g.job[job];
+        const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+        if (tile >= tiles) continue;
+        tn_all_tile_bf16(p, tile, pair - pair_begin[job], T, RED);
+        __syncthreads();
+    }
+}
+
 // C[i][j] += sum over the jobs of this destination (job order), sum over their splits (split order); the same for the biases
 __global__ __launch_bounds__(256) void k_gemm_tn_all_reduce(TnAll g) {
     const TnJob& head = g.job[blockIdx.y];
@@ -625,9 +849,14 @@ int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
                 break;
             }
     int cus = 0;
-    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all), 0, &cus));
     ProfileScope scope(3, s);
-    hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * PR_TNALL_WGS), dim3(256), 0, s, g);
+    if (g.split_precision) {
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all_bf16), 0, &cus));
+        hipLaunchKernelGGL(k_gemm_tn_all_bf16, dim3(cus * 2), dim3(256), 0, s, g);
+    } else {
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all), 0, &cus));
+        hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * PR_TNALL_WGS), dim3(256), 0, s, g);
+    }
     PR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gemm_tn_all_reduce, dim3((unsigned)((max_elems + 255) / 256), g.count), dim3(256), 0, s, g);
     PR_LAUNCH_CHECK();

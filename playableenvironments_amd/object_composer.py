@@ -291,8 +291,11 @@ class ObjectComposer(nn.Module):
         self._linspace: Dict[tuple, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
-        #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3": every product as three fp16 MFMAs with
-        #: fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant bits) - eval only.
+        #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3" (split precision): evaluation renders compute every product
+        #: as three fp16 MFMAs with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant
+        #: bits); differentiable / training calls keep the exact fp32 FORWARD kernels (train-mode BatchNorm phases, saved activations)
+        #: and run the BACKWARD pass's matrix products on bf16 triples (x = b1 + b2 + b3 exactly, six bf16 MFMAs per product, fp32
+        #: accumulation: PR_FLAG_SPLIT_BACKWARD) where a split kernel exists - gradients agree with the fp32 path to fp32 round-off.
         self.precision = "fp32"
         self._warned_precision_fallback = False
         #: sigma-gated feature head (PR_FLAG_GATE_HEAD): evaluation renders skip the feature head of samples whose raw density
@@ -518,11 +521,8 @@ class ObjectComposer(nn.Module):
         if self.precision not in ("fp32", "f16x3"):
             raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32' or 'f16x3')")
         if self.precision == "f16x3" and (self.training or differentiable):
-            if not self._warned_precision_fallback:
-                self._warned_precision_fallback = True
-                warnings.warn("precision='f16x3' applies to evaluation renders; training-mode and differentiable calls run "
-                              "on the exact fp32 kernel (train-mode BatchNorm phases and saved activations exist there only)",
-                              stacklevel=3)
+            # the forward pass of training / differentiable calls runs the exact fp32 kernels (train-mode BatchNorm phases, saved
+            # activations) on fp32-packed weights; "f16x3" selects the split-precision BACKWARD products for them (_render)
             return _lib.PR_PRECISION_FP32
         return _lib.PR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.PR_PRECISION_FP32
 
@@ -745,6 +745,8 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_TRAIN_BN
         if _save:
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
+            if self.precision == "f16x3":
+                flags |= _lib.PR_FLAG_SPLIT_BACKWARD     # the backward pass's matrix products as bf16 triples (six MFMAs per product)
         if self.gate_feature_head:
             flags |= _lib.PR_FLAG_GATE_HEAD      # honoured by the library for unperturbed evaluation calls only
 

@@ -177,7 +177,7 @@ def test_library_exports_every_declared_symbol(built_library):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(built_library, name) is not None
-    assert built_library.pr_abi_version() == 4
+    assert built_library.pr_abi_version() == 5
 
 
 def test_struct_sizes_match_header_layout():

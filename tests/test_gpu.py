@@ -495,11 +495,12 @@ def _probe_loss(results, probes, K):
 
 
 def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True, rays=False,
-               min_divergence=1e-2, absent=None, exact=False, noise_seed=123):
+               min_divergence=1e-2, absent=None, exact=False, noise_seed=123, precision="fp32"):
     """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``; ``rays``: also
     with respect to the camera rays (ray_origins, ray_directions).  ``exact``: a third entry per tensor - the oracle's
     autograd in float64 on the same weights, inputs and replayed noise (the arbiter of ill-conditioned cases)."""
-    comp = build(cfg, alpha_bias=bias).train(training)
+    # precision "f16x3": the split-precision BACKWARD (bf16 triples, PR_FLAG_SPLIT_BACKWARD) behind the exact fp32 forward
+    comp = build(cfg, alpha_bias=bias, precision=precision).train(training)
     inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
     o, d, nrm, w2o, sty, dfm, ins = inputs
     if absent is not None:           # (object index, frame index or None = every frame) marked absent
@@ -582,7 +583,8 @@ HIER_POSITIONS = {"background": (8, 12), "background_backplate": (8, 12), "playe
 @pytest.mark.parametrize("name,perturb", [("tennis", False), ("tennis", True), ("minecraft", False), ("minecraft", True),
                                           ("tennis_frames", True), ("tennis_hierarchical", False),
                                           ("tennis_hierarchical", True)])
-def test_backward_matches_oracle_autograd(name, perturb):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_backward_matches_oracle_autograd(name, perturb, precision):
     """Every parameter gradient, d style, d deformation and d transformation_matrix_w2o against torch.autograd
     through the oracle (train mode, replayed noise), on shallow networks where the comparison is well conditioned:
     max |difference| <= 1e-4 * max |reference| per tensor."""
@@ -597,7 +599,7 @@ def test_backward_matches_oracle_autograd(name, perturb):
         scene, n, bias = synthetic.tennis_scene(seed=5), 14, 2.0
     else:
         cfg, scene, n, bias = configs.reduced_config(configs.tennis_config(), **SMALL_NETS), synthetic.tennis_scene(), 16, 2.0
-    grads = _gradients(cfg, scene, n, bias, perturb)
+    grads = _gradients(cfg, scene, n, bias, perturb, precision=precision)
     assert len(grads) > 50
     # the fine pass places its samples by inverse-CDF resampling of the coarse weights, so fp32 round-off of the coarse
     # pass moves fine samples: perturbing the resampling variates by 1e-6 moves the ORACLE's own gradients by 6e-5 and
@@ -820,13 +822,14 @@ def test_backward_in_eval_mode_with_frozen_batchnorm(name, perturb):
     assert nonzero > 40
 
 
-def test_backward_full_size_networks():
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_backward_full_size_networks(precision):
     """Shipped network sizes (8 x 256 backbone, 6 x 128 bender, F = 192, two frames).  Deep ReLU / BatchNorm stacks on
     a few hundred samples are ill-conditioned - the ORACLE's own gradients move by up to 6e-3 (relative, max norm)
     when its weights are perturbed by one ulp (measured) - so the case is ARBITRATED in float64: per
     gradient tensor, max |HIP - fp64| <= 4 x max |fp32 oracle autograd - fp64| (+ 1e-6 of the tensor's largest entry)."""
     cfg = configs.minecraft_config()
-    grads = _gradients(cfg, synthetic.minecraft_scene(batch=2, seed=8), 14, 3.0, True, exact=True)
+    grads = _gradients(cfg, synthetic.minecraft_scene(batch=2, seed=8), 14, 3.0, True, exact=True, precision=precision)
     bad, worst = {}, 0.0
     for k, (a, b, e) in grads.items():
         err_hip, err_ref = float((b.double() - e).abs().max()), float((a.double() - e).abs().max())
@@ -874,7 +877,8 @@ from tests.test_cpu import GRAD_GOLDEN, load_gradient_fixture, probe_loss  # noq
 
 
 @pytest.mark.parametrize("path", GRAD_GOLDEN, ids=[os.path.basename(p)[:-4] for p in GRAD_GOLDEN])
-def test_backward_matches_reference_gradient_fixtures(path):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_backward_matches_reference_gradient_fixtures(path, precision):
     """HIP forward + backward against gradients recorded from the reference's own autograd (tests/golden/grads):
     max |difference| <= 1e-4 * max |reference| per tensor."""
     recipe, inputs, sd, noise, want, perturb, probes, grads = load_gradient_fixture(path)
@@ -882,6 +886,7 @@ def test_backward_matches_reference_gradient_fixtures(path):
     comp = ObjectComposer(cfg)
     comp.load_state_dict(sd, strict=True)
     comp = comp.cuda().train()
+    comp.precision = precision          # "f16x3": the split-precision backward products behind the fp32 forward
     leaf = [inputs[i].clone().cuda().requires_grad_(True) for i in (3, 4, 5)]
     got = comp(*[v.cuda() for v in inputs[:3]], *leaf, inputs[6].cuda(), perturb, _noise=noise if perturb else None)
     probe_loss(got, probes).backward()

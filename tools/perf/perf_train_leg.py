@@ -24,7 +24,7 @@ def main():
                                  warmup=int(sys.argv[2]) if len(sys.argv) > 2 else 5)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    out = bench.train_step_leg(args, dev, 1, 0, None, _lib.load())
+    out = bench.train_step_leg(args, dev, 1, 0, None, _lib.load(), precision=os.environ.get("PR_PERF_PRECISION", "fp32"))
     print(json.dumps(out))
 
 
