@@ -625,34 +625,39 @@ __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int s
     // fragment addresses: lane (r, half) of block `blk` reads column base + blk * 32 + r, logical slot 2 kb + half
     const int colA0 = wr * 64 + r, colB0 = wc * 64 + r;
     auto step = [&]() {
-#pragma unroll
+        // (one K block of 16 at a time, the B fragments of one column block at a time: 24 + 12 fragment registers live instead of
+        // 96 - with everything hoisted the kernel spilled)
+#pragma unroll 1
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 a[2][3], b[2][3];
+            bf16x8 a[2][3];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const int ca = colA0 + blk * 32, cb = colB0 + blk * 32;
+                const int ca = colA0 + blk * 32;
                 const int oa = ca * TROW + (((2 * kb + half + (ca >> 4)) & 3) << 4);
-                const int ob = cb * TROW + (((2 * kb + half + (cb >> 4)) & 3) << 4);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    a[blk][pl] = *reinterpret_cast<const bf16x8*>(T + pl * TPLANE + oa);
-                    b[blk][pl] = *reinterpret_cast<const bf16x8*>(T + (3 + pl) * TPLANE + ob);
-                }
+                for (int pl = 0; pl < 3; ++pl) a[blk][pl] = *reinterpret_cast<const bf16x8*>(T + pl * TPLANE + oa);
             }
 #pragma unroll
-            for (int rb2 = 0; rb2 < 2; ++rb2)
+            for (int cb = 0; cb < 2; ++cb) {
+                const int cc = colB0 + cb * 32;
+                const int ob = cc * TROW + (((2 * kb + half + (cc >> 4)) & 3) << 4);
+                bf16x8 b[3];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(T + (3 + pl) * TPLANE + ob);
+#pragma unroll
+                for (int rb2 = 0; rb2 < 2; ++rb2) {
                     // smallest terms first
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[cb][1]);
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][2]);
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][2], b[cb][0]);
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][1]);
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[cb][0]);
-                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[cb][0]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[1]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[2]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][2], b[0]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[1]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][1], b[0]);
+                    PR_MFMA_BF16(acc[rb2][cb], a[rb2][0], b[0]);
                 }
+            }
         }
     };
+#ifdef PR_TNBF_TWO_SLABS
     if (m_begin < m_end) {
         fetch(ra0, rb0, w0, m_begin);
         fetch(ra1, rb1, w1, m_begin + GK);
@@ -672,6 +677,23 @@ __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int s
         if (m0 + 2 * GK < m_end) stage(ra0, rb0, w0);
         __syncthreads();
     }
+#else
+    // ONE slab in flight in registers (requested before the current slab's MFMAs, staged behind them): the launch is bound by
+    // its operand traffic, and a second register set made the kernel spill
+    (void)ra1; (void)rb1; (void)w1;
+    if (m_begin < m_end) {
+        fetch(ra0, rb0, w0, m_begin);
+        stage(ra0, rb0, w0);
+    }
+    __syncthreads();
+    for (int m0 = m_begin; m0 < m_end; m0 += GK) {
+        fetch(ra0, rb0, w0, m0 + GK);           // (rows beyond m_end read nothing)
+        step();
+        __syncthreads();
+        if (m0 + GK < m_end) stage(ra0, rb0, w0);
+        __syncthreads();
+    }
+#endif
     const int ldp = tiles_j * GT;
     const int rows_p = ((p.ni + GT - 1) / GT) * GT;
     float* P = p.partial + (size_t)split * rows_p * ldp;
