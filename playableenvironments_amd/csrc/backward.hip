@@ -2051,6 +2051,10 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         float* dscale2 = tables + (size_t)c.frames * 2 * MAX_WIDTH;
         float* dbias2 = tables + (size_t)c.frames * 3 * MAX_WIDTH;
         const int frozen = (c.flags & PR_FLAG_TRAIN_BN) ? 0 : 1;
+        const int split_bwd = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 1 : 0;      // products on bf16 triples (t3_* segments)
+        // (the two head phases keep the fp32 product: with the phase's raw-activation prefetch registers the bf16 variant of
+        // k_head_bwd_group spills 125 VGPRs; they are 0.4 ms of the step)
+        const int split_head = 0;
         float lo[3], hi[3], size[3];
         bbox_split(m, lo, hi, size);
         const int nb = m.backbone_count;
@@ -2062,7 +2066,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         a.phase = 1; a.frozen = frozen; a.stat_count = stat_count; a.eps = m.bn_eps;
         a.table = table; a.table_stride = table_stride; a.goff = 2 * d.Wpad; a.boff = 2 * d.Wpad + d.W2pad;
         a.g_in = g_feat; a.ld_gin = Fs; a.k_real = F; a.kpad = d.Fpad;
-        a.wt = Seg{packed + l.t_h6, d.Fpad / 8, 0}; a.nblk = d.W2pad / 32;
+        a.wt = Seg{packed + (split_head ? l.t3_h6 : l.t_h6), d.Fpad / 8, 0}; a.nblk = d.W2pad / 32; a.split = split_head;
         a.h = h2v; a.ld = d.W2pad; a.mean = batch + 2 * MAX_WIDTH; a.var = batch + 3 * MAX_WIDTH; a.width = d.W2;
         a.a_out = a2; a.d_out = d2; a.sums = sums; a.dscale = dscale2; a.dbias = dbias2;
         a.tile_counter = counters + 4 * k;
@@ -2073,7 +2077,7 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         b.g_in = nullptr;
         b.d_in = d2; b.h_in = h2v; b.mean_in = batch + 2 * MAX_WIDTH; b.var_in = batch + 3 * MAX_WIDTH; b.sums_in = sums; b.width_in = d.W2;
         b.kpad = d.W2pad;
-        b.wt = Seg{packed + l.t_h3, d.W2pad / 8, 0}; b.nblk = d.Wpad / 32;
+        b.wt = Seg{packed + (split_head ? l.t3_h3 : l.t_h3), d.W2pad / 8, 0}; b.nblk = d.Wpad / 32; b.split = split_head;
         b.h = h1v; b.ld = d.Wpad; b.mean = batch; b.var = batch + MAX_WIDTH; b.width = d.W;
         b.a_out = a1; b.d_out = d1; b.sums = sums + 2 * MAX_WIDTH; b.dscale = dscale1; b.dbias = dbias1;
         b.tile_counter = counters + 4 * k + 1;
@@ -2085,15 +2089,15 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         n.entry = 1;
         n.d1 = d1; n.h1 = h1v; n.mean1 = batch; n.var1 = batch + MAX_WIDTH; n.sums1 = sums + 2 * MAX_WIDTH;
         n.stat_count = stat_count; n.frozen = frozen; n.eps = m.bn_eps;
-        n.w0t = Seg{packed + l.t_h0, d.Wpad / 8, 0};
+        n.w0t = Seg{packed + (split_bwd ? l.t3_h0 : l.t_h0), d.Wpad / 8, 0}; n.split = split_bwd;
         n.g_sigma = reinterpret_cast<const float*>(bws + bp.g_sigma[k]);
         n.in_scene = rc.in_scene; n.in_scene_stride = K;
         n.w_sigma = m.kind == 0 ? m.alpha_head.weight : nullptr;
         n.gsr4 = gsr4;
         n.count = nb; n.skip = m.skip_layer_idx; n.W = d.W; n.Wpad = d.Wpad; n.in_pad = d.enc_pad; n.in_real = d.enc;
-        for (int i = 1; i < nb; ++i) n.act_t[i] = Seg{packed + l.t_n_act[i], d.Wpad / 8, 0};
-        n.in0_skip = Seg{packed + l.t_n_skip, d.Wpad / 8, 0};
-        n.in0_first = Seg{packed + l.t_n_first, d.Wpad / 8, 0};
+        for (int i = 1; i < nb; ++i) n.act_t[i] = Seg{packed + (split_bwd ? l.t3_n_act[i] : l.t_n_act[i]), d.Wpad / 8, 0};
+        n.in0_skip = Seg{packed + (split_bwd ? l.t3_n_skip : l.t_n_skip), d.Wpad / 8, 0};
+        n.in0_first = Seg{packed + (split_bwd ? l.t3_n_first : l.t_n_first), d.Wpad / 8, 0};
         n.bits = reinterpret_cast<const unsigned char*>(fws + sv.bits); n.bits_stride = relu_bits_bytes(cap, d.Wpad);
         n.gstack = gstack; n.g_stride = cap * (size_t)d.Wpad;
         n.g_in = g_enc; n.ld_in = d.enc_pad;
@@ -2175,9 +2179,10 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
             e.entry = 0;
             e.g_braw4 = g_braw4; e.w_out = m.bender_out.weight; e.w_out_ld = d.BW;
             e.count = bc; e.skip = m.bender_skip; e.W = d.BW; e.Wpad = d.BWpad; e.in_pad = d.bin_pad; e.in_real = d.bin;
-            for (int i = 1; i < bc; ++i) e.act_t[i] = Seg{packed + l.t_b_act[i], d.BWpad / 8, 0};
-            e.in0_skip = Seg{packed + l.t_b_skip, d.BWpad / 8, 0};
-            e.in0_first = Seg{packed + l.t_b_first, d.BWpad / 8, 0};
+            for (int i = 1; i < bc; ++i) e.act_t[i] = Seg{packed + (split_bwd ? l.t3_b_act[i] : l.t_b_act[i]), d.BWpad / 8, 0};
+            e.split = split_bwd;
+            e.in0_skip = Seg{packed + (split_bwd ? l.t3_b_skip : l.t_b_skip), d.BWpad / 8, 0};
+            e.in0_first = Seg{packed + (split_bwd ? l.t3_b_first : l.t_b_first), d.BWpad / 8, 0};
             e.bits = reinterpret_cast<const unsigned char*>(fws + sv.bbits); e.bits_stride = relu_bits_bytes(cap, d.BWpad);
             e.gstack = bgstack; e.g_stride = cap * (size_t)d.BWpad;
             e.g_in = g_benc; e.ld_in = d.bin_pad;

@@ -132,6 +132,19 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
     off += seg_floats(d.Wpad / 32, d.W2pad);
     l->t_h6 = off;
     off += seg_floats(d.W2pad / 32, d.Fpad);
+    // ... and as bf16 triples (split-precision backward): 3 planes x 2 bytes per weight = 1.5 floats
+    auto take3 = [&](int nblk, int kpad) { const int at = off; off += seg_floats(nblk, kpad) / 2 * 3; return at; };
+    if (m.has_bender) {
+        for (int j = 1; j < m.bender_count; ++j) l->t3_b_act[j] = take3(d.BWpad / 32, d.BWpad);
+        l->t3_b_skip = take3(d.bin_pad / 32, d.BWpad);
+        l->t3_b_first = take3(d.bin_pad / 32, d.BWpad);
+    }
+    for (int i = 1; i < m.backbone_count; ++i) l->t3_n_act[i] = take3(d.Wpad / 32, d.Wpad);
+    l->t3_n_skip = take3(d.enc_pad / 32, d.Wpad);
+    l->t3_n_first = take3(d.enc_pad / 32, d.Wpad);
+    l->t3_h0 = take3(d.Wpad / 32, d.Wpad);
+    l->t3_h3 = take3(d.Wpad / 32, d.W2pad);
+    l->t3_h6 = take3(d.W2pad / 32, d.Fpad);
     l->total = off;
     return PR_OK;
 }
@@ -146,14 +159,15 @@ struct PackJob {
     const float* src;
     float* dst;
     int kind;       // 0 = fp32 fragment-ordered matrix segment, 1 = padded vector / raw row copy,
-                    // 2 = fp16 hi/lo split fragments (same byte size as kind 0)
+                    // 2 = fp16 hi/lo split fragments (same byte size as kind 0), 3 = bf16 triples (1.5 x the size of kind 0; `count`
+                    // counts 32-bit words)
     int in_total;   // row stride of src
     int col_off;
     int k_real, n_real, kq, nblk;
     int count;      // elements of dst
     int transposed; // kind 0: element (n, k) is read from src[k * in_total + col_off + n] (the backward chain's W^T)
 };
-constexpr int MAX_PACK_JOBS = 112;
+constexpr int MAX_PACK_JOBS = 160;
 struct PackJobs {
     PackJob job[MAX_PACK_JOBS];
     int n;
@@ -198,6 +212,32 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
             }
             reinterpret_cast<unsigned int*>(j.dst)[idx] = (unsigned int)out[0] | ((unsigned int)out[1] << 16);
             continue;
+        } else if (j.kind == 3) {
+            // bf16 triples of a segment, w = b1 + b2 + b3 exactly (each term the truncated top 8 significant bits of what is left):
+            // word idx holds the elements e, e + 1 of [column block][K step of 16][plane][lane]; lane l carries
+            // W(n = nb*32 + (l & 31), k = 16 s + 8 (l >> 5) + e), e = 0..7 - the B fragment of v_mfma_f32_32x32x16_bf16
+            unsigned int out[2];
+            for (int t = 0; t < 2; ++t) {
+                const int h = idx * 2 + t;
+                const int e = h & 7;
+                const int lane = (h >> 3) & 63;
+                const int rest = h >> 9;
+                const int plane = rest % 3;
+                const int step = (rest / 3) % (j.kq >> 1);
+                const int nb = (rest / 3) / (j.kq >> 1);
+                const int n = nb * 32 + (lane & 31);
+                const int k = 16 * step + 8 * (lane >> 5) + e;
+                float w = 0.f;
+                if (n < j.n_real && k < j.k_real)
+                    w = j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k];
+                const unsigned int p1 = __float_as_uint(w) & 0xffff0000u;
+                const float r1 = w - __uint_as_float(p1);
+                const unsigned int p2 = __float_as_uint(r1) & 0xffff0000u;
+                const unsigned int p3 = __float_as_uint(r1 - __uint_as_float(p2));
+                out[t] = (plane == 0 ? p1 : (plane == 1 ? p2 : p3)) >> 16;
+            }
+            reinterpret_cast<unsigned int*>(j.dst)[idx] = out[0] | (out[1] << 16);
+            continue;
         } else {
             // rows of length kq (padded) from rows of length k_real; n_real rows
             const int row = idx / j.kq, c = idx % j.kq;
@@ -233,6 +273,15 @@ static int add_seg_t(PackJobs* js, const pr_linear_t& lin, int col_off, int k_re
     j.kind = 0;            // fp32 fragments in every packing (differentiable calls run on the exact kernel)
     j.n_real = n_real;
     j.transposed = 1;
+    return PR_OK;
+}
+
+// the same W^T segment as bf16 triples (kind 3)
+static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int n_real, int npad, float* dst) {
+    PR_TRY(add_seg_t(js, lin, col_off, k_real, kpad, n_real, npad, dst));
+    PackJob& j = js->job[js->n - 1];
+    j.kind = 3;
+    j.count = j.count / 2 * 3;      // 32-bit words: two bf16 each, three planes
     return PR_OK;
 }
 
@@ -329,6 +378,19 @@ static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const
     PR_TRY(add_seg_t(js, m.head0, 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t_h0));
     PR_TRY(add_seg_t(js, m.head3, 0, d.W2, d.W2pad, d.W, d.Wpad, base + l.t_h3));
     PR_TRY(add_seg_t(js, m.head6, 0, d.F, d.Fpad, d.W2, d.W2pad, base + l.t_h6));
+    if (m.has_bender) {
+        for (int j = 1; j < m.bender_count; ++j)
+            PR_TRY(add_seg_t3(js, m.bender[j], 0, d.BW, d.BWpad, d.BW, d.BWpad, base + l.t3_b_act[j]));
+        PR_TRY(add_seg_t3(js, m.bender[m.bender_skip], d.BW, d.BW, d.BWpad, d.bin, d.bin_pad, base + l.t3_b_skip));
+        PR_TRY(add_seg_t3(js, m.bender[0], 0, d.BW, d.BWpad, d.bin, d.bin_pad, base + l.t3_b_first));
+    }
+    for (int i = 1; i < m.backbone_count; ++i)
+        PR_TRY(add_seg_t3(js, m.backbone[i], 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t3_n_act[i]));
+    PR_TRY(add_seg_t3(js, m.backbone[m.skip_layer_idx], d.W, d.W, d.Wpad, d.enc, d.enc_pad, base + l.t3_n_skip));
+    PR_TRY(add_seg_t3(js, m.backbone[0], 0, d.W, d.Wpad, d.enc, d.enc_pad, base + l.t3_n_first));
+    PR_TRY(add_seg_t3(js, m.head0, 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t3_h0));
+    PR_TRY(add_seg_t3(js, m.head3, 0, d.W2, d.W2pad, d.W, d.Wpad, base + l.t3_h3));
+    PR_TRY(add_seg_t3(js, m.head6, 0, d.F, d.Fpad, d.W2, d.W2pad, base + l.t3_h6));
     return PR_OK;
 }
 

@@ -110,6 +110,11 @@ struct PackedLayout {
     int t_b_act[PR_MAX_LAYERS], t_b_skip, t_b_first;   // bender chain: W_l[:, :BW]^T (l >= 1), W_skip[:, BW:]^T, W_0^T
     int t_n_act[PR_MAX_LAYERS], t_n_skip, t_n_first;   // NeRF backbone chain
     int t_h0, t_h3, t_h6;                              // head0^T (W -> W), head3^T (W/2 -> W), head6^T (F -> W/2)
+    // the same transposed segments as bf16 TRIPLES (PR_FLAG_SPLIT_BACKWARD): w = b1 + b2 + b3, fragments of v_mfma_f32_32x32x16_bf16
+    // - [column block][16-wide K step][plane][64 lanes][8 bf16] - 1.5 x the floats of the fp32 segment
+    int t3_b_act[PR_MAX_LAYERS], t3_b_skip, t3_b_first;
+    int t3_n_act[PR_MAX_LAYERS], t3_n_skip, t3_n_first;
+    int t3_h0, t3_h3, t3_h6;
     int total;
 };
 
@@ -541,6 +546,7 @@ struct HeadBwdJob {                 // feature-head backward, phase 1 (head laye
     double* sums;                   // [sum d x_hat (ld) | sum d x_hat x_hat (ld)], zeroed by the caller
     float* dscale; float* dbias;    // (frames, MAX_WIDTH) d loss / d AdaIN scale / bias, zeroed by the caller
     int32_t* tile_counter;          // zeroed
+    int split;                      // 1: `wt` is the bf16-triple packing of the segment, the product runs on six bf16 MFMAs
 };
 int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int count, hipStream_t s);
 
@@ -565,6 +571,7 @@ struct ChainBwdJob {                // backward chain of a ReLU MLP with one ski
     float* gstack; size_t g_stride; // out: pre-activation gradients of layers 0 .. count - 1, (cap, Wpad) each
     float* g_in; int ld_in;         // out: gradient of the network input (cap, ld_in)
     int32_t* tile_counter;          // zeroed
+    int split;                      // 1: the segments are bf16-triple packings, every product runs on six bf16 MFMAs
 };
 int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int count, hipStream_t s);
 

@@ -155,6 +155,92 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
     __builtin_amdgcn_s_setprio(0);
 }
 
+// The same product in SPLIT precision (PR_FLAG_SPLIT_BACKWARD; `sg.w` then points at the bf16-triple packing of the segment,
+// k_pack kind 3): every fp32 operand as three bf16 terms, x = b1 + b2 + b3 exactly, a product as the six bf16 MFMAs whose terms
+// are >= 2^-16 of it (see k_gemm_tn_all_bf16 in gemm.hip) - 16 K-values retire in 6 x 32 cycles where the fp32 pipe needs
+// 8 x 64.  The operand tile stays fp32 in X (it is also the gradient that is written out): a lane reads its eight consecutive
+// K-values of a step (two 16-byte LDS reads) and splits them in registers, behind the MFMAs of the previous step.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define PR_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
+
+struct Frag3 { bf16x8 p[3]; };
+__device__ __forceinline__ Frag3 split_fragment(const float4& lo, const float4& hi) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned int a[8], b[8], c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = __float_as_uint(v[i]) & 0xffff0000u;
+        const float r1 = v[i] - __uint_as_float(a[i]);        // exact
+        b[i] = __float_as_uint(r1) & 0xffff0000u;
+        c[i] = __float_as_uint(r1 - __uint_as_float(b[i]));   // exact: at most 8 significant bits are left
+    }
+    Frag3 f;
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(a[2 * i + 1], a[2 * i], 0x07060302u);
+    f.p[0] = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(b[2 * i + 1], b[2 * i], 0x07060302u);
+    f.p[1] = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(c[2 * i + 1], c[2 * i], 0x07060302u);
+    f.p[2] = __builtin_bit_cast(bf16x8, w);
+    return f;
+}
+// six MFMAs of one 32 x 32 block, smallest terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const Frag3& x, const bf16x8& w1, const bf16x8& w2, const bf16x8& w3) {
+    PR_MFMA_BF16(acc, x.p[1], w2);
+    PR_MFMA_BF16(acc, x.p[0], w3);
+    PR_MFMA_BF16(acc, x.p[2], w1);
+    PR_MFMA_BF16(acc, x.p[0], w2);
+    PR_MFMA_BF16(acc, x.p[1], w1);
+    PR_MFMA_BF16(acc, x.p[0], w1);
+}
+
+__device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                   f32x16& a11, const Drain* drain = nullptr) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    if (cbA >= nblk) return;
+    const bool two = cbB < nblk;
+    __builtin_amdgcn_s_setprio(1);
+    const int ks = sg.kq >> 1;                       // K steps of 16
+    const float* ap = X + r * LDX + 8 * half;
+    // [column block][step][plane][lane] fragments of 16 bytes
+    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
+    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
+    float4 x0l = *reinterpret_cast<const float4*>(ap), x0h = *reinterpret_cast<const float4*>(ap + 4);
+    float4 x1l = *reinterpret_cast<const float4*>(ap + 32 * LDX), x1h = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    bf16x8 wa0 = wpA[0], wa1 = wpA[64], wa2 = wpA[128];
+    bf16x8 wb0 = wpB[0], wb1 = wpB[64], wb2 = wpB[128];
+    for (int s = 0; s < ks; ++s) {
+        const Frag3 f0 = split_fragment(x0l, x0h), f1 = split_fragment(x1l, x1h);
+        const bf16x8 ca0 = wa0, ca1 = wa1, ca2 = wa2, cb0 = wb0, cb1 = wb1, cb2 = wb2;
+        const int sn = (s + 1 < ks) ? s + 1 : s;
+        // the next step's operands are requested before this step's MFMAs
+        x0l = *reinterpret_cast<const float4*>(ap + 16 * sn); x0h = *reinterpret_cast<const float4*>(ap + 16 * sn + 4);
+        x1l = *reinterpret_cast<const float4*>(ap + 32 * LDX + 16 * sn); x1h = *reinterpret_cast<const float4*>(ap + 32 * LDX + 16 * sn + 4);
+        wa0 = wpA[(size_t)sn * 192]; wa1 = wpA[(size_t)sn * 192 + 64]; wa2 = wpA[(size_t)sn * 192 + 128];
+        if (two) { wb0 = wpB[(size_t)sn * 192]; wb1 = wpB[(size_t)sn * 192 + 64]; wb2 = wpB[(size_t)sn * 192 + 128]; }
+        mfma6(a00, f0, ca0, ca1, ca2);
+        mfma6(a01, f1, ca0, ca1, ca2);
+        if (two) {
+            mfma6(a10, f0, cb0, cb1, cb2);
+            mfma6(a11, f1, cb0, cb1, cb2);
+        }
+        if (drain) drain_chunk(*drain, X, s);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+template <bool SPLIT>
+__device__ __forceinline__ void tile_products_any(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                  f32x16& a11, const Drain* drain = nullptr) {
+    if (SPLIT) tile_products_bf16(sg, nblk, X, a00, a01, a10, a11, drain);
+    else tile_products(sg, nblk, X, a00, a01, a10, a11, drain);
+}
+
 // rows of X -> rows of a (cap, ld) array, 16-byte stores; only the tile's real rows
 __device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int width_pad, int ld, int tile_base, int rows_valid) {
     const int w4 = width_pad >> 2;
@@ -313,7 +399,7 @@ __device__ __forceinline__ void flush_frame_sums(ColumnSums& cs, float* dscale, 
 // ---------------------------------------------------------------------------------------------
 // Feature-head backward, phases 1 and 2
 // ---------------------------------------------------------------------------------------------
-template <int UNUSED = 0>
+template <bool SPLIT>
 __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
@@ -394,7 +480,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 #endif
         f32x16 a00, a01, a10, a11;
         zero4(a00, a01, a10, a11);
-        tile_products(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+        tile_products_any<SPLIT>(p.wt, p.nblk, S.X, a00, a01, a10, a11);
         if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 #ifndef PR_HEAD_NO_PREFETCH
         prefetch(1, hvB);
@@ -528,10 +614,18 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
                                                                                    int count) {
-    head_bwd_loop(j0);
-    if (count > 1) head_bwd_loop(j1);
-    if (count > 2) head_bwd_loop(j2);
-    if (count > 3) head_bwd_loop(j3);
+    head_bwd_loop<false>(j0);
+    if (count > 1) head_bwd_loop<false>(j1);
+    if (count > 2) head_bwd_loop<false>(j2);
+    if (count > 3) head_bwd_loop<false>(j3);
+}
+
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group_bf16(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
+                                                                                        int count) {
+    head_bwd_loop<true>(j0);
+    if (count > 1) head_bwd_loop<true>(j1);
+    if (count > 2) head_bwd_loop<true>(j2);
+    if (count > 3) head_bwd_loop<true>(j3);
 }
 
 int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int count, hipStream_t s) {
@@ -546,11 +640,18 @@ int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int coun
         }
         if (max_tiles <= 0) continue;
         int cus = 0;
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_head_bwd_group), (int)sizeof(BSmem), &cus));
+        const bool split = g[0].split != 0;
+        for (int j = 1; j < n; ++j) PR_REQUIRE((g[j].split != 0) == split, "head backward: jobs of one launch differ in precision");
+        PR_TRY(prepare_kernel(split ? reinterpret_cast<const void*>(k_head_bwd_group_bf16) : reinterpret_cast<const void*>(k_head_bwd_group),
+                              (int)sizeof(BSmem), &cus));
         const long resident = (long)cus * MLP_BLOCKS_PER_CU;
         ProfileScope scope(2, s);
-        hipLaunchKernelGGL(k_head_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
-                           g[0], g[1], g[2], g[3], n);
+        if (split)
+            hipLaunchKernelGGL(k_head_bwd_group_bf16, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS),
+                               sizeof(BSmem), s, g[0], g[1], g[2], g[3], n);
+        else
+            hipLaunchKernelGGL(k_head_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                               g[0], g[1], g[2], g[3], n);
         PR_LAUNCH_CHECK();
     }
     return PR_OK;
@@ -559,6 +660,7 @@ int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int coun
 // ---------------------------------------------------------------------------------------------
 // Backward chain of a ReLU MLP with one skip concatenation, with its entry fused in
 // ---------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
@@ -597,7 +699,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             __syncthreads();
             PR_CT(0);
             zero4(a00, a01, a10, a11);
-            tile_products(c.w0t, nblk, S.X, a00, a01, a10, a11);
+            tile_products_any<SPLIT>(c.w0t, nblk, S.X, a00, a01, a10, a11);
             PR_CT(1);
             __syncthreads();
             PR_CT(2);
@@ -644,7 +746,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 store_tile_rows(S.X, pending.dst - (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad, tile_base, rows_valid);
                 pending.dst = nullptr;
             }
-            tile_products(sg, out_blk, S.X, a00, a01, a10, a11, pending.dst ? &pending : nullptr);
+            tile_products_any<SPLIT>(sg, out_blk, S.X, a00, a01, a10, a11, pending.dst ? &pending : nullptr);
             pending.dst = nullptr;
         };
         PR_CT(5);
@@ -685,10 +787,19 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
                                                                                     int count) {
-    chain_bwd_loop(j0);
-    if (count > 1) chain_bwd_loop(j1);
-    if (count > 2) chain_bwd_loop(j2);
-    if (count > 3) chain_bwd_loop(j3);
+    chain_bwd_loop<false>(j0);
+    if (count > 1) chain_bwd_loop<false>(j1);
+    if (count > 2) chain_bwd_loop<false>(j2);
+    if (count > 3) chain_bwd_loop<false>(j3);
+}
+
+// split precision (PR_FLAG_SPLIT_BACKWARD): the chains' products on bf16 triples
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group_bf16(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
+                                                                                         int count) {
+    chain_bwd_loop<true>(j0);
+    if (count > 1) chain_bwd_loop<true>(j1);
+    if (count > 2) chain_bwd_loop<true>(j2);
+    if (count > 3) chain_bwd_loop<true>(j3);
 }
 
 #ifdef PR_CHAIN_TIMING
@@ -716,11 +827,18 @@ int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int co
         }
         if (max_tiles <= 0) continue;
         int cus = 0;
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_chain_bwd_group), (int)sizeof(BSmem), &cus));
+        const bool split = g[0].split != 0;
+        for (int j = 1; j < n; ++j) PR_REQUIRE((g[j].split != 0) == split, "backward chain: jobs of one launch differ in precision");
+        PR_TRY(prepare_kernel(split ? reinterpret_cast<const void*>(k_chain_bwd_group_bf16) : reinterpret_cast<const void*>(k_chain_bwd_group),
+                              (int)sizeof(BSmem), &cus));
         const long resident = (long)cus * MLP_BLOCKS_PER_CU;
         ProfileScope scope(2, s);
-        hipLaunchKernelGGL(k_chain_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
-                           g[0], g[1], g[2], g[3], n);
+        if (split)
+            hipLaunchKernelGGL(k_chain_bwd_group_bf16, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS),
+                               sizeof(BSmem), s, g[0], g[1], g[2], g[3], n);
+        else
+            hipLaunchKernelGGL(k_chain_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                               g[0], g[1], g[2], g[3], n);
         PR_LAUNCH_CHECK();
     }
     return PR_OK;
