@@ -198,6 +198,26 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const Frag3& x, const bf16x8&
     PR_MFMA_BF16(acc, x.p[0], w1);
 }
 
+// the six terms of the blocks of one step, block by block inside a term (consecutive MFMAs write different accumulators)
+#define PR_STEP_MFMAS(F0, F1, WA0, WA1, WA2, WB0, WB1, WB2)                                                                             \
+    do {                                                                                                                             \
+        if (two) {                                                                                                                   \
+            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1); PR_MFMA_BF16(a10, F0.p[1], WB1); PR_MFMA_BF16(a11, F1.p[1], WB1); \
+            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2); PR_MFMA_BF16(a10, F0.p[0], WB2); PR_MFMA_BF16(a11, F1.p[0], WB2); \
+            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0); PR_MFMA_BF16(a10, F0.p[2], WB0); PR_MFMA_BF16(a11, F1.p[2], WB0); \
+            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1); PR_MFMA_BF16(a10, F0.p[0], WB1); PR_MFMA_BF16(a11, F1.p[0], WB1); \
+            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0); PR_MFMA_BF16(a10, F0.p[1], WB0); PR_MFMA_BF16(a11, F1.p[1], WB0); \
+            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0); PR_MFMA_BF16(a10, F0.p[0], WB0); PR_MFMA_BF16(a11, F1.p[0], WB0); \
+        } else {                                                                                                                     \
+            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2);                                                        \
+            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1);                                                        \
+            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0);                                                        \
+        }                                                                                                                            \
+    } while (0)
+
 __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
                                                    f32x16& a11, const Drain* drain = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -206,31 +226,50 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
     if (cbA >= nblk) return;
     const bool two = cbB < nblk;
     __builtin_amdgcn_s_setprio(1);
-    const int ks = sg.kq >> 1;                       // K steps of 16
+    const int ks = sg.kq >> 1;                       // K steps of 16 (even: the padded widths are multiples of 32)
     const float* ap = X + r * LDX + 8 * half;
     // [column block][step][plane][lane] fragments of 16 bytes
     const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
     const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
-    float4 x0l = *reinterpret_cast<const float4*>(ap), x0h = *reinterpret_cast<const float4*>(ap + 4);
-    float4 x1l = *reinterpret_cast<const float4*>(ap + 32 * LDX), x1h = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-    bf16x8 wa0 = wpA[0], wa1 = wpA[64], wa2 = wpA[128];
-    bf16x8 wb0 = wpB[0], wb1 = wpB[64], wb2 = wpB[128];
-    for (int s = 0; s < ks; ++s) {
-        const Frag3 f0 = split_fragment(x0l, x0h), f1 = split_fragment(x1l, x1h);
-        const bf16x8 ca0 = wa0, ca1 = wa1, ca2 = wa2, cb0 = wb0, cb1 = wb1, cb2 = wb2;
-        const int sn = (s + 1 < ks) ? s + 1 : s;
-        // the next step's operands are requested before this step's MFMAs
-        x0l = *reinterpret_cast<const float4*>(ap + 16 * sn); x0h = *reinterpret_cast<const float4*>(ap + 16 * sn + 4);
-        x1l = *reinterpret_cast<const float4*>(ap + 32 * LDX + 16 * sn); x1h = *reinterpret_cast<const float4*>(ap + 32 * LDX + 16 * sn + 4);
-        wa0 = wpA[(size_t)sn * 192]; wa1 = wpA[(size_t)sn * 192 + 64]; wa2 = wpA[(size_t)sn * 192 + 128];
-        if (two) { wb0 = wpB[(size_t)sn * 192]; wb1 = wpB[(size_t)sn * 192 + 64]; wb2 = wpB[(size_t)sn * 192 + 128]; }
-        mfma6(a00, f0, ca0, ca1, ca2);
-        mfma6(a01, f1, ca0, ca1, ca2);
-        if (two) {
-            mfma6(a10, f0, cb0, cb1, cb2);
-            mfma6(a11, f1, cb0, cb1, cb2);
+    // software pipeline with NAMED even / odd register sets (a rotating set costs a register copy per value and step: 6 moves
+    // per MFMA, measured): the MFMAs of a step run on fragments that were split during the previous step; while they execute, the
+    // raw operands of the next step (requested in front of them) are split - the conversions sit in the shadow of the MFMAs
+    float4 xl, xh, yl, yh;
+    xl = *reinterpret_cast<const float4*>(ap); xh = *reinterpret_cast<const float4*>(ap + 4);
+    yl = *reinterpret_cast<const float4*>(ap + 32 * LDX); yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    Frag3 e0 = split_fragment(xl, xh), e1 = split_fragment(yl, yh), o0, o1;
+    bf16x8 ea0 = wpA[0], ea1 = wpA[64], ea2 = wpA[128], eb0 = wpB[0], eb1 = wpB[64], eb2 = wpB[128];
+    bf16x8 oa0, oa1, oa2, ob0 = eb0, ob1 = eb1, ob2 = eb2;
+    for (int s = 0; s < ks; s += 2) {
+        // ---- even step: request the odd step's operands, multiply the even fragments, split the odd ones
+        {
+            const float* an = ap + 16 * (s + 1);
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)(s + 1) * 192;
+            oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
+            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);      // the requests stay in FRONT of the step's MFMAs (hipcc sank them behind: L2 latency exposed every step)
+            PR_STEP_MFMAS(e0, e1, ea0, ea1, ea2, eb0, eb1, eb2);
+            o0 = split_fragment(xl, xh); o1 = split_fragment(yl, yh);
+            if (drain) drain_chunk(*drain, X, s);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (drain) drain_chunk(*drain, X, s);
+        // ---- odd step
+        {
+            const int sn = (s + 2 < ks) ? s + 2 : s;
+            const float* an = ap + 16 * sn;
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)sn * 192;
+            ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
+            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS(o0, o1, oa0, oa1, oa2, ob0, ob1, ob2);
+            e0 = split_fragment(xl, xh); e1 = split_fragment(yl, yh);
+            if (drain) drain_chunk(*drain, X, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
 }

@@ -17,9 +17,9 @@ args = types.SimpleNamespace(steps=10, warmup=3)
 dev = torch.device("cuda", 0)
 out = (C.c_ulonglong * 16)()
 raw = C.CDLL(_lib.library_path())
-bench.train_step_leg(args, dev, 1, 0, None, lib)
+bench.train_step_leg(args, dev, 1, 0, None, lib, precision=os.environ.get("PR_PERF_PRECISION", "fp32"))
 raw.pr_debug_chain_phases(out, 1)
-bench.train_step_leg(args, dev, 1, 0, None, lib)
+bench.train_step_leg(args, dev, 1, 0, None, lib, precision=os.environ.get("PR_PERF_PRECISION", "fp32"))
 raw.pr_debug_chain_phases(out, 0)
 names = ["entry load", "K loops", "wait after K loop", "masked store", "wait after store", "gradient write-out", "mask fetch",
          "input products + global store", "tile end barrier"]
