@@ -531,8 +531,8 @@ __global__ __launch_bounds__(256, PR_TNALL_WGS) void k_gemm_tn_all(TnAll g) {
 
 // ---------------------------------------------------------------------------------------------
 // The same work item in SPLIT precision (pr_call_t.precision = PR_PRECISION_F16X3 on a differentiable call): every fp32 operand
-// as THREE bf16 terms, x = b1 + b2 + b3 EXACTLY (each term the truncated top 8 significant bits of what is left: 8 + 8 + 8 = the 24
-// bits of an fp32 mantissa, with the fp32 exponent range - gradients of 1e-7 are as well represented as activations of 1, which
+// as THREE bf16 terms, x = b1 + b2 + b3 (each term what is left rounded to the nearest bf16: 8 + 8 + 8 mantissa bits
+// with residuals of either sign, and the fp32 exponent range - gradients of 1e-7 are as well represented as activations of 1, which
 // an fp16 pair is not), and a product as the SIX bf16 MFMAs whose terms are >= 2^-16 of it:
 //     a b ~ a1 b1 + a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2        (dropped: a2 b3 + a3 b2 + a3 b3 <= 3 x 2^-24 |a b|, one fp32 rounding)
 // v_mfma_f32_32x32x16_bf16 multiplies exactly and accumulates in fp32; it retires 16 K-values in 32 cycles where the fp32 pipe
@@ -547,13 +547,21 @@ constexpr int TROW = 80;                       // bytes per LDS row of a plane: 
 constexpr int TPLANE = GT * TROW;              // one plane of one operand
 #define PR_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
 
-// x = b1 + b2 + b3 (bf16 terms in the high halves of p1, p2, p3)
-__device__ __forceinline__ void bf16_split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(p1);          // exact
-    p2 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(p2);         // exact; at most 8 significant bits are left
-    p3 = __float_as_uint(r2);
+typedef __bf16 bf16x2_g __attribute__((ext_vector_type(2)));
+typedef float f32x2_g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sub_f32_g(float a, float b) {      // (not packed into v_pk_add_f32: slow beside MFMAs)
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// two values -> their three bf16 terms, rounded to nearest (v_cvt_pk_bf16_f32): packed pairs [x0 | x1] per term
+__device__ __forceinline__ void bf16_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const f32x2_g v = {x0, x1};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_g));
+    const f32x2_g r = {sub_f32_g(x0, __uint_as_float(p1 << 16)), sub_f32_g(x1, __uint_as_float(p1 & 0xffff0000u))};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_g));
+    const f32x2_g q = {sub_f32_g(r[0], __uint_as_float(p2 << 16)), sub_f32_g(r[1], __uint_as_float(p2 & 0xffff0000u))};
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2_g));
 }
 
 __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int split, unsigned char* T, float* RED) {
@@ -589,16 +597,13 @@ __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int s
     };
     // the three planes of one operand: column c (of the tile), this thread's four k = 4 rr .. 4 rr + 3
     auto put = [&](unsigned char* planes, int c, float v0, float v1, float v2, float v3) {
-        unsigned a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
-        bf16_split3(v0, a1, a2, a3);
-        bf16_split3(v1, b1, b2, b3);
-        bf16_split3(v2, c1, c2, c3);
-        bf16_split3(v3, d1, d2, d3);
+        unsigned a1, a2, a3, b1, b2, b3;
+        bf16_split_pair(v0, v1, a1, a2, a3);
+        bf16_split_pair(v2, v3, b1, b2, b3);
         const int at = c * TROW + ((((rr >> 1) + (c >> 4)) & 3) << 4) + ((rr & 1) << 3);
-        // (v_perm_b32: the high halves of two words side by side)
-        *reinterpret_cast<uint2*>(planes + at) = make_uint2(__builtin_amdgcn_perm(b1, a1, 0x07060302u), __builtin_amdgcn_perm(d1, c1, 0x07060302u));
-        *reinterpret_cast<uint2*>(planes + TPLANE + at) = make_uint2(__builtin_amdgcn_perm(b2, a2, 0x07060302u), __builtin_amdgcn_perm(d2, c2, 0x07060302u));
-        *reinterpret_cast<uint2*>(planes + 2 * TPLANE + at) = make_uint2(__builtin_amdgcn_perm(b3, a3, 0x07060302u), __builtin_amdgcn_perm(d3, c3, 0x07060302u));
+        *reinterpret_cast<uint2*>(planes + at) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(planes + TPLANE + at) = make_uint2(a2, b2);
+        *reinterpret_cast<uint2*>(planes + 2 * TPLANE + at) = make_uint2(a3, b3);
     };
     auto stage = [&](const float4 (&ra)[4], const float4 (&rb)[4], const float (&wv)[4]) {
         put(T, 4 * c4 + 0, ra[0].x, ra[1].x, ra[2].x, ra[3].x);

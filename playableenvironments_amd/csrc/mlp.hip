@@ -145,6 +145,19 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
     l->t3_h0 = take3(d.Wpad / 32, d.Wpad);
     l->t3_h3 = take3(d.Wpad / 32, d.W2pad);
     l->t3_h6 = take3(d.W2pad / 32, d.Fpad);
+    // forward segments of a training call's phase 1 as bf16 triples
+    if (m.has_bender) {
+        const int nbb = d.BWpad / 32;
+        for (int j = 0; j < m.bender_count; ++j) {
+            l->b_seg3[j][0] = take3(nbb, j == 0 ? d.bin_pad : d.BWpad);
+            if (j == m.bender_skip) l->b_seg3[j][1] = take3(nbb, d.bin_pad);
+        }
+    }
+    for (int i = 0; i < m.backbone_count; ++i) {
+        l->n_seg3[i][0] = take3(d.Wpad / 32, i == 0 ? d.enc_pad : d.Wpad);
+        if (i == m.skip_layer_idx) l->n_seg3[i][1] = take3(d.Wpad / 32, d.enc_pad);
+    }
+    l->h0_3 = take3(d.Wpad / 32, d.Wpad);
     l->total = off;
     return PR_OK;
 }
@@ -167,7 +180,7 @@ struct PackJob {
     int count;      // elements of dst
     int transposed; // kind 0: element (n, k) is read from src[k * in_total + col_off + n] (the backward chain's W^T)
 };
-constexpr int MAX_PACK_JOBS = 160;
+constexpr int MAX_PACK_JOBS = 192;
 struct PackJobs {
     PackJob job[MAX_PACK_JOBS];
     int n;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
             reinterpret_cast<unsigned int*>(j.dst)[idx] = (unsigned int)out[0] | ((unsigned int)out[1] << 16);
             continue;
         } else if (j.kind == 3) {
-            // bf16 triples of a segment, w = b1 + b2 + b3 exactly (each term the truncated top 8 significant bits of what is left):
+            // bf16 triples of a segment, w = b1 + b2 + b3 (each term what is left, rounded to the nearest bf16):
             // word idx holds the elements e, e + 1 of [column block][K step of 16][plane][lane]; lane l carries
             // W(n = nb*32 + (l & 31), k = 16 s + 8 (l >> 5) + e), e = 0..7 - the B fragment of v_mfma_f32_32x32x16_bf16
             unsigned int out[2];
@@ -230,11 +243,13 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 float w = 0.f;
                 if (n < j.n_real && k < j.k_real)
                     w = j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k];
-                const unsigned int p1 = __float_as_uint(w) & 0xffff0000u;
-                const float r1 = w - __uint_as_float(p1);
-                const unsigned int p2 = __float_as_uint(r1) & 0xffff0000u;
-                const unsigned int p3 = __float_as_uint(r1 - __uint_as_float(p2));
-                out[t] = (plane == 0 ? p1 : (plane == 1 ? p2 : p3)) >> 16;
+                // (round to nearest, like the activations' split in the kernels)
+                const __bf16 b1 = (__bf16)w;
+                const float r1 = w - (float)b1;
+                const __bf16 b2 = (__bf16)r1;
+                const __bf16 b3 = (__bf16)(r1 - (float)b2);
+                const __bf16 sel = plane == 0 ? b1 : (plane == 1 ? b2 : b3);
+                out[t] = *reinterpret_cast<const unsigned short*>(&sel);
             }
             reinterpret_cast<unsigned int*>(j.dst)[idx] = out[0] | (out[1] << 16);
             continue;
@@ -282,6 +297,15 @@ static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_r
     PackJob& j = js->job[js->n - 1];
     j.kind = 3;
     j.count = j.count / 2 * 3;      // 32-bit words: two bf16 each, three planes
+    return PR_OK;
+}
+
+// a forward segment as bf16 triples (kind 3)
+static int add_seg3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
+    PR_TRY(add_seg(js, lin, col_off, k_real, kpad, npad, dst));
+    PackJob& j = js->job[js->n - 1];
+    j.kind = 3;
+    j.count = j.count / 2 * 3;
     return PR_OK;
 }
 
@@ -391,6 +415,25 @@ static int build_pack_jobs(const pr_object_model_t& m, const ModelDims& d, const
     PR_TRY(add_seg_t3(js, m.head0, 0, d.W, d.Wpad, d.W, d.Wpad, base + l.t3_h0));
     PR_TRY(add_seg_t3(js, m.head3, 0, d.W2, d.W2pad, d.W, d.Wpad, base + l.t3_h3));
     PR_TRY(add_seg_t3(js, m.head6, 0, d.F, d.Fpad, d.W2, d.W2pad, base + l.t3_h6));
+    if (m.has_bender) {
+        for (int j = 0; j < m.bender_count; ++j) {
+            if (j == 0) {
+                PR_TRY(add_seg3(js, m.bender[j], 0, d.bin, d.bin_pad, d.BWpad, base + l.b_seg3[j][0]));
+            } else {
+                PR_TRY(add_seg3(js, m.bender[j], 0, d.BW, d.BWpad, d.BWpad, base + l.b_seg3[j][0]));
+                if (j == m.bender_skip) PR_TRY(add_seg3(js, m.bender[j], d.BW, d.bin, d.bin_pad, d.BWpad, base + l.b_seg3[j][1]));
+            }
+        }
+    }
+    for (int i = 0; i < m.backbone_count; ++i) {
+        if (i == 0) {
+            PR_TRY(add_seg3(js, m.backbone[i], 0, d.enc, d.enc_pad, d.Wpad, base + l.n_seg3[i][0]));
+        } else {
+            PR_TRY(add_seg3(js, m.backbone[i], 0, d.W, d.Wpad, d.Wpad, base + l.n_seg3[i][0]));
+            if (i == m.skip_layer_idx) PR_TRY(add_seg3(js, m.backbone[i], d.W, d.enc, d.enc_pad, d.Wpad, base + l.n_seg3[i][1]));
+        }
+    }
+    PR_TRY(add_seg3(js, m.head0, 0, d.W, d.Wpad, d.Wpad, base + l.h0_3));
     return PR_OK;
 }
 
@@ -646,7 +689,7 @@ __device__ unsigned long long g_mlp_trace[1024][12];
 // objects in order, EVERY tile is claimed from the object's counter, and a workgroup that finds an object's tiles
 // exhausted moves on to the next object at once: small objects do not pay a launch of their own (a launch lasts at
 // least one tile time and ends with idle CUs) and the tail of one object overlaps the start of the next.
-template <bool TRAIN, bool GROUP>
+template <bool TRAIN, bool GROUP, bool SPLIT = false>
 __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
@@ -731,7 +774,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             if (TRAIN && p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
                 if (TRAIN) {
-                    run_layer<false, true>(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc, nullptr,
+                    run_layer<false, true, false, SPLIT>(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc, nullptr,
                                            p.save_bbits ? reinterpret_cast<unsigned long long*>(p.save_bbits + (size_t)l * p.save_bbits_stride) +
                                                               (size_t)tile * p.BWpad : nullptr);
                 } else {
@@ -784,7 +827,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         // ---- backbone ---------------------------------------------------------------------------
         for (int l = 0; l < p.n_backbone; ++l) {
             if (TRAIN) {
-                run_layer<false, true>(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc, nullptr,
+                run_layer<false, true, false, SPLIT>(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc, nullptr,
                                        (p.save_bits && !(PR_TRAINFWD_ABLATE & 2))
                                            ? reinterpret_cast<unsigned long long*>(p.save_bits + (size_t)l * p.save_bits_stride) + (size_t)tile * p.Wpad
                                            : nullptr);
@@ -838,7 +881,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             // their per-channel sums feed the batch statistics
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
-            run_layer<false, false, true>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats);
+            run_layer<false, false, true, SPLIT>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             count_stat_rows(S, p);
@@ -880,6 +923,15 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
     if (count > 1) mlp_tile_loop<true, true>(j1);
     if (count > 2) mlp_tile_loop<true, true>(j2);
     if (count > 3) mlp_tile_loop<true, true>(j3);
+}
+
+// phase 1 of a training call in split precision (PR_FLAG_SPLIT_BACKWARD): the same tile loop on bf16-triple segments
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group_bf16(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                                              int count) {
+    mlp_tile_loop<true, true, true>(j0);
+    if (count > 1) mlp_tile_loop<true, true, true>(j1);
+    if (count > 2) mlp_tile_loop<true, true, true>(j2);
+    if (count > 3) mlp_tile_loop<true, true, true>(j3);
 }
 
 // Train-mode phases 2 and 3: re-load the raw head activations of the previous phase, apply the AdaIN
@@ -1209,8 +1261,13 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         if (max_tiles <= 0) continue;
         int cu_count = 0;
         const int phase = host_jobs[0].phase;
+        const bool split3 = phase == 1 && host_jobs[begin].split3 != 0;
+        for (int j = 0; j < n; ++j)
+            PR_REQUIRE((host_jobs[begin + j].split3 != 0) == (host_jobs[begin].split3 != 0) && (phase == 1 || !host_jobs[begin + j].split3),
+                       "grouped MLP launch: bf16-triple segments belong to phase 1, for every job of the launch or none");
         const void* kernel = phase >= 2 ? reinterpret_cast<const void*>(k_mlp_head_group)
-                                        : (phase == 1 ? reinterpret_cast<const void*>(k_mlp_mfma_train_group)
+                                        : (phase == 1 ? (split3 ? reinterpret_cast<const void*>(k_mlp_mfma_train_group_bf16)
+                                                                : reinterpret_cast<const void*>(k_mlp_mfma_train_group))
                                                       : reinterpret_cast<const void*>(k_mlp_mfma_group));
         PR_TRY(prepare_kernel(kernel, (int)sizeof(Smem), &cu_count));
         int resident = cu_count * MLP_BLOCKS_PER_CU;
@@ -1220,6 +1277,8 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         ProfileScope scope(0, s);
         if (phase >= 2)
             hipLaunchKernelGGL(k_mlp_head_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        else if (phase == 1 && split3)
+            hipLaunchKernelGGL(k_mlp_mfma_train_group_bf16, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else if (phase == 1)
             hipLaunchKernelGGL(k_mlp_mfma_train_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else
@@ -1231,7 +1290,10 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
 
 // Fills the layer tables of MlpParams from the packed buffer.
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
-                     MlpParams* p) {
+                     MlpParams* p, bool split3) {
+    // split3 (phase 1 of a training call with PR_FLAG_SPLIT_BACKWARD): ray bender, backbone and head layer 0 read their
+    // bf16-triple packings; the head layers of the later phases and every small vector stay fp32
+    p->split3 = split3 ? 1 : 0;
     p->kind = m.kind;
     p->has_bender = m.has_bender;
     p->b_count = 0;
@@ -1254,11 +1316,11 @@ int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const Packe
             L.epi = EPI_RELU;
             L.nseg = 1;
             if (j == 0) {
-                L.seg[0] = Seg{base + l.b_seg_off[j][0], d.bin_pad / 8, 1};
+                L.seg[0] = Seg{base + (split3 ? l.b_seg3[j][0] : l.b_seg_off[j][0]), d.bin_pad / 8, 1};
             } else {
-                L.seg[0] = Seg{base + l.b_seg_off[j][0], d.BWpad / 8, 0};
+                L.seg[0] = Seg{base + (split3 ? l.b_seg3[j][0] : l.b_seg_off[j][0]), d.BWpad / 8, 0};
                 if (j == m.bender_skip) {
-                    L.seg[1] = Seg{base + l.b_seg_off[j][1], d.bin_pad / 8, 1};
+                    L.seg[1] = Seg{base + (split3 ? l.b_seg3[j][1] : l.b_seg_off[j][1]), d.bin_pad / 8, 1};
                     L.nseg = 2;
                 }
             }
@@ -1282,11 +1344,11 @@ int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const Packe
         L.epi = EPI_RELU;
         L.nseg = 1;
         if (i == 0) {
-            L.seg[0] = Seg{base + l.n_seg_off[i][0], d.enc_pad / 8, 1};
+            L.seg[0] = Seg{base + (split3 ? l.n_seg3[i][0] : l.n_seg_off[i][0]), d.enc_pad / 8, 1};
         } else {
-            L.seg[0] = Seg{base + l.n_seg_off[i][0], d.Wpad / 8, 0};
+            L.seg[0] = Seg{base + (split3 ? l.n_seg3[i][0] : l.n_seg_off[i][0]), d.Wpad / 8, 0};
             if (i == m.skip_layer_idx) {
-                L.seg[1] = Seg{base + l.n_seg_off[i][1], d.enc_pad / 8, 1};
+                L.seg[1] = Seg{base + (split3 ? l.n_seg3[i][1] : l.n_seg_off[i][1]), d.enc_pad / 8, 1};
                 L.nseg = 2;
             }
         }
@@ -1294,7 +1356,7 @@ int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const Packe
     p->sigma_w = base + l.sigma_off;
     Layer& h0 = p->layers[m.backbone_count];
     memset(&h0, 0, sizeof(h0));
-    h0.seg[0] = Seg{base + l.h0_off, d.Wpad / 8, 0};
+    h0.seg[0] = Seg{base + (split3 ? l.h0_3 : l.h0_off), d.Wpad / 8, 0};
     h0.nseg = 1;
     h0.nblk = d.Wpad / 32;
     h0.n_real = d.W;

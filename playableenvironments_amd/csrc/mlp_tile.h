@@ -138,7 +138,9 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
 // STATS (training forward, the raw head layers): the plain-store epilogue also adds the layer's per-column sum and sum of squares
 // over the tile's rows that enter the batch statistics to the lane's running sums (`stats`), straight from the accumulators
 struct ColumnStats { double s1[2], s2[2]; };      // this lane's columns of the blocks `wave` / `wave + 4`
-template <bool BWD = false, bool BITS = false, bool STATS = false>
+// SPLIT (training forward with PR_FLAG_SPLIT_BACKWARD): the segments are bf16-triple packings, the products run on six bf16
+// MFMAs per 16 K-values (tile_products_bf16) - same accumulator layout, so every epilogue is unchanged
+template <bool BWD = false, bool BITS = false, bool STATS = false, bool SPLIT = false>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
                                           const BwdEpilogue* bwd = nullptr, unsigned long long* bits_out = nullptr,
                                           ColumnStats* stats = nullptr);
@@ -253,7 +255,205 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
     }
 }
 
-template <bool BWD, bool BITS, bool STATS>
+// ``drain`` (backward chain): the operand tile in X is also WRITTEN OUT to global memory while a product runs - one 16-byte chunk
+// per thread and loop iteration, so that the 64 KB of a tile reach the memory system spread over the K loop
+struct Drain {
+    float* dst;            // row `tile_base` of the (cap, ld) destination; NULL: nothing to write
+    int ld, w4, rows_valid;
+};
+__device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int it) {
+    const int idx = threadIdx.x + it * MLP_THREADS;
+    const int row = idx / d.w4, c = (idx - row * d.w4) * 4;
+    if (row < d.rows_valid) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
+#ifdef PR_DRAIN_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
+#else
+        *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
+#endif
+    }
+}
+
+// The same product in SPLIT precision (PR_FLAG_SPLIT_BACKWARD; `sg.w` then points at the bf16-triple packing of the segment,
+// k_pack kind 3): every fp32 operand as three bf16 terms, x = b1 + b2 + b3 exactly, a product as the six bf16 MFMAs whose terms
+// are >= 2^-16 of it (see k_gemm_tn_all_bf16 in gemm.hip) - 16 K-values retire in 6 x 32 cycles where the fp32 pipe needs
+// 8 x 64.  The operand tile stays fp32 in X (it is also the gradient that is written out): a lane reads its eight consecutive
+// K-values of a step (two 16-byte LDS reads) and splits them in registers, behind the MFMAs of the previous step.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define PR_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
+
+struct Frag3 { bf16x8 p[3]; };
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (plain v_sub_f32: hipcc packs adjacent subtractions into v_pk_add_f32, which is slow beside MFMAs)
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// two values -> their three bf16 terms (round to nearest even: v_cvt_pk_bf16_f32), x = b1 + b2 + b3 with |b2| <= 2^-9 |x|,
+// |b3| <= 2^-18 |x| and residuals of either sign - the dropped product terms are below one fp32 rounding and unbiased (with
+// truncated terms they were up to 2^-20 and all of one sign: a systematic error the float64 arbitration caught)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+    const f32x2_t v = {x0, x1};
+    p1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t r = {sub_f32(x0, __uint_as_float(p1 << 16)), sub_f32(x1, __uint_as_float(p1 & 0xffff0000u))};
+    p2 = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, bf16x2_t));
+    const f32x2_t q = {sub_f32(r[0], __uint_as_float(p2 << 16)), sub_f32(r[1], __uint_as_float(p2 & 0xffff0000u))};
+    p3 = __builtin_bit_cast(unsigned int, __builtin_convertvector(q, bf16x2_t));
+}
+__device__ __forceinline__ Frag3 split_fragment(const float4& lo, const float4& hi) {
+    unsigned int a[4], b[4], c[4];
+    split_pair(lo.x, lo.y, a[0], b[0], c[0]);
+    split_pair(lo.z, lo.w, a[1], b[1], c[1]);
+    split_pair(hi.x, hi.y, a[2], b[2], c[2]);
+    split_pair(hi.z, hi.w, a[3], b[3], c[3]);
+    Frag3 f;
+    const u32x4 wa = {a[0], a[1], a[2], a[3]}, wb = {b[0], b[1], b[2], b[3]}, wc = {c[0], c[1], c[2], c[3]};
+    f.p[0] = __builtin_bit_cast(bf16x8, wa);
+    f.p[1] = __builtin_bit_cast(bf16x8, wb);
+    f.p[2] = __builtin_bit_cast(bf16x8, wc);
+    return f;
+}
+// six MFMAs of one 32 x 32 block, smallest terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const Frag3& x, const bf16x8& w1, const bf16x8& w2, const bf16x8& w3) {
+    PR_MFMA_BF16(acc, x.p[1], w2);
+    PR_MFMA_BF16(acc, x.p[0], w3);
+    PR_MFMA_BF16(acc, x.p[2], w1);
+    PR_MFMA_BF16(acc, x.p[0], w2);
+    PR_MFMA_BF16(acc, x.p[1], w1);
+    PR_MFMA_BF16(acc, x.p[0], w1);
+}
+
+// the six terms of the blocks of one step, block by block inside a term (consecutive MFMAs write different accumulators)
+#define PR_STEP_MFMAS(F0, F1, WA0, WA1, WA2, WB0, WB1, WB2)                                                                             \
+    do {                                                                                                                             \
+        if (two) {                                                                                                                   \
+            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1); PR_MFMA_BF16(a10, F0.p[1], WB1); PR_MFMA_BF16(a11, F1.p[1], WB1); \
+            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2); PR_MFMA_BF16(a10, F0.p[0], WB2); PR_MFMA_BF16(a11, F1.p[0], WB2); \
+            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0); PR_MFMA_BF16(a10, F0.p[2], WB0); PR_MFMA_BF16(a11, F1.p[2], WB0); \
+            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1); PR_MFMA_BF16(a10, F0.p[0], WB1); PR_MFMA_BF16(a11, F1.p[0], WB1); \
+            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0); PR_MFMA_BF16(a10, F0.p[1], WB0); PR_MFMA_BF16(a11, F1.p[1], WB0); \
+            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0); PR_MFMA_BF16(a10, F0.p[0], WB0); PR_MFMA_BF16(a11, F1.p[0], WB0); \
+        } else {                                                                                                                     \
+            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2);                                                        \
+            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1);                                                        \
+            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0);                                                        \
+            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0);                                                        \
+        }                                                                                                                            \
+    } while (0)
+
+__device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                   f32x16& a11, const Drain* drain = nullptr) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    if (cbA >= nblk) return;
+    const bool two = cbB < nblk;
+    __builtin_amdgcn_s_setprio(1);
+    const int ks = sg.kq >> 1;                       // K steps of 16 (even: the padded widths are multiples of 32)
+    const float* ap = X + r * LDX + 8 * half;
+    // [column block][step][plane][lane] fragments of 16 bytes
+    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
+    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
+    // software pipeline with NAMED even / odd register sets (a rotating set costs a register copy per value and step: 6 moves
+    // per MFMA, measured): the MFMAs of a step run on fragments that were split during the previous step; while they execute, the
+    // raw operands of the next step (requested in front of them) are split - the conversions sit in the shadow of the MFMAs
+    float4 xl, xh, yl, yh;
+    xl = *reinterpret_cast<const float4*>(ap); xh = *reinterpret_cast<const float4*>(ap + 4);
+    yl = *reinterpret_cast<const float4*>(ap + 32 * LDX); yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    Frag3 e0 = split_fragment(xl, xh), e1 = split_fragment(yl, yh), o0, o1;
+    bf16x8 ea0 = wpA[0], ea1 = wpA[64], ea2 = wpA[128], eb0 = wpB[0], eb1 = wpB[64], eb2 = wpB[128];
+    bf16x8 oa0, oa1, oa2, ob0 = eb0, ob1 = eb1, ob2 = eb2;
+    for (int s = 0; s < ks; s += 2) {
+        // ---- even step: request the odd step's operands, multiply the even fragments, split the odd ones
+        {
+            const float* an = ap + 16 * (s + 1);
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)(s + 1) * 192;
+            oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
+            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);      // the requests stay in FRONT of the step's MFMAs (hipcc sank them behind: L2 latency exposed every step)
+            PR_STEP_MFMAS(e0, e1, ea0, ea1, ea2, eb0, eb1, eb2);
+            o0 = split_fragment(xl, xh); o1 = split_fragment(yl, yh);
+            if (drain) drain_chunk(*drain, X, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- odd step
+        {
+            const int sn = (s + 2 < ks) ? s + 2 : s;
+            const float* an = ap + 16 * sn;
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)sn * 192;
+            ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
+            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS(o0, o1, oa0, oa1, oa2, ob0, ob1, ob2);
+            e0 = split_fragment(xl, xh); e1 = split_fragment(yl, yh);
+            if (drain) drain_chunk(*drain, X, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// The same loop with fewer live registers, for the training FORWARD kernel (which carries its input encoding and its batch-statistics
+// sums in registers across the layers): the fragments of a step are split at the top of the step from the raw operands requested
+// during the previous one - one converted set instead of two; the conversions then run in front of the step's MFMAs and overlap
+// the other resident tile's matrix work only.
+__device__ __forceinline__ void tile_products_bf16_lean(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                        f32x16& a11) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    if (cbA >= nblk) return;
+    const bool two = cbB < nblk;
+    __builtin_amdgcn_s_setprio(1);
+    const int ks = sg.kq >> 1;
+    const float* ap = X + r * LDX + 8 * half;
+    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
+    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
+    float4 xl = *reinterpret_cast<const float4*>(ap), xh = *reinterpret_cast<const float4*>(ap + 4);
+    float4 yl = *reinterpret_cast<const float4*>(ap + 32 * LDX), yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    bf16x8 ea0 = wpA[0], ea1 = wpA[64], ea2 = wpA[128], eb0 = wpB[0], eb1 = wpB[64], eb2 = wpB[128];
+    bf16x8 oa0, oa1, oa2, ob0 = eb0, ob1 = eb1, ob2 = eb2;
+    for (int s = 0; s < ks; s += 2) {
+        {
+            const Frag3 f0 = split_fragment(xl, xh), f1 = split_fragment(yl, yh);
+            const float* an = ap + 16 * (s + 1);
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)(s + 1) * 192;
+            oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
+            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS(f0, f1, ea0, ea1, ea2, eb0, eb1, eb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const Frag3 f0 = split_fragment(xl, xh), f1 = split_fragment(yl, yh);
+            const int sn = (s + 2 < ks) ? s + 2 : s;
+            const float* an = ap + 16 * sn;
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)sn * 192;
+            ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
+            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS(f0, f1, oa0, oa1, oa2, ob0, ob1, ob2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <bool BWD, bool BITS, bool STATS, bool SPLIT>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
                                           const BwdEpilogue* bwd, unsigned long long* bits_out, ColumnStats* stats) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -288,6 +488,10 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
 #if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 128)
         continue;   // measurement build: no matrix work (results are wrong)
 #endif
+        if (SPLIT) {
+            tile_products_bf16_lean(sg, nblk, S.X, a00, a01, a10, a11);
+            continue;
+        }
         // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
         __builtin_amdgcn_s_setprio(1);
         const int kq = sg.kq;   // even (K is padded to a multiple of 16)

@@ -115,6 +115,8 @@ struct PackedLayout {
     int t3_b_act[PR_MAX_LAYERS], t3_b_skip, t3_b_first;
     int t3_n_act[PR_MAX_LAYERS], t3_n_skip, t3_n_first;
     int t3_h0, t3_h3, t3_h6;
+    // ... and the FORWARD segments of phase 1 of a training call (ray bender, backbone, head layer 0) as bf16 triples
+    int b_seg3[PR_MAX_LAYERS][2], n_seg3[PR_MAX_LAYERS][2], h0_3;
     int total;
 };
 
@@ -202,6 +204,7 @@ struct MlpParams {
     int32_t* pend_meta;          // (MAX_RESIDENT_TILES, TILE_M, 2) [compact feature row, frame] of the pending rows
     int32_t* head_count;         // device counter: rows sent through the feature head (NULL = not counted)
     int32_t* tile_counter;       // zeroed device counter: tiles beyond the first of a workgroup are claimed from it (NULL: strided)
+    int split3;                  // 1 (phase 1 of a training call): the layer segments are bf16-triple packings (six bf16 MFMAs per product)
     // outputs
     float* sigma;                // dense (N,R,P)
     float* dispmag;              // dense (N,R,P) or NULL
@@ -479,7 +482,7 @@ bool group_active(const pr_call_t& c);
 int make_plan(const pr_call_t& c, const pr_object_t* objs, Plan* plan);
 void bbox_split(const pr_object_model_t& m, float* lo, float* hi, float* size);
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
-                     MlpParams* p);
+                     MlpParams* p, bool split3 = false);
 
 // ---------------------------------------------------------------------------------------------
 // Backward pass building blocks (gemm.hip, backward.hip)

@@ -95,7 +95,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
-                     MlpParams* p);
+                     MlpParams* p, bool split3);
 
 // ---------------------------------------------------------------------------------------------
 // Workspace plan (structs in pr_common.h)
@@ -497,7 +497,9 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
 
             MlpParams mp;
             memset(&mp, 0, sizeof(mp));
-            PR_TRY(build_mlp_layers(m, d, l, packed, &mp));
+            // training calls with PR_FLAG_SPLIT_BACKWARD: phase 1 of the grouped launches reads the bf16-triple packings
+            const bool split3 = train_grouped && (c.flags & PR_FLAG_SPLIT_BACKWARD) && (c.flags & PR_FLAG_SAVE_FOR_BACKWARD);
+            PR_TRY(build_mlp_layers(m, d, l, packed, &mp, split3));
             mp.rec_pos = rec_pos; mp.rec_flat = rec_flat; mp.total = totals + k;
             mp.samples_per_frame = c.rays * P; mp.positions = P; mp.rays = c.rays;
             mp.canonical = (c.flags & PR_FLAG_CANONICAL_POSE) ? 1 : 0;
@@ -599,6 +601,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                         b.running_mean = m.bn1_mean; b.running_var = m.bn1_var; b.num_batches_tracked = (long long*)m.bn1_batches;
                         b.batch_mean = J.batch; b.batch_var = J.batch + MAX_WIDTH;
                         b.affine = m.affine1; b.g_off = 0; b.b_off = J.d.Wpad;
+                        J.mp.split3 = 0;     // (the head phases read fp32 fragments)
                         J.mp.phase = 2; J.mp.h_in = J.h1; J.mp.h_in_width = J.d.Wpad; J.mp.h_out = J.h2; J.mp.h_out_width = J.d.W2pad;
                         J.mp.stats = J.stats + 2 * MAX_WIDTH;
                     } else {

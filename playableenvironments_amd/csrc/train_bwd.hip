@@ -58,23 +58,6 @@ __device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d
 // ``drain``: the operand tile in X is also WRITTEN OUT to global memory while the product runs - one 16-byte chunk per thread and
 // loop iteration (a tile of width Wpad has Wpad / 16 chunks per thread and the loop Wpad / 16 iterations), so that the 64 KB of a
 // tile reach the memory system spread over the K loop instead of as one burst in front of it.
-struct Drain {
-    float* dst;            // row `tile_base` of the (cap, ld) destination; NULL: nothing to write
-    int ld, w4, rows_valid;
-};
-__device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int it) {
-    const int idx = threadIdx.x + it * MLP_THREADS;
-    const int row = idx / d.w4, c = (idx - row * d.w4) * 4;
-    if (row < d.rows_valid) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
-#ifdef PR_DRAIN_NT
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
-#else
-        *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
-#endif
-    }
-}
 // every wave runs the loop (so every thread drains its chunks) when the product has at least MLP_WAVES column blocks
 __device__ __forceinline__ bool drains_in_loop(int nblk) {
 #ifdef PR_NO_DRAIN
@@ -155,124 +138,6 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
     __builtin_amdgcn_s_setprio(0);
 }
 
-// The same product in SPLIT precision (PR_FLAG_SPLIT_BACKWARD; `sg.w` then points at the bf16-triple packing of the segment,
-// k_pack kind 3): every fp32 operand as three bf16 terms, x = b1 + b2 + b3 exactly, a product as the six bf16 MFMAs whose terms
-// are >= 2^-16 of it (see k_gemm_tn_all_bf16 in gemm.hip) - 16 K-values retire in 6 x 32 cycles where the fp32 pipe needs
-// 8 x 64.  The operand tile stays fp32 in X (it is also the gradient that is written out): a lane reads its eight consecutive
-// K-values of a step (two 16-byte LDS reads) and splits them in registers, behind the MFMAs of the previous step.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define PR_MFMA_BF16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
-
-struct Frag3 { bf16x8 p[3]; };
-__device__ __forceinline__ Frag3 split_fragment(const float4& lo, const float4& hi) {
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    unsigned int a[8], b[8], c[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a[i] = __float_as_uint(v[i]) & 0xffff0000u;
-        const float r1 = v[i] - __uint_as_float(a[i]);        // exact
-        b[i] = __float_as_uint(r1) & 0xffff0000u;
-        c[i] = __float_as_uint(r1 - __uint_as_float(b[i]));   // exact: at most 8 significant bits are left
-    }
-    Frag3 f;
-    u32x4 w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(a[2 * i + 1], a[2 * i], 0x07060302u);
-    f.p[0] = __builtin_bit_cast(bf16x8, w);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(b[2 * i + 1], b[2 * i], 0x07060302u);
-    f.p[1] = __builtin_bit_cast(bf16x8, w);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(c[2 * i + 1], c[2 * i], 0x07060302u);
-    f.p[2] = __builtin_bit_cast(bf16x8, w);
-    return f;
-}
-// six MFMAs of one 32 x 32 block, smallest terms first
-__device__ __forceinline__ void mfma6(f32x16& acc, const Frag3& x, const bf16x8& w1, const bf16x8& w2, const bf16x8& w3) {
-    PR_MFMA_BF16(acc, x.p[1], w2);
-    PR_MFMA_BF16(acc, x.p[0], w3);
-    PR_MFMA_BF16(acc, x.p[2], w1);
-    PR_MFMA_BF16(acc, x.p[0], w2);
-    PR_MFMA_BF16(acc, x.p[1], w1);
-    PR_MFMA_BF16(acc, x.p[0], w1);
-}
-
-// the six terms of the blocks of one step, block by block inside a term (consecutive MFMAs write different accumulators)
-#define PR_STEP_MFMAS(F0, F1, WA0, WA1, WA2, WB0, WB1, WB2)                                                                             \
-    do {                                                                                                                             \
-        if (two) {                                                                                                                   \
-            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1); PR_MFMA_BF16(a10, F0.p[1], WB1); PR_MFMA_BF16(a11, F1.p[1], WB1); \
-            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2); PR_MFMA_BF16(a10, F0.p[0], WB2); PR_MFMA_BF16(a11, F1.p[0], WB2); \
-            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0); PR_MFMA_BF16(a10, F0.p[2], WB0); PR_MFMA_BF16(a11, F1.p[2], WB0); \
-            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1); PR_MFMA_BF16(a10, F0.p[0], WB1); PR_MFMA_BF16(a11, F1.p[0], WB1); \
-            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0); PR_MFMA_BF16(a10, F0.p[1], WB0); PR_MFMA_BF16(a11, F1.p[1], WB0); \
-            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0); PR_MFMA_BF16(a10, F0.p[0], WB0); PR_MFMA_BF16(a11, F1.p[0], WB0); \
-        } else {                                                                                                                     \
-            PR_MFMA_BF16(a00, F0.p[1], WA1); PR_MFMA_BF16(a01, F1.p[1], WA1);                                                        \
-            PR_MFMA_BF16(a00, F0.p[0], WA2); PR_MFMA_BF16(a01, F1.p[0], WA2);                                                        \
-            PR_MFMA_BF16(a00, F0.p[2], WA0); PR_MFMA_BF16(a01, F1.p[2], WA0);                                                        \
-            PR_MFMA_BF16(a00, F0.p[0], WA1); PR_MFMA_BF16(a01, F1.p[0], WA1);                                                        \
-            PR_MFMA_BF16(a00, F0.p[1], WA0); PR_MFMA_BF16(a01, F1.p[1], WA0);                                                        \
-            PR_MFMA_BF16(a00, F0.p[0], WA0); PR_MFMA_BF16(a01, F1.p[0], WA0);                                                        \
-        }                                                                                                                            \
-    } while (0)
-
-__device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                                   f32x16& a11, const Drain* drain = nullptr) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & 31, half = lane >> 5;
-    const int cbA = wave, cbB = wave + MLP_WAVES;
-    if (cbA >= nblk) return;
-    const bool two = cbB < nblk;
-    __builtin_amdgcn_s_setprio(1);
-    const int ks = sg.kq >> 1;                       // K steps of 16 (even: the padded widths are multiples of 32)
-    const float* ap = X + r * LDX + 8 * half;
-    // [column block][step][plane][lane] fragments of 16 bytes
-    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
-    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
-    // software pipeline with NAMED even / odd register sets (a rotating set costs a register copy per value and step: 6 moves
-    // per MFMA, measured): the MFMAs of a step run on fragments that were split during the previous step; while they execute, the
-    // raw operands of the next step (requested in front of them) are split - the conversions sit in the shadow of the MFMAs
-    float4 xl, xh, yl, yh;
-    xl = *reinterpret_cast<const float4*>(ap); xh = *reinterpret_cast<const float4*>(ap + 4);
-    yl = *reinterpret_cast<const float4*>(ap + 32 * LDX); yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-    Frag3 e0 = split_fragment(xl, xh), e1 = split_fragment(yl, yh), o0, o1;
-    bf16x8 ea0 = wpA[0], ea1 = wpA[64], ea2 = wpA[128], eb0 = wpB[0], eb1 = wpB[64], eb2 = wpB[128];
-    bf16x8 oa0, oa1, oa2, ob0 = eb0, ob1 = eb1, ob2 = eb2;
-    for (int s = 0; s < ks; s += 2) {
-        // ---- even step: request the odd step's operands, multiply the even fragments, split the odd ones
-        {
-            const float* an = ap + 16 * (s + 1);
-            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
-            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)(s + 1) * 192;
-            oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
-            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
-            __builtin_amdgcn_sched_barrier(0);      // the requests stay in FRONT of the step's MFMAs (hipcc sank them behind: L2 latency exposed every step)
-            PR_STEP_MFMAS(e0, e1, ea0, ea1, ea2, eb0, eb1, eb2);
-            o0 = split_fragment(xl, xh); o1 = split_fragment(yl, yh);
-            if (drain) drain_chunk(*drain, X, s);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- odd step
-        {
-            const int sn = (s + 2 < ks) ? s + 2 : s;
-            const float* an = ap + 16 * sn;
-            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
-            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)sn * 192;
-            ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
-            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
-            __builtin_amdgcn_sched_barrier(0);
-            PR_STEP_MFMAS(o0, o1, oa0, oa1, oa2, ob0, ob1, ob2);
-            e0 = split_fragment(xl, xh); e1 = split_fragment(yl, yh);
-            if (drain) drain_chunk(*drain, X, s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-}
 template <bool SPLIT>
 __device__ __forceinline__ void tile_products_any(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
                                                   f32x16& a11, const Drain* drain = nullptr) {
