@@ -379,6 +379,39 @@ int pr_pose_matrices(int32_t count, const float* rotations, const float* transla
 int pr_pose_matrices_backward(int32_t count, const float* rotations, const float* translations, const float* g_matrices,
                               const float* g_inverses, float* g_rotations, float* g_translations, void* stream);
 
+/* Scene set-up of an evaluation call in ONE launch - replaces, for tensors without a graph, the span of
+ * EnvironmentModel.forward_from_scene_encoding between the scene encoding and the composer call (reference:
+ * model/environment_model.py:1066-1112: Transformations3D.homogeneous_rotation_translation + torch.inverse for cameras and objects,
+ * compute_object_bounding_boxes :234-327, compute_object_axes_projection :329-404) and the permutes that bring the reference's
+ * (..., 3 | S | D, K) scene tensors into the renderer's layouts.  Arithmetic = pr_pose_matrices + pr_project_points, bit for bit.
+ * frames = product of the leading dims incl. observations; renderer frame n = frame * cameras + camera. */
+typedef struct {
+    int32_t frames, cameras, objects, box_points_per_object, style_features, deformation_features, height, width;
+    float focal_multiplier;          /* config["data"]["focal_length_multiplier"] */
+    float upsample_factor;           /* boxes (and the rays) use focals * multiplier * upsample_factor */
+    int32_t axes_with_upsampled_focals; /* 0: the axes use focals * multiplier (forward_from_scene_encoding), 1: the upsampled ones */
+    const float* camera_rotations;   /* (frames, cameras, 3) */
+    const float* camera_translations;
+    const float* focals;             /* (frames, cameras) */
+    const float* object_rotations;   /* (frames, 3, objects): the reference's trailing-object layout */
+    const float* object_translations;
+    const float* style;              /* (frames, S, objects) */
+    const float* deformation;        /* (frames, D, objects) */
+    const uint8_t* object_in_scene;  /* (frames, objects) bool */
+    const float* box_points;         /* (objects, box_points_per_object, 3) object-frame corner + edge points */
+    const float* axes_points;        /* (objects, 4, 3) origin + unit axes */
+    float* boxes;                    /* out (frames, cameras, 4, objects) [left, top, right, bottom], clamped to [0, 1] */
+    float* projected_points;         /* out (frames, cameras, box_points_per_object, 2, objects), clamped */
+    float* axes;                     /* out (frames, cameras, 4, 2, objects), not clamped */
+    float* camera34;                 /* out (frames * cameras, 3, 4): the c2w rows pr_camera_rays takes */
+    float* render_focals;            /* out (frames * cameras) */
+    float* w2o34;                    /* out (frames * cameras, objects, 3, 4): pr_call_t.w2o */
+    float* style_nks;                /* out (frames * cameras, objects, S): pr_call_t.style */
+    float* deformation_nkd;          /* out (frames * cameras, objects, D): pr_call_t.deformation */
+    uint8_t* present;                /* out (frames * cameras, objects): pr_call_t.object_in_scene */
+} pr_scene_setup_t;
+int pr_scene_setup(const pr_scene_setup_t* setup, void* stream);
+
 /*
  * Projects object-frame points into the cameras of their frame (EnvironmentModel.compute_object_bounding_boxes /
  * compute_object_axes_projection, model/environment_model.py:234-404).  points (K,P,3); o2w (F,K,4,4); w2c (F,C,4,4);

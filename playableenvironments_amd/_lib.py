@@ -146,6 +146,19 @@ class InputGrads(C.Structure):
 
 
 # every exported symbol of include/playrender.h : (restype, argtypes)
+class SceneSetup(C.Structure):
+    """pr_scene_setup_t (include/playrender.h)."""
+    _fields_ = [("frames", C.c_int32), ("cameras", C.c_int32), ("objects", C.c_int32), ("box_points_per_object", C.c_int32),
+                ("style_features", C.c_int32), ("deformation_features", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("focal_multiplier", C.c_float), ("upsample_factor", C.c_float), ("axes_with_upsampled_focals", C.c_int32),
+                ("camera_rotations", C.c_void_p), ("camera_translations", C.c_void_p), ("focals", C.c_void_p),
+                ("object_rotations", C.c_void_p), ("object_translations", C.c_void_p), ("style", C.c_void_p),
+                ("deformation", C.c_void_p), ("object_in_scene", C.c_void_p), ("box_points", C.c_void_p), ("axes_points", C.c_void_p),
+                ("boxes", C.c_void_p), ("projected_points", C.c_void_p), ("axes", C.c_void_p), ("camera34", C.c_void_p),
+                ("render_focals", C.c_void_p), ("w2o34", C.c_void_p), ("style_nks", C.c_void_p), ("deformation_nkd", C.c_void_p),
+                ("present", C.c_void_p)]
+
+
 SYMBOLS = {
     "pr_packed_size": (C.c_int, [C.POINTER(ObjectModel), C.POINTER(C.c_size_t)]),
     "pr_pack_model": (C.c_int, [C.POINTER(ObjectModel), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -174,6 +187,7 @@ SYMBOLS = {
                                             C.c_void_p]),
     "pr_project_points": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_scene_setup": (C.c_int, [C.POINTER(SceneSetup), C.c_void_p]),
     "pr_patch_pixels": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_last_error": (C.c_char_p, []),

@@ -684,11 +684,8 @@ namespace pr {
 // Transformations3D.homogeneous_rotation_translation (utils/lib_3d/transformations_3d.py:69-96) and the torch.inverse the
 // reference applies to it (environment_model.py:221, :1078).  As torch ops this is ~30 launches per call (six sin / cos,
 // stacks, two 3 x 3 products, slice assignments, the inverse's product and concatenations) for a few hundred FLOPs.
-__global__ void k_pose_matrices(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
-                                float* __restrict__ matrices, float* __restrict__ inverses) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float ax = rotations[i * 3 + 0], ay = rotations[i * 3 + 1], az = rotations[i * 3 + 2];
+// m / v: 16 floats each (row-major 4 x 4)
+__device__ __forceinline__ void pose_pair(float ax, float ay, float az, const float* t, float* m, float* v) {
     const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
     const float rx[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
     const float ry[9] = {cy, 0.f, sy, 0.f, 1.f, 0.f, -sy, 0.f, cy};
@@ -706,9 +703,6 @@ __global__ void k_pose_matrices(int count, const float* __restrict__ rotations, 
             for (int k = 0; k < 3; ++k) acc = __fadd_rn(acc, __fmul_rn(ry[a * 3 + k], xz[k * 3 + b]));
             r[a * 3 + b] = acc;
         }
-    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
-    float* m = matrices + (size_t)i * 16;
-    float* v = inverses + (size_t)i * 16;
     for (int a = 0; a < 3; ++a) {
         for (int b = 0; b < 3; ++b) {
             m[a * 4 + b] = r[a * 3 + b];
@@ -722,6 +716,19 @@ __global__ void k_pose_matrices(int count, const float* __restrict__ rotations, 
     for (int b = 0; b < 3; ++b) m[12 + b] = v[12 + b] = 0.f;
     m[15] = v[15] = 1.f;
 }
+
+__global__ void k_pose_matrices(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
+                                float* __restrict__ matrices, float* __restrict__ inverses) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
+    float m[16], v[16];
+    pose_pair(rotations[i * 3 + 0], rotations[i * 3 + 1], rotations[i * 3 + 2], t, m, v);
+    for (int e = 0; e < 16; ++e) {
+        matrices[(size_t)i * 16 + e] = m[e];
+        inverses[(size_t)i * 16 + e] = v[e];
+    }
+}
 }  // namespace pr
 
 namespace pr {
@@ -731,20 +738,14 @@ namespace pr {
 // (v + size / 2) / size.  One 64-lane workgroup per (frame, camera, object); with `boxes` the lanes also reduce the
 // points to [left, top, right, bottom], points behind the camera (cam.z > 0) counting as +-1e20, and both outputs are
 // clamped to [0, 1] (the bounding-box variant); without, the points are left unclamped (the axes variant).
-__global__ __launch_bounds__(64) void k_project_points(int frames, int cameras, int objects, int npoints, const float* __restrict__ points,
-                                                      const float* __restrict__ o2w, const float* __restrict__ w2c,
-                                                      const float* __restrict__ focals, float width, float height,
-                                                      float* __restrict__ out_points, float* __restrict__ boxes) {
-    const int k = blockIdx.x % objects;
-    const int c = (blockIdx.x / objects) % cameras;
-    const int f = blockIdx.x / (objects * cameras);
-    const int lane = threadIdx.x;
-    const float* mo = o2w + ((size_t)f * objects + k) * 16;
-    const float* mc = w2c + ((size_t)f * cameras + c) * 16;
-    const float focal = focals[(size_t)f * cameras + c];
+// one object's points through one camera, by the 64 lanes of a wave: mo / mc = 16-float matrices (o2w of the object, w2c of the
+// camera); out_points / boxes already point at element [f][c] of their arrays
+__device__ __forceinline__ void project_object(int lane, int k, int objects, int npoints, const float* __restrict__ pts, const float* mo,
+                                               const float* mc, float focal, float width, float height, float* __restrict__ out_points,
+                                               float* __restrict__ boxes) {
     float lo_x = 1e20f, lo_y = 1e20f, hi_x = -1e20f, hi_y = -1e20f;
     for (int i = lane; i < npoints; i += 64) {
-        const float* pt = points + ((size_t)k * npoints + i) * 3;
+        const float* pt = pts + (size_t)i * 3;
         float w[3], cam[3];
         for (int a = 0; a < 3; ++a)
             w[a] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(pt[0], mo[a * 4 + 0]), __fmul_rn(pt[1], mo[a * 4 + 1])),
@@ -766,8 +767,8 @@ __global__ __launch_bounds__(64) void k_project_points(int frames, int cameras, 
             nx = fminf(fmaxf(nx, 0.f), 1.f);
             ny = fminf(fmaxf(ny, 0.f), 1.f);
         }
-        // (frames, cameras, points, 2, objects)
-        float* dst = out_points + ((((size_t)f * cameras + c) * npoints + i) * 2) * objects + k;
+        // (points, 2, objects)
+        float* dst = out_points + ((size_t)i * 2) * objects + k;
         dst[0] = nx;
         dst[objects] = ny;
     }
@@ -782,12 +783,79 @@ __global__ __launch_bounds__(64) void k_project_points(int frames, int cameras, 
         if (lane == 0) {
             const float v[4] = {lo_x, lo_y, hi_x, hi_y};
             const float size[4] = {width, height, width, height};
-            float* dst = boxes + (((size_t)f * cameras + c) * 4) * objects + k;      // (frames, cameras, 4, objects)
+            float* dst = boxes + k;      // (4, objects)
             for (int a = 0; a < 4; ++a) {
                 const float n = __fdiv_rn(__fadd_rn(v[a], size[a] / 2.0f), size[a]);
                 dst[(size_t)a * objects] = fminf(fmaxf(n, 0.f), 1.f);
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_project_points(int frames, int cameras, int objects, int npoints, const float* __restrict__ points,
+                                                      const float* __restrict__ o2w, const float* __restrict__ w2c,
+                                                      const float* __restrict__ focals, float width, float height,
+                                                      float* __restrict__ out_points, float* __restrict__ boxes) {
+    const int k = blockIdx.x % objects;
+    const int c = (blockIdx.x / objects) % cameras;
+    const int f = blockIdx.x / (objects * cameras);
+    const size_t fc = (size_t)f * cameras + c;
+    project_object(threadIdx.x, k, objects, npoints, points + (size_t)k * npoints * 3, o2w + ((size_t)f * objects + k) * 16, w2c + fc * 16,
+                   focals[fc], width, height, out_points + fc * npoints * 2 * objects, boxes ? boxes + fc * 4 * objects : nullptr);
+}
+
+// Scene set-up of an evaluation call in ONE launch (EnvironmentModel.forward_from_scene_encoding without a graph): camera and
+// object pose matrices with their rigid inverses, the projected boxes / box points / axes, and the renderer's inputs in the
+// renderer's layouts - what used to be two pose launches, two projection launches and ~10 small copy kernels (permutes of the
+// (..., 3 | S | D, K) scene tensors).  One workgroup of 256 threads per (frame, camera); the arithmetic is pose_pair /
+// project_object, i.e. bit for bit what the separate launches compute.
+struct SceneSetup {
+    int frames, cameras, objects, points, S, D;
+    float width, height, focal_multiplier, upsample;
+    int axes_with_upsampled_focals;
+    const float* cam_rot; const float* cam_tr; const float* focals;          // (frames, cameras, 3), (frames, cameras)
+    const float* obj_rot; const float* obj_tr;                               // (frames, 3, objects)
+    const float* style; const float* deformation; const uint8_t* in_scene;   // (frames, S | D, objects), (frames, objects)
+    const float* box_points; const float* axes_points;                       // (objects, points, 3), (objects, 4, 3)
+    float* boxes; float* projected; float* axes;                             // (frames, cameras, 4 | points x 2 | 4 x 2, objects)
+    float* camera34; float* render_focals;                                   // (frames x cameras, 3, 4), (frames x cameras)
+    float* w2o34; float* style_nks; float* deformation_nkd; uint8_t* present; // (frames x cameras, objects, 3 x 4 | S | D | 1)
+};
+__global__ __launch_bounds__(256) void k_scene_setup(SceneSetup p) {
+    __shared__ float cam[32];                       // c2w, w2c
+    __shared__ float obj[PR_MAX_OBJECTS][32];       // o2w, w2o per object
+    __shared__ float foc[2];                        // rescaled focal, render focal
+    const int f = blockIdx.x / p.cameras, c = blockIdx.x % p.cameras;
+    const int tid = threadIdx.x, K = p.objects;
+    const size_t fc = blockIdx.x;
+    if (tid == 0) {
+        const float* r = p.cam_rot + fc * 3;
+        const float t[3] = {p.cam_tr[fc * 3 + 0], p.cam_tr[fc * 3 + 1], p.cam_tr[fc * 3 + 2]};
+        pose_pair(r[0], r[1], r[2], t, cam, cam + 16);
+        const float f1 = __fmul_rn(p.focals[fc], p.focal_multiplier);
+        foc[0] = f1;
+        foc[1] = p.upsample == 1.0f ? f1 : __fmul_rn(f1, p.upsample);
+    } else if (tid >= 64 && tid < 64 + K) {
+        const int k = tid - 64;
+        const float* r = p.obj_rot + (size_t)f * 3 * K + k;
+        const float* tr = p.obj_tr + (size_t)f * 3 * K + k;
+        const float t[3] = {tr[0], tr[K], tr[2 * K]};
+        pose_pair(r[0], r[K], r[2 * K], t, obj[k], obj[k] + 16);
+    }
+    __syncthreads();
+    if (tid < 12) p.camera34[fc * 12 + tid] = cam[tid];
+    if (tid == 12) p.render_focals[fc] = foc[1];
+    for (int e = tid; e < K * 12; e += 256) p.w2o34[fc * K * 12 + e] = obj[e / 12][16 + e % 12];
+    for (int e = tid; e < K * p.S; e += 256) p.style_nks[fc * K * p.S + e] = p.style[((size_t)f * p.S + e % p.S) * K + e / p.S];
+    for (int e = tid; e < K * p.D; e += 256) p.deformation_nkd[fc * K * p.D + e] = p.deformation[((size_t)f * p.D + e % p.D) * K + e / p.D];
+    if (tid < K) p.present[fc * K + tid] = p.in_scene[(size_t)f * K + tid] ? 1 : 0;
+    // projections: wave w takes the objects w, w + 4, ...
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int k = wave; k < K; k += 4) {
+        project_object(lane, k, K, p.points, p.box_points + (size_t)k * p.points * 3, obj[k], cam + 16, foc[1], p.width, p.height,
+                       p.projected + fc * p.points * 2 * K, p.boxes + fc * 4 * K);
+        project_object(lane, k, K, 4, p.axes_points + (size_t)k * 12, obj[k], cam + 16, p.axes_with_upsampled_focals ? foc[1] : foc[0],
+                       p.width, p.height, p.axes + fc * 8 * K, nullptr);
     }
 }
 }  // namespace pr
@@ -801,6 +869,33 @@ extern "C" int pr_project_points(int32_t frames, int32_t cameras, int32_t object
     PR_REQUIRE(points && o2w && w2c && focals && projected, "pr_project_points: NULL pointer");
     hipLaunchKernelGGL(pr::k_project_points, dim3((unsigned)(frames * cameras * objects)), dim3(64), 0, (hipStream_t)stream, frames,
                        cameras, objects, points_per_object, points, o2w, w2c, focals, (float)width, (float)height, projected, boxes);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
+
+extern "C" int pr_scene_setup(const pr_scene_setup_t* q, void* stream) {
+    PR_REQUIRE(q != nullptr, "pr_scene_setup: NULL argument");
+    PR_REQUIRE(q->frames >= 0 && q->cameras > 0 && q->objects > 0 && q->objects <= PR_MAX_OBJECTS && q->box_points_per_object > 0 &&
+                   q->height > 0 && q->width > 0 && q->style_features >= 0 && q->deformation_features >= 0,
+               "pr_scene_setup: bad sizes");
+    if (q->frames == 0) return PR_OK;
+    PR_REQUIRE(q->camera_rotations && q->camera_translations && q->focals && q->object_rotations && q->object_translations && q->style &&
+                   q->deformation && q->object_in_scene && q->box_points && q->axes_points && q->boxes && q->projected_points && q->axes &&
+                   q->camera34 && q->render_focals && q->w2o34 && q->style_nks && q->deformation_nkd && q->present,
+               "pr_scene_setup: NULL pointer");
+    pr::SceneSetup p;
+    p.frames = q->frames; p.cameras = q->cameras; p.objects = q->objects; p.points = q->box_points_per_object;
+    p.S = q->style_features; p.D = q->deformation_features;
+    p.width = (float)q->width; p.height = (float)q->height; p.focal_multiplier = q->focal_multiplier; p.upsample = q->upsample_factor;
+    p.axes_with_upsampled_focals = q->axes_with_upsampled_focals;
+    p.cam_rot = q->camera_rotations; p.cam_tr = q->camera_translations; p.focals = q->focals;
+    p.obj_rot = q->object_rotations; p.obj_tr = q->object_translations;
+    p.style = q->style; p.deformation = q->deformation; p.in_scene = q->object_in_scene;
+    p.box_points = q->box_points; p.axes_points = q->axes_points;
+    p.boxes = q->boxes; p.projected = q->projected_points; p.axes = q->axes;
+    p.camera34 = q->camera34; p.render_focals = q->render_focals;
+    p.w2o34 = q->w2o34; p.style_nks = q->style_nks; p.deformation_nkd = q->deformation_nkd; p.present = q->present;
+    hipLaunchKernelGGL(pr::k_scene_setup, dim3((unsigned)(q->frames * q->cameras)), dim3(256), 0, (hipStream_t)stream, p);
     PR_LAUNCH_CHECK();
     return PR_OK;
 }

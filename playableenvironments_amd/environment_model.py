@@ -179,6 +179,32 @@ def camera_rays(c2w: torch.Tensor, focals: torch.Tensor, height: int, width: int
     return origins.reshape(lead + [3]), dirs.reshape(lead + [r, 3]), normals.reshape(lead + [3])
 
 
+def _camera_rays_prepared(camera34: torch.Tensor, focals: torch.Tensor, lead, height: int, width: int, rows: torch.Tensor,
+                          cols: torch.Tensor):
+    """``camera_rays`` on pr_scene_setup's outputs: camera34 (n, 3, 4) c2w rows, focals (n) - no marshalling copies."""
+    n = camera34.size(0)
+    dev = camera34.device
+    per_frame = rows.dim() > 1
+    r = rows.size(-1)
+    if per_frame:
+        rows = torch.broadcast_to(rows, list(lead) + [r]).reshape(n, r)
+        cols = torch.broadcast_to(cols, list(lead) + [r]).reshape(n, r)
+    if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != dev:
+        rows = rows.to(device=dev, dtype=torch.int32).contiguous()
+        cols = cols.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty(n * (6 + 3 * r), dtype=torch.float32, device=dev)
+    origins, normals, dirs = out[:3 * n].view(n, 3), out[3 * n:6 * n].view(n, 3), out[6 * n:].view(n, r, 3)
+    if n * r == 0:
+        origins.copy_(camera34[:, :, 3])
+        normals.copy_(-camera34[:, :, 2])
+    else:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().pr_camera_rays(n, r, height, width, 1 if per_frame else 0, camera34.data_ptr(), focals.data_ptr(),
+                                                  rows.data_ptr(), cols.data_ptr(), origins.data_ptr(), dirs.data_ptr(), normals.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "pr_camera_rays")
+    return origins.view(list(lead) + [3]), dirs.view(list(lead) + [r, 3]), normals.view(list(lead) + [3])
+
+
 class _CameraRays(torch.autograd.Function):
     """``camera_rays`` with a backward pass: d_cam = ((col - W/2) / f, -(row - H/2) / f, -1), d_world = R d_cam, o = t,
     focal normal = -R[:, 2] (ray_helper.py:15-52, 1203-1227), differentiated with respect to the camera matrix and the
@@ -301,6 +327,9 @@ class EnvironmentModel(nn.Module):
             from .encoders import create_encoders
             self.set_encoders(*create_encoders(config))
         self.current_step = 0
+        #: evaluation calls without a graph run their scene set-up - pose matrices, projected boxes / points / axes, the renderer's
+        #: input layouts - as ONE launch (pr_scene_setup) instead of four kernels and ~10 small copies; results are bit-identical
+        self.fused_scene_setup = True
         # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
         self._pixel_cache: Dict = {}
         self._edge_point_cache: Dict = {}
@@ -484,6 +513,64 @@ class EnvironmentModel(nn.Module):
                  for k in range(helper.objects_count)], dim=0).to(device)
         return self._edge_point_cache[key]
 
+    def _scene_setup(self, camera_rotations, camera_translations, focals, object_rotations, object_translations, object_style,
+                     object_deformation, object_in_scene, height: int, width: int, upsample_factor: float):
+        """pr_scene_setup for an evaluation call (no graph, fp32 device tensors in the reference's layouts); None when the call
+        does not qualify (the tensor route then runs)."""
+        tensors = (camera_rotations, camera_translations, focals, object_rotations, object_translations, object_style, object_deformation)
+        if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+            return None
+        if not (torch.is_tensor(object_in_scene) and object_in_scene.is_cuda and object_in_scene.dtype == torch.bool
+                and object_in_scene.is_contiguous()):
+            return None
+        lead = list(camera_rotations.shape[:-1])                    # (..., O, C)
+        K = self.object_id_helper.objects_count
+        cameras = lead[-1]
+        outer = lead[:-1]
+        S, D = object_style.size(-2), object_deformation.size(-2)
+        if (list(camera_translations.shape) != lead + [3] or list(focals.shape) != lead or
+                list(object_rotations.shape) != outer + [3, K] or list(object_translations.shape) != outer + [3, K] or
+                list(object_style.shape) != outer + [S, K] or list(object_deformation.shape) != outer + [D, K] or
+                list(object_in_scene.shape) != outer + [K] or K > _lib.PR_MAX_OBJECTS):
+            return None
+        dev = camera_rotations.device
+        frames = int(math.prod(outer)) if outer else 1
+        n = frames * cameras
+        points = self._edge_points(dev)
+        key = ("axes_points", str(dev))
+        if key not in self._pixel_cache:
+            self._pixel_cache[key] = torch.tensor([(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)],
+                                                  device=dev).unsqueeze(0).repeat(K, 1, 1).contiguous()
+        axes_points = self._pixel_cache[key]
+        f32 = dict(dtype=torch.float32, device=dev)
+        P = points.size(1)
+        # one arena for the fp32 outputs
+        sizes = [n * 4 * K, n * P * 2 * K, n * 8 * K, n * 12, n, n * K * 12, n * K * S, n * K * D]
+        arena = torch.empty(sum(sizes), **f32)
+        parts, at = [], 0
+        for size in sizes:
+            parts.append(arena[at:at + size])
+            at += size
+        boxes, projected, axes, cam34, render_focals, w2o34, sty, dfm = parts
+        present = torch.empty((n, K), dtype=torch.uint8, device=dev)
+        q = _lib.SceneSetup()
+        q.frames, q.cameras, q.objects, q.box_points_per_object = frames, cameras, K, P
+        q.style_features, q.deformation_features, q.height, q.width = S, D, height, width
+        q.focal_multiplier, q.upsample_factor, q.axes_with_upsampled_focals = float(self.focal_length_multiplier), float(upsample_factor), 0
+        q.camera_rotations, q.camera_translations, q.focals = camera_rotations.data_ptr(), camera_translations.data_ptr(), focals.data_ptr()
+        q.object_rotations, q.object_translations = object_rotations.data_ptr(), object_translations.data_ptr()
+        q.style, q.deformation, q.object_in_scene = object_style.data_ptr(), object_deformation.data_ptr(), object_in_scene.data_ptr()
+        q.box_points, q.axes_points = points.data_ptr(), axes_points.data_ptr()
+        q.boxes, q.projected_points, q.axes = boxes.data_ptr(), projected.data_ptr(), axes.data_ptr()
+        q.camera34, q.render_focals = cam34.data_ptr(), render_focals.data_ptr()
+        q.w2o34, q.style_nks, q.deformation_nkd, q.present = w2o34.data_ptr(), sty.data_ptr(), dfm.data_ptr(), present.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().pr_scene_setup(C.byref(q), torch.cuda.current_stream(dev).cuda_stream), "pr_scene_setup")
+        return {"boxes": boxes.view(lead + [4, K]), "box_points": projected.view(lead + [P, 2, K]), "axes": axes.view(lead + [4, 2, K]),
+                "camera34": cam34.view(n, 3, 4), "render_focals": render_focals,
+                "renderer": {"w2o": w2o34.view(n, K, 3, 4), "style": sty.view(n, K, S), "deformation": dfm.view(n, K, D),
+                             "present": present, "frames": n, "S": S, "D": D}}
+
     def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width, _lazy=False):
         """Image-plane boxes (..., C, 4, K) [left, top, right, bottom] and projected box points
         (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
@@ -557,7 +644,7 @@ class EnvironmentModel(nn.Module):
     # ------------------------------------------------------------------ composer plumbing
     def batchified_composer_call(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                  deformation, object_in_scene, perturb, samples_per_image_batching: int = 0,
-                                 video_indexes=None, canonical_pose: bool = False, _decoder_layout=None):
+                                 video_indexes=None, canonical_pose: bool = False, _decoder_layout=None, _prepared=None):
         """model/environment_model.py:474-521.  The reference chunks rays (1000 per call in full-frame rendering) because it
         materialises (rays, samples, 192) tensors; the fused renderer does not need to.  In EVALUATION mode
         ``samples_per_image_batching`` is therefore accepted and ignored - rays are independent and the BatchNorm layers use
@@ -567,6 +654,8 @@ class EnvironmentModel(nn.Module):
         ``num_batches_tracked`` advance once per chunk - reproduced here chunk for chunk (TensorBatchifier.batchify:
         consecutive ranges of ``samples_per_image_batching`` rays, the last one shorter)."""
         extra = {} if _decoder_layout is None else {"_decoder_layout": _decoder_layout}
+        if _prepared is not None:
+            extra["_prepared"] = _prepared        # (pr_scene_setup's outputs: the composer skips its own marshalling)
         dimension = ray_directions.dim() - 2
         rays = ray_directions.size(dimension)
         if self.object_composer.training and 0 < samples_per_image_batching < rays:
@@ -578,7 +667,7 @@ class EnvironmentModel(nn.Module):
                 current = ray_directions.narrow(dimension, begin, min(samples_per_image_batching, rays - begin))
                 chunks.append(self.object_composer(ray_origins, current, focal_normals, transformation_matrix_w2o, style,
                                                    deformation, object_in_scene, perturb, video_indexes=video_indexes,
-                                                   canonical_pose=canonical_pose))
+                                                   canonical_pose=canonical_pose, **({} if _prepared is None else {"_prepared": _prepared})))
             return self.merge_dictionaries(chunks, dimension=dimension)
         results = self.object_composer(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                        deformation, object_in_scene, perturb, video_indexes=video_indexes,
@@ -649,17 +738,26 @@ class EnvironmentModel(nn.Module):
         a frame in ``render_sharded`` - or, given an int64 tensor, the listed rays (its share of interleaved tiles).  ``_decoder_features`` (extension): the decoder's feature count per stride, e.g.
         [64, 128] - the compositing kernel then also writes ``[type]["global"]["decoder_features"]``, the channels-first
         per-stride maps ``autoencoder_model.forward_decoder`` takes (see ``decoder_layout``)."""
-        rescaled_focals = focals * self.focal_length_multiplier
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
-        # (x * 1.0 is x bit for bit: the common case issues no launch for it)
-        render_focals = rescaled_focals if upsample_factor == 1.0 else rescaled_focals * upsample_factor
-
-        c2w, w2c = pose_matrices(camera_rotations, camera_translations)
-        w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
-                                                              object_translation_parameters_o2w)
-        boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, render_focals, height, width)
-        axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
+        prepared = None
+        if not torch.is_grad_enabled() and self.fused_scene_setup:
+            prepared = self._scene_setup(camera_rotations, camera_translations, focals, object_rotation_parameters_o2w,
+                                         object_translation_parameters_o2w, object_style, object_deformation, object_in_scene,
+                                         height, width, upsample_factor)
+        if prepared is not None:
+            # one launch (pr_scene_setup): pose matrices, projected boxes / points / axes, the renderer's inputs in its layouts
+            boxes, box_points, axes = prepared["boxes"], prepared["box_points"], prepared["axes"]
+            c2w = w2o = None
+        else:
+            rescaled_focals = focals * self.focal_length_multiplier
+            # (x * 1.0 is x bit for bit: the common case issues no launch for it)
+            render_focals = rescaled_focals if upsample_factor == 1.0 else rescaled_focals * upsample_factor
+            c2w, w2c = pose_matrices(camera_rotations, camera_translations)
+            w2o, o2w = self.compute_transformation_matrix_w2o_o2w(object_rotation_parameters_o2w,
+                                                                  object_translation_parameters_o2w)
+            boxes, box_points = self.compute_object_bounding_boxes(o2w, w2c, render_focals, height, width)
+            axes = self.compute_object_axes_projection(o2w, w2c.detach(), rescaled_focals.detach(), height, width)
 
         lead = list(camera_rotations.shape[:-1])
         flat_boxes = boxes.reshape(-1, 4, boxes.size(-1))
@@ -669,14 +767,15 @@ class EnvironmentModel(nn.Module):
         elif samples_per_image == 0:
             # static pixel lists (every pixel, or the strided grids): built once per (size, strides, device)
             strides = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else (int(patch_stride),)
-            key = (height, width, strides if patch_stride else None, str(c2w.device))
+            key = (height, width, strides if patch_stride else None, str(camera_rotations.device))
             if key not in self._pixel_cache:
                 if patch_stride:
                     rows, cols = strided_grid_pixels(height, width, patch_stride)
                 else:
                     r = torch.arange(height * width, dtype=torch.int32)
                     rows, cols = r // width, r % width
-                self._pixel_cache[key] = (rows.to(c2w.device), cols.to(c2w.device))
+                self._pixel_cache[key] = (rows.to(device=camera_rotations.device, dtype=torch.int32).contiguous(),
+                                          cols.to(device=camera_rotations.device, dtype=torch.int32).contiguous())
             rows, cols = self._pixel_cache[key]
         elif self.use_weighted_sampling:
             idx = ray_sampling.sample_pixels_weighted(flat_boxes, self.sampling_weights, height, width, samples_per_image)
@@ -689,7 +788,11 @@ class EnvironmentModel(nn.Module):
             rows, cols = rows.index_select(-1, _ray_range), cols.index_select(-1, _ray_range)
         elif _ray_range is not None:
             rows, cols = rows[..., _ray_range[0]:_ray_range[1]], cols[..., _ray_range[0]:_ray_range[1]]
-        origins, directions, normals = camera_rays(c2w, render_focals, height, width, rows, cols)
+        if prepared is not None:
+            origins, directions, normals = _camera_rays_prepared(prepared["camera34"], prepared["render_focals"], lead, height, width,
+                                                                 rows, cols)
+        else:
+            origins, directions, normals = camera_rays(c2w, render_focals, height, width, rows, cols)
 
         layout = None
         if _decoder_features is not None:
@@ -699,7 +802,7 @@ class EnvironmentModel(nn.Module):
         results = self.batchified_composer_call(origins, directions, normals, w2o, object_style.unsqueeze(-3),
                                                 object_deformation.unsqueeze(-3), object_in_scene.unsqueeze(-2),
                                                 perturb, samples_per_image_batching, canonical_pose=canonical_pose,
-                                                _decoder_layout=layout)
+                                                _decoder_layout=layout, _prepared=None if prepared is None else prepared["renderer"])
         if self.use_image_decoder:
             flat = rows.to(torch.int64) * width + cols.to(torch.int64)
             flat = flat.to(origins.device)

@@ -573,7 +573,7 @@ class ObjectComposer(nn.Module):
                 transformation_matrix_w2o: torch.Tensor, style: torch.Tensor, deformation: torch.Tensor,
                 object_in_scene: torch.Tensor, perturb: bool, video_indexes: torch.Tensor = None,
                 canonical_pose: bool = False, _noise: Optional[dict] = None, _export: bool = False,
-                _decoder_layout: Optional[dict] = None) -> Dict:
+                _decoder_layout: Optional[dict] = None, _prepared: Optional[dict] = None) -> Dict:
         """See model/object_composer.py:786-811 for the argument and result documentation.
 
         ray_origins (..., 3); ray_directions (..., R, 3); focal_normals (..., 3) [unused by the
@@ -598,13 +598,18 @@ class ObjectComposer(nn.Module):
             # the library launches on the caller's stream: that stream's device has to be the current one
             with torch.cuda.device(ray_directions.device):
                 return self._forward(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                                     object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout)
+                                     object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout, _prepared)
         raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
 
     def _forward(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
-                 object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout=None) -> Dict:
+                 object_in_scene, perturb, canonical_pose, _noise, _export, _decoder_layout=None, _prepared=None) -> Dict:
         K = self.object_id_helper.objects_count
         self._raise_pending_batchnorm_check()
+        if _prepared is not None:
+            # EnvironmentModel's fused scene set-up (pr_scene_setup) has produced the renderer's inputs in the renderer's layouts:
+            # an evaluation call without a graph
+            return self._render(ray_origins, ray_directions, focal_normals, None, style, deformation, object_in_scene, perturb,
+                                canonical_pose, _noise, _export, False, None, _decoder_layout, _prepared=_prepared)[0]
         if transformation_matrix_w2o.size(-1) != K:
             raise Exception(f"Transformation matrix must specifies transformations for"
                             f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
@@ -652,7 +657,7 @@ class ObjectComposer(nn.Module):
 
     def _render(self, ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style, deformation,
                 object_in_scene, perturb, canonical_pose=False, _noise=None, _export=False, _save=False, _object_ids=None,
-                _decoder_layout=None, _retry=False):
+                _decoder_layout=None, _retry=False, _prepared=None):
         """The renderer call proper.  Returns (results, state); ``state`` (only with ``_save``) keeps what
         pr_render_backward needs: the call structures, their tensors and the forward workspace.
         ``_object_ids``: render only these object instances (the tensors then carry ``len(_object_ids)`` objects);
@@ -669,17 +674,23 @@ class ObjectComposer(nn.Module):
 
         dirs = ray_directions.detach().to(torch.float32).reshape(N, R, 3).contiguous()
         origins = torch.broadcast_to(ray_origins.detach().to(torch.float32), lead + [3]).reshape(N, 3).contiguous()
-        w2o = torch.broadcast_to(transformation_matrix_w2o.detach().to(torch.float32), lead + [4, 4, K])
-        w2o = w2o.reshape(N, 4, 4, K).permute(0, 3, 1, 2)[:, :, :3, :].contiguous()          # (N, K, 3, 4)
-        S = style.size(-2)
-        D = deformation.size(-2)
-        sty = torch.broadcast_to(style.detach().to(torch.float32), lead + [S, K]).reshape(N, S, K).permute(0, 2, 1).contiguous()
-        dfm = torch.broadcast_to(deformation.detach().to(torch.float32), lead + [D, K]).reshape(N, D, K).permute(0, 2, 1).contiguous()
-        if _object_ids is None and object_in_scene.size(-1) > K:
-            # the reference indexes object_in_scene[..., object_idx] (object_composer.py:823-830): entries beyond the K
-            # objects are never read (forward_from_observations hands over such a tensor, environment_model.py:990-992)
-            object_in_scene = object_in_scene[..., :K]
-        present = torch.broadcast_to(object_in_scene, lead + [K]).reshape(N, K).to(torch.uint8).contiguous()
+        if _prepared is not None:
+            if _prepared["frames"] != N or _save:
+                raise RuntimeError("prepared renderer inputs do not match the call")
+            w2o, sty, dfm, present = _prepared["w2o"], _prepared["style"], _prepared["deformation"], _prepared["present"]
+            S, D = _prepared["S"], _prepared["D"]
+        else:
+            w2o = torch.broadcast_to(transformation_matrix_w2o.detach().to(torch.float32), lead + [4, 4, K])
+            w2o = w2o.reshape(N, 4, 4, K).permute(0, 3, 1, 2)[:, :, :3, :].contiguous()          # (N, K, 3, 4)
+            S = style.size(-2)
+            D = deformation.size(-2)
+            sty = torch.broadcast_to(style.detach().to(torch.float32), lead + [S, K]).reshape(N, S, K).permute(0, 2, 1).contiguous()
+            dfm = torch.broadcast_to(deformation.detach().to(torch.float32), lead + [D, K]).reshape(N, D, K).permute(0, 2, 1).contiguous()
+            if _object_ids is None and object_in_scene.size(-1) > K:
+                # the reference indexes object_in_scene[..., object_idx] (object_composer.py:823-830): entries beyond the K
+                # objects are never read (forward_from_observations hands over such a tensor, environment_model.py:990-992)
+                object_in_scene = object_in_scene[..., :K]
+            present = torch.broadcast_to(object_in_scene, lead + [K]).reshape(N, K).to(torch.uint8).contiguous()
 
         models_c = [self.object_models_coarse[helper.model_idx_by_object_idx(k)] for k in ids]
         models_f = [self.object_models_fine[helper.model_idx_by_object_idx(k)] for k in ids]
@@ -909,7 +920,7 @@ class ObjectComposer(nn.Module):
                         self._budget_ok = 0
                         return self._render(ray_origins, ray_directions, focal_normals, transformation_matrix_w2o, style,
                                             deformation, object_in_scene, perturb, canonical_pose, _noise, _export, _save,
-                                            _object_ids, _decoder_layout, _retry=True)
+                                            _object_ids, _decoder_layout, _retry=True, _prepared=_prepared)
                 workspace = self._workspace
             rc = r1 - r0
             outs = {}

@@ -202,9 +202,10 @@ def test_packed_and_workspace_sizes_on_host(built_library):
     size = C.c_size_t()
     assert built_library.pr_packed_size(C.byref(s), C.byref(size)) == 0
     # fragment-ordered copy = the padded weights for the forward kernels, plus every matrix once more as W^T fragments for
-    # the backward chains (biases and the small heads are not repeated): between 1.9x and 2.4x of the raw parameters
+    # the backward chains (biases and the small heads are not repeated), plus - split-precision training, round 4 - the W^T
+    # fragments and the forward segments of phase 1 once more as bf16 triples (1.5 x the fp32 fragments each)
     raw = sum(p.numel() for n, p in comp.named_parameters() if "affine_transform" not in n) * 4
-    assert 1.9 * raw <= size.value <= 2.4 * raw
+    assert 4.2 * raw <= size.value <= 5.4 * raw, size.value / raw
     call = _lib.Call()
     call.frames, call.rays, call.objects = 1, 1000, 1
     for f in ("ray_origins", "ray_directions", "w2o", "style", "deformation", "object_in_scene"):

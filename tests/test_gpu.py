@@ -1329,10 +1329,13 @@ def test_native_evaluation_frame_matches_oracle(world):
     comp.precision = "fp32"
 
 
-def test_frame_graph_of_the_observation_mode_is_bit_identical():
+def test_frame_graph_of_the_observation_mode_matches_the_eager_call():
     """FrameGraph(mode="observations"): the evaluators' ``render_full_frame_from_observations`` span - this package's CNN encoders
     and pose estimators, roi_pool crops, pose math, rays, renderer - captured once and replayed for another batch: every tensor
-    of the result dictionary equals the eager call's, bit for bit (native 288 x 512 frame, strides [4, 8], two frames)."""
+    of the result dictionary equals the eager call's (native 288 x 512 frame, strides [4, 8], two frames).  Not bit for bit: the
+    stock PyTorch-ROCm convolutions of the encoders are not run-to-run deterministic - two EAGER calls on the same batch differ by
+    5e-7 in the estimated poses (measured, tools/perf/dbg_obs_graph.py), which the render turns into 1e-5 .. 1e-4 - so the
+    yardstick is the eager call's own repeatability; the renderer's part of a replay is bit-identical (the scene-encoding tests)."""
     from playableenvironments_amd.frame_graph import FrameGraph, OBSERVATION_KEYS
     small = dict(width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32, bender_layers=3, bender_skip=1, bender_octaves=3)
     cfg = configs.reduced_config(configs.minecraft_config(encoders=True), **small)
@@ -1361,11 +1364,57 @@ def test_frame_graph_of_the_observation_mode_is_bit_identical():
         torch.cuda.synchronize()
         assert sorted(replayed) == sorted(eager) and len(eager) > 50
         for k in eager:
-            assert torch.equal(torch.nan_to_num(replayed[k].float(), nan=-7.0), torch.nan_to_num(eager[k].float(), nan=-7.0)), k
+            a, b = torch.nan_to_num(replayed[k].float(), nan=-7.0), torch.nan_to_num(eager[k].float(), nan=-7.0)
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-3, atol=1e-3), (k, float((a - b).abs().max()))
     with torch.no_grad():
         next(model.object_encoders[0].parameters()).add_(1e-3)           # the encoders' weights are part of the signature
     with pytest.raises(RuntimeError, match="changed since the frame was captured"):
         graph.render(batches[0])
+
+
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_fused_scene_setup_is_bit_identical(world):
+    """pr_scene_setup (one launch: pose matrices, projected boxes / points / axes, the renderer's input layouts) against the route
+    through pr_pose_matrices / pr_project_points and the composer's own marshalling: every tensor of the result dictionary of an
+    evaluation call equal bit for bit - batches, several observations, two cameras, upsampling, the strided grids, absent objects."""
+    cfg = configs.reduced_config(configs.tennis_config() if world == "tennis" else configs.minecraft_config(), **SMALL_NETS)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    model = model.eval().cuda()
+    make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+
+    def flat(d, prefix=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, prefix + k + "/")
+            elif torch.is_tensor(v):
+                yield prefix + k, v
+    cases = [dict(batch=1, observations=1, cameras=1, kw=dict(patch_stride=[4, 8])),
+             dict(batch=2, observations=3, cameras=1, kw=dict()),
+             dict(batch=1, observations=2, cameras=2, kw=dict(patch_stride=[4, 8], upsample_factor=2.0)),
+             dict(batch=2, observations=1, cameras=1, kw=dict(canonical_pose=True))]
+    for case in cases:
+        size = (32, 48)
+        scene = make(batch=case["batch"], observations=case["observations"], seed=41, image_size=size)
+        if case["cameras"] == 2:       # a second camera per observation: the first one moved
+            for k in ("camera_rotations", "camera_translations", "focals"):
+                other = scene[k] + (0.03 if k != "focals" else 5.0)
+                scene[k] = torch.cat([scene[k], other], dim=2)
+        scene["object_in_scene"][0, 0, -1] = False
+        args = [scene[k].cuda() for k in ("camera_rotations", "camera_translations", "focals")] + [size] + \
+               [scene[k].cuda() for k in ("object_rotation_parameters", "object_translation_parameters", "object_style",
+                                          "object_deformation", "object_in_scene")]
+        with torch.no_grad():
+            model.fused_scene_setup = True
+            fused = dict(flat(model(*args, 0, False, mode="scene_encodings", **case["kw"])))
+            model.fused_scene_setup = False
+            plain = dict(flat(model(*args, 0, False, mode="scene_encodings", **case["kw"])))
+        torch.cuda.synchronize()
+        model.fused_scene_setup = True
+        assert sorted(fused) == sorted(plain) and len(plain) > 40
+        for k in plain:
+            assert fused[k].shape == plain[k].shape, (case, k)
+            assert torch.equal(torch.nan_to_num(fused[k].float(), nan=-7.0), torch.nan_to_num(plain[k].float(), nan=-7.0)), (case, k)
 
 
 def test_two_cameras_per_observation():
