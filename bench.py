@@ -697,6 +697,11 @@ def native_eval_frame_leg(dev, lib, frames=200):
             graph = FrameGraph(model, scene, size, patch_stride=strides)
             cur["scene_encoding_frame_graph"] = timed(lambda: graph.render(scene))
             del graph
+            model.frame_replay = "alias"       # the SAME plain call, recorded once and replayed (EnvironmentModel.frame_replay)
+            cur["scene_encoding_auto_replay"] = timed(eager)
+            cur["observations_auto_replay"] = timed(eager_observations, n=max(20, frames // 4))
+            model.frame_replay = None
+            model._replays.clear()
             cur["scene_encoding_eager_with_decoder"] = timed(eager_decoder)
             cur["observations_eager"] = timed(eager_observations, n=max(20, frames // 4))
             graph = FrameGraph(model, batch, mode="observations", patch_stride=strides)
@@ -710,6 +715,7 @@ def native_eval_frame_leg(dev, lib, frames=200):
                    "host_issue_ms = the Python + launch time of a call; one_frame_device_ms / one_frame_latency_ms = first launch to last "
                    "launch / call to completion of ONE frame on an idle queue (the play loop's latency: host-paced for eager calls); "
                    "*_frame_graph = the same frame replayed from a captured HIP graph (FrameGraph, bit-identical results); "
+                   "*_auto_replay = the unchanged plain call with model.frame_replay = 'alias' (recorded once per shape, replayed); "
                    "with_decoder = + a DecoderV6-shaped stand-in (bench.StandInDecoder) consuming decoder_features; observations_* = "
                    "forward_from_observations with this package's CNN encoders in front (PyTorch-ROCm / MIOpen + pr_roi_pool)")
     return out

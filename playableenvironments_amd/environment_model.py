@@ -330,6 +330,18 @@ class EnvironmentModel(nn.Module):
         #: evaluation calls without a graph run their scene set-up - pose matrices, projected boxes / points / axes, the renderer's
         #: input layouts - as ONE launch (pr_scene_setup) instead of four kernels and ~10 small copies; results are bit-identical
         self.fused_scene_setup = True
+        #: Automatic capture-and-replay of EVALUATION frames (off by default).  "alias" / "clone": a call of
+        #: ``forward_from_scene_encoding`` / ``forward_from_observations`` under ``torch.no_grad()`` in eval mode without perturbation
+        #: and with a static pixel selection (``samples_per_image == 0``: every pixel or the strided grids - what
+        #: ``render_full_frame_*`` and the reference's autoencoder subclasses issue) is recorded ONCE per (mode, argument shapes,
+        #: options, weights) as a HIP graph and replayed afterwards: the unchanged evaluator / play-loop code then costs ~0.1 ms of
+        #: host time per frame instead of 0.4 - 9 ms (the observation mode's CNN encoders are ~300 small launches).  "alias": the
+        #: result dictionary holds the graph's static tensors, valid until the next call with the same shapes (what an evaluator that
+        #: writes its images before it renders the next batch needs); "clone": every tensor is copied out.  Recorded frames are
+        #: dropped when the weights, the precision or the annealing step change (FrameGraph's signature).
+        self.frame_replay = None
+        self._replays: Dict = {}
+        self._in_replay = False
         # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
         self._pixel_cache: Dict = {}
         self._edge_point_cache: Dict = {}
@@ -724,6 +736,58 @@ class EnvironmentModel(nn.Module):
                         break
         return dictionary
 
+    # ------------------------------------------------------------------ automatic frame replay
+    def __getstate__(self):
+        # copy.deepcopy / pickle: recorded graphs and per-device caches stay with the original
+        state = dict(self.__dict__)
+        state.update(_replays={}, _in_replay=False, _pixel_cache={}, _edge_point_cache={}, _axes_point_cache={})
+        return state
+
+    def _replay_signature(self, name: str):
+        composer = self.object_composer
+        # (the renderer-only mode does not read the encoders' weights; the parameter lists are the composer's cached ones)
+        params = composer._parameter_list() if name == "scene_encodings" else composer._parameter_list(self)
+        return (tuple((p.data_ptr(), p._version) for p in params), composer.precision, bool(composer.gate_feature_head),
+                composer.state_epoch, None if composer.object_entry_fields is None else tuple(composer.object_entry_fields),
+                bool(self.fused_scene_setup))
+
+    def _replayed(self, name: str, method, tensors, statics: tuple):
+        """The evaluation call ``method(*tensors, *statics...)`` through a recorded graph (see ``frame_replay``)."""
+        from .frame_graph import CapturedCall
+        key = (name, tuple((tuple(t.shape), t.dtype, str(t.device)) for t in tensors), statics)
+        signature = self._replay_signature(name)
+        entry = self._replays.get(key)
+        if entry is None or entry[0] != signature:
+            if len(self._replays) >= 4:                     # a handful of frame shapes at most: drop the oldest recording
+                self._replays.pop(next(iter(self._replays)))
+            self._in_replay = True
+            try:
+                entry = (signature, CapturedCall(lambda *ts: method(*ts), list(tensors)), self.object_composer._workspace,
+                         [e[1] for e in self.object_composer._packed.values()])      # (raw pointers recorded: keep them alive)
+            finally:
+                self._in_replay = False
+            self._replays[key] = entry
+        results = entry[1].replay(tensors)
+        if self.frame_replay == "clone":
+            def clone(x):
+                if torch.is_tensor(x):
+                    return x.clone()
+                if isinstance(x, dict):
+                    return {k: clone(v) for k, v in x.items()}
+                if isinstance(x, (list, tuple)):
+                    return type(x)(clone(v) for v in x)
+                return x
+            return clone(results)
+        return results
+
+    def _replay_wanted(self, tensors, perturb, samples_per_image) -> bool:
+        if self.frame_replay is None or self._in_replay:
+            return False
+        if self.frame_replay not in ("alias", "clone"):
+            raise ValueError(f"unknown frame_replay {self.frame_replay!r} (expected None, 'alias' or 'clone')")
+        return (not torch.is_grad_enabled() and not self.training and not perturb and samples_per_image == 0 and
+                all(torch.is_tensor(t) and t.is_cuda for t in tensors) and not torch.cuda.is_current_stream_capturing())
+
     # ------------------------------------------------------------------ scene encoding -> rays -> composer
     def forward_from_scene_encoding(self, camera_rotations, camera_translations, focals, image_size,
                                     object_rotation_parameters_o2w, object_translation_parameters_o2w, object_style,
@@ -738,6 +802,18 @@ class EnvironmentModel(nn.Module):
         a frame in ``render_sharded`` - or, given an int64 tensor, the listed rays (its share of interleaved tiles).  ``_decoder_features`` (extension): the decoder's feature count per stride, e.g.
         [64, 128] - the compositing kernel then also writes ``[type]["global"]["decoder_features"]``, the channels-first
         per-stride maps ``autoencoder_model.forward_decoder`` takes (see ``decoder_layout``)."""
+        scene = (camera_rotations, camera_translations, focals, object_rotation_parameters_o2w, object_translation_parameters_o2w,
+                 object_style, object_deformation, object_in_scene)
+        if _ray_range is None and self._replay_wanted(scene, perturb, samples_per_image):
+            stride_key = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else patch_stride
+            statics = (tuple(image_size), samples_per_image_batching, upsample_factor, patch_size, stride_key, canonical_pose,
+                       None if _decoder_features is None else tuple(_decoder_features))
+            return self._replayed(
+                "scene_encodings",
+                lambda a, b, c, d, e, f, g, h: self.forward_from_scene_encoding(
+                    a, b, c, image_size, d, e, f, g, h, samples_per_image, perturb, samples_per_image_batching, upsample_factor,
+                    patch_size, patch_stride, canonical_pose, _decoder_features=_decoder_features),
+                scene, statics)
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
         prepared = None
@@ -969,6 +1045,18 @@ class EnvironmentModel(nn.Module):
         synchronisation-free host math).  The optional image decoder (config["model"]["image_decoder"]) is an injected
         module like the encoders (``align_grid=False`` with a patch raises in the reference too)."""
         self._require_encoders()
+        batch = (observations, camera_rotations, camera_translations, focals, bounding_boxes, bounding_boxes_validity,
+                 global_frame_indexes, video_frame_indexes, video_indexes)
+        if not shuffle_style and self._replay_wanted(batch, perturb, samples_per_image):
+            stride_key = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else patch_stride
+            statics = (samples_per_image_batching, upsample_factor, patch_size, stride_key, align_grid, canonical_pose,
+                       None if _decoder_features is None else tuple(_decoder_features))
+            return self._replayed(
+                "observations",
+                lambda *ts: self.forward_from_observations(*ts, samples_per_image, perturb, samples_per_image_batching, shuffle_style,
+                                                           upsample_factor, patch_size, patch_stride, align_grid, canonical_pose,
+                                                           _decoder_features=_decoder_features),
+                batch, statics)
         camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
                                                                                 global_frame_indexes)
         rescaled_focals = focals * self.focal_length_multiplier

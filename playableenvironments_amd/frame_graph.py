@@ -131,6 +131,35 @@ class FrameGraph:
         return self.results
 
 
+class CapturedCall:
+    """``fn(*tensors)`` recorded once as a HIP graph and replayed for new values of the same-shaped tensors (copied into the
+    recorded input buffers).  The building block of ``EnvironmentModel.frame_replay``; results are the graph's static tensors."""
+
+    def __init__(self, fn, tensors, warmup: int = 2):
+        self.inputs = [t.detach().clone() for t in tensors]
+        device = self.inputs[0].device
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(1, warmup)):
+                fn(*self.inputs)
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.results = fn(*self.inputs)
+        except BaseException:
+            import traceback
+            traceback.print_exc()
+            raise
+
+    def replay(self, tensors):
+        for dst, src in zip(self.inputs, tensors):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.results
+
+
 class GraphedStep:
     """A whole training iteration - renderer forward, loss, ``backward()``, optimiser step - recorded once as a HIP graph
     and replayed: ``step_fn()`` (no arguments; it reads its inputs from tensors that stay in place, e.g. a ``Batch`` arena
