@@ -154,9 +154,13 @@ int pr_packed_size(const pr_object_model_t* model, size_t* bytes);
  * precision: PR_PRECISION_FP32 = fp32 MFMA fragments (exact fp32 arithmetic); PR_PRECISION_F16X3 = every weight
  * as an fp16 pair (hi, lo = w - hi) for the split kernel, which evaluates
  * a*w ~ a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with three fp16 MFMAs and fp32 accumulation
- * (~22 significant bits).  Both layouts have the same size. */
+ * (~22 significant bits).  Both layouts have the same size.  PR_PRECISION_F16 = the F16X3 layout (the same bytes)
+ * evaluated with the a_hi*w_hi product only: plain fp16 operands (11 significant bits each), fp32 accumulation, one
+ * MFMA per step instead of three - the throughput tier for interactive play, ~1e-3 relative error on the rendered
+ * features (tests/test_gpu.py holds it to >= 40 dB PSNR against the oracle); not for parity checks. */
 #define PR_PRECISION_FP32  0
 #define PR_PRECISION_F16X3 1
+#define PR_PRECISION_F16   2
 int pr_pack_model(const pr_object_model_t* model, int32_t precision, void* packed, size_t packed_bytes, void* stream);
 
 /* One object instance of a call: its (shared) coarse / fine models and their packed copies. */

@@ -26,6 +26,7 @@ PR_FLAG_SIGMOID_FEATURES = 512
 PR_FLAG_SPLIT_BACKWARD = 1024
 PR_PRECISION_FP32 = 0
 PR_PRECISION_F16X3 = 1
+PR_PRECISION_F16 = 2
 PR_PROFILE_CATEGORIES = 8   # host array length of pr_profile_collect
 
 c_float_p = C.POINTER(C.c_float)

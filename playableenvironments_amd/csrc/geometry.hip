@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void k_scene_setup(SceneSetup p) {
     __shared__ float cam[32];                       // c2w, w2c
     __shared__ float obj[PR_MAX_OBJECTS][32];       // o2w, w2o per object
     __shared__ float foc[2];                        // rescaled focal, render focal
-    const int f = blockIdx.x / p.cameras, c = blockIdx.x % p.cameras;
+    const int f = blockIdx.x / p.cameras;
     const int tid = threadIdx.x, K = p.objects;
     const size_t fc = blockIdx.x;
     if (tid == 0) {

@@ -1614,7 +1614,8 @@ extern "C" int pr_packed_size(const pr_object_model_t* model, size_t* bytes) {
 }
 
 extern "C" int pr_pack_model(const pr_object_model_t* model, int32_t precision, void* packed, size_t packed_bytes, void* stream) {
-    PR_REQUIRE(precision == 0 || precision == 1, "pr_pack_model: precision must be 0 (fp32) or 1 (fp16 split)");
+    PR_REQUIRE(precision == PR_PRECISION_FP32 || precision == PR_PRECISION_F16X3 || precision == PR_PRECISION_F16,
+               "pr_pack_model: precision must be one of PR_PRECISION_*");
     PR_REQUIRE(model && packed, "pr_pack_model: NULL argument");
     PR_REQUIRE(((uintptr_t)packed & 15) == 0, "pr_pack_model: packed buffer must be 16-byte aligned");
     pr::ModelDims d;

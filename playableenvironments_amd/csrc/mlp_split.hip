@@ -135,11 +135,16 @@ __device__ __forceinline__ void fill_bender_input_h(SmemH& S, const MlpParams& p
 // One layer on the tile (see run_layer in mlp.hip for the geometry: wave w owns the column blocks w and w + 4 for
 // both row blocks; here every block has a main and a correction accumulator).  input_kind: what a src == 1 segment
 // re-computes into X[:, 0:K) - 0 NeRF input, 1 ray-bender input.
+// TERMS = 3: hi x hi + hi x lo + lo x hi (precision "f16x3", fp32-grade); TERMS = 1: hi x hi only (precision "f16": plain
+// fp16 operands, fp32 accumulation) - the lo fragments are then never loaded.
 #define PR_SPLIT3(M, AH, AL, BH, BL) \
     PR_MFMA16(M, AH, BH);            \
-    PR_MFMA16(M, AH, BL);            \
-    PR_MFMA16(M, AL, BH)
+    if (TERMS == 3) {                \
+        PR_MFMA16(M, AH, BL);        \
+        PR_MFMA16(M, AL, BH);        \
+    }
 
+template <int TERMS>
 __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpParams& p, int input_kind) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
@@ -222,12 +227,12 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
                 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
                 al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TERMS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, TERMS == 3 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TERMS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, TERMS == 3 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 4 : 2, 0);
             }
         } else {
             for (int s = 0; s < ks; s += 2) {
@@ -248,12 +253,12 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 al0O = *reinterpret_cast<const f16x8*>(a0l + 16 * so);
                 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16 * so);
                 al1O = *reinterpret_cast<const f16x8*>(a1l + 16 * so);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, TERMS == 3 ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, TERMS == 3 ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 4 : 2, 0);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -377,8 +382,9 @@ __device__ __forceinline__ void write_rows_indirect_h(const SmemH& S, const MlpP
     }
 }
 
+template <int TERMS>
 __device__ __forceinline__ void head_on_tile_h(SmemH& S, const MlpParams& p, int valid_rows) {
-    for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p, 0);
+    for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h<TERMS>(p.layers[l], S, p, 0);
     write_rows_indirect_h(S, p);
     if (threadIdx.x == 0 && p.head_count) atomicAdd(p.head_count, valid_rows);
     __syncthreads();
@@ -400,6 +406,7 @@ __device__ __forceinline__ void move_pending_rows(SmemH& S, const MlpParams& p, 
     }
 }
 
+template <int TERMS>
 __device__ __forceinline__ int gated_head_h(SmemH& S, const MlpParams& p, int tile_base, int pending) {
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long live = __ballot((S.flags[lane] & 4) != 0);   // the same value in every wave
@@ -429,7 +436,7 @@ __device__ __forceinline__ int gated_head_h(SmemH& S, const MlpParams& p, int ti
         if (need) move_pending_rows<true>(S, p, stack, STILE_M, [&](int row) { return S.src[row]; });
         if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
         __syncthreads();
-        head_on_tile_h(S, p, STILE_M);
+        head_on_tile_h<TERMS>(S, p, STILE_M);
         return pending - need;
     }
     if (tid < STILE_M) {
@@ -447,6 +454,7 @@ __device__ __forceinline__ int gated_head_h(SmemH& S, const MlpParams& p, int ti
     return pending + L;
 }
 
+template <int TERMS>
 __device__ __forceinline__ void gated_head_flush_h(SmemH& S, const MlpParams& p, int pending) {
     if (pending <= 0) return;
     const int tid = threadIdx.x;
@@ -462,12 +470,12 @@ __device__ __forceinline__ void gated_head_flush_h(SmemH& S, const MlpParams& p,
     move_pending_rows<true>(S, p, stack, pending, [&](int row) { return row; });
     if (tid < STILE_M && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
     __syncthreads();
-    head_on_tile_h(S, p, pending);
+    head_on_tile_h<TERMS>(S, p, pending);
 }
 
 // GROUP: one of several objects evaluated by the same launch (k_mlp_split_group), as in mlp.hip: every tile is claimed from
 // the object's counter and a workgroup that finds an object's tiles exhausted moves on to the next object.
-template <bool GROUP>
+template <bool GROUP, int TERMS>
 __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
@@ -523,7 +531,7 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         if (p.has_bender) {
             fill_bender_input_h(S, p);
             __syncthreads();
-            for (int l = 0; l < p.b_count; ++l) run_layer_h(p.b_layers[l], S, p, /*input_kind=*/1);
+            for (int l = 0; l < p.b_count; ++l) run_layer_h<TERMS>(p.b_layers[l], S, p, /*input_kind=*/1);
             for (int s = tid >> 3; s < STILE_M; s += STHREADS / 8) {
                 float out[3];
                 row_dots_h(S, s, p.b_out, p.BWpad, p.BWpad, 3, out);
@@ -555,7 +563,7 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         fill_nerf_input_h(S, p);
         __syncthreads();
         PR_PHASE(2);
-        for (int l = 0; l < p.n_backbone; ++l) run_layer_h(p.layers[l], S, p, 0);
+        for (int l = 0; l < p.n_backbone; ++l) run_layer_h<TERMS>(p.layers[l], S, p, 0);
         PR_PHASE(15);
         if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 
@@ -581,11 +589,11 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         PR_PHASE(7);
         if (p.gate) {
             __syncthreads();   // the liveness bits are complete
-            pending = gated_head_h(S, p, tile_base, pending);
+            pending = gated_head_h<TERMS>(S, p, tile_base, pending);
             PR_PHASE(8);
             continue;
         }
-        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h(p.layers[l], S, p, 0);
+        for (int l = p.n_backbone; l < p.n_layers; ++l) run_layer_h<TERMS>(p.layers[l], S, p, 0);
         PR_PHASE(15);
 
         // feature rows: the last layer staged an fp32 tile over the activation planes
@@ -616,20 +624,30 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
         __syncthreads();
         PR_PHASE(8);
     }
-    if (p.gate) gated_head_flush_h(S, p, pending);
+    if (p.gate) gated_head_flush_h<TERMS>(S, p, pending);
 }
 
-__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) { split_tile_loop<false>(p); }
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) { split_tile_loop<false, 3>(p); }
 // one copy of the tile loop per job slot: parameters as kernel arguments at constant offsets (see k_mlp_mfma_group)
 __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                 int count) {
-    split_tile_loop<true>(j0);
-    if (count > 1) split_tile_loop<true>(j1);
-    if (count > 2) split_tile_loop<true>(j2);
-    if (count > 3) split_tile_loop<true>(j3);
+    split_tile_loop<true, 3>(j0);
+    if (count > 1) split_tile_loop<true, 3>(j1);
+    if (count > 2) split_tile_loop<true, 3>(j2);
+    if (count > 3) split_tile_loop<true, 3>(j3);
+}
+// PR_PRECISION_F16: the same tile loop with the hi x hi product only (one fp16 MFMA per step instead of three)
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_f16(MlpParams p) { split_tile_loop<false, 1>(p); }
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_f16_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+                                                                              int count) {
+    split_tile_loop<true, 1>(j0);
+    if (count > 1) split_tile_loop<true, 1>(j1);
+    if (count > 2) split_tile_loop<true, 1>(j2);
+    if (count > 3) split_tile_loop<true, 1>(j3);
 }
 
-int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s) {
+int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, int terms, hipStream_t s) {
+    auto* const kernel = terms == 1 ? k_mlp_f16_group : k_mlp_split_group;
     PR_REQUIRE(count >= 1, "grouped MLP launch: no jobs");
     static thread_local MlpGroupParams g;     // 18 KB: not on the stack
     for (int begin = 0; begin < count; begin += MLP_GROUP_MAX) {
@@ -644,28 +662,29 @@ int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int 
         }
         if (max_tiles <= 0) continue;
         int cu_count = 0;
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_split_group), (int)sizeof(SmemH), &cu_count));
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(kernel), (int)sizeof(SmemH), &cu_count));
         int resident = cu_count * SBLOCKS_PER_CU;
         if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;
         const int grid = max_tiles < resident ? (int)max_tiles : resident;
         ProfileScope scope(0, s);
-        hipLaunchKernelGGL(k_mlp_split_group, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         PR_LAUNCH_CHECK();
     }
     return PR_OK;
 }
 
-int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s) {
+int launch_mlp_split(const MlpParams& p, int max_rows, int terms, hipStream_t s) {
     if (max_rows <= 0) return PR_OK;
+    auto* const kernel = terms == 1 ? k_mlp_f16 : k_mlp_split;
     const int max_tiles = (max_rows + STILE_M - 1) / STILE_M;
     int cu_count = 0;
-    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_mlp_split), (int)sizeof(SmemH), &cu_count));
+    PR_TRY(prepare_kernel(reinterpret_cast<const void*>(kernel), (int)sizeof(SmemH), &cu_count));
     int resident = cu_count * SBLOCKS_PER_CU;
     if (resident > MAX_RESIDENT_TILES) resident = MAX_RESIDENT_TILES;   // the pending stacks of the gated head are sized for this
     const int grid = max_tiles < resident ? max_tiles : resident;
     PR_REQUIRE(!p.gate || (p.pend_act && p.pend_meta), "gated head: pending buffers missing");
     ProfileScope scope(0, s);
-    hipLaunchKernelGGL(k_mlp_split, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();
 #if PR_SPLIT_ABLATE & 64
     {

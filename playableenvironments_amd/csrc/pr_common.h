@@ -354,8 +354,9 @@ int launch_adain_fold_group(const FoldParams* jobs, int count, hipStream_t s);  
 int launch_mlp(const MlpParams& p, int max_rows, bool naive, const pr_object_model_t* raw, hipStream_t s);
 // evaluation launches of several objects as one
 int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s);
-int launch_mlp_split(const MlpParams& p, int max_rows, hipStream_t s);   // PR_PRECISION_F16X3, eval only
-int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, hipStream_t s);
+// PR_PRECISION_F16X3 (terms = 3) / PR_PRECISION_F16 (terms = 1), eval only
+int launch_mlp_split(const MlpParams& p, int max_rows, int terms, hipStream_t s);
+int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, int terms, hipStream_t s);
 
 // BatchNorm1d(affine=False) in training mode: batch mean / biased variance from the accumulated sums,
 // running statistics updated in place with momentum 0.1 and the unbiased variance, num_batches_tracked += 1

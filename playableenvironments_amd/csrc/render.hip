@@ -109,10 +109,11 @@ int validate_call(const pr_call_t& c, const pr_object_t* objs) {
     PR_REQUIRE((long)c.frames * c.rays < (1L << 31), "too many rays in one call");
     PR_REQUIRE(c.ray_origins && c.ray_directions && c.w2o && c.style && c.deformation && c.object_in_scene,
                "NULL input pointer");
-    PR_REQUIRE(c.precision == PR_PRECISION_FP32 || c.precision == PR_PRECISION_F16X3, "unknown precision %d", c.precision);
-    PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_TRAIN_BN)),
-               "the split-precision kernel has no train-mode BatchNorm phases yet: use PR_PRECISION_FP32 for training");
-    PR_REQUIRE(!(c.precision == PR_PRECISION_F16X3 && (c.flags & PR_FLAG_SAVE_FOR_BACKWARD)),
+    PR_REQUIRE(c.precision == PR_PRECISION_FP32 || c.precision == PR_PRECISION_F16X3 || c.precision == PR_PRECISION_F16,
+               "unknown precision %d", c.precision);
+    PR_REQUIRE(!(c.precision != PR_PRECISION_FP32 && (c.flags & PR_FLAG_TRAIN_BN)),
+               "the fp16 kernels have no train-mode BatchNorm phases: use PR_PRECISION_FP32 for training");
+    PR_REQUIRE(!(c.precision != PR_PRECISION_FP32 && (c.flags & PR_FLAG_SAVE_FOR_BACKWARD)),
                "differentiable calls run on the exact kernel: use PR_PRECISION_FP32 with PR_FLAG_SAVE_FOR_BACKWARD");
     PR_REQUIRE(!(c.flags & PR_FLAG_SAVE_FOR_BACKWARD) || !(c.flags & PR_FLAG_NAIVE_MLP), "the scalar debugging kernel saves nothing");
     for (int k = 0; k < c.objects; ++k) {
@@ -533,8 +534,8 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                     continue;
                 }
                 PR_TRY(launch_adain_fold(fo, s));
-                if (c.precision == PR_PRECISION_F16X3 && !naive)
-                    PR_TRY(launch_mlp_split(mp, max_tiles, s));
+                if (c.precision != PR_PRECISION_FP32 && !naive)
+                    PR_TRY(launch_mlp_split(mp, max_tiles, c.precision == PR_PRECISION_F16 ? 1 : 3, s));
                 else
                     PR_TRY(launch_mlp(mp, max_tiles, naive, &m, s));
             } else {
@@ -660,8 +661,8 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
 
         if (grouped) {
             PR_TRY(launch_adain_fold_group(fold_jobs, K, s));
-            if (c.precision == PR_PRECISION_F16X3)
-                PR_TRY(launch_mlp_split_group(jobs, job_rows, K, s));
+            if (c.precision != PR_PRECISION_FP32)
+                PR_TRY(launch_mlp_split_group(jobs, job_rows, K, c.precision == PR_PRECISION_F16 ? 1 : 3, s));
             else
                 PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
         }

@@ -296,6 +296,9 @@ class ObjectComposer(nn.Module):
         #: bits); differentiable / training calls keep the exact fp32 FORWARD kernels (train-mode BatchNorm phases, saved activations)
         #: and run the BACKWARD pass's matrix products on bf16 triples (x = b1 + b2 + b3 exactly, six bf16 MFMAs per product, fp32
         #: accumulation: PR_FLAG_SPLIT_BACKWARD) where a split kernel exists - gradients agree with the fp32 path to fp32 round-off.
+        #: "f16" (throughput tier, interactive play): evaluation renders keep the a_hi*w_hi product only - plain fp16 operands, fp32
+        #: accumulation, one MFMA per step; ~1e-3 relative error on the rendered features (>= 40 dB PSNR against the oracle), so
+        #: NOT a parity configuration.  Shares the packed weights with "f16x3"; training / differentiable calls behave as "f16x3".
         self.precision = "fp32"
         self._warned_precision_fallback = False
         #: sigma-gated feature head (PR_FLAG_GATE_HEAD): evaluation renders skip the feature head of samples whose raw density
@@ -518,21 +521,23 @@ class ObjectComposer(nn.Module):
         return cached[1]
 
     def _precision_code(self, differentiable: bool = False) -> int:
-        if self.precision not in ("fp32", "f16x3"):
-            raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32' or 'f16x3')")
-        if self.precision == "f16x3" and (self.training or differentiable):
+        if self.precision not in ("fp32", "f16x3", "f16"):
+            raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32', 'f16x3' or 'f16')")
+        if self.precision != "fp32" and (self.training or differentiable):
             # the forward pass of training / differentiable calls runs the exact fp32 kernels (train-mode BatchNorm phases, saved
             # activations) on fp32-packed weights; "f16x3" selects the split-precision BACKWARD products for them (_render)
             return _lib.PR_PRECISION_FP32
-        return _lib.PR_PRECISION_F16X3 if self.precision == "f16x3" else _lib.PR_PRECISION_FP32
+        return {"fp32": _lib.PR_PRECISION_FP32, "f16x3": _lib.PR_PRECISION_F16X3, "f16": _lib.PR_PRECISION_F16}[self.precision]
 
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int,
                         differentiable: bool = False) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
         params = self._parameter_list(model)
         precision = self._precision_code(differentiable)
+        if precision == _lib.PR_PRECISION_F16:
+            precision = _lib.PR_PRECISION_F16X3      # the same fp16 (hi, lo) fragments; the kernel skips the lo halves
         key = tuple((p.data_ptr(), p._version) for p in params)
-        slot = (id(model), precision)   # one buffer per precision: a render at the other precision never evicts this one
+        slot = (id(model), precision)   # one buffer per layout: a render at the other precision never evicts this one
         cached = self._packed.get(slot)
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -756,7 +761,7 @@ class ObjectComposer(nn.Module):
             flags |= _lib.PR_FLAG_TRAIN_BN
         if _save:
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
-            if self.precision == "f16x3":
+            if self.precision in ("f16x3", "f16"):
                 flags |= _lib.PR_FLAG_SPLIT_BACKWARD     # the backward pass's matrix products as bf16 triples (six MFMAs per product)
         if self.gate_feature_head:
             flags |= _lib.PR_FLAG_GATE_HEAD      # honoured by the library for unperturbed evaluation calls only

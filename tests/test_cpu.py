@@ -259,6 +259,11 @@ def test_abi_error_paths_without_a_device(built_library):
     call.precision = _lib.PR_PRECISION_F16X3
     assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1          # split kernel: no saved activations
     assert b"PR_PRECISION_FP32" in lib.pr_last_error()
+    call.precision = _lib.PR_PRECISION_F16                                            # ... nor the single-product fp16 tier
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1
+    assert b"PR_PRECISION_FP32" in lib.pr_last_error()
+    call.flags = 0
+    assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == 0 and size.value == eval_size
     call.precision, call.flags = 7, 0
     assert lib.pr_workspace_size(C.byref(call), objs, C.byref(size)) == -1
     assert b"precision" in lib.pr_last_error()

@@ -121,6 +121,39 @@ def test_composer_matches_oracle(name, perturb, precision):
     assert_close(want, got)
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_half_precision_tier_is_close_to_the_oracle(name):
+    """precision="f16" (PR_PRECISION_F16: the split kernel's hi x hi product only - plain fp16 operands, fp32 accumulation) is the
+    throughput tier, not a parity configuration: its rendered fields stay within rtol 2e-2 (atol 2e-2 of the field's peak) of the
+    oracle and the feature image keeps >= 40 dB PSNR; the geometry (sample counts) is the exact path's; and it really is another
+    kernel than "f16x3" (the results differ)."""
+    make_cfg, make_scene, n, bias = CASES[name]
+    cfg, scene = make_cfg(), make_scene()
+    comp = build(cfg, alpha_bias=bias, precision="f16")
+    inputs = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
+    want, got = run_both(cfg, comp, inputs)
+    comp.precision = "f16x3"
+    with torch.no_grad():
+        split = comp(*[v.cuda() for v in inputs], False)
+    last = "fine" if "fine" in got else "coarse"
+    differs = False
+    for level in ("coarse", "fine"):
+        if level not in got:
+            continue
+        for field in ("integrated_features", "opacity", "depth"):
+            if field not in got[level]["global"]:
+                continue
+            w, g = want[level]["global"][field].double(), got[level]["global"][field].cpu().double()
+            peak = float(w.abs().max())
+            assert torch.allclose(g, w, rtol=2e-2, atol=2e-2 * peak), (level, field, float((g - w).abs().max()), peak)
+            differs |= not torch.equal(got[level]["global"][field], split[level]["global"][field])
+    w = want[last]["global"]["integrated_features"].double()
+    g = got[last]["global"]["integrated_features"].cpu().double()
+    psnr = 10.0 * torch.log10(w.abs().max() ** 2 / ((g - w) ** 2).mean())
+    assert float(psnr) >= 40.0, float(psnr)
+    assert differs
+
+
 def test_single_player_all_rays_in_box():
     """BASELINE.json configs[0] shape: one player object, 32 samples/ray, every ray crosses the box."""
     cfg = configs.tennis_single_player_config()

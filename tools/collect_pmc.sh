@@ -8,7 +8,9 @@ ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/pmc
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-step --no-split-precision --no-distinct-frames --no-minecraft --no-reference-graph --no-shard-balance"
+CMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-step --no-split-precision --no-distinct-frames --no-minecraft --no-reference-graph --no-shard-balance --no-native-frame"
+# (--no-native-frame: that leg replays captured HIP graphs, whose packets the counter-collection service cannot instrument - 
+#  "HSA_STATUS_ERROR_INVALID_PACKET_FORMAT" and a hung pass, measured in round 4)
 cd /tmp
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "busy:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   name=${pass%%:*}; counters=${pass#*:}
