@@ -29,10 +29,13 @@ constexpr int LDSTAGE = 260;         // floats per row when the activation plane
 struct SmemH {
     int uniform_frame;
     int next_tile;           // the tile claimed for this workgroup's next iteration (see mlp.hip)
-    int pad_[2];
+    int matrix_priority;     // s_setprio level of this workgroup's K loops: the CU's two resident tiles differ (cu_arrival_parity)
+    int pad_[1];
     float head_w[MAX_WIDTH + 8];          // sigma head weights + bias
     _Float16 Xh[STILE_M * LDH];            // activations, hi plane
     _Float16 Xl[STILE_M * LDH];            // activations, lo plane (scaled by 2^11)
+    float adain_g[MAX_WIDTH];    // scale / shift row of the layer's AdaIN table for a tile of ONE frame: requested in front of
+    float adain_b[MAX_WIDTH];    // the layer's K loop, parked here behind it (the epilogue does not wait for L2)
     float pos[STILE_M * 8];
     int flat[STILE_M];
     int frame[STILE_M];
@@ -123,6 +126,18 @@ __device__ __forceinline__ void store_adain_h(const f32x16& m, SmemH& S, int idx
         split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
     }
 }
+// the same with the table row parked in LDS (a tile of one frame); feat0 = the lane's first feature
+__device__ __forceinline__ void store_adain_lds_h(const f32x16& m, SmemH& S, int idx0, int feat0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(S.adain_g + feat0 + 8 * j);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(S.adain_b + feat0 + 8 * j);
+        f32x4 v = pick4(m, j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(fmaf(v[k], gg[k], bb[k]), 0.f, 65504.0f);
+        split_store4(S.Xh, S.Xl, idx0 + 8 * j, v);
+    }
+}
 // stage = fp32 staging tile over the activation planes; base = &stage[sample row * LDSTAGE + first feature]
 __device__ __forceinline__ void store_stage_h(const f32x16& m, float* base) {
 #pragma unroll
@@ -176,6 +191,18 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
     }
     mA1 = mA0;
     mB1 = mB0;
+#ifndef PR_SPLIT_NO_ADAIN_PREFETCH
+    // AdaIN table row of a one-frame tile: requested now, parked in LDS behind the K loop (2 VGPRs across the loop)
+    const bool park = L.epi == EPI_ADAIN_RELU && S.uniform_frame != 0;
+    float park_g = 0.f, park_b = 0.f;
+    if (park && (int)threadIdx.x < nblk * 32) {
+        const float* tab = p.adain + (size_t)S.frame[0] * p.adain_stride + L.adain_off + threadIdx.x;
+        park_g = tab[0];
+        park_b = tab[nblk * 32];
+    }
+#else
+    const bool park = false;
+#endif
     for (int sidx = 0; sidx < L.nseg; ++sidx) {
         const Seg& sg = L.seg[sidx];
         if (sg.src == 1 && sidx > 0) {
@@ -184,7 +211,8 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             __syncthreads();
         }
         if (!active) continue;
-        __builtin_amdgcn_s_setprio(1);   // matrix work outranks the other resident tile's serial phases
+        // matrix work outranks the other resident tile's serial phases, and one tile's matrix work the other's
+        if (S.matrix_priority) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
         const int ks = sg.kq >> 1;   // 16-wide steps, even (K padded to 32)
         const int aoff = r * LDH + 8 * half;
         const _Float16* a0h = S.Xh + aoff;
@@ -264,7 +292,13 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
         __builtin_amdgcn_s_setprio(0);
     }
     PR_PHASE(3);
-    __syncthreads();  // every wave has finished reading the activation planes
+#ifndef PR_SPLIT_NO_ADAIN_PREFETCH
+    if (park && (int)threadIdx.x < nblk * 32) {
+        S.adain_g[threadIdx.x] = park_g;
+        S.adain_b[threadIdx.x] = park_b;
+    }
+#endif
+    __syncthreads();  // every wave has finished reading the activation planes (and the parked table row is complete)
     PR_PHASE(4);
     if (active && !((PR_SPLIT_ABLATE & 8) && L.epi != EPI_FEATURES)) {
         for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
@@ -275,6 +309,11 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 store_relu_h(m0, S, r * LDH + feat0);
                 store_relu_h(m1, S, (r + 32) * LDH + feat0);
             } else if (L.epi == EPI_ADAIN_RELU) {
+                if (park) {
+                    store_adain_lds_h(m0, S, r * LDH + feat0, feat0);
+                    store_adain_lds_h(m1, S, (r + 32) * LDH + feat0, feat0);
+                    continue;
+                }
                 const int bofs = L.nblk * 32;
                 const bool uniform = S.uniform_frame != 0;
                 const float* t0 = p.adain + (size_t)S.frame[uniform ? 0 : r] * p.adain_stride + L.adain_off + feat0;
@@ -627,24 +666,55 @@ __device__ __forceinline__ void split_tile_loop(const MlpParams& p) {
     if (p.gate) gated_head_flush_h<TERMS>(S, p, pending);
 }
 
-__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) { split_tile_loop<false, 3>(p); }
+__device__ __forceinline__ void claim_matrix_priority() {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SmemH& S = *reinterpret_cast<SmemH*>(smem_raw);
+#ifdef PR_EQUAL_TILE_PRIORITY
+    if (threadIdx.x == 0) S.matrix_priority = 0;
+#else
+    if (threadIdx.x == 0) S.matrix_priority = cu_arrival_parity();
+#endif
+    // (published by the tile loop's first barrier)
+}
+
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split(MlpParams p) {
+    claim_matrix_priority();
+    split_tile_loop<false, 3>(p);
+}
 // one copy of the tile loop per job slot: parameters as kernel arguments at constant offsets (see k_mlp_mfma_group)
 __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_split_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                 int count) {
+    claim_matrix_priority();
     split_tile_loop<true, 3>(j0);
     if (count > 1) split_tile_loop<true, 3>(j1);
     if (count > 2) split_tile_loop<true, 3>(j2);
     if (count > 3) split_tile_loop<true, 3>(j3);
 }
 // PR_PRECISION_F16: the same tile loop with the hi x hi product only (one fp16 MFMA per step instead of three)
-__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_f16(MlpParams p) { split_tile_loop<false, 1>(p); }
+__global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_f16(MlpParams p) {
+    claim_matrix_priority();
+    split_tile_loop<false, 1>(p);
+}
 __global__ __launch_bounds__(STHREADS, SBLOCKS_PER_CU) void k_mlp_f16_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                               int count) {
+    claim_matrix_priority();
     split_tile_loop<true, 1>(j0);
     if (count > 1) split_tile_loop<true, 1>(j1);
     if (count > 2) split_tile_loop<true, 1>(j2);
     if (count > 3) split_tile_loop<true, 1>(j3);
 }
+
+#if PR_SPLIT_ABLATE & 64
+// phase timing build: cumulative shader-clock Mcycles of thread 0 per phase, summed over the workgroups (100 MHz clock)
+static void dump_phase_cycles(hipStream_t s) {
+    unsigned long long now[16];
+    hipStreamSynchronize(s);
+    hipMemcpyFromSymbol(now, HIP_SYMBOL(g_phase_cycles), sizeof(now));
+    fprintf(stderr, "[split phases, cumulative Mcycles]");
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " p%d=%.2f", i, (double)now[i] * 1e-6);
+    fprintf(stderr, "\n");
+}
+#endif
 
 int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int count, int terms, hipStream_t s) {
     auto* const kernel = terms == 1 ? k_mlp_f16_group : k_mlp_split_group;
@@ -669,6 +739,9 @@ int launch_mlp_split_group(const MlpParams* host_jobs, const int* max_rows, int 
         ProfileScope scope(0, s);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         PR_LAUNCH_CHECK();
+#if PR_SPLIT_ABLATE & 64
+        dump_phase_cycles(s);
+#endif
     }
     return PR_OK;
 }
@@ -687,16 +760,7 @@ int launch_mlp_split(const MlpParams& p, int max_rows, int terms, hipStream_t s)
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(STHREADS), sizeof(SmemH), s, p);
     PR_LAUNCH_CHECK();
 #if PR_SPLIT_ABLATE & 64
-    {
-        static unsigned long long total[16];
-        unsigned long long now[16];
-        hipStreamSynchronize(s);
-        hipMemcpyFromSymbol(now, HIP_SYMBOL(g_phase_cycles), sizeof(now));
-        fprintf(stderr, "[split phases, cumulative Mcycles of thread 0 summed over workgroups]");
-        for (int i = 0; i < 9; ++i) fprintf(stderr, " p%d=%.1f", i, (double)now[i] * 1e-6);
-        fprintf(stderr, "\n");
-        (void)total;
-    }
+    dump_phase_cycles(s);
 #endif
     return PR_OK;
 }

@@ -701,6 +701,18 @@ __device__ __forceinline__ float noise_normal(const NoiseRef& n, long g, int per
 }
 
 // torch.min / torch.max / clamp propagate NaN; fminf/fmaxf do not.
+// Two persistent workgroups share a CU (and each of its four matrix pipes).  With EQUAL wave priorities the SIMD arbitrates
+// between their K loops fairly, the two tiles stay in lock step, and their serial phases (epilogues, barriers, encodings)
+// coincide - the matrix pipes then idle for the whole of those phases.  Resident workgroups therefore take alternating
+// matrix-phase priorities: the arrival order on the CU (a counter per physical CU, keyed by the hardware id registers; only
+// the parity matters, so it is never reset) decides which one outranks the other.  One table per translation unit.
+static __device__ unsigned int g_cu_arrivals[4096];
+__device__ __forceinline__ int cu_arrival_parity() {   // call from ONE thread of the workgroup
+    const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    const unsigned int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID [3:0]
+    return (int)(atomicAdd(&g_cu_arrivals[((xcc & 15u) << 8) | ((hw >> 8) & 255u)], 1u) & 1u);
+}
+
 __device__ __forceinline__ float nan_min(float a, float b) { return (a < b || a != a) ? a : b; }
 __device__ __forceinline__ float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }
 __device__ __forceinline__ float nan_clamp(float v, float lo, float hi) {
