@@ -240,15 +240,18 @@ def max_over_ranks(value, dist, dev):
 def train_traffic():
     """HBM bytes per training step from the committed PMC passes of tools/collect_pmc_train.sh (all library kernels of a step, and
     the three largest), with the library stamp they were collected from."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_train_summary.json")
-    if not os.path.exists(path):
+    for name in ("r04_pmc_train_summary.json", "r03_pmc_train_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
         return {"traffic": None}
     with open(path) as f:
         pmc = json.load(f)
     big = {k.split("::")[1]: int(v["hbm_MB"] * 1e6) for k, v in list(pmc["per_step"].items())[:3]}
     return {"traffic": int(pmc["hbm_MB_per_step_all_library_kernels"] * 1e6),
             "traffic_unit": "HBM bytes per training step, all library kernels (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of "
-                            "tools/collect_pmc_train.sh, profiles/r03_pmc_train_summary.json): ~1.4 TB/s over the step - the step is bound "
+                            f"tools/collect_pmc_train.sh, profiles/{name}: the fp32 step): ~1.5 TB/s over the step - the step is bound "
                             "by the matrix pipes, not by HBM",
             "traffic_largest_kernels": big,
             "traffic_from_this_library": pmc.get("library_sha256") == library_sha256()}
