@@ -49,7 +49,7 @@ static_assert(offsetof(SmemH, head_w) % 16 == 0 && offsetof(SmemH, Xh) % 16 == 0
               "16-byte LDS reads of the activation planes");
 
 #ifndef PR_SPLIT_ABLATE
-#define PR_SPLIT_ABLATE 0   // profiling builds only: 1 = no weight re-loads, 2 = no activation re-loads, 8 = no epilogue
+#define PR_SPLIT_ABLATE 0   // profiling builds only (results are wrong): 1 = every K step re-reads the operands of steps 0 / 1 (L1 hits: no L2 weight stream), 8 = no epilogue
 #endif
 #if PR_SPLIT_ABLATE & 64
 // phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase
@@ -230,7 +230,7 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             const f16x8* wpB = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cbB * ks * 128 + lane;
             f16x8 bBhE = wpB[0], bBlE = wpB[64], bBhO = wpB[128], bBlO = wpB[192];
             for (int s = 0; s < ks; s += 2) {
-                const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                const int se = (PR_SPLIT_ABLATE & 1) ? 0 : ((s + 2 < ks) ? s + 2 : s), so = (PR_SPLIT_ABLATE & 1) ? 1 : ((s + 3 < ks) ? s + 3 : s + 1);
                 PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
                 PR_SPLIT3(mA1, ah1E, al1E, bAhE, bAlE);
                 PR_SPLIT3(mB0, ah0E, al0E, bBhE, bBlE);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
             }
         } else {
             for (int s = 0; s < ks; s += 2) {
-                const int se = (s + 2 < ks) ? s + 2 : s, so = (s + 3 < ks) ? s + 3 : s + 1;
+                const int se = (PR_SPLIT_ABLATE & 1) ? 0 : ((s + 2 < ks) ? s + 2 : s), so = (PR_SPLIT_ABLATE & 1) ? 1 : ((s + 3 < ks) ? s + 3 : s + 1);
                 PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
                 PR_SPLIT3(mA1, ah1E, al1E, bAhE, bAlE);
                 bAhE = wpA[(size_t)se * 128];

@@ -26,7 +26,7 @@ from playableenvironments_amd import _lib, configs, synthetic  # noqa: E402
 
 if os.environ.get("PR_FUZZ_LIB"):      # a measurement / comparison build of the library (tools/build_variant.sh)
     _lib.library_path = lambda: os.path.abspath(os.environ["PR_FUZZ_LIB"])
-from tests.helpers import arbitrate, compare_results, composer_inputs, grid_pixels, poison_device_memory as poison  # noqa: E402
+from tests.helpers import arbitrate, bender_kink_margin, compare_results, composer_inputs, grid_pixels, poison_device_memory as poison  # noqa: E402
 from tests.test_gpu import build, run_both, run_exact  # noqa: E402
 
 
@@ -109,8 +109,28 @@ def oracle_sensitivity(cfg, scene, n, bias, perturb, keys, rays, eps=1e-6, trial
     return worst
 
 
+def divergence_kink_margin(cfg, scene, n, bias, perturb, absent, noise_seed=123):
+    """tests.helpers.bender_kink_margin of the oracle run `_gradients` makes for this case."""
+    from oracle import render_oracle as ro
+    comp = build(cfg, alpha_bias=bias).train(True)
+    o, d, nrm, w2o, sty, dfm, ins = composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))
+    if absent is not None:
+        ins = ins.clone()
+        flat = ins.reshape(-1, ins.size(-1))
+        if absent[1] is None:
+            flat[:, absent[0]] = False
+        else:
+            flat[absent[1] % flat.size(0), absent[0]] = False
+    sd = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+
+    def run_oracle():
+        torch.manual_seed(noise_seed)
+        ro.composer_forward(cfg, sd, o, d, nrm, w2o, sty, dfm, ins, perturb, training=True, record_noise={}, stable_merge=True)
+    return bender_kink_margin(run_oracle)
+
+
 def backward_sweep(cases, rng, only=None):
-    from tests.test_gpu import GRAD_KEYS, _gradients
+    from tests.test_gpu import GRAD_KEYS, ForwardFieldMismatch, _gradients
     failures = 0
     for i in range(cases):
         world = rng.choice(["tennis", "minecraft"])
@@ -180,6 +200,17 @@ def backward_sweep(cases, rng, only=None):
                 print("ok", label[:170])
         except ValueError as e:       # train-mode BatchNorm on exactly one sample: the reference raises too
             print("skipped", label[:120], str(e)[:60])
+        except ForwardFieldMismatch as e:
+            # only the Hutchinson divergence estimate, with a sample within fp32 rounding of a kink of the benders' Jacobian (its
+            # displacement at the clamp bound, a hidden unit at 0): the estimate is discontinuous there
+            margin = 1.0
+            if all(k.endswith("integrated_divergence") for k in e.fields):
+                margin = divergence_kink_margin(cfg, scene, n, bias, perturb, absent)
+            if margin < 2e-7:
+                print(f"divergence kink (a sample {margin:.1e} of its scale from a kink of the ray bender's Jacobian; every other field agrees)", label[:120])
+            else:
+                failures += 1
+                print("ERROR", label, e.fields, f"kink margin {margin:.1e}")
         except Exception:
             failures += 1
             print("ERROR", label)

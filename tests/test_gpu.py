@@ -527,6 +527,13 @@ def _probe_loss(results, probes, K):
     return total
 
 
+class ForwardFieldMismatch(AssertionError):
+    """A forward field of a differentiable call beyond the tolerance AND farther from float64 than the fp32 oracle (x 4)."""
+    def __init__(self, fields):
+        super().__init__(fields)
+        self.fields = fields
+
+
 def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GRAD_KEYS, training=True, rays=False,
                min_divergence=1e-2, absent=None, exact=False, noise_seed=123, precision="fp32"):
     """(oracle autograd, HIP backward) gradients of a random linear functional of the output fields ``keys``; ``rays``: also
@@ -587,12 +594,26 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
     fields = {ty: want[ty] for ty in ("coarse", "fine") if ty in want}
     rep = compare_results(fields, {ty: got[ty] for ty in fields}, rtol=1e-3, atol=2e-4)
     bad = {k: f"{v[0]:.3e}" for k, v in rep.items() if not v[1]}
-    assert not bad, bad
+    settled = set()
+    if bad:
+        # a field beyond the tolerance is ARBITRATED, not waved through: the oracle's op graph in float64 on the same weights, inputs
+        # and replayed noise is the exact result, and the HIP field may be as far from it as the fp32 oracle's is (x 4) - the
+        # Hutchinson estimate of a narrow ray bender cancels to a small fraction of its terms (randomized sweep, seed 7 case 0)
+        with oracle_in_float64():
+            exact_fwd = ro.composer_forward(cfg, to_double({k: v.detach() for k, v in sd.items()}), *[t.detach().double() for t in ref_rays],
+                                            nrm.double(), *[t.detach().double() for t in ref_in], ins, perturb, canonical_pose=canonical,
+                                            training=training, noise=to_double(rec), update_stats=False, stable_merge=True)
+        verdicts = arbitrate({ty: exact_fwd[ty] for ty in fields}, fields, {ty: got[ty] for ty in fields})
+        settled = {k for k in bad if verdicts[k][2]}
+        bad = {k: f"{v} (HIP - fp64 {verdicts[k][0]:.3e}, fp32 oracle - fp64 {verdicts[k][1]:.3e})" for k, v in bad.items() if k not in settled}
+    if bad:
+        raise ForwardFieldMismatch(bad)
     if not canonical and training:
         a = want["coarse"]["global"]["integrated_divergence"].detach()
         b = got["coarse"]["global"]["integrated_divergence"].detach().cpu()
         # (min_divergence: the suite's scenes are built to have a sizeable estimate; the random sweep passes 0)
-        assert float(a.abs().max()) > min_divergence and float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 2e-4
+        assert float(a.abs().max()) > min_divergence
+        assert "coarse.global.integrated_divergence" in settled or float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 2e-4
     params = dict(comp.named_parameters())
     ref = {k: sd[k].grad for k in names}
     hip = {k: params[k].grad for k in names}
@@ -2821,7 +2842,7 @@ def test_randomized_sweep_slice(sweep, cases, capsys):
     report = capsys.readouterr().out
     assert failures == 0, report[-4000:]
     plain = report.count("ok case")
-    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("skipped")
+    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("divergence kink") + report.count("skipped")
     assert plain + classified == cases, report[-2000:]
     # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floors = the
     # plain-ok counts of seed 0 when the check was introduced (round 4: forward 40 / 40 of which hierarchical cases may need the
