@@ -145,21 +145,19 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
     l->t3_h0 = take3(d.Wpad / 32, d.Wpad);
     l->t3_h3 = take3(d.Wpad / 32, d.W2pad);
     l->t3_h6 = take3(d.W2pad / 32, d.Fpad);
-    // forward segments of a training call's phase 1 in split precision: fp16 (hi, lo) fragment pairs, the layout of the split
-    // evaluation kernel (k_pack kind 2: the same number of bytes as the fp32 fragments)
-    auto take2 = [&](int nblk, int kpad) { const int at = off; off += seg_floats(nblk, kpad); return at; };
+    // forward segments of a training call's phase 1 as bf16 triples
     if (m.has_bender) {
         const int nbb = d.BWpad / 32;
         for (int j = 0; j < m.bender_count; ++j) {
-            l->b_seg3[j][0] = take2(nbb, j == 0 ? d.bin_pad : d.BWpad);
-            if (j == m.bender_skip) l->b_seg3[j][1] = take2(nbb, d.bin_pad);
+            l->b_seg3[j][0] = take3(nbb, j == 0 ? d.bin_pad : d.BWpad);
+            if (j == m.bender_skip) l->b_seg3[j][1] = take3(nbb, d.bin_pad);
         }
     }
     for (int i = 0; i < m.backbone_count; ++i) {
-        l->n_seg3[i][0] = take2(d.Wpad / 32, i == 0 ? d.enc_pad : d.Wpad);
-        if (i == m.skip_layer_idx) l->n_seg3[i][1] = take2(d.Wpad / 32, d.enc_pad);
+        l->n_seg3[i][0] = take3(d.Wpad / 32, i == 0 ? d.enc_pad : d.Wpad);
+        if (i == m.skip_layer_idx) l->n_seg3[i][1] = take3(d.Wpad / 32, d.enc_pad);
     }
-    l->h0_3 = take2(d.Wpad / 32, d.Wpad);
+    l->h0_3 = take3(d.Wpad / 32, d.Wpad);
     l->total = off;
     return PR_OK;
 }
@@ -302,10 +300,12 @@ static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_r
     return PR_OK;
 }
 
-// a forward segment as fp16 (hi, lo) fragment pairs (kind 2) inside the fp32 packing: phase 1 of a split-precision training call
+// a forward segment as bf16 triples (kind 3)
 static int add_seg3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
     PR_TRY(add_seg(js, lin, col_off, k_real, kpad, npad, dst));
-    js->job[js->n - 1].kind = 2;
+    PackJob& j = js->job[js->n - 1];
+    j.kind = 3;
+    j.count = j.count / 2 * 3;
     return PR_OK;
 }
 
