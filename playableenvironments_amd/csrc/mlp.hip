@@ -145,19 +145,21 @@ int compute_layout(const pr_object_model_t& m, const ModelDims& d, PackedLayout*
     l->t3_h0 = take3(d.Wpad / 32, d.Wpad);
     l->t3_h3 = take3(d.Wpad / 32, d.W2pad);
     l->t3_h6 = take3(d.W2pad / 32, d.Fpad);
-    // forward segments of a training call's phase 1 as bf16 triples
+    // forward segments of a training call's phase 1 in split precision: fp16 (hi, lo) fragment pairs, the layout of the split
+    // evaluation kernel (k_pack kind 2: the same number of bytes as the fp32 fragments)
+    auto take2 = [&](int nblk, int kpad) { const int at = off; off += seg_floats(nblk, kpad); return at; };
     if (m.has_bender) {
         const int nbb = d.BWpad / 32;
         for (int j = 0; j < m.bender_count; ++j) {
-            l->b_seg3[j][0] = take3(nbb, j == 0 ? d.bin_pad : d.BWpad);
-            if (j == m.bender_skip) l->b_seg3[j][1] = take3(nbb, d.bin_pad);
+            l->b_seg3[j][0] = take2(nbb, j == 0 ? d.bin_pad : d.BWpad);
+            if (j == m.bender_skip) l->b_seg3[j][1] = take2(nbb, d.bin_pad);
         }
     }
     for (int i = 0; i < m.backbone_count; ++i) {
-        l->n_seg3[i][0] = take3(d.Wpad / 32, i == 0 ? d.enc_pad : d.Wpad);
-        if (i == m.skip_layer_idx) l->n_seg3[i][1] = take3(d.Wpad / 32, d.enc_pad);
+        l->n_seg3[i][0] = take2(d.Wpad / 32, i == 0 ? d.enc_pad : d.Wpad);
+        if (i == m.skip_layer_idx) l->n_seg3[i][1] = take2(d.Wpad / 32, d.enc_pad);
     }
-    l->h0_3 = take3(d.Wpad / 32, d.Wpad);
+    l->h0_3 = take2(d.Wpad / 32, d.Wpad);
     l->total = off;
     return PR_OK;
 }
@@ -179,6 +181,7 @@ struct PackJob {
     int k_real, n_real, kq, nblk;
     int count;      // elements of dst
     int transposed; // kind 0: element (n, k) is read from src[k * in_total + col_off + n] (the backward chain's W^T)
+    int scale_log2; // kind 2: the weights are multiplied by 2^scale_log2 before they are split (0 for the evaluation packing)
 };
 constexpr int MAX_PACK_JOBS = 192;
 struct PackJobs {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 const int n = nb * 32 + (lane & 31);
                 const int k = 16 * sidx + 8 * (lane >> 5) + e;
                 float w = 0.f;
-                if (n < j.n_real && k < j.k_real) w = j.src[(size_t)n * j.in_total + j.col_off + k];
+                if (n < j.n_real && k < j.k_real) w = ldexpf(j.src[(size_t)n * j.in_total + j.col_off + k], j.scale_log2);
                 const _Float16 hi = (_Float16)w;
                 const _Float16 lo = (_Float16)(w - (float)hi);
                 const _Float16 sel = part ? lo : hi;
@@ -277,6 +280,7 @@ static int add_seg(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real
     j.nblk = npad / 32;
     j.count = seg_floats(j.nblk, kpad);
     j.transposed = 0;
+    j.scale_log2 = 0;
     return PR_OK;
 }
 
@@ -300,12 +304,15 @@ static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_r
     return PR_OK;
 }
 
-// a forward segment as bf16 triples (kind 3)
+// a forward segment as fp16 (hi, lo) fragment pairs (kind 2) inside the fp32 packing: phase 1 of a split-precision training call
 static int add_seg3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int npad, float* dst) {
     PR_TRY(add_seg(js, lin, col_off, k_real, kpad, npad, dst));
-    PackJob& j = js->job[js->n - 1];
-    j.kind = 3;
-    j.count = j.count / 2 * 3;
+    js->job[js->n - 1].kind = 2;
+    // weights of 0.01 - 0.1 have their lo half in fp16's subnormal range (relative error 2^-25 / |w|: harmless for a rendered value,
+    // 10 x fp32's on the density head's bias gradient, which sums over every sample - measured); scaled by 2^4 the lo halves of
+    // |w| > 0.016 are normal numbers and |w| < 4094 stays in range.  The kernel starts its accumulators at bias x 2^4 and multiplies
+    // them by 2^-4 behind the K loops - both exact.
+    js->job[js->n - 1].scale_log2 = TRAIN_SPLIT_WEIGHT_SCALE_LOG2;
     return PR_OK;
 }
 
@@ -925,8 +932,8 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
     if (count > 3) mlp_tile_loop<true, true>(j3);
 }
 
-// phase 1 of a training call in split precision (PR_FLAG_SPLIT_BACKWARD): the same tile loop on bf16-triple segments
-__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group_bf16(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
+// phase 1 of a training call in split precision (PR_FLAG_SPLIT_BACKWARD): the same tile loop on fp16-pair segments (tile_products_f16x3_lean)
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group_split(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                               int count) {
     mlp_tile_loop<true, true, true>(j0);
     if (count > 1) mlp_tile_loop<true, true, true>(j1);
@@ -1266,7 +1273,7 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
             PR_REQUIRE((host_jobs[begin + j].split3 != 0) == (host_jobs[begin].split3 != 0) && (phase == 1 || !host_jobs[begin + j].split3),
                        "grouped MLP launch: bf16-triple segments belong to phase 1, for every job of the launch or none");
         const void* kernel = phase >= 2 ? reinterpret_cast<const void*>(k_mlp_head_group)
-                                        : (phase == 1 ? (split3 ? reinterpret_cast<const void*>(k_mlp_mfma_train_group_bf16)
+                                        : (phase == 1 ? (split3 ? reinterpret_cast<const void*>(k_mlp_mfma_train_group_split)
                                                                 : reinterpret_cast<const void*>(k_mlp_mfma_train_group))
                                                       : reinterpret_cast<const void*>(k_mlp_mfma_group));
         PR_TRY(prepare_kernel(kernel, (int)sizeof(Smem), &cu_count));
@@ -1278,7 +1285,7 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         if (phase >= 2)
             hipLaunchKernelGGL(k_mlp_head_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else if (phase == 1 && split3)
-            hipLaunchKernelGGL(k_mlp_mfma_train_group_bf16, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
+            hipLaunchKernelGGL(k_mlp_mfma_train_group_split, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else if (phase == 1)
             hipLaunchKernelGGL(k_mlp_mfma_train_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         else
@@ -1292,7 +1299,7 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
 int build_mlp_layers(const pr_object_model_t& m, const ModelDims& d, const PackedLayout& l, const float* base,
                      MlpParams* p, bool split3) {
     // split3 (phase 1 of a training call with PR_FLAG_SPLIT_BACKWARD): ray bender, backbone and head layer 0 read their
-    // bf16-triple packings; the head layers of the later phases and every small vector stay fp32
+    // fp16-pair packings (add_seg3); the head layers of the later phases and every small vector stay fp32
     p->split3 = split3 ? 1 : 0;
     p->kind = m.kind;
     p->has_bender = m.has_bender;

@@ -403,12 +403,56 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
     __builtin_amdgcn_s_setprio(0);
 }
 
-// The same loop with fewer live registers, for the training FORWARD kernel (which carries its input encoding and its batch-statistics
-// sums in registers across the layers): the fragments of a step are split at the top of the step from the raw operands requested
-// during the previous one - one converted set instead of two; the conversions then run in front of the step's MFMAs and overlap
-// the other resident tile's matrix work only.
-__device__ __forceinline__ void tile_products_bf16_lean(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                                        f32x16& a11) {
+// The FORWARD products of a split-precision training call (phase 1): operands as fp16 pairs, x = hi + lo (hi = fp16(x), lo =
+// fp16(x - hi): ~22 significant bits; forward activations are O(1) - the range that rules fp16 out for gradients is not an issue
+// here, and the split evaluation kernel passes the fp32 parity tolerance with this representation), a product as the THREE
+// v_mfma_f32_32x32x16_f16 hi x hi + hi x lo + lo x hi: half the matrix time and two thirds of the weight bytes of the bf16-triple
+// form, which the backward pass keeps (gradients need the fp32 exponent range).  `sg.w`: the segment as k_pack kind 2 fragments
+// ([column block][K step][hi 64 lanes x 16 B | lo 64 lanes x 16 B]); the operand tile stays fp32 in X (it is what gets saved) and
+// is split in registers at the top of every step from the raw operands requested during the previous one (one converted set: the
+// forward carries its input encoding and its batch-statistics sums in registers across the layers).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#ifndef PR_TRAIN_SPLIT_SCALE
+#define PR_TRAIN_SPLIT_SCALE 4
+#endif
+constexpr int TRAIN_SPLIT_WEIGHT_SCALE_LOG2 = PR_TRAIN_SPLIT_SCALE;    // the packed fp16 pairs hold w x 2^4 (add_seg3 in mlp.hip)
+#define PR_MFMA_F16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
+struct FragH { f16x8_t hi, lo; };
+__device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned int& ph, unsigned int& pl) {
+    // fp16 range guard (never reached by sane activations; the split evaluation kernel has the same one)
+    const f32x2_t v = {__builtin_amdgcn_fmed3f(x0, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(x1, -65504.0f, 65504.0f)};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    const f32x2_t back = __builtin_convertvector(h, f32x2_t);
+    const f32x2_t r = {sub_f32(v[0], back[0]), sub_f32(v[1], back[1])};
+    ph = __builtin_bit_cast(unsigned int, h);
+    pl = __builtin_bit_cast(unsigned int, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ FragH split_fragment_h(const float4& lo, const float4& hi) {
+    unsigned int a[4], b[4];
+    split_pair_h(lo.x, lo.y, a[0], b[0]);
+    split_pair_h(lo.z, lo.w, a[1], b[1]);
+    split_pair_h(hi.x, hi.y, a[2], b[2]);
+    split_pair_h(hi.z, hi.w, a[3], b[3]);
+    FragH f;
+    const u32x4 wa = {a[0], a[1], a[2], a[3]}, wb = {b[0], b[1], b[2], b[3]};
+    f.hi = __builtin_bit_cast(f16x8_t, wa);
+    f.lo = __builtin_bit_cast(f16x8_t, wb);
+    return f;
+}
+// the three terms of the blocks of one step, smallest first, block by block inside a term
+#define PR_STEP_MFMAS_H(F0, F1, WAH, WAL, WBH, WBL)                                                                          \
+    do {                                                                                                                    \
+        PR_MFMA_F16(a00, F0.lo, WAH); PR_MFMA_F16(a01, F1.lo, WAH);                                                         \
+        if (two) { PR_MFMA_F16(a10, F0.lo, WBH); PR_MFMA_F16(a11, F1.lo, WBH); }                                            \
+        PR_MFMA_F16(a00, F0.hi, WAL); PR_MFMA_F16(a01, F1.hi, WAL);                                                         \
+        if (two) { PR_MFMA_F16(a10, F0.hi, WBL); PR_MFMA_F16(a11, F1.hi, WBL); }                                            \
+        PR_MFMA_F16(a00, F0.hi, WAH); PR_MFMA_F16(a01, F1.hi, WAH);                                                         \
+        if (two) { PR_MFMA_F16(a10, F0.hi, WBH); PR_MFMA_F16(a11, F1.hi, WBH); }                                            \
+    } while (0)
+
+__device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                         f32x16& a11) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int cbA = wave, cbB = wave + MLP_WAVES;
@@ -417,36 +461,37 @@ __device__ __forceinline__ void tile_products_bf16_lean(const Seg& sg, int nblk,
     __builtin_amdgcn_s_setprio(1);
     const int ks = sg.kq >> 1;
     const float* ap = X + r * LDX + 8 * half;
-    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
-    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
+    // per (column block, step): hi fragment (64 lanes x 16 B), then lo fragment
+    const f16x8_t* wpA = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)cbA * ks * 128 + lane;
+    const f16x8_t* wpB = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
     float4 xl = *reinterpret_cast<const float4*>(ap), xh = *reinterpret_cast<const float4*>(ap + 4);
     float4 yl = *reinterpret_cast<const float4*>(ap + 32 * LDX), yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-    bf16x8 ea0 = wpA[0], ea1 = wpA[64], ea2 = wpA[128], eb0 = wpB[0], eb1 = wpB[64], eb2 = wpB[128];
-    bf16x8 oa0, oa1, oa2, ob0 = eb0, ob1 = eb1, ob2 = eb2;
+    f16x8_t eah = wpA[0], eal = wpA[64], ebh = wpB[0], ebl = wpB[64];
+    f16x8_t oah, oal, obh = ebh, obl = ebl;
     for (int s = 0; s < ks; s += 2) {
         {
-            const Frag3 f0 = split_fragment(xl, xh), f1 = split_fragment(yl, yh);
+            const FragH f0 = split_fragment_h(xl, xh), f1 = split_fragment_h(yl, yh);
             const float* an = ap + 16 * (s + 1);
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)(s + 1) * 192;
-            oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
-            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
-            __builtin_amdgcn_sched_barrier(0);
-            PR_STEP_MFMAS(f0, f1, ea0, ea1, ea2, eb0, eb1, eb2);
+            const size_t at = (size_t)(s + 1) * 128;
+            oah = wpA[at]; oal = wpA[at + 64];
+            if (two) { obh = wpB[at]; obl = wpB[at + 64]; }
+            __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of the step's MFMAs
+            PR_STEP_MFMAS_H(f0, f1, eah, eal, ebh, ebl);
             __builtin_amdgcn_sched_barrier(0);
         }
         {
-            const Frag3 f0 = split_fragment(xl, xh), f1 = split_fragment(yl, yh);
+            const FragH f0 = split_fragment_h(xl, xh), f1 = split_fragment_h(yl, yh);
             const int sn = (s + 2 < ks) ? s + 2 : s;
             const float* an = ap + 16 * sn;
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)sn * 192;
-            ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
-            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
+            const size_t at = (size_t)sn * 128;
+            eah = wpA[at]; eal = wpA[at + 64];
+            if (two) { ebh = wpB[at]; ebl = wpB[at + 64]; }
             __builtin_amdgcn_sched_barrier(0);
-            PR_STEP_MFMAS(f0, f1, oa0, oa1, oa2, ob0, ob1, ob2);
+            PR_STEP_MFMAS_H(f0, f1, oah, oal, obh, obl);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -465,8 +510,12 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     PR_PHASE_T0();
     f32x16 a00, a01, a10, a11;           // [column block A / B][row block 0 / 1]
     {
-        const float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
-        const float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
+        float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
+        float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
+        if (SPLIT) {        // the split-precision segments hold w x 2^4: the accumulators run at that scale
+            biasA = ldexpf(biasA, TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+            biasB = ldexpf(biasB, TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             a00[i] = biasA;
@@ -488,8 +537,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
 #if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 128)
         continue;   // measurement build: no matrix work (results are wrong)
 #endif
-        if (SPLIT) {
-            tile_products_bf16_lean(sg, nblk, S.X, a00, a01, a10, a11);
+        if (SPLIT) {             // phase 1 of a training call with PR_FLAG_SPLIT_BACKWARD: fp16 pairs
+            tile_products_f16x3_lean(sg, nblk, S.X, a00, a01, a10, a11);
             continue;
         }
         // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
@@ -554,6 +603,16 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             }
         }
         __builtin_amdgcn_s_setprio(0);
+    }
+    if (SPLIT) {
+        const float back = 1.0f / (float)(1 << TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a00[i] *= back;
+            a01[i] *= back;
+            a10[i] *= back;
+            a11[i] *= back;
+        }
     }
 #if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 4)
     return;   // measurement build: no barriers, no epilogue (results are wrong)
