@@ -293,9 +293,10 @@ class ObjectComposer(nn.Module):
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
         #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3" (split precision): evaluation renders compute every product
         #: as three fp16 MFMAs with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant
-        #: bits); differentiable / training calls keep the exact fp32 FORWARD kernels (train-mode BatchNorm phases, saved activations)
-        #: and run the BACKWARD pass's matrix products on bf16 triples (x = b1 + b2 + b3 exactly, six bf16 MFMAs per product, fp32
-        #: accumulation: PR_FLAG_SPLIT_BACKWARD) where a split kernel exists - gradients agree with the fp32 path to fp32 round-off.
+        #: bits); differentiable / training calls keep the fp32 forward PIPELINE (train-mode BatchNorm phases, fp32 saved activations)
+        #: with phase 1's matrix products on fp16 pairs as well, and run the BACKWARD pass's matrix products on bf16 triples (x = b1 +
+        #: b2 + b3 exactly, six bf16 MFMAs per product, fp32 accumulation: PR_FLAG_SPLIT_BACKWARD) where a split kernel exists -
+        #: gradients pass the fp32 path's tests, the float64 arbitration at shipped sizes included.
         #: "f16" (throughput tier, interactive play): evaluation renders keep the a_hi*w_hi product only - plain fp16 operands, fp32
         #: accumulation, one MFMA per step; ~1e-3 relative error on the rendered features (>= 40 dB PSNR against the oracle), so
         #: NOT a parity configuration.  Shares the packed weights with "f16x3"; training / differentiable calls behave as "f16x3".
@@ -525,7 +526,7 @@ class ObjectComposer(nn.Module):
             raise ValueError(f"unknown precision {self.precision!r} (expected 'fp32', 'f16x3' or 'f16')")
         if self.precision != "fp32" and (self.training or differentiable):
             # the forward pass of training / differentiable calls runs the exact fp32 kernels (train-mode BatchNorm phases, saved
-            # activations) on fp32-packed weights; "f16x3" selects the split-precision BACKWARD products for them (_render)
+            # activations) on fp32-packed weights; "f16x3" selects the split-precision products of those kernels (_render)
             return _lib.PR_PRECISION_FP32
         return {"fp32": _lib.PR_PRECISION_FP32, "f16x3": _lib.PR_PRECISION_F16X3, "f16": _lib.PR_PRECISION_F16}[self.precision]
 
