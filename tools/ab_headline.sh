@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of measurement builds of the split / f16 kernels on the headline workload: tools/run_r4k.sh <variant> [<variant> ...]
+# A/B of measurement builds of the split / f16 kernels on the headline workload: tools/ab_headline.sh <variant> [<variant> ...]
 mkdir -p gpurun_out/r4
 {
 for rep in 1 2; do
