@@ -1058,3 +1058,22 @@ def test_trainer_loss_fixtures_present():
         assert len(keys) == 58 and "info/loss" in keys and "info/bounding_box_loss" in keys and "info/coarse_reconstruction_loss" in keys
         assert abs(float(z["info/loss"]) - float(z["total_loss"])) < 1e-6
         assert all(np.isfinite(float(z[k])) for k in keys)
+
+
+def test_scene_setup_rejects_bad_arguments_without_a_gpu():
+    """pr_scene_setup (the fused scene set-up of an evaluation call) validates its sizes and pointers before anything is
+    enqueued: callable error paths on a box without a GPU, like the renderer's (test_abi_error_paths)."""
+    lib = _lib.load()
+    assert lib.pr_scene_setup(None, None) == -1
+    assert b"NULL argument" in lib.pr_last_error()
+    q = _lib.SceneSetup()
+    q.frames, q.cameras, q.objects, q.box_points_per_object = 1, 1, 4, 8
+    q.style_features, q.deformation_features, q.height, q.width = 32, 32, 288, 512
+    q.focal_multiplier, q.upsample_factor = 0.5, 1.0
+    assert lib.pr_scene_setup(C.byref(q), None) == -1               # every pointer is NULL
+    assert b"NULL pointer" in lib.pr_last_error()
+    q.objects = 9                                                     # more instances than the ABI holds
+    assert lib.pr_scene_setup(C.byref(q), None) == -1
+    assert b"bad sizes" in lib.pr_last_error()
+    q.objects, q.frames = 4, 0                                        # an empty call is a no-op
+    assert lib.pr_scene_setup(C.byref(q), None) == 0
