@@ -2051,7 +2051,11 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         float* dscale2 = tables + (size_t)c.frames * 2 * MAX_WIDTH;
         float* dbias2 = tables + (size_t)c.frames * 3 * MAX_WIDTH;
         const int frozen = (c.flags & PR_FLAG_TRAIN_BN) ? 0 : 1;
+#ifdef PR_CHAIN_BF16
         const int split_bwd = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 1 : 0;      // products on bf16 triples (t3_* segments)
+#else
+        const int split_bwd = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 2 : 0;      // products on fp16 pairs of scaled tiles (t3_* segments)
+#endif
         // (the two head phases keep the fp32 product: with the phase's raw-activation prefetch registers the bf16 variant of
         // k_head_bwd_group spills 125 VGPRs; they are 0.4 ms of the step)
         const int split_head = 0;

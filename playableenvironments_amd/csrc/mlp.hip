@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 const int n = nb * 32 + (lane & 31);
                 const int k = 16 * sidx + 8 * (lane >> 5) + e;
                 float w = 0.f;
-                if (n < j.n_real && k < j.k_real) w = ldexpf(j.src[(size_t)n * j.in_total + j.col_off + k], j.scale_log2);
+                if (n < j.n_real && k < j.k_real)
+                    w = ldexpf(j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k],
+                               j.scale_log2);
                 const _Float16 hi = (_Float16)w;
                 const _Float16 lo = (_Float16)(w - (float)hi);
                 const _Float16 sel = part ? lo : hi;
@@ -295,12 +297,18 @@ static int add_seg_t(PackJobs* js, const pr_linear_t& lin, int col_off, int k_re
     return PR_OK;
 }
 
-// the same W^T segment as bf16 triples (kind 3)
+// the same W^T segment for the split-precision backward chains: fp16 (hi, lo) pairs of w x 2^4 (kind 2; the chains scale their
+// gradient tiles into fp16's range, train_bwd.hip) - or bf16 triples (kind 3, -DPR_CHAIN_BF16: 1.5 x the bytes, six MFMAs per product)
 static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int n_real, int npad, float* dst) {
     PR_TRY(add_seg_t(js, lin, col_off, k_real, kpad, n_real, npad, dst));
     PackJob& j = js->job[js->n - 1];
+#ifdef PR_CHAIN_BF16
     j.kind = 3;
     j.count = j.count / 2 * 3;      // 32-bit words: two bf16 each, three planes
+#else
+    j.kind = 2;                     // (in the region sized for the triples)
+    j.scale_log2 = TRAIN_SPLIT_WEIGHT_SCALE_LOG2;
+#endif
     return PR_OK;
 }
 

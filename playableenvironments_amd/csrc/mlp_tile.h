@@ -498,6 +498,64 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
     __builtin_amdgcn_s_setprio(0);
 }
 
+// The same products for the BACKWARD chain (gradient tiles): the operand is multiplied by `scale` (a power of two chosen per tile so
+// that its largest entry sits just under 2^15: gradients of ~1e-7 are far below fp16's range) while it is split; the caller
+// multiplies the accumulators by 1 / (scale x 2^TRAIN_SPLIT_WEIGHT_SCALE_LOG2) behind the loop.  Entries within 2^-16 of the tile's
+// largest keep 22 significant bits, smaller ones an absolute error of 2^-39 of it.  With the gradient write-out of tile_products.
+__device__ __forceinline__ FragH split_fragment_scaled_h(const float4& lo, const float4& hi, float scale) {
+    const float4 l = make_float4(lo.x * scale, lo.y * scale, lo.z * scale, lo.w * scale);
+    const float4 h = make_float4(hi.x * scale, hi.y * scale, hi.z * scale, hi.w * scale);
+    return split_fragment_h(l, h);
+}
+__device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                    f32x16& a11, const Drain* drain, float scale) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, half = lane >> 5;
+    const int cbA = wave, cbB = wave + MLP_WAVES;
+    if (cbA >= nblk) return;
+    const bool two = cbB < nblk;
+    __builtin_amdgcn_s_setprio(1);
+    const int ks = sg.kq >> 1;
+    const float* ap = X + r * LDX + 8 * half;
+    const f16x8_t* wpA = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)cbA * ks * 128 + lane;
+    const f16x8_t* wpB = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
+    float4 xl = *reinterpret_cast<const float4*>(ap), xh = *reinterpret_cast<const float4*>(ap + 4);
+    float4 yl = *reinterpret_cast<const float4*>(ap + 32 * LDX), yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
+    FragH e0 = split_fragment_scaled_h(xl, xh, scale), e1 = split_fragment_scaled_h(yl, yh, scale), o0, o1;
+    f16x8_t eah = wpA[0], eal = wpA[64], ebh = wpB[0], ebl = wpB[64];
+    f16x8_t oah, oal, obh = ebh, obl = ebl;
+    for (int s = 0; s < ks; s += 2) {
+        {   // even step: request the odd step's operands, multiply the even fragments, split the odd ones behind the MFMAs
+            const float* an = ap + 16 * (s + 1);
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)(s + 1) * 128;
+            oah = wpA[at]; oal = wpA[at + 64];
+            if (two) { obh = wpB[at]; obl = wpB[at + 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS_H(e0, e1, eah, eal, ebh, ebl);
+            o0 = split_fragment_scaled_h(xl, xh, scale); o1 = split_fragment_scaled_h(yl, yh, scale);
+            if (drain) drain_chunk(*drain, X, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const int sn = (s + 2 < ks) ? s + 2 : s;
+            const float* an = ap + 16 * sn;
+            xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
+            yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
+            const size_t at = (size_t)sn * 128;
+            eah = wpA[at]; eal = wpA[at + 64];
+            if (two) { ebh = wpB[at]; ebl = wpB[at + 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+            PR_STEP_MFMAS_H(o0, o1, oah, oal, obh, obl);
+            e0 = split_fragment_scaled_h(xl, xh, scale); e1 = split_fragment_scaled_h(yl, yh, scale);
+            if (drain) drain_chunk(*drain, X, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
 template <bool BWD, bool BITS, bool STATS, bool SPLIT>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
                                           const BwdEpilogue* bwd, unsigned long long* bits_out, ColumnStats* stats) {

@@ -138,11 +138,28 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
     __builtin_amdgcn_s_setprio(0);
 }
 
-template <bool SPLIT>
+// MODE 0: exact fp32; 1: bf16 triples; 2: fp16 pairs of the operand x `scale` (chain_bwd_loop: per-tile power-of-two scales)
+template <int MODE>
 __device__ __forceinline__ void tile_products_any(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                                  f32x16& a11, const Drain* drain = nullptr) {
-    if (SPLIT) tile_products_bf16(sg, nblk, X, a00, a01, a10, a11, drain);
+                                                  f32x16& a11, const Drain* drain = nullptr, float scale = 1.0f) {
+    if (MODE == 2) tile_products_f16x3(sg, nblk, X, a00, a01, a10, a11, drain, scale);
+    else if (MODE == 1) tile_products_bf16(sg, nblk, X, a00, a01, a10, a11, drain);
     else tile_products(sg, nblk, X, a00, a01, a10, a11, drain);
+}
+
+// Largest |entry| of the tile a producer writes into X, for the fp16-pair products (MODE 2): every thread folds what it writes into
+// a running maximum and commits it to one of two LDS words (non-negative floats order like their bit patterns); the products that
+// read the tile turn the word into a power-of-two scale.  `slot` == nullptr: nothing is tracked (the other modes).
+__device__ __forceinline__ void commit_tile_max(float m, int* slot) {
+    if (slot == nullptr) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+}
+// scale = 2^k with max x 2^k in [2^14, 2^15); k = 0 for an all-zero (or non-finite) tile
+__device__ __forceinline__ int tile_scale_log2(int bits) {
+    const int e = ((bits >> 23) & 255);
+    return (e == 0 || e == 255) ? 0 : 14 - (e - 127);
 }
 
 // rows of X -> rows of a (cap, ld) array, 16-byte stores; only the tile's real rows
@@ -172,9 +189,10 @@ __device__ __forceinline__ ColMasks fetch_col_masks(const unsigned char* bits_la
 
 // ReLU backward of a product: X[row][col] = mask bit ? acc : 0  (the callers put barriers around it)
 __device__ __forceinline__ void store_masked(BSmem& S, int nblk, const ColMasks& masks, const f32x16& a00, const f32x16& a01, const f32x16& a10,
-                                             const f32x16& a11) {
+                                             const f32x16& a11, int* max_slot = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
+    float biggest = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         const int cb = wave + blk * MLP_WAVES;
@@ -189,10 +207,13 @@ __device__ __forceinline__ void store_masked(BSmem& S, int nblk, const ColMasks&
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ro = PR_ACC_ROW(i);
-            x0[ro * LDX] = ((mlo >> ro) & 1u) ? lo[i] : 0.f;
-            x0[(ro + 32) * LDX] = ((mhi >> ro) & 1u) ? hi[i] : 0.f;
+            const float v0 = ((mlo >> ro) & 1u) ? lo[i] : 0.f, v1 = ((mhi >> ro) & 1u) ? hi[i] : 0.f;
+            x0[ro * LDX] = v0;
+            x0[(ro + 32) * LDX] = v1;
+            biggest = fmaxf(biggest, fmaxf(fabsf(v0), fabsf(v1)));
         }
     }
+    commit_tile_max(biggest, max_slot);
 }
 
 // a product's rows straight to global memory (the gradient of a network input: X keeps its operand)
@@ -238,8 +259,10 @@ __device__ __forceinline__ void stage_bn_constants(BSmem& S, const float* mean, 
 
 // BatchNorm (batch statistics) backward of the tile while it is loaded: dh = rstd (dxh - mean(dxh) - xh mean(dxh xh)) for the rows
 // that entered the statistics, 0 otherwise -> X, and back to `d` in place (the left factor of the layer's weight gradient)
-__device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float* h, int width_pad, int tile_base, int rows_valid) {
+__device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float* h, int width_pad, int tile_base, int rows_valid,
+                                                 int* max_slot = nullptr) {
     const int w4 = width_pad >> 2;
+    float biggest = 0.f;
     for (int idx = threadIdx.x; idx < TILE_M * w4; idx += MLP_THREADS) {
         const int row = idx / w4, c = (idx - row * w4) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -260,7 +283,9 @@ __device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float
             *reinterpret_cast<float4*>(d + (size_t)(tile_base + row) * width_pad + c) = v;
         }
         *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
+        biggest = fmaxf(fmaxf(biggest, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    commit_tile_max(biggest, max_slot);
 }
 
 // records of the tile: flat sample index, frame, row flags (0 beyond the real rows)
@@ -303,7 +328,7 @@ __device__ __forceinline__ void flush_frame_sums(ColumnSums& cs, float* dscale, 
 // ---------------------------------------------------------------------------------------------
 // Feature-head backward, phases 1 and 2
 // ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
@@ -518,18 +543,18 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
                                                                                    int count) {
-    head_bwd_loop<false>(j0);
-    if (count > 1) head_bwd_loop<false>(j1);
-    if (count > 2) head_bwd_loop<false>(j2);
-    if (count > 3) head_bwd_loop<false>(j3);
+    head_bwd_loop<0>(j0);
+    if (count > 1) head_bwd_loop<0>(j1);
+    if (count > 2) head_bwd_loop<0>(j2);
+    if (count > 3) head_bwd_loop<0>(j3);
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group_bf16(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
                                                                                         int count) {
-    head_bwd_loop<true>(j0);
-    if (count > 1) head_bwd_loop<true>(j1);
-    if (count > 2) head_bwd_loop<true>(j2);
-    if (count > 3) head_bwd_loop<true>(j3);
+    head_bwd_loop<1>(j0);
+    if (count > 1) head_bwd_loop<1>(j1);
+    if (count > 2) head_bwd_loop<1>(j2);
+    if (count > 3) head_bwd_loop<1>(j3);
 }
 
 int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int count, hipStream_t s) {
@@ -564,7 +589,7 @@ int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int coun
 // ---------------------------------------------------------------------------------------------
 // Backward chain of a ReLU MLP with one skip concatenation, with its entry fused in
 // ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BSmem& S = *reinterpret_cast<BSmem*>(smem_raw);
@@ -586,8 +611,32 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         PR_CT0();
         load_tile_records(S, c.rec_flat, c.row_flags, c.samples_per_frame, tile_base, total);
         ColMasks masks = fetch_col_masks(c.bits + (size_t)(c.count - 1) * c.bits_stride, c.Wpad, nblk, tile);
+        // fp16-pair products (SPLIT == 2): the largest |entry| of the tile in X, in one of two LDS words - `cur` names the word of the
+        // tile the next product reads, its producer wrote into it, the other word is cleared while that product runs
+        int cur = 0;
+        if (SPLIT == 2 && tid == 0) S.pad_[0] = S.pad_[1] = 0;
         __syncthreads();
         f32x16 a00, a01, a10, a11;
+        // the product of the tile in X with one segment, at the tile's scale
+        auto scaled_product = [&](const Seg& sg, int out_blk, const Drain* drain) {
+            float scale = 1.0f;
+            if (SPLIT == 2) {
+                const int k = tile_scale_log2(S.pad_[cur]);
+                scale = ldexpf(1.0f, k);
+                if (tid == 0) S.pad_[cur ^ 1] = 0;      // (its next writers are behind this product's barrier)
+                tile_products_any<SPLIT>(sg, out_blk, S.X, a00, a01, a10, a11, drain, scale);
+                const float back = ldexpf(1.0f, -k - TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    a00[i] *= back;
+                    a01[i] *= back;
+                    a10[i] *= back;
+                    a11[i] *= back;
+                }
+            } else {
+                tile_products_any<SPLIT>(sg, out_blk, S.X, a00, a01, a10, a11, drain);
+            }
+        };
         if (c.entry == 1) {
             // NeRF: normalisation backward of head layer 1, . W0, + the density's path through the sigma head, ReLU mask of
             // the backbone's last layer
@@ -599,11 +648,11 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 S.gsr[tid] = gs;
                 if (tid < rows_valid && c.gsr4) *reinterpret_cast<float4*>(c.gsr4 + (size_t)(tile_base + tid) * 4) = make_float4(gs, 0.f, 0.f, 0.f);
             }
-            load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid);
+            load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid, SPLIT == 2 ? &S.pad_[0] : nullptr);
             __syncthreads();
             PR_CT(0);
             zero4(a00, a01, a10, a11);
-            tile_products_any<SPLIT>(c.w0t, nblk, S.X, a00, a01, a10, a11);
+            scaled_product(c.w0t, nblk, nullptr);
             PR_CT(1);
             __syncthreads();
             PR_CT(2);
@@ -619,7 +668,8 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                     hi[i] = fmaf(S.gsr[PR_ROWS_OF(i, half, 1)], w, hi[i]);
                 }
             }
-            store_masked(S, nblk, masks, a00, a01, a10, a11);
+            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.pad_[1] : nullptr);
+            cur = 1;
         } else {
             // ray bender: G = (g_raw . W_out) masked by the last layer's ReLU; one thread per column, the rows' raw gradients via LDS
             if (tid < TILE_M) {
@@ -632,10 +682,14 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 const bool live = col < c.W;
                 const float w0 = live ? c.w_out[col] : 0.f, w1 = live ? c.w_out[c.w_out_ld + col] : 0.f, w2 = live ? c.w_out[2 * c.w_out_ld + col] : 0.f;
                 const unsigned long long word = reinterpret_cast<const unsigned long long*>(c.bits + (size_t)(c.count - 1) * c.bits_stride)[(size_t)tile * c.Wpad + col];
+                float biggest = 0.f;
                 for (int row = 0; row < TILE_M; ++row) {
                     const float4 g = *reinterpret_cast<const float4*>(&S.cst[0][row * 4]);
-                    S.X[row * LDX + col] = ((word >> row) & 1ull) ? fmaf(g.x, w0, fmaf(g.y, w1, g.z * w2)) : 0.f;
+                    const float v = ((word >> row) & 1ull) ? fmaf(g.x, w0, fmaf(g.y, w1, g.z * w2)) : 0.f;
+                    S.X[row * LDX + col] = v;
+                    biggest = fmaxf(biggest, fabsf(v));
                 }
+                if (SPLIT == 2) atomicMax(reinterpret_cast<unsigned int*>(&S.pad_[0]), __float_as_uint(biggest));
             }
         }
         PR_CT(3);
@@ -650,7 +704,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 store_tile_rows(S.X, pending.dst - (size_t)tile_base * c.Wpad, c.Wpad, c.Wpad, tile_base, rows_valid);
                 pending.dst = nullptr;
             }
-            tile_products_any<SPLIT>(sg, out_blk, S.X, a00, a01, a10, a11, pending.dst ? &pending : nullptr);
+            scaled_product(sg, out_blk, pending.dst ? &pending : nullptr);
             pending.dst = nullptr;
         };
         PR_CT(5);
@@ -672,7 +726,8 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             PR_CT(1);
             __syncthreads();
             PR_CT(2);
-            store_masked(S, nblk, masks, a00, a01, a10, a11);
+            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.pad_[cur ^ 1] : nullptr);
+            cur ^= 1;
             PR_CT(3);
             __syncthreads();
             PR_CT(4);
@@ -691,19 +746,28 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
                                                                                     int count) {
-    chain_bwd_loop<false>(j0);
-    if (count > 1) chain_bwd_loop<false>(j1);
-    if (count > 2) chain_bwd_loop<false>(j2);
-    if (count > 3) chain_bwd_loop<false>(j3);
+    chain_bwd_loop<0>(j0);
+    if (count > 1) chain_bwd_loop<0>(j1);
+    if (count > 2) chain_bwd_loop<0>(j2);
+    if (count > 3) chain_bwd_loop<0>(j3);
 }
 
 // split precision (PR_FLAG_SPLIT_BACKWARD): the chains' products on bf16 triples
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group_bf16(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
                                                                                          int count) {
-    chain_bwd_loop<true>(j0);
-    if (count > 1) chain_bwd_loop<true>(j1);
-    if (count > 2) chain_bwd_loop<true>(j2);
-    if (count > 3) chain_bwd_loop<true>(j3);
+    chain_bwd_loop<1>(j0);
+    if (count > 1) chain_bwd_loop<1>(j1);
+    if (count > 2) chain_bwd_loop<1>(j2);
+    if (count > 3) chain_bwd_loop<1>(j3);
+}
+
+// ... or (the default of PR_FLAG_SPLIT_BACKWARD) on fp16 pairs of the tile x a per-tile power of two (job.split == 2)
+__global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group_f16(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
+                                                                                        int count) {
+    chain_bwd_loop<2>(j0);
+    if (count > 1) chain_bwd_loop<2>(j1);
+    if (count > 2) chain_bwd_loop<2>(j2);
+    if (count > 3) chain_bwd_loop<2>(j3);
 }
 
 #ifdef PR_CHAIN_TIMING
@@ -731,18 +795,14 @@ int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int co
         }
         if (max_tiles <= 0) continue;
         int cus = 0;
-        const bool split = g[0].split != 0;
-        for (int j = 1; j < n; ++j) PR_REQUIRE((g[j].split != 0) == split, "backward chain: jobs of one launch differ in precision");
-        PR_TRY(prepare_kernel(split ? reinterpret_cast<const void*>(k_chain_bwd_group_bf16) : reinterpret_cast<const void*>(k_chain_bwd_group),
-                              (int)sizeof(BSmem), &cus));
+        const int split = g[0].split;
+        for (int j = 1; j < n; ++j) PR_REQUIRE(g[j].split == split, "backward chain: jobs of one launch differ in precision");
+        auto* const kernel = split == 2 ? k_chain_bwd_group_f16 : (split == 1 ? k_chain_bwd_group_bf16 : k_chain_bwd_group);
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(kernel), (int)sizeof(BSmem), &cus));
         const long resident = (long)cus * MLP_BLOCKS_PER_CU;
         ProfileScope scope(2, s);
-        if (split)
-            hipLaunchKernelGGL(k_chain_bwd_group_bf16, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS),
-                               sizeof(BSmem), s, g[0], g[1], g[2], g[3], n);
-        else
-            hipLaunchKernelGGL(k_chain_bwd_group, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
-                               g[0], g[1], g[2], g[3], n);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS), sizeof(BSmem), s,
+                           g[0], g[1], g[2], g[3], n);
         PR_LAUNCH_CHECK();
     }
     return PR_OK;
