@@ -1144,10 +1144,11 @@ def main():
         result["train_step"]["f16x3"] = {
             "ms_per_step": split_train["ms_per_step"], "ms_per_step_median": split_train["ms_per_step_median"], "value": split_train["value"],
             "unit": split_train["unit"], "kernel_ms_per_step": split_train["roofline"]["kernel_ms_per_step"],
-            "note": "ObjectComposer.precision='f16x3' on a training call (PR_FLAG_SPLIT_BACKWARD): the backward pass's big products on bf16 "
-                    "triples (x = b1 + b2 + b3, round to nearest, six v_mfma_f32_32x32x16_bf16 per product: k_chain_bwd_group_bf16, "
-                    "k_gemm_tn_all_bf16), phase 1 of the forward on fp16 pairs (x = hi + lo, three fp16 MFMAs, weights packed as w x 2^4: "
-                    "k_mlp_mfma_train_group_split), fp32 accumulation everywhere; the head phases stay fp32.  Same gradient tests as fp32 "
+            "note": "ObjectComposer.precision='f16x3' on a training call (PR_FLAG_SPLIT_BACKWARD): phase 1 of the forward and the backward "
+                    "chains on fp16 pairs (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product, weights packed as w x 2^4, gradient tiles "
+                    "scaled by a power of two per tile: k_mlp_mfma_train_group_split, k_chain_bwd_group_f16), the weight gradients on bf16 "
+                    "triples (x = b1 + b2 + b3, six bf16 MFMAs per product: k_gemm_tn_all_bf16), fp32 accumulation everywhere; the head "
+                    "phases stay fp32.  Same gradient tests as fp32 "
                     "(reference fixtures at 1e-4, oracle autograd, float64 arbitration at shipped sizes)"}
         if world == 1:      # (a comparison leg: not repeated on every GPU count of a scaling run)
             separate = train_step_leg(args, dev, world, rank, dist, lib, arena=False)
