@@ -24,7 +24,8 @@ struct BSmem {
     float ws[MAX_WIDTH];                            // sigma head weights / rows 0..2: bender output head (3 x BWpad <= 3 x 128 ... see use)
     float gsr[TILE_M];                              // d loss / d sigma of the tile rows
     int flat[TILE_M], frame[TILE_M], flags[TILE_M];
-    int uniform_frame, next_tile, pad_[2];
+    int uniform_frame, next_tile;
+    int tile_max[2];                                // fp16-pair chains: bit patterns of the largest |entry| of the tile in X (two alternating words)
 };
 static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
 static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0, "16-byte LDS accesses");
@@ -614,16 +615,16 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         // fp16-pair products (SPLIT == 2): the largest |entry| of the tile in X, in one of two LDS words - `cur` names the word of the
         // tile the next product reads, its producer wrote into it, the other word is cleared while that product runs
         int cur = 0;
-        if (SPLIT == 2 && tid == 0) S.pad_[0] = S.pad_[1] = 0;
+        if (SPLIT == 2 && tid == 0) S.tile_max[0] = S.tile_max[1] = 0;
         __syncthreads();
         f32x16 a00, a01, a10, a11;
         // the product of the tile in X with one segment, at the tile's scale
         auto scaled_product = [&](const Seg& sg, int out_blk, const Drain* drain) {
             float scale = 1.0f;
             if (SPLIT == 2) {
-                const int k = tile_scale_log2(S.pad_[cur]);
+                const int k = tile_scale_log2(S.tile_max[cur]);
                 scale = ldexpf(1.0f, k);
-                if (tid == 0) S.pad_[cur ^ 1] = 0;      // (its next writers are behind this product's barrier)
+                if (tid == 0) S.tile_max[cur ^ 1] = 0;      // (its next writers are behind this product's barrier)
                 tile_products_any<SPLIT>(sg, out_blk, S.X, a00, a01, a10, a11, drain, scale);
                 const float back = ldexpf(1.0f, -k - TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
 #pragma unroll
@@ -648,7 +649,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                 S.gsr[tid] = gs;
                 if (tid < rows_valid && c.gsr4) *reinterpret_cast<float4*>(c.gsr4 + (size_t)(tile_base + tid) * 4) = make_float4(gs, 0.f, 0.f, 0.f);
             }
-            load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid, SPLIT == 2 ? &S.pad_[0] : nullptr);
+            load_bn_backward(S, c.d1, c.h1, c.Wpad, tile_base, rows_valid, SPLIT == 2 ? &S.tile_max[0] : nullptr);
             __syncthreads();
             PR_CT(0);
             zero4(a00, a01, a10, a11);
@@ -668,7 +669,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                     hi[i] = fmaf(S.gsr[PR_ROWS_OF(i, half, 1)], w, hi[i]);
                 }
             }
-            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.pad_[1] : nullptr);
+            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.tile_max[1] : nullptr);
             cur = 1;
         } else {
             // ray bender: G = (g_raw . W_out) masked by the last layer's ReLU; one thread per column, the rows' raw gradients via LDS
@@ -689,7 +690,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
                     S.X[row * LDX + col] = v;
                     biggest = fmaxf(biggest, fabsf(v));
                 }
-                if (SPLIT == 2) atomicMax(reinterpret_cast<unsigned int*>(&S.pad_[0]), __float_as_uint(biggest));
+                if (SPLIT == 2) atomicMax(reinterpret_cast<unsigned int*>(&S.tile_max[0]), __float_as_uint(biggest));
             }
         }
         PR_CT(3);
@@ -726,7 +727,7 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
             PR_CT(1);
             __syncthreads();
             PR_CT(2);
-            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.pad_[cur ^ 1] : nullptr);
+            store_masked(S, nblk, masks, a00, a01, a10, a11, SPLIT == 2 ? &S.tile_max[cur ^ 1] : nullptr);
             cur ^= 1;
             PR_CT(3);
             __syncthreads();
