@@ -1145,7 +1145,7 @@ def main():
             "ms_per_step": split_train["ms_per_step"], "ms_per_step_median": split_train["ms_per_step_median"], "value": split_train["value"],
             "unit": split_train["unit"], "kernel_ms_per_step": split_train["roofline"]["kernel_ms_per_step"],
             "note": "ObjectComposer.precision='f16x3' on a training call (PR_FLAG_SPLIT_BACKWARD): phase 1 of the forward and the backward "
-                    "chains on fp16 pairs (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product, weights packed as w x 2^4, gradient tiles "
+                    "chains on fp16 pairs (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product, weights packed as w x 2^8, activation and gradient tiles "
                     "scaled by a power of two per tile: k_mlp_mfma_train_group_split, k_chain_bwd_group_f16), the weight gradients on bf16 "
                     "triples (x = b1 + b2 + b3, six bf16 MFMAs per product: k_gemm_tn_all_bf16), fp32 accumulation everywhere; the head "
                     "phases stay fp32.  Same gradient tests as fp32 "

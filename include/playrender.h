@@ -85,7 +85,7 @@ typedef enum pr_status {
                                        gradients with every fp32 operand as three bf16 terms (exactly: 8 + 8 + 8 mantissa bits, fp32
                                        exponent range; the six bf16 MFMAs whose terms are >= 2^-16 of a product), the backward chains
                                        with fp16 pairs (x = hi + lo, three fp16 MFMAs) of the gradient tile times a power of two chosen
-                                       per 64-row tile and of the weights times 2^4 (all scalings exact).  On the forward call the flag
+                                       per 64-row tile and of the weights times 2^8 (all scalings exact).  On the forward call the flag
                                        selects fp16-pair products for phase 1 of a train-mode forward pass too.  The call
                                        stays PR_PRECISION_FP32 (fp32-packed weights, which carry both split forms as well).  Products
                                        that have no split kernel run the exact fp32 one. */

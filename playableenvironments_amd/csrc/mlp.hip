@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 if (n < j.n_real && k < j.k_real)
                     w = ldexpf(j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k],
                                j.scale_log2);
+                w = fminf(fmaxf(w, -65504.0f), 65504.0f);      // (a scaled weight beyond fp16's range saturates instead of turning into inf)
                 const _Float16 hi = (_Float16)w;
                 const _Float16 lo = (_Float16)(w - (float)hi);
                 const _Float16 sel = part ? lo : hi;
@@ -297,7 +298,7 @@ static int add_seg_t(PackJobs* js, const pr_linear_t& lin, int col_off, int k_re
     return PR_OK;
 }
 
-// the same W^T segment for the split-precision backward chains: fp16 (hi, lo) pairs of w x 2^4 (kind 2; the chains scale their
+// the same W^T segment for the split-precision backward chains: fp16 (hi, lo) pairs of w x 2^8 (kind 2; the chains scale their
 // gradient tiles into fp16's range, train_bwd.hip) - or bf16 triples (kind 3, -DPR_CHAIN_BF16: 1.5 x the bytes, six MFMAs per product)
 static int add_seg_t3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_real, int kpad, int n_real, int npad, float* dst) {
     PR_TRY(add_seg_t(js, lin, col_off, k_real, kpad, n_real, npad, dst));
@@ -317,9 +318,9 @@ static int add_seg3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_rea
     PR_TRY(add_seg(js, lin, col_off, k_real, kpad, npad, dst));
     js->job[js->n - 1].kind = 2;
     // weights of 0.01 - 0.1 have their lo half in fp16's subnormal range (relative error 2^-25 / |w|: harmless for a rendered value,
-    // 10 x fp32's on the density head's bias gradient, which sums over every sample - measured); scaled by 2^4 the lo halves of
-    // |w| > 0.016 are normal numbers and |w| < 4094 stays in range.  The kernel starts its accumulators at bias x 2^4 and multiplies
-    // them by 2^-4 behind the K loops - both exact.
+    // 10 x fp32's on the density head's bias gradient, which sums over every sample - measured); scaled by 2^8 the lo halves of
+    // |w| > 0.001 are normal numbers and |w| < 255 stays in range (beyond, k_pack saturates).  The kernel starts its accumulators
+    // at bias x 2^8 (x the operand tile's scale) and divides both out behind the K loops - exact.
     js->job[js->n - 1].scale_log2 = TRAIN_SPLIT_WEIGHT_SCALE_LOG2;
     return PR_OK;
 }
@@ -748,6 +749,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         if (dynamic_tiles && tid == 0) claimed = atomicAdd(p.tile_counter, 1);      // measurement build: round 3's claim at the top of the tile
 #endif
         if (tid == 0) S.uniform_frame = 1;
+        if (SPLIT && tid == 0) S.tile_max[0] = S.tile_max[1] = 0;
         // ---- load the sample records of the tile --------------------------------------------
         if (tid < TILE_M) {
             const int idx = tile_base + tid;
@@ -783,15 +785,18 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
         PR_PHASE(0);
 
         // ---- ray bender -----------------------------------------------------------------------
+        // (split-precision training forward: `cur` names the tile_max word of the tile in X, see commit_tile_max in mlp_tile.h; both
+        // words were cleared in front of the tile's first barrier)
+        int cur = p.has_bender ? 0 : 1;
         if (p.has_bender) {
-            fill_bender_input(S, p, enc, false);
+            fill_bender_input(S, p, enc, false, SPLIT ? &S.tile_max[0] : nullptr);
             __syncthreads();
             if (TRAIN && p.save_bin) write_tile_rows(S, p.save_bin, p.bin_pad, p.bin_pad, tile_base, false);
             for (int l = 0; l < p.b_count; ++l) {
                 if (TRAIN) {
                     run_layer<false, true, false, SPLIT>(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc, nullptr,
                                            p.save_bbits ? reinterpret_cast<unsigned long long*>(p.save_bbits + (size_t)l * p.save_bbits_stride) +
-                                                              (size_t)tile * p.BWpad : nullptr);
+                                                              (size_t)tile * p.BWpad : nullptr, nullptr, &cur);
                 } else {
                     run_layer(p.b_layers[l], S, p, tile_base, /*input_kind=*/1, enc);
                 }
@@ -799,6 +804,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
                 // barrier in front of its epilogue: no barrier needed behind the copy)
                 if (TRAIN && p.save_bact) write_tile_rows(S, p.save_bact + (size_t)l * p.save_bact_stride, p.BWpad, p.BWpad, tile_base, false);
             }
+            if (SPLIT && tid == 0) S.tile_max[cur ^ 1] = 0;     // the NeRF input's word (its last reader was the last layer's product)
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
             for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
                 float out[3];
@@ -834,7 +840,8 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
 
         PR_PHASE(1);
         // ---- positional encoding of the NeRF input --------------------------------------------
-        fill_nerf_input(S, p, enc, false);
+        fill_nerf_input(S, p, enc, false, SPLIT ? &S.tile_max[cur ^ 1] : nullptr);
+        cur ^= 1;
         __syncthreads();
         PR_PHASE(2);
         if (TRAIN && p.save_enc) write_tile_rows(S, p.save_enc, p.enc_pad, p.enc_pad, tile_base, false);
@@ -845,7 +852,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
                 run_layer<false, true, false, SPLIT>(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc, nullptr,
                                        (p.save_bits && !(PR_TRAINFWD_ABLATE & 2))
                                            ? reinterpret_cast<unsigned long long*>(p.save_bits + (size_t)l * p.save_bits_stride) + (size_t)tile * p.Wpad
-                                           : nullptr);
+                                           : nullptr, nullptr, &cur);
             } else {
                 run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
             }
@@ -896,7 +903,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             // their per-channel sums feed the batch statistics
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
-            run_layer<false, false, true, SPLIT>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats);
+            run_layer<false, false, true, SPLIT>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats, &cur);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             count_stat_rows(S, p);

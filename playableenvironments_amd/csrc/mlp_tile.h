@@ -18,7 +18,7 @@ constexpr int HEAD_BENDER = 0;              // the 3-row bender head is read fro
 struct Smem {
     int uniform_frame;       // every row of the tile belongs to the same frame
     int next_tile;           // the tile this workgroup claimed for its next iteration (dynamic tile order)
-    int pad_[2];
+    int tile_max[2];         // split-precision training forward: bit patterns of the largest |entry| of the tile in X (two alternating words)
     float head_w[HEAD_SIGMA + HEAD_BENDER];
     float X[TILE_M * LDX];   // activations; columns [0, K) also hold a layer's input encoding while it is needed
     float pos[TILE_M * 8];   // object-frame position (3) / skybox input (6)
@@ -114,8 +114,8 @@ __device__ unsigned long long g_mlp_phase[16];
 #endif
 
 struct EncRegs;
-__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
-__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay);
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay, int* max_slot = nullptr);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay, int* max_slot = nullptr);
 
 // One layer on the tile.  All threads of the workgroup call it (workgroup barriers inside).
 //
@@ -138,12 +138,13 @@ __device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, E
 // STATS (training forward, the raw head layers): the plain-store epilogue also adds the layer's per-column sum and sum of squares
 // over the tile's rows that enter the batch statistics to the lane's running sums (`stats`), straight from the accumulators
 struct ColumnStats { double s1[2], s2[2]; };      // this lane's columns of the blocks `wave` / `wave + 4`
-// SPLIT (training forward with PR_FLAG_SPLIT_BACKWARD): the segments are bf16-triple packings, the products run on six bf16
-// MFMAs per 16 K-values (tile_products_bf16) - same accumulator layout, so every epilogue is unchanged
+// SPLIT (training forward with PR_FLAG_SPLIT_BACKWARD): the segments are fp16-pair packings of w x 2^8, the products run on three
+// fp16 MFMAs per 16 K-values on the operand tile x a per-tile power of two (tile_products_f16x3_lean; *cur_slot names the tile's
+// tile_max word and is moved on to the word of the tile this layer writes) - same accumulator layout, so every epilogue is unchanged
 template <bool BWD = false, bool BITS = false, bool STATS = false, bool SPLIT = false>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
                                           const BwdEpilogue* bwd = nullptr, unsigned long long* bits_out = nullptr,
-                                          ColumnStats* stats = nullptr);
+                                          ColumnStats* stats = nullptr, int* cur_slot = nullptr);
 
 // Positional encoding of every tile row into columns [0, pad) of X (model/positional_encoder.py:54-64):
 //   [v, sin(2^0 v), cos(2^0 v), sin(2^1 v), ...], each block `din` wide; columns [zero_from, pad) are zeroed.
@@ -158,6 +159,24 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
 constexpr int ENC_ROWS = TILE_M / (MLP_THREADS / 8);
 constexpr int ENC_SLOTS = (PR_MAX_OCTAVES + 7) / 8;
 constexpr int ENC_DIMS = 3;        // positions; the 6-dimensional skybox input is simply evaluated twice
+// Largest |entry| of a tile a producer writes into X, for the fp16-pair products of the split-precision training kernels: every
+// thread folds what it writes into a running maximum and commits it to one of two LDS words (wave reduction, one atomicMax per
+// wave; non-negative floats order like their bit patterns).  The product that reads the tile turns the word into a power of two
+// that puts the tile's largest entry just under 2^15 - without it, operands below 0.25 have their lo half in fp16's subnormal range
+// (absolute floor 2^-25), which a train-mode BatchNorm over small activations amplifies into 1e-3 gradient errors (randomized
+// backward sweep, seed 7 case 18: the skybox model).  A product clears the word it does NOT read; the next producer writes that one.
+__device__ __forceinline__ void commit_tile_max(float m, int* slot) {
+    if (slot == nullptr) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
+}
+// scale = 2^k with max x 2^k in [2^14, 2^15); k = 0 for an all-zero (or non-finite) tile
+__device__ __forceinline__ int tile_scale_log2(int bits) {
+    const int e = ((bits >> 23) & 255);
+    return (e == 0 || e == 255) ? 0 : 14 - (e - 127);
+}
+
 struct EncRegs {
     float raw[ENC_ROWS][ENC_DIMS];
     float sc[ENC_ROWS][ENC_SLOTS][2 * ENC_DIMS];
@@ -165,7 +184,7 @@ struct EncRegs {
 static_assert(ENC_ROWS == 2, "fill_encoding keeps two rows per thread");
 
 __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int din, int octaves, int zero_from, int pad,
-                                              const float* octave_weights, bool normalise, EncRegs& regs, bool replay) {
+                                              const float* octave_weights, bool normalise, EncRegs& regs, bool replay, float& biggest) {
     const int part = threadIdx.x & 7;
     if (din != ENC_DIMS) {
         for (int s = threadIdx.x >> 3; s < TILE_M; s += MLP_THREADS / 8) {
@@ -176,7 +195,10 @@ __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int d
             }
             float* row = S.X + s * LDX;
             if (part == 0)
-                for (int a = 0; a < din; ++a) row[a] = v[a];
+                for (int a = 0; a < din; ++a) {
+                    row[a] = v[a];
+                    biggest = fmaxf(biggest, fabsf(v[a]));
+                }
             if (part == 1)
                 for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
             for (int k = part; k < octaves; k += 8) {
@@ -192,6 +214,7 @@ __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int d
                     }
                     dst[a] = sn;
                     dst[din + a] = cs;
+                    biggest = fmaxf(biggest, fmaxf(fabsf(sn), fabsf(cs)));
                 }
             }
         }
@@ -210,7 +233,10 @@ __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int d
         }
         if (part == 0) {
 #pragma unroll
-            for (int a = 0; a < ENC_DIMS; ++a) row[a] = regs.raw[j][a];
+            for (int a = 0; a < ENC_DIMS; ++a) {
+                row[a] = regs.raw[j][a];
+                biggest = fmaxf(biggest, fabsf(regs.raw[j][a]));
+            }
         }
         if (part == 1)
             for (int q = zero_from; q < pad; ++q) row[q] = 0.f;
@@ -235,24 +261,34 @@ __device__ __forceinline__ void fill_encoding(Smem& S, const MlpParams& p, int d
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < 2 * ENC_DIMS; ++a) dst[a] = regs.sc[j][slot][a];
+                for (int a = 0; a < 2 * ENC_DIMS; ++a) {
+                    dst[a] = regs.sc[j][slot][a];
+                    biggest = fmaxf(biggest, fabsf(regs.sc[j][slot][a]));
+                }
             }
         }
     }
 }
 
 // input of the NeRF: PE of the (bent, normalised) position / of the skybox's [o / size, d / |d|]
-__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
-    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0, regs, replay);
+// (max_slot: see commit_tile_max - the split-precision training forward only)
+__device__ __forceinline__ void fill_nerf_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay, int* max_slot) {
+    float biggest = 0.f;
+    fill_encoding(S, p, p.din, p.octaves, p.enc, p.enc_pad, nullptr, p.kind == 0, regs, replay, biggest);
+    commit_tile_max(biggest, max_slot);
 }
 
 // input of the ray bender: [annealed PE(x / size) | deformation code of the sample's frame], zero padded
-__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay) {
-    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true, regs, replay);
+__device__ __forceinline__ void fill_bender_input(Smem& S, const MlpParams& p, EncRegs& regs, bool replay, int* max_slot) {
+    float biggest = 0.f;
+    fill_encoding(S, p, /*din=*/3, p.b_octaves, p.benc + p.D, p.bin_pad, p.b_weights, /*normalise=*/true, regs, replay, biggest);
     for (int idx = threadIdx.x; idx < TILE_M * p.D; idx += MLP_THREADS) {
         const int s = idx / p.D, j = idx - s * p.D;
-        S.X[s * LDX + p.benc + j] = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
+        const float v = p.deformation[(size_t)S.frame[s] * p.deformation_stride + j];
+        S.X[s * LDX + p.benc + j] = v;
+        biggest = fmaxf(biggest, fabsf(v));
     }
+    commit_tile_max(biggest, max_slot);
 }
 
 // ``drain`` (backward chain): the operand tile in X is also WRITTEN OUT to global memory while a product runs - one 16-byte chunk
@@ -414,9 +450,9 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 #ifndef PR_TRAIN_SPLIT_SCALE
-#define PR_TRAIN_SPLIT_SCALE 4
+#define PR_TRAIN_SPLIT_SCALE 8
 #endif
-constexpr int TRAIN_SPLIT_WEIGHT_SCALE_LOG2 = PR_TRAIN_SPLIT_SCALE;    // the packed fp16 pairs hold w x 2^4 (add_seg3 in mlp.hip)
+constexpr int TRAIN_SPLIT_WEIGHT_SCALE_LOG2 = PR_TRAIN_SPLIT_SCALE;    // the packed fp16 pairs hold w x 2^8 (add_seg3 in mlp.hip)
 #define PR_MFMA_F16(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
 struct FragH { f16x8_t hi, lo; };
 __device__ __forceinline__ void split_pair_h(float x0, float x1, unsigned int& ph, unsigned int& pl) {
@@ -451,8 +487,9 @@ __device__ __forceinline__ FragH split_fragment_h(const float4& lo, const float4
         if (two) { PR_MFMA_F16(a10, F0.hi, WBH); PR_MFMA_F16(a11, F1.hi, WBH); }                                            \
     } while (0)
 
+__device__ __forceinline__ FragH split_fragment_scaled_h(const float4& lo, const float4& hi, float scale);
 __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                                         f32x16& a11) {
+                                                         f32x16& a11, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int cbA = wave, cbB = wave + MLP_WAVES;
@@ -470,7 +507,7 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
     f16x8_t oah, oal, obh = ebh, obl = ebl;
     for (int s = 0; s < ks; s += 2) {
         {
-            const FragH f0 = split_fragment_h(xl, xh), f1 = split_fragment_h(yl, yh);
+            const FragH f0 = split_fragment_scaled_h(xl, xh, scale), f1 = split_fragment_scaled_h(yl, yh, scale);
             const float* an = ap + 16 * (s + 1);
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
@@ -482,7 +519,7 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
             __builtin_amdgcn_sched_barrier(0);
         }
         {
-            const FragH f0 = split_fragment_h(xl, xh), f1 = split_fragment_h(yl, yh);
+            const FragH f0 = split_fragment_scaled_h(xl, xh, scale), f1 = split_fragment_scaled_h(yl, yh, scale);
             const int sn = (s + 2 < ks) ? s + 2 : s;
             const float* an = ap + 16 * sn;
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
@@ -558,10 +595,13 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
 
 template <bool BWD, bool BITS, bool STATS, bool SPLIT>
 __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpParams& p, int tile_base, int input_kind, EncRegs& enc,
-                                          const BwdEpilogue* bwd, unsigned long long* bits_out, ColumnStats* stats) {
+                                          const BwdEpilogue* bwd, unsigned long long* bits_out, ColumnStats* stats, int* cur_slot) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int nblk = L.nblk;
+    // SPLIT: `slot` names the tile_max word of the tile this layer reads, `k` its scale exponent (commit_tile_max)
+    int slot = SPLIT ? *cur_slot : 0;
+    int k = SPLIT ? tile_scale_log2(S.tile_max[slot]) : 0;
     const int cbA = wave, cbB = wave + MLP_WAVES;
     const bool active = cbA < nblk;      // this wave has a first column block
     const bool two = cbB < nblk;         // ... and a second one
@@ -570,9 +610,9 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     {
         float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
         float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
-        if (SPLIT) {        // the split-precision segments hold w x 2^4: the accumulators run at that scale
-            biasA = ldexpf(biasA, TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
-            biasB = ldexpf(biasB, TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+        if (SPLIT) {        // the split-precision segments hold w x 2^8, the operand is multiplied by 2^k: the accumulators run at that scale
+            biasA = ldexpf(biasA, k + TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+            biasB = ldexpf(biasB, k + TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -588,15 +628,30 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             // second K segment of a skip layer: its operand is the network input, re-encoded over the
             // (now dead) activations of the first segment
             __syncthreads();
-            if (input_kind == 1) fill_bender_input(S, p, enc, true); else fill_nerf_input(S, p, enc, true);
+            int* refill_slot = SPLIT ? &S.tile_max[slot ^ 1] : nullptr;      // (cleared by the first segment's product)
+            if (input_kind == 1) fill_bender_input(S, p, enc, true, refill_slot); else fill_nerf_input(S, p, enc, true, refill_slot);
             __syncthreads();
+            if (SPLIT) {         // the re-encoded input has its own scale: bring the accumulators over
+                slot ^= 1;
+                const int k1 = tile_scale_log2(S.tile_max[slot]);
+                const float shift = ldexpf(1.0f, k1 - k);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    a00[i] *= shift;
+                    a01[i] *= shift;
+                    a10[i] *= shift;
+                    a11[i] *= shift;
+                }
+                k = k1;
+            }
         }
+        if (SPLIT && threadIdx.x == 0) S.tile_max[slot ^ 1] = 0;       // the next producer's word (nobody reads it any more)
         if (!active) continue;
 #if defined(PR_MLP_ABLATE) && (PR_MLP_ABLATE & 128)
         continue;   // measurement build: no matrix work (results are wrong)
 #endif
         if (SPLIT) {             // phase 1 of a training call with PR_FLAG_SPLIT_BACKWARD: fp16 pairs
-            tile_products_f16x3_lean(sg, nblk, S.X, a00, a01, a10, a11);
+            tile_products_f16x3_lean(sg, nblk, S.X, a00, a01, a10, a11, ldexpf(1.0f, k));
             continue;
         }
         // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
@@ -663,7 +718,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         __builtin_amdgcn_s_setprio(0);
     }
     if (SPLIT) {
-        const float back = 1.0f / (float)(1 << TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
+        *cur_slot = slot ^ 1;        // (the word the epilogue below commits this layer's output tile to)
+        const float back = ldexpf(1.0f, -k - TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             a00[i] *= back;
@@ -753,6 +809,12 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             if (L.epi == EPI_RELU) {
                 store_relu(lo, x0);
                 store_relu(hi, x0 + 32 * LDX);
+                if (SPLIT) {        // the next layer's operand tile: its largest entry
+                    float biggest = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) biggest = fmaxf(biggest, fmaxf(lo[i], hi[i]));
+                    commit_tile_max(fmaxf(biggest, 0.f), &S.tile_max[slot ^ 1]);
+                }
                 if (BITS && bits_out) {
                     // this lane holds column `col` for the rows PR_ACC_ROW(i) + 4 half (+ 32): its half of the column's word, the
                     // other half sits in lane ^ 32

@@ -148,20 +148,7 @@ __device__ __forceinline__ void tile_products_any(const Seg& sg, int nblk, const
     else tile_products(sg, nblk, X, a00, a01, a10, a11, drain);
 }
 
-// Largest |entry| of the tile a producer writes into X, for the fp16-pair products (MODE 2): every thread folds what it writes into
-// a running maximum and commits it to one of two LDS words (non-negative floats order like their bit patterns); the products that
-// read the tile turn the word into a power-of-two scale.  `slot` == nullptr: nothing is tracked (the other modes).
-__device__ __forceinline__ void commit_tile_max(float m, int* slot) {
-    if (slot == nullptr) return;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
-}
-// scale = 2^k with max x 2^k in [2^14, 2^15); k = 0 for an all-zero (or non-finite) tile
-__device__ __forceinline__ int tile_scale_log2(int bits) {
-    const int e = ((bits >> 23) & 255);
-    return (e == 0 || e == 255) ? 0 : 14 - (e - 127);
-}
+// (commit_tile_max / tile_scale_log2: mlp_tile.h - every producer of a gradient tile folds what it writes into one of two LDS words)
 
 // rows of X -> rows of a (cap, ld) array, 16-byte stores; only the tile's real rows
 __device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int width_pad, int ld, int tile_base, int rows_valid) {

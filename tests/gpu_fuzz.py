@@ -130,7 +130,13 @@ def divergence_kink_margin(cfg, scene, n, bias, perturb, absent, noise_seed=123)
 
 
 def backward_sweep(cases, rng, only=None):
-    from tests.test_gpu import GRAD_KEYS, ForwardFieldMismatch, _gradients
+    from tests.test_gpu import GRAD_KEYS, ForwardFieldMismatch, _gradients as _gradients_fp32
+    # PR_FUZZ_PRECISION=f16x3: the same sweep with the split-precision training kernels (fp16-pair forward phase and backward chains,
+    # bf16-triple weight gradients) against the same oracle, tolerances and classifications
+    precision = os.environ.get("PR_FUZZ_PRECISION", "fp32")
+
+    def _gradients(*a, **kw):
+        return _gradients_fp32(*a, precision=precision, **kw)
     failures = 0
     for i in range(cases):
         world = rng.choice(["tennis", "minecraft"])
@@ -196,6 +202,17 @@ def backward_sweep(cases, rng, only=None):
                 else:
                     failures += 1
                     print(f"MISMATCH (worst {worst:.1e}, oracle self-sensitivity {own:.1e})", label, dict(list(bad.items())[:4]))
+                    # where the excess sits: a flipped ReLU decision of ONE hidden unit shows as one row of its layer's weight
+                    # gradient (and one entry of its bias gradient) carrying the error
+                    for k in list(bad)[:8]:
+                        a, b = grads[k]
+                        e = (a - b.cpu() if b.is_cuda else a - b).double()
+                        if e.dim() == 2:
+                            rows = (e ** 2).sum(1)
+                            print(f"    {k}: row {int(rows.argmax())} holds {float(rows.max() / rows.sum()):.3f} of the squared error "
+                                  f"({e.shape[0]} rows)")
+                        elif e.dim() == 1:
+                            print(f"    {k}: entry {int(e.abs().argmax())} holds {float((e ** 2).max() / (e ** 2).sum()):.3f} of the squared error")
             else:
                 print("ok", label[:170])
         except ValueError as e:       # train-mode BatchNorm on exactly one sample: the reference raises too
