@@ -2859,11 +2859,14 @@ def test_generated_noise_is_independent_of_ray_chunking():
 SWEEP_OK_FLOOR_FORWARD, SWEEP_OK_FLOOR_BACKWARD = 30, 14      # recorded on the GPU box: see test_randomized_sweep_slice
 
 
-@pytest.mark.parametrize("sweep,cases", [("forward", 40), ("backward", 20)])
-def test_randomized_sweep_slice(sweep, cases, capsys):
+@pytest.mark.parametrize("sweep,cases", [("forward", 40), ("backward", 20), ("backward_f16x3", 20)])
+def test_randomized_sweep_slice(sweep, cases, capsys, monkeypatch):
     import random
     from tests import gpu_fuzz
     run = gpu_fuzz.forward_sweep if sweep == "forward" else gpu_fuzz.backward_sweep
+    if sweep == "backward_f16x3":        # the same backward slice on the split-precision training kernels (precision="f16x3")
+        monkeypatch.setenv("PR_FUZZ_PRECISION", "f16x3")
+        sweep = "backward"
     failures = run(cases, random.Random(0))
     report = capsys.readouterr().out
     assert failures == 0, report[-4000:]
