@@ -27,6 +27,7 @@ frame on this box's host cores with 1 / 16 / all threads.
 """
 import argparse
 import ctypes as C
+import contextlib
 import json
 import os
 import socket
@@ -235,6 +236,24 @@ def max_over_ranks(value, dist, dev):
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    """File descriptor 1 -> stderr for the duration of the block (C-level writers included), C stdio flushed on the way out."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def train_traffic():
@@ -864,10 +883,20 @@ def main():
         os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # the communication libraries announce themselves on the process's STDOUT from C (RCCL: a version / host banner when the
+        # first communicator is created; gloo: one "connected to N peer ranks" line per rank) - through C stdio, i.e. flushed when
+        # the process exits, behind the JSON line.  Stdout has to stay that one line: the file descriptor points at stderr while the
+        # group and its first communicator are created, and C's buffers are flushed before it is restored.
+        with _c_stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            probe = torch.zeros(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
 
     from playableenvironments_amd import configs, synthetic, _lib
     from playableenvironments_amd.environment_model import EnvironmentModel
