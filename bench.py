@@ -45,6 +45,114 @@ SCENE_KEYS = ("camera_rotations", "camera_translations", "focals", "object_rotat
               "object_translation_parameters", "object_style", "object_deformation", "object_in_scene")
 
 
+LINE_BUDGET = 4096      # bytes of the ONE stdout line (r04's 22.6 KB line was not parsed by the driver; everything else -> bench_full.json)
+
+
+def _dig(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def compact_result(result: dict, full_path=None) -> dict:
+    """The driver's line: the contract keys, `roofline` and `cpu_baseline` of the headline, and a flat handful of scalar summaries
+    of the secondary legs.  Every note, per-run list and per-shard table stays in the full record (`full`)."""
+    r = result
+    roof = dict(r.get("roofline") or {})
+    line = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
+                                  "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfgw = dict(r.get("config") or {})
+    line["config"] = cfgw
+    line["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from_this_library",
+                                                   "peak_measured", "flop_per_step", "flop_per_step_algorithmic", "algorithmic_tflops",
+                                                   "mlp_ms_per_step", "mlp_launches_per_step", "composite_ms_per_step") if k in roof}
+    if isinstance(line["roofline"].get("kernel"), str):
+        line["roofline"]["kernel"] = line["roofline"]["kernel"].split(" ")[0]
+    cpu = r.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                "sample": f"{_dig(cpu, 'runs', default=[{}])[0].get('rays')} rays of the same frame, oracle in 1000-ray chunks, "
+                                          f"2 warm-ups + median of 5 ({_dig(cpu, 'runs', default=[{}])[0].get('seconds')} s each)",
+                                "cpu_model": cpu.get("cpu_model"), "host_cores": cpu.get("host_cores"), "usable_cores": cpu.get("usable_cores"),
+                                "full_size_value": _dig(cpu, "full_size", "value"), "gpu_over_cpu": cpu.get("gpu_over_cpu")}
+    dist = r.get("distributed") or {}
+    line["distributed"] = {k: dist[k] for k in ("world_size", "backend", "nccl_version", "rank_devices") if k in dist}
+    fg = r.get("feature_gather") or {}
+    if "all_gather" in fg:
+        line["feature_gather"] = {"bytes_per_rank": fg.get("bytes_per_rank"),
+                                  "all_gather_ms": _dig(fg, "all_gather", "ms"),
+                                  "all_gather_GB_per_s": _dig(fg, "all_gather", "receive_GB_per_s_per_receiving_rank"),
+                                  "gather_dst0_ms": _dig(fg, "gather_dst0", "ms"),
+                                  "gather_dst0_GB_per_s": _dig(fg, "gather_dst0", "receive_GB_per_s_per_receiving_rank")}
+    summary = {
+        "identical_frames_mrays": _dig(r, "identical_frames", "value"),
+        "split_precision_mrays": _dig(r, "split_precision", "value"),
+        "half_precision_mrays": _dig(r, "half_precision", "value"),
+        "train_step_ms": _dig(r, "train_step", "ms_per_step"),
+        "train_step_ms_median": _dig(r, "train_step", "ms_per_step_median"),
+        "train_step_frac": _dig(r, "train_step", "roofline", "frac"),
+        "train_step_f16x3_ms": _dig(r, "train_step", "f16x3", "ms_per_step"),
+        "train_step_f16x3_ms_median": _dig(r, "train_step", "f16x3", "ms_per_step_median"),
+        "train_step_with_decoder_ms": _dig(r, "train_step_with_decoder", "maps_route", "ms_per_step"),
+        "distinct_frames_shipped_mrays": _dig(r, "distinct_frames", "shipped_p72", "value"),
+        "distinct_frames_hierarchical_mrays": _dig(r, "distinct_frames", "hierarchical_64_128", "value"),
+        "native_frame_tennis_ms": _dig(r, "native_eval_frame", "tennis", "fp32", "scene_encoding_default", "ms_per_frame"),
+        "native_frame_tennis_f16x3_ms": _dig(r, "native_eval_frame", "tennis", "f16x3", "scene_encoding_default", "ms_per_frame"),
+        "native_frame_tennis_frac": _dig(r, "native_eval_frame", "tennis", "fp32", "roofline", "frac"),
+        "native_frame_minecraft_ms": _dig(r, "native_eval_frame", "minecraft", "fp32", "scene_encoding_default", "ms_per_frame"),
+        "native_frame_minecraft_frac": _dig(r, "native_eval_frame", "minecraft", "fp32", "roofline", "frac"),
+        "evaluator_default_call_tennis_ms": _dig(r, "native_eval_frame", "tennis", "fp32", "observations_default", "ms_per_frame"),
+        "evaluator_default_call_minecraft_ms": _dig(r, "native_eval_frame", "minecraft", "fp32", "observations_default", "ms_per_frame"),
+        "config0_frac": _dig(r, "config0_single_player_128", "roofline", "frac"),
+        "config2_minecraft_ms": _dig(r, "config2_minecraft_256", "fp32", "ms_per_frame"),
+        "config2_minecraft_frac": _dig(r, "config2_minecraft_256", "roofline", "frac"),
+        "reference_graph_fastest_mrays": _dig(r, "reference_graph_on_gpu", "value"),
+        "hip_over_reference_graph": _dig(r, "reference_graph_on_gpu", "hip_over_reference_graph"),
+        "psnr_db": _dig(r, "psnr_db", "fp32"),
+        "psnr_db_f16x3": _dig(r, "psnr_db", "f16x3"),
+    }
+    line["summary"] = {k: v for k, v in summary.items() if v is not None}
+    line["library_sha256"] = (r.get("library_sha256") or "")[:16]
+    line["full"] = full_path
+    return line
+
+
+def compact_line(result: dict, full_path=None, budget: int = LINE_BUDGET) -> str:
+    """json of compact_result, guaranteed < `budget` bytes: optional blocks are dropped (last first) rather than ever exceeding it."""
+    line = compact_result(result, full_path)
+    text = json.dumps(line, separators=(",", ":"))
+    for optional in ("summary", "feature_gather", "distributed"):
+        if len(text.encode()) < budget:
+            break
+        if optional == "distributed" and isinstance(line.get("distributed"), dict):
+            line["distributed"].pop("rank_devices", None)
+        else:
+            line.pop(optional, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text.encode()) < budget and "\n" not in text, len(text)
+    return text
+
+
+def emit(result: dict, full_path: str) -> None:
+    """Full record -> `full_path` (and gpurun_out/ when it exists, so that a gpurun call brings it home); compact line -> stdout, LAST."""
+    paths = [full_path]
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(scratch) and os.path.dirname(os.path.abspath(full_path)) != scratch:
+        paths.append(os.path.join(scratch, os.path.basename(full_path)))
+    written = None
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                json.dump(result, f, indent=1)
+            written = written or path
+        except OSError as e:
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    sys.stderr.flush()
+    print(compact_line(result, os.path.relpath(written, ROOT) if written else None), flush=True)
+
+
 def flops_per_sample(model_cfg: dict, head_only: bool = False) -> float:
     """Matmul FLOPs (2 per MAC) of one evaluated sample, SURVEY.md section 8d.  ``head_only``: the three feature-head
     products alone (what the sigma gate skips for a sample that cannot contribute)."""
@@ -841,10 +949,15 @@ def main():
     ap.add_argument("--no-gate", action="store_true", help="disable the sigma-gated feature head (measurement)")
     ap.add_argument("--cpu-rays", type=int, default=32, help="the 16-thread CPU baseline renders a cpu_rays x cpu_rays pixel grid "
                                                              "(2 warm-ups + median of 5)")
-    ap.add_argument("--no-cpu-full-size", action="store_true", help="skip the one full-size (every ray of the frame) CPU run (~200 s)")
+    ap.add_argument("--cpu-full-size", action="store_true",
+                    help="also run the CPU oracle ONCE on every ray of the frame (~190 s of host time; recorded at 0.000348 Mrays/s in "
+                         "profiles/r04_bench.json).  Off by default: the cpu_baseline sample is bounded so that the default run takes ~1.5 min")
+    ap.add_argument("--no-cpu-full-size", action="store_true", help=argparse.SUPPRESS)     # (accepted: the old default-on switch)
     ap.add_argument("--no-shard-balance", action="store_true", help="skip the virtual-shard balance measurement (N = 1 only)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the main CPU baseline run (all 256 host cores are >50x SLOWER on these small ops)")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"),
+                    help="where the FULL record (every leg, note and table) is written; stdout carries one compact line < 4 KB")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -1194,7 +1307,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, args.full_json)
     if multi:
         dist.destroy_process_group()
 
@@ -1267,7 +1380,7 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
         runs.append({"threads": threads, "rays": small * small, "seconds": round(t, 3), "protocol": "1 warm-up, 1 run",
                      "value": round(small * small / t / 1e6, 7), "unit": "Mrays/s"})
     full_size = None
-    if not args.no_cpu_full_size:
+    if args.cpu_full_size and not args.no_cpu_full_size:
         every = composer_inputs(cfg, scene, pixels=grid_pixels(size[0], size[1], size[0]))
         assert every[1].size(-2) == size[0] * size[1]
         t, _ = cpu_run(main_threads, every)

@@ -1077,3 +1077,48 @@ def test_scene_setup_rejects_bad_arguments_without_a_gpu():
     assert b"bad sizes" in lib.pr_last_error()
     q.objects, q.frames = 4, 0                                        # an empty call is a no-op
     assert lib.pr_scene_setup(C.byref(q), None) == 0
+
+
+def test_bench_line_is_compact_and_complete():
+    """The ONE stdout line of bench.py (what the driver parses into BENCH_rNN.json): built from a full record of every leg - round
+    4's committed 22.6 KB record, which the driver could not parse as a line - it must stay under bench.LINE_BUDGET bytes, be
+    json, and carry the contract keys with `roofline` and `cpu_baseline`; an 8-rank record (rank_devices, both collectives) too."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.LINE_BUDGET <= 4096
+    with open(os.path.join(root, "profiles", "r04_bench.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    # the widest case: 8 ranks, both collectives, the identical-frames secondary
+    wide = dict(full, n_gpus=8)
+    wide["distributed"] = {"world_size": 8, "backend": "nccl", "nccl_version": "2.26.6", "launched_by": "torch.distributed.run",
+                           "rank_devices": [f"rank {r}: cuda:{r} AMD Instinct MI355X" for r in range(8)]}
+    wide["feature_gather"] = {"world_size": 8, "bytes_per_rank": 50331648, "tensor": [1, 1, 1, 65536, 192],
+                              "all_gather": {"ms": 3.2, "receive_GB_per_s_per_receiving_rank": 110.1, "receiving_ranks": 8},
+                              "gather_dst0": {"ms": 3.0, "receive_GB_per_s_per_receiving_rank": 117.4, "receiving_ranks": 1}, "link_note": "x" * 300}
+    wide["identical_frames"] = {"value": 2.5, "unit": "Mrays/s", "ms_per_step": 207.0, "note": "y" * 200}
+    for record in (full, wide):
+        text = bench.compact_line(record, "bench_full.json")
+        assert len(text.encode()) < bench.LINE_BUDGET and "\n" not in text
+        line = json.loads(text)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "distributed", "summary", "full"):
+            assert key in line, key
+        assert line["value"] == record["value"] and line["ms_per_step"] == record["ms_per_step"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in line["roofline"], key
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in line["cpu_baseline"], key
+        assert line["summary"]["train_step_ms"] == record["train_step"]["ms_per_step"]
+    assert len(json.loads(bench.compact_line(wide))["distributed"]["rank_devices"]) == 8
+    assert json.loads(bench.compact_line(wide))["feature_gather"]["all_gather_GB_per_s"] == 110.1
+    # a record bloated beyond the budget still yields a parsable line (optional blocks go first, the contract keys never)
+    bloated = dict(wide)
+    bloated["config"] = dict(wide["config"], workload="w" * 1500)
+    bloated["distributed"] = dict(wide["distributed"], rank_devices=["d" * 300 for _ in range(8)])
+    text = bench.compact_line(bloated)
+    assert len(text.encode()) < bench.LINE_BUDGET and json.loads(text)["roofline"]["frac"] == full["roofline"]["frac"]

@@ -2358,24 +2358,44 @@ def test_render_sharded_ranks_on_one_gpu_gloo(world):
     assert all(results[r] for r in range(world)), dict(results)
 
 
-def test_bench_self_launches_two_ranks():
-    """`python bench.py --gpus 2` (no launcher): bench.py starts torch.distributed.run itself; with the PR_BENCH_DEVICE /
-    PR_BENCH_BACKEND knobs both ranks share this box's GPU over gloo.  One JSON line, n_gpus = 2, two per-rank times."""
+def _run_bench(argv, env, tmp_path):
+    """bench.py as the driver runs it: stdout must hold exactly ONE line, compact json under bench.LINE_BUDGET bytes with the contract
+    keys; returns (line, full record read back from --full-json)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full_path = os.path.join(str(tmp_path), "bench_full.json")
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv + ["--full-json", full_path], env=env,
+                          capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out_lines = [line for line in proc.stdout.splitlines() if line.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), proc.stdout[-2000:]      # nothing but the line on stdout
+    assert len(out_lines[0].encode()) < 4096, len(out_lines[0])
+    line = json.loads(out_lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "distributed", "full"):
+        assert key in line, key
+    assert line["roofline"]["bound"] == "mfma" and line["roofline"]["frac"] > 0 and "workload" in line["config"]
+    with open(full_path) as f:
+        full = json.load(f)
+    assert full["value"] == line["value"] and full["ms_per_step"] == line["ms_per_step"]
+    return line, full
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no launcher): bench.py starts torch.distributed.run itself; with the PR_BENCH_DEVICE /
+    PR_BENCH_BACKEND knobs both ranks share this box's GPU over gloo.  One compact JSON line, n_gpus = 2, two per-rank times."""
     env = dict(os.environ, PR_BENCH_DEVICE="0", PR_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--image", "64",
-                           "--no-cpu-baseline", "--no-split-precision"], env=env, capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, proc.stdout[-2000:]
-    result = json.loads(lines[0])
-    assert result["n_gpus"] == 2 and result["distributed"]["world_size"] == 2 and result["distributed"]["backend"] == "gloo"
-    assert result["value"] > 0 and result["steps"] == 2
+    line, result = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--image", "64", "--no-cpu-baseline", "--no-split-precision"],
+                              env, tmp_path)
+    assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and line["distributed"]["backend"] == "gloo"
+    assert len(line["distributed"]["rank_devices"]) == 2
+    assert line["value"] > 0 and line["steps"] == 2
+    assert line["feature_gather"]["all_gather_ms"] > 0 and line["feature_gather"]["gather_dst0_GB_per_s"] > 0
+    assert line["summary"]["identical_frames_mrays"] > 0 and line["summary"]["train_step_ms"] > 0
     assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == 2
     assert result["train_step"]["parallelism"].startswith("data parallel x2")
     # the exchange on its own, both collectives, and the identical-frame secondary beside the per-rank frames of the headline
@@ -2386,24 +2406,17 @@ def test_bench_self_launches_two_ranks():
     assert len(result["library_sha256"]) == 64
 
 
-def test_bench_collectives_through_rccl_with_one_rank():
+def test_bench_collectives_through_rccl_with_one_rank(tmp_path):
     """PR_BENCH_FORCE_DIST=1: bench.py initialises the process group with backend "nccl" (= RCCL) for its single rank and runs
     every collective of the multi-rank legs (barriers, the max over ranks, all_gather_into_tensor and gather of the feature
     map, the identical-frame secondary) - the code path of `--gpus 8`, which only the driver can run with 8 devices."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--image", "64",
-                           "--no-cpu-baseline", "--no-split-precision", "--no-minecraft", "--no-distinct-frames", "--no-shard-balance"],
-                          env=env, capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    result = json.loads([line for line in proc.stdout.splitlines() if line.startswith("{")][-1])
-    assert result["distributed"]["backend"] == "nccl" and result["distributed"]["world_size"] == 1
-    assert result["distributed"]["nccl_version"][0].isdigit(), result["distributed"]
+    line, result = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--image", "64", "--no-cpu-baseline", "--no-split-precision",
+                               "--no-minecraft", "--no-distinct-frames", "--no-shard-balance"], env, tmp_path)
+    assert line["distributed"]["backend"] == "nccl" and line["distributed"]["world_size"] == 1
+    assert line["distributed"]["nccl_version"][0].isdigit(), line["distributed"]
     assert result["feature_gather"]["all_gather"]["ms"] > 0 and result["feature_gather"]["gather_dst0"]["ms"] > 0
     assert result["identical_frames"]["value"] > 0 and result["train_step"]["value"] > 0
     assert result["train_step_with_decoder"]["maps_route"]["ms_per_step"] > 0
