@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .modules import AvgPool2d, BatchNorm2d, Conv2d, LeakyReLU, Linear, Sequential, Tracked
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -73,25 +74,25 @@ def roi_pool(inputs: torch.Tensor, boxes: torch.Tensor, output_size: Sequence[in
 
 # ---------------------------------------------------------------------------------------------------------------------
 # building blocks
-class ResidualBlock(nn.Module):
+class ResidualBlock(Tracked, nn.Module):
     """model/layers/residual_block.py:13-68: conv3x3 -> avg-pool -> BN -> LeakyReLU(0.2) -> conv3x3 -> BN, plus a
     conv1x1 -> avg-pool -> BN shortcut when the shape changes."""
 
     def __init__(self, in_planes: int, out_planes: int, downsample_factor: int = 1, last_affine: bool = True,
                  drop_final_activation: bool = False):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(out_planes)
-        self.relu = nn.LeakyReLU(0.2, inplace=True)
-        self.conv2 = nn.Conv2d(out_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(out_planes, affine=last_affine)
+        self.conv1 = Conv2d(in_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(out_planes)
+        self.relu = LeakyReLU(0.2, inplace=True)
+        self.conv2 = Conv2d(out_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(out_planes, affine=last_affine)
         self.downsample_factor = downsample_factor
         self.drop_final_activation = drop_final_activation
         self.downsample = None
         if downsample_factor != 1 or in_planes != out_planes:
-            self.downsample = nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=1, bias=False),
-                                            nn.AvgPool2d(downsample_factor),
-                                            nn.BatchNorm2d(out_planes, affine=last_affine))
+            self.downsample = Sequential(Conv2d(in_planes, out_planes, kernel_size=1, stride=1, bias=False),
+                                            AvgPool2d(downsample_factor),
+                                            BatchNorm2d(out_planes, affine=last_affine))
 
     def forward(self, x):
         out = self.relu(self.bn1(F.avg_pool2d(self.conv1(x), self.downsample_factor)))
@@ -140,7 +141,7 @@ def _crop_first_camera(observations: torch.Tensor, boxes: torch.Tensor, input_si
     return crops, lead
 
 
-class _CropEncoderBase(nn.Module):
+class _CropEncoderBase(Tracked, nn.Module):
     def _read_expansion(self, model_config: Dict):
         self.expansion_factor_rows = 0.0
         self.expansion_factor_cols = 0.0
@@ -160,13 +161,13 @@ class ObjectEncoderV4(_CropEncoderBase):
         self.deformation_features = model_config["deformation_features"]
         self.style_features = model_config["style_features"]
         self._read_expansion(model_config)
-        self.conv1 = nn.Conv2d(3 + 6, 16, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm2d(16)
-        self.initial_backbone = nn.Sequential(ResidualBlock(16, 16 + 1, downsample_factor=1, drop_final_activation=True))
-        self.final_backbone = nn.Sequential(ResidualBlock(16, 32, downsample_factor=2), ResidualBlock(32, 32, downsample_factor=1),
+        self.conv1 = Conv2d(3 + 6, 16, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(16)
+        self.initial_backbone = Sequential(ResidualBlock(16, 16 + 1, downsample_factor=1, drop_final_activation=True))
+        self.final_backbone = Sequential(ResidualBlock(16, 32, downsample_factor=2), ResidualBlock(32, 32, downsample_factor=1),
                                             ResidualBlock(32, 64, downsample_factor=2), ResidualBlock(64, 64, downsample_factor=1))
-        self.style_head = nn.Linear(64, self.style_features)
-        self.deformation_head = nn.Linear(64, self.deformation_features)
+        self.style_head = Linear(64, self.style_features)
+        self.deformation_head = Linear(64, self.deformation_features)
 
     def forward(self, observations, bounding_boxes, camera_rotations, camera_translations, global_frame_indexes,
                 video_frame_indexes, video_indexes):
@@ -188,8 +189,8 @@ class ObjectEncoderV4(_CropEncoderBase):
 
 
 def _resnet_trunk() -> Tuple[nn.Sequential, nn.Sequential]:
-    initial = nn.Sequential(ResidualBlock(64, 64, downsample_factor=2), ResidualBlock(64, 64, downsample_factor=1))
-    final = nn.Sequential(ResidualBlock(64, 128, downsample_factor=2), ResidualBlock(128, 128, downsample_factor=1),
+    initial = Sequential(ResidualBlock(64, 64, downsample_factor=2), ResidualBlock(64, 64, downsample_factor=1))
+    final = Sequential(ResidualBlock(64, 128, downsample_factor=2), ResidualBlock(128, 128, downsample_factor=1),
                           ResidualBlock(128, 256, downsample_factor=2), ResidualBlock(256, 256, downsample_factor=1),
                           ResidualBlock(256, 512, downsample_factor=2), ResidualBlock(512, 512, downsample_factor=1))
     return initial, final
@@ -206,11 +207,11 @@ class ObjectEncoderV5(_CropEncoderBase):
         self.deformation_features = model_config["deformation_features"]
         self.style_features = model_config["style_features"]
         self._read_expansion(model_config)
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
         self.initial_backbone, self.final_backbone = _resnet_trunk()
-        self.style_head = nn.Linear(512, self.style_features)
-        self.deformation_head = nn.Linear(512, self.deformation_features)
+        self.style_head = Linear(512, self.style_features)
+        self.deformation_head = Linear(512, self.deformation_features)
 
     def forward(self, observations, bounding_boxes, camera_rotations, camera_translations, global_frame_indexes,
                 video_frame_indexes, video_indexes):
@@ -251,7 +252,7 @@ def _ground_plane_feet(transformation_matrix_w2c, focals, bounding_boxes, height
     return points * keep.view(3, 1), dirs
 
 
-class StaticObjectParametersEncoder(nn.Module):
+class StaticObjectParametersEncoder(Tracked, nn.Module):
     """model/static_object_parameters_encoder.py:7-66: static objects sit at the midpoint of their configured ranges."""
 
     def __init__(self, config: Dict, model_config: Dict):
@@ -270,7 +271,7 @@ class StaticObjectParametersEncoder(nn.Module):
         return rotation, translation
 
 
-class ClassicObjectParametersEncoder(nn.Module):
+class ClassicObjectParametersEncoder(Tracked, nn.Module):
     """model/classic_object_parameters_encoder.py:14-237: translation = the box's bottom centre cast on the ground plane
     (``zero_axis``, raised to the middle of that axis' configured range), rotation = the middle of the configured range;
     absent objects get zero translation."""
@@ -316,10 +317,10 @@ class ObjectParametersEncoderV4(_CropEncoderBase):
         self.input_size = model_config["input_size"]
         self.edge_to_center_distance = model_config["edge_to_center_distance"]
         self._read_expansion(model_config)
-        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
         self.initial_backbone, self.final_backbone = _resnet_trunk()
-        self.rotation_head = nn.Linear(512, 2)
+        self.rotation_head = Linear(512, 2)
         torch.nn.init.uniform_(self.rotation_head.weight, a=-1e-5, b=1e-5)
         with torch.no_grad():
             self.rotation_head.bias.mul_(0.0)

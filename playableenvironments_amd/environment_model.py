@@ -22,13 +22,14 @@ from __future__ import annotations
 import collections.abc
 import ctypes as C
 import math
+import warnings
 from typing import Dict, List, Tuple
 
 import torch
 import torch.nn as nn
 
 from . import _lib, ray_sampling
-from .modules import CameraParametersStorage
+from .modules import REGISTRATION_EPOCH as _REGISTRATION_EPOCH, CameraParametersStorage, ModuleList, Tracked
 from .object_composer import ObjectComposer, ObjectIDsHelper
 
 
@@ -294,7 +295,7 @@ class _LazyGraph(torch.autograd.Function):
         return (None, None) + tuple(next(it) if t.requires_grad else None for t in inputs)
 
 
-class EnvironmentModel(nn.Module):
+class EnvironmentModel(Tracked, nn.Module):
 
     def __init__(self, config, object_encoders=None, object_parameters_encoders=None, image_decoder=None, grid_sampler=None):
         super().__init__()
@@ -316,8 +317,8 @@ class EnvironmentModel(nn.Module):
         self.object_composer = ObjectComposer(config)
         self.object_id_helper = ObjectIDsHelper(config)
         # the reference's attribute names (environment_model.py:44-50); empty until encoders are injected
-        self.object_parameters_encoders = nn.ModuleList()
-        self.object_encoders = nn.ModuleList()
+        self.object_parameters_encoders = ModuleList()
+        self.object_encoders = ModuleList()
         if object_encoders is not None or object_parameters_encoders is not None:
             self.set_encoders(object_encoders, object_parameters_encoders)
         elif all("architecture" in e for e in config["model"].get("object_encoders", [{}])) and \
@@ -330,16 +331,22 @@ class EnvironmentModel(nn.Module):
         #: evaluation calls without a graph run their scene set-up - pose matrices, projected boxes / points / axes, the renderer's
         #: input layouts - as ONE launch (pr_scene_setup) instead of four kernels and ~10 small copies; results are bit-identical
         self.fused_scene_setup = True
-        #: Automatic capture-and-replay of EVALUATION frames (off by default).  "alias" / "clone": a call of
-        #: ``forward_from_scene_encoding`` / ``forward_from_observations`` under ``torch.no_grad()`` in eval mode without perturbation
-        #: and with a static pixel selection (``samples_per_image == 0``: every pixel or the strided grids - what
-        #: ``render_full_frame_*`` and the reference's autoencoder subclasses issue) is recorded ONCE per (mode, argument shapes,
-        #: options, weights) as a HIP graph and replayed afterwards: the unchanged evaluator / play-loop code then costs ~0.1 ms of
-        #: host time per frame instead of 0.4 - 9 ms (the observation mode's CNN encoders are ~300 small launches).  "alias": the
-        #: result dictionary holds the graph's static tensors, valid until the next call with the same shapes (what an evaluator that
-        #: writes its images before it renders the next batch needs); "clone": every tensor is copied out.  Recorded frames are
-        #: dropped when the weights, the precision or the annealing step change (FrameGraph's signature).
-        self.frame_replay = None
+        #: Automatic capture-and-replay of EVALUATION frames.  A call of ``forward_from_scene_encoding`` /
+        #: ``forward_from_observations`` (so ``render_full_frame_*``, what the reference's evaluators and dataset creators call:
+        #: evaluation/reconstructed_dataset_creator.py:121, evaluation/evaluator.py:58,95) under ``torch.no_grad()`` in eval mode
+        #: without perturbation and with a static pixel selection (``samples_per_image == 0``: every pixel or the strided grids) is
+        #: recorded per (mode, argument shapes, options, weights) as a HIP graph the SECOND time it is seen (the first call runs
+        #: eagerly and warms the recording up) and replayed afterwards: the unchanged evaluator / play-loop code then costs ~0.1 -
+        #: 1.3 ms of host time per frame instead of 0.4 - 11 ms (the observation mode's CNN encoders are ~300 small launches).
+        #: "clone" (DEFAULT): every tensor of the result dictionary is copied out of the recording - for the caller
+        #: indistinguishable from the eager call (same kernels, same launch order: the renderer's part is bit-identical);
+        #: "alias": the dictionary holds the recording's static tensors, valid until the next call with the same shapes (an
+        #: evaluator that writes its images before it renders the next batch); None: always eager.  A recording is dropped when the
+        #: weights, a module registration, the precision, the annealing step or any switch it baked in changes (``_replay_signature``);
+        #: a call that cannot be recorded (an injected module that reads back to the host) is detected once and stays eager.
+        self.frame_replay = "clone"
+        #: recordings kept (one per mode / shape / option combination; the oldest is dropped)
+        self.frame_replay_slots = 4
         self._replays: Dict = {}
         self._in_replay = False
         # per-device constants of the host path (pixel lists of full-frame / strided-grid renders, box points)
@@ -363,9 +370,9 @@ class EnvironmentModel(nn.Module):
           bounding_boxes (..., O, C, 4, n_m), bounding_boxes_validity (..., O, C, n_m)) -> (rotations, translations)``
           (model/classic_object_parameters_encoder.py:129-237; environment_model.py:178-191)."""
         if object_encoders is not None:
-            self.object_encoders = nn.ModuleList(list(object_encoders))
+            self.object_encoders = ModuleList(list(object_encoders))
         if object_parameters_encoders is not None:
-            self.object_parameters_encoders = nn.ModuleList(list(object_parameters_encoders))
+            self.object_parameters_encoders = ModuleList(list(object_parameters_encoders))
         return self
 
     def create_object_encoders(self) -> List[nn.Module]:
@@ -744,29 +751,58 @@ class EnvironmentModel(nn.Module):
         return state
 
     def _replay_signature(self, name: str):
+        """Everything a recorded evaluation frame baked in besides its input buffers: the storages AND values of the renderer's
+        weights (the packed MFMA copies are made outside the recording), the storages of everything else the call reads through a
+        raw pointer (the encoders' / the decoder's parameters and buffers), and the switches that select kernels or host branches."""
         composer = self.object_composer
-        # (the renderer-only mode does not read the encoders' weights; the parameter lists are the composer's cached ones)
-        params = composer._parameter_list() if name == "scene_encodings" else composer._parameter_list(self)
-        return (tuple((p.data_ptr(), p._version) for p in params), composer.precision, bool(composer.gate_feature_head),
+        owner = None if name == "scene_encodings" else self       # (the renderer-only mode does not read the encoders' weights)
+        params = composer._parameter_list(owner)                    # cached lists; walked every call when the tree holds foreign modules
+        root = composer if owner is None else self
+        if composer._tree_is_tracked(root):
+            tree = _REGISTRATION_EPOCH[0]                           # a replaced buffer / parameter / submodule moves it
+        else:
+            tree = tuple(b.data_ptr() for b in root.buffers())
+        decoder = None
+        if self.use_image_decoder and name == "scene_encodings":
+            decoder = tuple(t.data_ptr() for m in (self.image_decoder, self.grid_sampler) if isinstance(m, nn.Module)
+                            for t in list(m.parameters()) + list(m.buffers()))
+        return (tuple((p.data_ptr(), p._version) for p in params), tree, decoder, composer.precision, bool(composer.gate_feature_head),
                 composer.state_epoch, None if composer.object_entry_fields is None else tuple(composer.object_entry_fields),
-                bool(self.fused_scene_setup))
+                bool(self.fused_scene_setup), bool(composer.training), bool(composer.use_naive_mlp), float(self.focal_length_multiplier),
+                int(composer.max_workspace_bytes))
 
     def _replayed(self, name: str, method, tensors, statics: tuple):
-        """The evaluation call ``method(*tensors, *statics...)`` through a recorded graph (see ``frame_replay``)."""
+        """The evaluation call ``method(*tensors, *statics...)`` through a recorded graph (see ``frame_replay``).  Returns None when
+        the call has to run eagerly: the first call of a (mode, shapes, options) combination (it doubles as the recording's warm-up:
+        a one-off render costs what it cost before), or a combination whose recording failed."""
         from .frame_graph import CapturedCall
         key = (name, tuple((tuple(t.shape), t.dtype, str(t.device)) for t in tensors), statics)
         signature = self._replay_signature(name)
         entry = self._replays.get(key)
-        if entry is None or entry[0] != signature:
-            if len(self._replays) >= 4:                     # a handful of frame shapes at most: drop the oldest recording
+        if entry is not None and entry[0] != signature:
+            del self._replays[key]                              # stale: weights / precision / step changed since (re-record below)
+            entry = None
+        if entry is None:
+            while len(self._replays) >= self.frame_replay_slots:        # a handful of frame shapes at most: drop the oldest one
                 self._replays.pop(next(iter(self._replays)))
+            self._replays[key] = (signature, None)              # seen once: the next call with this signature records
+            return None
+        if entry[1] is None:
             self._in_replay = True
             try:
-                entry = (signature, CapturedCall(lambda *ts: method(*ts), list(tensors)), self.object_composer._workspace,
-                         [e[1] for e in self.object_composer._packed.values()])      # (raw pointers recorded: keep them alive)
+                recorded = CapturedCall(lambda *ts: method(*ts), list(tensors), warmup=1)
+            except Exception as error:             # a module in front of the renderer that cannot be recorded (host reads, ...)
+                torch.cuda.synchronize()
+                warnings.warn(f"frame_replay: recording the {name} evaluation call failed ({type(error).__name__}: {error}); calls of "
+                              "this shape run eagerly from now on", RuntimeWarning)
+                recorded = False
             finally:
                 self._in_replay = False
+            # (raw pointers recorded: the workspace and the packed weights stay alive with the entry)
+            entry = (signature, recorded, self.object_composer._workspace, [e[1] for e in self.object_composer._packed.values()])
             self._replays[key] = entry
+        if entry[1] is False:
+            return None
         results = entry[1].replay(tensors)
         if self.frame_replay == "clone":
             def clone(x):
@@ -781,12 +817,19 @@ class EnvironmentModel(nn.Module):
         return results
 
     def _replay_wanted(self, tensors, perturb, samples_per_image) -> bool:
-        if self.frame_replay is None or self._in_replay:
+        if self.frame_replay is None or self._in_replay or self.__dict__.get("_is_replica"):
             return False
         if self.frame_replay not in ("alias", "clone"):
             raise ValueError(f"unknown frame_replay {self.frame_replay!r} (expected None, 'alias' or 'clone')")
-        return (not torch.is_grad_enabled() and not self.training and not perturb and samples_per_image == 0 and
-                all(torch.is_tensor(t) and t.is_cuda for t in tensors) and not torch.cuda.is_current_stream_capturing())
+        return (not torch.is_grad_enabled() and not self.training and not self.object_composer.training and not perturb and
+                samples_per_image == 0 and all(torch.is_tensor(t) and t.is_cuda for t in tensors) and
+                not torch.cuda.is_current_stream_capturing())
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel: per-call replicas never record, and must not share the recordings / per-device constants of the original
+        replica = super()._replicate_for_data_parallel()
+        replica.__dict__.update(_replays={}, _in_replay=False, _pixel_cache={}, _edge_point_cache={}, _axes_point_cache={})
+        return replica
 
     # ------------------------------------------------------------------ scene encoding -> rays -> composer
     def forward_from_scene_encoding(self, camera_rotations, camera_translations, focals, image_size,
@@ -808,12 +851,14 @@ class EnvironmentModel(nn.Module):
             stride_key = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else patch_stride
             statics = (tuple(image_size), samples_per_image_batching, upsample_factor, patch_size, stride_key, canonical_pose,
                        None if _decoder_features is None else tuple(_decoder_features))
-            return self._replayed(
+            replayed = self._replayed(
                 "scene_encodings",
                 lambda a, b, c, d, e, f, g, h: self.forward_from_scene_encoding(
                     a, b, c, image_size, d, e, f, g, h, samples_per_image, perturb, samples_per_image_batching, upsample_factor,
                     patch_size, patch_stride, canonical_pose, _decoder_features=_decoder_features),
                 scene, statics)
+            if replayed is not None:
+                return replayed
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
         prepared = None
@@ -1051,12 +1096,14 @@ class EnvironmentModel(nn.Module):
             stride_key = tuple(patch_stride) if isinstance(patch_stride, collections.abc.Sequence) else patch_stride
             statics = (samples_per_image_batching, upsample_factor, patch_size, stride_key, align_grid, canonical_pose,
                        None if _decoder_features is None else tuple(_decoder_features))
-            return self._replayed(
+            replayed = self._replayed(
                 "observations",
                 lambda *ts: self.forward_from_observations(*ts, samples_per_image, perturb, samples_per_image_batching, shuffle_style,
                                                            upsample_factor, patch_size, patch_stride, align_grid, canonical_pose,
                                                            _decoder_features=_decoder_features),
                 batch, statics)
+            if replayed is not None:
+                return replayed
         camera_rotations, camera_translations, focals = self._corrected_cameras(camera_rotations, camera_translations, focals,
                                                                                 global_frame_indexes)
         rescaled_focals = focals * self.focal_length_multiplier

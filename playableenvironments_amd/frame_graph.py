@@ -83,22 +83,27 @@ class FrameGraph:
         # library pick its algorithms), then capture
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(max(1, warmup)):
-                self._call()
-        torch.cuda.current_stream(device).wait_stream(side)
         composer = model.object_composer
-        self._workspace = composer._workspace      # the graph writes through this pointer: keep it alive
-        self._weights_version = self._signature()
-        self.graph = torch.cuda.CUDAGraph()
+        was_recording = getattr(model, "_in_replay", False)
+        model._in_replay = True              # (the model's own automatic recording - EnvironmentModel.frame_replay - stays out of this one)
         try:
-            with torch.cuda.graph(self.graph), torch.no_grad():
-                self.results = self._call()
-        except BaseException:
-            # (a failed capture can take the process down when the half-built graph is destroyed: say why first)
-            import traceback
-            traceback.print_exc()
-            raise
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(max(1, warmup)):
+                    self._call()
+            torch.cuda.current_stream(device).wait_stream(side)
+            self._workspace = composer._workspace      # the graph writes through this pointer: keep it alive
+            self._weights_version = self._signature()
+            self.graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(self.graph), torch.no_grad():
+                    self.results = self._call()
+            except BaseException:
+                # (a failed capture can take the process down when the half-built graph is destroyed: say why first)
+                import traceback
+                traceback.print_exc()
+                raise
+        finally:
+            model._in_replay = was_recording
         # the graph also reads the composer's packed weight buffers through raw pointers: hold them, so that a repack
         # (another precision, a differentiable call) can drop them from the composer's cache without freeing them
         self._packed = [entry[1] for entry in composer._packed.values()]
@@ -145,13 +150,10 @@ class CapturedCall:
                 fn(*self.inputs)
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(self.graph), torch.no_grad():
-                self.results = fn(*self.inputs)
-        except BaseException:
-            import traceback
-            traceback.print_exc()
-            raise
+        # capture_error_mode="thread_local": other threads of the process (a DataLoader's pin-memory thread, a writer) keep making
+        # HIP calls while this thread records - the default "global" mode would fail THEIR calls
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+            self.results = fn(*self.inputs)
 
     def replay(self, tensors):
         for dst, src in zip(self.inputs, tensors):
@@ -213,6 +215,8 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.outputs = step_fn()
         self.replays = 0
+        for c in self.composers:
+            c.resolve_host_step()          # (after a checkpoint load the host learns the step from the device, once)
         self._annealing = [c.annealing_fingerprint() for c in self.composers]
         for c in self.composers:
             c.after_graph_replay()         # (the capture itself left packed copies keyed on counters the replays will not move)

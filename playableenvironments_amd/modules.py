@@ -16,8 +16,94 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
+#: bumped whenever a module OF THIS PACKAGE (re-)registers a parameter, a buffer or a submodule (``layer.weight = nn.Parameter(...)``,
+#: ``load_state_dict(assign=True)``, a replaced BatchNorm buffer, ``model.alpha_head = other``): ``ObjectComposer`` caches parameter
+#: lists and raw-pointer structs of its module tree and rebuilds them when the tree may have changed under them.  Scoped to the
+#: package's own classes (``Tracked`` below) - no process-wide ``torch.nn.modules.module.register_module_*_registration_hook``: other
+#: people's modules constructed in the same process neither pay for nor disturb this bookkeeping.  A tree that contains a module
+#: of another class (a user swapped a stock ``nn.Linear`` in) is never cached (``tree_is_tracked``).
+REGISTRATION_EPOCH = [0]
+_TREE_SLOTS = ("_parameters", "_buffers", "_modules")
 
-class BoundingBox(nn.Module):
+
+class Tracked:
+    """Mixin in front of ``nn.Module`` subclasses: every way a parameter / buffer / submodule can be (re-)registered or removed -
+    ``__setattr__`` (which ``nn.Module`` uses for plain assignment and ``load_state_dict(assign=True)``), ``__delattr__``,
+    ``register_parameter`` / ``register_buffer`` / ``add_module`` / ``register_module`` - moves ``REGISTRATION_EPOCH``.
+    ``nn.DataParallel`` replicas (``_is_replica``) do not: they are per-call copies whose composers never cache."""
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if not d.get("_is_replica") and (isinstance(value, (torch.Tensor, nn.Module)) or name in _TREE_SLOTS or
+                                         any(name in (d.get(slot) or ()) for slot in _TREE_SLOTS)):
+            REGISTRATION_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        REGISTRATION_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        REGISTRATION_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        REGISTRATION_EPOCH[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
+
+    def add_module(self, name, module):
+        REGISTRATION_EPOCH[0] += 1
+        super().add_module(name, module)
+
+    def register_module(self, name, module):
+        REGISTRATION_EPOCH[0] += 1
+        super().register_module(name, module)
+
+    def _replicate_for_data_parallel(self):
+        epoch = REGISTRATION_EPOCH[0]
+        replica = super()._replicate_for_data_parallel()       # (assigns the replica's _parameters / _buffers / _modules dictionaries)
+        REGISTRATION_EPOCH[0] = epoch
+        return replica
+
+
+def tree_is_tracked(module: nn.Module) -> bool:
+    """Every module of the tree is one of this package's tracked classes: its registrations cannot change unnoticed."""
+    return all(isinstance(m, Tracked) for m in module.modules())
+
+
+class Linear(Tracked, nn.Linear):
+    pass
+
+
+class BatchNorm1d(Tracked, nn.BatchNorm1d):
+    pass
+
+
+class ModuleList(Tracked, nn.ModuleList):
+    pass
+
+
+class Sequential(Tracked, nn.Sequential):
+    pass
+
+
+class Conv2d(Tracked, nn.Conv2d):
+    pass
+
+
+class BatchNorm2d(Tracked, nn.BatchNorm2d):
+    pass
+
+
+class LeakyReLU(Tracked, nn.LeakyReLU):
+    pass
+
+
+class AvgPool2d(Tracked, nn.AvgPool2d):
+    pass
+
+
+class BoundingBox(Tracked, nn.Module):
     """Axis-aligned box, ``dimensions`` (3, 2) non-persistent buffer (utils/lib_3d/bounding_box.py:10-21)."""
 
     def __init__(self, dimensions):
@@ -52,44 +138,44 @@ class BoundingBox(nn.Module):
         return torch.cat([corners, pts], dim=0)
 
 
-class _Normalization(nn.Module):
+class _Normalization(Tracked, nn.Module):
     """``ada_in`` level: holds ``normalization`` = BatchNorm1d(affine=False) (model/layers/adain.py:44-47)."""
 
     def __init__(self, features: int):
         super().__init__()
-        self.normalization = nn.BatchNorm1d(features, affine=False)
+        self.normalization = BatchNorm1d(features, affine=False)
 
 
-class AffineTransformAdaIn(nn.Module):
+class AffineTransformAdaIn(Tracked, nn.Module):
     """Style affine + AdaIN statistics (model/layers/adain.py:5-19): scale biased to 1, bias to 0."""
 
     def __init__(self, in_features: int, style_features_count: int):
         super().__init__()
         self.style_features_count = style_features_count
-        self.affine_transform = nn.Linear(style_features_count, 2 * in_features)
+        self.affine_transform = Linear(style_features_count, 2 * in_features)
         self.ada_in = _Normalization(in_features)
         self.affine_transform.bias.data[:in_features] = 1
         self.affine_transform.bias.data[in_features:] = 0
 
 
-class _Placeholder(nn.Module):
+class _Placeholder(Tracked, nn.Module):
     """Parameter-free slot (the ReLUs of the reference's AdaInSequential) that keeps the indices."""
 
 
 def _features_head(width: int, style: int, out: int) -> nn.Sequential:
     # indices 0,1,3,4,6 carry parameters (model/nerf_models/adain_style_nerf_model.py:57-71)
-    return nn.Sequential(
-        nn.Linear(width, width, bias=False),
+    return Sequential(
+        Linear(width, width, bias=False),
         AffineTransformAdaIn(width, style),
         _Placeholder(),
-        nn.Linear(width, width // 2, bias=False),
+        Linear(width, width // 2, bias=False),
         AffineTransformAdaIn(width // 2, style),
         _Placeholder(),
-        nn.Linear(width // 2, out),
+        Linear(width // 2, out),
     )
 
 
-class AdaInStyleNerfModel(nn.Module):
+class AdaInStyleNerfModel(Tracked, nn.Module):
     """Weights of model/nerf_models/adain_style_nerf_model.py:14-55 (input: 3-D position)."""
     input_dimensions = 3
     kind = 0
@@ -111,15 +197,15 @@ class AdaInStyleNerfModel(nn.Module):
         self.octaves = pe["octaves"]
         self.encoding_size = self.input_dimensions * (1 + 2 * self.octaves)
         self.bounding_box = BoundingBox(model_config["bounding_box"])
-        self.backbone_layers = nn.ModuleList()
+        self.backbone_layers = ModuleList()
         size = self.encoding_size
         for idx in range(self.backbone_layers_count):
             if idx == self.skip_layer_idx:
                 size += self.encoding_size
-            self.backbone_layers.append(nn.Linear(size, self.layers_width))
+            self.backbone_layers.append(Linear(size, self.layers_width))
             size = self.layers_width
         if self.kind == 0:
-            self.alpha_head = nn.Linear(self.layers_width, 1)
+            self.alpha_head = Linear(self.layers_width, 1)
         self.features_head = _features_head(self.layers_width, self.style_features, self.output_features)
 
 
@@ -130,7 +216,7 @@ class SkyboxAdaInStyleNerfModelV3(AdaInStyleNerfModel):
     kind = 1
 
 
-class _AnnealableEncoderState(nn.Module):
+class _AnnealableEncoderState(Tracked, nn.Module):
     """``positional_encoder`` level of the bender: int32 ``current_step`` buffer
     (model/annealable_positional_encoder.py:26-44)."""
 
@@ -152,7 +238,7 @@ class _AnnealableEncoderState(nn.Module):
         return (1 - torch.cos(math.pi * torch.clamp(alpha - k, min=0.0, max=1.0))) / 2
 
 
-class PositionalRayBender(nn.Module):
+class PositionalRayBender(Tracked, nn.Module):
     """Weights of model/nerf_models/positional_ray_bender_model.py:12-79."""
     has_weights = True
 
@@ -169,14 +255,14 @@ class PositionalRayBender(nn.Module):
         self.positional_encoder = _AnnealableEncoderState(pe["octaves"], pe["num_steps"])
         self.encoding_size = 3 * (1 + 2 * pe["octaves"])
         self.bounding_box = BoundingBox(model_config["bounding_box"])
-        self.backbone_layers = nn.ModuleList()
+        self.backbone_layers = ModuleList()
         size = self.encoding_size + self.deformation_features
         for idx in range(self.layers_count):
             if idx == self.skip_layer_idx:
                 size += self.encoding_size + self.deformation_features
-            self.backbone_layers.append(nn.Linear(size, self.layers_width))
+            self.backbone_layers.append(Linear(size, self.layers_width))
             size = self.layers_width
-        self.output_head = nn.Linear(self.layers_width, 3, bias=False)
+        self.output_head = Linear(self.layers_width, 3, bias=False)
         for layer in self.backbone_layers:
             torch.nn.init.kaiming_uniform_(layer.weight, a=0, mode="fan_in", nonlinearity="relu")
             torch.nn.init.zeros_(layer.bias)
@@ -186,7 +272,7 @@ class PositionalRayBender(nn.Module):
         self.positional_encoder.set_step(current_step)
 
 
-class ZeroedRayBender(nn.Module):
+class ZeroedRayBender(Tracked, nn.Module):
     """model/nerf_models/zeroed_ray_bender_model.py:7-37: no parameters, displacement == 0."""
     has_weights = False
 
@@ -208,7 +294,7 @@ _BENDER_CLASSES = {
 }
 
 
-class RayBendingStyleNerfModel(nn.Module):
+class RayBendingStyleNerfModel(Tracked, nn.Module):
     """One object model: NeRF + ray bender + box (model/nerf_models/ray_bending_style_nerf_model.py:12-60).
 
     The ``architecture`` strings of the reference configs are mapped to the classes above (the
@@ -244,7 +330,7 @@ class RayBendingStyleNerfModel(nn.Module):
 OBJECT_MODEL_CLASSES = {"model.nerf_models.ray_bending_style_nerf_model": RayBendingStyleNerfModel}
 
 
-class CameraParametersStorage(nn.Module):
+class CameraParametersStorage(Tracked, nn.Module):
     """Learnable per-frame corrections of the measured cameras: 3 rotation, 3 translation and 1 focal offset per
     (frame, camera), zero-initialised, read only in training mode (zeros in evaluation), translations scaled by 10 and
     focals by 1000 (model/layers/camera_parameters_storage.py:9-67 over model/layers/indexed_storage.py:9-58).

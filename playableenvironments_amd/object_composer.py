@@ -17,21 +17,12 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .modules import OBJECT_MODEL_CLASSES, RayBendingStyleNerfModel
+from .modules import OBJECT_MODEL_CLASSES, REGISTRATION_EPOCH as _REGISTRATION_EPOCH, ModuleList, RayBendingStyleNerfModel, Tracked, \
+    tree_is_tracked
 
-#: bumped whenever ANY module registers a parameter, buffer or submodule (``module.weight = nn.Parameter(...)``,
-#: ``load_state_dict(assign=True)``, a replaced BatchNorm buffer ...): the composer's cached parameter lists and model structs hold
-#: Python objects and raw pointers, so they are rebuilt when the module tree may have changed under them
-_REGISTRATION_EPOCH = [0]
-
-
-def _bump_registration_epoch(*_args):
-    _REGISTRATION_EPOCH[0] += 1
-
-
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
-torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
-torch.nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
+# (_REGISTRATION_EPOCH: moved by this package's own module classes whenever one of them (re-)registers a parameter, buffer or
+# submodule - modules.Tracked; the composer's cached parameter lists and model structs hold Python objects and raw pointers, so
+# they are rebuilt when its module tree may have changed under them.  No process-wide registration hooks.)
 
 ENTRY_KEYS = ("integrated_features", "opacity", "weights", "depth", "disparity",
               "integrated_displacements_magnitude", "integrated_divergence")
@@ -89,6 +80,74 @@ class ObjectIDsHelper:
             raise Exception(f"Model id {model_idx} does not refer to a dynamic object")
         first = self.dynamic_object_idx_by_object_idx(self.first_object_idx_by_model_idx_map[model_idx])
         return first, first + self.objects_count_by_model_idx(model_idx)
+
+
+#: limits of the kernels behind the C ABI (include/playrender.h: PR_MAX_OBJECTS / PR_MAX_LAYERS / PR_MAX_OCTAVES; csrc/pr_common.h:
+#: MAX_WIDTH = 256 padded columns per layer, MAX_ENC = 128 padded input columns) - every shipped configuration fits
+MAX_LAYER_WIDTH = 256
+MAX_ENCODING_WIDTH = 128
+
+
+def validate_config_limits(config) -> None:
+    """Raises ``ValueError`` naming the configuration key when the renderer's kernels cannot run the configuration - at
+    construction, not at the first render.  What the reference accepts and this renderer refuses: more than PR_MAX_OBJECTS
+    object instances, layers wider than 256, more than PR_MAX_LAYERS layers / PR_MAX_OCTAVES octaves, encodings wider than 128
+    columns, ``append_original: False`` (model/nerf_models/adain_style_nerf_model.py:24-45, model/positional_encoder.py:41-65)."""
+    def pad(v):
+        return (int(v) + 31) // 32 * 32
+
+    model = config["model"]
+    instances = sum(int(e["objects_count"]) for e in model["object_parameters_encoder"])
+    if not 1 <= instances <= _lib.PR_MAX_OBJECTS:
+        raise ValueError(f"config['model']['object_parameters_encoder'][*]['objects_count'] add up to {instances} object instances: the HIP "
+                         f"renderer composes 1..{_lib.PR_MAX_OBJECTS} (PR_MAX_OBJECTS, include/playrender.h)")
+    features = set()
+    for i, m in enumerate(model["object_models"]):
+        where = f"config['model']['object_models'][{i}]"
+        n, b = m["nerf_model"], m["ray_bender_model"]
+        skybox = n["architecture"].endswith("skybox_adain_style_nerf_model_v3")
+        din = 6 if skybox else 3
+        pe = n["position_encoder"]
+        if not pe["append_original"]:
+            raise ValueError(f"{where}['nerf_model']['position_encoder']['append_original'] = False is not supported by the HIP renderer "
+                             "(the kernels' encodings always start with the raw input)")
+        if not 0 <= pe["octaves"] <= _lib.PR_MAX_OCTAVES or pad(din * (1 + 2 * pe["octaves"])) > MAX_ENCODING_WIDTH:
+            raise ValueError(f"{where}['nerf_model']['position_encoder']['octaves'] = {pe['octaves']}: at most {_lib.PR_MAX_OCTAVES} octaves "
+                             f"(PR_MAX_OCTAVES) and an encoding of at most {MAX_ENCODING_WIDTH} columns ({din} x (1 + 2 x octaves))")
+        w = n["layers_width"]
+        if w < 2 or pad(w) > MAX_LAYER_WIDTH:
+            raise ValueError(f"{where}['nerf_model']['layers_width'] = {w}: the HIP renderer's MLP kernels hold layers of 2..{MAX_LAYER_WIDTH} "
+                             "units (MAX_WIDTH, csrc/pr_common.h)")
+        f = n["output_features"]
+        if f < 1 or pad(f) > MAX_LAYER_WIDTH:
+            raise ValueError(f"{where}['nerf_model']['output_features'] = {f}: 1..{MAX_LAYER_WIDTH}")
+        features.add(f)
+        if not 2 <= n["backbone_layers_count"] <= _lib.PR_MAX_LAYERS:
+            raise ValueError(f"{where}['nerf_model']['backbone_layers_count'] = {n['backbone_layers_count']}: 2..{_lib.PR_MAX_LAYERS} "
+                             "(PR_MAX_LAYERS, include/playrender.h)")
+        if not 1 <= n["skip_layer_idx"] < n["backbone_layers_count"]:
+            raise ValueError(f"{where}['nerf_model']['skip_layer_idx'] = {n['skip_layer_idx']}: 1..backbone_layers_count - 1")
+        if b["architecture"].endswith("positional_ray_bender_model"):
+            if skybox:
+                raise ValueError(f"{where}: a positional ray bender on the skybox model is not supported")
+            bpe = b["position_encoder"]
+            if not bpe["append_original"]:
+                raise ValueError(f"{where}['ray_bender_model']['position_encoder']['append_original'] = False is not supported by the HIP "
+                                 "renderer")
+            width_in = 3 * (1 + 2 * bpe["octaves"]) + m["deformation_features"]
+            if not 0 <= bpe["octaves"] <= _lib.PR_MAX_OCTAVES or pad(width_in) > MAX_ENCODING_WIDTH:
+                raise ValueError(f"{where}['ray_bender_model']['position_encoder']['octaves'] = {bpe['octaves']} with deformation_features = "
+                                 f"{m['deformation_features']}: at most {_lib.PR_MAX_OCTAVES} octaves and {MAX_ENCODING_WIDTH} input columns "
+                                 "(3 x (1 + 2 x octaves) + deformation_features)")
+            if b["layers_width"] < 1 or pad(b["layers_width"]) > MAX_LAYER_WIDTH:
+                raise ValueError(f"{where}['ray_bender_model']['layers_width'] = {b['layers_width']}: 1..{MAX_LAYER_WIDTH}")
+            if not 2 <= b["layers_count"] <= _lib.PR_MAX_LAYERS:
+                raise ValueError(f"{where}['ray_bender_model']['layers_count'] = {b['layers_count']}: 2..{_lib.PR_MAX_LAYERS}")
+            if not 1 <= b["skip_layer_idx"] < b["layers_count"]:
+                raise ValueError(f"{where}['ray_bender_model']['skip_layer_idx'] = {b['skip_layer_idx']}: 1..layers_count - 1")
+    if len(features) > 1:
+        raise ValueError(f"config['model']['object_models'][*]['nerf_model']['output_features'] differ ({sorted(features)}): the composer "
+                         "merges the objects' features per ray, as the reference's does")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -262,7 +321,7 @@ class _RenderFunction(torch.autograd.Function):
         return (None, None, None, d_ray_o, d_ray_d, g_w2o, g_style, g_def) + tuple(grads[id(p)] for p in ctx.params)
 
 
-class ObjectComposer(nn.Module):
+class ObjectComposer(Tracked, nn.Module):
 
     #: upper limit for the per-call scratch (MLP feature rows dominate); larger calls are split along the ray dimension,
     #: which is exact because rays are independent.  The effective budget of a call is the smaller of this and 80 % of
@@ -272,8 +331,10 @@ class ObjectComposer(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
-        self.object_models_coarse = nn.ModuleList(self.create_object_models(fine=False))
-        self.object_models_fine = nn.ModuleList(self.create_object_models(fine=True))
+        validate_config_limits(config)
+        self.register_load_state_dict_post_hook(ObjectComposer._after_load_state_dict)
+        self.object_models_coarse = ModuleList(self.create_object_models(fine=False))
+        self.object_models_fine = ModuleList(self.create_object_models(fine=True))
         self.apply_activation = self.config["model"]["apply_activation"]
         if self.object_models_coarse[0].model_config["nerf_model"]["output_features"] != 3 and self.apply_activation:
             raise Exception("The application of activations to the nerf output is requested, but the model seem not "
@@ -284,6 +345,7 @@ class ObjectComposer(nn.Module):
         self._packed: Dict[tuple, tuple] = {}
         self._param_lists: Dict[int, list] = {}      # id(module) -> list(module.parameters())
         self._structs: Dict[tuple, tuple] = {}       # (id(model), positions) -> (key, pr_object_model_t)
+        self._tracked: Dict[int, bool] = {}          # id(module) -> its tree holds this package's tracked classes only
         self._registration_epoch = _REGISTRATION_EPOCH[0]
         self._budget_ok = 0                          # largest workspace size a device query has granted
         self._annealing: Dict[int, tuple] = {}
@@ -293,15 +355,18 @@ class ObjectComposer(nn.Module):
         self.use_naive_mlp = False  # debugging switch (PR_FLAG_NAIVE_MLP)
         #: "fp32": exact fp32 matrix-core arithmetic (default).  "f16x3" (split precision): evaluation renders compute every product
         #: as three fp16 MFMAs with fp32 accumulation (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with x = hi + lo in fp16, ~22 significant
-        #: bits); differentiable / training calls keep the fp32 forward PIPELINE (train-mode BatchNorm phases, fp32 saved activations)
-        #: with phase 1's matrix products on fp16 pairs as well, and run the BACKWARD pass's matrix products on bf16 triples (x = b1 +
-        #: b2 + b3 exactly, six bf16 MFMAs per product, fp32 accumulation: PR_FLAG_SPLIT_BACKWARD) where a split kernel exists -
-        #: gradients pass the fp32 path's tests, the float64 arbitration at shipped sizes included.
+        #: bits).  Differentiable / training calls keep the fp32 forward PIPELINE (train-mode BatchNorm phases, fp32 saved activations,
+        #: fp32 head phases) and run, where a split kernel exists (PR_FLAG_SPLIT_BACKWARD): phase 1 of the forward pass and the backward
+        #: CHAINS (dX) on fp16 pairs (weights x 2^8, tiles scaled by a power of two: all scalings exact), the WEIGHT GRADIENTS (dW) on
+        #: bf16 triples (x = b1 + b2 + b3 exactly, six bf16 MFMAs per product), fp32 accumulation everywhere - gradients pass the fp32
+        #: path's tests, the float64 arbitration at shipped sizes included.  A train-mode call WITHOUT gradients (no_grad) runs exact
+        #: fp32.  The first differentiable call at a non-fp32 precision says so once (a model switched to "f16x3" for evaluation and
+        #: trained afterwards changes its training numerics at round-off level).
         #: "f16" (throughput tier, interactive play): evaluation renders keep the a_hi*w_hi product only - plain fp16 operands, fp32
         #: accumulation, one MFMA per step; ~1e-3 relative error on the rendered features (>= 40 dB PSNR against the oracle), so
         #: NOT a parity configuration.  Shares the packed weights with "f16x3"; training / differentiable calls behave as "f16x3".
         self.precision = "fp32"
-        self._warned_precision_fallback = False
+        self._noted_split_training = False
         #: sigma-gated feature head (PR_FLAG_GATE_HEAD): evaluation renders skip the feature head of samples whose raw density
         #: is <= 0 - their compositing weight is exactly 0, so the results are bit-identical.  Ignored (by the library) for
         #: perturbed, training and differentiable calls.
@@ -393,6 +458,17 @@ class ObjectComposer(nn.Module):
                 out.append(tuple((1 - math.cos(math.pi * min(1.0, max(0.0, alpha - k)))) / 2 for k in range(enc.octaves_count)))
         return tuple(out)
 
+    def resolve_host_step(self) -> Optional[int]:
+        """The annealing step, read back from the device ONCE when the host does not know it (after ``load_state_dict`` / ``.to()``:
+        the buffers hold the checkpoint's step).  One synchronisation; ``GraphedStep`` calls it when it records, so that a resumed
+        run's first ``set_step(step)`` - the step the checkpoint already holds - does not look like a change of the baked weights."""
+        if self._host_step is None:
+            for m in list(self.object_models_coarse) + [m for m in self.object_models_fine if m is not None]:
+                if m.ray_bender.has_weights:
+                    self._host_step = int(m.ray_bender.positional_encoder.current_step.item())
+                    break
+        return self._host_step
+
     def after_graph_replay(self):
         """A replayed HIP graph (frame_graph.GraphedStep) updates parameter storages on the device without moving the Python
         version counters the packed-weight cache keys on: forget the packed copies, so that the next eager render packs the
@@ -402,24 +478,63 @@ class ObjectComposer(nn.Module):
 
     def _parameter_list(self, module=None) -> list:
         """``list(module.parameters())`` (module = None: the composer), cached: walking the module tree costs ~0.3 ms per call and
-        a training step asks five times.  Dropped with the other storage-derived caches (``_apply``, ``load_state_dict``)."""
+        a training step asks five times.  Dropped with the other storage-derived caches (``_apply``, ``load_state_dict``) and when a
+        module of this package re-registered anything; a tree holding a module of a foreign class (whose registrations this package
+        cannot see) is walked on every call instead, and so is an ``nn.DataParallel`` replica - whose parameters are the broadcast
+        copies ``replicate`` files under ``_former_parameters`` (they are no ``nn.Parameter`` s: the gradients flow back to the
+        originals through the broadcast's autograd node)."""
+        root = self if module is None else module
+        if getattr(root, "_is_replica", False):
+            seen, out = set(), []
+            for m in root.modules():
+                for p in getattr(m, "_former_parameters", {}).values():
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        out.append(p)
+            return out
+        self._sync_registrations()
+        key = id(root)
+        cached = self._param_lists.get(key)
+        if cached is None:
+            cached = list(root.parameters())
+            if self._tree_is_tracked(root):
+                self._param_lists[key] = cached
+        return cached
+
+    def _sync_registrations(self):
         if self._registration_epoch != _REGISTRATION_EPOCH[0]:
-            # some module (re-)registered a parameter / buffer / submodule since the lists were built: they may hold replaced objects
+            # a module of this package (re-)registered a parameter / buffer / submodule since the lists were built: they may hold
+            # replaced objects
             self._registration_epoch = _REGISTRATION_EPOCH[0]
             self._param_lists.clear()
             self._structs.clear()
-        key = id(self if module is None else module)
-        cached = self._param_lists.get(key)
-        if cached is None:
-            cached = list((self if module is None else module).parameters())
-            self._param_lists[key] = cached
-        return cached
+            self._tracked.clear()
+
+    def _tree_is_tracked(self, root) -> bool:
+        """Cached per registration epoch: every module under ``root`` is one of this package's tracked classes."""
+        key = id(root)
+        self._sync_registrations()
+        known = self._tracked.get(key)
+        if known is None:
+            known = self._tracked[key] = tree_is_tracked(root)
+        return known
+
+    def _replicate_for_data_parallel(self):
+        """``nn.DataParallel`` (the reference wraps its model unconditionally, train.py:61): every replica gets its OWN caches -
+        packed weights, pointer structs, workspace, pending checks - on its own device; the shallow ``__dict__`` copy of
+        ``nn.Module._replicate_for_data_parallel`` would otherwise share dictionaries that hold device-0 pointers between the
+        replicas' threads.  A replica lives for one call: it packs the broadcast weights it is given and never caches lists."""
+        replica = super()._replicate_for_data_parallel()
+        fresh = dict(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _tracked={}, _annealing={}, _linspace={}, _workspace=None,
+                     _budget_ok=0, _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None)
+        replica.__dict__.update(fresh)
+        return replica
 
     def __getstate__(self):
         # copy.deepcopy / pickle (EMA helpers, swa_utils.AveragedModel): the caches hold ctypes structures with raw pointers
         # (not picklable) and device scratch that a copy must not share
         state = dict(self.__dict__)
-        state.update(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
+        state.update(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _tracked={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
                      _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None, _host_step=None)
         return state
 
@@ -427,6 +542,7 @@ class ObjectComposer(nn.Module):
         """Everything derived from parameter / buffer storages or tied to a device."""
         self._param_lists.clear()
         self._structs.clear()
+        self._tracked.clear()
         self._budget_ok = 0
         self._packed.clear()
         self._annealing.clear()
@@ -439,11 +555,11 @@ class ObjectComposer(nn.Module):
         self._drop_device_caches()
         return out
 
-    def load_state_dict(self, *args, **kwargs):
-        out = super().load_state_dict(*args, **kwargs)
+    def _after_load_state_dict(self, *_):
+        # a checkpoint was loaded - through this module or through a parent (EnvironmentModel.load_state_dict, the usual way): the
+        # step buffers now hold the checkpoint's value, unknown to the host until set_step; storage-derived caches are stale
         self._drop_device_caches()
-        self._host_step = None          # (the step buffers now hold the checkpoint's value: unknown to the host until set_step)
-        return out
+        self._host_step = None
 
     # ------------------------------------------------------------------ marshalling
     def _model_struct(self, model: RayBendingStyleNerfModel, positions: int) -> _lib.ObjectModel:
@@ -455,6 +571,8 @@ class ObjectComposer(nn.Module):
         step = model.ray_bender.positional_encoder.current_step if model.ray_bender.has_weights else None
         key = (self.state_epoch, tuple(p.data_ptr() for p in params),
                None if step is None else (step.data_ptr(), step._version))
+        if getattr(model, "_is_replica", False) or not self._tree_is_tracked(model):
+            return self._build_model_struct(model, positions)     # (buffers of a foreign / per-call tree may move unnoticed)
         cached = self._structs.get((id(model), positions))
         if cached is not None and cached[0] == key:
             return cached[1]
@@ -763,7 +881,14 @@ class ObjectComposer(nn.Module):
         if _save:
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
             if self.precision in ("f16x3", "f16"):
-                flags |= _lib.PR_FLAG_SPLIT_BACKWARD     # the backward pass's matrix products as bf16 triples (six MFMAs per product)
+                # phase 1 of the forward pass and the backward chains on fp16 pairs, the weight gradients on bf16 triples
+                flags |= _lib.PR_FLAG_SPLIT_BACKWARD
+                if not self._noted_split_training:
+                    self._noted_split_training = True
+                    warnings.warn(f"ObjectComposer.precision = {self.precision!r} applies to this differentiable call too: phase 1 of the "
+                                  "forward pass and the backward chains run on fp16 pairs, the weight gradients on bf16 triples (fp32 "
+                                  "accumulation; gradients within the fp32 path's tolerances).  Set precision = 'fp32' for exact-fp32 "
+                                  "training.", UserWarning, stacklevel=2)
         if self.gate_feature_head:
             flags |= _lib.PR_FLAG_GATE_HEAD      # honoured by the library for unperturbed evaluation calls only
 

@@ -187,34 +187,88 @@ class OverlappedGradientAllReduce:
     calls its ``gradient_hooks`` with the flat buffer all its parameter gradients are views of, as soon as ``pr_render_backward`` is
     enqueued - i.e. before autograd walks on into whatever produced the renderer's inputs (the object / pose encoders' CNN backward in
     the reference's trainers, training/trainer.py).  The collective runs on the backend's stream behind the renderer's kernels and
-    overlaps that tail; ``finish()`` (call it where ``allreduce_gradients`` would go, before ``optimizer.step()``) waits for it and
-    averages.  One flat message: a ring over point-to-point xGMI links is per-link bound, few large collectives are the cheap ones.
+    overlaps that tail; ``finish()`` (call it where ``allreduce_gradients`` would go, before ``optimizer.step()`` and before anything
+    else reads the gradients) waits for it and averages.  One flat message: a ring over point-to-point xGMI links is per-link
+    bound, few large collectives are the cheap ones.
+
+    The in-place, in-flight reduction is only sound when autograd then ADOPTS the buffer's views as ``p.grad`` - ONE differentiable
+    composer call per ``backward()`` into empty gradients (``zero_grad(set_to_none=True)``, no ``create_graph``, no tensor hooks on the
+    parameters): the overlapped case.  Everything else - a second composer call in the same graph (train-mode
+    ``batchified_composer_call`` makes one per ray chunk), gradient accumulation over micro-batches - is detected when the hook
+    fires: such a buffer is NOT reduced in flight (autograd is about to ADD it to gradients that exist or are being reduced; the
+    adds are ordered behind the collective already started), it is kept, and ``finish()`` reduces it and corrects the accumulated
+    gradient by (reduced - local).  The result is the same in every case: ``p.grad`` = what ``allreduce_gradients`` after
+    ``backward()`` would have left.
 
     >>> overlap = OverlappedGradientAllReduce(model.object_composer)
     >>> loss.backward(); overlap.finish(); allreduce_gradients(other_parameters); optimizer.step()"""
 
     def __init__(self, composer, group=None, average: bool = True):
         self.group, self.average = group, average
-        self.pending: List[tuple] = []
+        self.pending: List[tuple] = []       # (work, flat): reduced in place, in flight since the hook fired
+        self.late: List[torch.Tensor] = []   # buffers autograd accumulates unreduced: corrected in finish()
         self.launched = 0
+        self.deferred = 0
         composer.gradient_hooks.append(self._launch)
         self._composer = composer
+
+    def _parameters(self) -> List[torch.Tensor]:
+        return [p for p in self._composer._parameter_list() if p.requires_grad]
 
     def _launch(self, flat: torch.Tensor) -> None:
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
-        self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
-        self.launched += 1
+        adopts = (not self.pending and not self.late and not torch.is_grad_enabled() and
+                  all(p.grad is None and not p._backward_hooks for p in self._parameters()))
+        if adopts:
+            self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
+            self.launched += 1
+            return
+        for work, _ in self.pending:
+            work.wait()          # (the current stream waits: autograd's accumulation into the adopted buffer runs behind the collective)
+        self.late.append(flat)
+        self.deferred += 1
 
     def finish(self) -> int:
-        """Waits for the collectives started since the last call (the current stream waits, not the host) and averages; returns
-        how many there were."""
-        done = len(self.pending)
+        """Waits for the collective started since the last call (the current stream waits, not the host), reduces what could not be
+        reduced in flight, and averages; returns how many buffers there were."""
+        done = len(self.pending) + len(self.late)
+        if not done:
+            return 0
+        world = dist.get_world_size(self.group)
+        scale = 1.0 / world if self.average else 1.0
         for work, flat in self.pending:
             work.wait()
+        params = self._parameters()
+        if not self.late:
+            # the overlapped case: p.grad are the views autograd adopted
+            (_, flat), = self.pending
+            shared = _shared_gradient_buffer(params)
+            if shared is None or shared.data_ptr() != flat.data_ptr() or shared.numel() != flat.numel():
+                raise RuntimeError("OverlappedGradientAllReduce: the parameter gradients are not the buffer whose all-reduce was started "
+                                   "inside backward() (something replaced or copied p.grad before finish()): call finish() right after "
+                                   "backward(), or use parallel.allreduce_gradients")
             if self.average:
-                flat /= dist.get_world_size(self.group)
-        self.pending = []
+                flat *= scale
+        else:
+            # p.grad = [sum over ranks of the in-flight buffer, if any] + [gradients from before, already final] + the late buffers'
+            # LOCAL values.  Rescale the first part, then swap every late buffer's local value for its reduced one.
+            if self.pending and self.average:
+                # (p.grad holds nothing from before: the in-flight collective only starts into empty gradients)
+                torch._foreach_mul_([p.grad for p in params], scale)
+            for flat in self.late:
+                reduced = flat.clone()
+                dist.all_reduce(reduced, op=dist.ReduceOp.SUM, group=self.group)
+                # correction = scale * reduced - (what autograd added: the local buffer, already rescaled above when there was an
+                # in-flight part)
+                reduced.mul_(scale).sub_(flat, alpha=scale if (self.pending and self.average) else 1.0)
+                offset = 0
+                for p in params:
+                    p.grad.add_(reduced[offset:offset + p.numel()].view_as(p))
+                    offset += p.numel()
+                if offset != flat.numel():
+                    raise RuntimeError("OverlappedGradientAllReduce: the composer's trainable parameters changed during backward()")
+        self.pending, self.late = [], []
         return done
 
     def remove(self) -> None:

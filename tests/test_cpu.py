@@ -285,13 +285,88 @@ def test_abi_error_paths_without_a_device(built_library):
 
 
 def test_unsupported_configuration_is_rejected_loudly(built_library):
+    """The C ABI refuses a model it has no kernel for (a struct edited behind the host layer's back) ..."""
     cfg = configs.tennis_config()
-    m = dict(cfg["model"]["object_models"][0])
-    m["nerf_model"] = dict(m["nerf_model"], layers_width=512)
-    _, s = _model_struct_host(m, 4)
+    _, s = _model_struct_host(cfg["model"]["object_models"][0], 4)
+    s.layers_width = 512
     size = C.c_size_t()
     assert built_library.pr_packed_size(C.byref(s), C.byref(size)) != 0
     assert b"layers_width" in built_library.pr_last_error()
+
+
+def _edited(cfg, path, value):
+    import copy
+    out = copy.deepcopy(cfg)
+    cur = out
+    for key in path[:-1]:
+        cur = cur[key]
+    cur[path[-1]] = value
+    return out
+
+
+@pytest.mark.parametrize("path, value, needle", [
+    (("model", "object_models", 2, "nerf_model", "layers_width"), 512, "['nerf_model']['layers_width'] = 512"),
+    (("model", "object_models", 2, "nerf_model", "layers_width"), 257, "['nerf_model']['layers_width'] = 257"),
+    (("model", "object_models", 0, "nerf_model", "backbone_layers_count"), 13, "['backbone_layers_count'] = 13"),
+    (("model", "object_models", 0, "nerf_model", "position_encoder", "octaves"), 17, "['position_encoder']['octaves'] = 17"),
+    (("model", "object_models", 1, "nerf_model", "position_encoder", "append_original"), False, "['append_original'] = False"),
+    (("model", "object_models", 2, "ray_bender_model", "layers_width"), 288, "['ray_bender_model']['layers_width'] = 288"),
+    (("model", "object_models", 2, "ray_bender_model", "layers_count"), 13, "['ray_bender_model']['layers_count'] = 13"),
+    (("model", "object_models", 2, "ray_bender_model", "position_encoder", "octaves"), 20, "['ray_bender_model']['position_encoder']['octaves'] = 20"),
+    (("model", "object_models", 2, "ray_bender_model", "position_encoder", "append_original"), False, "['ray_bender_model']['position_encoder']"),
+    (("model", "object_models", 3, "nerf_model", "output_features"), 64, "['output_features'] differ"),
+    (("model", "object_parameters_encoder", 2, "objects_count"), 7, "add up to 10 object instances"),
+])
+def test_kernel_limits_are_checked_at_construction(path, value, needle):
+    """... and the host layer says so at CONSTRUCTION, with the configuration key in the message - not at the first render
+    (model/nerf_models/adain_style_nerf_model.py:24-45 and model/positional_encoder.py:41-65 accept any width / depth / octave
+    count; these are the limits of the kernels behind include/playrender.h, listed in INTEGRATION.md)."""
+    cfg = configs.tennis_config()
+    with pytest.raises(ValueError) as err:
+        ObjectComposer(_edited(cfg, path, value))
+    assert needle in str(err.value), str(err.value)
+    with pytest.raises(ValueError):
+        from playableenvironments_amd.environment_model import EnvironmentModel
+        EnvironmentModel(_edited(cfg, path, value))
+
+
+def test_construction_limits_agree_with_the_library(built_library):
+    """The host-side limits cannot drift from the library's: for a sweep of widths / depths / octave counts the constructor accepts
+    exactly the models ``pr_packed_size`` (csrc/mlp.hip compute_dims) accepts."""
+    from playableenvironments_amd.object_composer import validate_config_limits
+    base = configs.tennis_config()
+    _, s0 = _model_struct_host(base["model"]["object_models"][2], 8)
+    cases = [("layers_width", w) for w in (1, 2, 31, 200, 224, 225, 256, 257, 288)] + \
+            [("backbone_layers_count", c) for c in (1, 2, 12, 13)] + [("octaves", o) for o in (0, 10, 16, 17)] + \
+            [("output_features", f) for f in (1, 3, 256, 257)] + [("bender_width", w) for w in (1, 64, 256, 257)] + \
+            [("bender_count", c) for c in (1, 2, 12, 13)] + [("bender_octaves", o) for o in (0, 6, 16, 17)]
+    host_keys = {"layers_width": ("nerf_model", "layers_width"), "backbone_layers_count": ("nerf_model", "backbone_layers_count"),
+                 "octaves": ("nerf_model", "position_encoder", "octaves"), "output_features": ("nerf_model", "output_features"),
+                 "bender_width": ("ray_bender_model", "layers_width"), "bender_count": ("ray_bender_model", "layers_count"),
+                 "bender_octaves": ("ray_bender_model", "position_encoder", "octaves")}
+    for field, value in cases:
+        cfg = _edited(base, ("model", "object_models", 2) + host_keys[field], value)
+        if field == "output_features":      # (keep the objects' feature counts equal: that is a composer rule, not a kernel limit)
+            for i in range(4):
+                cfg = _edited(cfg, ("model", "object_models", i, "nerf_model", "output_features"), value)
+        if field in ("backbone_layers_count", "bender_count"):      # (keep the skip index inside the stack)
+            cfg = _edited(cfg, ("model", "object_models", 2) + host_keys[field][:1] + ("skip_layer_idx",), 1)
+        try:
+            validate_config_limits(cfg)
+            host_ok = True
+        except ValueError:
+            host_ok = False
+        s = type(s0).from_buffer_copy(s0)        # (ctypes structure: a byte copy)
+        struct_field = {"backbone_layers_count": "backbone_count"}.get(field, field)
+        assert struct_field in dict(type(s)._fields_)
+        setattr(s, struct_field, value)
+        if field == "backbone_layers_count":
+            s.skip_layer_idx = 1
+        if field == "bender_count":
+            s.bender_skip = 1
+        size = C.c_size_t()
+        lib_ok = built_library.pr_packed_size(C.byref(s), C.byref(size)) == 0
+        assert host_ok == lib_ok, (field, value, host_ok, built_library.pr_last_error())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -491,6 +566,124 @@ def test_gradient_allreduce_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert results[0] and results[1]
+
+
+class _HookedRender(torch.autograd.Function):
+    """What ObjectComposer's autograd node does with its parameter gradients: views of ONE flat buffer, handed to the composer's
+    ``gradient_hooks`` before they are returned to autograd.  out = sum_i (i + 1) * sum(x) * sum(p_i)."""
+
+    @staticmethod
+    def forward(ctx, composer, x, *params):
+        ctx.composer, ctx.params, ctx.scale = composer, params, float(x.sum())
+        return sum((i + 1) * ctx.scale * p.sum() for i, p in enumerate(params))
+
+    @staticmethod
+    def backward(ctx, grad):
+        flat = torch.zeros(sum(p.numel() for p in ctx.params))
+        views, offset = [], 0
+        for i, p in enumerate(ctx.params):
+            v = flat[offset:offset + p.numel()].view(p.shape)
+            v.fill_((i + 1) * ctx.scale * float(grad))
+            views.append(v)
+            offset += p.numel()
+        for hook in ctx.composer.gradient_hooks:
+            hook(flat)
+        return (None, None) + tuple(views)
+
+
+class _HookedComposer:
+    def __init__(self):
+        torch.manual_seed(0)
+        self.params = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+        self.gradient_hooks = []
+
+    def _parameter_list(self):
+        return self.params
+
+    def __call__(self, x):
+        return _HookedRender.apply(self, x, *self.params)
+
+
+def _overlap_worker(rank, world, port, results):
+    import torch.distributed as dist
+    from playableenvironments_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comp = _HookedComposer()
+        overlap = parallel.OverlappedGradientAllReduce(comp)
+        xs = [torch.full((2,), float(rank + 1 + j)) for j in range(3)]       # rank-dependent inputs: rank-dependent gradients
+
+        def mean_scale(js):            # gradient of p_i = (i + 1) * sum_j sum(x_j), averaged over the ranks
+            return sum(sum(2.0 * (r + 1 + j) for j in js) for r in range(world)) / world
+
+        def check(total, what):
+            for i, p in enumerate(comp.params):
+                assert torch.allclose(p.grad, torch.full_like(p, (i + 1) * total)), (what, i, p.grad.flatten()[:2], (i + 1) * total)
+
+        # (1) one call into empty gradients: reduced in flight, in place
+        comp(xs[0]).backward()
+        assert overlap.finish() == 1 and overlap.launched == 1 and overlap.deferred == 0
+        check(mean_scale([0]), "one call")
+        assert parallel._shared_gradient_buffer(comp.params) is not None
+        # (2) gradient accumulation: a second backward() into the gradients of (1)
+        comp(xs[1]).backward()
+        assert overlap.finish() == 1 and overlap.launched == 1 and overlap.deferred == 1
+        check(mean_scale([0]) + mean_scale([1]), "accumulation")
+        # (3) several composer calls in ONE graph (train-mode ray chunks): the first is reduced in flight, the others corrected
+        for p in comp.params:
+            p.grad = None
+        (comp(xs[0]) + comp(xs[1]) + comp(xs[2])).backward()
+        assert overlap.finish() == 3 and overlap.launched == 2 and overlap.deferred == 3
+        check(mean_scale([0, 1, 2]), "three calls in one graph")
+        # (4) a tensor hook on a parameter: autograd does not adopt the buffer's view - nothing is reduced in flight
+        for p in comp.params:
+            p.grad = None
+        handle = comp.params[1].register_hook(lambda g: g * 1.0)
+        comp(xs[2]).backward()
+        assert overlap.finish() == 1 and overlap.launched == 2
+        check(mean_scale([2]), "tensor hook")
+        handle.remove()
+        # (5) sums instead of averages; nothing pending: finish() is a no-op
+        for p in comp.params:
+            p.grad = None
+        overlap.remove()
+        overlap = parallel.OverlappedGradientAllReduce(comp, average=False)
+        (comp(xs[0]) + comp(xs[1])).backward()
+        assert overlap.finish() == 2 and overlap.finish() == 0
+        check(mean_scale([0, 1]) * world, "sum")
+        # (6) gradients replaced behind the collective's back: refused, not silently wrong
+        for p in comp.params:
+            p.grad = None
+        comp(xs[0]).backward()
+        comp.params[0].grad = comp.params[0].grad.clone()
+        try:
+            overlap.finish()
+            raise AssertionError("finish() accepted gradients that are not the reduced buffer")
+        except RuntimeError as e:
+            assert "not the buffer" in str(e)
+        results[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_guards_world2_gloo():
+    """parallel.OverlappedGradientAllReduce (the all-reduce started inside backward()) on two gloo ranks, driven by an autograd node
+    that hands out its gradients the way ObjectComposer's does: the overlapped single-call case, gradient accumulation, several
+    composer calls in one graph (train-mode ray chunks), a parameter with a tensor hook, sums - always the gradients
+    ``allreduce_gradients`` after ``backward()`` would leave."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = ctx.Manager().dict()
+    port = 29650 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, results)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert results.get(0) and results.get(1)
 
 
 def test_tile_shard_lists_partition_the_pixel_list():
