@@ -138,33 +138,49 @@ def run_world(world, write):
             grads.update({"decoder." + n: p.grad.clone() for n, p in model.autoencoder_model.named_parameters() if p.grad is not None})
             return total.detach(), info, grads, encodings
 
-        out = {}
+        def float64_iteration(seed):
+            mine.load_state_dict(states["mine"])
+            mine.double()
+            try:
+                with oracle_in_float64(), check_dropin._Float32Draws():
+                    return iteration("mine", mine, seed, _Batch(to_double(tensors)))
+            finally:
+                mine.float()
+                mine.load_state_dict(states["mine"])
+
+        # The seed of the compared iteration: (a) no object's BatchNorm is left with one sample (both sides raise: next seed);
+        # (b) the float64 run of the SAME iteration makes the same discrete choices - the weighted patch sampler compares pixel
+        # centres with box edges, and in float64 a box edge can fall on the other side of a pixel: the patch moves, the float64
+        # gradients belong to another patch and "no farther from float64 than the reference" would compare both fp32 sides with
+        # something unrelated (seen on minecraft with seed 41: both sides 1.02 of the largest gradient away).  Such a seed is
+        # SKIPPED BY NAME, not passed.
+        out, exact = {}, None
         seed = None
-        for candidate in range(41, 70):       # (a patch that leaves an object's BatchNorm one sample raises on both sides: next seed)
+        skipped = []
+        for candidate in range(41, 70):
+            for side, model in (("ref", ref), ("mine", mine)):
+                model.load_state_dict(states[side])
             try:
                 out["ref"] = iteration("ref", ref, candidate)
             except ValueError:
-                ref.load_state_dict(states["ref"])
+                skipped.append((candidate, "an object's train-mode BatchNorm saw one sample"))
                 continue
             out["mine"] = iteration("mine", mine, candidate)
+            exact = float64_iteration(candidate)
+            if abs(float(exact[0]) - float(out["mine"][0])) > 1e-4 * abs(float(out["mine"][0])):
+                skipped.append((candidate, f"the float64 run sampled another patch (loss {float(exact[0]):.6f} vs {float(out['mine'][0]):.6f})"))
+                continue
             seed = candidate
             break
-        assert seed is not None
+        assert seed is not None, skipped
+        print(f"[consumers, {world}] iteration seed {seed}" + ("".join(f"; seed {c} skipped: {why}" for c, why in skipped)))
         info_ref, info_mine = out["ref"][1], out["mine"][1]
         keys_same = sorted(info_ref) == sorted(info_mine)
         worst_info = max(abs(float(info_ref[k]) - float(info_mine[k])) / max(abs(float(info_ref[k])), 1e-3) for k in info_ref) if keys_same else float("inf")
         print(f"[consumers, {world}] compute_losses: {len(info_ref)} loss_info entries, same keys: {keys_same}, worst relative difference "
               f"{worst_info:.2e}; total loss {float(out['ref'][0]):.6f} / {float(out['mine'][0]):.6f}")
         ok &= keys_same and worst_info < 2e-3
-        # gradients of the total loss: float64 arbitration, as in check_dropin.py
-        mine.load_state_dict(states["mine"])
-        mine.double()
-        try:
-            with oracle_in_float64(), check_dropin._Float32Draws():
-                exact = iteration("mine", mine, seed, _Batch(to_double(tensors)))
-        finally:
-            mine.float()
-            mine.load_state_dict(states["mine"])
+        # gradients of the total loss: float64 arbitration, as in check_dropin.py (a float64 run that made the SAME discrete choices)
         same_sets = set(out["ref"][2]) == set(out["mine"][2]) == set(exact[2])
         farther, err = {}, {"ref": 0.0, "mine": 0.0}
         if same_sets:
@@ -185,10 +201,9 @@ def run_world(world, write):
               f"arbitration: worst error relative to the group's largest gradient - reference {err['ref']:.2e}, swapped model "
               f"{err['mine']:.2e}; farther than 4 x the reference: {farther}")
         ok &= same_sets and not farther
-        # the float64 run is only an arbiter while it makes the same discrete choices (the weighted patch sampler compares pixel
-        # centres with box edges: in float64 a box edge can fall on the other side of a pixel and the patch moves - seen on minecraft);
-        # the direct yardstick stands beside it: relative L2 difference of all gradients of a group between the two fp32 sides
+        # the direct yardstick stands beside the arbitration: relative L2 difference of all gradients of a group between the two fp32 sides
         same_choices = abs(float(exact[0]) - float(out["mine"][0])) <= 1e-4 * abs(float(out["mine"][0]))
+        ok &= same_choices and max(err.values()) < 5e-2          # (an arbiter 100 % away from both sides arbitrates nothing)
         l2 = {}
         for prefix in ("composer.", "decoder."):
             names = [n for n in out["ref"][2] if n.startswith(prefix)]

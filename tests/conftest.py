@@ -32,3 +32,19 @@ def _poisoned_device_memory(request):
             from tests.helpers import poison_device_memory
             poison_device_memory()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _settlement_log(request):
+    """Every forward-field excess the gradient harness SETTLED (float64 arbitration / divergence kink) during a test goes to the
+    file named by PR_SETTLEMENT_LOG with the test's id - how profiles/r05_settlements.log was recorded."""
+    yield
+    path = os.environ.get("PR_SETTLEMENT_LOG")
+    module = sys.modules.get("tests.test_gpu")
+    if module is None or not getattr(module, "SETTLEMENTS", None):
+        return
+    entries = module.drain_settlements()
+    if path:
+        with open(path, "a") as f:
+            for e in entries:
+                f.write(f"{request.node.nodeid} {e}\n")
