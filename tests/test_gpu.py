@@ -2427,12 +2427,14 @@ def test_data_parallel_wrapper_matches_the_plain_call():
     with torch.no_grad():
         plain = model(*args, 0, False, 1200, **kw)
     comp = model.object_composer
-    structs_before, workspace_before = dict(comp._structs), comp._workspace
     for ids in ([0], [0, 0]):
         wrapped = torch.nn.DataParallel(model, device_ids=ids)
+        structs_before, workspace_before, packed_before = dict(comp._structs), comp._workspace, dict(comp._packed)
         with torch.no_grad():
             got = wrapped(*args, 0, False, 1200, **kw)
         torch.cuda.synchronize()
+        if len(ids) > 1:      # the replicas used their OWN pointer structs / packed weights / workspace: the original's are untouched
+            assert comp._workspace is workspace_before and comp._structs == structs_before and comp._packed == packed_before
         a, b = dict(_flat_tensors(got)), dict(_flat_tensors(plain))
         assert sorted(k for k in a if k != "pytorch_hook") == sorted(k for k in b if k != "pytorch_hook")
         for k in b:
@@ -2440,7 +2442,6 @@ def test_data_parallel_wrapper_matches_the_plain_call():
                 continue
             x, y = torch.nan_to_num(a[k].float(), nan=-7.0), torch.nan_to_num(b[k].float(), nan=-7.0)
             assert x.shape == y.shape and torch.equal(x, y), (ids, k, float((x - y).abs().max()))
-    assert comp._workspace is workspace_before and comp._structs.keys() == structs_before.keys()      # replicas used their own
     # training: forward + backward through the wrapper = the sum over the replicas' chunks (one frame each)
     model.train()
     params = [p for p in comp.parameters() if p.requires_grad]
@@ -2669,24 +2670,31 @@ def _run_bench(argv, env, tmp_path):
     return line, full
 
 
-def test_bench_self_launches_two_ranks(tmp_path):
-    """`python bench.py --gpus 2` (no launcher): bench.py starts torch.distributed.run itself; with the PR_BENCH_DEVICE /
-    PR_BENCH_BACKEND knobs both ranks share this box's GPU over gloo.  One compact JSON line, n_gpus = 2, two per-rank times."""
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_self_launches_ranks(tmp_path, ranks):
+    """`python bench.py --gpus N` (no launcher): bench.py starts torch.distributed.run itself; with the PR_BENCH_DEVICE /
+    PR_BENCH_BACKEND knobs all N ranks share this box's GPU over gloo.  N = 8 is the driver's scaling run in miniature: one
+    compact JSON line (< 4 KB with eight rank_devices entries), both collectives of the feature exchange, the identical-frame
+    secondary, per-rank times - and every N-rank leg done within five minutes even with the eight ranks queueing on ONE GPU."""
+    import time
     env = dict(os.environ, PR_BENCH_DEVICE="0", PR_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    line, result = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--image", "64", "--no-cpu-baseline", "--no-split-precision"],
-                              env, tmp_path)
-    assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and line["distributed"]["backend"] == "gloo"
-    assert len(line["distributed"]["rank_devices"]) == 2
+    t0 = time.perf_counter()
+    line, result = _run_bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--image", "64", "--no-cpu-baseline",
+                               "--no-split-precision"], env, tmp_path)
+    elapsed = time.perf_counter() - t0
+    assert elapsed < 300.0, elapsed
+    assert line["n_gpus"] == ranks and line["distributed"]["world_size"] == ranks and line["distributed"]["backend"] == "gloo"
+    assert len(line["distributed"]["rank_devices"]) == ranks
     assert line["value"] > 0 and line["steps"] == 2
     assert line["feature_gather"]["all_gather_ms"] > 0 and line["feature_gather"]["gather_dst0_GB_per_s"] > 0
     assert line["summary"]["identical_frames_mrays"] > 0 and line["summary"]["train_step_ms"] > 0
-    assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == 2
-    assert result["train_step"]["parallelism"].startswith("data parallel x2")
+    assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == ranks
+    assert result["train_step"]["parallelism"].startswith(f"data parallel x{ranks}")
     # the exchange on its own, both collectives, and the identical-frame secondary beside the per-rank frames of the headline
     gather = result["feature_gather"]
-    assert gather["world_size"] == 2 and gather["bytes_per_rank"] == 64 * 64 * 192 * 4
+    assert gather["world_size"] == ranks and gather["bytes_per_rank"] == 64 * 64 * 192 * 4
     assert gather["all_gather"]["ms"] > 0 and gather["gather_dst0"]["receiving_ranks"] == 1
     assert result["identical_frames"]["value"] > 0 and "seed 1234 + r" in result["config"]["workload"]
     assert len(result["library_sha256"]) == 64
