@@ -1367,7 +1367,8 @@ def test_frame_graph_replay_is_bit_identical():
 
 
 #: rays of the seeded native frame whose drop-in render (matrices / rays built on the GPU) leaves the oracle's tolerance: measured
-NATIVE_FRAME_FLIPPED_RAYS = {("tennis", "fp32"): 57, ("tennis", "f16x3"): 57, ("minecraft", "fp32"): 57, ("minecraft", "f16x3"): 57}
+#: (round 5, MI355X: none - the GPU-built pose matrices and rays reproduce the CPU-built ones closely enough for every box decision)
+NATIVE_FRAME_FLIPPED_RAYS = {("tennis", "fp32"): 0, ("tennis", "f16x3"): 0, ("minecraft", "fp32"): 0, ("minecraft", "f16x3"): 0}
 
 
 @pytest.mark.parametrize("world", ["tennis", "minecraft"])
@@ -3163,28 +3164,36 @@ def test_generated_noise_is_independent_of_ray_chunking():
 # ---------------------------------------------------------------------------------------------------------------------
 # a fixed-seed slice of the randomized sweep (tests/gpu_fuzz.py: random network shapes, sample counts, frames, flags, absent
 # objects, both precisions; forward fields and every gradient against the oracle)
-SWEEP_OK_FLOOR_FORWARD, SWEEP_OK_FLOOR_BACKWARD = 30, 14      # recorded on the GPU box: see test_randomized_sweep_slice
+#: plain "ok" cases of the seed-0 slices as recorded on the MI355X box (round 5: see profiles/r05_sweep_*.log) minus two cases for
+#: run-to-run differences of atomically accumulated sums; and the most cases per slice whose FORWARD fields the harness may settle
+#: (float64 arbitration / divergence kink: tests.test_gpu.SETTLEMENTS - logged with their numbers, never silent)
+SWEEP_RECORDED_OK = {"forward": 40, "backward": 17, "backward_f16x3": 17}
+SWEEP_MAX_SETTLED = {"forward": 0, "backward": 2, "backward_f16x3": 2}
 
 
 @pytest.mark.parametrize("sweep,cases", [("forward", 40), ("backward", 20), ("backward_f16x3", 20)])
 def test_randomized_sweep_slice(sweep, cases, capsys, monkeypatch):
     import random
     from tests import gpu_fuzz
+    name = sweep
     run = gpu_fuzz.forward_sweep if sweep == "forward" else gpu_fuzz.backward_sweep
     if sweep == "backward_f16x3":        # the same backward slice on the split-precision training kernels (precision="f16x3")
         monkeypatch.setenv("PR_FUZZ_PRECISION", "f16x3")
-        sweep = "backward"
+    drain_settlements()
     failures = run(cases, random.Random(0))
     report = capsys.readouterr().out
+    if os.environ.get("PR_SWEEP_REPORT_DIR"):            # (how profiles/r05_sweep_*.log were recorded)
+        with open(os.path.join(os.environ["PR_SWEEP_REPORT_DIR"], f"sweep_{name}_{cases}_seed0.log"), "w") as f:
+            f.write(report)
     assert failures == 0, report[-4000:]
     plain = report.count("ok case")
-    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + report.count("divergence kink") + report.count("skipped")
+    settled = report.count("ok (forward ") + report.count("divergence kink")
+    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + settled + report.count("skipped")
     assert plain + classified == cases, report[-2000:]
-    # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floors = the
-    # plain-ok counts of seed 0 when the check was introduced (round 4: forward 40 / 40 of which hierarchical cases may need the
-    # float64 arbitration, backward 17 / 20), minus a margin of two cases for run-to-run differences of atomically accumulated sums
-    floor = {"forward": SWEEP_OK_FLOOR_FORWARD, "backward": SWEEP_OK_FLOOR_BACKWARD}[sweep]
-    assert plain >= floor, (plain, floor, report[-3000:])
+    # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floor = the
+    # plain-ok count recorded for this slice - 2; forward fields settled by arbitration / as a kink are capped per slice
+    assert plain >= SWEEP_RECORDED_OK[name] - 2, (plain, SWEEP_RECORDED_OK[name], report[-3000:])
+    assert settled <= SWEEP_MAX_SETTLED[name], (settled, report[-3000:])
 
 
 def test_object_entry_fields_extension():
