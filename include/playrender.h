@@ -489,6 +489,20 @@ int pr_probe_mfma_f32(int32_t iterations, int32_t random_operands, double* tflop
  * v_mfma_f32_32x32x16_f16 per step); TFLOP/s counts hardware fp16 FLOPs (3 per emulated fp32 FLOP). */
 int pr_probe_mfma_f16(int32_t iterations, int32_t random_operands, double* tflops, double* milliseconds, void* stream);
 
+/*
+ * Adam / AdamW update of ONE flat fp32 tensor in place - the arena every trainable parameter of the renderer is a view of
+ * (parallel.flatten_parameters).  Replaces, for that tensor, the optimiser step of the reference's trainers
+ * (torch.optim.Adam built at /root/reference/training/trainer.py:62-75 and stepped at :207-216): torch's fused multi-tensor
+ * kernel deals one block per 65 536 elements (32 blocks for the 2.1 M parameters of the minecraft renderers: 0.10 ms);
+ * this launch covers the tensor with one thread per four elements.  Arithmetic and update order of torch.optim.Adam
+ * (amsgrad = False): see csrc/optim.hip.  `step` = the step count AFTER this update (>= 1), by value; or `step_device`
+ * != NULL: a device float holding the count BEFORE the update, incremented on the stream first (optimisers recorded into a
+ * HIP graph).  grad_scale / found_inf: optional device floats of torch.amp.GradScaler (NULL: plain update).
+ */
+int pr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int32_t decoupled_weight_decay, int32_t maximize, double step, float* step_device,
+                 const float* grad_scale, const float* found_inf, void* stream);
+
 /* Library / device introspection. */
 int pr_abi_version(void);
 const char* pr_last_error(void);
