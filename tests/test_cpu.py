@@ -1253,6 +1253,21 @@ def test_trainer_loss_fixtures_present():
         assert all(np.isfinite(float(z[k])) for k in keys)
 
 
+def test_adam_step_rejects_bad_arguments_without_a_gpu():
+    """pr_adam_step validates before anything is enqueued (callable error paths on a box without a GPU)."""
+    lib = _lib.load()
+    assert lib.pr_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 0, 1.0, None, None, None, None) == 0     # nothing to do
+    assert lib.pr_adam_step(None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 0, 1.0, None, None, None, None) == -1
+    assert b"NULL pointer" in lib.pr_last_error()
+    assert lib.pr_adam_step(256, 256, 256, 256, 8, 1e-3, 1.0, 0.999, 1e-8, 0.0, 0, 0, 1.0, None, None, None, None) == -1
+    assert b"betas" in lib.pr_last_error()
+    assert lib.pr_adam_step(256, 256, 256, 256, 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 0, 0.0, None, None, None, None) == -1
+    assert b"step" in lib.pr_last_error()
+    from playableenvironments_amd import parallel
+    with pytest.raises(ValueError, match="amsgrad"):
+        parallel.ArenaAdam([torch.nn.Parameter(torch.zeros(2))], amsgrad=True)
+
+
 def test_scene_setup_rejects_bad_arguments_without_a_gpu():
     """pr_scene_setup (the fused scene set-up of an evaluation call) validates its sizes and pointers before anything is
     enqueued: callable error paths on a box without a GPU, like the renderer's (test_abi_error_paths)."""

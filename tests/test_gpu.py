@@ -2415,6 +2415,62 @@ def _tennis_model_and_args(batch, size=(32, 48)):
     return model.eval().cuda(), args
 
 
+@pytest.mark.parametrize("mode", ["adam", "adam_l2", "adamw", "maximize", "capturable"])
+def test_arena_adam_matches_torch_adam(mode):
+    """parallel.ArenaAdam (pr_adam_step: one full-grid launch per flat tensor) against torch.optim.Adam / AdamW on the same
+    parameters and gradients over several steps: parameters and both moment buffers to fp32 round-off (the formulas and their
+    order are torch's; torch's own fused kernel contracts multiply-adds, so bit identity is not the yardstick), odd sizes and
+    unaligned views included; optimiser state dictionaries move between the two."""
+    from playableenvironments_amd import parallel
+    torch.manual_seed(3)
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+    if mode == "adam_l2":
+        kw["weight_decay"] = 0.05
+    if mode == "maximize":
+        kw["maximize"] = True
+    theirs_cls = torch.optim.AdamW if mode == "adamw" else torch.optim.Adam
+    if mode == "adamw":
+        kw["weight_decay"] = 0.05
+    sizes = [1 << 20, 4099, 3]
+    storage = torch.randn(sum(sizes) + 1, device="cuda")
+    base, at = [], 1                                            # (views at an odd offset: not 16-byte aligned)
+    for n in sizes:
+        base.append(storage[at:at + n])
+        at += n
+    mine_p = [torch.nn.Parameter(b.clone()) for b in base]
+    theirs_p = [torch.nn.Parameter(b.clone()) for b in base]
+    mine_kw = dict(kw, decoupled_weight_decay=(mode == "adamw"), capturable=(mode == "capturable"))
+    mine = parallel.ArenaAdam(mine_p, **mine_kw)
+    theirs = theirs_cls(theirs_p, **kw)
+    for step in range(6):
+        for a, b in zip(mine_p, theirs_p):
+            g = torch.randn_like(a) * (10.0 ** (step - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        versions = [p._version for p in mine_p]
+        mine.step()
+        theirs.step()
+        assert all(p._version > v for p, v in zip(mine_p, versions))          # the raw-pointer update is visible to autograd
+        if step == 2:        # the state of one optimiser continues in the other
+            state = mine.state_dict()
+            assert sorted(state["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
+            other = parallel.ArenaAdam(mine_p, **mine_kw)
+            other.load_state_dict(theirs.state_dict())
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert torch.allclose(other.state[mine_p[0]][k], mine.state[mine_p[0]][k], rtol=1e-5, atol=1e-12)
+            assert float(other.state[mine_p[0]]["step"]) == float(mine.state[mine_p[0]]["step"]) == 3.0
+    torch.cuda.synchronize()
+    for a, b in zip(mine_p, theirs_p):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+        for k in ("exp_avg", "exp_avg_sq"):
+            x, y = mine.state[a][k], theirs.state[b][k]
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-12), (k, float((x - y).abs().max()))
+    assert float(mine.state[mine_p[0]]["step"]) == 6.0 and mine.state[mine_p[0]]["step"].is_cuda == (mode == "capturable")
+    with pytest.raises(RuntimeError, match="contiguous fp32 device tensors"):
+        bad = torch.nn.Parameter(torch.zeros(4))
+        bad.grad = torch.zeros(4)
+        parallel.ArenaAdam([bad]).step()
+
+
 def test_data_parallel_wrapper_matches_the_plain_call():
     """``nn.DataParallel(model)`` - how the reference wraps its model unconditionally (train.py:61; called as ``self.model(...)`` in
     training/trainer.py:148,630): ``device_ids=[0]`` (pass-through) and ``device_ids=[0, 0]`` (TWO replicas on this box's one GPU:
