@@ -922,7 +922,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                    int count) {
     PR_TRACE_MARK(0);
-    pr_stagger(32);
     mlp_tile_loop<false, true>(j0);
     PR_TRACE_MARK(1);
     if (count > 1) mlp_tile_loop<false, true>(j1);
@@ -942,7 +941,6 @@ extern "C" int pr_debug_mlp_trace(unsigned long long* out) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                          int count) {
-    pr_stagger(4);
     mlp_tile_loop<true, true>(j0);
     if (count > 1) mlp_tile_loop<true, true>(j1);
     if (count > 2) mlp_tile_loop<true, true>(j2);
@@ -952,7 +950,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 // phase 1 of a training call in split precision (PR_FLAG_SPLIT_BACKWARD): the same tile loop on fp16-pair segments (tile_products_f16x3_lean)
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group_split(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                               int count) {
-    pr_stagger(4);
     mlp_tile_loop<true, true, true>(j0);
     if (count > 1) mlp_tile_loop<true, true, true>(j1);
     if (count > 2) mlp_tile_loop<true, true, true>(j2);
@@ -1027,7 +1024,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
 // the same phase of several objects in one launch: a workgroup takes its strided share of every object's tiles in turn
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                    int count) {
-    pr_stagger(1);
     int first = (int)blockIdx.x;
     mlp_head_loop<true>(j0, first);
     if (count > 1) mlp_head_loop<true>(j1, first);

@@ -42,34 +42,6 @@ constexpr int MLP_WAVES = 4;      // 256 threads; every wave owns two 32-column 
 constexpr int MLP_BLOCKS_PER_CU = 2;   // two independent tiles per CU (LDS ~70 KB each): one computes while the other
                                        // is in a prologue / epilogue / barrier
 constexpr int MLP_THREADS = MLP_WAVES * 64;
-// Co-resident workgroups of the persistent tile kernels start together and run identical per-tile timelines (load - product -
-// epilogue - write-out): left alone they stay in LOCKSTEP - both load while the matrix pipes idle, both multiply while HBM idles.
-// pr_stagger(kernel bit) delays every second workgroup of a CU by about half a tile at the start of the launch so that one
-// tile's memory phases sit under the other's products.  PR_STAGGER_RULE picks "every second": 1 = the second dispatch wave
-// (block index >= grid / 2), 2 = bit 3 of the block index (the blocks of an XCD alternate), 0 = off.
-#ifndef PR_STAGGER_RULE
-#define PR_STAGGER_RULE 0
-#endif
-#ifndef PR_STAGGER_KERNELS
-#define PR_STAGGER_KERNELS 0      // 1 head forward phases, 2 head backward phases, 4 training forward phase 1, 8 backward chains, 16 divergence
-#endif
-#ifndef PR_STAGGER_SLEEPS
-#define PR_STAGGER_SLEEPS 2       // x 127 x 64 clocks (~3.4 us each)
-#endif
-__device__ __forceinline__ void pr_stagger(int kernel_bit) {
-#if PR_STAGGER_RULE != 0
-    if (!(PR_STAGGER_KERNELS & kernel_bit)) return;
-    const unsigned b = blockIdx.x;
-    const bool late = PR_STAGGER_RULE == 1 ? (b >= gridDim.x / 2) : (((b >> 3) & 1u) != 0u);
-    if (late) {
-#pragma unroll 1
-        for (int i = 0; i < PR_STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#else
-    (void)kernel_bit;
-#endif
-}
-
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
 constexpr int MAX_RESIDENT_TILES = 1024;   // upper bound of the persistent MLP grid (2 workgroups x CUs; 512 on MI355X)

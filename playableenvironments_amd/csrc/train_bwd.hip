@@ -531,7 +531,6 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
                                                                                    int count) {
-    pr_stagger(2);
     head_bwd_loop<0>(j0);
     if (count > 1) head_bwd_loop<0>(j1);
     if (count > 2) head_bwd_loop<0>(j2);
@@ -735,7 +734,6 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
                                                                                     int count) {
-    pr_stagger(8);
     chain_bwd_loop<0>(j0);
     if (count > 1) chain_bwd_loop<0>(j1);
     if (count > 2) chain_bwd_loop<0>(j2);
@@ -754,7 +752,6 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_gr
 // ... or (the default of PR_FLAG_SPLIT_BACKWARD) on fp16 pairs of the tile x a per-tile power of two (job.split == 2)
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group_f16(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,
                                                                                         int count) {
-    pr_stagger(8);
     chain_bwd_loop<2>(j0);
     if (count > 1) chain_bwd_loop<2>(j1);
     if (count > 2) chain_bwd_loop<2>(j2);
@@ -910,7 +907,6 @@ __device__ __forceinline__ void div_chain_loop(const DivChainJob& c) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_div_chain_group(DivChainJob j0, DivChainJob j1, DivChainJob j2, DivChainJob j3,
                                                                                     int count) {
-    pr_stagger(16);
     div_chain_loop(j0);
     if (count > 1) div_chain_loop(j1);
     if (count > 2) div_chain_loop(j2);

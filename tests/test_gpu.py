@@ -2456,14 +2456,15 @@ def test_arena_adam_matches_torch_adam(mode):
             other = parallel.ArenaAdam(mine_p, **mine_kw)
             other.load_state_dict(theirs.state_dict())
             for k in ("exp_avg", "exp_avg_sq"):
-                assert torch.allclose(other.state[mine_p[0]][k], mine.state[mine_p[0]][k], rtol=1e-5, atol=1e-12)
+                x, y = other.state[mine_p[0]][k], mine.state[mine_p[0]][k]
+                assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max())), (k, float((x - y).abs().max()))
             assert float(other.state[mine_p[0]]["step"]) == float(mine.state[mine_p[0]]["step"]) == 3.0
     torch.cuda.synchronize()
     for a, b in zip(mine_p, theirs_p):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
         for k in ("exp_avg", "exp_avg_sq"):
             x, y = mine.state[a][k], theirs.state[b][k]
-            assert torch.allclose(x, y, rtol=2e-6, atol=1e-12), (k, float((x - y).abs().max()))
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-6 * float(y.abs().max())), (k, float((x - y).abs().max()))
     assert float(mine.state[mine_p[0]]["step"]) == 6.0 and mine.state[mine_p[0]]["step"].is_cuda == (mode == "capturable")
     with pytest.raises(RuntimeError, match="contiguous fp32 device tensors"):
         bad = torch.nn.Parameter(torch.zeros(4))
@@ -3223,8 +3224,8 @@ def test_generated_noise_is_independent_of_ray_chunking():
 #: plain "ok" cases of the seed-0 slices as recorded on the MI355X box (round 5: see profiles/r05_sweep_*.log) minus two cases for
 #: run-to-run differences of atomically accumulated sums; and the most cases per slice whose FORWARD fields the harness may settle
 #: (float64 arbitration / divergence kink: tests.test_gpu.SETTLEMENTS - logged with their numbers, never silent)
-SWEEP_RECORDED_OK = {"forward": 40, "backward": 17, "backward_f16x3": 17}
-SWEEP_MAX_SETTLED = {"forward": 0, "backward": 2, "backward_f16x3": 2}
+SWEEP_RECORDED_OK = {"forward": 40, "backward": 17, "backward_f16x3": 17}      # (forward: 38 plain + 2 arbitrated in round 5)
+SWEEP_MAX_SETTLED = {"forward": 0, "backward": 1, "backward_f16x3": 1}       # (recorded: none in any slice)
 
 
 @pytest.mark.parametrize("sweep,cases", [("forward", 40), ("backward", 20), ("backward_f16x3", 20)])
