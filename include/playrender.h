@@ -418,6 +418,20 @@ typedef struct {
     uint8_t* present;                /* out (frames * cameras, objects): pr_call_t.object_in_scene */
 } pr_scene_setup_t;
 int pr_scene_setup(const pr_scene_setup_t* setup, void* stream);
+/*
+ * Backward of pr_scene_setup's renderer inputs, one launch (a TRAINING call through the fused scene set-up): the gradients
+ * pr_render_backward leaves in the renderer's layouts - g_w2o34 (frames x cameras, objects, 3, 4), g_style_nks (.., objects,
+ * S), g_deformation_nkd (.., objects, D); any may be NULL = zero - are summed over the cameras of a frame and taken to the
+ * scene tensors' layouts: g_rotations / g_translations (frames, 3, objects) through the pose matrices' backward (w2o is the
+ * rigid inverse of [R t; 0 1], R = Ry (Rx Rz): /root/reference/utils/lib_3d/transformations_3d.py:69-96 and torch.inverse at
+ * /root/reference/model/environment_model.py:221), g_style (frames, S, objects), g_deformation (frames, D, objects).  Outputs
+ * that are NULL are skipped (rotations and translations come together).  What torch.autograd does for the reference through
+ * ~150 small tensor ops (model/environment_model.py:206-232).
+ */
+int pr_scene_setup_backward(int32_t frames, int32_t cameras, int32_t objects, int32_t style_features, int32_t deformation_features,
+                            const float* object_rotations, const float* object_translations, const float* g_w2o34,
+                            const float* g_style_nks, const float* g_deformation_nkd, float* g_rotations, float* g_translations,
+                            float* g_style, float* g_deformation, void* stream);
 
 /*
  * Projects object-frame points into the cameras of their frame (EnvironmentModel.compute_object_bounding_boxes /

@@ -914,12 +914,9 @@ __device__ __forceinline__ float mat3_dot(const float* a, const float* b) {
 // Backward of k_pose_matrices: M = [R t; 0 1], M^-1 = [R^T u; 0 1] with u = -R^T t, R = Ry (Rx Rz).
 //   d loss / d R[k][a] = gM[k][a] + gInv[a][k] - t[k] gu[a],  d loss / d t = gM[:, 3] - R gu,
 //   d loss / d angle = <d loss / d R, d R / d angle>  with d R / d x = Ry (Rx' Rz), d R / d y = Ry' (Rx Rz), d R / d z = Ry (Rx Rz').
-__global__ void k_pose_matrices_bwd(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
-                                    const float* __restrict__ g_matrices, const float* __restrict__ g_inverses,
-                                    float* __restrict__ g_rotations, float* __restrict__ g_translations) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float ax = rotations[i * 3 + 0], ay = rotations[i * 3 + 1], az = rotations[i * 3 + 2];
+// gm / gv: 16-float gradients of the matrix / of its inverse (row-major 4 x 4; only the first three rows are read), or NULL
+__device__ __forceinline__ void pose_backward(float ax, float ay, float az, const float* t, const float* gm, const float* gv,
+                                              float* g_rot, float* g_tr) {
     const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay), cz = cosf(az), sz = sinf(az);
     const float rx[9] = {1.f, 0.f, 0.f, 0.f, cx, -sx, 0.f, sx, cx};
     const float ry[9] = {cy, 0.f, sy, 0.f, 1.f, 0.f, -sy, 0.f, cy};
@@ -930,27 +927,105 @@ __global__ void k_pose_matrices_bwd(int count, const float* __restrict__ rotatio
     float xz[9], r[9], tmp[9], d[9];
     mat3_mul(rx, rz, xz);
     mat3_mul(ry, xz, r);
-    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
-    const float* gm = g_matrices ? g_matrices + (size_t)i * 16 : nullptr;
-    const float* gv = g_inverses ? g_inverses + (size_t)i * 16 : nullptr;
-    float gu[3] = {0.f, 0.f, 0.f}, gr[9], gt[3];
+    float gu[3] = {0.f, 0.f, 0.f}, gr[9];
     if (gv)
         for (int a = 0; a < 3; ++a) gu[a] = gv[a * 4 + 3];
     for (int k = 0; k < 3; ++k) {
         for (int a = 0; a < 3; ++a) gr[k * 3 + a] = (gm ? gm[k * 4 + a] : 0.f) + (gv ? gv[a * 4 + k] : 0.f) - t[k] * gu[a];
-        gt[k] = (gm ? gm[k * 4 + 3] : 0.f) - (r[k * 3] * gu[0] + r[k * 3 + 1] * gu[1] + r[k * 3 + 2] * gu[2]);
+        g_tr[k] = (gm ? gm[k * 4 + 3] : 0.f) - (r[k * 3] * gu[0] + r[k * 3 + 1] * gu[1] + r[k * 3 + 2] * gu[2]);
     }
     mat3_mul(dx, rz, tmp);
     mat3_mul(ry, tmp, d);
-    g_rotations[i * 3 + 0] = mat3_dot(gr, d);
+    g_rot[0] = mat3_dot(gr, d);
     mat3_mul(dy, xz, d);
-    g_rotations[i * 3 + 1] = mat3_dot(gr, d);
+    g_rot[1] = mat3_dot(gr, d);
     mat3_mul(rx, dz, tmp);
     mat3_mul(ry, tmp, d);
-    g_rotations[i * 3 + 2] = mat3_dot(gr, d);
-    for (int k = 0; k < 3; ++k) g_translations[i * 3 + k] = gt[k];
+    g_rot[2] = mat3_dot(gr, d);
+}
+
+__global__ void k_pose_matrices_bwd(int count, const float* __restrict__ rotations, const float* __restrict__ translations,
+                                    const float* __restrict__ g_matrices, const float* __restrict__ g_inverses,
+                                    float* __restrict__ g_rotations, float* __restrict__ g_translations) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float t[3] = {translations[i * 3 + 0], translations[i * 3 + 1], translations[i * 3 + 2]};
+    float g_rot[3], g_tr[3];
+    pose_backward(rotations[i * 3 + 0], rotations[i * 3 + 1], rotations[i * 3 + 2], t, g_matrices ? g_matrices + (size_t)i * 16 : nullptr,
+                  g_inverses ? g_inverses + (size_t)i * 16 : nullptr, g_rot, g_tr);
+    for (int k = 0; k < 3; ++k) {
+        g_rotations[i * 3 + k] = g_rot[k];
+        g_translations[i * 3 + k] = g_tr[k];
+    }
+}
+
+// Backward of k_scene_setup's renderer inputs in ONE launch (a training call through the fused scene set-up): the gradients the
+// renderer's backward pass leaves in ITS layouts - d w2o (frames x cameras, objects, 3, 4), d style (.., objects, S), d deformation
+// (.., objects, D) - summed over the cameras of a frame and taken back to the scene tensors' layouts: d object rotations /
+// translations (frames, 3, objects) through pose_backward (w2o is the INVERSE of the pose matrix: gv), d style (frames, S, objects),
+// d deformation (frames, D, objects).  One workgroup per frame.  (As tensor ops: two zero fills, four permuting copies, the
+// pose-backward launch and its reshapes - ~10 launches of ~5 us at the end of every training step's backward pass.)
+struct SceneSetupBwd {
+    int frames, cameras, objects, S, D;
+    const float* obj_rot; const float* obj_tr;                                 // (frames, 3, objects)
+    const float* g_w2o34; const float* g_style_nks; const float* g_deformation_nkd;   // or NULL
+    float* g_rot; float* g_tr; float* g_style; float* g_deformation;          // (frames, 3 | 3 | S | D, objects); NULL: not wanted
+};
+__global__ __launch_bounds__(256) void k_scene_setup_bwd(SceneSetupBwd p) {
+    const int f = blockIdx.x, tid = threadIdx.x, K = p.objects, C = p.cameras;
+    if (tid < K && p.g_rot && p.g_tr) {
+        const int k = tid;
+        float gv[16];
+        for (int e = 0; e < 16; ++e) gv[e] = 0.f;
+        if (p.g_w2o34)
+            for (int c = 0; c < C; ++c) {
+                const float* src = p.g_w2o34 + (((size_t)f * C + c) * K + k) * 12;
+                for (int e = 0; e < 12; ++e) gv[e] += src[e];
+            }
+        const float* r = p.obj_rot + (size_t)f * 3 * K + k;
+        const float* tr = p.obj_tr + (size_t)f * 3 * K + k;
+        const float t[3] = {tr[0], tr[K], tr[2 * K]};
+        float g_rot[3], g_tr[3];
+        pose_backward(r[0], r[K], r[2 * K], t, nullptr, gv, g_rot, g_tr);
+        for (int a = 0; a < 3; ++a) {
+            p.g_rot[((size_t)f * 3 + a) * K + k] = g_rot[a];
+            p.g_tr[((size_t)f * 3 + a) * K + k] = g_tr[a];
+        }
+    }
+    if (p.g_style)
+        for (int e = tid; e < K * p.S; e += 256) {
+            const int k = e / p.S, s = e - k * p.S;
+            float acc = 0.f;
+            if (p.g_style_nks)
+                for (int c = 0; c < C; ++c) acc += p.g_style_nks[(((size_t)f * C + c) * K + k) * p.S + s];
+            p.g_style[((size_t)f * p.S + s) * K + k] = acc;
+        }
+    if (p.g_deformation)
+        for (int e = tid; e < K * p.D; e += 256) {
+            const int k = e / p.D, d = e - k * p.D;
+            float acc = 0.f;
+            if (p.g_deformation_nkd)
+                for (int c = 0; c < C; ++c) acc += p.g_deformation_nkd[(((size_t)f * C + c) * K + k) * p.D + d];
+            p.g_deformation[((size_t)f * p.D + d) * K + k] = acc;
+        }
 }
 }  // namespace pr
+
+extern "C" int pr_scene_setup_backward(int32_t frames, int32_t cameras, int32_t objects, int32_t style_features, int32_t deformation_features,
+                                       const float* object_rotations, const float* object_translations, const float* g_w2o34,
+                                       const float* g_style_nks, const float* g_deformation_nkd, float* g_rotations, float* g_translations,
+                                       float* g_style, float* g_deformation, void* stream) {
+    PR_REQUIRE(frames >= 0 && cameras > 0 && objects > 0 && objects <= PR_MAX_OBJECTS && style_features >= 0 && deformation_features >= 0,
+               "pr_scene_setup_backward: bad sizes");
+    if (frames == 0) return PR_OK;
+    PR_REQUIRE((g_rotations == nullptr) == (g_translations == nullptr), "pr_scene_setup_backward: rotation and translation gradients come together");
+    PR_REQUIRE(!g_rotations || (object_rotations && object_translations), "pr_scene_setup_backward: NULL pose pointer");
+    pr::SceneSetupBwd p{frames, cameras, objects, style_features, deformation_features, object_rotations, object_translations, g_w2o34,
+                        g_style_nks, g_deformation_nkd, g_rotations, g_translations, g_style, g_deformation};
+    hipLaunchKernelGGL(pr::k_scene_setup_bwd, dim3((unsigned)frames), dim3(256), 0, (hipStream_t)stream, p);
+    PR_LAUNCH_CHECK();
+    return PR_OK;
+}
 
 extern "C" int pr_pose_matrices_backward(int32_t count, const float* rotations, const float* translations, const float* g_matrices,
                                          const float* g_inverses, float* g_rotations, float* g_translations, void* stream) {

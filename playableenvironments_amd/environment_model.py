@@ -295,6 +295,52 @@ class _LazyGraph(torch.autograd.Function):
         return (None, None) + tuple(next(it) if t.requires_grad else None for t in inputs)
 
 
+class _SceneSetupGraph(torch.autograd.Function):
+    """Attaches the graph of a TRAINING call to the outputs of ``pr_scene_setup`` (one launch: pose matrices, projected boxes /
+    points / axes, the renderer's inputs in the renderer's layouts): the object poses, style and deformation codes carry a graph
+    (trainable encoders produce them), the cameras do not.  Backward: ``pr_scene_setup_backward`` - ONE launch from the renderer's
+    input gradients to d rotations / d translations / d style / d deformation; the projected boxes, points and axes get their
+    gradients (no shipped loss reads them) from the tensor formulation, recomputed only if one ever arrives (``_LazyGraph``)."""
+
+    @staticmethod
+    def forward(ctx, model, prepared, meta, object_rotations, object_translations, object_style, object_deformation):
+        ctx.model, ctx.meta = model, meta
+        ctx.save_for_backward(object_rotations, object_translations, object_style, object_deformation)
+        r = prepared["renderer"]
+        # (fresh tensor objects: the arena's views handed out as outputs of this node)
+        return (prepared["boxes"].view_as(prepared["boxes"]), prepared["box_points"].view_as(prepared["box_points"]),
+                prepared["axes"].view_as(prepared["axes"]), r["w2o"].view_as(r["w2o"]), r["style"].view_as(r["style"]),
+                r["deformation"].view_as(r["deformation"]))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_boxes, g_points, g_axes, g_w2o, g_style, g_deformation):
+        rot, tr, style, dfm = ctx.saved_tensors
+        frames, cameras, K, S, D = ctx.meta["frames"], ctx.meta["cameras"], ctx.meta["objects"], ctx.meta["S"], ctx.meta["D"]
+        need = ctx.needs_input_grad[3:]
+        dev = rot.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = torch.empty(frames * K * (6 + S + D), **f32)          # (one allocation for the four gradients)
+        g_rot = out[:frames * K * 3].view(rot.shape)
+        g_tr = out[frames * K * 3:frames * K * 6].view(tr.shape)
+        g_sty = out[frames * K * 6:frames * K * (6 + S)].view(style.shape)
+        g_dfm = out[frames * K * (6 + S):].view(dfm.shape)
+        keep = [t.contiguous() for t in (g_w2o, g_style, g_deformation) if t is not None]
+        it = iter(keep)
+        ptrs = [next(it).data_ptr() if t is not None else None for t in (g_w2o, g_style, g_deformation)]
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().pr_scene_setup_backward(frames, cameras, K, S, D, rot.data_ptr(), tr.data_ptr(), ptrs[0], ptrs[1], ptrs[2],
+                                                           g_rot.data_ptr(), g_tr.data_ptr(), g_sty.data_ptr(), g_dfm.data_ptr(),
+                                                           torch.cuda.current_stream(dev).cuda_stream), "pr_scene_setup_backward")
+        grads = [g_rot, g_tr, g_sty, g_dfm]
+        if g_boxes is not None or g_points is not None or g_axes is not None:
+            # a loss that reads the projected boxes / box points / axes: their gradients through the tensor formulation
+            extra = ctx.model._projection_gradients(ctx.meta, rot, tr, g_boxes, g_points, g_axes)
+            grads[0] = grads[0] + extra[0]
+            grads[1] = grads[1] + extra[1]
+        return (None, None, None) + tuple(g if n else None for g, n in zip(grads, need))
+
+
 class EnvironmentModel(Tracked, nn.Module):
 
     def __init__(self, config, object_encoders=None, object_parameters_encoders=None, image_decoder=None, grid_sampler=None):
@@ -590,6 +636,23 @@ class EnvironmentModel(Tracked, nn.Module):
                 "renderer": {"w2o": w2o34.view(n, K, 3, 4), "style": sty.view(n, K, S), "deformation": dfm.view(n, K, D),
                              "present": present, "frames": n, "S": S, "D": D}}
 
+    def _projection_gradients(self, meta, rotations, translations, g_boxes, g_points, g_axes):
+        """d (projected boxes, box points, axes) / d (object rotations, translations) for ``_SceneSetupGraph``: the differentiable
+        tensor formulation of the projections, recomputed on the saved inputs (only when a loss reads those outputs)."""
+        cam_rot, cam_tr, focals = meta["cameras_tensors"]
+        with torch.enable_grad():
+            rot = rotations.detach().requires_grad_(True)
+            tr = translations.detach().requires_grad_(True)
+            rescaled = focals * self.focal_length_multiplier
+            render_focals = rescaled if meta["upsample"] == 1.0 else rescaled * meta["upsample"]
+            _, w2c = pose_matrices(cam_rot, cam_tr)
+            _, o2w = self.compute_transformation_matrix_w2o_o2w(rot, tr)
+            boxes, points = self.compute_object_bounding_boxes(o2w, w2c, render_focals, meta["height"], meta["width"], _lazy=True)
+            axes = self.compute_object_axes_projection(o2w, w2c, rescaled, meta["height"], meta["width"], _lazy=True)
+            pairs = [(o, g) for o, g in ((boxes, g_boxes), (points, g_points), (axes, g_axes)) if g is not None]
+            got = torch.autograd.grad([o for o, _ in pairs], [rot, tr], [g.reshape(o.shape) for o, g in pairs], allow_unused=True)
+        return [g if g is not None else torch.zeros_like(t) for g, t in zip(got, (rotations, translations))]
+
     def compute_object_bounding_boxes(self, transformation_matrix_o2w, transformation_matrix_w2c, focals, height, width, _lazy=False):
         """Image-plane boxes (..., C, 4, K) [left, top, right, bottom] and projected box points
         (..., C, 68, 2, K), normalised to [0, 1].  model/environment_model.py:234-327."""
@@ -862,10 +925,22 @@ class EnvironmentModel(Tracked, nn.Module):
         height = int(image_size[0] * upsample_factor)
         width = int(image_size[1] * upsample_factor)
         prepared = None
-        if not torch.is_grad_enabled() and self.fused_scene_setup:
-            prepared = self._scene_setup(camera_rotations, camera_translations, focals, object_rotation_parameters_o2w,
-                                         object_translation_parameters_o2w, object_style, object_deformation, object_in_scene,
+        scene_graph = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in scene)
+        cameras_graph = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in scene[:3])
+        if self.fused_scene_setup and not cameras_graph:
+            # (learnable camera offsets - a graph on the cameras - take the tensor route below)
+            prepared = self._scene_setup(*[t.detach() if torch.is_tensor(t) else t for t in scene[:-1]], object_in_scene,
                                          height, width, upsample_factor)
+        if prepared is not None and scene_graph:
+            # a training call: the same launch, with the graph of the object poses / style / deformation attached to its outputs
+            renderer = prepared["renderer"]
+            meta = dict(frames=renderer["frames"] // camera_rotations.shape[-2], cameras=camera_rotations.shape[-2],
+                        objects=self.object_id_helper.objects_count, S=renderer["S"], D=renderer["D"], height=height, width=width,
+                        upsample=upsample_factor, cameras_tensors=(camera_rotations.detach(), camera_translations.detach(), focals.detach()))
+            boxes_g, points_g, axes_g, w2o_g, sty_g, dfm_g = _SceneSetupGraph.apply(
+                self, prepared, meta, object_rotation_parameters_o2w, object_translation_parameters_o2w, object_style, object_deformation)
+            prepared = dict(prepared, boxes=boxes_g, box_points=points_g, axes=axes_g,
+                            renderer=dict(renderer, w2o=w2o_g, style=sty_g, deformation=dfm_g))
         if prepared is not None:
             # one launch (pr_scene_setup): pose matrices, projected boxes / points / axes, the renderer's inputs in its layouts
             boxes, box_points, axes = prepared["boxes"], prepared["box_points"], prepared["axes"]

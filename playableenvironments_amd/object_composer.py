@@ -182,6 +182,9 @@ class _RenderFunction(torch.autograd.Function):
         # (an optimiser step, a GAN-style second network update) must raise, as torch's saved-tensor check would
         ctx.versions = tuple(p._version for p in composer._parameter_list())
         ctx.shapes = (w2o.shape, style.shape, deformation.shape)
+        # inputs in the RENDERER's layouts (EnvironmentModel's fused scene set-up: w2o (N, K, 3, 4), style (N, K, S), deformation
+        # (N, K, D)): their gradients are what pr_render_backward writes - no permuting copies on either side
+        ctx.prepared = kwargs.get("_prepared") is not None
         ctx.set_materialize_grads(False)      # outputs the loss does not read arrive as None, not as zero tensors
         holder["results"], holder["types"] = results, state["types"]
         flat, skip = [], []
@@ -285,9 +288,10 @@ class _RenderFunction(torch.autograd.Function):
             grads[id(p)] = flat[offset:offset + p.numel()].view(p.shape)
             offset += p.numel()
         ig = _lib.InputGrads()
-        d_w2o = torch.zeros((N, K, 3, 4), **f32)
-        d_style = torch.zeros((N, K, S), **f32)
-        d_def = torch.zeros((N, K, D), **f32)
+        small = torch.zeros(N * K * (12 + S + D), **f32)          # (one fill for the three input-gradient buffers)
+        d_w2o = small[:N * K * 12].view(N, K, 3, 4)
+        d_style = small[N * K * 12:N * K * (12 + S)].view(N, K, S)
+        d_def = small[N * K * (12 + S):].view(N, K, D)
         ig.w2o, ig.style, ig.deformation = d_w2o.data_ptr(), d_style.data_ptr(), d_def.data_ptr()
         d_ray_o = d_ray_d = None
         if ctx.ray_grads:
@@ -308,6 +312,11 @@ class _RenderFunction(torch.autograd.Function):
                    "pr_render_backward")
         for hook in composer.gradient_hooks:
             hook(flat)
+        if ctx.prepared:
+            ctx.state = None   # releases the forward workspace
+            if ctx.ray_grads:
+                d_ray_o, d_ray_d = d_ray_o.reshape(ctx.ray_shapes[0]), d_ray_d.reshape(ctx.ray_shapes[1])
+            return (None, None, None, d_ray_o, d_ray_d, d_w2o, d_style, d_def) + tuple(grads[id(p)] for p in ctx.params)
         lead = st["lead"]
         w_shape, s_shape, d_shape = ctx.shapes
         g_w2o = torch.zeros((N, 4, 4, K), **f32)
@@ -730,10 +739,22 @@ class ObjectComposer(Tracked, nn.Module):
         K = self.object_id_helper.objects_count
         self._raise_pending_batchnorm_check()
         if _prepared is not None:
-            # EnvironmentModel's fused scene set-up (pr_scene_setup) has produced the renderer's inputs in the renderer's layouts:
-            # an evaluation call without a graph
-            return self._render(ray_origins, ray_directions, focal_normals, None, style, deformation, object_in_scene, perturb,
-                                canonical_pose, _noise, _export, False, None, _decoder_layout, _prepared=_prepared)[0]
+            # EnvironmentModel's fused scene set-up (pr_scene_setup) has produced the renderer's inputs in the renderer's layouts
+            if not ray_directions.is_cuda:
+                raise RuntimeError("the HIP renderer needs device tensors (there is no CPU fallback)")
+            params = [p for p in self._parameter_list() if p.requires_grad] if torch.is_grad_enabled() else []
+            wants_grad = torch.is_grad_enabled() and (bool(params) or any(_prepared[k].requires_grad for k in ("w2o", "style", "deformation"))
+                                                      or ray_origins.requires_grad or ray_directions.requires_grad)
+            if not wants_grad:
+                return self._render(ray_origins, ray_directions, focal_normals, None, style, deformation, object_in_scene, perturb,
+                                    canonical_pose, _noise, _export, False, None, _decoder_layout, _prepared=_prepared)[0]
+            # a training call: the same autograd node; its w2o / style / deformation inputs ARE the prepared tensors, and their
+            # gradients come back in those layouts (EnvironmentModel's set-up node takes them to the scene tensors in one launch)
+            kwargs = dict(ray_origins=ray_origins, ray_directions=ray_directions, focal_normals=focal_normals,
+                          transformation_matrix_w2o=None, style=style, deformation=deformation, object_in_scene=object_in_scene,
+                          perturb=perturb, canonical_pose=canonical_pose, _noise=_noise, _export=_export, _decoder_layout=_decoder_layout,
+                          _prepared=_prepared)
+            return self._render_with_graph(kwargs, K, params)
         if transformation_matrix_w2o.size(-1) != K:
             raise Exception(f"Transformation matrix must specifies transformations for"
                             f"({transformation_matrix_w2o.size(-1)}) objects instead of ({K})")
@@ -756,8 +777,13 @@ class ObjectComposer(Tracked, nn.Module):
     def _render_with_graph(self, kwargs: dict, K: int, params) -> Dict:
         """One differentiable renderer call: the tensors of the result dictionary are the outputs of the autograd node."""
         holder = {}
-        flat = _RenderFunction.apply(self, kwargs, holder, kwargs["ray_origins"], kwargs["ray_directions"],
-                                     kwargs["transformation_matrix_w2o"], kwargs["style"], kwargs["deformation"], *params)
+        prepared = kwargs.get("_prepared")
+        if prepared is not None:
+            flat = _RenderFunction.apply(self, kwargs, holder, kwargs["ray_origins"], kwargs["ray_directions"], prepared["w2o"],
+                                         prepared["style"], prepared["deformation"], *params)
+        else:
+            flat = _RenderFunction.apply(self, kwargs, holder, kwargs["ray_origins"], kwargs["ray_directions"],
+                                         kwargs["transformation_matrix_w2o"], kwargs["style"], kwargs["deformation"], *params)
         results = holder["results"]
         i = 0
         for ty in holder["types"]:
@@ -799,9 +825,10 @@ class ObjectComposer(Tracked, nn.Module):
         dirs = ray_directions.detach().to(torch.float32).reshape(N, R, 3).contiguous()
         origins = torch.broadcast_to(ray_origins.detach().to(torch.float32), lead + [3]).reshape(N, 3).contiguous()
         if _prepared is not None:
-            if _prepared["frames"] != N or _save:
+            if _prepared["frames"] != N:
                 raise RuntimeError("prepared renderer inputs do not match the call")
-            w2o, sty, dfm, present = _prepared["w2o"], _prepared["style"], _prepared["deformation"], _prepared["present"]
+            w2o, sty, dfm, present = (_prepared["w2o"].detach(), _prepared["style"].detach(), _prepared["deformation"].detach(),
+                                      _prepared["present"])
             S, D = _prepared["S"], _prepared["D"]
         else:
             w2o = torch.broadcast_to(transformation_matrix_w2o.detach().to(torch.float32), lead + [4, 4, K])

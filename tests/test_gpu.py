@@ -1550,6 +1550,62 @@ def _same_results(a, b, what=""):
         assert torch.equal(x, y), (what, k, float((x.float() - y.float()).abs().max()))
 
 
+@pytest.mark.parametrize("world", ["tennis", "minecraft"])
+def test_fused_scene_setup_of_a_training_call(world):
+    """A TRAINING call through pr_scene_setup + pr_scene_setup_backward (one launch each instead of ~25 + ~10 small ones) against
+    the tensor route (``fused_scene_setup = False``: pr_pose_matrices with its autograd node, permuting copies, the composer's own
+    marshalling): every output and every gradient - object rotations / translations, style, deformation, the renderer's
+    parameters - bit for bit with one camera per observation (same launches in the renderer, the same pose-backward arithmetic);
+    and a loss that reads the projected boxes / axes gets the tensor formulation's gradients."""
+    cfg = configs.reduced_config(configs.tennis_config() if world == "tennis" else configs.minecraft_config(), **SMALL_NETS)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.5, bender_scale=1e4)
+    model = model.cuda().train()
+    make = synthetic.tennis_scene if world == "tennis" else synthetic.minecraft_scene
+    size = (64, 96)
+    scene = make(batch=2, observations=2, seed=17, image_size=size)
+    keys = ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation")
+    params = [p for p in model.object_composer.parameters() if p.requires_grad]
+
+    def run(fused, read_boxes):
+        model.fused_scene_setup = fused
+        sc = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in scene.items()}
+        for k in keys:
+            sc[k] = sc[k].clone().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        torch.manual_seed(5)
+        out = model(sc["camera_rotations"], sc["camera_translations"], sc["focals"], size, sc["object_rotation_parameters"],
+                    sc["object_translation_parameters"], sc["object_style"], sc["object_deformation"], sc["object_in_scene"],
+                    400, True, 0, patch_size=16, patch_stride=[2, 4], mode="scene_encodings")
+        g = out["coarse"]["global"]
+        loss = (g["integrated_features"] ** 2).mean() + g["opacity"].mean() + 0.1 * g["depth"].mean()
+        if read_boxes:
+            loss = loss + out["reconstructed_bounding_boxes"].square().mean() + out["projected_axes"].square().mean() + \
+                out["reconstructed_3d_bounding_boxes"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        fields = {k: out["coarse"]["global"][k].detach().clone() for k in ("integrated_features", "opacity", "depth")}
+        fields.update({k: out[k].detach().clone() for k in ("reconstructed_bounding_boxes", "projected_axes", "reconstructed_3d_bounding_boxes")})
+        return fields, {k: sc[k].grad.clone() for k in keys}, [p.grad.clone() for p in params]
+    for read_boxes in (False, True):
+        want = run(False, read_boxes)
+        got = run(True, read_boxes)
+        for k in want[0]:
+            assert torch.equal(torch.nan_to_num(got[0][k]), torch.nan_to_num(want[0][k])), (read_boxes, k)
+        for k in keys:
+            a, b = got[1][k], want[1][k]
+            assert a.shape == b.shape and float(b.abs().max()) > 0, k
+            if read_boxes and k in keys[:2]:      # (+ the projections' gradients: tensor ops on both sides, summed in another order)
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max())), (k, float((a - b).abs().max()))
+            else:
+                assert torch.equal(a, b), (read_boxes, k, float((a - b).abs().max()))
+        for a, b in zip(got[2], want[2]):
+            assert torch.equal(a, b)
+    model.fused_scene_setup = True
+
+
 def test_automatic_frame_replay():
     """``EnvironmentModel.frame_replay`` ("clone" by DEFAULT): the UNCHANGED evaluation calls (forward_from_scene_encoding with the
     strided grids - what the reference's autoencoder subclasses issue - and forward_from_observations) are recorded the second time a
