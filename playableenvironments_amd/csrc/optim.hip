@@ -45,9 +45,15 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
 
 __global__ __launch_bounds__(256) void k_adam_arena(AdamParams q) {
     if (q.found_inf != nullptr && *q.found_inf != 0.f) return;
-    const double t = q.step_device ? (double)*q.step_device : q.step;
-    const float bc1 = (float)(1.0 - pow((double)q.beta1, t));
-    const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)q.beta2, t)));
+    // the bias corrections: once per workgroup (two double-precision pow calls), not once per thread
+    __shared__ float corrections[2];
+    if (threadIdx.x == 0) {
+        const double t = q.step_device ? (double)*q.step_device : q.step;
+        corrections[0] = (float)(1.0 - pow((double)q.beta1, t));
+        corrections[1] = sqrtf((float)(1.0 - pow((double)q.beta2, t)));
+    }
+    __syncthreads();
+    const float bc1 = corrections[0], bc2_sqrt = corrections[1];
     const float step_size = q.lr / bc1;
     const float inv_scale = q.grad_scale ? 1.0f / *q.grad_scale : 1.0f;
     const long n4 = q.n >> 2;
@@ -97,9 +103,9 @@ extern "C" int pr_adam_step(float* param, const float* grad, float* exp_avg, flo
     }
     pr::AdamParams q{param, grad, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, decoupled_weight_decay, maximize,
                      step, step_device, grad_scale, found_inf};
-    long blocks = ((n >> 2) + 255) / 256;
+    long blocks = ((n >> 2) + 1023) / 1024;       // four float4 per thread
     if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pr::k_adam_arena, dim3((unsigned)blocks), dim3(256), 0, s, q);
     PR_LAUNCH_CHECK();
     return PR_OK;
