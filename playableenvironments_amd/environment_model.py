@@ -305,6 +305,7 @@ class _SceneSetupGraph(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, prepared, meta, object_rotations, object_translations, object_style, object_deformation):
         ctx.model, ctx.meta = model, meta
+        ctx.set_materialize_grads(False)      # outputs no loss reads (boxes, points, axes) arrive as None, not as zero tensors
         ctx.save_for_backward(object_rotations, object_translations, object_style, object_deformation)
         r = prepared["renderer"]
         # (fresh tensor objects: the arena's views handed out as outputs of this node)
