@@ -831,7 +831,8 @@ class EnvironmentModel(Tracked, nn.Module):
             decoder = tuple(t.data_ptr() for m in (self.image_decoder, self.grid_sampler) if isinstance(m, nn.Module)
                             for t in list(m.parameters()) + list(m.buffers()))
         return (tuple((p.data_ptr(), p._version) for p in params), tree, decoder, composer.precision, bool(composer.gate_feature_head),
-                composer.state_epoch, None if composer.object_entry_fields is None else tuple(composer.object_entry_fields),
+                composer.state_epoch, composer.weights_epoch,
+                None if composer.object_entry_fields is None else tuple(composer.object_entry_fields),
                 bool(self.fused_scene_setup), bool(composer.training), bool(composer.use_naive_mlp), float(self.focal_length_multiplier),
                 int(composer.max_workspace_bytes))
 

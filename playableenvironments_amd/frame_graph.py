@@ -119,7 +119,7 @@ class FrameGraph:
         # state_epoch counts set_step / load_state_dict / .to() calls (reading the step buffers back would synchronise)
         owner = composer if self.mode == "scene_encodings" else self.model       # (observations: the encoders' weights too)
         return (tuple((p.data_ptr(), p._version) for p in owner.parameters()), composer.precision,
-                bool(composer.gate_feature_head), composer.state_epoch,
+                bool(composer.gate_feature_head), composer.state_epoch, composer.weights_epoch,
                 None if composer.object_entry_fields is None else tuple(composer.object_entry_fields))
 
     def render(self, scene: Dict[str, torch.Tensor]) -> Dict:

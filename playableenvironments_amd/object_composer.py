@@ -312,6 +312,11 @@ class _RenderFunction(torch.autograd.Function):
                    "pr_render_backward")
         for hook in composer.gradient_hooks:
             hook(flat)
+        # parameter gradients exist now: an optimiser step is about to change the weights, and torch's FUSED optimisers
+        # (torch.optim.Adam(fused=True): torch._fused_adam_) update the storages WITHOUT moving the tensors' version counters
+        # (measured, tools/perf/dbg_version_counters.py) - the packed MFMA copies and recorded frames cannot key on them alone
+        if ctx.params:
+            composer.weights_epoch += 1
         if ctx.prepared:
             ctx.state = None   # releases the forward workspace
             if ctx.ray_grads:
@@ -351,6 +356,9 @@ class ObjectComposer(Tracked, nn.Module):
         self.object_id_helper = ObjectIDsHelper(self.config)
         #: bumped by set_step / load_state_dict / .to(): captured frame graphs compare it (frame_graph.FrameGraph)
         self.state_epoch = 0
+        #: bumped by every backward pass that produced parameter gradients (an optimiser step follows; torch's fused optimisers do
+        #: not move the parameters' version counters): the packed weights are re-made and recorded frames dropped when it moved
+        self.weights_epoch = 0
         self._packed: Dict[tuple, tuple] = {}
         self._param_lists: Dict[int, list] = {}      # id(module) -> list(module.parameters())
         self._structs: Dict[tuple, tuple] = {}       # (id(model), positions) -> (key, pr_object_model_t)
@@ -664,7 +672,7 @@ class ObjectComposer(Tracked, nn.Module):
         precision = self._precision_code(differentiable)
         if precision == _lib.PR_PRECISION_F16:
             precision = _lib.PR_PRECISION_F16X3      # the same fp16 (hi, lo) fragments; the kernel skips the lo halves
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (self.weights_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
         slot = (id(model), precision)   # one buffer per layout: a render at the other precision never evicts this one
         cached = self._packed.get(slot)
         if cached is not None and cached[0] == key:

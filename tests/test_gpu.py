@@ -2527,6 +2527,61 @@ def test_arena_adam_matches_torch_adam(mode):
         parallel.ArenaAdam([bad]).step()
 
 
+@pytest.mark.parametrize("optimizer", ["torch_fused_separate", "torch_fused_arena", "arena_adam", "torch_foreach"])
+def test_optimizer_steps_reach_the_next_render(optimizer):
+    """Training with the optimisers a trainer may build, ``torch.optim.Adam(fused=True)`` included: torch's fused optimisers update
+    the parameter storages WITHOUT moving the tensors' version counters (tools/perf/dbg_version_counters.py: values change,
+    ``_version`` stays) - the composer's packed MFMA weight copies and the recorded evaluation frames therefore also key on
+    ``weights_epoch`` (moved by every backward pass that produced parameter gradients).  After every step the training render,
+    an evaluation render and a RECORDED evaluation frame must show the new weights: equal to a freshly built composer holding
+    the same state."""
+    from playableenvironments_amd import parallel
+    from playableenvironments_amd.frame_graph import SCENE_KEYS
+    cfg = configs.reduced_config(configs.tennis_config(), **SMALL_NETS)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.0, bender_scale=1e4)
+    model = model.cuda()
+    comp = model.object_composer
+    size = (32, 48)
+    sc = {k: v.cuda() for k, v in synthetic.tennis_scene(batch=1, seed=9, image_size=size).items() if torch.is_tensor(v)}
+    args = [sc[k] for k in SCENE_KEYS[:3]] + [size] + [sc[k] for k in SCENE_KEYS[3:]]
+    arena = parallel.flatten_parameters(comp) if "arena" in optimizer else None
+    params = list(comp.parameters())
+    if optimizer == "torch_fused_separate":
+        opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+    elif optimizer == "torch_fused_arena":
+        opt = torch.optim.Adam([arena], lr=1e-2, fused=True)
+    elif optimizer == "arena_adam":
+        opt = parallel.ArenaAdam([arena], lr=1e-2)
+    else:
+        opt = torch.optim.Adam(params, lr=1e-2, foreach=True)
+
+    def fresh_eval():
+        other = em.EnvironmentModel(cfg).cuda().eval()
+        other.load_state_dict(model.state_dict())
+        other.frame_replay = None
+        with torch.no_grad():
+            return other(*args, 0, False, 0, patch_stride=[4, 8], mode="scene_encodings")["coarse"]["global"]["integrated_features"]
+    previous = None
+    for step in range(4):
+        model.train()
+        opt.zero_grad(set_to_none=True)
+        out = model(*args, 0, False, 0, patch_stride=[4, 8], mode="scene_encodings")
+        out["coarse"]["global"]["integrated_features"].square().mean().backward()
+        if arena is not None:
+            parallel.flat_gradient(arena, comp)
+        opt.step()
+        model.eval()
+        with torch.no_grad():        # (the default frame_replay: eager, recording, replay, replay ... across the optimiser steps)
+            got = model(*args, 0, False, 0, patch_stride=[4, 8], mode="scene_encodings")["coarse"]["global"]["integrated_features"]
+            again = model(*args, 0, False, 0, patch_stride=[4, 8], mode="scene_encodings")["coarse"]["global"]["integrated_features"]
+        want = fresh_eval()
+        assert torch.equal(got, want) and torch.equal(again, want), (optimizer, step, float((got - want).abs().max()))
+        assert previous is None or not torch.equal(want, previous), (optimizer, step)       # the step did change the render
+        previous = want
+
+
 def test_data_parallel_wrapper_matches_the_plain_call():
     """``nn.DataParallel(model)`` - how the reference wraps its model unconditionally (train.py:61; called as ``self.model(...)`` in
     training/trainer.py:148,630): ``device_ids=[0]`` (pass-through) and ``device_ids=[0, 0]`` (TWO replicas on this box's one GPU:
