@@ -295,6 +295,56 @@ class _LazyGraph(torch.autograd.Function):
         return (None, None) + tuple(next(it) if t.requires_grad else None for t in inputs)
 
 
+def _copy_out(results):
+    """A copy of a (nested) result dictionary whose tensors do not alias the originals - the recorded frame's static outputs ->
+    tensors the caller owns.  One allocation and ONE multi-tensor copy launch per dtype (``torch._foreach_copy_``) instead of a
+    ``clone()`` per tensor: a result dictionary holds ~60 tensors, and 60 launches of ~5 us are as long as the small frames
+    themselves.  The copies of a dtype are views of one flat buffer (disjoint regions)."""
+    tensors = []
+
+    def collect(x):
+        if torch.is_tensor(x):
+            tensors.append(x)
+        elif isinstance(x, dict):
+            for v in x.values():
+                collect(v)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                collect(v)
+    collect(results)
+    copies = {}
+    groups = {}
+    for t in tensors:
+        if id(t) in copies:
+            continue
+        if t.is_contiguous() and t.numel() > 0:
+            groups.setdefault((t.dtype, t.device), []).append(t)
+            copies[id(t)] = None
+        else:
+            copies[id(t)] = t.clone()
+    for (dtype, device), members in groups.items():
+        # every view starts at a multiple of 64 elements (>= 256 bytes for 4-byte types): aligned like separate allocations
+        offsets, at = [], 0
+        for t in members:
+            offsets.append(at)
+            at += (t.numel() + 63) // 64 * 64
+        flat = torch.empty(at, dtype=dtype, device=device)
+        views = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offsets, members)]
+        torch._foreach_copy_(views, members)
+        for t, v in zip(members, views):
+            copies[id(t)] = v
+
+    def rebuild(x):
+        if torch.is_tensor(x):
+            return copies[id(x)]
+        if isinstance(x, dict):
+            return {k: rebuild(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return type(x)(rebuild(v) for v in x)
+        return x
+    return rebuild(results)
+
+
 class _SceneSetupGraph(torch.autograd.Function):
     """Attaches the graph of a TRAINING call to the outputs of ``pr_scene_setup`` (one launch: pose matrices, projected boxes /
     points / axes, the renderer's inputs in the renderer's layouts): the object poses, style and deformation codes carry a graph
@@ -870,15 +920,7 @@ class EnvironmentModel(Tracked, nn.Module):
             return None
         results = entry[1].replay(tensors)
         if self.frame_replay == "clone":
-            def clone(x):
-                if torch.is_tensor(x):
-                    return x.clone()
-                if isinstance(x, dict):
-                    return {k: clone(v) for k, v in x.items()}
-                if isinstance(x, (list, tuple)):
-                    return type(x)(clone(v) for v in x)
-                return x
-            return clone(results)
+            return _copy_out(results)
         return results
 
     def _replay_wanted(self, tensors, perturb, samples_per_image) -> bool:
