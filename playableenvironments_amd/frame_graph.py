@@ -12,6 +12,8 @@ the weights (re-capture after an optimiser step or ``load_state_dict``), the com
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import os
 from typing import Dict, Tuple
 
@@ -27,6 +29,23 @@ SCENE_KEYS = ("camera_rotations", "camera_translations", "focals", "object_rotat
 #: path off the replays are correct (tests/graph_step_check.py) - and cost what eager launches cost on the device side, so
 #: what a recording buys is HOST time.  The switch has to be in the environment before the process makes its first HIP call.
 GRAPH_RUNTIME_SWITCH = ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+@contextlib.contextmanager
+def _no_collections_while_recording():
+    """Python's cyclic garbage collector can run at any allocation - also between the launches of a recording - and a
+    ``torch.cuda.CUDAGraph`` that dies there (an older recording kept alive by a reference cycle) calls hipGraphDestroy inside
+    the capture: "operation not permitted when stream is capturing", raised from a destructor, i.e. the process aborts (seen
+    with a deleted ``FrameGraph`` still pending collection when ``EnvironmentModel.frame_replay`` recorded its next frame).
+    Collect BEFORE the recording starts, keep the collector off during it."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def graph_runtime_is_safe() -> bool:
@@ -73,11 +92,13 @@ class FrameGraph:
         if mode == "scene_encodings":
             if image_size is None:
                 raise ValueError("mode='scene_encodings' needs image_size")
-            self._call = lambda: model(*[self.inputs[k] for k in SCENE_KEYS[:3]], image_size, *[self.inputs[k] for k in SCENE_KEYS[3:]],
+            inputs = self.inputs       # (the closure must not hold `self`: a reference cycle would leave the graph to the cyclic collector)
+            self._call = lambda: model(*[inputs[k] for k in SCENE_KEYS[:3]], image_size, *[inputs[k] for k in SCENE_KEYS[3:]],
                                        0, False, patch_stride=patch_stride, upsample_factor=upsample_factor,
                                        canonical_pose=canonical_pose, mode="scene_encodings", **extra)
         else:
-            self._call = lambda: model(*[self.inputs[k] for k in OBSERVATION_KEYS], 0, False, patch_stride=patch_stride,
+            inputs = self.inputs
+            self._call = lambda: model(*[inputs[k] for k in OBSERVATION_KEYS], 0, False, patch_stride=patch_stride,
                                        upsample_factor=upsample_factor, canonical_pose=canonical_pose, mode="observations", **extra)
         # warm-up on a side stream (packs the weights, sizes the workspace, fills the host-side caches, lets the convolution
         # library pick its algorithms), then capture
@@ -95,7 +116,7 @@ class FrameGraph:
             self._weights_version = self._signature()
             self.graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(self.graph), torch.no_grad():
+                with _no_collections_while_recording(), torch.cuda.graph(self.graph), torch.no_grad():
                     self.results = self._call()
             except BaseException:
                 # (a failed capture can take the process down when the half-built graph is destroyed: say why first)
@@ -152,7 +173,7 @@ class CapturedCall:
         self.graph = torch.cuda.CUDAGraph()
         # capture_error_mode="thread_local": other threads of the process (a DataLoader's pin-memory thread, a writer) keep making
         # HIP calls while this thread records - the default "global" mode would fail THEIR calls
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
+        with _no_collections_while_recording(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.results = fn(*self.inputs)
 
     def replay(self, tensors):
@@ -212,7 +233,7 @@ class GraphedStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _no_collections_while_recording(), torch.cuda.graph(self.graph):
             self.outputs = step_fn()
         self.replays = 0
         for c in self.composers:
