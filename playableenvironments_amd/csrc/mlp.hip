@@ -223,7 +223,10 @@ __global__ __launch_bounds__(256) void k_pack(PackJobs jobs) {
                 if (n < j.n_real && k < j.k_real)
                     w = ldexpf(j.transposed ? j.src[(size_t)k * j.in_total + j.col_off + n] : j.src[(size_t)n * j.in_total + j.col_off + k],
                                j.scale_log2);
-                w = fminf(fmaxf(w, -65504.0f), 65504.0f);      // (a scaled weight beyond fp16's range saturates instead of turning into inf)
+                // an UNSCALED weight beyond fp16's range (|w| > 65504: evaluation packing) saturates; a weight whose training-time
+                // scaled form w x 2^8 leaves the range (|w| >= 255.9) is left to overflow: hi = inf, lo = NaN - the step's outputs and
+                // gradients turn NaN, which a trainer notices, instead of silently training against a saturated copy of the weight
+                if (j.scale_log2 == 0) w = fminf(fmaxf(w, -65504.0f), 65504.0f);
                 const _Float16 hi = (_Float16)w;
                 const _Float16 lo = (_Float16)(w - (float)hi);
                 const _Float16 sel = part ? lo : hi;
