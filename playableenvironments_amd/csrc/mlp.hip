@@ -964,6 +964,9 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 // GROUP: `first` is this workgroup's first tile of the object and comes back advanced by the object's tile count (mod grid): the
 // objects of a launch are dealt to the workgroups as ONE round-robin sequence - strided from the block index per object, the
 // workgroups 0 .. (tiles mod grid) of EVERY object took an extra tile (a few objects of a few hundred tiles each on 512 workgroups).
+#ifndef PR_HEADF_ABLATE
+#define PR_HEADF_ABLATE 0     // timing builds only (k_mlp_head*): 1 = no activation reads, 2 = no row write-out, 4 = no statistics flush
+#endif
 template <bool GROUP>
 __device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -996,7 +999,11 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
         for (int idx = tid; idx < TILE_M * wq; idx += MLP_THREADS) {
             const int row = idx / wq, c = (idx - row * wq) * 4;
             const int src = (tile_base + row < total) ? tile_base + row : tile_base;
+#if PR_HEADF_ABLATE & 1
+            const float4 h = make_float4(0.5f, 0.25f, -0.5f, 1.f);    // measurement build: no activation reads (results are wrong)
+#else
             const float4 h = *reinterpret_cast<const float4*>(p.h_in + (size_t)src * p.h_in_width + c);
+#endif
             const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + prev.adain_off;
             const float4 g = *reinterpret_cast<const float4*>(tab + c);
             const float4 b = *reinterpret_cast<const float4*>(tab + prev.nblk * 32 + c);
@@ -1009,6 +1016,9 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
         Layer raw = cur;
         raw.epi = EPI_FEATURES;   // plain store into X
         run_layer<false, false, true>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, p.phase == 2 ? &cstats : nullptr);
+#if PR_HEADF_ABLATE & 2
+        __syncthreads();      // measurement build: no row write-out
+#else
         if (p.phase == 2) {
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             __syncthreads();
@@ -1016,8 +1026,11 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
             write_tile_rows(S, p.feat, p.F, p.F, tile_base, /*zero_dead=*/true);
             __syncthreads();
         }
+#endif
     }
+#if !(PR_HEADF_ABLATE & 4)
     if (p.phase == 2) flush_column_stats(cstats, p, cur.nblk);
+#endif
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(MlpParams p) {

@@ -30,6 +30,9 @@ struct BSmem {
 static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
 static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0, "16-byte LDS accesses");
 
+#ifndef PR_HEADB_ABLATE
+#define PR_HEADB_ABLATE 0       // timing builds only (k_head_bwd_group): 1 = no raw-activation prefetch, 2 = no a_out stores, 4 = no d_out rows,
+#endif                          // 8 = no MFMA, 16 = no operand load from memory, 32 = no statistics atomics
 #ifndef PR_CHAINGRP_ABLATE
 #define PR_CHAINGRP_ABLATE 0    // timing builds only (k_chain_bwd_group): 1 = no gradient write-out, 2 = no mask bits, 4 = no MFMA
 #endif
@@ -358,7 +361,9 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < rows_valid && c < p.ld_gin) {
                     float* src = p.g_in + (size_t)(tile_base + row) * p.ld_gin + c;
-                    if ((S.flags[row] & 3) == 3) {
+                    if (PR_HEADB_ABLATE & 16) {
+                        v = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
+                    } else if ((S.flags[row] & 3) == 3) {
                         v = *reinterpret_cast<const float4*>(src);
                         if (c + 3 >= p.k_real) {       // padding columns of the rows
                             if (c + 0 >= p.k_real) v.x = 0.f;
@@ -372,6 +377,9 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 }
                 *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
             }
+        } else if (PR_HEADB_ABLATE & 16) {
+            for (int idx = tid; idx < TILE_M * (p.kpad >> 2); idx += MLP_THREADS)
+                *reinterpret_cast<float4*>(S.X + (idx / (p.kpad >> 2)) * LDX + (idx % (p.kpad >> 2)) * 4) = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
         } else {
             load_bn_backward(S, p.d_in, p.h_in, p.kpad, tile_base, rows_valid);
         }
@@ -388,7 +396,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int ro = PR_ACC_ROW(i & 15) + 32 * (i >> 4);
-                hv[i] = (live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.f;
+                hv[i] = (!(PR_HEADB_ABLATE & 1) && live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.25f;
             }
         };
         float hvA[32], hvB[32];
@@ -397,7 +405,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 #endif
         f32x16 a00, a01, a10, a11;
         zero4(a00, a01, a10, a11);
-        tile_products_any<SPLIT>(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+        if (!(PR_HEADB_ABLATE & 8)) tile_products_any<SPLIT>(p.wt, p.nblk, S.X, a00, a01, a10, a11);
         if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 #ifndef PR_HEAD_NO_PREFETCH
         prefetch(1, hvB);
@@ -453,7 +461,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                         db += dy;
                     }
                     xb[ro * LDX] = dxh;
-                    if (ro < limit) ab[ro * ld] = a;
+                    if (!(PR_HEADB_ABLATE & 2) && ro < limit) ab[ro * ld] = a;
                 }
                 // the two halves of the wave hold the same column: combine
                 s1 += __shfl_xor(s1, 32, 64);
@@ -513,9 +521,10 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
         }
         if (tid == 0) S.next_tile = claimed;
         __syncthreads();
-        store_tile_rows(S.X, p.d_out, p.nblk * 32, p.ld, tile_base, rows_valid);
+        if (!(PR_HEADB_ABLATE & 4)) store_tile_rows(S.X, p.d_out, p.nblk * 32, p.ld, tile_base, rows_valid);
         __syncthreads();      // the next tile overwrites X and the records
     }
+    if (PR_HEADB_ABLATE & 32) return;
     flush_frame_sums(cs, p.dscale, p.dbias, p.nblk, p.width);
     if (lane < 32 && !p.frozen) {
 #pragma unroll

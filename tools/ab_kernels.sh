@@ -17,9 +17,9 @@ keep = {}
 for r in rows:
     name = r['Name'].split('(')[0].replace('pr::', '').replace('void ', '')
     if name.startswith('k_'):
-        keep[name] = (float(r['AverageNs']) / 1e3, int(r['Calls']))
+        keep[name] = (float(r['AverageNs']) / 1e3, int(r['Calls']), float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3)
 order = sorted(keep, key=lambda k: -keep[k][0] * keep[k][1])
 print(f"{v:10s} {precision} step {line['ms_per_step']:.3f} ms (median {line['ms_per_step_median']:.3f})  " +
-      "  ".join(f"{k}:{keep[k][0]:.0f}us" for k in order[:14]))
+      "  ".join(f"{k}:{keep[k][0]:.0f}[{keep[k][2]:.0f}-{keep[k][3]:.0f}]" for k in order[:8]))
 PY
 done
