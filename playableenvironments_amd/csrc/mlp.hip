@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head(Mlp
 // the same phase of several objects in one launch: a workgroup takes its strided share of every object's tiles in turn
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_head_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                    int count) {
+    pr_stagger(1);
     int first = (int)blockIdx.x;
     mlp_head_loop<true>(j0, first);
     if (count > 1) mlp_head_loop<true>(j1, first);

@@ -42,6 +42,30 @@ constexpr int MLP_WAVES = 4;      // 256 threads; every wave owns two 32-column 
 constexpr int MLP_BLOCKS_PER_CU = 2;   // two independent tiles per CU (LDS ~70 KB each): one computes while the other
                                        // is in a prologue / epilogue / barrier
 constexpr int MLP_THREADS = MLP_WAVES * 64;
+// measurement builds only: delay every second workgroup (rule 1: the second half of the grid; 2: bit 3 of the block index) at launch
+#ifndef PR_STAGGER_RULE
+#define PR_STAGGER_RULE 0
+#endif
+#ifndef PR_STAGGER_KERNELS
+#define PR_STAGGER_KERNELS 0      // 1 head forward phases, 2 head backward phases
+#endif
+#ifndef PR_STAGGER_SLEEPS
+#define PR_STAGGER_SLEEPS 2       // x 127 x 64 clocks (~3.4 us each)
+#endif
+__device__ __forceinline__ void pr_stagger(int kernel_bit) {
+#if PR_STAGGER_RULE != 0
+    if (!(PR_STAGGER_KERNELS & kernel_bit)) return;
+    const unsigned b = blockIdx.x;
+    const bool late = PR_STAGGER_RULE == 1 ? (b >= gridDim.x / 2) : (((b >> 3) & 1u) != 0u);
+    if (late) {
+#pragma unroll 1
+        for (int i = 0; i < PR_STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#else
+    (void)kernel_bit;
+#endif
+}
+
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
 constexpr int MAX_RESIDENT_TILES = 1024;   // upper bound of the persistent MLP grid (2 workgroups x CUs; 512 on MI355X)

@@ -50,6 +50,21 @@ __device__ unsigned long long g_chain_phase[16];
 #define PR_CT0() do {} while (0)
 #define PR_CT(idx) do {} while (0)
 #endif
+#ifdef PR_HEAD_TIMING
+// phase timing build: thread 0 of every workgroup accumulates shader-clock deltas per phase of k_head_bwd_group (slots 0..7 phase 1,
+// 8..15 phase 2 of the head backward)
+__device__ unsigned long long g_head_phase[16];
+#define PR_HT0() unsigned long long _ht = __builtin_amdgcn_s_memtime()
+#define PR_HT(idx)                                                                         \
+    do {                                                                                   \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0) atomicAdd(&g_head_phase[(idx) + (p.phase == 2 ? 8 : 0)], _n - _ht); \
+        _ht = _n;                                                                          \
+    } while (0)
+#else
+#define PR_HT0() do {} while (0)
+#define PR_HT(idx) do {} while (0)
+#endif
 #define PR_ROWS_OF(i, half, rb) (PR_ACC_ROW(i) + 4 * (half) + 32 * (rb))
 
 __device__ __forceinline__ void zero4(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {
@@ -348,8 +363,10 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
         const int tile_base = tile * TILE_M;
         const int rows_valid = (total - tile_base < TILE_M) ? total - tile_base : TILE_M;
         int claimed = 0;      // (claimed late, behind the tile's product: see "Tile order" in mlp.hip)
+        PR_HT0();
         load_tile_records(S, p.rec_flat, p.row_flags, p.samples_per_frame, tile_base, total);
         __syncthreads();
+        PR_HT(0);
         if (tid < TILE_M && tid < rows_valid && S.frame[tid] != S.frame[0]) S.uniform_frame = 0;
         // ---- the operand: the incoming gradient of the layer's output ---------------------------------
         if (p.phase == 1) {
@@ -384,6 +401,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
             load_bn_backward(S, p.d_in, p.h_in, p.kpad, tile_base, rows_valid);
         }
         __syncthreads();
+        PR_HT(1);
         // the raw activations the epilogue needs (this lane's column, its 32 rows per column block) are REQUESTED before the
         // product and arrive while it runs: loaded inside the epilogue, four at a time, their latency was the tile's critical path
         // (31 TFLOP/s for the two head phases)
@@ -403,14 +421,17 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 #ifndef PR_HEAD_NO_PREFETCH
         prefetch(0, hvA);
 #endif
+        PR_HT(2);
         f32x16 a00, a01, a10, a11;
         zero4(a00, a01, a10, a11);
         if (!(PR_HEADB_ABLATE & 8)) tile_products_any<SPLIT>(p.wt, p.nblk, S.X, a00, a01, a10, a11);
+        PR_HT(3);
         if (tid == 0) claimed = atomicAdd(p.tile_counter, 1);
 #ifndef PR_HEAD_NO_PREFETCH
         prefetch(1, hvB);
 #endif
         __syncthreads();      // every wave has finished reading X
+        PR_HT(4);
 #ifdef PR_HEAD_NO_PREFETCH
         prefetch(0, hvA);
         prefetch(1, hvB);
@@ -519,10 +540,13 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 }
             }
         }
+        PR_HT(5);
         if (tid == 0) S.next_tile = claimed;
         __syncthreads();
+        PR_HT(6);
         if (!(PR_HEADB_ABLATE & 4)) store_tile_rows(S.X, p.d_out, p.nblk * 32, p.ld, tile_base, rows_valid);
         __syncthreads();      // the next tile overwrites X and the records
+        PR_HT(7);
     }
     if (PR_HEADB_ABLATE & 32) return;
     flush_frame_sums(cs, p.dscale, p.dbias, p.nblk, p.width);
@@ -540,6 +564,7 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_head_bwd_group(HeadBwdJob j0, HeadBwdJob j1, HeadBwdJob j2, HeadBwdJob j3,
                                                                                    int count) {
+    pr_stagger(2);
     head_bwd_loop<0>(j0);
     if (count > 1) head_bwd_loop<0>(j1);
     if (count > 2) head_bwd_loop<0>(j2);
@@ -767,6 +792,17 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_gr
     if (count > 3) chain_bwd_loop<2>(j3);
 }
 
+#ifdef PR_HEAD_TIMING
+extern "C" int pr_debug_head_phases(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_head_phase), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long zero[16] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_head_phase), zero, sizeof(zero));
+    }
+    return 0;
+}
+#endif
 #ifdef PR_CHAIN_TIMING
 extern "C" int pr_debug_chain_phases(unsigned long long* out16, int reset) {
     (void)hipDeviceSynchronize();
