@@ -996,21 +996,39 @@ __device__ __forceinline__ void mlp_head_loop(const MlpParams& p, int& first) {
         }
         __syncthreads();
         const int wq = p.h_in_width >> 2;
-        for (int idx = tid; idx < TILE_M * wq; idx += MLP_THREADS) {
-            const int row = idx / wq, c = (idx - row * wq) * 4;
-            const int src = (tile_base + row < total) ? tile_base + row : tile_base;
+        {
+            // batches of loads first (raw activations + the AdaIN table rows of their frames), then the arithmetic and the LDS
+            // stores: as one loop every iteration waited for its own loads (8 - 16 round trips to memory per tile)
+            constexpr int BATCH = 4;
+            const int count = TILE_M * wq;
+            for (int base = tid; base < count; base += MLP_THREADS * BATCH) {
+                float4 h[BATCH], g[BATCH], b[BATCH];
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q) {
+                    const int idx = base + q * MLP_THREADS;
+                    const int row = idx < count ? idx / wq : 0, c = idx < count ? (idx - row * wq) * 4 : 0;
+                    const int src = (tile_base + row < total) ? tile_base + row : tile_base;
 #if PR_HEADF_ABLATE & 1
-            const float4 h = make_float4(0.5f, 0.25f, -0.5f, 1.f);    // measurement build: no activation reads (results are wrong)
+                    h[q] = make_float4(0.5f, 0.25f, -0.5f, 1.f);    // measurement build: no activation reads (results are wrong)
 #else
-            const float4 h = *reinterpret_cast<const float4*>(p.h_in + (size_t)src * p.h_in_width + c);
+                    h[q] = *reinterpret_cast<const float4*>(p.h_in + (size_t)src * p.h_in_width + c);
 #endif
-            const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + prev.adain_off;
-            const float4 g = *reinterpret_cast<const float4*>(tab + c);
-            const float4 b = *reinterpret_cast<const float4*>(tab + prev.nblk * 32 + c);
-            float4 y;
-            y.x = fmaf(h.x, g.x, b.x); y.y = fmaf(h.y, g.y, b.y); y.z = fmaf(h.z, g.z, b.z); y.w = fmaf(h.w, g.w, b.w);
-            y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f; y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
-            *reinterpret_cast<float4*>(S.X + row * LDX + c) = y;
+                    const float* tab = p.adain + (size_t)S.frame[row] * p.adain_stride + prev.adain_off;
+                    g[q] = *reinterpret_cast<const float4*>(tab + c);
+                    b[q] = *reinterpret_cast<const float4*>(tab + prev.nblk * 32 + c);
+                }
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q) {
+                    const int idx = base + q * MLP_THREADS;
+                    if (idx >= count) continue;
+                    const int row = idx / wq, c = (idx - row * wq) * 4;
+                    float4 y;
+                    y.x = fmaf(h[q].x, g[q].x, b[q].x); y.y = fmaf(h[q].y, g[q].y, b[q].y);
+                    y.z = fmaf(h[q].z, g[q].z, b[q].z); y.w = fmaf(h[q].w, g[q].w, b[q].w);
+                    y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f; y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
+                    *reinterpret_cast<float4*>(S.X + row * LDX + c) = y;
+                }
+            }
         }
         __syncthreads();
         Layer raw = cur;

@@ -267,29 +267,45 @@ __device__ __forceinline__ void stage_bn_constants(BSmem& S, const float* mean, 
 // that entered the statistics, 0 otherwise -> X, and back to `d` in place (the left factor of the layer's weight gradient)
 __device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float* h, int width_pad, int tile_base, int rows_valid,
                                                  int* max_slot = nullptr) {
+    // Batches of LOADS first, then the arithmetic and the stores: written as one loop (load d, load h, compute, store d back) every
+    // iteration waited for its own loads - the store to `d` may alias the next iteration's load for all the compiler knows - and a
+    // tile's 8 - 16 iterations cost as many round trips to memory (21 - 28 % of the head backward's time, tools/perf/perf_head_phases.py).
+    constexpr int BATCH = 4;
     const int w4 = width_pad >> 2;
+    const int count = TILE_M * w4;                 // a multiple of MLP_THREADS * BATCH (width_pad is a multiple of 64 here or handled by the guard)
     float biggest = 0.f;
-    for (int idx = threadIdx.x; idx < TILE_M * w4; idx += MLP_THREADS) {
-        const int row = idx / w4, c = (idx - row * w4) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < rows_valid) {
-            if ((S.flags[row] & 3) == 3) {
-                const size_t at = (size_t)(tile_base + row) * width_pad + c;
-                const float4 g = *reinterpret_cast<const float4*>(d + at);
-                const float4 hv = *reinterpret_cast<const float4*>(h + at);
+    for (int base = threadIdx.x; base < count; base += MLP_THREADS * BATCH) {
+        float4 g[BATCH], hv[BATCH];
+        bool live[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = base + b * MLP_THREADS;
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            live[b] = idx < count && row < rows_valid && (S.flags[row] & 3) == 3;
+            const size_t at = (size_t)(tile_base + (live[b] ? row : 0)) * width_pad + (live[b] ? c : 0);
+            g[b] = live[b] ? *reinterpret_cast<const float4*>(d + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[b] = live[b] ? *reinterpret_cast<const float4*>(h + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int idx = base + b * MLP_THREADS;
+            if (idx >= count) continue;
+            const int row = idx / w4, c = (idx - row * w4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[b]) {
                 const float4 mu = *reinterpret_cast<const float4*>(&S.cst[0][c]);
                 const float4 rs = *reinterpret_cast<const float4*>(&S.cst[1][c]);
                 const float4 m1 = *reinterpret_cast<const float4*>(&S.cst[2][c]);
                 const float4 m2 = *reinterpret_cast<const float4*>(&S.cst[3][c]);
-                v.x = rs.x * (g.x - m1.x - (hv.x - mu.x) * rs.x * m2.x);
-                v.y = rs.y * (g.y - m1.y - (hv.y - mu.y) * rs.y * m2.y);
-                v.z = rs.z * (g.z - m1.z - (hv.z - mu.z) * rs.z * m2.z);
-                v.w = rs.w * (g.w - m1.w - (hv.w - mu.w) * rs.w * m2.w);
+                v.x = rs.x * (g[b].x - m1.x - (hv[b].x - mu.x) * rs.x * m2.x);
+                v.y = rs.y * (g[b].y - m1.y - (hv[b].y - mu.y) * rs.y * m2.y);
+                v.z = rs.z * (g[b].z - m1.z - (hv[b].z - mu.z) * rs.z * m2.z);
+                v.w = rs.w * (g[b].w - m1.w - (hv[b].w - mu.w) * rs.w * m2.w);
             }
-            *reinterpret_cast<float4*>(d + (size_t)(tile_base + row) * width_pad + c) = v;
+            if (row < rows_valid) *reinterpret_cast<float4*>(d + (size_t)(tile_base + row) * width_pad + c) = v;
+            *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
+            biggest = fmaxf(fmaxf(biggest, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
-        *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
-        biggest = fmaxf(fmaxf(biggest, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     commit_tile_max(biggest, max_slot);
 }
@@ -373,26 +389,45 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
             // feature-row gradients from the compositing backward; rows that failed the second AABB test produced zeros in
             // the forward pass: their gradient is cleared here (it also feeds the bias gradient's column sums)
             const int k4 = p.kpad >> 2;
-            for (int idx = tid; idx < TILE_M * k4; idx += MLP_THREADS) {
-                const int row = idx / k4, c = (idx - row * k4) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows_valid && c < p.ld_gin) {
-                    float* src = p.g_in + (size_t)(tile_base + row) * p.ld_gin + c;
-                    if (PR_HEADB_ABLATE & 16) {
-                        v = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
-                    } else if ((S.flags[row] & 3) == 3) {
-                        v = *reinterpret_cast<const float4*>(src);
-                        if (c + 3 >= p.k_real) {       // padding columns of the rows
-                            if (c + 0 >= p.k_real) v.x = 0.f;
-                            if (c + 1 >= p.k_real) v.y = 0.f;
-                            if (c + 2 >= p.k_real) v.z = 0.f;
-                            if (c + 3 >= p.k_real) v.w = 0.f;
+            constexpr int BATCH = 4;          // loads first, then the LDS stores (see load_bn_backward)
+            const int count = TILE_M * k4;
+            for (int base = tid; base < count; base += MLP_THREADS * BATCH) {
+                float4 v[BATCH];
+                int kind[BATCH];              // 0: nothing to do in memory, 1: loaded, 2: a dead row whose gradient is cleared in memory
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    const int idx = base + b * MLP_THREADS;
+                    const int row = idx / k4, c = (idx - row * k4) * 4;
+                    v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    kind[b] = 0;
+                    if (idx < count && row < rows_valid && c < p.ld_gin) {
+                        const float* src = p.g_in + (size_t)(tile_base + row) * p.ld_gin + c;
+                        if (PR_HEADB_ABLATE & 16) {
+                            v[b] = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
+                        } else if ((S.flags[row] & 3) == 3) {
+                            v[b] = *reinterpret_cast<const float4*>(src);
+                            kind[b] = 1;
+                        } else {
+                            kind[b] = 2;
                         }
-                    } else {
-                        *reinterpret_cast<float4*>(src) = v;
                     }
                 }
-                *reinterpret_cast<float4*>(S.X + row * LDX + c) = v;
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    const int idx = base + b * MLP_THREADS;
+                    if (idx >= count) continue;
+                    const int row = idx / k4, c = (idx - row * k4) * 4;
+                    if (kind[b] == 1 && c + 3 >= p.k_real) {       // padding columns of the rows
+                        if (c + 0 >= p.k_real) v[b].x = 0.f;
+                        if (c + 1 >= p.k_real) v[b].y = 0.f;
+                        if (c + 2 >= p.k_real) v[b].z = 0.f;
+                        if (c + 3 >= p.k_real) v[b].w = 0.f;
+                    }
+                    // feature-row gradients of rows that failed the second AABB test produced zeros in the forward pass: their
+                    // gradient is cleared in memory too (it also feeds the bias gradient's column sums)
+                    if (kind[b] == 2) *reinterpret_cast<float4*>(p.g_in + (size_t)(tile_base + row) * p.ld_gin + c) = v[b];
+                    *reinterpret_cast<float4*>(S.X + row * LDX + c) = v[b];
+                }
             }
         } else if (PR_HEADB_ABLATE & 16) {
             for (int idx = tid; idx < TILE_M * (p.kpad >> 2); idx += MLP_THREADS)
@@ -595,7 +630,11 @@ int launch_head_bwd_group(const HeadBwdJob* jobs, const long* max_rows, int coun
         for (int j = 1; j < n; ++j) PR_REQUIRE((g[j].split != 0) == split, "head backward: jobs of one launch differ in precision");
         PR_TRY(prepare_kernel(split ? reinterpret_cast<const void*>(k_head_bwd_group_bf16) : reinterpret_cast<const void*>(k_head_bwd_group),
                               (int)sizeof(BSmem), &cus));
+        #ifdef PR_HEAD_RESIDENT
+        const long resident = (long)cus * PR_HEAD_RESIDENT;        // measurement build: workgroups per CU of the head backward launch
+#else
         const long resident = (long)cus * MLP_BLOCKS_PER_CU;
+#endif
         ProfileScope scope(2, s);
         if (split)
             hipLaunchKernelGGL(k_head_bwd_group_bf16, dim3((unsigned)(max_tiles < resident ? max_tiles : resident)), dim3(MLP_THREADS),
