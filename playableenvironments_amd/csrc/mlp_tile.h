@@ -853,16 +853,14 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
                     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        if ((mlo >> PR_ACC_ROW(i)) & 1u) {
-                            const double x = (double)lo[i];
-                            s1 += x;
-                            s2 = fma(x, x, s2);
-                        }
-                        if ((mhi >> PR_ACC_ROW(i)) & 1u) {
-                            const double x = (double)hi[i];
-                            s1 += x;
-                            s2 = fma(x, x, s2);
-                        }
+                        // (selects, not branches: the two halves of a wave hold different rows - 32 divergent branches per block;
+                        // a row outside the statistics adds exact zeros)
+                        const double x0 = ((mlo >> PR_ACC_ROW(i)) & 1u) ? (double)lo[i] : 0.0;
+                        s1 += x0;
+                        s2 = fma(x0, x0, s2);
+                        const double x1 = ((mhi >> PR_ACC_ROW(i)) & 1u) ? (double)hi[i] : 0.0;
+                        s1 += x1;
+                        s2 = fma(x1, x1, s2);
                     }
                     s1 += __shfl_xor(s1, 32, 64);      // the other half of the column
                     s2 += __shfl_xor(s2, 32, 64);

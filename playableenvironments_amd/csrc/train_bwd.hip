@@ -270,7 +270,7 @@ __device__ __forceinline__ void load_bn_backward(BSmem& S, float* d, const float
     // Batches of LOADS first, then the arithmetic and the stores: written as one loop (load d, load h, compute, store d back) every
     // iteration waited for its own loads - the store to `d` may alias the next iteration's load for all the compiler knows - and a
     // tile's 8 - 16 iterations cost as many round trips to memory (21 - 28 % of the head backward's time, tools/perf/perf_head_phases.py).
-    constexpr int BATCH = 4;
+    constexpr int BATCH = 8;       // (a 128-wide tile in one batch: 16 float4 in flight per thread; nothing else is live here)
     const int w4 = width_pad >> 2;
     const int count = TILE_M * w4;                 // a multiple of MLP_THREADS * BATCH (width_pad is a multiple of 64 here or handled by the guard)
     float biggest = 0.f;
@@ -441,15 +441,21 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
         // product and arrive while it runs: loaded inside the epilogue, four at a time, their latency was the tile's critical path
         // (31 TFLOP/s for the two head phases)
         const unsigned long long mine = __ballot((S.flags[lane] & 3) == 3) >> (4 * half);   // bit ro <-> tile row ro + 4 half
+        // (unconditional loads from clamped addresses - a lane without a live column reads the array's first row, rows beyond the
+        // tile's last read the last - instead of 32 predicated loads: every predicate was an exec-mask change around one load.
+        // What the values of dead rows / columns are does not matter: the epilogue selects them away.)
         auto prefetch = [&](int blk, float (&hv)[32]) {
             const int cb = wave + blk * MLP_WAVES;
             const bool live = cb < p.nblk && live_col[blk];
-            const float* hb = p.h + (size_t)(tile_base + 4 * half) * p.ld + cb * 32 + r;
+            const float* hb = live ? p.h + (size_t)(tile_base + 4 * half) * p.ld + cb * 32 + r : p.h + (size_t)tile_base * p.ld;
             const int ld = p.ld;
+            const int last = live ? rows_valid - 1 - 4 * half : 0;      // largest row offset of this lane inside the tile (may be < 0)
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int ro = PR_ACC_ROW(i & 15) + 32 * (i >> 4);
-                hv[i] = (!(PR_HEADB_ABLATE & 1) && live && ((mine >> ro) & 1ull)) ? hb[ro * ld] : 0.25f;
+                int rc = ro < last ? ro : last;
+                rc = rc > -4 * half ? rc : (live ? -4 * half : 0);
+                hv[i] = (PR_HEADB_ABLATE & 1) ? 0.25f : hb[rc * ld];
             }
         };
         float hvA[32], hvB[32];
@@ -500,24 +506,26 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
                 const int ld = p.ld;
                 double s1 = 0.0, s2 = 0.0;
                 float ds = 0.f, db = 0.f;
+                // branch-free: a row that did not enter the statistics (or a padding column) contributes exact zeros - the same sums
+                // as skipping it, without 32 divergent branches (the two halves of a wave hold different rows)
+                const bool full = rows_valid == TILE_M;       // every row offset of this lane is inside the tile
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     const int ro = PR_ACC_ROW(i & 15) + 32 * (i >> 4);
                     const float acc = (i >> 4) ? hi[i & 15] : lo[i & 15];
-                    float a = 0.f, dxh = 0.f;
-                    if (live && ((mine >> ro) & 1ull)) {
-                        const float y = fmaf(hv[i], g, b);
-                        a = y > 0.f ? y : 0.f;
-                        const float dy = y > 0.f ? acc : 0.f;
-                        const float xh = (hv[i] - mu[blk]) * rstd[blk];
-                        dxh = dy * scale;
-                        s1 += (double)dxh;
-                        s2 += (double)dxh * (double)xh;
-                        ds = fmaf(dy, xh, ds);
-                        db += dy;
-                    }
+                    const bool on = live && ((mine >> ro) & 1ull);
+                    const float y = fmaf(hv[i], g, b);
+                    const bool pass = on && y > 0.f;
+                    const float a = pass ? y : 0.f;
+                    const float dy = pass ? acc : 0.f;
+                    const float xh = on ? (hv[i] - mu[blk]) * rstd[blk] : 0.f;
+                    const float dxh = dy * scale;
+                    s1 += (double)dxh;
+                    s2 += (double)dxh * (double)xh;
+                    ds = fmaf(dy, xh, ds);
+                    db += dy;
                     xb[ro * LDX] = dxh;
-                    if (!(PR_HEADB_ABLATE & 2) && ro < limit) ab[ro * ld] = a;
+                    if (!(PR_HEADB_ABLATE & 2) && (full || ro < limit)) ab[ro * ld] = a;
                 }
                 // the two halves of the wave hold the same column: combine
                 s1 += __shfl_xor(s1, 32, 64);
