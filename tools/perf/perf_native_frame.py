@@ -23,6 +23,7 @@ def build(world: str, dev, batch: int = 1):
     cfg = configs.tennis_config() if world == "tennis" else configs.minecraft_config()
     torch.manual_seed(0)
     model = EnvironmentModel(cfg)
+    model.frame_replay = None      # eager launches: what this script measures / what counter passes can instrument
     synthetic.randomize_module_state(model.object_composer, seed=0, step=60000, alpha_bias=1.0, bender_scale=1e4)
     model.eval().to(dev)
     size = (288, 512)
