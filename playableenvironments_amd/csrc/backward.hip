@@ -129,52 +129,41 @@ __device__ __forceinline__ void entry_backward(const CompositeBwdParams& p, BwdS
             const int q = sub + 16 * c;
             gF4[c] = q < f4n ? *reinterpret_cast<const float4*>(g.integrated_features + (size_t)ray * F + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // software-pipelined: the rows of entries j0 + 4 .. j0 + 7 are requested before the dot products of j0 .. j0 + 3 are reduced
-        // (as a plain loop every iteration waited for its own rows: ~20 round trips to memory per list, five lists per ray)
-        auto request = [&](int j0, float4 (&fv)[4], int& e_out) {
+        for (int j0 = 0; j0 < n; j0 += 4) {
             const int j = j0 + grp;
             const float* f = nullptr;
-            e_out = 0;
+            int e = 0;
             if (j < n) {
-                e_out = entry_of(j);
-                const int row = sm.sl[e_out];
+                e = entry_of(j);
+                const int row = sm.sl[e];
                 if (row >= 0 && sm.Tj[j] != 0.f) {
                     int k = 0, o2 = 0;
-                    while (k + 1 < p.objects && e_out >= o2 + p.obj[k].positions) {
+                    while (k + 1 < p.objects && e >= o2 + p.obj[k].positions) {
                         o2 += p.obj[k].positions;
                         ++k;
                     }
                     f = p.obj[k].feat + (size_t)row * F;
                 }
             }
+            float4 fv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int q = sub + 16 * c;
                 fv[c] = (f && q < f4n) ? *reinterpret_cast<const float4*>(f + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        };
-        float4 cur[4], nxt[4];
-        int e_cur = 0, e_nxt = 0;
-        request(0, cur, e_cur);
-        for (int j0 = 0; j0 < n; j0 += 4) {
-            const int j = j0 + grp;
-            if (j0 + 4 < n) request(j0 + 4, nxt, e_nxt);
             float part = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                part = fmaf(gF4[c].x, cur[c].x, part);
-                part = fmaf(gF4[c].y, cur[c].y, part);
-                part = fmaf(gF4[c].z, cur[c].z, part);
-                part = fmaf(gF4[c].w, cur[c].w, part);
+                part = fmaf(gF4[c].x, fv[c].x, part);
+                part = fmaf(gF4[c].y, fv[c].y, part);
+                part = fmaf(gF4[c].z, fv[c].z, part);
+                part = fmaf(gF4[c].w, fv[c].w, part);
             }
             part += __shfl_xor(part, 8, 64);
             part += __shfl_xor(part, 4, 64);
             part += __shfl_xor(part, 2, 64);
             part += __shfl_xor(part, 1, 64);
-            if (sub == 0 && j < n) sm.dw[j] = part + gO + gD * sm.tt[e_cur] + (gW ? gW[j] : 0.f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
-            e_cur = e_nxt;
+            if (sub == 0 && j < n) sm.dw[j] = part + gO + gD * sm.tt[e] + (gW ? gW[j] : 0.f);
         }
     } else {
     float gF[MAX_FCHUNK_B];
