@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void k_patch_pixels(PatchPixelsParams p) {
     const int n = blockIdx.x;
     const int H = p.height, W = p.width, K = p.objects;
     const int s0 = p.strides[0], sm = p.strides[p.nstrides - 1];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {          // the first wave: every lane holds the boxes, the lookup probes 64 pixels at a time
+        const int lane = threadIdx.x;
         float left[PR_MAX_OBJECTS], right[PR_MAX_OBJECTS], top[PR_MAX_OBJECTS], bottom[PR_MAX_OBJECTS], per[PR_MAX_OBJECTS];
         for (int k = 0; k < K; ++k) {
             const float* b = p.boxes + (size_t)n * 4 * K + k;
@@ -617,11 +618,22 @@ __global__ __launch_bounds__(256) void k_patch_pixels(PatchPixelsParams p) {
         const double total = prefix(total_px - 1);
         long idx = total_px - 1;     // a weight image that does not normalise (empty boxes): the lookup runs off the end and is clamped
         if (total > 0.0 && total < 1e300) {
+            // first pixel whose cumulative weight reaches the draw.  prefix() is monotone (a sum of non-negative terms that each
+            // grow with the pixel index, rounded to nearest), so a 64-way search - lane l probes the end of the l-th of 64 equal
+            // parts of [lo, hi], the first lane whose prefix reaches the target names the part - finds the pixel a binary search
+            // finds, in 3 rounds of one probe per lane instead of 18 dependent probes of one thread
             const double target = (double)p.u[n] * total;
-            long lo = 0, hi = total_px - 1;
-            while (lo < hi) {                        // first pixel whose cumulative weight reaches the draw
-                const long mid = (lo + hi) >> 1;
-                if (prefix(mid) >= target) hi = mid; else lo = mid + 1;
+            long lo = 0, hi = total_px - 1;          // the answer lies in [lo, hi]; prefix(hi) >= target
+            while (lo < hi) {
+                const long step = (hi - lo + 63) / 64;                    // >= 1
+                long cand = lo + (long)(lane + 1) * step - 1;
+                if (cand > hi) cand = hi;
+                const unsigned long long reached = __ballot(prefix(cand) >= target);
+                const int first = __ffsll((long long)reached) - 1;        // (the last lane probes hi: always set)
+                long part_hi = lo + (long)(first + 1) * step - 1;
+                if (part_hi > hi) part_hi = hi;
+                lo = lo + (long)first * step;
+                hi = part_hi;
             }
             idx = lo;
         }
@@ -635,8 +647,10 @@ __global__ __launch_bounds__(256) void k_patch_pixels(PatchPixelsParams p) {
             if (d == h) return st;
             return st >= h ? st - (d + h) % sm : st + (sm + h - d);
         };
-        start[0] = align(row - half * sm);
-        start[1] = align(col - half * sm);
+        if (lane == 0) {
+            start[0] = align(row - half * sm);
+            start[1] = align(col - half * sm);
+        }
     }
     __syncthreads();
     int base = 0;

@@ -1125,12 +1125,31 @@ __global__ __launch_bounds__(256) void k_bn_fold_group(BnFoldJobs jobs) {
     const float* ws = p.affine.weight + (size_t)c * p.S;
     const float* wb = p.affine.weight + (size_t)(p.width + c) * p.S;
     const float inv = 1.0f / sqrtf(var_f + p.eps);
+    const bool live = c < p.width;
+    const float bias_s = live ? p.affine.bias[c] : 0.f, bias_b = live ? p.affine.bias[p.width + c] : 0.f;
     for (int n = 0; n < p.frames; ++n) {
         float g = 0.f, b = 0.f;
-        if (c < p.width) {
+        if (live) {
             const float* style = p.style + (size_t)n * p.style_stride;
-            float scale = p.affine.bias[c], bias = p.affine.bias[p.width + c];
-            for (int q = 0; q < p.S; ++q) {
+            float scale = bias_s, bias = bias_b;
+            // eight terms' loads at a time, then their multiply-adds in the same (ascending) order: as one loop of dependent
+            // load - fma pairs this kernel - 4 workgroups, on the critical path between two phases - took 19 - 26 us
+            int q = 0;
+            for (; q + 8 <= p.S; q += 8) {
+                float w8[8], b8[8], s8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    w8[k] = ws[q + k];
+                    b8[k] = wb[q + k];
+                    s8[k] = style[q + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    scale = fmaf(w8[k], s8[k], scale);
+                    bias = fmaf(b8[k], s8[k], bias);
+                }
+            }
+            for (; q < p.S; ++q) {
                 scale = fmaf(ws[q], style[q], scale);
                 bias = fmaf(wb[q], style[q], bias);
             }
