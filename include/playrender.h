@@ -165,6 +165,10 @@ int pr_packed_size(const pr_object_model_t* model, size_t* bytes);
 #define PR_PRECISION_F16X3 1
 #define PR_PRECISION_F16   2
 int pr_pack_model(const pr_object_model_t* model, int32_t precision, void* packed, size_t packed_bytes, void* stream);
+/* The same for several models (models[i] -> packed[i] at precisions[i]) in as few launches as their jobs allow: a training step
+ * re-packs every model after every optimiser step. */
+int pr_pack_models(int32_t count, const pr_object_model_t* const* models, const int32_t* precisions, void* const* packed,
+                   const size_t* packed_bytes, void* stream);
 
 /* One object instance of a call: its (shared) coarse / fine models and their packed copies. */
 typedef struct pr_object_t {

@@ -163,6 +163,8 @@ class SceneSetup(C.Structure):
 SYMBOLS = {
     "pr_packed_size": (C.c_int, [C.POINTER(ObjectModel), C.POINTER(C.c_size_t)]),
     "pr_pack_model": (C.c_int, [C.POINTER(ObjectModel), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pr_pack_models": (C.c_int, [C.c_int32, C.POINTER(C.POINTER(ObjectModel)), c_int32_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                 C.c_void_p]),
     "pr_workspace_size": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(C.c_size_t)]),
     "pr_render_forward": (C.c_int, [C.POINTER(Call), C.POINTER(Object), C.POINTER(Outputs), C.POINTER(Outputs),
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

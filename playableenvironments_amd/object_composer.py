@@ -668,22 +668,45 @@ class ObjectComposer(Tracked, nn.Module):
     def _packed_weights(self, model: RayBendingStyleNerfModel, struct: _lib.ObjectModel, stream: int,
                         differentiable: bool = False) -> torch.Tensor:
         """MFMA-fragment-ordered copy of the model's weights, rebuilt whenever a parameter changed."""
-        params = self._parameter_list(model)
+        return self._packed_weights_many([(model, struct)], stream, differentiable)[0]
+
+    def _packed_weights_many(self, pairs, stream: int, differentiable: bool = False) -> List[torch.Tensor]:
+        """The packed copies of several (model, struct) pairs; those that are stale - a parameter's storage or version moved, or a
+        backward pass has produced gradients since (``weights_epoch``) - are re-made by ONE ``pr_pack_models`` call (a training step
+        re-packs every model after every optimiser step)."""
         precision = self._precision_code(differentiable)
         if precision == _lib.PR_PRECISION_F16:
             precision = _lib.PR_PRECISION_F16X3      # the same fp16 (hi, lo) fragments; the kernel skips the lo halves
-        key = (self.weights_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
-        slot = (id(model), precision)   # one buffer per layout: a render at the other precision never evicts this one
-        cached = self._packed.get(slot)
-        if cached is not None and cached[0] == key:
-            return cached[1]
-        lib = _lib.load()
-        size = C.c_size_t()
-        _lib.check(lib.pr_packed_size(C.byref(struct), C.byref(size)), "pr_packed_size")
-        buf = torch.empty(size.value, dtype=torch.uint8, device=params[0].device)
-        _lib.check(lib.pr_pack_model(C.byref(struct), precision, buf.data_ptr(), size.value, stream), "pr_pack_model")
-        self._packed[slot] = (key, buf)
-        return buf
+        out, todo = [], {}
+        lib = None
+        for model, struct in pairs:
+            params = self._parameter_list(model)
+            key = (self.weights_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
+            slot = (id(model), precision)   # one buffer per layout: a render at the other precision never evicts this one
+            cached = self._packed.get(slot)
+            if cached is not None and cached[0] == key:
+                out.append(cached[1])
+                continue
+            if slot in todo:                # (object instances that share a model)
+                out.append(todo[slot][1])
+                continue
+            lib = lib or _lib.load()
+            size = C.c_size_t()
+            _lib.check(lib.pr_packed_size(C.byref(struct), C.byref(size)), "pr_packed_size")
+            buf = torch.empty(size.value, dtype=torch.uint8, device=params[0].device)
+            todo[slot] = (key, buf, struct, size.value)
+            out.append(buf)
+        if todo:
+            n = len(todo)
+            entries = list(todo.values())
+            models = (C.POINTER(_lib.ObjectModel) * n)(*[C.pointer(e[2]) for e in entries])
+            precisions = (C.c_int32 * n)(*([precision] * n))
+            buffers = (C.c_void_p * n)(*[e[1].data_ptr() for e in entries])
+            sizes = (C.c_size_t * n)(*[e[3] for e in entries])
+            _lib.check(lib.pr_pack_models(n, models, precisions, buffers, sizes, stream), "pr_pack_models")
+            for slot, (key, buf, _, _) in todo.items():
+                self._packed[slot] = (key, buf)
+        return out
 
     def _workspace_budget(self, dev, need: int) -> int:
         """Scratch bytes a call may use: ``max_workspace_bytes``, and - when the call needs more than the workspace this
@@ -885,18 +908,22 @@ class ObjectComposer(Tracked, nn.Module):
         keep = []  # tensors that must outlive the enqueue
         objs = (_lib.Object * K)()
         packed_keep = []   # the packed buffers this call reads (kept alive by the autograd state of differentiable calls)
+        pairs = []
         for k in range(K):
             for attr in ("style_features", "deformation_features"):
                 want = S if attr == "style_features" else D
                 if models_c[k].model_config[attr] != want:
                     raise Exception(f"object {k}: {attr} is {models_c[k].model_config[attr]} but the tensor has {want}")
             objs[k].coarse = self._model_struct(models_c[k], pc[k])
-            packed_keep.append(self._packed_weights(models_c[k], objs[k].coarse, stream, _save))
-            objs[k].packed_coarse = packed_keep[-1].data_ptr()
+            pairs.append((models_c[k], objs[k].coarse))
             if use_fine:
                 objs[k].fine = self._model_struct(models_f[k], pc[k] + pf[k])
-                packed_keep.append(self._packed_weights(models_f[k], objs[k].fine, stream, _save))
-                objs[k].packed_fine = packed_keep[-1].data_ptr()
+                pairs.append((models_f[k], objs[k].fine))
+        packed_keep = self._packed_weights_many(pairs, stream, _save)      # (stale copies re-made in one launch)
+        for k in range(K):
+            objs[k].packed_coarse = packed_keep[k * (2 if use_fine else 1)].data_ptr()
+            if use_fine:
+                objs[k].packed_fine = packed_keep[2 * k + 1].data_ptr()
 
         flags = 0
         if perturb:
@@ -1150,7 +1177,7 @@ class ObjectComposer(Tracked, nn.Module):
         if self.training and capturing:
             pass       # a recorded call cannot raise from its replays: the counts stay in last_normalised_samples for the caller
         elif self.training and self.batchnorm_check == "deferred":
-            counts = torch.cat([pieces[0][ty]["_normalised"] for ty in types])
+            counts = pieces[0][types[0]]["_normalised"] if len(types) == 1 else torch.cat([pieces[0][ty]["_normalised"] for ty in types])
             host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
             host.copy_(counts, non_blocking=True)
             event = torch.cuda.Event()
