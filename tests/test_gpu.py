@@ -2823,7 +2823,11 @@ def _run_bench(argv, env, tmp_path):
     full_path = os.path.join(str(tmp_path), "bench_full.json")
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv + ["--full-json", full_path], env=env,
                           capture_output=True, text=True, timeout=1500)
-    assert proc.returncode == 0, proc.stderr[-2000:]
+    if proc.returncode != 0:       # the first error of any rank, not only the launcher's summary at the end
+        import re
+        first = re.search(r"Traceback|what\(\)|HIP error|Error:|terminate called", proc.stderr)
+        at = first.start() if first else max(0, len(proc.stderr) - 3000)
+        raise AssertionError(f"bench.py exited with {proc.returncode}\n--- first error ---\n{proc.stderr[at:at + 3000]}\n--- tail ---\n{proc.stderr[-1500:]}")
     out_lines = [line for line in proc.stdout.splitlines() if line.strip()]
     assert len(out_lines) == 1 and out_lines[0].startswith("{"), proc.stdout[-2000:]      # nothing but the line on stdout
     assert len(out_lines[0].encode()) < 4096, len(out_lines[0])
