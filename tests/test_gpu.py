@@ -2821,6 +2821,11 @@ def _run_bench(argv, env, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     full_path = os.path.join(str(tmp_path), "bench_full.json")
+    # the ranks share this box's ONE GPU with the test process: hand back what its allocator caches (after ~200 tests: most of the
+    # 288 GB - eight ranks of ~25 GB each then ran out of memory in their decoder leg)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv + ["--full-json", full_path], env=env,
                           capture_output=True, text=True, timeout=1500)
     if proc.returncode != 0:       # the first error of any rank, not only the launcher's summary at the end
