@@ -855,71 +855,47 @@ __device__ __forceinline__ void geometry_bwd_body(const GeometryBwd& p) {
         const int Pc = p.t_coarse ? p.pc : P;
         const size_t cbase = (size_t)g * Pc;
         int jc = 0;   // next unmatched coarse depth (hierarchical pass)
-        // The samples in chunks of eight: their records (g_t, slot, t) first, then the rows' position gradients, then the
-        // accumulation in the original (ascending) order - as one loop every sample waited for slot -> g_x[row], two dependent
-        // round trips to memory per sample and up to 32 samples per thread (48 - 55 us for 35 K threads).
-        constexpr int CH = 8;
-        for (int i0 = 0; i0 < P; i0 += CH) {
-            float gt8[CH], ti8[CH], gx8[CH][3];
-            int row8[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const bool in = i0 + k < P;
-                gt8[k] = in ? p.g_t[base + i0 + k] : 0.f;
-                row8[k] = in ? p.slot[base + i0 + k] : -1;
-                ti8[k] = in ? p.t[base + i0 + k] : 0.f;
+        for (int i = 0; i < P; ++i) {
+            float gt = p.g_t[base + i];
+            const int row = p.slot[base + i];
+            if (row >= 0 && p.g_x) {
+                const float ti = p.t[base + i];
+                for (int a = 0; a < 3; ++a) {
+                    const float gx = p.g_x[(size_t)row * 3 + a];
+                    go[a] += gx;
+                    gd[a] = fmaf(gx, ti, gd[a]);
+                    gt = fmaf(gx, rr.d[a], gt);
+                }
             }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const bool rowed = row8[k] >= 0 && p.g_x != nullptr;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) gx8[k][a] = rowed ? p.g_x[(size_t)row8[k] * 3 + a] : 0.f;
+            if (row >= 0 && p.g_in6) {   // skybox input [o / size, d / |d|]
+                const float* gi = p.g_in6 + (size_t)row * 6;
+                const float nrm = sqrtf(rr.d[0] * rr.d[0] + rr.d[1] * rr.d[1] + rr.d[2] * rr.d[2]);
+                float dotg = 0.f;
+                for (int a = 0; a < 3; ++a) dotg = fmaf(gi[3 + a], rr.d[a] / nrm, dotg);
+                for (int a = 0; a < 3; ++a) {
+                    go[a] += gi[a] / (p.hi[a] - p.lo[a]);
+                    gd[a] += (gi[3 + a] - dotg * rr.d[a] / nrm) / nrm;
+                }
             }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int i = i0 + k;
-                if (i >= P) break;
-                float gt = gt8[k];
-                const int row = row8[k];
-                if (row >= 0 && p.g_x) {
-                    const float ti = ti8[k];
-                    for (int a = 0; a < 3; ++a) {
-                        const float gx = gx8[k][a];
-                        go[a] += gx;
-                        gd[a] = fmaf(gx, ti, gd[a]);
-                        gt = fmaf(gx, rr.d[a], gt);
-                    }
-                }
-                if (row >= 0 && p.g_in6) {   // skybox input [o / size, d / |d|]
-                    const float* gi = p.g_in6 + (size_t)row * 6;
-                    const float nrm = sqrtf(rr.d[0] * rr.d[0] + rr.d[1] * rr.d[1] + rr.d[2] * rr.d[2]);
-                    float dotg = 0.f;
-                    for (int a = 0; a < 3; ++a) dotg = fmaf(gi[3 + a], rr.d[a] / nrm, dotg);
-                    for (int a = 0; a < 3; ++a) {
-                        go[a] += gi[a] / (p.hi[a] - p.lo[a]);
-                        gd[a] += (gi[3 + a] - dotg * rr.d[a] / nrm) / nrm;
-                    }
-                }
-                // t_i = near A_i + far B_i  (stratified_positions: linspace placement, optional jitter between midpoints)
-                int ci = i;   // index of the coarse depth this sample is
-                if (p.t_coarse) {
-                    const float ti = ti8[k];
-                    while (jc < Pc && p.t_coarse[cbase + jc] < ti) ++jc;
-                    if (jc < Pc && p.t_coarse[cbase + jc] == ti) ci = jc++;
-                    else continue;   // resampled depth: detached (ray_helper.py:1340)
-                }
-                const float s_i = p.linspace[ci];
-                float An = 1.0f - s_i, Bf = s_i;
-                if (noise_present(p.jitter)) {
-                    const float u = noise_uniform(p.jitter, (long)(cbase / Pc), Pc, ci);
-                    const float s_lo = ci > 0 ? 0.5f * (p.linspace[ci - 1] + s_i) : s_i;
-                    const float s_hi = ci < Pc - 1 ? 0.5f * (p.linspace[ci + 1] + s_i) : s_i;
-                    Bf = s_lo + (s_hi - s_lo) * u;
-                    An = 1.0f - Bf;
-                }
-                g_near = fmaf(gt, An, g_near);
-                g_far = fmaf(gt, Bf, g_far);
+            // t_i = near A_i + far B_i  (stratified_positions: linspace placement, optional jitter between midpoints)
+            int ci = i;   // index of the coarse depth this sample is
+            if (p.t_coarse) {
+                const float ti = p.t[base + i];
+                while (jc < Pc && p.t_coarse[cbase + jc] < ti) ++jc;
+                if (jc < Pc && p.t_coarse[cbase + jc] == ti) ci = jc++;
+                else continue;   // resampled depth: detached (ray_helper.py:1340)
             }
+            const float s_i = p.linspace[ci];
+            float An = 1.0f - s_i, Bf = s_i;
+            if (noise_present(p.jitter)) {
+                const float u = noise_uniform(p.jitter, (long)(cbase / Pc), Pc, ci);
+                const float s_lo = ci > 0 ? 0.5f * (p.linspace[ci - 1] + s_i) : s_i;
+                const float s_hi = ci < Pc - 1 ? 0.5f * (p.linspace[ci + 1] + s_i) : s_i;
+                Bf = s_lo + (s_hi - s_lo) * u;
+                An = 1.0f - Bf;
+            }
+            g_near = fmaf(gt, An, g_near);
+            g_far = fmaf(gt, Bf, g_far);
         }
         // slab test backward: tb = (c - o_a) / (d_a + eps)
         if (near_free) {
