@@ -443,6 +443,8 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True, precision="fp3
         (and therefore the reference) accepts: statistics untouched, no gradient.  Only a batch of exactly one sample raises; the call
         would be repeated with a new patch and counted (never observed: a ray that meets a box brings all its samples)."""
         opt.zero_grad(set_to_none=True)       # (arena: flat_gradient has moved the views' gradients to the arena)
+        for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
+            sc[k].grad = None                 # (stand-ins for encoder outputs: their gradients are consumed, not accumulated over steps)
         for attempt in range(20):
             try:
                 return iteration()
