@@ -2259,40 +2259,59 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
         }
     }
 
-    PR_TRY(launch_head_bwd_group(h1, rows, K, s));
-    PR_TRY(launch_head_bwd_group(h2, rows, K, s));
-    PR_TRY(launch_chain_bwd_group(cn, rows, K, s));
-    const int row_blocks = (int)((max_cap + POST_ROWS - 1) / POST_ROWS);
-    if (row_blocks > 0) {
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_nerf_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
-        hipLaunchKernelGGL(k_post_nerf_group, dim3(row_blocks, K), dim3(256), sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_n + 1), s, pn);
+    // Two small-grid kernels leave the caller's stream: the style affines' backward (536 workgroups, ~58 us) needs the head phases' d scale /
+    // d bias only and runs beside the NeRF chains; the sample-placement backward (144 workgroups, ~47 us) needs the position gradients and
+    // runs beside the weight-gradient launch.  Both fit next to the persistent tile kernels (a few waves, ~1 KB of LDS per workgroup); on
+    // the caller's stream each was ~50 us of a mostly idle chip plus a launch gap.  The second stream (one per device, lane_stream)
+    // forks from and joins the caller's stream through events: for the caller everything is still ordered on its own stream.
+    hipStream_t aux = nullptr;
+    auto run = [&]() -> int {
+        PR_TRY(launch_head_bwd_group(h1, rows, K, s));
+        PR_TRY(launch_head_bwd_group(h2, rows, K, s));
+#ifndef PR_BWD_ONE_STREAM
+        PR_TRY(lane_stream(&aux));
+        PR_TRY(stream_wait(aux, s));                 // fork: behind the head phases
+#endif
+        hipLaunchKernelGGL(k_style_bwd_group, dim3(style_blocks, style_jobs), dim3(256), 0, aux ? aux : s, sj);
         PR_LAUNCH_CHECK();
+        PR_TRY(launch_chain_bwd_group(cn, rows, K, s));
+        const int row_blocks = (int)((max_cap + POST_ROWS - 1) / POST_ROWS);
+        if (row_blocks > 0) {
+            PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_nerf_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
+            hipLaunchKernelGGL(k_post_nerf_group, dim3(row_blocks, K), dim3(256), sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_n + 1), s, pn);
+            PR_LAUNCH_CHECK();
+        }
+        if (benders) {
+            PR_TRY(launch_chain_bwd_group(cb, rows_b, benders, s));
+            long cap_b = 0;
+            for (int i = 0; i < benders; ++i) cap_b = std::max(cap_b, rows_b[i]);
+            PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_bender_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
+            hipLaunchKernelGGL(k_post_bender_group, dim3((unsigned)((cap_b + POST_ROWS - 1) / POST_ROWS), benders), dim3(256),
+                               sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_b + 1), s, pb);
+            PR_LAUNCH_CHECK();
+        }
+        if (out.w2o || cr.ray_grads) {
+            if (aux) PR_TRY(stream_wait(aux, s));    // the position gradients are complete
+            hipLaunchKernelGGL(k_geometry_bwd_group, dim3((c.rays + 255) / 256, c.frames, K), dim3(256), 0, aux ? aux : s, gj);
+            PR_LAUNCH_CHECK();
+        }
+        // every weight gradient of the call: one launch (+ its reduction) per TN_ALL_MAX products, each with its own claim counters;
+        // instances of one model that land in different launches accumulate one after the other (same stream)
+        for (int begin = 0, chunk = 0; begin < tn_count; begin += TN_ALL_MAX, ++chunk) {
+            tn.count = std::min(TN_ALL_MAX, tn_count - begin);
+            memcpy(tn.job, tn_jobs + begin, sizeof(TnJob) * tn.count);
+            tn.counters = counters + 4 * PR_MAX_OBJECTS + 8 * chunk;
+            tn.split_precision = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 1 : 0;
+            PR_TRY(launch_gemm_tn_all(tn, tn_rows + begin, s));
+        }
+        return PR_OK;
+    };
+    int status = run();
+    if (aux) {                                       // join, whatever happened above: the caller's stream continues behind both
+        const int joined = stream_wait(s, aux);
+        if (status == PR_OK) status = joined;
     }
-    if (benders) {
-        PR_TRY(launch_chain_bwd_group(cb, rows_b, benders, s));
-        long cap_b = 0;
-        for (int i = 0; i < benders; ++i) cap_b = std::max(cap_b, rows_b[i]);
-        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_post_bender_group), (int)(sizeof(float) * 2 * POST_ROWS * (MAX_ENC + 1)), nullptr));
-        hipLaunchKernelGGL(k_post_bender_group, dim3((unsigned)((cap_b + POST_ROWS - 1) / POST_ROWS), benders), dim3(256),
-                           sizeof(float) * 2 * POST_ROWS * (size_t)(max_ld_b + 1), s, pb);
-        PR_LAUNCH_CHECK();
-    }
-    // every weight gradient of the call: one launch (+ its reduction) per TN_ALL_MAX products, each with its own claim counters;
-    // instances of one model that land in different launches accumulate one after the other (same stream)
-    for (int begin = 0, chunk = 0; begin < tn_count; begin += TN_ALL_MAX, ++chunk) {
-        tn.count = std::min(TN_ALL_MAX, tn_count - begin);
-        memcpy(tn.job, tn_jobs + begin, sizeof(TnJob) * tn.count);
-        tn.counters = counters + 4 * PR_MAX_OBJECTS + 8 * chunk;
-        tn.split_precision = (c.flags & PR_FLAG_SPLIT_BACKWARD) ? 1 : 0;
-        PR_TRY(launch_gemm_tn_all(tn, tn_rows + begin, s));
-    }
-    hipLaunchKernelGGL(k_style_bwd_group, dim3(style_blocks, style_jobs), dim3(256), 0, s, sj);
-    PR_LAUNCH_CHECK();
-    if (out.w2o || cr.ray_grads) {
-        hipLaunchKernelGGL(k_geometry_bwd_group, dim3((c.rays + 255) / 256, c.frames, K), dim3(256), 0, s, gj);
-        PR_LAUNCH_CHECK();
-    }
-    return PR_OK;
+    return status;
 }
 
 }  // namespace pr
