@@ -1437,7 +1437,7 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
 // object are small, so two objects side by side fill the GPU better than one after the other.  The caller's stream forks
 // into it after the compositing backward and joins it before the call returns - for the caller everything is still
 // enqueued on its own stream.
-int lane_stream(hipStream_t* out) {
+static int lane_stream(hipStream_t* out) {
     static std::mutex mu;
     static hipStream_t streams[64] = {};
     int dev = 0;
@@ -1449,7 +1449,7 @@ int lane_stream(hipStream_t* out) {
     return PR_OK;
 }
 
-int stream_wait(hipStream_t waiter, hipStream_t on) {      // `waiter` continues after everything enqueued on `on` so far
+static int stream_wait(hipStream_t waiter, hipStream_t on) {      // `waiter` continues after everything enqueued on `on` so far
     hipEvent_t e;
     PR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PR_CHECK_HIP(hipEventRecord(e, on));

@@ -603,11 +603,6 @@ struct ChainBwdJob {                // backward chain of a ReLU MLP with one ski
 };
 int launch_chain_bwd_group(const ChainBwdJob* jobs, const long* max_rows, int count, hipStream_t s);
 
-// The library's second stream (one per device, created on first use, never destroyed) and the event that orders one stream behind
-// another: small-grid kernels that are independent of the persistent tile kernels run beside them (backward.hip).
-int lane_stream(hipStream_t* out);
-int stream_wait(hipStream_t waiter, hipStream_t on);      // `waiter` continues after everything enqueued on `on` so far
-
 // Every weight-gradient product of a backward pass in one launch (k_gemm_tn_all in gemm.hip): the products of all layers of
 // all objects as (job, split of TN_ALL_CHUNK sample rows, 128 x 128 tile) work items of a persistent grid.
 constexpr int TN_ALL_MAX = 96;         // jobs per launch

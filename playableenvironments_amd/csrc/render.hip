@@ -586,7 +586,39 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
         }   // pass
         if (train_grouped) {
             PR_TRY(launch_mlp_group(jobs, job_rows, K, s));                  // phase 1 of every object
-            hipStream_t div_lane = nullptr;
+            static thread_local BnFoldJobs bj;
+            for (int stage = 1; stage <= 2; ++stage) {                       // statistics + fold of all objects, then their next phase
+                for (int k = 0; k < K; ++k) {
+                    TrainJob& J = train_jobs[k];
+                    const pr_object_model_t& m = *J.m;
+                    BnFoldJob& b = bj.job[k];
+                    memset(&b, 0, sizeof(b));
+                    b.count = J.stat_count; b.momentum = 0.1f; b.frozen = J.frozen ? 1 : 0;
+                    b.style = c.style + (size_t)k * m.style_features; b.style_stride = K * m.style_features; b.S = m.style_features;
+                    b.frames = c.frames; b.eps = m.bn_eps;
+                    b.table = const_cast<float*>(J.mp.adain); b.row_floats = J.mp.adain_stride;
+                    if (stage == 1) {
+                        b.stats = J.stats; b.width = J.d.W; b.width_pad = J.d.Wpad;
+                        b.running_mean = m.bn1_mean; b.running_var = m.bn1_var; b.num_batches_tracked = (long long*)m.bn1_batches;
+                        b.batch_mean = J.batch; b.batch_var = J.batch + MAX_WIDTH;
+                        b.affine = m.affine1; b.g_off = 0; b.b_off = J.d.Wpad;
+                        J.mp.split3 = 0;     // (the head phases read fp32 fragments)
+                        J.mp.phase = 2; J.mp.h_in = J.h1; J.mp.h_in_width = J.d.Wpad; J.mp.h_out = J.h2; J.mp.h_out_width = J.d.W2pad;
+                        J.mp.stats = J.stats + 2 * MAX_WIDTH;
+                    } else {
+                        b.stats = J.stats + 2 * MAX_WIDTH; b.width = J.d.W2; b.width_pad = J.d.W2pad;
+                        b.running_mean = m.bn4_mean; b.running_var = m.bn4_var; b.num_batches_tracked = (long long*)m.bn4_batches;
+                        b.batch_mean = J.batch + 2 * MAX_WIDTH; b.batch_var = J.batch + 3 * MAX_WIDTH;
+                        b.affine = m.affine4; b.g_off = 2 * J.d.Wpad; b.b_off = 2 * J.d.Wpad + J.d.W2pad;
+                        b.normalised_out = (outs[t] && outs[t]->normalised_samples) ? outs[t]->normalised_samples + k : nullptr;
+                        J.mp.phase = 3; J.mp.h_in = J.h2; J.mp.h_in_width = J.d.W2pad; J.mp.h_out = nullptr;
+                    }
+                    PR_REQUIRE(b.affine.weight && b.affine.bias && b.running_mean && b.running_var, "AdaIN parameters missing");
+                    jobs[k] = J.mp;
+                }
+                PR_TRY(launch_bn_fold_group(bj, K, s));
+                PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
+            }
             // Hutchinson divergence of the displacement fields (train mode with a graph): the ray benders of the call as one launch
             static thread_local DivChainJob dj[PR_MAX_OBJECTS];
             long div_rows[PR_MAX_OBJECTS];
@@ -624,61 +656,7 @@ static int render(const pr_call_t& c, const pr_object_t* objs, const pr_outputs_
                 div_rows[div_jobs] = (long)cap_rows;
                 ++div_jobs;
             }
-            // (it needs phase 1's saved bender state only: on the library's second stream it runs beside the BatchNorm folds and the head
-            // phases - small launches and launch gaps of the caller's stream - and is joined in front of the compositing)
-            if (div_jobs) {
-#ifndef PR_FWD_ONE_STREAM
-                PR_TRY(lane_stream(&div_lane));
-                PR_TRY(stream_wait(div_lane, s));
-#endif
-                const int launched = launch_div_chain_group(dj, div_rows, div_jobs, div_lane ? div_lane : s);
-                if (launched != PR_OK) {
-                    if (div_lane) (void)stream_wait(s, div_lane);
-                    return launched;
-                }
-            }
-            static thread_local BnFoldJobs bj;
-            auto head_phases = [&]() -> int {
-            for (int stage = 1; stage <= 2; ++stage) {                       // statistics + fold of all objects, then their next phase
-                for (int k = 0; k < K; ++k) {
-                    TrainJob& J = train_jobs[k];
-                    const pr_object_model_t& m = *J.m;
-                    BnFoldJob& b = bj.job[k];
-                    memset(&b, 0, sizeof(b));
-                    b.count = J.stat_count; b.momentum = 0.1f; b.frozen = J.frozen ? 1 : 0;
-                    b.style = c.style + (size_t)k * m.style_features; b.style_stride = K * m.style_features; b.S = m.style_features;
-                    b.frames = c.frames; b.eps = m.bn_eps;
-                    b.table = const_cast<float*>(J.mp.adain); b.row_floats = J.mp.adain_stride;
-                    if (stage == 1) {
-                        b.stats = J.stats; b.width = J.d.W; b.width_pad = J.d.Wpad;
-                        b.running_mean = m.bn1_mean; b.running_var = m.bn1_var; b.num_batches_tracked = (long long*)m.bn1_batches;
-                        b.batch_mean = J.batch; b.batch_var = J.batch + MAX_WIDTH;
-                        b.affine = m.affine1; b.g_off = 0; b.b_off = J.d.Wpad;
-                        J.mp.split3 = 0;     // (the head phases read fp32 fragments)
-                        J.mp.phase = 2; J.mp.h_in = J.h1; J.mp.h_in_width = J.d.Wpad; J.mp.h_out = J.h2; J.mp.h_out_width = J.d.W2pad;
-                        J.mp.stats = J.stats + 2 * MAX_WIDTH;
-                    } else {
-                        b.stats = J.stats + 2 * MAX_WIDTH; b.width = J.d.W2; b.width_pad = J.d.W2pad;
-                        b.running_mean = m.bn4_mean; b.running_var = m.bn4_var; b.num_batches_tracked = (long long*)m.bn4_batches;
-                        b.batch_mean = J.batch + 2 * MAX_WIDTH; b.batch_var = J.batch + 3 * MAX_WIDTH;
-                        b.affine = m.affine4; b.g_off = 2 * J.d.Wpad; b.b_off = 2 * J.d.Wpad + J.d.W2pad;
-                        b.normalised_out = (outs[t] && outs[t]->normalised_samples) ? outs[t]->normalised_samples + k : nullptr;
-                        J.mp.phase = 3; J.mp.h_in = J.h2; J.mp.h_in_width = J.d.W2pad; J.mp.h_out = nullptr;
-                    }
-                    PR_REQUIRE(b.affine.weight && b.affine.bias && b.running_mean && b.running_var, "AdaIN parameters missing");
-                    jobs[k] = J.mp;
-                }
-                PR_TRY(launch_bn_fold_group(bj, K, s));
-                PR_TRY(launch_mlp_group(jobs, job_rows, K, s));
-            }
-            return PR_OK;
-            };
-            int phases_status = head_phases();
-            if (div_lane) {                                  // join, whatever happened: the compositing reads the divergence estimate
-                const int joined = stream_wait(s, div_lane);
-                if (phases_status == PR_OK) phases_status = joined;
-            }
-            PR_TRY(phases_status);
+            if (div_jobs) PR_TRY(launch_div_chain_group(dj, div_rows, div_jobs, s));
         }
 
         if (grouped) {
