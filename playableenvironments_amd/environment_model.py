@@ -898,7 +898,7 @@ class EnvironmentModel(Tracked, nn.Module):
             del self._replays[key]                              # stale: weights / precision / step changed since (re-record below)
             entry = None
         if entry is None:
-            while len(self._replays) >= self.frame_replay_slots:        # a handful of frame shapes at most: drop the oldest one
+            while len(self._replays) >= max(1, int(self.frame_replay_slots)):        # a handful of frame shapes at most: drop the oldest one
                 self._replays.pop(next(iter(self._replays)))
             self._replays[key] = (signature, None)              # seen once: the next call with this signature records
             return None

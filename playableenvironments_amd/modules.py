@@ -24,6 +24,7 @@ import torch.nn as nn
 #: of another class (a user swapped a stock ``nn.Linear`` in) is never cached (``tree_is_tracked``).
 REGISTRATION_EPOCH = [0]
 _TREE_SLOTS = ("_parameters", "_buffers", "_modules")
+_BUFFER_TYPE = getattr(nn, "Buffer", nn.Parameter)      # (torch >= 2.5: assigning an nn.Buffer registers a buffer)
 
 
 class Tracked:
@@ -34,7 +35,8 @@ class Tracked:
 
     def __setattr__(self, name, value):
         d = self.__dict__
-        if not d.get("_is_replica") and (isinstance(value, (torch.Tensor, nn.Module)) or name in _TREE_SLOTS or
+        # (a plain tensor under a NEW name is an ordinary attribute - the composer's scratch, a noise seed word - not a registration)
+        if not d.get("_is_replica") and (isinstance(value, (nn.Parameter, nn.Module, _BUFFER_TYPE)) or name in _TREE_SLOTS or
                                          any(name in (d.get(slot) or ()) for slot in _TREE_SLOTS)):
             REGISTRATION_EPOCH[0] += 1
         super().__setattr__(name, value)
