@@ -63,6 +63,8 @@ def compact_result(result: dict, full_path=None) -> dict:
     roof = dict(r.get("roofline") or {})
     line = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if "frames_per_s_256x256" in r:
+        line["frames_per_s_256x256"] = r["frames_per_s_256x256"]       # (BASELINE.json: "Mrays/s (and frames/s at 256x256)")
     cfgw = dict(r.get("config") or {})
     line["config"] = cfgw
     line["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from_this_library",
