@@ -282,13 +282,17 @@ class _RenderFunction(torch.autograd.Function):
                             getattr(ogs[ty], field)[k] = g.data_ptr()
         # every parameter gradient is a view of ONE zero-initialised buffer (a single fill instead of one per tensor;
         # parallel.allreduce_gradients reduces such a buffer in place, without flattening copies)
-        flat = torch.zeros(sum(p.numel() for p in ctx.params), **f32)
+        # ONE zero fill for the parameter gradients and the three input-gradient buffers behind them
+        total = sum(p.numel() for p in ctx.params)
+        total_padded = (total + 63) // 64 * 64
+        both = torch.zeros(total_padded + N * K * (12 + S + D), **f32)
+        flat = both[:total]
         grads, offset = {}, 0
         for p in ctx.params:
             grads[id(p)] = flat[offset:offset + p.numel()].view(p.shape)
             offset += p.numel()
         ig = _lib.InputGrads()
-        small = torch.zeros(N * K * (12 + S + D), **f32)          # (one fill for the three input-gradient buffers)
+        small = both[total_padded:]
         d_w2o = small[:N * K * 12].view(N, K, 3, 4)
         d_style = small[N * K * 12:N * K * (12 + S)].view(N, K, S)
         d_def = small[N * K * (12 + S):].view(N, K, D)
@@ -725,6 +729,15 @@ class ObjectComposer(Tracked, nn.Module):
             self._budget_ok = need       # (a training loop asks for the same size every step; reset with the other caches)
         return budget
 
+    def _hook_tensor(self, device) -> torch.Tensor:
+        """The reference's ``pytorch_hook`` entry (object_composer.py:890: a dummy tensor that gives ``nn.DataParallel`` something to
+        gather): one zero tensor per device, made once - a fill launch per call is 1 % of a small frame.  Shared between the result
+        dictionaries of this composer: read-only by contract."""
+        key = ("hook", str(device))
+        if key not in self._linspace:
+            self._linspace[key] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=device)
+        return self._linspace[key]
+
     def _linspace_for(self, count: int, device) -> torch.Tensor:
         key = (count, str(device))
         if key not in self._linspace:
@@ -900,7 +913,7 @@ class ObjectComposer(Tracked, nn.Module):
                     if k < K:
                         entry["extra_outputs"] = {}
                     results[ty][f"object_{k}" if k < K else "global"] = entry
-            results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
+            results["pytorch_hook"] = self._hook_tensor(dev)
             return results, None
 
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -1213,7 +1226,7 @@ class ObjectComposer(Tracked, nn.Module):
                 results[ty]["_samples"] = [p[ty]["_samples"] for p in pieces]
             if layout is not None:
                 results[ty]["global"]["decoder_features"] = [m.reshape(lead + list(m.shape[1:])) for m in pieces[0][ty]["_decoder"]]
-        results["pytorch_hook"] = torch.zeros((1, 1, 1, 1, 1, 1, 1, 1, 1), device=dev)
+        results["pytorch_hook"] = self._hook_tensor(dev)
         return results, (state if _save else None)
 
     def forward_expected_positions(self, ray_origins: torch.Tensor, ray_directions: torch.Tensor, focal_normals: torch.Tensor,
