@@ -714,15 +714,13 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
     Smem& S = *reinterpret_cast<Smem*>(smem_raw);
     const int tid = threadIdx.x;
     const int total = *p.total;
+    PR_PHASE_BEGIN();
     if (GROUP) {
         __syncthreads();   // every wave has left the previous object's last tile (head weights, flags, X are reused)
         if (tid == 0) S.next_tile = atomicAdd(p.tile_counter, 1);
     }
-    // stage the small head weights once: [0, Wpad] sigma weights + bias, then 3 rows of the bender head
+    // stage the small head weights once: [0, Wpad] sigma weights + bias (the 3 rows of the bender head are read from L2: HEAD_BENDER)
     for (int i = tid; i <= p.Wpad; i += MLP_THREADS) S.head_w[i] = p.sigma_w[i];
-    const bool bender_head_staged = p.has_bender && 3 * p.BWpad <= HEAD_BENDER;
-    if (bender_head_staged)
-        for (int i = tid; i < 3 * p.BWpad; i += MLP_THREADS) S.head_w[HEAD_SIGMA + i] = p.b_out[i];
     __syncthreads();
     int pending = 0;   // rows on this workgroup's pending stack (sigma-gated head), uniform across the workgroup
     EncRegs enc;       // this thread's share of the current network input (see fill_encoding)
@@ -811,7 +809,7 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             // output head (no bias), * size, clamp into the box  (positional_ray_bender_model.py:108-140)
             for (int s = tid >> 3; s < TILE_M; s += MLP_THREADS / 8) {
                 float out[3];
-                row_dots(S, s, bender_head_staged ? S.head_w + HEAD_SIGMA : p.b_out, p.BWpad, p.BWpad, 3, out);
+                row_dots(S, s, as_global(p.b_out), p.BWpad, p.BWpad, 3, out);
                 if ((tid & 7) != 0) continue;
                 float d[3], bent[3];
                 if (TRAIN && p.save_braw && (S.flags[s] & 1))
@@ -859,8 +857,10 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             } else {
                 run_layer(p.layers[l], S, p, tile_base, /*input_kind=*/0, enc);
             }
+            PR_PHASE(10);
             if (TRAIN && p.save_act && !(PR_TRAINFWD_ABLATE & 1))
                 write_tile_rows(S, p.save_act + (size_t)l * p.save_act_stride, p.Wpad, p.Wpad, tile_base, false);
+            PR_PHASE(11);
         }
 
         PR_PHASE(15);
@@ -907,14 +907,18 @@ __device__ __forceinline__ void mlp_tile_loop(const MlpParams& p) {
             Layer raw = p.layers[p.n_backbone];
             raw.epi = EPI_FEATURES;   // plain store into X
             run_layer<false, false, true, SPLIT>(raw, S, p, tile_base, 0, enc, nullptr, nullptr, (PR_TRAINFWD_ABLATE & 4) ? nullptr : &cstats, &cur);
+            PR_PHASE(12);
             if (tid < TILE_M && (S.flags[tid] & 1)) p.row_flags[tile_base + tid] = S.flags[tid];
             write_tile_rows(S, p.h_out, p.h_out_width, p.h_out_width, tile_base, /*zero_dead=*/false);
             count_stat_rows(S, p);
+            PR_PHASE(13);
             __syncthreads();
+            PR_PHASE(14);
         }
     }
     if (!TRAIN && p.gate) gated_head_flush(S, p, pending, enc);
     if (TRAIN) flush_column_stats(cstats, p, p.layers[p.n_backbone].nblk);
+    PR_PHASE_FLUSH();
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma(MlpParams p) { mlp_tile_loop<false, false>(p); }
@@ -1360,6 +1364,20 @@ int launch_mlp_group(const MlpParams* host_jobs, const int* max_rows, int count,
         else
             hipLaunchKernelGGL(k_mlp_mfma_group, dim3(grid), dim3(MLP_THREADS), sizeof(Smem), s, g.jobs[0], g.jobs[1], g.jobs[2], g.jobs[3], n);
         PR_LAUNCH_CHECK();
+#ifdef PR_MLP_TIMING
+        {
+            static unsigned long long before[16];
+            unsigned long long now[16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(now, HIP_SYMBOL(g_mlp_phase), sizeof(now));
+            fprintf(stderr, "[mlp group phases, phase %d%s, grid %d, Mticks of thread 0 summed over workgroups]", phase, split3 ? " split" : "", grid);
+            for (int i = 0; i < 16; ++i) {
+                if (now[i] != before[i]) fprintf(stderr, " p%d=%.2f", i, (double)(now[i] - before[i]) * 1e-6);
+                before[i] = now[i];
+            }
+            fprintf(stderr, "\n");
+        }
+#endif
     }
     return PR_OK;
 }

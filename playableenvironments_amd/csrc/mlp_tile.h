@@ -28,6 +28,9 @@ struct Smem {
                              // head only): its density is not <= 0, i.e. its feature row can reach a compositing sum
     int dest[TILE_M];        // gated head: compact feature row a tile row is written to (-1: none)
     int src[TILE_M];         // gated head: slot of the workgroup's pending stack a tile row is exchanged with (-1: none)
+#ifdef PR_MLP_TIMING
+    unsigned long long phase_acc[16];   // phase timing build: thread 0's clock deltas, flushed once per tile loop
+#endif
 };
 static_assert(sizeof(Smem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "the workgroups of one CU must fit its LDS");
 static_assert(offsetof(Smem, head_w) % 16 == 0 && offsetof(Smem, X) % 16 == 0 && offsetof(Smem, pos) % 16 == 0,
@@ -105,10 +108,26 @@ __device__ unsigned long long g_mlp_phase[16];
 #define PR_PHASE(idx)                                                                      \
     do {                                                                                   \
         const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
-        if (threadIdx.x == 0) atomicAdd(&g_mlp_phase[idx], _n - _pt);                      \
+        if (threadIdx.x == 0) S.phase_acc[idx] += _n - _pt;                                \
         _pt = _n;                                                                          \
     } while (0)
+// (global atomics per phase queue in front of the wave's weight loads and distort what they time: LDS sums, one flush per loop)
+#define PR_PHASE_COUNT(idx, n) do { if (threadIdx.x == 0) S.phase_acc[idx] += (n); } while (0)
+#define PR_PHASE_BEGIN()                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0)                                                              \
+            for (int _i = 0; _i < 16; ++_i) S.phase_acc[_i] = 0;                           \
+    } while (0)
+#define PR_PHASE_FLUSH()                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0)                                                              \
+            for (int _i = 0; _i < 16; ++_i)                                                \
+                if (S.phase_acc[_i]) atomicAdd(&g_mlp_phase[_i], S.phase_acc[_i]);         \
+    } while (0)
 #else
+#define PR_PHASE_BEGIN() do {} while (0)
+#define PR_PHASE_COUNT(idx, n) do {} while (0)
+#define PR_PHASE_FLUSH() do {} while (0)
 #define PR_PHASE_T0() do {} while (0)
 #define PR_PHASE(idx) do {} while (0)
 #endif
@@ -394,8 +413,8 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
     const int ks = sg.kq >> 1;                       // K steps of 16 (even: the padded widths are multiples of 32)
     const float* ap = X + r * LDX + 8 * half;
     // [column block][step][plane][lane] fragments of 16 bytes
-    const bf16x8* wpA = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)cbA * ks * 192 + lane;
-    const bf16x8* wpB = reinterpret_cast<const bf16x8*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
+    const auto* wpA = as_global(reinterpret_cast<const bf16x8*>(sg.w)) + (size_t)cbA * ks * 192 + lane;
+    const auto* wpB = as_global(reinterpret_cast<const bf16x8*>(sg.w)) + (size_t)(two ? cbB : cbA) * ks * 192 + lane;
     // software pipeline with NAMED even / odd register sets (a rotating set costs a register copy per value and step: 6 moves
     // per MFMA, measured): the MFMAs of a step run on fragments that were split during the previous step; while they execute, the
     // raw operands of the next step (requested in front of them) are split - the conversions sit in the shadow of the MFMAs
@@ -413,7 +432,7 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
             const size_t at = (size_t)(s + 1) * 192;
             oa0 = wpA[at]; oa1 = wpA[at + 64]; oa2 = wpA[at + 128];
-            if (two) { ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128]; }
+            ob0 = wpB[at]; ob1 = wpB[at + 64]; ob2 = wpB[at + 128];      // (unconditional: see wpB)
             __builtin_amdgcn_sched_barrier(0);      // the requests stay in FRONT of the step's MFMAs (hipcc sank them behind: L2 latency exposed every step)
             PR_STEP_MFMAS(e0, e1, ea0, ea1, ea2, eb0, eb1, eb2);
             o0 = split_fragment(xl, xh); o1 = split_fragment(yl, yh);
@@ -428,7 +447,7 @@ __device__ __forceinline__ void tile_products_bf16(const Seg& sg, int nblk, cons
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
             const size_t at = (size_t)sn * 192;
             ea0 = wpA[at]; ea1 = wpA[at + 64]; ea2 = wpA[at + 128];
-            if (two) { eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128]; }
+            eb0 = wpB[at]; eb1 = wpB[at + 64]; eb2 = wpB[at + 128];
             __builtin_amdgcn_sched_barrier(0);
             PR_STEP_MFMAS(o0, o1, oa0, oa1, oa2, ob0, ob1, ob2);
             e0 = split_fragment(xl, xh); e1 = split_fragment(yl, yh);
@@ -488,6 +507,36 @@ __device__ __forceinline__ FragH split_fragment_h(const float4& lo, const float4
     } while (0)
 
 __device__ __forceinline__ FragH split_fragment_scaled_h(const float4& lo, const float4& hi, float scale);
+// timing builds only (results are wrong): PR_LEAN_ABLATE 1 = every step reads the first step's weight fragments, 2 = no operand
+// conversions, 4 = a third of the MFMAs
+#ifndef PR_LEAN_ABLATE
+#define PR_LEAN_ABLATE 0
+#endif
+#if PR_LEAN_ABLATE & 1
+#define PR_LEAN_WSTEP(s) ((s) & 1)
+#else
+#define PR_LEAN_WSTEP(s) (s)
+#endif
+#if PR_LEAN_ABLATE & 2
+__device__ __forceinline__ FragH raw_fragment_h(const float4& lo, const float4& hi) {
+    FragH f;
+    f.hi = __builtin_bit_cast(f16x8_t, lo);
+    f.lo = __builtin_bit_cast(f16x8_t, hi);
+    return f;
+}
+#define PR_LEAN_SPLIT(l, h) raw_fragment_h(l, h)
+#else
+#define PR_LEAN_SPLIT(l, h) split_fragment_scaled_h(l, h, scale)
+#endif
+#if PR_LEAN_ABLATE & 4
+#define PR_LEAN_MFMAS(F0, F1, WAH, WAL, WBH, WBL)                                  \
+    do {                                                                          \
+        PR_MFMA_F16(a00, F0.lo, WAH); PR_MFMA_F16(a01, F1.hi, WAL);               \
+        if (two) { PR_MFMA_F16(a10, F0.hi, WBH); PR_MFMA_F16(a11, F1.lo, WBL); }  \
+    } while (0)
+#else
+#define PR_LEAN_MFMAS(F0, F1, WAH, WAL, WBH, WBL) PR_STEP_MFMAS_H(F0, F1, WAH, WAL, WBH, WBL)
+#endif
 __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
                                                          f32x16& a11, float scale) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -499,36 +548,38 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
     const int ks = sg.kq >> 1;
     const float* ap = X + r * LDX + 8 * half;
     // per (column block, step): hi fragment (64 lanes x 16 B), then lo fragment
-    const f16x8_t* wpA = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)cbA * ks * 128 + lane;
-    const f16x8_t* wpB = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
+    const auto* wpA = as_global(reinterpret_cast<const f16x8_t*>(sg.w)) + (size_t)cbA * ks * 128 + lane;
+    // (a wave without a second column block requests its first one again: requests under `if (two)` leave the number of requests in
+    // flight unknown at the step's s_waitcnt, and hipcc then waits for one of the requests it has just issued)
+    const auto* wpB = as_global(reinterpret_cast<const f16x8_t*>(sg.w)) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
     float4 xl = *reinterpret_cast<const float4*>(ap), xh = *reinterpret_cast<const float4*>(ap + 4);
     float4 yl = *reinterpret_cast<const float4*>(ap + 32 * LDX), yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
     f16x8_t eah = wpA[0], eal = wpA[64], ebh = wpB[0], ebl = wpB[64];
     f16x8_t oah, oal, obh = ebh, obl = ebl;
     for (int s = 0; s < ks; s += 2) {
         {
-            const FragH f0 = split_fragment_scaled_h(xl, xh, scale), f1 = split_fragment_scaled_h(yl, yh, scale);
+            const FragH f0 = PR_LEAN_SPLIT(xl, xh), f1 = PR_LEAN_SPLIT(yl, yh);
             const float* an = ap + 16 * (s + 1);
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)(s + 1) * 128;
+            const size_t at = (size_t)PR_LEAN_WSTEP(s + 1) * 128;
             oah = wpA[at]; oal = wpA[at + 64];
-            if (two) { obh = wpB[at]; obl = wpB[at + 64]; }
+            obh = wpB[at]; obl = wpB[at + 64];      // (unconditional: see wpB)
             __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of the step's MFMAs
-            PR_STEP_MFMAS_H(f0, f1, eah, eal, ebh, ebl);
+            PR_LEAN_MFMAS(f0, f1, eah, eal, ebh, ebl);
             __builtin_amdgcn_sched_barrier(0);
         }
         {
-            const FragH f0 = split_fragment_scaled_h(xl, xh, scale), f1 = split_fragment_scaled_h(yl, yh, scale);
+            const FragH f0 = PR_LEAN_SPLIT(xl, xh), f1 = PR_LEAN_SPLIT(yl, yh);
             const int sn = (s + 2 < ks) ? s + 2 : s;
             const float* an = ap + 16 * sn;
             xl = *reinterpret_cast<const float4*>(an); xh = *reinterpret_cast<const float4*>(an + 4);
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
-            const size_t at = (size_t)sn * 128;
+            const size_t at = (size_t)PR_LEAN_WSTEP(sn) * 128;
             eah = wpA[at]; eal = wpA[at + 64];
-            if (two) { ebh = wpB[at]; ebl = wpB[at + 64]; }
+            ebh = wpB[at]; ebl = wpB[at + 64];
             __builtin_amdgcn_sched_barrier(0);
-            PR_STEP_MFMAS_H(f0, f1, oah, oal, obh, obl);
+            PR_LEAN_MFMAS(f0, f1, oah, oal, obh, obl);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -554,8 +605,8 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
     __builtin_amdgcn_s_setprio(1);
     const int ks = sg.kq >> 1;
     const float* ap = X + r * LDX + 8 * half;
-    const f16x8_t* wpA = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)cbA * ks * 128 + lane;
-    const f16x8_t* wpB = reinterpret_cast<const f16x8_t*>(sg.w) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
+    const auto* wpA = as_global(reinterpret_cast<const f16x8_t*>(sg.w)) + (size_t)cbA * ks * 128 + lane;
+    const auto* wpB = as_global(reinterpret_cast<const f16x8_t*>(sg.w)) + (size_t)(two ? cbB : cbA) * ks * 128 + lane;
     float4 xl = *reinterpret_cast<const float4*>(ap), xh = *reinterpret_cast<const float4*>(ap + 4);
     float4 yl = *reinterpret_cast<const float4*>(ap + 32 * LDX), yh = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
     FragH e0 = split_fragment_scaled_h(xl, xh, scale), e1 = split_fragment_scaled_h(yl, yh, scale), o0, o1;
@@ -568,7 +619,7 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
             const size_t at = (size_t)(s + 1) * 128;
             oah = wpA[at]; oal = wpA[at + 64];
-            if (two) { obh = wpB[at]; obl = wpB[at + 64]; }
+            obh = wpB[at]; obl = wpB[at + 64];      // (unconditional: see wpB)
             __builtin_amdgcn_sched_barrier(0);
             PR_STEP_MFMAS_H(e0, e1, eah, eal, ebh, ebl);
             o0 = split_fragment_scaled_h(xl, xh, scale); o1 = split_fragment_scaled_h(yl, yh, scale);
@@ -582,7 +633,7 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
             yl = *reinterpret_cast<const float4*>(an + 32 * LDX); yh = *reinterpret_cast<const float4*>(an + 32 * LDX + 4);
             const size_t at = (size_t)sn * 128;
             eah = wpA[at]; eal = wpA[at + 64];
-            if (two) { ebh = wpB[at]; ebl = wpB[at + 64]; }
+            ebh = wpB[at]; ebl = wpB[at + 64];
             __builtin_amdgcn_sched_barrier(0);
             PR_STEP_MFMAS_H(o0, o1, oah, oal, obh, obl);
             e0 = split_fragment_scaled_h(xl, xh, scale); e1 = split_fragment_scaled_h(yl, yh, scale);
@@ -608,8 +659,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
     PR_PHASE_T0();
     f32x16 a00, a01, a10, a11;           // [column block A / B][row block 0 / 1]
     {
-        float biasA = (L.bias != nullptr && active) ? L.bias[cbA * 32 + r] : 0.f;
-        float biasB = (L.bias != nullptr && two) ? L.bias[cbB * 32 + r] : 0.f;
+        float biasA = (L.bias != nullptr && active) ? as_global(L.bias)[cbA * 32 + r] : 0.f;
+        float biasB = (L.bias != nullptr && two) ? as_global(L.bias)[cbB * 32 + r] : 0.f;
         if (SPLIT) {        // the split-precision segments hold w x 2^8, the operand is multiplied by 2^k: the accumulators run at that scale
             biasA = ldexpf(biasA, k + TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
             biasB = ldexpf(biasB, k + TRAIN_SPLIT_WEIGHT_SCALE_LOG2);
@@ -651,6 +702,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         continue;   // measurement build: no matrix work (results are wrong)
 #endif
         if (SPLIT) {             // phase 1 of a training call with PR_FLAG_SPLIT_BACKWARD: fp16 pairs
+            PR_PHASE_COUNT(8, 1000000ull * (sg.kq >> 1));       // K steps of 16 (read as p8 x 1e6)
+            PR_PHASE_COUNT(9, 1000000ull);                      // products
             tile_products_f16x3_lean(sg, nblk, S.X, a00, a01, a10, a11, ldexpf(1.0f, k));
             continue;
         }
@@ -658,17 +711,17 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         __builtin_amdgcn_s_setprio(1);
         const int kq = sg.kq;   // even (K is padded to a multiple of 16)
         const float* ap = S.X + r * LDX + half * 4 * kq;
-        const float4* wpA = reinterpret_cast<const float4*>(sg.w) + (size_t)cbA * kq * 64 + lane;
+        const auto* wpA = as_global(reinterpret_cast<const f32x4_t*>(sg.w)) + (size_t)cbA * kq * 64 + lane;
         // two steps in flight: even/odd fragments live in their own registers and are re-loaded
         // right after their last use, a full step before they are needed again
         float4 x0e = *reinterpret_cast<const float4*>(ap);
         float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
         float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
         float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-        float4 wAe = wpA[0], wAo = wpA[64];
+        f32x4_t wAe = wpA[0], wAo = wpA[64];
         if (two) {
-            const float4* wpB = reinterpret_cast<const float4*>(sg.w) + (size_t)cbB * kq * 64 + lane;
-            float4 wBe = wpB[0], wBo = wpB[64];
+            const auto* wpB = as_global(reinterpret_cast<const f32x4_t*>(sg.w)) + (size_t)cbB * kq * 64 + lane;
+            f32x4_t wBe = wpB[0], wBo = wpB[64];
             for (int q = 0; q < kq; q += 2) {
                 const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
                 PR_MFMA4(a00, x0e, wAe);
@@ -882,7 +935,9 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
 
 // dot products of every tile row with `nout` (<= 3) weight rows of length `width` (raw, padded),
 // for tile row `s`: 8 threads per row (callers loop s = tid / 8, + MLP_THREADS / 8, ...); the result is valid in all 8.
-__device__ __forceinline__ void row_dots(const Smem& S, int s, const float* w, int width, int wstride, int nout, float* out) {
+// (W: an LDS array or an as_global() pointer - a plain `const float*` chosen between the two at run time would be a flat pointer)
+template <class W>
+__device__ __forceinline__ void row_dots(const Smem& S, int s, W w, int width, int wstride, int nout, float* out) {
     const int part = threadIdx.x & 7;
     float acc[3] = {0.f, 0.f, 0.f};
     for (int k = part; k < width; k += 8) {

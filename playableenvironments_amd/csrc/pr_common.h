@@ -66,6 +66,23 @@ __device__ __forceinline__ void pr_stagger(int kernel_bit) {
 #endif
 }
 
+// A device pointer that reaches a kernel through a table (a Layer / Seg copied out of the kernel arguments, a pointer chosen at run
+// time) has lost its address space: hipcc then emits flat_load, and - because a flat access may also be an LDS access - waits for
+// EVERY outstanding memory and LDS operation (s_waitcnt vmcnt(0) lgkmcnt(0)) in front of the first use of any loaded value.  In a
+// software-pipelined K loop that wait includes the requests just issued for the NEXT step: the pipelining is gone and every step
+// pays a full L2 round trip.  as_global() states what the host code guarantees - the pointer names global memory.
+#define PR_GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const PR_GLOBAL_AS T* as_global(const T* p) {
+    return (const PR_GLOBAL_AS T*)(p);
+}
+template <class T>
+__device__ __forceinline__ PR_GLOBAL_AS T* as_global(T* p) {
+    return (PR_GLOBAL_AS T*)(p);
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));     // (a native vector: loadable through an address-space pointer, float4 is a class)
+
 constexpr int MAX_WIDTH = 256;    // padded layer width limit (8 column blocks of 32)
 constexpr int LDX = MAX_WIDTH + 4;  // activation row stride (floats): conflict-free ds_read_b128
 constexpr int MAX_RESIDENT_TILES = 1024;   // upper bound of the persistent MLP grid (2 workgroups x CUs; 512 on MI355X)
