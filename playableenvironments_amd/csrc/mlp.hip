@@ -948,6 +948,7 @@ extern "C" int pr_debug_mlp_trace(unsigned long long* out) {
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                          int count) {
+    pr_stagger(4);
     mlp_tile_loop<true, true>(j0);
     if (count > 1) mlp_tile_loop<true, true>(j1);
     if (count > 2) mlp_tile_loop<true, true>(j2);
@@ -957,6 +958,7 @@ __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_tra
 // phase 1 of a training call in split precision (PR_FLAG_SPLIT_BACKWARD): the same tile loop on fp16-pair segments (tile_products_f16x3_lean)
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_mlp_mfma_train_group_split(MlpParams j0, MlpParams j1, MlpParams j2, MlpParams j3,
                                                                                               int count) {
+    pr_stagger(4);
     mlp_tile_loop<true, true, true>(j0);
     if (count > 1) mlp_tile_loop<true, true, true>(j1);
     if (count > 2) mlp_tile_loop<true, true, true>(j2);

@@ -318,16 +318,23 @@ struct Drain {
 };
 __device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int it) {
     const int idx = threadIdx.x + it * MLP_THREADS;
-    const int row = idx / d.w4, c = (idx - row * d.w4) * 4;
-    if (row < d.rows_valid) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
-#ifdef PR_DRAIN_NT
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
+    int row = idx / d.w4;
+    const int c = (idx - row * d.w4) * 4;
+    // no branch in the K loop (a branch ends the basic block, and with it the scheduling groups that keep the operand requests of the
+    // next step in front of this step's MFMAs): a thread whose row lies beyond the tile's real rows writes the LAST real row's chunk
+    // of its columns again - the same bytes its owner writes (X is read-only while a product runs; a tile has >= 1 real row)
+    row = row < d.rows_valid ? row : d.rows_valid - 1;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
+    // streamed once (the weight-gradient launch reads the stack from memory): non-temporal, so that the rows neither evict the weight
+    // fragments from L2 nor wait for an L2 line - the loads of the following steps stand behind these stores in the wave's
+    // request queue (one in-order counter on gfx9), and their waits end when the stores are acknowledged (measured: the NeRF chain
+    // of the step 1.105 -> 1.051 ms; -DPR_DRAIN_PLAIN is the plain-store measurement build)
+#ifdef PR_DRAIN_PLAIN
+    *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
 #else
-        *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
 #endif
-    }
 }
 
 // The same product in SPLIT precision (PR_FLAG_SPLIT_BACKWARD; `sg.w` then points at the bf16-triple packing of the segment,
@@ -707,6 +714,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
             tile_products_f16x3_lean(sg, nblk, S.X, a00, a01, a10, a11, ldexpf(1.0f, k));
             continue;
         }
+        PR_PHASE_COUNT(8, 1000000ull * (sg.kq >> 1));
+        PR_PHASE_COUNT(9, 1000000ull);
         // matrix work outranks the other resident tile's serial phases in the per-SIMD issue arbitration
         __builtin_amdgcn_s_setprio(1);
         const int kq = sg.kq;   // even (K is padded to a multiple of 16)
@@ -718,10 +727,15 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
         float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
         float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-        f32x4_t wAe = wpA[0], wAo = wpA[64];
         if (two) {
+            // (the first requests in the order the loop repeats them - even A, even B, odd A, odd B: hipcc merges the request queue of
+            // the loop entry with that of the back edge, and with A, A, B, B in front of the loop the wait for the even B fragment
+            // became vmcnt(0), i.e. every iteration waited for the odd fragments it had requested a moment before)
             const auto* wpB = as_global(reinterpret_cast<const f32x4_t*>(sg.w)) + (size_t)cbB * kq * 64 + lane;
-            f32x4_t wBe = wpB[0], wBo = wpB[64];
+            f32x4_t wAe = wpA[0], wBe = wpB[0];
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t wAo = wpA[64], wBo = wpB[64];
+            __builtin_amdgcn_sched_barrier(0);
             for (int q = 0; q < kq; q += 2) {
                 const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
                 PR_MFMA4(a00, x0e, wAe);
@@ -748,6 +762,10 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
         } else {
+            f32x4_t wAe = wpA[0];
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t wAo = wpA[64];
+            __builtin_amdgcn_sched_barrier(0);
             for (int q = 0; q < kq; q += 2) {
                 const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
                 PR_MFMA4(a00, x0e, wAe);

@@ -47,7 +47,7 @@ constexpr int MLP_THREADS = MLP_WAVES * 64;
 #define PR_STAGGER_RULE 0
 #endif
 #ifndef PR_STAGGER_KERNELS
-#define PR_STAGGER_KERNELS 0      // 1 head forward phases, 2 head backward phases
+#define PR_STAGGER_KERNELS 0      // 1 head forward phases, 2 head backward phases, 4 phase 1 of the training forward
 #endif
 #ifndef PR_STAGGER_SLEEPS
 #define PR_STAGGER_SLEEPS 2       // x 127 x 64 clocks (~3.4 us each)

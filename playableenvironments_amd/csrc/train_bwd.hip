@@ -86,8 +86,11 @@ __device__ __forceinline__ bool drains_in_loop(int nblk) {
 #endif
 }
 
-__device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
-                                              f32x16& a11, const Drain* drain = nullptr) {
+// DRAIN is a template parameter: tested inside the loop (a pointer compare and a branch) it ended the basic block in front of the
+// scheduling groups, and hipcc issued all 32 MFMAs of an iteration first and the operand requests of the next one behind them
+template <bool DRAIN>
+__device__ __forceinline__ void tile_products_loop(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                                   f32x16& a11, const Drain* drain) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, half = lane >> 5;
     const int cbA = wave, cbB = wave + MLP_WAVES;
@@ -102,10 +105,13 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
     float4 x1e = *reinterpret_cast<const float4*>(ap + 32 * LDX);
     float4 x0o = *reinterpret_cast<const float4*>(ap + 4);
     float4 x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4);
-    float4 wAe = wpA[0], wAo = wpA[64];
     if (two) {
+        // (first requests in the loop's order - even A, even B, odd A, odd B: see run_layer in mlp_tile.h)
         const float4* wpB = reinterpret_cast<const float4*>(sg.w) + (size_t)cbB * kq * 64 + lane;
-        float4 wBe = wpB[0], wBo = wpB[64];
+        float4 wAe = wpA[0], wBe = wpB[0];
+        __builtin_amdgcn_sched_barrier(0);
+        float4 wAo = wpA[64], wBo = wpB[64];
+        __builtin_amdgcn_sched_barrier(0);
         for (int q = 0; q < kq; q += 2) {
             const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
             PR_MFMA4(a00, x0e, wAe);
@@ -124,15 +130,28 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
             wBo = wpB[(size_t)qo * 64];
             x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
             x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
-            if (drain) drain_chunk(*drain, X, q >> 1);
+            if (DRAIN) drain_chunk(*drain, X, q >> 1);
+            // (the drained chunk: read from LDS with the even operands, stored behind the odd MFMAs and IN FRONT of the odd requests -
+            // as the last request of the iteration, the store stood between the even fragments and the top of the next iteration in
+            // the request queue, and the wait for the even B fragment also waited for the odd A fragment requested a moment before)
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DRAIN ? 3 : 2, 0);
+            if (DRAIN) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
     } else {
+        float4 wAe = wpA[0];
+        __builtin_amdgcn_sched_barrier(0);
+        float4 wAo = wpA[64];
+        __builtin_amdgcn_sched_barrier(0);
         for (int q = 0; q < kq; q += 2) {
             const int qe = (q + 2 < kq) ? q + 2 : q, qo = (q + 3 < kq) ? q + 3 : q + 1;
             PR_MFMA4(a00, x0e, wAe);
@@ -145,16 +164,28 @@ __device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const flo
             wAo = wpA[(size_t)qo * 64];
             x0o = *reinterpret_cast<const float4*>(ap + 4 * qo);
             x1o = *reinterpret_cast<const float4*>(ap + 32 * LDX + 4 * qo);
-            if (drain) drain_chunk(*drain, X, q >> 1);
+            if (DRAIN) drain_chunk(*drain, X, q >> 1);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, DRAIN ? 3 : 2, 0);
+            if (DRAIN) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
     }
     __builtin_amdgcn_s_setprio(0);
+}
+
+__device__ __forceinline__ void tile_products(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
+                                              f32x16& a11, const Drain* drain = nullptr) {
+    if (drain) tile_products_loop<true>(sg, nblk, X, a00, a01, a10, a11, drain);
+    else tile_products_loop<false>(sg, nblk, X, a00, a01, a10, a11, nullptr);
 }
 
 // MODE 0: exact fp32; 1: bf16 triples; 2: fp16 pairs of the operand x `scale` (chain_bwd_loop: per-tile power-of-two scales)
@@ -174,8 +205,8 @@ __device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int 
     for (int idx = threadIdx.x; idx < TILE_M * w4; idx += MLP_THREADS) {
         const int row = idx / w4, c = (idx - row * w4) * 4;
         if (row < rows_valid) {
-            const float4 v = *reinterpret_cast<const float4*>(X + row * LDX + c);
-            *reinterpret_cast<float4*>(dst + (size_t)(tile_base + row) * ld + c) = v;
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + row * LDX + c);
+            *reinterpret_cast<f32x4_t*>(dst + (size_t)(tile_base + row) * ld + c) = v;      // (non-temporal: no difference, measured)
         }
     }
 }
