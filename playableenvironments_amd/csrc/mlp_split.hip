@@ -225,10 +225,14 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
         f16x8 ah1E = *reinterpret_cast<const f16x8*>(a1h), al1E = *reinterpret_cast<const f16x8*>(a1l);
         f16x8 ah0O = *reinterpret_cast<const f16x8*>(a0h + 16), al0O = *reinterpret_cast<const f16x8*>(a0l + 16);
         f16x8 ah1O = *reinterpret_cast<const f16x8*>(a1h + 16), al1O = *reinterpret_cast<const f16x8*>(a1l + 16);
-        f16x8 bAhE = wpA[0], bAlE = wpA[64], bAhO = wpA[128], bAlO = wpA[192];
         if (two) {
+            // (the first requests in the order the loop repeats them - even A, even B, odd A, odd B: with A, A, B, B in front of the
+            // loop the merged request queue turned the wait for the even B fragments into vmcnt(0): see run_layer in mlp_tile.h)
             const f16x8* wpB = reinterpret_cast<const f16x8*>(sg.w) + (size_t)cbB * ks * 128 + lane;
-            f16x8 bBhE = wpB[0], bBlE = wpB[64], bBhO = wpB[128], bBlO = wpB[192];
+            f16x8 bAhE = wpA[0], bAlE = wpA[64], bBhE = wpB[0], bBlE = wpB[64];
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 bAhO = wpA[128], bAlO = wpA[192], bBhO = wpB[128], bBlO = wpB[192];
+            __builtin_amdgcn_sched_barrier(0);
             for (int s = 0; s < ks; s += 2) {
                 const int se = (PR_SPLIT_ABLATE & 1) ? 0 : ((s + 2 < ks) ? s + 2 : s), so = (PR_SPLIT_ABLATE & 1) ? 1 : ((s + 3 < ks) ? s + 3 : s + 1);
                 PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
@@ -263,6 +267,10 @@ __device__ __forceinline__ void run_layer_h(const Layer& L, SmemH& S, const MlpP
                 __builtin_amdgcn_sched_group_barrier(0x100, TERMS == 3 ? 4 : 2, 0);
             }
         } else {
+            f16x8 bAhE = wpA[0], bAlE = wpA[64];
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 bAhO = wpA[128], bAlO = wpA[192];
+            __builtin_amdgcn_sched_barrier(0);
             for (int s = 0; s < ks; s += 2) {
                 const int se = (PR_SPLIT_ABLATE & 1) ? 0 : ((s + 2 < ks) ? s + 2 : s), so = (PR_SPLIT_ABLATE & 1) ? 1 : ((s + 3 < ks) ? s + 3 : s + 1);
                 PR_SPLIT3(mA0, ah0E, al0E, bAhE, bAlE);
