@@ -564,6 +564,9 @@ __device__ __forceinline__ void bf16_split_pair(float x0, float x1, unsigned& p1
     p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2_g));
 }
 
+#ifndef PR_TNBF_ABLATE
+#define PR_TNBF_ABLATE 0      // timing builds only (results are wrong): 1 = slabs are not staged, 2 = no MFMAs, 4 = no operand requests
+#endif
 __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int split, unsigned char* T, float* RED) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
@@ -692,10 +695,10 @@ __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int s
     }
     __syncthreads();
     for (int m0 = m_begin; m0 < m_end; m0 += GK) {
-        fetch(ra0, rb0, w0, m0 + GK);           // (rows beyond m_end read nothing)
-        step();
+        if (!(PR_TNBF_ABLATE & 4)) fetch(ra0, rb0, w0, m0 + GK);           // (rows beyond m_end read nothing)
+        if (!(PR_TNBF_ABLATE & 2)) step();
         __syncthreads();
-        if (m0 + GK < m_end) stage(ra0, rb0, w0);
+        if (m0 + GK < m_end && !(PR_TNBF_ABLATE & 1)) stage(ra0, rb0, w0);
         __syncthreads();
     }
 #endif
@@ -742,6 +745,215 @@ __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int s
     }
 }
 
+
+// The same tile with the staging of the NEXT half slab inside the products of the current one.  In tn_all_tile_bf16 a slab is
+// multiplied (48 MFMAs per wave), then - behind a barrier - the next one is split into bf16 triples and written to LDS (~250 VALU
+// operations and 24 LDS stores per thread), then - behind another barrier - multiplied: measured with either half removed, the two
+// phases take the same time (0.87 ms each of a 1.41 ms launch; the second workgroup of the CU is all that overlaps them).  A plane
+// row already holds its 32 k-values as two independent halves (slots 0 - 1: k 0..15, slots 2 - 3: k 16..31), so the halves serve as a
+// double buffer of 16-row half slabs with no more LDS: while the MFMAs of half h read one pair of slots, the same wave converts half
+// h + 1 into the other pair (VALU work issues while the matrix pipe executes), ONE barrier per half slab.  Waves 0 - 1 stage the A
+// operand, waves 2 - 3 the B operand (four rows x four columns per thread and half slab: the 8-byte LDS stores of the full-slab
+// version); three register sets, the requests of half h + 3 issued at the top of half step h.
+// Requests are unconditional (clamped addresses, values zeroed afterwards where a row or column is outside): see as_global() in
+// pr_common.h for what requests under a branch do to the waits.
+// Measured (same box, per launch of the training step): 1.444 -> 1.376 ms; without the operand requests 1.126, MFMAs alone 0.745,
+// staging alone 0.892 - VALU work beside MFMAs of the same SIMD is only partly free (tools/perf/probe_overlap.hip: six conversions
+// per MFMA cost + 20 - 35 % with two waves per SIMD), and the requests are bound by the 5.2 GB the launch reads, not by their latency.
+// Explicit (MFMA, n x VALU) scheduling groups were slower than hipcc's own interleaving (1.39 vs 1.31 ms).
+__device__ __forceinline__ void tn_all_tile_bf16_overlap(const TnJob& p, int tile, int split, unsigned char* T, float* RED) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
+    const int M = *p.rows;
+    const int tiles_j = (p.nj + GT - 1) / GT;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * GT, j0 = tj * GT;
+    const int m_begin = split * TN_ALL_CHUNK;
+    const int m_end = (m_begin + TN_ALL_CHUNK < M) ? m_begin + TN_ALL_CHUNK : M;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const bool want_bias = p.bias_partial && tj == 0;
+    const bool side = p.w != nullptr && ti == 0;
+    const bool opB = wave >= 2;                      // this wave stages the B operand (wave-uniform)
+    const int t7 = tid & 127, c4 = t7 & 31, rq = t7 >> 5;
+    const int ncols = opB ? ((p.nj + 3) & ~3) : ((p.ni + 3) & ~3);
+    const int base_col = opB ? j0 : i0;
+    const bool colok = base_col + 4 * c4 < ncols;
+    const bool cols_full = base_col + GT <= ncols;   // (wave-uniform)
+    const size_t ldx = opB ? (size_t)p.ldb : (size_t)p.lda;
+    const float* __restrict__ gX = (opB ? p.B : p.A) + base_col + (colok ? 4 * c4 : 0);
+    // the side product's weights: B-staging threads read w[m]; everybody else (and every thread without a side product) reads a
+    // valid dummy with stride 0 - the requests stay unconditional
+    const float* __restrict__ gW = (side && opB) ? p.w : gX;
+    const size_t ldw = (side && opB) ? (size_t)p.ldw : 0;
+    unsigned char* planes = T + (opB ? 3 * TPLANE : 0);
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f}, wtot = 0.f;
+    const int halves = (m_end - m_begin + 15) >> 4;
+    if (halves > 0) {
+        f32x4_t s0[4], s1[4], s2[4];
+        float w0[4], w1[4], w2[4];
+        auto fetch = [&](f32x4_t (&sv)[4], float (&wv)[4], int h) {
+            const int mh = m_begin + 16 * h + rq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mh + 4 * i;
+                const int mc = m < m_end ? m : m_end - 1;
+                sv[i] = *reinterpret_cast<const f32x4_t*>(gX + (size_t)mc * ldx);
+                wv[i] = gW[(size_t)mc * ldw];
+            }
+        };
+        // rows / columns outside the operand contribute zeros (wave-uniform test first: full half slabs of full tiles skip the selects)
+        auto mask = [&](f32x4_t (&sv)[4], float (&wv)[4], int h) {
+            const int mh = m_begin + 16 * h;
+            if (mh + 16 <= m_end && cols_full) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool row = mh + rq + 4 * i < m_end;
+                const bool ok = row && colok;
+                sv[i].x = ok ? sv[i].x : 0.f; sv[i].y = ok ? sv[i].y : 0.f; sv[i].z = ok ? sv[i].z : 0.f; sv[i].w = ok ? sv[i].w : 0.f;
+                wv[i] = row ? wv[i] : 0.f;
+            }
+        };
+        // one column of the staged 4 x 4 block: four consecutive k of half buffer `hb` (logical slots 2 hb, 2 hb + 1)
+        const int rot = c4 >> 2;                       // (column >> 4) of the thread's four columns
+        auto put = [&](int hb, int e, float v0, float v1, float v2, float v3) {
+            unsigned a1, a2, a3, b1, b2, b3;
+            bf16_split_pair(v0, v1, a1, a2, a3);
+            bf16_split_pair(v2, v3, b1, b2, b3);
+            const int at = (4 * c4 + e) * TROW + (((2 * hb + (rq >> 1) + rot) & 3) << 4) + ((rq & 1) << 3);
+            *reinterpret_cast<uint2*>(planes + at) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(planes + TPLANE + at) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(planes + 2 * TPLANE + at) = make_uint2(a3, b3);
+        };
+        auto sums = [&](const f32x4_t (&sv)[4], const float (&wv)[4]) {
+            if (want_bias && !opB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bsum[0] += sv[i].x; bsum[1] += sv[i].y; bsum[2] += sv[i].z; bsum[3] += sv[i].w; }
+            }
+            if (side && opB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wsum[0] = fmaf(wv[i], sv[i].x, wsum[0]); wsum[1] = fmaf(wv[i], sv[i].y, wsum[1]);
+                    wsum[2] = fmaf(wv[i], sv[i].z, wsum[2]); wsum[3] = fmaf(wv[i], sv[i].w, wsum[3]);
+                    wtot += wv[i];
+                }
+            }
+        };
+        const int colA0 = wr * 64 + r, colB0 = wc * 64 + r;
+        // the products of half buffer `hc` with the staging of `sv` into half buffer `hs` between them
+        auto half_step = [&](int hc, f32x4_t (&sv)[4], float (&wv)[4], int hs) {
+            bf16x8 a[2][3], b[3];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int ca = colA0 + blk * 32;
+                const int oa = ca * TROW + (((2 * hc + half + (ca >> 4)) & 3) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[blk][pl] = *reinterpret_cast<const bf16x8*>(T + pl * TPLANE + oa);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int cc = colB0 + cb * 32;
+                const int ob = cc * TROW + (((2 * hc + half + (cc >> 4)) & 3) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(T + (3 + pl) * TPLANE + ob);
+                // smallest terms first, the two row blocks alternating (independent accumulators back to back)
+                if (!(PR_TNBF_ABLATE & 2)) {
+                PR_MFMA_BF16(acc[0][cb], a[0][1], b[1]); PR_MFMA_BF16(acc[1][cb], a[1][1], b[1]);
+                PR_MFMA_BF16(acc[0][cb], a[0][0], b[2]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[2]);
+                PR_MFMA_BF16(acc[0][cb], a[0][2], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][2], b[0]);
+                PR_MFMA_BF16(acc[0][cb], a[0][0], b[1]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[1]);
+                PR_MFMA_BF16(acc[0][cb], a[0][1], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][1], b[0]);
+                PR_MFMA_BF16(acc[0][cb], a[0][0], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[0]);
+                }
+                // (no test for "nothing left to stage": a half slab beyond the split's rows is staged as zeros and never multiplied - a
+                // branch here would end the basic block between the MFMAs and the conversions that are to issue beside them)
+                if (PR_TNBF_ABLATE & 1) {
+                } else if (cb == 0) {
+                    put(hs, 0, sv[0].x, sv[1].x, sv[2].x, sv[3].x);
+                    put(hs, 1, sv[0].y, sv[1].y, sv[2].y, sv[3].y);
+                } else {
+                    put(hs, 2, sv[0].z, sv[1].z, sv[2].z, sv[3].z);
+                    put(hs, 3, sv[0].w, sv[1].w, sv[2].w, sv[3].w);
+                    sums(sv, wv);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // half 0 -> buffer 0 in front of the loop; THREE register sets: while one is staged, the next is in flight and the third is
+        // requested at the top of the half step (two half steps ahead of its use: with two sets the requests could only be issued
+        // behind the staging of the same registers, one half step ahead, and the conversions waited for memory)
+        fetch(s0, w0, 0);
+        fetch(s1, w1, 1);
+        fetch(s2, w2, 2);
+        mask(s0, w0, 0);
+        put(0, 0, s0[0].x, s0[1].x, s0[2].x, s0[3].x);
+        put(0, 1, s0[0].y, s0[1].y, s0[2].y, s0[3].y);
+        put(0, 2, s0[0].z, s0[1].z, s0[2].z, s0[3].z);
+        put(0, 3, s0[0].w, s0[1].w, s0[2].w, s0[3].w);
+        sums(s0, w0);
+        __syncthreads();
+        for (int h = 0; h < halves;) {
+            // half h multiplied out of buffer h & 1, half h + 1 staged into the other buffer, half h + 3 requested
+            if (!(PR_TNBF_ABLATE & 4)) fetch(s0, w0, h + 3);
+            mask(s1, w1, h + 1);
+            half_step(h & 1, s1, w1, (h + 1) & 1);
+            __syncthreads();
+            if (++h >= halves) break;
+            if (!(PR_TNBF_ABLATE & 4)) fetch(s1, w1, h + 3);
+            mask(s2, w2, h + 1);
+            half_step(h & 1, s2, w2, (h + 1) & 1);
+            __syncthreads();
+            if (++h >= halves) break;
+            if (!(PR_TNBF_ABLATE & 4)) fetch(s2, w2, h + 3);
+            mask(s0, w0, h + 1);
+            half_step(h & 1, s0, w0, (h + 1) & 1);
+            __syncthreads();
+            ++h;
+        }
+    }
+    const int ldp = tiles_j * GT;
+    const int rows_p = ((p.ni + GT - 1) / GT) * GT;
+    float* P = p.partial + (size_t)split * rows_p * ldp;
+#pragma unroll
+    for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = j0 + wc * 64 + cb * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                P[(size_t)row * ldp + col] = acc[rb2][cb][i];
+            }
+        }
+    // column sums kept per thread (its 4 columns, the rows it staged): added over the 4 row groups in a fixed order
+    if (want_bias || side) {
+        __syncthreads();
+        float* R = RED;                                  // [4 row groups][128 columns] bias, then the same for the side product
+        if (want_bias && !opB) for (int e = 0; e < 4; ++e) R[rq * GT + 4 * c4 + e] = bsum[e];
+        if (side && opB) {
+            for (int e = 0; e < 4; ++e) R[4 * GT + rq * GT + 4 * c4 + e] = wsum[e];
+            if (c4 == 0) R[8 * GT + rq] = wtot;
+        }
+        __syncthreads();
+        if (want_bias && tid < GT) {
+            float v = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) v += R[g4 * GT + tid];
+            p.bias_partial[(size_t)split * rows_p + i0 + tid] = v;
+        }
+        if (side && tid >= GT) {
+            float* W = p.w_partial + (size_t)split * (ldp + 4);
+            float v = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) v += R[4 * GT + g4 * GT + tid - GT];
+            W[j0 + tid - GT] = v;
+            if (tid == GT && tj == 0) {
+                float t = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) t += R[8 * GT + g4];
+                W[ldp] = t;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_all_bf16(TnAll g) {
     __shared__ __attribute__((aligned(16))) unsigned char T[6 * TPLANE];
     __shared__ float RED[16 * GT + 8];
@@ -775,7 +987,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_all_bf16(TnAll g) {
         const TnJob& p = g.job[job];
         const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
         if (tile >= tiles) continue;
+#ifdef PR_TNBF_SERIAL       // measurement build: the full-slab version (stage and multiply in turns)
         tn_all_tile_bf16(p, tile, pair - pair_begin[job], T, RED);
+#else
+        tn_all_tile_bf16_overlap(p, tile, pair - pair_begin[job], T, RED);
+#endif
         __syncthreads();
     }
 }
