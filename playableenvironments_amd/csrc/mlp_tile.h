@@ -331,9 +331,9 @@ __device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int 
     // request queue (one in-order counter on gfx9), and their waits end when the stores are acknowledged (measured: the NeRF chain
     // of the step 1.105 -> 1.051 ms; -DPR_DRAIN_PLAIN is the plain-store measurement build)
 #ifdef PR_DRAIN_PLAIN
-    *reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c) = v;
+    *as_global(reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c)) = v;
 #else
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c));
+    __builtin_nontemporal_store(v, as_global(reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c)));
 #endif
 }
 
@@ -817,7 +817,7 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
                     const f32x16& hi = blk ? a11 : a01;
                     if (col < bwd->n_real) {
                         // one base pointer per lane, row offsets are wave-uniform multiples of the leading dimension
-                        float* base = bwd->gout + (size_t)(tile_base + 4 * half) * bwd->ldg + col;
+                        auto* base = as_global(bwd->gout) + (size_t)(tile_base + 4 * half) * bwd->ldg + col;
                         const int ldg = bwd->ldg;
                         const int limit = rows_valid - 4 * half;       // rows of this lane: PR_ACC_ROW(i) (+ 32) < limit
                         float old_lo[16], old_hi[16];
@@ -845,7 +845,8 @@ __device__ __forceinline__ void run_layer(const Layer& L, Smem& S, const MlpPara
         if (active) {
             // bit (row, col) of the ReLU mask: byte row * (width / 8) + col / 8 of the tile's bit image (built by
             // build_relu_mask_bits before the product), bit col % 8
-            const unsigned char* bits = bwd->mask_bits;
+            // (the bit image lives in Smem::pos - named here, not read through the pointer in *bwd, which would be a flat pointer)
+            const unsigned char* bits = reinterpret_cast<const unsigned char*>(S.pos);
             const int bpr = bwd->mask_bytes_per_row;
             for (int blk = 0; blk < (two ? 2 : 1); ++blk) {
                 const int col = (blk ? cbB : cbA) * 32 + r;

@@ -26,6 +26,9 @@ struct BSmem {
     int flat[TILE_M], frame[TILE_M], flags[TILE_M];
     int uniform_frame, next_tile;
     int tile_max[2];                                // fp16-pair chains: bit patterns of the largest |entry| of the tile in X (two alternating words)
+#ifdef PR_CHAIN_TIMING
+    unsigned long long phase_acc[16];               // phase timing build: thread 0's clock deltas (flushed once per chain_bwd_loop)
+#endif
 };
 static_assert(sizeof(BSmem) * MLP_BLOCKS_PER_CU <= 160 * 1024 - MLP_BLOCKS_PER_CU * 1024, "two backward tiles per CU");
 static_assert(offsetof(BSmem, cst) % 16 == 0 && offsetof(BSmem, ws) % 16 == 0, "16-byte LDS accesses");
@@ -43,7 +46,7 @@ __device__ unsigned long long g_chain_phase[16];
 #define PR_CT(idx)                                                                         \
     do {                                                                                   \
         const unsigned long long _n = __builtin_amdgcn_s_memtime();                        \
-        if (threadIdx.x == 0) atomicAdd(&g_chain_phase[idx], _n - _ct);                    \
+        if (threadIdx.x == 0) S.phase_acc[idx] += _n - _ct;    /* (LDS: see PR_PHASE in mlp_tile.h) */ \
         _ct = _n;                                                                          \
     } while (0)
 #else
@@ -206,7 +209,11 @@ __device__ __forceinline__ void store_tile_rows(const float* X, float* dst, int 
         const int row = idx / w4, c = (idx - row * w4) * 4;
         if (row < rows_valid) {
             const f32x4_t v = *reinterpret_cast<const f32x4_t*>(X + row * LDX + c);
-            *reinterpret_cast<f32x4_t*>(dst + (size_t)(tile_base + row) * ld + c) = v;      // (non-temporal: no difference, measured)
+#ifdef PR_STORE_ROWS_NT      // measurement build (no difference for the head phases' rows)
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(dst + (size_t)(tile_base + row) * ld + c));
+#else
+            *reinterpret_cast<f32x4_t*>(dst + (size_t)(tile_base + row) * ld + c) = v;
+#endif
         }
     }
 }
@@ -698,6 +705,9 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
     const int total = *c.total;
     const int nblk = c.Wpad >> 5, in_nblk = c.in_pad >> 5;
     __syncthreads();
+#ifdef PR_CHAIN_TIMING
+    if (tid == 0) for (int i = 0; i < 16; ++i) S.phase_acc[i] = 0;
+#endif
     if (tid == 0) S.next_tile = atomicAdd(c.tile_counter, 1);
     if (c.entry == 1) {
         stage_bn_constants(S, c.mean1, c.var1, c.sums1, c.W, c.Wpad, c.stat_count, c.eps, c.frozen);
@@ -842,6 +852,9 @@ __device__ __forceinline__ void chain_bwd_loop(const ChainBwdJob& c) {
         __syncthreads();   // the next tile overwrites X, the bits and the records
         PR_CT(8);
     }
+#ifdef PR_CHAIN_TIMING
+    if (tid == 0) for (int i = 0; i < 16; ++i) if (S.phase_acc[i]) atomicAdd(&g_chain_phase[i], S.phase_acc[i]);
+#endif
 }
 
 __global__ __launch_bounds__(MLP_THREADS, MLP_BLOCKS_PER_CU) void k_chain_bwd_group(ChainBwdJob j0, ChainBwdJob j1, ChainBwdJob j2, ChainBwdJob j3,

@@ -180,6 +180,50 @@ def test_library_exports_every_declared_symbol(built_library):
     assert built_library.pr_abi_version() == 5
 
 
+def test_product_kernels_have_no_flat_memory_operations(built_library):
+    """A device pointer that reaches a kernel through a table loses its address space; hipcc then emits flat loads / stores and, since a
+    flat access may be an LDS access, waits for EVERY outstanding request in front of the first use of any loaded value - inside a
+    software-pipelined K loop that is a full L2 round trip per step (the training forward, both head phases and the
+    ray-bender head had them for four rounds).  `as_global()` states the address space where such a pointer is used; this test reads the
+    built library's gfx950 code objects and holds every kernel to zero flat accesses."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_check
+    if not os.path.exists(isa_check.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    counts = isa_check.memory_operations(_lib.library_path())
+    kernels = [k for k in counts if "k_" in k]
+    assert len(kernels) >= 60, len(kernels)                       # the disassembly found the library's kernels
+    for wanted in ("k_mlp_mfma_group", "k_mlp_mfma_train_group_split", "k_mlp_head_group", "k_chain_bwd_group_f16", "k_head_bwd_group",
+                   "k_gemm_tn_all_bf16", "k_mlp_split_group", "k_composite"):
+        assert any(wanted in k for k in kernels), wanted
+    flat = {k: v for k, v in counts.items() if v["flat_load"] or v["flat_store"]}
+    assert not flat, flat
+
+
+def test_k_loops_never_wait_for_every_outstanding_request(built_library):
+    """The software-pipelined K loops request the fragments of the next step(s) in front of the current step's MFMAs; a `s_waitcnt
+    vmcnt(0)` inside such a loop waits for the requests just issued and turns the pipeline into one memory round trip per step.  hipcc
+    produced exactly that from three harmless-looking things: flat pointers, requests under `if (two)`, and first
+    requests in another order than the loop's.  Every K loop of the shipped product kernels is held to partial waits."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_check
+    if not os.path.exists(isa_check.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    loops = isa_check.matrix_loops(_lib.library_path())
+    held = ("k_mlp_mfma_group", "k_mlp_mfma_train_group", "k_mlp_mfma_train_group_split", "k_mlp_head_group", "k_mlp_split_group",
+            "k_mlp_f16_group", "k_chain_bwd_group", "k_chain_bwd_group_f16", "k_head_bwd_group", "k_div_chain_group")
+    for wanted in held:
+        # (mangled: _ZN2pr<len><name>E...)
+        names = [k for k in loops if f"{len(wanted)}{wanted}E" in k]
+        assert names, wanted
+        for k in names:
+            assert loops[k], k
+            for loop in loops[k]:
+                assert not any("vmcnt(0)" in w for w in loop["waits"]), (k, loop)
+
+
 def test_struct_sizes_match_header_layout():
     """ctypes mirrors must have the C sizes (pointer = 8, int32 = 4, natural alignment)."""
     assert C.sizeof(_lib.Linear) == 24
