@@ -432,23 +432,29 @@ __device__ __forceinline__ void head_bwd_loop(const HeadBwdJob& p) {
             for (int base = tid; base < count; base += MLP_THREADS * BATCH) {
                 float4 v[BATCH];
                 int kind[BATCH];              // 0: nothing to do in memory, 1: loaded, 2: a dead row whose gradient is cleared in memory
+                // the row flags first, then FOUR UNCONDITIONAL requests (a row or column outside the operand reads the tile's first
+                // chunk instead and drops the value): under `if (flags ...)` every request waited for its own LDS read, and hipcc -
+                // which cannot count requests issued under a branch - waited for all of them in front of the fourth
+                int fl[BATCH];
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    const int idx = base + b * MLP_THREADS;
+                    const int row = idx / k4;
+                    fl[b] = S.flags[idx < count ? row : 0];
+                }
 #pragma unroll
                 for (int b = 0; b < BATCH; ++b) {
                     const int idx = base + b * MLP_THREADS;
                     const int row = idx / k4, c = (idx - row * k4) * 4;
-                    v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    kind[b] = 0;
-                    if (idx < count && row < rows_valid && c < p.ld_gin) {
-                        const float* src = p.g_in + (size_t)(tile_base + row) * p.ld_gin + c;
-                        if (PR_HEADB_ABLATE & 16) {
-                            v[b] = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
-                        } else if ((S.flags[row] & 3) == 3) {
-                            v[b] = *reinterpret_cast<const float4*>(src);
-                            kind[b] = 1;
-                        } else {
-                            kind[b] = 2;
-                        }
-                    }
+                    const bool inside = idx < count && row < rows_valid && c < p.ld_gin;
+                    kind[b] = !inside ? 0 : ((fl[b] & 3) == 3 ? 1 : 2);
+                    const float* src = p.g_in + (size_t)(tile_base + (inside ? row : 0)) * p.ld_gin + (inside ? c : 0);
+                    v[b] = *reinterpret_cast<const float4*>(src);
+                }
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) {
+                    if (PR_HEADB_ABLATE & 16) v[b] = make_float4(1e-3f, -1e-3f, 2e-3f, 0.f);
+                    if (kind[b] != 1) v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int b = 0; b < BATCH; ++b) {
