@@ -337,6 +337,38 @@ __device__ __forceinline__ void drain_chunk(const Drain& d, const float* X, int 
 #endif
 }
 
+// The same write-out with the chunk index kept as a (row, column) cursor: drain_chunk's `idx / w4` is a division by a run-time value,
+// ~20 VALU instructions per K step of a loop whose VALU work (the operand split) is what bounds it; the cursor advances by
+// MLP_THREADS chunks per call with one carry (same chunks in the same order as drain_chunk(d, X, 0), (d, X, 1), ...)
+#ifndef PR_DRAIN_CURSOR
+#define PR_DRAIN_CURSOR 1   // 0: drain_chunk's division in every K step (A/B builds)
+#endif
+struct DrainCursor { int row, c4, drow, dc4; };
+__device__ __forceinline__ DrainCursor drain_begin(const Drain& d) {
+    DrainCursor k;
+    k.row = (int)threadIdx.x / d.w4;
+    k.c4 = (int)threadIdx.x - k.row * d.w4;
+    k.drow = MLP_THREADS / d.w4;
+    k.dc4 = MLP_THREADS - k.drow * d.w4;
+    return k;
+}
+__device__ __forceinline__ void drain_next(const Drain& d, const float* X, DrainCursor& k) {
+    const int row = k.row < d.rows_valid ? k.row : d.rows_valid - 1;      // (branch-free: see drain_chunk)
+    const int c = 4 * k.c4;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = *reinterpret_cast<const v4f*>(X + row * LDX + c);
+#ifdef PR_DRAIN_PLAIN
+    *as_global(reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c)) = v;
+#else
+    __builtin_nontemporal_store(v, as_global(reinterpret_cast<v4f*>(d.dst + (size_t)row * d.ld + c)));
+#endif
+    k.c4 += k.dc4;
+    k.row += k.drow;
+    const int wrap = k.c4 >= d.w4 ? 1 : 0;
+    k.c4 -= wrap ? d.w4 : 0;
+    k.row += wrap;
+}
+
 // The same product in SPLIT precision (PR_FLAG_SPLIT_BACKWARD; `sg.w` then points at the bf16-triple packing of the segment,
 // k_pack kind 3): every fp32 operand as three bf16 terms, x = b1 + b2 + b3 exactly, a product as the six bf16 MFMAs whose terms
 // are >= 2^-16 of it (see k_gemm_tn_all_bf16 in gemm.hip) - 16 K-values retire in 6 x 32 cycles where the fp32 pipe needs
@@ -597,10 +629,47 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
 // that its largest entry sits just under 2^15: gradients of ~1e-7 are far below fp16's range) while it is split; the caller
 // multiplies the accumulators by 1 / (scale x 2^TRAIN_SPLIT_WEIGHT_SCALE_LOG2) behind the loop.  Entries within 2^-16 of the tile's
 // largest keep 22 significant bits, smaller ones an absolute error of 2^-39 of it.  With the gradient write-out of tile_products.
+#ifndef PR_SPLIT_MIX
+#define PR_SPLIT_MIX 1      // 0: the multiply / clamp / convert / convert back / subtract / convert sequence (A/B builds)
+#endif
+// Four operands x `scale` -> their packed fp16 hi halves (h01, h23) and lo halves (l01, l23) in EIGHT instructions: v_fma_mixlo/hi_f16
+// evaluate x * scale + c in fp32 and round the result to fp16 into one half of the destination, and take c as either half of a packed
+// fp16 register.  hi = fp16(x * scale) (the product by a power of two is exact), lo = fp16(x * scale - hi) (the difference has <= 13
+// significant bits: exact in fp32) - bit for bit what multiply, v_cvt_pk_f16_f32, two v_cvt_f32_f16, two subtractions and a second
+// v_cvt_pk_f16_f32 produce (10 instructions per pair with the range guard; the K loops of the split-precision training kernels issued
+// 115 VALU instructions per twelve MFMAs and were bound by them).  No range guard: the scale puts the tile's largest entry under 2^15; a
+// tile with a non-finite entry yields NaN products like the fp32 kernels.  A write to one half of a register must not be followed
+// directly by a read of that register on gfx940+ (destination-select forwarding hazard; hipcc does not look inside the asm block): every
+// v_fma_mixhi is one instruction away from the first reader of its destination, and the block ends with a wait state.
+__device__ __forceinline__ void split_quad_scaled_h(float x0, float x1, float x2, float x3, float scale, unsigned int& h01,
+                                                    unsigned int& h23, unsigned int& l01, unsigned int& l23) {
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(scale));
+}
 __device__ __forceinline__ FragH split_fragment_scaled_h(const float4& lo, const float4& hi, float scale) {
+#if PR_SPLIT_MIX
+    unsigned int a[4], b[4];
+    split_quad_scaled_h(lo.x, lo.y, lo.z, lo.w, scale, a[0], a[1], b[0], b[1]);
+    split_quad_scaled_h(hi.x, hi.y, hi.z, hi.w, scale, a[2], a[3], b[2], b[3]);
+    FragH f;
+    const u32x4 wa = {a[0], a[1], a[2], a[3]}, wb = {b[0], b[1], b[2], b[3]};
+    f.hi = __builtin_bit_cast(f16x8_t, wa);
+    f.lo = __builtin_bit_cast(f16x8_t, wb);
+    return f;
+#else
     const float4 l = make_float4(lo.x * scale, lo.y * scale, lo.z * scale, lo.w * scale);
     const float4 h = make_float4(hi.x * scale, hi.y * scale, hi.z * scale, hi.w * scale);
     return split_fragment_h(l, h);
+#endif
 }
 __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, const float* X, f32x16& a00, f32x16& a01, f32x16& a10,
                                                     f32x16& a11, const Drain* drain, float scale) {
@@ -619,6 +688,8 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
     FragH e0 = split_fragment_scaled_h(xl, xh, scale), e1 = split_fragment_scaled_h(yl, yh, scale), o0, o1;
     f16x8_t eah = wpA[0], eal = wpA[64], ebh = wpB[0], ebl = wpB[64];
     f16x8_t oah, oal, obh = ebh, obl = ebl;
+    DrainCursor cursor = {0, 0, 0, 0};
+    if (drain) cursor = drain_begin(*drain);
     for (int s = 0; s < ks; s += 2) {
         {   // even step: request the odd step's operands, multiply the even fragments, split the odd ones behind the MFMAs
             const float* an = ap + 16 * (s + 1);
@@ -630,7 +701,7 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
             __builtin_amdgcn_sched_barrier(0);
             PR_STEP_MFMAS_H(e0, e1, eah, eal, ebh, ebl);
             o0 = split_fragment_scaled_h(xl, xh, scale); o1 = split_fragment_scaled_h(yl, yh, scale);
-            if (drain) drain_chunk(*drain, X, s);
+            if (drain) { if (PR_DRAIN_CURSOR) drain_next(*drain, X, cursor); else drain_chunk(*drain, X, s); }
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -644,7 +715,7 @@ __device__ __forceinline__ void tile_products_f16x3(const Seg& sg, int nblk, con
             __builtin_amdgcn_sched_barrier(0);
             PR_STEP_MFMAS_H(o0, o1, oah, oal, obh, obl);
             e0 = split_fragment_scaled_h(xl, xh, scale); e1 = split_fragment_scaled_h(yl, yh, scale);
-            if (drain) drain_chunk(*drain, X, s + 1);
+            if (drain) { if (PR_DRAIN_CURSOR) drain_next(*drain, X, cursor); else drain_chunk(*drain, X, s + 1); }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
