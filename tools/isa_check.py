@@ -101,9 +101,11 @@ def matrix_loops(library_path, arch="gfx950", min_mfma=8, max_instructions=600):
                     n_mfma = sum(1 for (_, op, _, _) in body if op.startswith("v_mfma"))
                     if n_mfma < min_mfma or len(body) > max_instructions:
                         continue
-                    if any((a2, b2) != (a, b) and a <= a2 and b2 <= b and
+                    # not innermost: a shorter loop with matrix instructions starts inside this one (nested, or - a rotated layer loop
+                    # around a K loop - overlapping: the K loop's back edge then lies behind the layer loop's)
+                    if any((a2, b2) != (a, b) and a <= a2 <= b and (b2 - a2) < (b - a) and
                            sum(1 for (_, op, _, _) in code[a2:b2 + 1] if op.startswith("v_mfma")) >= min_mfma for (a2, b2) in spans):
-                        continue        # not innermost
+                        continue
                     found.append({"mfma": n_mfma, "instructions": len(body),
                                   "waits": [args for (_, op, args, _) in body if op == "s_waitcnt"]})
                 if found:
