@@ -6,7 +6,7 @@ the product build); writes a SHA-256 per output field / parameter gradient to th
     PR_PERF_LIB=build/variants/libplayrender_old.so python tools/perf/dbg_split_identity.py gpurun_out/id_old.json
     python tools/perf/dbg_split_identity.py --compare gpurun_out/id_base.json gpurun_out/id_old.json
 
-Used for the v_fma_mix operand split (DESIGN.md 10.10): the new sequence must produce the SAME fp16 pairs as the old one."""
+Used for the v_fma_mix operand split (DESIGN.md 10.9): the new sequence must produce the SAME fp16 pairs as the old one."""
 import hashlib
 import json
 import os
