@@ -640,7 +640,8 @@ __device__ __forceinline__ void tile_products_f16x3_lean(const Seg& sg, int nblk
 // 115 VALU instructions per twelve MFMAs and were bound by them).  No range guard: the scale puts the tile's largest entry under 2^15; a
 // tile with a non-finite entry yields NaN products like the fp32 kernels.  A write to one half of a register must not be followed
 // directly by a read of that register on gfx940+ (destination-select forwarding hazard; hipcc does not look inside the asm block): every
-// v_fma_mixhi is one instruction away from the first reader of its destination, and the block ends with a wait state.
+// v_fma_mixhi is one instruction away from the first reader of its destination, and the block ends with two wait states (what a VALU
+// result needs in front of a matrix instruction that reads it, should hipcc ever schedule one right behind the block).
 __device__ __forceinline__ void split_quad_scaled_h(float x0, float x1, float x2, float x3, float scale, unsigned int& h01,
                                                     unsigned int& h23, unsigned int& l01, unsigned int& l23) {
     asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
@@ -651,7 +652,7 @@ __device__ __forceinline__ void split_quad_scaled_h(float x0, float x1, float x2
         "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "s_nop 0"
+        "s_nop 1"
         : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
         : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(scale));
 }
