@@ -13,7 +13,9 @@ Forward fields are compared at the parity tolerance of the suite (rtol 1e-4, ato
 perturbed cases replay the oracle's noise.  A HIERARCHICAL case that exceeds it (the inverse CDF turns last-bit differences of the
 coarse weights into sample positions) is ARBITRATED instead of loosened: the oracle's op graph in float64 on the same weights,
 inputs and noise is the exact result, and every field of the HIP render has to be no farther from it than 4 x the fp32 oracle is
-("ok (arbitrated)"); anything else is a failure."""
+("ok (arbitrated)"); anything else is a failure.  A single-pass case gets the same arbitration under its own label ("ok (arbitrated,
+single pass)": the fp32 oracle itself is then that far from float64 - high-frequency encodings in front of shallow random layers).
+Recorded (profiles/r05_sweep_forward_*): 1 such case in 1 340 (seeds 7, 11, 12, 13, 14), none in the suite's slice."""
 import os
 import random
 import sys
@@ -316,6 +318,19 @@ def forward_sweep(cases, rng, only=None):
                 rest = ~(torch.isnan(a) | torch.isnan(b))
                 if bool((differ & ~tiny).sum() == 0) and torch.allclose(a[rest], b[rest], **tol):
                     del bad[key]
+            if bad and not hierarchical:
+                # a single-pass case beyond the tolerance (1 of 1 340 forward cases of the round-5 sweeps: eight octaves in front of
+                # shallow random layers - the fp32 ORACLE is 4.7e-5 from float64 there): the same float64 arbitration, reported under
+                # its own label and capped by tests/test_gpu.py::test_randomized_sweep_slice (never a plain "ok")
+                state = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+                exact = run_exact(cfg, state, inputs, flags["perturb"], run_both.noise if flags["perturb"] else None,
+                                  canonical=flags["canonical"])
+                verdict = arbitrate(exact, want, got, factor=4.0, floor=1e-6)
+                report = {k: f"HIP {verdict[k][0]:.2e} vs fp32 oracle {verdict[k][1]:.2e} from float64" for k in bad}
+                bad = {k: report[k] for k in bad if not verdict[k][2]}
+                if not bad:
+                    print("ok (arbitrated, single pass) " + label[:150], report)
+                    continue
             if bad:
                 failures += 1
                 print("MISMATCH", label, bad)
@@ -326,7 +341,15 @@ def forward_sweep(cases, rng, only=None):
                         d = (a - b).abs().reshape(-1)
                         idx = int(d.argmax())
                         print("  ", key, "shape", tuple(a.shape), "worst at flat", idx, "oracle", float(a.reshape(-1)[idx]), "hip", float(b.reshape(-1)[idx]),
-                              "nan oracle/hip", int(torch.isnan(a).sum()), int(torch.isnan(b).sum()), "entries off", int((d > 1e-3).sum()))
+                              "nan oracle/hip", int(torch.isnan(a).sum()), int(torch.isnan(b).sum()), "entries off", int((d > 1e-3).sum()),
+                              "entries beyond the tolerance", int((d > tol["atol"] + tol["rtol"] * a.abs().reshape(-1)).sum()))
+                    # single-case mode: where float64 puts the two fp32 sides (diagnosis only - the sweep's verdict stays MISMATCH)
+                    state = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
+                    exact = run_exact(cfg, state, inputs, flags["perturb"], run_both.noise if flags["perturb"] else None,
+                                      canonical=flags["canonical"])
+                    verdict = arbitrate(exact, want, got, factor=4.0, floor=1e-6)
+                    for key in bad:
+                        print("   float64:", key, f"HIP {verdict[key][0]:.2e}, fp32 oracle {verdict[key][1]:.2e} from the float64 result; within 4 x: {verdict[key][2]}")
             else:
                 print("ok (arbitrated)" if arbitrated else "ok", label[:150])
         except Exception:

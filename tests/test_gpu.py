@@ -3376,7 +3376,10 @@ def test_randomized_sweep_slice(sweep, cases, capsys, monkeypatch):
     assert failures == 0, report[-4000:]
     plain = report.count("ok case")
     settled = report.count("ok (forward ") + report.count("divergence kink")
-    classified = report.count("ok (arbitrated) case") + report.count("ill-conditioned") + report.count("noise kink") + settled + report.count("skipped")
+    single_pass = report.count("ok (arbitrated, single pass)")
+    classified = (report.count("ok (arbitrated) case") + single_pass + report.count("ill-conditioned") + report.count("noise kink") + settled +
+                  report.count("skipped"))
+    assert single_pass == 0, report[-3000:]          # (recorded: none in this slice; 1 in the 1 340 forward cases of the round's sweeps)
     assert plain + classified == cases, report[-2000:]
     # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floor = the
     # plain-ok count recorded for this slice - 2; forward fields settled by arbitration / as a kink are capped per slice
