@@ -14,11 +14,11 @@ mkdir -p profiles && cp "$OUT/${R}_pmc_summary.json" profiles/${R}_pmc_summary.j
 bash tools/collect_pmc_train.sh > "$OUT/${R}_pmc_train.log" 2>&1
 cp gpurun_out/pmc_train_summary.json "$OUT/${R}_pmc_train_summary.json"
 cp "$OUT/${R}_pmc_train_summary.json" profiles/${R}_pmc_train_summary.json
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.err"
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --full-json "$OUT/${R}_bench_full.json" > "$OUT/${R}_bench.json" 2> "$OUT/${R}_bench.err"
 cd /tmp
 rm -rf /tmp/hl /tmp/tr
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hl -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline \
-    --no-train-step --no-split-precision --no-distinct-frames --no-reference-graph --no-minecraft --no-shard-balance --no-native-frame \
+    --no-train-step --no-split-precision --no-distinct-frames --no-reference-graph --no-minecraft --no-shard-balance --no-native-frame --full-json /tmp/headline_full.json \
     > "$OUT/${R}_headline_bench.json" 2> "$OUT/${R}_headline.err"
 cp /tmp/hl/*/*_kernel_stats.csv "$OUT/${R}_headline_kernel_stats.csv"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr -- python $ROOT/tools/perf/perf_train_leg.py 6 3 \
