@@ -558,6 +558,10 @@ __device__ __forceinline__ float sub_f32_g(float a, float b) {      // (not pack
 __device__ __forceinline__ void bf16_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
     const f32x2_g v = {x0, x1};
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_g));
+#if defined(PR_TNBF_ABLATE) && (PR_TNBF_ABLATE & 16)
+    p2 = p1 ^ 0x00010001u; p3 = p1 ^ 0x00020002u;
+    return;
+#endif
     const f32x2_g r = {sub_f32_g(x0, __uint_as_float(p1 << 16)), sub_f32_g(x1, __uint_as_float(p1 & 0xffff0000u))};
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_g));
     const f32x2_g q = {sub_f32_g(r[0], __uint_as_float(p2 << 16)), sub_f32_g(r[1], __uint_as_float(p2 & 0xffff0000u))};
@@ -565,8 +569,8 @@ __device__ __forceinline__ void bf16_split_pair(float x0, float x1, unsigned& p1
 }
 
 #ifndef PR_TNBF_ABLATE
-#define PR_TNBF_ABLATE 0      // timing builds only (results are wrong): 1 = slabs are not staged, 2 = no MFMAs, 4 = no operand requests
-#endif
+#define PR_TNBF_ABLATE 0      // timing builds only (results are wrong): 1 = slabs are not staged, 2 = no MFMAs, 4 = no operand requests,
+#endif                        // 8 = three of the six MFMAs (what fp16 pairs would issue), 16 = one conversion per pair instead of three
 __device__ __forceinline__ void tn_all_tile_bf16(const TnJob& p, int tile, int split, unsigned char* T, float* RED) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
@@ -858,9 +862,11 @@ __device__ __forceinline__ void tn_all_tile_bf16_overlap(const TnJob& p, int til
                 for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(T + (3 + pl) * TPLANE + ob);
                 // smallest terms first, the two row blocks alternating (independent accumulators back to back)
                 if (!(PR_TNBF_ABLATE & 2)) {
+                if (!(PR_TNBF_ABLATE & 8)) {
                 PR_MFMA_BF16(acc[0][cb], a[0][1], b[1]); PR_MFMA_BF16(acc[1][cb], a[1][1], b[1]);
                 PR_MFMA_BF16(acc[0][cb], a[0][0], b[2]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[2]);
                 PR_MFMA_BF16(acc[0][cb], a[0][2], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][2], b[0]);
+                }
                 PR_MFMA_BF16(acc[0][cb], a[0][0], b[1]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[1]);
                 PR_MFMA_BF16(acc[0][cb], a[0][1], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][1], b[0]);
                 PR_MFMA_BF16(acc[0][cb], a[0][0], b[0]); PR_MFMA_BF16(acc[1][cb], a[1][0], b[0]);

@@ -322,7 +322,7 @@ static int add_seg3(PackJobs* js, const pr_linear_t& lin, int col_off, int k_rea
     js->job[js->n - 1].kind = 2;
     // weights of 0.01 - 0.1 have their lo half in fp16's subnormal range (relative error 2^-25 / |w|: harmless for a rendered value,
     // 10 x fp32's on the density head's bias gradient, which sums over every sample - measured); scaled by 2^8 the lo halves of
-    // |w| > 0.001 are normal numbers and |w| < 255 stays in range (beyond, k_pack saturates).  The kernel starts its accumulators
+    // |w| > 0.001 are normal numbers and |w| < 255 stays in range (beyond, k_pack lets the scaled weight overflow: NaN gradients, loud).  The kernel starts its accumulators
     // at bias x 2^8 (x the operand tile's scale) and divides both out behind the K loops - exact.
     js->job[js->n - 1].scale_log2 = TRAIN_SPLIT_WEIGHT_SCALE_LOG2;
     return PR_OK;
