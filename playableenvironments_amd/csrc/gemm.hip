@@ -960,6 +960,289 @@ __device__ __forceinline__ void tn_all_tile_bf16_overlap(const TnJob& p, int til
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same work item on fp16 PAIRS (k_gemm_tn_all_f16, the default of split-precision calls; -DPR_TNALL_F16=0 launches the bf16-triple
+// kernel above): x = hi + lo, a product as THREE v_mfma_f32_32x32x16_f16 (hi x hi + hi x lo + lo x hi) - measured on the triples with
+// -DPR_TNBF_ABLATE=8, half the matrix instructions are worth 0.25 ms of a 1.33 ms launch, the conversions nothing.  fp16 does not have the range of a gradient (1e-7 and below), so every HALF SLAB (16 sample rows) is scaled on its way into
+// LDS, the gradient rows by alpha_h, the activation rows by C / alpha_h: the product of a row pair is C x the true one for every half
+// slab, so all of them share the accumulators.
+//   alpha_h = the power of two that puts the half slab's largest |dY| in [2^13, 2^14)
+//   C       = 2^(27 - E), E = the running maximum of  exponent(max |dY|) + exponent(max |X|)  over the half slabs seen: the scaled
+//             activations stay below 2^15; when a later half slab raises E by d, the accumulators are multiplied by 2^-d (exact)
+// Entries within 2^-16 of their half slab's largest keep 22 significant bits, smaller ones an absolute error of 2^-39 of the largest
+// product (what k_chain_bwd_group_f16 does per 64-row tile); half slabs whose contribution is below 2^-17 of the largest one degrade
+// the same way.  The maxima travel between the A- and the B-staging waves through four rotating LDS words per operand, published one
+// half step ahead of the staging they steer (behind the barrier that is there anyway).
+// ---------------------------------------------------------------------------------------------
+#ifndef PR_TNALL_F16
+#define PR_TNALL_F16 1          // 0: the split-precision weight gradients on bf16 triples (k_gemm_tn_all_bf16; A/B builds)
+#endif
+typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
+#define PR_MFMA_F16G(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
+// four values x scale -> packed fp16 hi halves (h01, h23) and lo halves (l01, l23): see split_quad_scaled_h in mlp_tile.h
+__device__ __forceinline__ void split_quad_scaled_g(float x0, float x1, float x2, float x3, float scale, unsigned& h01, unsigned& h23,
+                                                    unsigned& l01, unsigned& l23) {
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(scale));
+}
+// biased exponent of a non-negative float's bit pattern; 0 for zero / subnormal, and for a non-finite maximum (no scaling: NaN products)
+__device__ __forceinline__ int max_exponent(unsigned bits) {
+    const int e = (int)((bits >> 23) & 255u);
+    return e == 255 ? 0 : e;
+}
+
+// maximum of a non-negative bit pattern over the wave (every lane active): four DPP steps inside the rows of 16 lanes, the four rows
+// through the scalar unit - no LDS traffic (a shuffle ladder is six ds_bpermute per call in a kernel that lives on its LDS)
+__device__ __forceinline__ unsigned wave_max_bits(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1, 0, 3, 2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2, 3, 0, 1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));     // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ void tn_all_tile_f16_overlap(const TnJob& p, int tile, int split, unsigned char* T, float* RED, unsigned* MAXW) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, half = lane >> 5;
+    const int M = *p.rows;
+    const int tiles_j = (p.nj + GT - 1) / GT;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * GT, j0 = tj * GT;
+    const int m_begin = split * TN_ALL_CHUNK;
+    const int m_end = (m_begin + TN_ALL_CHUNK < M) ? m_begin + TN_ALL_CHUNK : M;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const bool want_bias = p.bias_partial && tj == 0;
+    const bool side = p.w != nullptr && ti == 0;
+    const bool opB = wave >= 2;
+    const int t7 = tid & 127, c4 = t7 & 31, rq = t7 >> 5;
+    const int ncols = opB ? ((p.nj + 3) & ~3) : ((p.ni + 3) & ~3);
+    const int base_col = opB ? j0 : i0;
+    const bool colok = base_col + 4 * c4 < ncols;
+    const bool cols_full = base_col + GT <= ncols;
+    const size_t ldx = opB ? (size_t)p.ldb : (size_t)p.lda;
+    const float* __restrict__ gX = (opB ? p.B : p.A) + base_col + (colok ? 4 * c4 : 0);
+    const float* __restrict__ gW = (side && opB) ? p.w : gX;
+    const size_t ldw = (side && opB) ? (size_t)p.ldw : 0;
+    unsigned char* planes = T + (opB ? 2 * TPLANE : 0);          // planes: A hi, A lo, B hi, B lo
+    unsigned* mine = MAXW + (opB ? 4 : 0);                       // words [half & 3] of this wave's operand
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f}, wtot = 0.f;
+    const int halves = (m_end - m_begin + 15) >> 4;
+    int E = -1000;                  // running maximum of the exponent sums (workgroup-uniform: every thread derives it from the same words)
+    if (halves > 0) {
+        f32x4_t s0[4], s1[4], s2[4];
+        float w0[4], w1[4], w2[4];
+        auto fetch = [&](f32x4_t (&sv)[4], float (&wv)[4], int h) {
+            const int mh = m_begin + 16 * h + rq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mh + 4 * i;
+                const int mc = m < m_end ? m : m_end - 1;
+                sv[i] = *reinterpret_cast<const f32x4_t*>(gX + (size_t)mc * ldx);
+                wv[i] = gW[(size_t)mc * ldw];
+            }
+        };
+        auto mask = [&](f32x4_t (&sv)[4], float (&wv)[4], int h) {
+            const int mh = m_begin + 16 * h;
+            if (mh + 16 <= m_end && cols_full) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool row = mh + rq + 4 * i < m_end;
+                const bool ok = row && colok;
+                sv[i].x = ok ? sv[i].x : 0.f; sv[i].y = ok ? sv[i].y : 0.f; sv[i].z = ok ? sv[i].z : 0.f; sv[i].w = ok ? sv[i].w : 0.f;
+                wv[i] = row ? wv[i] : 0.f;
+            }
+        };
+        // largest |entry| of this wave's share of half slab h -> this operand's word h & 3 (non-negative floats order like their bits)
+        auto publish = [&](const f32x4_t (&sv)[4], int h) {
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(sv[i].x), fabsf(sv[i].y))), fmaxf(fabsf(sv[i].z), fabsf(sv[i].w)));
+            const unsigned top = wave_max_bits(__float_as_uint(m));
+            if (lane == 0) atomicMax(&mine[h & 3], top);
+        };
+        // the scale of this wave's operand for half slab h (read behind the barrier that followed its publish), and the running C
+        float scale = 1.0f;
+        int shrink = 0;             // the accumulators are to be multiplied by 2^-shrink in front of the products of the NEXT half step
+        auto steer = [&](int h) {
+            const int ea = max_exponent(MAXW[h & 3]), eb = max_exponent(MAXW[4 + (h & 3)]);
+            shrink = 0;
+            if (ea == 0 || eb == 0) {           // an all-zero operand: nothing to scale, nothing to constrain
+                scale = 0.f;
+                return;
+            }
+            const int sum = (ea - 127) + (eb - 127);
+            if (sum > E) {
+                if (E > -1000) shrink = sum - E;
+                E = sum;
+            }
+            // dY x 2^(13 - ea'),  X x 2^(27 - E) / 2^(13 - ea') = X x 2^(14 - E + ea')
+            const int ka = 13 - (ea - 127);
+            scale = opB ? ldexpf(1.0f, 27 - E - ka) : ldexpf(1.0f, ka);
+        };
+        const int rot = c4 >> 2;
+        auto put = [&](int hb, int e, float v0, float v1, float v2, float v3) {
+            unsigned h01, h23, l01, l23;
+            split_quad_scaled_g(v0, v1, v2, v3, scale, h01, h23, l01, l23);
+            const int at = (4 * c4 + e) * TROW + (((2 * hb + (rq >> 1) + rot) & 3) << 4) + ((rq & 1) << 3);
+            *reinterpret_cast<uint2*>(planes + at) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(planes + TPLANE + at) = make_uint2(l01, l23);
+        };
+        auto sums = [&](const f32x4_t (&sv)[4], const float (&wv)[4]) {
+            if (want_bias && !opB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bsum[0] += sv[i].x; bsum[1] += sv[i].y; bsum[2] += sv[i].z; bsum[3] += sv[i].w; }
+            }
+            if (side && opB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wsum[0] = fmaf(wv[i], sv[i].x, wsum[0]); wsum[1] = fmaf(wv[i], sv[i].y, wsum[1]);
+                    wsum[2] = fmaf(wv[i], sv[i].z, wsum[2]); wsum[3] = fmaf(wv[i], sv[i].w, wsum[3]);
+                    wtot += wv[i];
+                }
+            }
+        };
+        auto rescale = [&](int d) {
+            const float f = ldexpf(1.0f, -d);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] *= f;
+        };
+        const int colA0 = wr * 64 + r, colB0 = wc * 64 + r;
+        auto half_step = [&](int hc, f32x4_t (&sv)[4], float (&wv)[4], int hs) {
+            f16x8_g a[2][2], b[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int ca = colA0 + blk * 32;
+                const int oa = ca * TROW + (((2 * hc + half + (ca >> 4)) & 3) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[blk][pl] = *reinterpret_cast<const f16x8_g*>(T + pl * TPLANE + oa);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int cc = colB0 + cb * 32;
+                const int ob = cc * TROW + (((2 * hc + half + (cc >> 4)) & 3) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) b[pl] = *reinterpret_cast<const f16x8_g*>(T + (2 + pl) * TPLANE + ob);
+                // smallest terms first, the two row blocks alternating
+                PR_MFMA_F16G(acc[0][cb], a[0][1], b[0]); PR_MFMA_F16G(acc[1][cb], a[1][1], b[0]);
+                PR_MFMA_F16G(acc[0][cb], a[0][0], b[1]); PR_MFMA_F16G(acc[1][cb], a[1][0], b[1]);
+                PR_MFMA_F16G(acc[0][cb], a[0][0], b[0]); PR_MFMA_F16G(acc[1][cb], a[1][0], b[0]);
+                if (cb == 0) {
+                    put(hs, 0, sv[0].x, sv[1].x, sv[2].x, sv[3].x);
+                    put(hs, 1, sv[0].y, sv[1].y, sv[2].y, sv[3].y);
+                } else {
+                    put(hs, 2, sv[0].z, sv[1].z, sv[2].z, sv[3].z);
+                    put(hs, 3, sv[0].w, sv[1].w, sv[2].w, sv[3].w);
+                    sums(sv, wv);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // one iteration: half h + 3 requested into the set half h was staged from; half h multiplied out of buffer h & 1; half h + 1 (set
+        // `nx`, masked and published one iteration ago) staged into the other buffer at the scale its maxima dictate; half h + 2 (set `n2`,
+        // requested one iteration ago) masked and published
+        auto iteration = [&](int h, f32x4_t (&rq_set)[4], float (&rq_w)[4], f32x4_t (&nx)[4], float (&nxw)[4], f32x4_t (&n2)[4],
+                             float (&n2w)[4]) {
+            if (tid == 0) { MAXW[(h + 3) & 3] = 0u; MAXW[4 + ((h + 3) & 3)] = 0u; }      // (published at the end of the next iteration)
+            fetch(rq_set, rq_w, h + 3);
+            if (shrink) rescale(shrink);        // half h was staged at a smaller C than the accumulators carry
+            steer(h + 1);
+            half_step(h & 1, nx, nxw, (h + 1) & 1);
+            // half h + 2 was requested a whole iteration ago: its maxima are taken HERE, behind the products, not at the top (there the
+            // wait for its rows was exposed: 1.35 instead of 1.28 ms per launch)
+            mask(n2, n2w, h + 2);
+            publish(n2, h + 2);
+            __syncthreads();
+        };
+        if (tid < 8) MAXW[tid] = 0u;
+        __syncthreads();
+        fetch(s0, w0, 0);
+        fetch(s1, w1, 1);
+        fetch(s2, w2, 2);
+        mask(s0, w0, 0);
+        publish(s0, 0);
+        mask(s1, w1, 1);
+        publish(s1, 1);
+        __syncthreads();
+        steer(0);
+        shrink = 0;
+        put(0, 0, s0[0].x, s0[1].x, s0[2].x, s0[3].x);
+        put(0, 1, s0[0].y, s0[1].y, s0[2].y, s0[3].y);
+        put(0, 2, s0[0].z, s0[1].z, s0[2].z, s0[3].z);
+        put(0, 3, s0[0].w, s0[1].w, s0[2].w, s0[3].w);
+        sums(s0, w0);
+        __syncthreads();
+        for (int h = 0; h < halves;) {
+            iteration(h, s0, w0, s1, w1, s2, w2);
+            if (++h >= halves) break;
+            iteration(h, s1, w1, s2, w2, s0, w0);
+            if (++h >= halves) break;
+            iteration(h, s2, w2, s0, w0, s1, w1);
+            ++h;
+        }
+        // (the last iteration's steer may have asked for a rescale that no product followed: the accumulators are at the C of the
+        // last MULTIPLIED half slab, which is E minus that pending shrink)
+        E -= shrink;
+    }
+    const float back = (E > -1000) ? ldexpf(1.0f, E - 27) : 0.f;
+    const int ldp = tiles_j * GT;
+    const int rows_p = ((p.ni + GT - 1) / GT) * GT;
+    float* P = p.partial + (size_t)split * rows_p * ldp;
+#pragma unroll
+    for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = j0 + wc * 64 + cb * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + wr * 64 + rb2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                P[(size_t)row * ldp + col] = acc[rb2][cb][i] * back;
+            }
+        }
+    if (want_bias || side) {
+        __syncthreads();
+        float* R = RED;
+        if (want_bias && !opB) for (int e = 0; e < 4; ++e) R[rq * GT + 4 * c4 + e] = bsum[e];
+        if (side && opB) {
+            for (int e = 0; e < 4; ++e) R[4 * GT + rq * GT + 4 * c4 + e] = wsum[e];
+            if (c4 == 0) R[8 * GT + rq] = wtot;
+        }
+        __syncthreads();
+        if (want_bias && tid < GT) {
+            float v = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) v += R[g4 * GT + tid];
+            p.bias_partial[(size_t)split * rows_p + i0 + tid] = v;
+        }
+        if (side && tid >= GT) {
+            float* W = p.w_partial + (size_t)split * (ldp + 4);
+            float v = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) v += R[4 * GT + g4 * GT + tid - GT];
+            W[j0 + tid - GT] = v;
+            if (tid == GT && tj == 0) {
+                float t = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) t += R[8 * GT + g4];
+                W[ldp] = t;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_all_bf16(TnAll g) {
     __shared__ __attribute__((aligned(16))) unsigned char T[6 * TPLANE];
     __shared__ float RED[16 * GT + 8];
@@ -998,6 +1281,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_all_bf16(TnAll g) {
 #else
         tn_all_tile_bf16_overlap(p, tile, pair - pair_begin[job], T, RED);
 #endif
+        __syncthreads();
+    }
+}
+
+// the same persistent loop over the fp16-pair work item (the default of split-precision calls)
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_all_f16(TnAll g) {
+    __shared__ __attribute__((aligned(16))) unsigned char T[4 * TPLANE];      // A hi, A lo, B hi, B lo
+    __shared__ float RED[16 * GT + 8];
+    __shared__ int pair_begin[TN_ALL_MAX + 1];
+    __shared__ int claimed;
+    __shared__ unsigned MAXW[8];     // the half slabs' maxima: four rotating words per operand
+    const int tid = threadIdx.x;
+    if (tid < g.count) pair_begin[tid + 1] = tn_all_splits(*g.job[tid].rows);
+    __syncthreads();
+    if (tid == 0) {
+        int at = 0;
+        for (int q = 0; q < g.count; ++q) {
+            const int n = pair_begin[q + 1];
+            pair_begin[q] = at;
+            at += n;
+        }
+        pair_begin[g.count] = at;
+    }
+    __syncthreads();
+    const int total_pairs = pair_begin[g.count];
+    const int xcd = blockIdx.x & 7;
+    int job = 0;
+    for (;;) {
+        if (tid == 0) claimed = atomicAdd(g.counters + xcd, 1);
+        __syncthreads();
+        const int c = claimed;
+        __syncthreads();
+        const int pair = (c / TN_ALL_TILES) * 8 + xcd;
+        if (pair >= total_pairs) break;
+        const int tile = c % TN_ALL_TILES;
+        while (pair >= pair_begin[job + 1]) ++job;
+        const TnJob& p = g.job[job];
+        const int tiles = ((p.ni + GT - 1) / GT) * ((p.nj + GT - 1) / GT);
+        if (tile >= tiles) continue;
+        tn_all_tile_f16_overlap(p, tile, pair - pair_begin[job], T, RED, MAXW);
         __syncthreads();
     }
 }
@@ -1100,8 +1423,13 @@ int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s) {
     int cus = 0;
     ProfileScope scope(3, s);
     if (g.split_precision) {
+#if PR_TNALL_F16
+        PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all_f16), 0, &cus));
+        hipLaunchKernelGGL(k_gemm_tn_all_f16, dim3(cus * 2), dim3(256), 0, s, g);
+#else
         PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all_bf16), 0, &cus));
         hipLaunchKernelGGL(k_gemm_tn_all_bf16, dim3(cus * 2), dim3(256), 0, s, g);
+#endif
     } else {
         PR_TRY(prepare_kernel(reinterpret_cast<const void*>(k_gemm_tn_all), 0, &cus));
         hipLaunchKernelGGL(k_gemm_tn_all, dim3(cus * PR_TNALL_WGS), dim3(256), 0, s, g);
