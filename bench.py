@@ -410,7 +410,7 @@ def train_step_leg(args, dev, world, rank, dist, lib, arena=True, precision="fp3
     for k in ("object_rotation_parameters", "object_translation_parameters", "object_style", "object_deformation"):
         sc[k].requires_grad_(True)          # produced by trainable encoders in the reference
     comp = model.object_composer
-    comp.precision = precision      # "f16x3": split-precision backward products (bf16 triples) behind the exact fp32 forward
+    comp.precision = precision      # "f16x3": split-precision products (fp16 pairs of scaled operands) in phase 1 of the forward and in the backward
     # the optimiser works on the composer's parameter ARENA (parallel.flatten_parameters: every parameter a view of one flat
     # tensor - names, state_dict and values unchanged; Adam is element-wise, so the update is bit for bit the per-tensor one):
     # one fused launch instead of a multi-tensor sweep over 170 tensors.  arena=False: torch's Adam on the separate tensors.
@@ -1301,7 +1301,7 @@ def main():
         del shipped
     if not args.no_train_step:
         result["train_step"] = train_step_leg(args, dev, world, rank, dist, lib)
-        # the same step with precision="f16x3" (opt-in split precision: bf16-triple products in the training forward's phase 1, the
+        # the same step with precision="f16x3" (opt-in split precision: fp16-pair products in the training forward's phase 1, the
         # backward chains and every weight gradient; fp32 accumulation, gradients at fp32 round-off) - beside the fp32 figure, never as it
         split_train = train_step_leg(args, dev, world, rank, dist, lib, precision="f16x3")
         result["train_step"]["f16x3"] = {
@@ -1309,8 +1309,8 @@ def main():
             "unit": split_train["unit"], "kernel_ms_per_step": split_train["roofline"]["kernel_ms_per_step"],
             "note": "ObjectComposer.precision='f16x3' on a training call (PR_FLAG_SPLIT_BACKWARD): phase 1 of the forward and the backward "
                     "chains on fp16 pairs (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product, weights packed as w x 2^8, activation and gradient tiles "
-                    "scaled by a power of two per tile: k_mlp_mfma_train_group_split, k_chain_bwd_group_f16), the weight gradients on bf16 "
-                    "triples (x = b1 + b2 + b3, six bf16 MFMAs per product: k_gemm_tn_all_bf16), fp32 accumulation everywhere; the head "
+                    "scaled by a power of two per tile: k_mlp_mfma_train_group_split, k_chain_bwd_group_f16), the weight gradients on fp16 "
+                    "pairs of 16-row half slabs scaled by powers of two (k_gemm_tn_all_f16), fp32 accumulation everywhere; the head "
                     "phases stay fp32.  Same gradient tests as fp32 "
                     "(reference fixtures at 1e-4, oracle autograd, float64 arbitration at shipped sizes)"}
         if world == 1:      # (a comparison leg: not repeated on every GPU count of a scaling run)

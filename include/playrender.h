@@ -81,11 +81,12 @@ typedef enum pr_status {
                                         where the compositing kernel reads a feature row; samples without a row (outside the box:
                                         raw feature 0) composite sigmoid(0) = 0.5 wherever their weight is not zero. */
 #define PR_FLAG_SPLIT_BACKWARD 1024u /* differentiable calls (with PR_FLAG_SAVE_FOR_BACKWARD, on the forward AND the backward call; ABI 5):
-                                       the matrix products of pr_render_backward in split precision, fp32 accumulation: the weight
-                                       gradients with every fp32 operand as three bf16 terms (exactly: 8 + 8 + 8 mantissa bits, fp32
-                                       exponent range; the six bf16 MFMAs whose terms are >= 2^-16 of a product), the backward chains
-                                       with fp16 pairs (x = hi + lo, three fp16 MFMAs) of the gradient tile times a power of two chosen
-                                       per 64-row tile and of the weights times 2^8 (all scalings exact).  On the forward call the flag
+                                       the matrix products of pr_render_backward in split precision, fp32 accumulation, every operand an
+                                       fp16 pair (x = hi + lo, three fp16 MFMAs per product): the backward chains on the gradient tile
+                                       times a power of two chosen per 64-row tile and the weights times 2^8, the weight gradients on
+                                       16-row half slabs - gradient rows times a power of two alpha, activation rows times C / alpha, C a
+                                       running power of two per work item (all scalings exact; a build with -DPR_TNALL_F16=0 keeps the
+                                       round-4 form of the weight gradients, three bf16 terms per operand and six bf16 MFMAs).  On the forward call the flag
                                        selects fp16-pair products for phase 1 of a train-mode forward pass too.  The call
                                        stays PR_PRECISION_FP32 (fp32-packed weights, which carry both split forms as well).  Products
                                        that have no split kernel run the exact fp32 one. */

@@ -647,7 +647,7 @@ struct TnAll {
     TnJob job[TN_ALL_MAX];
     int count;
     int32_t* counters;                 // 8 zeroed ints: the per-XCD claim counters
-    int split_precision;               // 1: operands as bf16 triples, six bf16 MFMAs per product (k_gemm_tn_all_bf16)
+    int split_precision;               // 1: operands as fp16 pairs of scaled half slabs (k_gemm_tn_all_f16; -DPR_TNALL_F16=0: bf16 triples)
 };
 size_t tn_all_partial_floats(int ni, int nj, long max_rows);
 int launch_gemm_tn_all(TnAll& g, const long* max_rows, hipStream_t s);

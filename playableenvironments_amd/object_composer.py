@@ -379,7 +379,8 @@ class ObjectComposer(Tracked, nn.Module):
         #: bits).  Differentiable / training calls keep the fp32 forward PIPELINE (train-mode BatchNorm phases, fp32 saved activations,
         #: fp32 head phases) and run, where a split kernel exists (PR_FLAG_SPLIT_BACKWARD): phase 1 of the forward pass and the backward
         #: CHAINS (dX) on fp16 pairs (weights x 2^8, tiles scaled by a power of two: all scalings exact), the WEIGHT GRADIENTS (dW) on
-        #: bf16 triples (x = b1 + b2 + b3 exactly, six bf16 MFMAs per product), fp32 accumulation everywhere - gradients pass the fp32
+        #: fp16 pairs of 16-row half slabs (gradient rows x alpha, activation rows x C / alpha, powers of two: exact; bf16 triples until
+        #: round 5), fp32 accumulation everywhere - gradients pass the fp32
         #: path's tests, the float64 arbitration at shipped sizes included.  A train-mode call WITHOUT gradients (no_grad) runs exact
         #: fp32.  The first differentiable call at a non-fp32 precision says so once (a model switched to "f16x3" for evaluation and
         #: trained afterwards changes its training numerics at round-off level).
@@ -956,13 +957,13 @@ class ObjectComposer(Tracked, nn.Module):
         if _save:
             flags |= _lib.PR_FLAG_SAVE_FOR_BACKWARD
             if self.precision in ("f16x3", "f16"):
-                # phase 1 of the forward pass and the backward chains on fp16 pairs, the weight gradients on bf16 triples
+                # phase 1 of the forward pass, the backward chains and the weight gradients on fp16 pairs of power-of-two scaled operands
                 flags |= _lib.PR_FLAG_SPLIT_BACKWARD
                 if not self._noted_split_training:
                     self._noted_split_training = True
                     warnings.warn(f"ObjectComposer.precision = {self.precision!r} applies to this differentiable call too: phase 1 of the "
-                                  "forward pass and the backward chains run on fp16 pairs, the weight gradients on bf16 triples (fp32 "
-                                  "accumulation; gradients within the fp32 path's tolerances).  Set precision = 'fp32' for exact-fp32 "
+                                  "forward pass, the backward chains and the weight gradients run on fp16 pairs of power-of-two scaled operands "
+                                  "(fp32 accumulation; gradients within the fp32 path's tolerances).  Set precision = 'fp32' for exact-fp32 "
                                   "training.", UserWarning, stacklevel=2)
         if self.gate_feature_head:
             flags |= _lib.PR_FLAG_GATE_HEAD      # honoured by the library for unperturbed evaluation calls only

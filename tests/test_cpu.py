@@ -195,7 +195,7 @@ def test_product_kernels_have_no_flat_memory_operations(built_library):
     kernels = [k for k in counts if "k_" in k]
     assert len(kernels) >= 60, len(kernels)                       # the disassembly found the library's kernels
     for wanted in ("k_mlp_mfma_group", "k_mlp_mfma_train_group_split", "k_mlp_head_group", "k_chain_bwd_group_f16", "k_head_bwd_group",
-                   "k_gemm_tn_all_bf16", "k_mlp_split_group", "k_composite"):
+                   "k_gemm_tn_all_bf16", "k_gemm_tn_all_f16", "k_mlp_split_group", "k_composite"):
         assert any(wanted in k for k in kernels), wanted
     flat = {k: v for k, v in counts.items() if v["flat_load"] or v["flat_store"]}
     assert not flat, flat
