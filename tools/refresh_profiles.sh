@@ -27,7 +27,7 @@ cp /tmp/tr/*/*_kernel_stats.csv "$OUT/${R}_train_step_kernel_stats.csv"
 cd "$ROOT"
 python tools/summarise_train_trace.py /tmp/tr/*/*_kernel_trace.csv > "$OUT/${R}_train_step_trace_summary.json"
 python tools/trace_timeline.py /tmp/tr/*/*_kernel_trace.csv --all > "$OUT/${R}_train_step_timeline.txt"
-# the split-precision (bf16-triple backward) training step: its own trace
+# the split-precision (fp16-pair) training step: its own trace
 cd /tmp; rm -rf /tmp/tr3
 PR_PERF_PRECISION=f16x3 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr3 -- python $ROOT/tools/perf/perf_train_leg.py 6 3 \
     > "$OUT/${R}_train_f16x3_leg.json" 2> "$OUT/${R}_train_f16x3_leg.err"
