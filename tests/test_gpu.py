@@ -7,6 +7,8 @@ import os
 import sys
 
 import pytest
+import warnings
+
 import torch
 
 from oracle import render_oracle as ro
@@ -944,6 +946,51 @@ def test_backward_full_size_networks(precision):
             bad[k] = (err_hip, err_ref, scale)
     assert not bad, (worst, bad)
     assert len(grads) > 80
+
+
+@pytest.mark.parametrize("profile", ["rising", "falling", "gaps"])
+def test_split_weight_gradients_follow_the_rows_scales(profile):
+    """The split-precision weight gradients (k_gemm_tn_all_f16) scale every 16-row half slab of their operands by powers of
+    two that follow the rows' magnitudes, and multiply their accumulators down when a later half slab raises the running scale.  A loss
+    whose per-ray weight spans fifteen orders of magnitude along the rays (rising: the running scale is raised again and again; falling:
+    later half slabs sink below fp16's range and must degrade to nothing, not to garbage; gaps: stretches of rays without any gradient
+    between them - all-zero half slabs) against the exact-fp32 kernels on the same call: every gradient within 5e-4 of its tensor's
+    largest entry (the sweeps' bar), nothing non-finite."""
+    cfg = configs.reduced_config(configs.minecraft_config(), width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32,
+                                 bender_layers=3, bender_skip=1, bender_octaves=3)
+    scene = synthetic.minecraft_scene(batch=1, seed=21)
+    n = 48                                                 # 2 304 rays: several 2 048-row splits per object
+    inputs = [v.cuda() for v in composer_inputs(cfg, scene, pixels=grid_pixels(scene["image_size"][0], scene["image_size"][1], n))]
+    rays = n * n
+    ramp = torch.linspace(-9.0, 6.0, rays)
+    if profile == "falling":
+        ramp = ramp.flip(0)
+    weight = torch.pow(torch.tensor(10.0), ramp)
+    if profile == "gaps":
+        weight = weight * ((torch.arange(rays) // 97) % 3 != 1).float()
+    weight = weight.cuda()
+    grads = {}
+    for precision in ("fp32", "f16x3"):
+        comp = build(cfg, alpha_bias=2.0, precision=precision).cuda().train()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = comp(*inputs, False)
+        feat = out["coarse"]["global"]["integrated_features"]
+        assert feat.shape[-2] == rays, feat.shape
+        loss = (feat.square().sum(-1).reshape(-1) * weight).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[precision] = {k: p.grad.detach().clone() for k, p in comp.named_parameters() if p.grad is not None}
+    assert len(grads["fp32"]) == len(grads["f16x3"]) > 20
+    bad = {}
+    for k, exact in grads["fp32"].items():
+        split = grads["f16x3"][k]
+        assert bool(torch.isfinite(split).all()), k
+        scale = float(exact.abs().max())
+        err = float((exact - split).abs().max())
+        if err > 5e-4 * scale + 1e-30:
+            bad[k] = (err, scale)
+    assert not bad, bad
 
 
 def test_backward_absent_object_and_frozen_parameters():
