@@ -1083,13 +1083,16 @@ __device__ __forceinline__ void tn_all_tile_f16_overlap(const TnJob& p, int tile
                 scale = 0.f;
                 return;
             }
-            const int sum = (ea - 127) + (eb - 127);
+            // (exponents below -100 count as -100: a half slab of gradients around 1e-36 - samples behind an opaque surface - would
+            // ask for alpha beyond fp32's range, inf, and 0 x inf = NaN; it is scaled as far as the range goes instead)
+            const int xa = ea - 127 > -100 ? ea - 127 : -100, xb = eb - 127 > -100 ? eb - 127 : -100;
+            const int sum = xa + xb;
             if (sum > E) {
                 if (E > -1000) shrink = sum - E;
                 E = sum;
             }
             // dY x 2^(13 - ea'),  X x 2^(27 - E) / 2^(13 - ea') = X x 2^(14 - E + ea')
-            const int ka = 13 - (ea - 127);
+            const int ka = 13 - xa;
             scale = opB ? ldexpf(1.0f, 27 - E - ka) : ldexpf(1.0f, ka);
         };
         const int rot = c4 >> 2;

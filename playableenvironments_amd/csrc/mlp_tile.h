@@ -190,10 +190,13 @@ __device__ __forceinline__ void commit_tile_max(float m, int* slot) {
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(m));
 }
-// scale = 2^k with max x 2^k in [2^14, 2^15); k = 0 for an all-zero (or non-finite) tile
+// scale = 2^k with max x 2^k in [2^14, 2^15); k = 0 for an all-zero (or non-finite) tile.  k <= 120: a tile whose largest entry is
+// below 2^-106 (gradients behind an opaque surface: transmittances of 1e-35) would ask for a scale beyond fp32's range - 2^k = inf,
+// 0 x inf = NaN in every product of the tile; such a tile is scaled as far as fp32 goes and keeps what precision is left
 __device__ __forceinline__ int tile_scale_log2(int bits) {
     const int e = ((bits >> 23) & 255);
-    return (e == 0 || e == 255) ? 0 : 14 - (e - 127);
+    const int k = 14 - (e - 127);
+    return (e == 0 || e == 255) ? 0 : (k < 120 ? k : 120);
 }
 
 struct EncRegs {

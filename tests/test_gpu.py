@@ -948,13 +948,14 @@ def test_backward_full_size_networks(precision):
     assert len(grads) > 80
 
 
-@pytest.mark.parametrize("profile", ["rising", "falling", "gaps"])
+@pytest.mark.parametrize("profile", ["rising", "falling", "gaps", "vanishing"])
 def test_split_weight_gradients_follow_the_rows_scales(profile):
     """The split-precision weight gradients (k_gemm_tn_all_f16) scale every 16-row half slab of their operands by powers of
     two that follow the rows' magnitudes, and multiply their accumulators down when a later half slab raises the running scale.  A loss
     whose per-ray weight spans fifteen orders of magnitude along the rays (rising: the running scale is raised again and again; falling:
     later half slabs sink below fp16's range and must degrade to nothing, not to garbage; gaps: stretches of rays without any gradient
-    between them - all-zero half slabs) against the exact-fp32 kernels on the same call: every gradient within 5e-4 of its tensor's
+    between them - all-zero half slabs; vanishing: every gradient around 1e-35, where a power of two that lifts a tile into fp16's range
+    does not exist in fp32 - the scales are capped, 0 x inf never happens) against the exact-fp32 kernels on the same call: every gradient within 5e-4 of its tensor's
     largest entry (the sweeps' bar), nothing non-finite."""
     cfg = configs.reduced_config(configs.minecraft_config(), width=64, layers=4, skip=2, features=32, octaves=4, bender_width=32,
                                  bender_layers=3, bender_skip=1, bender_octaves=3)
@@ -968,6 +969,8 @@ def test_split_weight_gradients_follow_the_rows_scales(profile):
     weight = torch.pow(torch.tensor(10.0), ramp)
     if profile == "gaps":
         weight = weight * ((torch.arange(rays) // 97) % 3 != 1).float()
+    if profile == "vanishing":
+        weight = torch.full((rays,), 1e-33)
     weight = weight.cuda()
     grads = {}
     for precision in ("fp32", "f16x3"):
@@ -988,7 +991,7 @@ def test_split_weight_gradients_follow_the_rows_scales(profile):
         assert bool(torch.isfinite(split).all()), k
         scale = float(exact.abs().max())
         err = float((exact - split).abs().max())
-        if err > 5e-4 * scale + 1e-30:
+        if err > 5e-4 * scale + 1e-44:
             bad[k] = (err, scale)
     assert not bad, bad
 
