@@ -522,6 +522,18 @@ int pr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  float eps, float weight_decay, int32_t decoupled_weight_decay, int32_t maximize, double step, float* step_device,
                  const float* grad_scale, const float* found_inf, void* stream);
 
+/*
+ * Node census of a recorded HIP graph: counts[0] = all nodes, [1] = kernel nodes, [2] = memset nodes, [3] = memcpy nodes
+ * (child graphs included).  `graph` is a hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Host-only: no
+ * launch, no synchronisation.  Why it exists: on ROCm 7.0.2 with the runtime's AQL packet capture the MEMSET nodes of a
+ * replayed graph stop executing once the host has synchronised between replays (torch's multi-block reductions zero their
+ * semaphores with one).  This library never records a memset (every zero fill is a kernel), but the automatic evaluation-frame
+ * recording of the host side (EnvironmentModel.frame_replay, the drop-in for model/environment_model.py:581-651) also records
+ * whatever encoder / decoder modules the caller injected - a recording with memset nodes is only replayed when the runtime
+ * switch DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is set, otherwise the call stays eager.
+ */
+int pr_graph_node_census(void* graph, int32_t* counts);
+
 /* Library / device introspection. */
 int pr_abi_version(void);
 const char* pr_last_error(void);

@@ -196,6 +196,7 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pr_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pr_graph_node_census": (C.c_int, [C.c_void_p, c_int32_p]),
     "pr_last_error": (C.c_char_p, []),
     "pr_device_info": (C.c_int, [c_int32_p, c_int32_p, C.c_char_p, C.c_size_t]),
 }

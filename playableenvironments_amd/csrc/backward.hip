@@ -13,6 +13,8 @@
 #include "pr_common.h"
 
 #include <algorithm>
+#include <map>
+#include <utility>
 #include <mutex>
 #include "composite_dev.h"
 
@@ -1432,29 +1434,41 @@ static int make_bwd_plan(const pr_call_t& c, const pr_object_t* objs, BwdPlan* b
     return PR_OK;
 }
 
-// Second stream of the backward pass (one per device, created on first use, never destroyed): the per-object parts of
-// different objects are independent between the compositing backward and the end of the call; most of their ~50 launches per
-// object are small, so two objects side by side fill the GPU better than one after the other.  The caller's stream forks
+// Second stream of the backward pass (one per device AND caller stream, created on first use, never destroyed): the per-object
+// parts of different objects are independent between the compositing backward and the end of the call; most of their ~50 launches
+// per object are small, so two objects side by side fill the GPU better than one after the other.  The caller's stream forks
 // into it after the compositing backward and joins it before the call returns - for the caller everything is still
-// enqueued on its own stream.
-static int lane_stream(hipStream_t* out) {
+// enqueued on its own stream.  Keyed by the caller's stream: two host threads that run backward passes on one device do so on
+// different streams (torch's autograd threads inherit the forward pass's stream), and one of them may be RECORDING its stream
+// into a HIP graph (capture_error_mode = thread_local) - a second stream shared per device would be pulled into that capture by
+// its fork and then receive the other thread's eager launches.
+static int lane_stream(hipStream_t caller, hipStream_t* out) {
     static std::mutex mu;
-    static hipStream_t streams[64] = {};
+    static std::map<std::pair<int, hipStream_t>, hipStream_t> streams;
     int dev = 0;
     PR_CHECK_HIP(hipGetDevice(&dev));
-    PR_REQUIRE(dev >= 0 && dev < 64, "device index %d", dev);
     std::lock_guard<std::mutex> lock(mu);
-    if (!streams[dev]) PR_CHECK_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
-    *out = streams[dev];
+    hipStream_t& slot = streams[std::make_pair(dev, caller)];
+    if (!slot) PR_CHECK_HIP(hipStreamCreateWithFlags(&slot, hipStreamNonBlocking));
+    *out = slot;
     return PR_OK;
 }
 
-static int stream_wait(hipStream_t waiter, hipStream_t on) {      // `waiter` continues after everything enqueued on `on` so far
-    hipEvent_t e;
-    PR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+// `waiter` continues after everything enqueued on `on` so far.  The events come from a small per-thread, per-device ring (a wait
+// holds what the event had recorded when hipStreamWaitEvent was called; recording it again later does not disturb that wait), so a
+// backward pass creates no events after its first calls.
+static int stream_wait(hipStream_t waiter, hipStream_t on) {
+    constexpr int RING = 8;
+    struct Ring { hipEvent_t e[RING] = {}; int next = 0; };
+    static thread_local std::map<int, Ring> rings;
+    int dev = 0;
+    PR_CHECK_HIP(hipGetDevice(&dev));
+    Ring& ring = rings[dev];
+    hipEvent_t& e = ring.e[ring.next];
+    ring.next = (ring.next + 1) % RING;
+    if (!e) PR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PR_CHECK_HIP(hipEventRecord(e, on));
     PR_CHECK_HIP(hipStreamWaitEvent(waiter, e, 0));
-    PR_CHECK_HIP(hipEventDestroy(e));                             // released once the recorded work has completed
     return PR_OK;
 }
 
@@ -1706,7 +1720,7 @@ static int backward(const pr_call_t& c, const pr_object_t* objs, int t, const pr
             any |= lane_of[k] == 1;
         }
         if (any) {
-            PR_TRY(lane_stream(&aux));
+            PR_TRY(lane_stream(s_caller, &aux));
             PR_TRY(stream_wait(aux, s_caller));          // fork: the second lane starts after the compositing backward
         }
     }
@@ -2262,14 +2276,14 @@ static int backward_grouped(const pr_call_t& c, const pr_object_t* objs, int t, 
     // Two small-grid kernels leave the caller's stream: the style affines' backward (536 workgroups, ~58 us) needs the head phases' d scale /
     // d bias only and runs beside the NeRF chains; the sample-placement backward (144 workgroups, ~47 us) needs the position gradients and
     // runs beside the weight-gradient launch.  Both fit next to the persistent tile kernels (a few waves, ~1 KB of LDS per workgroup); on
-    // the caller's stream each was ~50 us of a mostly idle chip plus a launch gap.  The second stream (one per device, lane_stream)
+    // the caller's stream each was ~50 us of a mostly idle chip plus a launch gap.  The second stream (one per device and caller stream, lane_stream)
     // forks from and joins the caller's stream through events: for the caller everything is still ordered on its own stream.
     hipStream_t aux = nullptr;
     auto run = [&]() -> int {
         PR_TRY(launch_head_bwd_group(h1, rows, K, s));
         PR_TRY(launch_head_bwd_group(h2, rows, K, s));
 #ifndef PR_BWD_ONE_STREAM
-        PR_TRY(lane_stream(&aux));
+        PR_TRY(lane_stream(s, &aux));
         PR_TRY(stream_wait(aux, s));                 // fork: behind the head phases
 #endif
         hipLaunchKernelGGL(k_style_bwd_group, dim3(style_blocks, style_jobs), dim3(256), 0, aux ? aux : s, sj);

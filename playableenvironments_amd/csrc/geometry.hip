@@ -625,11 +625,11 @@ __global__ __launch_bounds__(256) void k_patch_pixels(PatchPixelsParams p) {
             const double target = (double)p.u[n] * total;
             long lo = 0, hi = total_px - 1;          // the answer lies in [lo, hi]; prefix(hi) >= target
             while (lo < hi) {
-                const long step = (hi - lo + 63) / 64;                    // >= 1
+                const long step = (hi - lo + 64) / 64;                    // ceil((hi - lo + 1) / 64): 64 parts cover [lo, hi]
                 long cand = lo + (long)(lane + 1) * step - 1;
                 if (cand > hi) cand = hi;
                 const unsigned long long reached = __ballot(prefix(cand) >= target);
-                const int first = __ffsll((long long)reached) - 1;        // (the last lane probes hi: always set)
+                const int first = reached ? __ffsll((long long)reached) - 1 : 63;   // (the last lane probes hi: always set)
                 long part_hi = lo + (long)(first + 1) * step - 1;
                 if (part_hi > hi) part_hi = hi;
                 lo = lo + (long)first * step;

@@ -806,6 +806,39 @@ extern "C" int pr_profile_collect(double* milliseconds, int32_t* launches) {
     return PR_OK;
 }
 
+// Node census of a recorded HIP graph (child graphs included): what EnvironmentModel.frame_replay asks before it trusts a
+// recording that holds launches of modules this library does not own (see include/playrender.h).
+namespace pr {
+static int census_of(hipGraph_t graph, int32_t* counts, int depth) {
+    size_t n = 0;
+    PR_CHECK_HIP(hipGraphGetNodes(graph, nullptr, &n));
+    if (n == 0) return PR_OK;
+    std::vector<hipGraphNode_t> nodes(n);
+    PR_CHECK_HIP(hipGraphGetNodes(graph, nodes.data(), &n));
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType type;
+        PR_CHECK_HIP(hipGraphNodeGetType(nodes[i], &type));
+        counts[0] += 1;
+        if (type == hipGraphNodeTypeKernel) counts[1] += 1;
+        else if (type == hipGraphNodeTypeMemset) counts[2] += 1;
+        else if (type == hipGraphNodeTypeMemcpy) counts[3] += 1;
+        else if (type == hipGraphNodeTypeGraph && depth < 8) {
+            hipGraph_t child = nullptr;
+            PR_CHECK_HIP(hipGraphChildGraphNodeGetGraph(nodes[i], &child));
+            const int status = census_of(child, counts, depth + 1);
+            if (status != PR_OK) return status;
+        }
+    }
+    return PR_OK;
+}
+}  // namespace pr
+
+extern "C" int pr_graph_node_census(void* graph, int32_t* counts) {
+    PR_REQUIRE(graph && counts, "pr_graph_node_census: NULL pointer");
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    return pr::census_of((hipGraph_t)graph, counts, 0);
+}
+
 extern "C" int pr_abi_version(void) { return PR_ABI_VERSION; }
 
 extern "C" const char* pr_last_error(void) { return pr::g_error; }

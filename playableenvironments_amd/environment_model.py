@@ -440,7 +440,10 @@ class EnvironmentModel(Tracked, nn.Module):
         #: "alias": the dictionary holds the recording's static tensors, valid until the next call with the same shapes (an
         #: evaluator that writes its images before it renders the next batch); None: always eager.  A recording is dropped when the
         #: weights, a module registration, the precision, the annealing step or any switch it baked in changes (``_replay_signature``);
-        #: a call that cannot be recorded (an injected module that reads back to the host) is detected once and stays eager.
+        #: a call that cannot be recorded (an injected module that reads back to the host) is detected once and stays eager - and so
+        #: is a recording that holds MEMSET nodes (``pr_graph_node_census``; the renderer and this package's encoders record none,
+        #: an injected decoder with a large ``mean`` / ``sum`` does): on ROCm 7.0.2 those stop executing after a host
+        #: synchronisation between replays unless ``frame_graph.GRAPH_RUNTIME_SWITCH`` is in the environment.
         self.frame_replay = "clone"
         #: recordings kept (one per mode / shape / option combination; the oldest is dropped)
         self.frame_replay_slots = 4
@@ -905,7 +908,7 @@ class EnvironmentModel(Tracked, nn.Module):
         if entry[1] is None:
             self._in_replay = True
             try:
-                recorded = CapturedCall(lambda *ts: method(*ts), list(tensors), warmup=1)
+                recorded = CapturedCall(lambda *ts: method(*ts), list(tensors), warmup=1, what=f"frame_replay ({name})")
             except Exception as error:             # a module in front of the renderer that cannot be recorded (host reads, ...)
                 torch.cuda.synchronize()
                 warnings.warn(f"frame_replay: recording the {name} evaluation call failed ({type(error).__name__}: {error}); calls of "

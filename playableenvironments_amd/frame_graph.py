@@ -52,6 +52,34 @@ def graph_runtime_is_safe() -> bool:
     return os.environ.get(GRAPH_RUNTIME_SWITCH[0]) == GRAPH_RUNTIME_SWITCH[1]
 
 
+class UnsafeRecording(RuntimeError):
+    """A recorded graph holds memset nodes and the runtime switch that keeps them alive across host synchronisations is not set."""
+
+
+def node_census(graph: "torch.cuda.CUDAGraph") -> Dict[str, int]:
+    """Node counts of a recording made with ``torch.cuda.CUDAGraph(keep_graph=True)`` (``pr_graph_node_census``)."""
+    import ctypes as C
+    from . import _lib
+    counts = (C.c_int32 * 4)()
+    _lib.check(_lib.load().pr_graph_node_census(C.c_void_p(graph.raw_cuda_graph()), counts), "pr_graph_node_census")
+    return {"nodes": counts[0], "kernels": counts[1], "memsets": counts[2], "memcpys": counts[3]}
+
+
+def _checked_recording(graph: "torch.cuda.CUDAGraph", what: str) -> Dict[str, int]:
+    """The renderer's own launches never record a memset (every zero fill of the library is a kernel), the torch modules around
+    it may (multi-block ``sum`` / ``mean`` reductions zero their semaphores with one, ``torch.zeros`` of a large tensor): such a
+    recording replays correctly only with ``GRAPH_RUNTIME_SWITCH`` in the environment (see above) - without it the recording is
+    refused, which leaves the call eager (``EnvironmentModel.frame_replay``) or raises to the caller (``FrameGraph``)."""
+    census = node_census(graph)
+    if census["memsets"] and not graph_runtime_is_safe():
+        graph.reset()
+        raise UnsafeRecording(
+            f"{what}: the recording holds {census['memsets']} memset node(s) (of {census['nodes']} nodes) from torch modules around the "
+            f"renderer; on this HIP runtime they stop executing after a host synchronisation between replays unless "
+            f"{GRAPH_RUNTIME_SWITCH[0]}={GRAPH_RUNTIME_SWITCH[1]} is in the environment before the first HIP call")
+    return census
+
+
 OBSERVATION_KEYS = ("observations", "camera_rotations", "camera_translations", "focals", "bounding_boxes", "bounding_boxes_validity",
                     "global_frame_indexes", "video_frame_indexes", "video_indexes")
 
@@ -114,7 +142,7 @@ class FrameGraph:
             torch.cuda.current_stream(device).wait_stream(side)
             self._workspace = composer._workspace      # the graph writes through this pointer: keep it alive
             self._weights_version = self._signature()
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
             try:
                 with _no_collections_while_recording(), torch.cuda.graph(self.graph), torch.no_grad():
                     self.results = self._call()
@@ -123,6 +151,8 @@ class FrameGraph:
                 import traceback
                 traceback.print_exc()
                 raise
+            self.census = _checked_recording(self.graph, f"FrameGraph(mode={mode!r})")
+            self.graph.instantiate()
         finally:
             model._in_replay = was_recording
         # the graph also reads the composer's packed weight buffers through raw pointers: hold them, so that a repack
@@ -161,7 +191,7 @@ class CapturedCall:
     """``fn(*tensors)`` recorded once as a HIP graph and replayed for new values of the same-shaped tensors (copied into the
     recorded input buffers).  The building block of ``EnvironmentModel.frame_replay``; results are the graph's static tensors."""
 
-    def __init__(self, fn, tensors, warmup: int = 2):
+    def __init__(self, fn, tensors, warmup: int = 2, what: str = "CapturedCall"):
         self.inputs = [t.detach().clone() for t in tensors]
         device = self.inputs[0].device
         side = torch.cuda.Stream(device)
@@ -170,11 +200,13 @@ class CapturedCall:
             for _ in range(max(1, warmup)):
                 fn(*self.inputs)
         torch.cuda.current_stream(device).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         # capture_error_mode="thread_local": other threads of the process (a DataLoader's pin-memory thread, a writer) keep making
         # HIP calls while this thread records - the default "global" mode would fail THEIR calls
         with _no_collections_while_recording(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.results = fn(*self.inputs)
+        self.census = _checked_recording(self.graph, what)     # (raises UnsafeRecording: the caller stays eager)
+        self.graph.instantiate()
 
     def replay(self, tensors):
         for dst, src in zip(self.inputs, tensors):

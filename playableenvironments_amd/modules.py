@@ -82,11 +82,41 @@ class BatchNorm1d(Tracked, nn.BatchNorm1d):
 
 
 class ModuleList(Tracked, nn.ModuleList):
-    pass
+    # nn.ModuleList edits ``self._modules`` directly in these (``insert`` shifts entries by dictionary writes, ``pop`` / ``__delitem__``
+    # rebuild the dictionary, ``__setitem__`` goes through ``setattr`` with a string index): count them as registrations
+    def insert(self, index, module):
+        REGISTRATION_EPOCH[0] += 1
+        super().insert(index, module)
+
+    def __delitem__(self, idx):
+        REGISTRATION_EPOCH[0] += 1
+        super().__delitem__(idx)
+
+    def pop(self, key):
+        REGISTRATION_EPOCH[0] += 1
+        return super().pop(key)
+
+    def __setitem__(self, idx, module):
+        REGISTRATION_EPOCH[0] += 1
+        super().__setitem__(idx, module)
 
 
 class Sequential(Tracked, nn.Sequential):
-    pass
+    def insert(self, index, module):
+        REGISTRATION_EPOCH[0] += 1
+        return super().insert(index, module)
+
+    def __delitem__(self, idx):
+        REGISTRATION_EPOCH[0] += 1
+        super().__delitem__(idx)
+
+    def pop(self, key):
+        REGISTRATION_EPOCH[0] += 1
+        return super().pop(key)
+
+    def __setitem__(self, idx, module):
+        REGISTRATION_EPOCH[0] += 1
+        super().__setitem__(idx, module)
 
 
 class Conv2d(Tracked, nn.Conv2d):

@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import warnings
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -26,6 +27,34 @@ from .modules import OBJECT_MODEL_CLASSES, REGISTRATION_EPOCH as _REGISTRATION_E
 
 ENTRY_KEYS = ("integrated_features", "opacity", "weights", "depth", "disparity",
               "integrated_displacements_magnitude", "integrated_divergence")
+
+# Composers whose last backward pass produced parameter gradients and whose optimiser has not stepped since.  torch's FUSED
+# optimisers update the storages without moving the tensors' version counters, so the packed MFMA copies (and recorded frames) key on
+# ``weights_epoch`` as well - and that has to move AFTER the step: a validation / logging render between ``backward()`` and
+# ``optimizer.step()`` would otherwise pack the pre-step weights under the key the post-step forward looks up.  The hook below is
+# torch's optimiser post-step hook, installed by the first such backward pass (not on import); it only touches composers in this
+# set, and only when the optimiser that stepped holds (views of) their parameters' storages.
+_AWAITING_STEP: "weakref.WeakSet" = weakref.WeakSet()
+_STEP_HOOK = []
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    if not _AWAITING_STEP:
+        return
+    storages = None
+    for composer in list(_AWAITING_STEP):
+        if storages is None:
+            storages = {p.untyped_storage().data_ptr() for group in optimizer.param_groups for p in group["params"] if torch.is_tensor(p)}
+        if not storages.isdisjoint(composer._parameter_storages()):
+            composer.weights_epoch += 1
+            _AWAITING_STEP.discard(composer)
+
+
+def _watch_optimizer_steps(composer):
+    _AWAITING_STEP.add(composer)
+    if not _STEP_HOOK:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        _STEP_HOOK.append(register_optimizer_step_post_hook(_after_optimizer_step))
 
 
 class ObjectIDsHelper:
@@ -318,9 +347,13 @@ class _RenderFunction(torch.autograd.Function):
             hook(flat)
         # parameter gradients exist now: an optimiser step is about to change the weights, and torch's FUSED optimisers
         # (torch.optim.Adam(fused=True): torch._fused_adam_) update the storages WITHOUT moving the tensors' version counters
-        # (measured, tools/perf/dbg_version_counters.py) - the packed MFMA copies and recorded frames cannot key on them alone
+        # (measured, tools/perf/dbg_version_counters.py) - the packed MFMA copies and recorded frames cannot key on them alone.
+        # The epoch moves here (an update written by hand, p.data.add_(...), is seen by the next forward pass) AND after the step of
+        # the optimiser that owns the parameters (a render between backward() and step() packs the pre-step weights)
         if ctx.params:
             composer.weights_epoch += 1
+            if not getattr(composer, "_is_replica", False):      # (an nn.DataParallel replica lives for one call)
+                _watch_optimizer_steps(composer)
         if ctx.prepared:
             ctx.state = None   # releases the forward workspace
             if ctx.ray_grads:
@@ -497,6 +530,11 @@ class ObjectComposer(Tracked, nn.Module):
         weights it finds (the graph's own packed buffers live in its memory pool and are re-filled by every replay)."""
         self._packed.clear()
         self.state_epoch += 1
+
+    def _parameter_storages(self) -> set:
+        """Base addresses of the storages the composer's parameters live in (views of a ``parallel.flatten_parameters`` arena share
+        the arena's): what ``_after_optimizer_step`` intersects with the stepping optimiser's tensors."""
+        return {p.untyped_storage().data_ptr() for p in self._parameter_list()}
 
     def _parameter_list(self, module=None) -> list:
         """``list(module.parameters())`` (module = None: the composer), cached: walking the module tree costs ~0.3 ms per call and

@@ -326,6 +326,10 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
         for part in path:
             owner = getattr(owner, part)
         owner._parameters[attr] = views[id(p)]
+    # (written into the _parameters dictionaries directly - modules.Tracked cannot see that: composers ANYWHERE that cached the old
+    # Parameter objects, e.g. the parent model's composer when only the encoders were flattened, rebuild their lists)
+    from .modules import REGISTRATION_EPOCH
+    REGISTRATION_EPOCH[0] += 1
     for m in module.modules():     # caches derived from the old storages (ObjectComposer)
         drop = getattr(m, "_drop_device_caches", None)
         if callable(drop):

@@ -788,6 +788,34 @@ def test_flattened_parameters_train_like_separate_ones():
     assert torch.equal(arena.detach()[:35].view(7, 5), before["0.weight"])
 
 
+def test_direct_dictionary_edits_move_the_registration_epoch():
+    """modules.Tracked sees ``__setattr__`` / ``register_*`` / ``add_module``; the edits that write a module's ``_parameters`` /
+    ``_modules`` dictionaries directly have to report themselves: ``parallel.flatten_parameters`` (of ANY module - flattening the
+    encoders alone must reach the composer of the parent model, whose cached parameter lists feed the evaluation recordings'
+    signature) and ``ModuleList`` / ``Sequential`` ``insert`` / ``pop`` / ``del`` / item assignment."""
+    from playableenvironments_amd import modules, parallel
+    from playableenvironments_amd import environment_model as em
+    cfg = configs.reduced_config(configs.minecraft_config(encoders=True), width=32, layers=3, skip=1, features=16, octaves=2,
+                                 bender_width=16, bender_layers=2, bender_skip=1, bender_octaves=2)
+    model = em.EnvironmentModel(cfg)
+    composer = model.object_composer
+    cached = composer._parameter_list(model)                  # the whole model's parameters, as the recordings' signature reads them
+    assert composer._parameter_list(model) is cached
+    epoch = modules.REGISTRATION_EPOCH[0]
+    parallel.flatten_parameters(model.object_encoders)        # a module that does not contain the composer
+    assert modules.REGISTRATION_EPOCH[0] > epoch
+    fresh = composer._parameter_list(model)
+    assert fresh is not cached and all(a is b for a, b in zip(fresh, model.parameters())) and len(fresh) == len(list(model.parameters()))
+    for make in (lambda: modules.ModuleList([modules.Linear(2, 2) for _ in range(3)]),
+                 lambda: modules.Sequential(*[modules.Linear(2, 2) for _ in range(3)])):
+        for edit in (lambda c: c.insert(1, modules.Linear(2, 2)), lambda c: c.pop(0), lambda c: c.__delitem__(1),
+                     lambda c: c.__setitem__(0, modules.Linear(2, 2))):
+            container = make()
+            epoch = modules.REGISTRATION_EPOCH[0]
+            edit(container)
+            assert modules.REGISTRATION_EPOCH[0] > epoch, (type(container).__name__, edit)
+
+
 def test_shard_range_partitions():
     from playableenvironments_amd.parallel import shard_range
     for total in (0, 1, 7, 8, 65536):

@@ -1335,7 +1335,10 @@ def test_patch_pixel_kernel_matches_the_tensor_route():
     torch.manual_seed(3)
     dev = torch.device("cuda")
     weights = [0.2, 0.1, 0.35, 0.35]
-    for (h, w, patch, strides) in ((288, 512, 48, [4, 8]), (96, 160, 16, [2, 4]), (64, 64, 8, [4])):
+    # sizes whose pixel count is 64 k + 1 or leaves ranges of 64 k + 1 pixels inside the 64-way lookup (65 x 64, 33 x 33, 65 x 65,
+    # 129 x 129): a step rounded from hi - lo instead of hi - lo + 1 never probes the last pixel of such a range
+    for (h, w, patch, strides) in ((288, 512, 48, [4, 8]), (96, 160, 16, [2, 4]), (64, 64, 8, [4]), (65, 64, 8, [2, 4]),
+                                   (33, 33, 8, [2]), (65, 65, 8, [4]), (129, 129, 16, [2, 4])):
         n, k = 64, 4
         lo = torch.rand((n, 2, k), device=dev) * 0.7
         ext = torch.rand((n, 2, k), device=dev) * 0.3 + 0.02
@@ -1343,6 +1346,7 @@ def test_patch_pixel_kernel_matches_the_tensor_route():
         boxes[:, :, 3] = torch.tensor([0.0, 0.0, 1.0, 1.0], device=dev)        # one object covers the frame: corners get drawn too
         u = torch.rand((n,), device=dev)
         u[:4] = torch.tensor([0.0, 1e-7, 0.9999999, 0.5], device=dev)
+        u[4] = 1.0                                                             # the last pixel of the image
         rows, cols = rs.strided_patch_rows_cols(boxes, weights, h, w, patch, strides, _u=u)
         mask = rs._weight_masks(boxes, weights, h, w, guard_zero_area=False).double()
         cdf = torch.cumsum(mask, dim=1)
@@ -1843,6 +1847,76 @@ def _soak_loop(model, twin, shapes, scenes, checkpoints, rng, call):
             if x.is_floating_point():
                 x, y = torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)
             assert torch.equal(x, y), (it, k, model.object_composer.precision, size)
+
+
+def test_frame_replay_refuses_recordings_with_memset_nodes():
+    """The automatic evaluation-frame recording also records whatever decoder / encoder modules the caller injected.  torch's
+    multi-block reductions (a large ``mean`` / ``sum``) record a MEMSET node, and on this HIP runtime the memset nodes of a replayed
+    graph stop executing after a host synchronisation unless ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` is in the environment
+    (frame_graph.GRAPH_RUNTIME_SWITCH).  ``pr_graph_node_census`` counts the nodes of every recording: the renderer's own frame holds
+    kernels only and is replayed; a frame whose injected decoder reduces 6 M values is refused (one warning, the call stays eager
+    and right, host synchronisations between frames included) - unless the switch is set, then it replays."""
+    import ctypes as C
+    import warnings
+    from playableenvironments_amd import _lib, frame_graph
+    from playableenvironments_amd.frame_graph import SCENE_KEYS
+    x = torch.randn(1 << 22, device="cuda")
+    plain = frame_graph.CapturedCall(lambda t: t * 2 + 1, [x], warmup=1)
+    assert plain.census["memsets"] == 0 and plain.census["kernels"] == plain.census["nodes"] >= 1
+    assert torch.equal(plain.replay([x]), x * 2 + 1)
+    with pytest.raises(_lib.PlayRenderError):
+        _lib.check(_lib.load().pr_graph_node_census(None, (C.c_int32 * 4)()), "pr_graph_node_census")
+    safe = frame_graph.graph_runtime_is_safe()
+    if safe:
+        reduced = frame_graph.CapturedCall(lambda t: t.sum(), [x], warmup=1)
+        assert reduced.census["memsets"] >= 1
+    else:
+        with pytest.raises(frame_graph.UnsafeRecording, match="memset"):
+            frame_graph.CapturedCall(lambda t: t.sum(), [x], warmup=1)
+    torch.cuda.synchronize()
+    # the model: renderer-only frames replay; with a reducing decoder behind the renderer the recording is refused
+    cfg = configs.reduced_config(configs.tennis_config(), **SMALL_NETS)
+    torch.manual_seed(0)
+    model = em.EnvironmentModel(cfg)
+    synthetic.randomize_module_state(model.object_composer, seed=0, step=20000, alpha_bias=2.0, bender_scale=1e4)
+    model = model.cuda().eval()
+    size = (64, 96)
+    scenes = [{k: v.cuda() for k, v in synthetic.tennis_scene(seed=s, image_size=size).items() if torch.is_tensor(v)} for s in (5, 6, 7)]
+
+    def call(sc):
+        with torch.no_grad():
+            return model.forward_from_scene_encoding(*[sc[k] for k in SCENE_KEYS[:3]], size, *[sc[k] for k in SCENE_KEYS[3:]], 0, False)
+    for sc in scenes:
+        call(sc)
+    (entry,) = model._replays.values()
+    assert entry[1] not in (None, False) and entry[1].census["memsets"] == 0 and entry[1].census["kernels"] >= 5
+
+    class Sampler(torch.nn.Module):
+        def forward(self, feats, positions):
+            return feats
+
+    class Decoder(torch.nn.Module):
+        def forward(self, grid):                      # (..., rays, features) -> a global statistic: a multi-block reduction
+            big = grid.reshape(-1).repeat(32)
+            return grid[..., :3] - big.mean()
+    model.use_image_decoder = True
+    model.set_image_decoder(Decoder(), Sampler())
+    model.frame_replay = None
+    want = [call(sc)["coarse"]["global"]["decoded_images"] for sc in scenes]
+    model.frame_replay = "clone"
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for round_ in range(3):
+            for sc, w in zip(scenes, want):
+                got = call(sc)["coarse"]["global"]["decoded_images"]
+                torch.cuda.synchronize()              # (what stops the memset nodes of a replayed graph on the unsafe runtime)
+                assert torch.allclose(got, w, rtol=1e-5, atol=1e-6), (round_, float((got - w).abs().max()))
+    refused = [w for w in caught if "memset" in str(w.message)]
+    decoded = [e for k, e in model._replays.items() if e[1] is not None][-1]
+    if safe:
+        assert not refused and decoded[1] is not False and decoded[1].census["memsets"] >= 1
+    else:
+        assert len(refused) == 1 and decoded[1] is False          # detected once; the shape stays eager
 
 
 def test_two_cameras_per_observation():
@@ -2584,7 +2658,8 @@ def test_optimizer_steps_reach_the_next_render(optimizer):
     """Training with the optimisers a trainer may build, ``torch.optim.Adam(fused=True)`` included: torch's fused optimisers update
     the parameter storages WITHOUT moving the tensors' version counters (tools/perf/dbg_version_counters.py: values change,
     ``_version`` stays) - the composer's packed MFMA weight copies and the recorded evaluation frames therefore also key on
-    ``weights_epoch`` (moved by every backward pass that produced parameter gradients).  After every step the training render,
+    ``weights_epoch`` (moved by every backward pass that produced parameter gradients, and again by the step of the optimiser that
+    holds the parameters: every other iteration renders between ``backward()`` and ``step()``).  After every step the training render,
     an evaluation render and a RECORDED evaluation frame must show the new weights: equal to a freshly built composer holding
     the same state."""
     from playableenvironments_amd import parallel
@@ -2623,6 +2698,13 @@ def test_optimizer_steps_reach_the_next_render(optimizer):
         out["coarse"]["global"]["integrated_features"].square().mean().backward()
         if arena is not None:
             parallel.flat_gradient(arena, comp)
+        if step % 2 == 1:
+            # a validation / logging render BETWEEN backward() and the optimiser step packs the pre-step weights: the epoch has to
+            # move again once the optimiser that owns the parameters has stepped (torch's optimiser post-step hook)
+            model.eval()
+            with torch.no_grad():
+                before = model(*args, 0, False, 0, patch_stride=[4, 8], mode="scene_encodings")["coarse"]["global"]["integrated_features"]
+            assert torch.equal(before, fresh_eval()), (optimizer, step)      # (pre-step weights, this iteration's BatchNorm statistics)
         opt.step()
         model.eval()
         with torch.no_grad():        # (the default frame_replay: eager, recording, replay, replay ... across the optimiser steps)
