@@ -369,7 +369,7 @@ def _c_stdout_to_stderr():
 def train_traffic():
     """HBM bytes per training step from the committed PMC passes of tools/collect_pmc_train.sh (all library kernels of a step, and
     the three largest), with the library stamp they were collected from."""
-    for name in ("r05_pmc_train_summary.json", "r04_pmc_train_summary.json", "r03_pmc_train_summary.json"):
+    for name in ("r06_pmc_train_summary.json", "r05_pmc_train_summary.json", "r04_pmc_train_summary.json", "r03_pmc_train_summary.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
@@ -1142,7 +1142,7 @@ def main():
     traffic = None
     traffic_source = traffic_stamp = None
     sha = library_sha256()
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         pmc_path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc_path) and size == (256, 256):
             with open(pmc_path) as f:

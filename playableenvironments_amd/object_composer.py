@@ -41,11 +41,12 @@ _STEP_HOOK = []
 def _after_optimizer_step(optimizer, args, kwargs):
     if not _AWAITING_STEP:
         return
-    storages = None
+    try:
+        storages = {p.untyped_storage().data_ptr() for group in optimizer.param_groups for p in group["params"] if torch.is_tensor(p)}
+    except Exception:              # (a tensor without a plain storage among the optimiser's: assume it may own ours)
+        storages = None
     for composer in list(_AWAITING_STEP):
-        if storages is None:
-            storages = {p.untyped_storage().data_ptr() for group in optimizer.param_groups for p in group["params"] if torch.is_tensor(p)}
-        if not storages.isdisjoint(composer._parameter_storages()):
+        if storages is None or not storages.isdisjoint(composer._parameter_storages()):
             composer.weights_epoch += 1
             _AWAITING_STEP.discard(composer)
 

@@ -816,6 +816,41 @@ def test_direct_dictionary_edits_move_the_registration_epoch():
             assert modules.REGISTRATION_EPOCH[0] > epoch, (type(container).__name__, edit)
 
 
+def test_weights_epoch_follows_the_owning_optimisers_step():
+    """``ObjectComposer.weights_epoch`` (part of the packed-weight and recorded-frame keys: torch's fused optimisers do not move version
+    counters) moves once more AFTER the step of the optimiser that holds the composer's parameters - a render between ``backward()``
+    and ``step()`` must not leave pre-step packed weights under the post-step key.  The hook is torch's optimiser post-step hook,
+    installed by the first backward pass that produced parameter gradients; steps of optimisers that own other tensors, and steps
+    while no backward pass is pending, leave the epoch alone; views of a ``flatten_parameters`` arena count as the arena's storage."""
+    from playableenvironments_amd import object_composer as oc, parallel
+    cfg = configs.reduced_config(configs.tennis_config(), width=32, layers=3, skip=1, features=16, octaves=2,
+                                 bender_width=16, bender_layers=2, bender_skip=1, bender_octaves=2)
+    composer = ObjectComposer(cfg)
+    other = torch.nn.Linear(3, 3)
+    mine = torch.optim.SGD(composer.parameters(), lr=0.0)
+    theirs = torch.optim.SGD(other.parameters(), lr=0.0)
+    for p in list(composer.parameters()) + list(other.parameters()):
+        p.grad = torch.zeros_like(p)
+    epoch = composer.weights_epoch
+    mine.step()
+    assert composer.weights_epoch == epoch                  # nothing pending: optimiser steps are not watched
+    oc._watch_optimizer_steps(composer)                      # (what _RenderFunction.backward does after it produced parameter gradients)
+    theirs.step()
+    assert composer.weights_epoch == epoch and composer in oc._AWAITING_STEP
+    mine.step()
+    assert composer.weights_epoch == epoch + 1 and composer not in oc._AWAITING_STEP
+    mine.step()
+    assert composer.weights_epoch == epoch + 1
+    arena = parallel.flatten_parameters(composer)
+    arena.grad = torch.zeros_like(arena)
+    flat = torch.optim.SGD([arena], lr=0.0)             # (the arena is what the optimiser holds; the composer's parameters are views of it)
+    oc._watch_optimizer_steps(composer)
+    theirs.step()
+    assert composer.weights_epoch == epoch + 1
+    flat.step()
+    assert composer.weights_epoch == epoch + 2
+
+
 def test_shard_range_partitions():
     from playableenvironments_amd.parallel import shard_range
     for total in (0, 1, 7, 8, 65536):
