@@ -69,7 +69,7 @@ def compact_result(result: dict, full_path=None) -> dict:
     line["config"] = cfgw
     line["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_from_this_library",
                                                    "peak_measured", "flop_per_step", "flop_per_step_algorithmic", "algorithmic_tflops",
-                                                   "mlp_ms_per_step", "mlp_launches_per_step", "composite_ms_per_step") if k in roof}
+                                                   "mlp_ms_per_step", "mlp_launches_per_step", "composite_ms_per_step", "clock") if k in roof}
     if isinstance(line["roofline"].get("kernel"), str):
         line["roofline"]["kernel"] = line["roofline"]["kernel"].split(" ")[0]
     cpu = r.get("cpu_baseline")
@@ -91,6 +91,7 @@ def compact_result(result: dict, full_path=None) -> dict:
     summary = {
         "identical_frames_mrays": _dig(r, "identical_frames", "value"),
         "split_precision_mrays": _dig(r, "split_precision", "value"),
+        "split_precision_sclk_mhz": _dig(r, "split_precision", "clock", "sclk_mhz"),
         "half_precision_mrays": _dig(r, "half_precision", "value"),
         "train_step_ms": _dig(r, "train_step", "ms_per_step"),
         "train_step_ms_median": _dig(r, "train_step", "ms_per_step_median"),
@@ -969,6 +970,7 @@ def main():
                     help="also run the CPU oracle ONCE on every ray of the frame (~190 s of host time; recorded at 0.000348 Mrays/s in "
                          "profiles/r04_bench.json).  Off by default: the cpu_baseline sample is bounded so that the default run takes ~1.5 min")
     ap.add_argument("--no-cpu-full-size", action="store_true", help=argparse.SUPPRESS)     # (accepted: the old default-on switch)
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample shader clock / package power during the timed regions")
     ap.add_argument("--no-shard-balance", action="store_true", help="skip the virtual-shard balance measurement (N = 1 only)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch threads of the main CPU baseline run (all 256 host cores are >50x SLOWER on these small ops)")
@@ -1112,7 +1114,35 @@ def main():
         timed.gaps = event_gaps_ms(marks)
         return dt, kernel_ms, kernel_launches
 
-    elapsed, ms, launches = timed(args.steps, args.warmup)
+    # shader clock / package power during the timed regions (amdgpu sysfs, sampled by a thread of this process; one GPU only - the node
+    # is found by the power rise of a matrix probe): says whether a measured region ran clock limited.  Never fails the run.
+    telemetry = None
+    if world == 1 and not args.no_telemetry:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gpu_telemetry
+
+            def _load():
+                tf, pms = C.c_double(), C.c_double()
+                lib.pr_probe_mfma_f32(20000, 1, C.byref(tf), C.byref(pms), None)
+            card = gpu_telemetry.find_card(_load)
+            if card is not None:
+                telemetry = gpu_telemetry.Telemetry(card)
+                telemetry.start()
+        except Exception as error:      # (no sysfs in a container, ...: the line simply carries no clock block)
+            print(f"bench.py: no clock / power telemetry ({type(error).__name__}: {error})", file=sys.stderr)
+            telemetry = None
+
+    def watched(label, fn):
+        if telemetry is None:
+            return fn()
+        telemetry.label = label
+        try:
+            return fn()
+        finally:
+            telemetry.label = None
+
+    elapsed, ms, launches = watched("headline", lambda: timed(args.steps, args.warmup))
     step_gaps = timed.gaps
     identical = None
     if multi:
@@ -1125,10 +1155,10 @@ def main():
         # secondary measurement, never the headline: the same step with the MLP on the split-precision
         # kernel (fp32 emulated with three fp16 MFMAs; same parity tolerance in tests/test_gpu.py)
         comp.precision = "f16x3"
-        split_s, split_ms, _ = timed(args.steps, max(1, args.warmup))
+        split_s, split_ms, _ = watched("f16x3", lambda: timed(args.steps, max(1, args.warmup)))
         # ... and on the single-product fp16 tier (throughput configuration, ~1e-3 relative error: not a parity configuration)
         comp.precision = "f16"
-        half_s, half_ms, _ = timed(args.steps, max(1, args.warmup))
+        half_s, half_ms, _ = watched("f16", lambda: timed(args.steps, max(1, args.warmup)))
         comp.precision = "fp32"
         split = (split_s, split_ms[0] / max(1, args.steps))
         half = (half_s, half_ms[0] / max(1, args.steps))
@@ -1234,6 +1264,15 @@ def main():
         },
     }
 
+    clocks = {}
+    if telemetry is not None:
+        telemetry.finish()
+        clocks = {label: telemetry.summary(label) for label in ("headline", "f16x3", "f16")}
+        if clocks["headline"].get("samples"):
+            result["roofline"]["clock"] = {k: clocks["headline"].get(k) for k in ("sclk_mhz", "power_w", "power_cap_w") if k in clocks["headline"]}
+            result["roofline"]["clock_note"] = ("mean shader clock / package power over the headline's warm-up + timed steps (amdgpu sysfs, 20 ms samples, "
+                                                "tools/gpu_telemetry.py); nominal 2 400 MHz: the fp32 kernel is not clock limited, the fp16 tiers are "
+                                                "(DESIGN.md 11.3)")
     if args.precision == "f16x3":
         result["dtype"] = "f16x3 (fp32 emulated with three fp16 MFMAs, fp32 accumulate)"
         result["roofline"]["kernel"] = "k_mlp_split (fused split-precision MFMA MLP); achieved/peak are in fp32-equivalent FLOPs"
@@ -1247,6 +1286,7 @@ def main():
             "ms_per_step": round(split[0] / args.steps * 1e3, 3),
             "mlp_ms_per_step": round(split[1], 3),
             "executed_tflops": round(executed / (split[1] * 1e-3) / 1e12, 2) if split[1] > 0 else None,
+            "clock": {k: clocks["f16x3"].get(k) for k in ("sclk_mhz", "power_w") if k in clocks.get("f16x3", {})} or None,
             "note": "same workload with ObjectComposer.precision='f16x3' (k_mlp_split): every fp32 product as three fp16 "
                     "MFMAs, ~22-bit operands, fp32 accumulation; passes the same oracle/golden parity tolerance; "
                     "reported beside the exact-fp32 headline, not as it",

@@ -1416,6 +1416,9 @@ def test_bench_line_is_compact_and_complete():
                               "all_gather": {"ms": 3.2, "receive_GB_per_s_per_receiving_rank": 110.1, "receiving_ranks": 8},
                               "gather_dst0": {"ms": 3.0, "receive_GB_per_s_per_receiving_rank": 117.4, "receiving_ranks": 1}, "link_note": "x" * 300}
     wide["identical_frames"] = {"value": 2.5, "unit": "Mrays/s", "ms_per_step": 207.0, "note": "y" * 200}
+    # round 6: the shader clock / package power of the measured region ride along (tools/gpu_telemetry.py)
+    full["roofline"] = dict(full["roofline"], clock={"sclk_mhz": 2395.1, "power_w": 1157.3, "power_cap_w": 1400.0}, clock_note="z" * 300)
+    full["split_precision"] = dict(full["split_precision"], clock={"sclk_mhz": 2062.0, "power_w": 1284.0})
     for record in (full, wide):
         text = bench.compact_line(record, "bench_full.json")
         assert len(text.encode()) < bench.LINE_BUDGET and "\n" not in text
@@ -1429,6 +1432,8 @@ def test_bench_line_is_compact_and_complete():
         for key in ("value", "unit", "cores", "kind", "sample"):
             assert key in line["cpu_baseline"], key
         assert line["summary"]["train_step_ms"] == record["train_step"]["ms_per_step"]
+    assert json.loads(bench.compact_line(full))["roofline"]["clock"]["sclk_mhz"] == 2395.1
+    assert json.loads(bench.compact_line(full))["summary"]["split_precision_sclk_mhz"] == 2062.0
     assert len(json.loads(bench.compact_line(wide))["distributed"]["rank_devices"]) == 8
     assert json.loads(bench.compact_line(wide))["feature_gather"]["all_gather_GB_per_s"] == 110.1
     # a record bloated beyond the budget still yields a parsable line (optional blocks go first, the contract keys never)
