@@ -115,6 +115,7 @@ def compact_result(result: dict, full_path=None) -> dict:
         "hip_over_reference_graph": _dig(r, "reference_graph_on_gpu", "hip_over_reference_graph"),
         "psnr_db": _dig(r, "psnr_db", "fp32"),
         "psnr_db_f16x3": _dig(r, "psnr_db", "f16x3"),
+        "psnr_db_f16": _dig(r, "psnr_db", "f16"),
     }
     line["summary"] = {k: v for k, v in summary.items() if v is not None}
     line["library_sha256"] = (r.get("library_sha256") or "")[:16]
@@ -1485,7 +1486,7 @@ def baseline_legs(args, cfg, comp, scene, size, dev, gpu_mrays):
     lo, hi = float(a.min()), float(a.max())
     psnr = {}
     before = comp.precision
-    for precision in ("fp32", "f16x3"):
+    for precision in ("fp32", "f16x3", "f16"):     # (f16: the throughput tier - NOT a parity configuration; its PSNR says what it costs)
         comp.precision = precision
         with torch.no_grad():
             got = comp(*[v.to(dev) for v in inputs], False)

@@ -224,6 +224,47 @@ def test_k_loops_never_wait_for_every_outstanding_request(built_library):
                 assert not any("vmcnt(0)" in w for w in loop["waits"]), (k, loop)
 
 
+def test_plain_c_client_links_and_calls_the_abi(built_library, tmp_path):
+    """The drop-in boundary is a C ABI: ``include/playrender.h`` has to compile as plain C99 (what a cgo / JNI / N-API stub includes, no
+    C++ or torch type in any signature) and a C program linked against ``libplayrender.so`` has to reach the host-side entry points -
+    the version, a size query on a zeroed model (refused with a message), the host-only graph census on a NULL graph (refused).  No
+    device call: runs without a GPU."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    source = tmp_path / "client.c"
+    source.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "playrender.h"
+int main(void) {
+    pr_object_model_t model;
+    size_t bytes = 0;
+    int32_t counts[4] = {7, 7, 7, 7};
+    memset(&model, 0, sizeof model);
+    if (pr_abi_version() != PR_ABI_VERSION) return 1;
+    if (pr_packed_size(&model, &bytes) == 0) return 2;            /* a zeroed description is not a model */
+    if (pr_last_error() == NULL || strlen(pr_last_error()) == 0) return 3;
+    if (pr_graph_node_census(NULL, counts) == 0) return 4;
+    if (pr_profile_enable(0) != 0) return 5;
+    printf("abi %d, sizeof(pr_call_t) %zu, sizeof(pr_object_model_t) %zu, refusal: %s\n", pr_abi_version(), sizeof(pr_call_t),
+           sizeof(pr_object_model_t), pr_last_error());
+    return 0;
+}
+""")
+    lib_dir = os.path.dirname(_lib.library_path())
+    binary = tmp_path / "client"
+    build = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(source),
+                            "-L", lib_dir, "-lplayrender", f"-Wl,-rpath,{lib_dir}", "-o", str(binary)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(binary)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr[-2000:])
+    assert f"sizeof(pr_call_t) {C.sizeof(_lib.Call)}," in run.stdout and f"sizeof(pr_object_model_t) {C.sizeof(_lib.ObjectModel)}," in run.stdout
+
+
 def test_struct_sizes_match_header_layout():
     """ctypes mirrors must have the C sizes (pointer = 8, int32 = 4, natural alignment)."""
     assert C.sizeof(_lib.Linear) == 24
