@@ -113,6 +113,8 @@ def compact_result(result: dict, full_path=None) -> dict:
         "config2_minecraft_frac": _dig(r, "config2_minecraft_256", "roofline", "frac"),
         "reference_graph_fastest_mrays": _dig(r, "reference_graph_on_gpu", "value"),
         "hip_over_reference_graph": _dig(r, "reference_graph_on_gpu", "hip_over_reference_graph"),
+        "f16x3_over_reference_graph": _dig(r, "reference_graph_on_gpu", "tiers", "f16x3", "over_reference_graph"),
+        "f16_over_reference_graph": _dig(r, "reference_graph_on_gpu", "tiers", "f16", "over_reference_graph"),
         "psnr_db": _dig(r, "psnr_db", "fp32"),
         "psnr_db_f16x3": _dig(r, "psnr_db", "f16x3"),
         "psnr_db_f16": _dig(r, "psnr_db", "f16"),
@@ -1368,6 +1370,16 @@ def main():
             result["shard_balance"]["minecraft_shipped"] = result["config2_minecraft_256"].pop("shard_balance")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(baseline_legs(args, cfg, comp, scene, size, dev, value))
+    graph_rate = _dig(result, "reference_graph_on_gpu", "value")
+    if graph_rate:
+        # north_star: ">= 10 x the reference PyTorch renderer's Mrays/s on one MI355X at matched PSNR" - every tier against the FASTEST chunk
+        # size of the reference's op graph on this GPU, with the tier's PSNR against the oracle beside it (80 dB = the formula's ceiling)
+        tiers = {}
+        for tier, rate, key in (("fp32", result["value"], "fp32"), ("f16x3", _dig(result, "split_precision", "value"), "f16x3"),
+                                ("f16", _dig(result, "half_precision", "value"), "f16")):
+            if rate:
+                tiers[tier] = {"over_reference_graph": round(rate / graph_rate, 2), "psnr_db": _dig(result, "psnr_db", key)}
+        result["reference_graph_on_gpu"]["tiers"] = tiers
     if rank == 0:
         emit(result, args.full_json)
     if multi:
