@@ -1128,7 +1128,8 @@ def main():
             def _load():
                 tf, pms = C.c_double(), C.c_double()
                 lib.pr_probe_mfma_f32(20000, 1, C.byref(tf), C.byref(pms), None)
-            card = gpu_telemetry.find_card(_load)
+            props = torch.cuda.get_device_properties(dev)
+            card = gpu_telemetry.find_card(_load, pci=(props.pci_domain_id, props.pci_bus_id, props.pci_device_id))
             if card is not None:
                 telemetry = gpu_telemetry.Telemetry(card)
                 telemetry.start()

@@ -49,9 +49,27 @@ def power_cap_w(dev):
     return None
 
 
-def find_card(load, seconds: float = 1.5):
-    """The DRM node of the GPU `load()` runs on: a box exposes one node per GPU of its host, one of them is ours - the node whose
-    package power rises most while `load()` (a callable that keeps the GPU busy for a few milliseconds per call) runs."""
+def card_of_pci_address(domain: int, bus: int, device: int):
+    """The DRM node whose PCI address is domain:bus:device.0 (torch.cuda.get_device_properties(i).pci_domain_id / pci_bus_id /
+    pci_device_id) - exact, where the sysfs tree shows the addresses (it does on the pool's boxes)."""
+    want = f"{domain:04x}:{bus:02x}:{device:02x}."
+    try:
+        for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if os.path.basename(os.path.realpath(d)).lower().startswith(want) and _power_w(d) is not None:
+                return d
+    except Exception:
+        pass
+    return None
+
+
+def find_card(load, seconds: float = 1.5, pci=None):
+    """The DRM node of the GPU `load()` runs on: a box exposes one node per GPU of its host, one of them is ours.  `pci` = (domain,
+    bus, device) of the device names it exactly; otherwise it is the node whose package power rises most while `load()` (a callable
+    that keeps the GPU busy for a few milliseconds per call) runs - which a busy neighbour on the same host can fool."""
+    if pci is not None:
+        exact = card_of_pci_address(*pci)
+        if exact is not None:
+            return exact
     try:
         cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if _power_w(d) is not None]
         if len(cards) <= 1:

@@ -38,7 +38,12 @@ def main():
     def load():
         tf, ms = C.c_double(), C.c_double()
         lib.pr_probe_mfma_f32(20000, 1, C.byref(tf), C.byref(ms), None)
-    dev_path = gpu_telemetry.find_card(load)
+    props = torch.cuda.get_device_properties(dev)
+    print(f"device 0: {props.name} at PCI {props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0")
+    by_address = gpu_telemetry.card_of_pci_address(props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    by_power = gpu_telemetry.find_card(load)
+    print("DRM node by PCI address:", by_address, " by power rise:", by_power)
+    dev_path = by_address or by_power
     print("sysfs device:", dev_path, " power cap:", gpu_telemetry.power_cap_w(dev_path) if dev_path else None, "W")
     sampler = gpu_telemetry.Telemetry(dev_path) if dev_path else None
     cfg = configs.tennis_config(hierarchical=(64, 128))
