@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 import warnings
 import weakref
 from typing import Dict, List, Optional, Tuple
@@ -35,6 +36,7 @@ ENTRY_KEYS = ("integrated_features", "opacity", "weights", "depth", "disparity",
 # torch's optimiser post-step hook, installed by the first such backward pass (not on import); it only touches composers in this
 # set, and only when the optimiser that stepped holds (views of) their parameters' storages.
 _AWAITING_STEP: "weakref.WeakSet" = weakref.WeakSet()
+_AWAITING_LOCK = threading.Lock()      # (backward passes run on autograd's threads, optimisers step on the caller's)
 _STEP_HOOK = []
 
 
@@ -45,17 +47,21 @@ def _after_optimizer_step(optimizer, args, kwargs):
         storages = {p.untyped_storage().data_ptr() for group in optimizer.param_groups for p in group["params"] if torch.is_tensor(p)}
     except Exception:              # (a tensor without a plain storage among the optimiser's: assume it may own ours)
         storages = None
-    for composer in list(_AWAITING_STEP):
+    with _AWAITING_LOCK:
+        waiting = list(_AWAITING_STEP)
+    for composer in waiting:
         if storages is None or not storages.isdisjoint(composer._parameter_storages()):
             composer.weights_epoch += 1
-            _AWAITING_STEP.discard(composer)
+            with _AWAITING_LOCK:
+                _AWAITING_STEP.discard(composer)
 
 
 def _watch_optimizer_steps(composer):
-    _AWAITING_STEP.add(composer)
-    if not _STEP_HOOK:
-        from torch.optim.optimizer import register_optimizer_step_post_hook
-        _STEP_HOOK.append(register_optimizer_step_post_hook(_after_optimizer_step))
+    with _AWAITING_LOCK:
+        _AWAITING_STEP.add(composer)
+        if not _STEP_HOOK:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            _STEP_HOOK.append(register_optimizer_step_post_hook(_after_optimizer_step))
 
 
 class ObjectIDsHelper:
