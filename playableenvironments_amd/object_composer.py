@@ -358,9 +358,13 @@ class _RenderFunction(torch.autograd.Function):
         # The epoch moves here (an update written by hand, p.data.add_(...), is seen by the next forward pass) AND after the step of
         # the optimiser that owns the parameters (a render between backward() and step() packs the pre-step weights)
         if ctx.params:
-            composer.weights_epoch += 1
-            if not getattr(composer, "_is_replica", False):      # (an nn.DataParallel replica lives for one call)
-                _watch_optimizer_steps(composer)
+            owner = composer
+            if getattr(composer, "_is_replica", False):          # (an nn.DataParallel replica lives for one call: its original counts)
+                ref = composer.__dict__.get("_replica_of")
+                owner = ref() if ref is not None else None
+            if owner is not None:
+                owner.weights_epoch += 1
+                _watch_optimizer_steps(owner)
         if ctx.prepared:
             ctx.state = None   # releases the forward workspace
             if ctx.ray_grads:
@@ -595,6 +599,9 @@ class ObjectComposer(Tracked, nn.Module):
         fresh = dict(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _tracked={}, _annealing={}, _linspace={}, _workspace=None,
                      _budget_ok=0, _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None)
         replica.__dict__.update(fresh)
+        # (the replica's backward pass reports parameter gradients to the ORIGINAL: its packed copies / recorded frames are what an
+        # evaluation render outside the wrapper - model.module.render_full_frame_* - reads after the optimiser step)
+        replica.__dict__["_replica_of"] = weakref.ref(self.__dict__["_replica_of"]() if "_replica_of" in self.__dict__ else self)
         return replica
 
     def __getstate__(self):
@@ -603,6 +610,7 @@ class ObjectComposer(Tracked, nn.Module):
         state = dict(self.__dict__)
         state.update(gradient_hooks=[], _packed={}, _param_lists={}, _structs={}, _tracked={}, _annealing={}, _linspace={}, _workspace=None, _budget_ok=0,
                      _pending_bn_check=None, last_normalised_samples={}, last_noise_seed=None, _host_step=None)
+        state.pop("_replica_of", None)
         return state
 
     def _drop_device_caches(self):

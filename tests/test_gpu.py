@@ -1358,6 +1358,25 @@ def test_patch_pixel_kernel_matches_the_tensor_route():
         # a draw that lands within rounding of a pixel's cumulative weight may resolve to the neighbouring pixel
         assert int((~same).sum()) <= 1, (int((~same).sum()), h, w)
         assert int(rows.min()) >= 0 and int(rows.max()) < h and int(cols.min()) >= 0 and int(cols.max()) < w
+    # the centre lookup itself, sharply: a 2 x 2 patch at stride 1 starts one pixel up / left of the drawn centre (no alignment, clamped only
+    # at the image border), so a wrong centre shows as a wrong pixel list - 40 random image sizes (odd, prime, 64 k + 1 ...), 256 draws each
+    rng = np.random.default_rng(11)
+    for h, w in [(int(a), int(b)) for a, b in rng.integers(5, 330, size=(36, 2))] + [(65, 65), (1 + 64 * 3, 7), (9, 1 + 64 * 5), (64, 65)]:
+        n, k = 256, 4
+        lo = torch.rand((n, 2, k), device=dev) * 0.7
+        ext = torch.rand((n, 2, k), device=dev) * 0.3 + 0.02
+        boxes = torch.cat([lo, (lo + ext).clamp(max=1.0)], dim=1)
+        boxes[:, :, 3] = torch.tensor([0.0, 0.0, 1.0, 1.0], device=dev)
+        u = torch.rand((n,), device=dev)
+        u[:3] = torch.tensor([0.0, 1.0, 0.9999999], device=dev)
+        rows, cols = rs.strided_patch_rows_cols(boxes, weights, h, w, 2, [1], _u=u)
+        mask = rs._weight_masks(boxes, weights, h, w, guard_zero_area=False).double()
+        cdf = torch.cumsum(mask, dim=1)
+        centres = torch.searchsorted(cdf, (u.double() * cdf[:, -1]).unsqueeze(1)).clamp(max=h * w - 1)[:, 0]
+        want = rs.patch_pixels_around(centres, h, w, 2, [1])
+        got = rows.to(torch.int64) * w + cols.to(torch.int64)
+        differing = int((~(got == want).all(dim=1)).sum())
+        assert differing <= 2, (differing, h, w)          # (draws within rounding of a pixel's cumulative weight)
 
 
 def test_recorded_training_step_equals_eager_steps():
@@ -2778,6 +2797,28 @@ def test_data_parallel_wrapper_matches_the_plain_call():
         worst = max(worst, float((p.grad - w).abs().max()) / scale)
     assert worst < 1e-5, worst
     model.eval()
+    # ... and the optimiser step that follows reaches the ORIGINAL's renders: the replicas (which ran the backward pass) report their
+    # parameter gradients to the module they were copied from - torch's fused Adam moves no version counter, and the reference's
+    # evaluators render through ``model.module`` outside the wrapper (evaluation/evaluator.py:58)
+    epoch = comp.weights_epoch
+    with torch.no_grad():
+        before = model(*args, 0, False, 1200, **kw)["coarse"]["global"]["integrated_features"].clone()
+    opt = torch.optim.Adam(params, lr=1e-2, fused=True)
+    model.train()
+    for p in params:
+        p.grad = None
+    out = wrapped(*args, 0, False, 1200, **kw)
+    (out["coarse"]["global"]["integrated_features"] ** 2).mean().backward()
+    assert comp.weights_epoch > epoch
+    opt.step()
+    model.eval()
+    fresh = em.EnvironmentModel(model.config).cuda().eval()
+    fresh.load_state_dict(model.state_dict())
+    fresh.frame_replay = None
+    with torch.no_grad():
+        after = model(*args, 0, False, 1200, **kw)["coarse"]["global"]["integrated_features"]
+        want_after = fresh(*args, 0, False, 1200, **kw)["coarse"]["global"]["integrated_features"]
+    assert not torch.equal(after, before) and torch.equal(after, want_after), float((after - want_after).abs().max())
 
 
 def test_replaced_parameters_buffers_and_modules_are_noticed():
