@@ -542,6 +542,13 @@ class ObjectComposer(Tracked, nn.Module):
         self._packed.clear()
         self.state_epoch += 1
 
+    def weights_changed(self):
+        """Call after writing parameter VALUES behind autograd's back - ``p.data.mul_(...)`` / ``p.data = ...`` style updates (a hand-written
+        EMA or optimiser; ``.data`` has its own version counter, the parameter's does not move) when no backward pass of this composer
+        preceded them: the packed MFMA copies and recorded evaluation frames are re-made from the current values.  In-place ops under
+        ``torch.no_grad()``, ``load_state_dict``, ``.to()`` and every ``torch.optim`` optimiser (fused ones included) need no call."""
+        self.weights_epoch += 1
+
     def _parameter_storages(self) -> set:
         """Base addresses of the storages the composer's parameters live in (views of a ``parallel.flatten_parameters`` arena share
         the arena's): what ``_after_optimizer_step`` intersects with the stepping optimiser's tensors."""

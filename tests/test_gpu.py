@@ -2877,6 +2877,12 @@ def test_replaced_parameters_buffers_and_modules_are_noticed():
     stock.weight = torch.nn.Parameter(stock.weight.detach() * 3.0)        # (a registration this package cannot see)
     five = render()
     assert not torch.equal(five, four) and torch.equal(five, fresh_render())
+    # (5) values written through .data (its own version counter: the parameter's does not move, nothing observable changes) are the
+    # one update the composer cannot see - ObjectComposer.weights_changed() is the documented call for them
+    comp.object_models_coarse[0].nerf_model.backbone_layers[0].weight.data.mul_(1.25)
+    comp.weights_changed()
+    six = render()
+    assert not torch.equal(six, five) and torch.equal(six, fresh_render())
 
 
 def test_render_sharded_and_async_gather_rccl_world1():
