@@ -2821,6 +2821,53 @@ def test_data_parallel_wrapper_matches_the_plain_call():
     assert not torch.equal(after, before) and torch.equal(after, want_after), float((after - want_after).abs().max())
 
 
+def test_backward_passes_of_two_threads_on_their_own_streams():
+    """Two host threads, each with its own stream and its own model (same weights), run training steps at the same time: the backward
+    pass forks into the library's second stream, which is keyed by (device, CALLER stream) - one shared per device would interleave the
+    two threads' forks and joins (and be pulled into a thread-local graph capture of either).  Every thread's gradients equal the ones
+    the same call produces alone (up to the order of the kernels' atomic sums)."""
+    import threading
+    models, argss = [], []
+    for _ in range(2):
+        model, args = _tennis_model_and_args(batch=2)
+        model.frame_replay = None
+        models.append(model.train())
+        argss.append(args)
+    kw = dict(patch_stride=[4, 8], mode="scene_encodings")
+
+    def step(model, args):
+        for p in model.parameters():
+            p.grad = None
+        out = model(*args, 0, False, 1200, **kw)
+        g = out["coarse"]["global"]
+        ((g["integrated_features"] ** 2).mean() + g["opacity"].mean() + 0.1 * g["depth"].mean()).backward()
+        return [p.grad.clone() for p in model.object_composer.parameters() if p.grad is not None]
+    alone = step(models[0], argss[0])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    results[i] = step(models[i], argss[i])
+                streams[i].synchronize()
+        except Exception as error:      # noqa: BLE001
+            errors.append(error)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == len(alone)
+        worst = max(float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(results[i], alone))
+        assert worst < 1e-5, (i, worst)
+
+
 def test_replaced_parameters_buffers_and_modules_are_noticed():
     """The composer caches parameter lists and raw-pointer structs of its module tree; the tree's classes (modules.Tracked) report
     every re-registration, without process-wide hooks: a replaced ``nn.Parameter`` object, a replaced BatchNorm buffer,
